@@ -1,0 +1,295 @@
+"""Thin object wrappers over the C ABI (include/gmg.h, include/gmg_icm.h) for tests and bench.py.
+
+Names follow the reference: an Icm is an ICM_t (src/ICM/icm.hh:116-180), reads are the sequences
+glimmer3 / glimmer-mg score, a segment is an ORF-style scoring buffer cut from a read.
+Nothing here computes a score: every function forwards to libgmg.so and raises GmgError with the
+library's message when a call fails (including "no GPU").
+"""
+import ctypes as C
+import numpy as np
+
+from . import capi
+
+FORWARD, REVERSED, COMPLEMENTED, REVCOMP = 0, 1, 2, 3
+DEFAULT_STOPS = ("taa", "tag", "tga")     # src/Glimmer/glimmer_base.cc Set_Start_And_Stop_Codons defaults
+
+
+class GmgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("gmg status %d: %s" % (code, msg))
+        self.code = code
+
+
+def _ck(rc):
+    if rc != 0:
+        raise GmgError(rc, capi.lib().gmg_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def init(device=0):
+    """gmg_init: bind this process to one GPU.  Raises GmgError (GMG_ENODEV) without a gfx950 device."""
+    _ck(capi.lib().gmg_init(int(device)))
+
+
+def read_fasta(path):
+    """Host-side ingest with the reference's semantics (src/Common/fasta.cc:236-286 Fasta_Read):
+    header = text after '>' (leading blanks skipped) up to the newline; sequence = every
+    non-whitespace character up to the next '>'.  Returns (headers, sequences) as str lists."""
+    hdrs, seqs = [], []
+    with open(path, "rb") as fh:
+        data = fh.read()
+    pos = data.find(b">")
+    while pos >= 0:
+        pos += 1
+        while pos < len(data) and data[pos:pos + 1] == b" ":
+            pos += 1
+        eol = data.find(b"\n", pos)
+        if eol < 0:
+            eol = len(data)
+        nxt = data.find(b">", eol)
+        body = data[eol:nxt if nxt >= 0 else len(data)]
+        hdrs.append(data[pos:eol].decode("latin-1"))
+        seqs.append(b"".join(body.split()).decode("latin-1"))
+        pos = nxt
+    return hdrs, seqs
+
+
+class _DeviceBuffer:
+    """device scratch from gmg_device_malloc, copied back with gmg_memcpy_d2h"""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        self.nbytes = int(nbytes)
+        _ck(capi.lib().gmg_device_malloc(C.byref(self.ptr), self.nbytes))
+
+    @classmethod
+    def from_host(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = cls(max(arr.nbytes, 1))
+        if arr.nbytes:
+            _ck(capi.lib().gmg_memcpy_h2d(buf.ptr, _ptr(arr), arr.nbytes, None))
+        return buf
+
+    def to_host(self, dtype, count):
+        out = np.empty(count, dtype)
+        if out.nbytes:
+            _ck(capi.lib().gmg_memcpy_d2h(_ptr(out), self.ptr, out.nbytes, None))
+        return out
+
+    def free(self):
+        if self.ptr:
+            capi.lib().gmg_device_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Icm:
+    """Host ICM_t behind gmg_icm (model I/O + null-model builder run on the host, as in the reference)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def open(cls, path):
+        h = C.c_void_p()
+        _ck(capi.lib().gmg_icm_open(str(path).encode(), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def new(cls, model_len=12, model_depth=7, periodicity=3):
+        h = C.c_void_p()
+        _ck(capi.lib().gmg_icm_new(model_len, model_depth, periodicity, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def indep(cls, gc_frac, stops=DEFAULT_STOPS):
+        """ICM_t Indep_Model(3,2,3); Indep_Model.Build_Indep_WO_Stops(gc, stops)  (glimmer3.cc:64,214)"""
+        m = cls.new(3, 2, 3)
+        arr = (C.c_char_p * len(stops))(*[s.encode() for s in stops])
+        _ck(capi.lib().gmg_icm_build_indep(m.h, float(gc_frac), arr, len(stops)))
+        return m
+
+    @property
+    def params(self):
+        w, d, p, n = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _ck(capi.lib().gmg_icm_params(self.h, C.byref(w), C.byref(d), C.byref(p), C.byref(n)))
+        return w.value, d.value, p.value, n.value
+
+    def tables(self):
+        """(mip int16 [P,N], prob float32 [P,N,4])"""
+        _, _, p, n = self.params
+        mip = np.empty((p, n), np.int16)
+        prob = np.empty((p, n, 4), np.float32)
+        _ck(capi.lib().gmg_icm_tables(self.h, _ptr(mip), _ptr(prob)))
+        return mip, prob
+
+    def write(self, path):
+        _ck(capi.lib().gmg_icm_write(self.h, str(path).encode()))
+
+    def device(self):
+        """gmg_model handle (uploaded once, owned by this Icm)"""
+        out = C.c_void_p()
+        _ck(capi.lib().gmg_icm_device_model(self.h, C.byref(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            capi.lib().gmg_icm_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pack_strings(seqs):
+    """Filter + lower + 2-bit pack a list of str/bytes sequences -> (packed uint32, offsets uint64)."""
+    lens = np.array([len(s) for s in seqs], np.uint64)
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    np.cumsum(lens, out=off[1:])
+    total = int(off[-1])
+    packed = np.zeros(int(capi.lib().gmg_packed_words(total)), np.uint32)
+    blob = b"".join(s.encode("latin-1") if isinstance(s, str) else bytes(s) for s in seqs)
+    _ck(capi.lib().gmg_pack_bases(blob, total, 0, _ptr(packed)))
+    return packed, off
+
+
+class Reads:
+    """A batch of reads resident in HBM (gmg_reads)."""
+
+    def __init__(self, packed, offsets):
+        self.offsets = np.ascontiguousarray(offsets, np.uint64)
+        packed = np.ascontiguousarray(packed, np.uint32)
+        self.n_reads = len(self.offsets) - 1
+        self.total_bases = int(self.offsets[-1]) if len(self.offsets) else 0
+        self.h = C.c_void_p()
+        _ck(capi.lib().gmg_reads_upload(_ptr(packed), _ptr(self.offsets), self.n_reads, C.byref(self.h)))
+
+    @classmethod
+    def from_strings(cls, seqs):
+        return cls(*pack_strings(seqs))
+
+    def close(self):
+        if self.h:
+            capi.lib().gmg_reads_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Segments:
+    """ORF-style scoring buffers (gmg_segments): rows of (read, lo, len, orient)."""
+
+    def __init__(self, reads, rows):
+        rows = np.ascontiguousarray(np.asarray(rows, np.uint32).reshape(-1, 4))
+        self.n = rows.shape[0]
+        self.rows = rows
+        self.offsets = np.zeros(self.n + 1, np.uint64)
+        total = C.c_uint64()
+        self.h = C.c_void_p()
+        _ck(capi.lib().gmg_segments_upload(reads.h, _ptr(rows), self.n, _ptr(self.offsets), C.byref(total),
+                                           C.byref(self.h)))
+        self.total_len = int(total.value)
+
+    def split(self, flat):
+        return [flat[int(self.offsets[i]):int(self.offsets[i + 1])] for i in range(self.n)]
+
+    def close(self):
+        if self.h:
+            capi.lib().gmg_segments_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def frame_score6(gene, null, reads, d_out=None, stream=None):
+    """Score_All_Frames (glimmer-mg.cc:1468-1510) for every read.  With d_out (a device pointer to
+    6*total_bases doubles) the call is asynchronous on `stream` and returns None; otherwise the
+    result comes back as a float64 array [6, total_bases]."""
+    if d_out is not None:
+        _ck(capi.lib().gmg_frame_score6(gene.device(), null.device(), reads.h, C.c_void_p(d_out), stream))
+        return None
+    buf = _DeviceBuffer(6 * reads.total_bases * 8)
+    _ck(capi.lib().gmg_frame_score6(gene.device(), null.device(), reads.h, buf.ptr, stream))
+    _ck(capi.lib().gmg_synchronize(stream))
+    out = buf.to_host(np.float64, 6 * reads.total_bases).reshape(6, reads.total_bases)
+    buf.free()
+    return out
+
+
+def _seg_call(fn, model, reads, segs, frame, count):
+    buf = _DeviceBuffer(max(count, 1) * 8)
+    _ck(fn(model.device(), reads.h, segs.h, int(frame), buf.ptr, None))
+    _ck(capi.lib().gmg_synchronize(None))
+    out = buf.to_host(np.float64, count)
+    buf.free()
+    return out
+
+
+def segment_frame_score(model, reads, segs, frame):
+    """ICM_t::Frame_Score (icm.cc:485-509) per segment, flat float64[total_len]"""
+    return _seg_call(capi.lib().gmg_segment_frame_score, model, reads, segs, frame, segs.total_len)
+
+
+def segment_cumscore(model, reads, segs, frame0):
+    """ICM_t::Cumulative_Score (icm.cc:354-405) per segment, flat float64[total_len]"""
+    return _seg_call(capi.lib().gmg_segment_cumscore, model, reads, segs, frame0, segs.total_len)
+
+
+def score_string(model, reads, segs, frame0):
+    """ICM_t::Score_String (icm.cc:864-903) per segment, float64[n]"""
+    return _seg_call(capi.lib().gmg_score_string, model, reads, segs, frame0, segs.n)
+
+
+def segment_partial_prob(model, reads, segs, frame):
+    """ICM_t::Partial_Window_Prob (icm.cc:807-842) of each segment's last base, float64[n]"""
+    return _seg_call(capi.lib().gmg_segment_partial_prob, model, reads, segs, frame, segs.n)
+
+
+def all_frame_score(gene, reads, segs, prefix_len, frames):
+    """All_Frame_Score (glimmer3.cc:328-359) per segment -> float64[n, 6]"""
+    pre = _DeviceBuffer.from_host(np.asarray(prefix_len, np.uint32))
+    frs = _DeviceBuffer.from_host(np.asarray(frames, np.int32))
+    buf = _DeviceBuffer(max(segs.n, 1) * 48)
+    _ck(capi.lib().gmg_all_frame_score(gene.device(), reads.h, segs.h, pre.ptr, frs.ptr, buf.ptr, None))
+    _ck(capi.lib().gmg_synchronize(None))
+    out = buf.to_host(np.float64, 6 * segs.n).reshape(segs.n, 6)
+    for b in (pre, frs, buf):
+        b.free()
+    return out
+
+
+def window_distrib(model, windows, frames):
+    """Full_Window_Distrib / Full_Window_Prob (icm.cc:512-610).  windows: uint8 codes [n, model_len]
+    -> (dist float32 [n,4], prob float64 [n])"""
+    windows = np.ascontiguousarray(windows, np.uint8)
+    n = windows.shape[0]
+    dw = _DeviceBuffer.from_host(windows)
+    df = _DeviceBuffer.from_host(np.asarray(frames, np.int32))
+    dd = _DeviceBuffer(max(n, 1) * 16)
+    dp = _DeviceBuffer(max(n, 1) * 8)
+    _ck(capi.lib().gmg_window_distrib(model.device(), dw.ptr, df.ptr, n, dd.ptr, dp.ptr, None))
+    _ck(capi.lib().gmg_synchronize(None))
+    dist = dd.to_host(np.float32, 4 * n).reshape(n, 4)
+    prob = dp.to_host(np.float64, n)
+    for b in (dw, df, dd, dp):
+        b.free()
+    return dist, prob

@@ -1,0 +1,34 @@
+"""Build lib/libgmg.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(PKG, "lib", "libgmg.so")
+SOURCES = ["csrc/gmg_api.hip", "csrc/gmg_kernels.hip", "host/icm.cc", "host/gmg_icm_c.cc"]
+HEADERS = ["csrc/gmg_internal.h", "host/icm.hh", "../include/gmg.h", "../include/gmg_icm.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function"]
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(PKG, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_lib(force=False, verbose=False):
+    """Compile every HIP/C++ source into lib/libgmg.so.  Returns the library path."""
+    if not force and not stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [hipcc, *FLAGS, "-o", LIB, *SOURCES]
+    res = subprocess.run(cmd, cwd=PKG, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(" ".join(cmd))
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed building libgmg.so")
+    return LIB

@@ -1,0 +1,72 @@
+"""ctypes prototypes for include/gmg.h and include/gmg_icm.h.  Loading fails loudly when the
+library is missing: there is no Python or CPU fallback."""
+import ctypes as C
+import os
+
+from .build import LIB
+
+_lib = None
+
+vp = C.c_void_p
+u64 = C.c_uint64
+i32 = C.c_int
+
+
+class Segment(C.Structure):
+    _fields_ = [("read", C.c_uint32), ("lo", C.c_uint32), ("len", C.c_uint32), ("orient", C.c_uint32)]
+
+
+PROTOTYPES = {
+    # include/gmg.h
+    "gmg_init": (i32, [i32]),
+    "gmg_device_count": (i32, []),
+    "gmg_last_error": (C.c_char_p, []),
+    "gmg_version": (C.c_char_p, []),
+    "gmg_synchronize": (i32, [vp]),
+    "gmg_base_code": (i32, [i32]),
+    "gmg_pack_bases": (i32, [C.c_char_p, u64, u64, vp]),
+    "gmg_packed_words": (u64, [u64]),
+    "gmg_model_upload": (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(vp)]),
+    "gmg_model_free": (i32, [vp]),
+    "gmg_model_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "gmg_reads_upload": (i32, [vp, vp, u64, C.POINTER(vp)]),
+    "gmg_reads_wrap_device": (i32, [vp, vp, u64, u64, C.POINTER(vp)]),
+    "gmg_reads_free": (i32, [vp]),
+    "gmg_reads_info": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
+    "gmg_segments_upload": (i32, [vp, vp, u64, vp, C.POINTER(u64), C.POINTER(vp)]),
+    "gmg_segments_free": (i32, [vp]),
+    "gmg_frame_score6": (i32, [vp, vp, vp, vp, vp]),
+    "gmg_segment_frame_score": (i32, [vp, vp, vp, i32, vp, vp]),
+    "gmg_segment_cumscore": (i32, [vp, vp, vp, i32, vp, vp]),
+    "gmg_score_string": (i32, [vp, vp, vp, i32, vp, vp]),
+    "gmg_segment_partial_prob": (i32, [vp, vp, vp, i32, vp, vp]),
+    "gmg_all_frame_score": (i32, [vp, vp, vp, vp, vp, vp, vp]),
+    "gmg_window_distrib": (i32, [vp, vp, vp, u64, vp, vp, vp]),
+    "gmg_device_malloc": (i32, [C.POINTER(vp), C.c_size_t]),
+    "gmg_device_free": (i32, [vp]),
+    "gmg_memcpy_h2d": (i32, [vp, vp, C.c_size_t, vp]),
+    "gmg_memcpy_d2h": (i32, [vp, vp, C.c_size_t, vp]),
+    # include/gmg_icm.h
+    "gmg_icm_new": (i32, [i32, i32, i32, C.POINTER(vp)]),
+    "gmg_icm_open": (i32, [C.c_char_p, C.POINTER(vp)]),
+    "gmg_icm_build_indep": (i32, [vp, C.c_double, C.POINTER(C.c_char_p), i32]),
+    "gmg_icm_write": (i32, [vp, C.c_char_p]),
+    "gmg_icm_free": (i32, [vp]),
+    "gmg_icm_params": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "gmg_icm_tables": (i32, [vp, vp, vp]),
+    "gmg_icm_device_model": (i32, [vp, C.POINTER(vp)]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise RuntimeError("%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                               "there is no fallback path" % LIB)
+        _lib = C.CDLL(LIB)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(_lib, name)      # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+    return _lib

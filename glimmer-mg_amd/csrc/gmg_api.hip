@@ -1,0 +1,543 @@
+// gmg_api.hip -- extern "C" entry points declared in include/gmg.h.
+// Host-side table flattening + handle management; all compute is in gmg_kernels.hip.
+// No CPU fallback: without a gfx950 device every scoring entry point fails loudly.
+
+#include "gmg_internal.h"
+
+#include <ctype.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+static int g_device = -1;
+
+int gmg_set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char *gmg_last_error(void) { return g_err; }
+extern "C" const char *gmg_version(void) { return "glimmer-mg_amd 0.1 (gfx950)"; }
+
+extern "C" int gmg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int gmg_init(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return gmg_set_error(GMG_ENODEV, "gmg_init: no HIP device (%s); there is no CPU fallback",
+                             e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return gmg_set_error(GMG_EINVAL, "gmg_init: device %d out of range (have %d)", device, n);
+    hipDeviceProp_t prop;
+    GMG_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return gmg_set_error(GMG_ENODEV, "gmg_init: device %d is %s; this library is built for gfx950 only",
+                             device, prop.gcnArchName);
+    GMG_HIP(hipSetDevice(device));
+    g_device = device;
+    return GMG_OK;
+}
+
+static int require_init(const char *who)
+{
+    if (g_device < 0) return gmg_set_error(GMG_ENODEV, "%s: gmg_init() has not succeeded in this process", who);
+    return GMG_OK;
+}
+
+extern "C" int gmg_synchronize(void *stream)
+{
+    GMG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return GMG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// packing helpers (host only)
+// ---------------------------------------------------------------------------
+
+// tolower(Filter(ch)) then Subscript: src/Common/gene.cc:1139-1175, src/ICM/icm.cc:2008-2027.
+// a c g t keep their meaning; r,d -> g; w,k -> t; everything else -> c.
+extern "C" int gmg_base_code(int ch)
+{
+    switch (tolower(ch & 0xff)) {
+    case 'a': return 0;
+    case 'c': return 1;
+    case 'g': case 'r': case 'd': return 2;
+    case 't': case 'w': case 'k': return 3;
+    default: return 1;
+    }
+}
+
+extern "C" uint64_t gmg_packed_words(uint64_t total_bases) { return (total_bases + 15) / 16 + 1; }
+
+extern "C" int gmg_pack_bases(const char *ascii, uint64_t n, uint64_t first_base, uint32_t *packed)
+{
+    if ((!ascii && n) || !packed) return gmg_set_error(GMG_EINVAL, "gmg_pack_bases: NULL argument");
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t g = first_base + i;
+        packed[g >> 4] |= (uint32_t)gmg_base_code((unsigned char)ascii[i]) << (2 * (g & 15));
+    }
+    return GMG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// models
+// ---------------------------------------------------------------------------
+
+static inline int parent_of(int x) { return (x - 1) / 4; }   // src/ICM/icm.hh:84, C truncation
+
+// Row the reference uses when a FULL-window descent ends at original node n
+// (src/ICM/icm.cc:568-595).  `by_break` = the loop left through the mip < -1 branch.
+static int full_final_row(const int16_t *mip, int n, bool by_break)
+{
+    if (by_break) n = parent_of(n);
+    if (mip[n] < -1) n = parent_of(n);
+    return n;
+}
+
+// Expand sub-model tables into the completed tree (see gmg_internal.h).
+static void complete_tree(const int16_t *mip, const float *prob, int D, uint8_t *cshift, float *cleaf)
+{
+    // breadth-first over the completed tree; per node: original node (>=0) while still
+    // descending, or ~row (negative) once stopped.
+    std::vector<int> cur(1, 0), nxt;
+    size_t lvl_base = 0, lvl_size = 1;
+    for (int l = 0; l < D; l++) {
+        nxt.assign(lvl_size * 4, 0);
+        for (size_t i = 0; i < lvl_size; i++) {
+            int st = cur[i];
+            uint8_t sh = 0;
+            if (st >= 0) {
+                int m = mip[st];
+                if (m >= 0) {
+                    sh = (uint8_t)(2 * m);
+                    for (int b = 0; b < 4; b++) nxt[4 * i + b] = 4 * st + 1 + b;
+                } else {
+                    int row = (m == -1) ? st : full_final_row(mip, st, true);
+                    for (int b = 0; b < 4; b++) nxt[4 * i + b] = ~row;
+                }
+            } else {
+                for (int b = 0; b < 4; b++) nxt[4 * i + b] = st;
+            }
+            cshift[lvl_base + i] = sh;
+        }
+        lvl_base += lvl_size;
+        lvl_size *= 4;
+        cur.swap(nxt);
+    }
+    for (size_t i = 0; i < lvl_size; i++) {
+        int st = cur[i];
+        int row = (st >= 0) ? full_final_row(mip, st, false) : ~st;
+        memcpy(cleaf + 4 * i, prob + 4 * (size_t)row, 4 * sizeof(float));
+    }
+}
+
+// Full-window value for window index idx (code of w[k] at bits 2k), by the plain descent.
+static float dense_entry(const int16_t *mip, const float *prob, int W, int D, uint32_t idx)
+{
+    int node = 0;
+    for (int i = 0; i < D; i++) {
+        int pos = mip[node];
+        if (pos == -1) break;
+        if (pos < -1) { node = parent_of(node); break; }
+        node = 4 * node + (int)((idx >> (2 * pos)) & 3) + 1;
+    }
+    if (mip[node] < -1) node = parent_of(node);
+    return prob[4 * (size_t)node + ((idx >> (2 * (W - 1))) & 3)];
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" int gmg_model_upload(const int16_t *mip, const float *prob4, int W, int D, int P, int N,
+                                gmg_model **out)
+{
+    int rc = require_init("gmg_model_upload");
+    if (rc) return rc;
+    if (!mip || !prob4 || !out) return gmg_set_error(GMG_EINVAL, "gmg_model_upload: NULL argument");
+    if (W < 1 || W > GMG_MAX_MODEL_LEN || D < 0 || D > 12 || P < 1 || N < 1)
+        return gmg_set_error(GMG_EBADMODEL, "gmg_model_upload: unsupported shape len=%d depth=%d period=%d nodes=%d",
+                             W, D, P, N);
+    long need = 0, pw = 1;
+    for (int l = 0; l <= D; l++) { need += pw; pw *= 4; }
+    if (N < need)
+        return gmg_set_error(GMG_EBADMODEL, "gmg_model_upload: num_nodes=%d < %ld needed for depth %d", N, need, D);
+    const size_t PN = (size_t)P * N;
+    for (size_t i = 0; i < PN; i++)
+        if (mip[i] < -2 || mip[i] > W - 1)
+            return gmg_set_error(GMG_EBADMODEL, "gmg_model_upload: mut_info_pos %d at slot %zu outside [-2,%d]",
+                                 (int)mip[i], i, W - 1);
+
+    const bool fast = (W <= GMG_FAST_MAX_LEN && D <= GMG_FAST_MAX_DEPTH);
+    const bool dense = (W <= GMG_DENSE_MAX_LEN);
+    const size_t n_internal = (size_t)((pw / 4 - 1) / 3);   // (4^D - 1) / 3
+    const size_t n_leaf = (size_t)(pw / 4);                  // 4^D
+    const size_t cstride = align_up(n_internal ? n_internal : 1, 16);
+    const size_t n_dense = dense ? ((size_t)1 << (2 * W)) : 0;
+
+    size_t o_mip = 0;
+    size_t o_prob = align_up(o_mip + PN, 256);
+    size_t o_cshift = align_up(o_prob + PN * 16, 256);
+    size_t o_cleaf = align_up(o_cshift + (fast ? P * cstride : 0), 256);
+    size_t o_dense = align_up(o_cleaf + (fast ? (size_t)P * n_leaf * 16 : 0), 256);
+    size_t total = align_up(o_dense + (size_t)P * n_dense * 4, 256);
+
+    std::vector<unsigned char> blob(total, 0);
+    int8_t *h_mip = (int8_t *)(blob.data() + o_mip);
+    for (size_t i = 0; i < PN; i++) h_mip[i] = (int8_t)mip[i];
+    memcpy(blob.data() + o_prob, prob4, PN * 16);
+    if (fast)
+        for (int p = 0; p < P; p++)
+            complete_tree(mip + (size_t)p * N, prob4 + 4 * (size_t)p * N, D,
+                          blob.data() + o_cshift + p * cstride,
+                          (float *)(blob.data() + o_cleaf) + (size_t)p * n_leaf * 4);
+    if (dense)
+        for (int p = 0; p < P; p++)
+            for (uint32_t idx = 0; idx < n_dense; idx++)
+                ((float *)(blob.data() + o_dense))[(size_t)p * n_dense + idx] =
+                    dense_entry(mip + (size_t)p * N, prob4 + 4 * (size_t)p * N, W, D, idx);
+
+    gmg_model *m = new (std::nothrow) gmg_model();
+    if (!m) return gmg_set_error(GMG_ENOMEM, "gmg_model_upload: out of host memory");
+    hipError_t e = hipMalloc(&m->d_blob, total);
+    if (e != hipSuccess) { delete m; return gmg_set_error(GMG_ENOMEM, "gmg_model_upload: hipMalloc(%zu): %s", total, hipGetErrorString(e)); }
+    e = hipMemcpy(m->d_blob, blob.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(m->d_blob); delete m; return gmg_set_error(GMG_EHIP, "gmg_model_upload: hipMemcpy: %s", hipGetErrorString(e)); }
+    m->blob_bytes = total;
+    unsigned char *d = (unsigned char *)m->d_blob;
+    m->dev.W = W; m->dev.D = D; m->dev.P = P; m->dev.N = N;
+    m->dev.mip = (const int8_t *)(d + o_mip);
+    m->dev.prob = (const float *)(d + o_prob);
+    m->dev.cshift = fast ? (const uint8_t *)(d + o_cshift) : nullptr;
+    m->dev.cleaf = fast ? (const float *)(d + o_cleaf) : nullptr;
+    m->dev.cstride = (int)cstride;
+    m->dev.has_fast = fast;
+    m->dev.dense = dense ? (const float *)(d + o_dense) : nullptr;
+    m->dev.has_dense = dense;
+    *out = m;
+    return GMG_OK;
+}
+
+extern "C" int gmg_model_free(gmg_model *m)
+{
+    if (!m) return GMG_OK;
+    if (m->d_blob) (void)hipFree(m->d_blob);
+    delete m;
+    return GMG_OK;
+}
+
+extern "C" int gmg_model_info(const gmg_model *m, int *W, int *D, int *P, int *N)
+{
+    if (!m) return gmg_set_error(GMG_EINVAL, "gmg_model_info: NULL model");
+    if (W) *W = m->dev.W;
+    if (D) *D = m->dev.D;
+    if (P) *P = m->dev.P;
+    if (N) *N = m->dev.N;
+    return GMG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// reads
+// ---------------------------------------------------------------------------
+
+static int finish_reads(gmg_reads *r, const uint64_t *h_off /* may be NULL */)
+{
+    r->n_tiles = (r->total_bases + GMG_TILE - 1) / GMG_TILE;
+    hipError_t e = hipMalloc((void **)&r->d_tile_read, (r->n_tiles + 1) * sizeof(uint32_t));
+    if (e != hipSuccess) return gmg_set_error(GMG_ENOMEM, "gmg_reads: hipMalloc tile table: %s", hipGetErrorString(e));
+    int rc = gmg_launch_tile_read(r->d_off, r->n_reads, r->n_tiles, r->d_tile_read, 0);
+    if (rc) return rc;
+    GMG_HIP(hipStreamSynchronize(0));
+    r->uniform_len = 0;
+    if (h_off && r->n_reads > 0) {
+        uint64_t L = h_off[1] - h_off[0];
+        bool uni = L > 0 && L < (1u << 30);
+        for (uint64_t i = 1; uni && i < r->n_reads; i++) uni = (h_off[i + 1] - h_off[i] == L);
+        if (uni) r->uniform_len = (int)L;
+    }
+    return GMG_OK;
+}
+
+extern "C" int gmg_reads_upload(const uint32_t *packed, const uint64_t *off, uint64_t n_reads, gmg_reads **out)
+{
+    int rc = require_init("gmg_reads_upload");
+    if (rc) return rc;
+    if (!off || !out || n_reads >= 0xffffffffull) return gmg_set_error(GMG_EINVAL, "gmg_reads_upload: bad argument");
+    for (uint64_t i = 0; i < n_reads; i++)
+        if (off[i + 1] < off[i] || off[i + 1] - off[i] > 0x7fffffffull)
+            return gmg_set_error(GMG_EINVAL, "gmg_reads_upload: base_offsets not monotone at read %llu", (unsigned long long)i);
+    if (off[0] != 0) return gmg_set_error(GMG_EINVAL, "gmg_reads_upload: base_offsets[0] must be 0");
+    uint64_t total = off[n_reads];
+    if (total && !packed) return gmg_set_error(GMG_EINVAL, "gmg_reads_upload: NULL packed reads");
+    gmg_reads *r = new (std::nothrow) gmg_reads();
+    if (!r) return gmg_set_error(GMG_ENOMEM, "gmg_reads_upload: out of host memory");
+    memset(r, 0, sizeof *r);
+    r->n_reads = n_reads;
+    r->total_bases = total;
+    r->owns = 1;
+    uint64_t data_words = (total + 15) / 16;
+    r->n_words = data_words + 4;                      // guard words: window loads never leave the buffer
+    uint32_t *d_packed = nullptr;
+    uint64_t *d_off = nullptr;
+    hipError_t e = hipMalloc((void **)&d_packed, r->n_words * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_off, (n_reads + 1) * 8);
+    if (e != hipSuccess) {
+        if (d_packed) (void)hipFree(d_packed);
+        delete r;
+        return gmg_set_error(GMG_ENOMEM, "gmg_reads_upload: hipMalloc: %s", hipGetErrorString(e));
+    }
+    r->d_packed = d_packed;
+    r->d_off = d_off;
+    e = hipMemset(d_packed, 0, r->n_words * 4);
+    if (e == hipSuccess && data_words) e = hipMemcpy(d_packed, packed, data_words * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_off, off, (n_reads + 1) * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { gmg_reads_free(r); return gmg_set_error(GMG_EHIP, "gmg_reads_upload: copy: %s", hipGetErrorString(e)); }
+    rc = finish_reads(r, off);
+    if (rc) { gmg_reads_free(r); return rc; }
+    *out = r;
+    return GMG_OK;
+}
+
+extern "C" int gmg_reads_wrap_device(const uint32_t *d_packed, const uint64_t *d_off, uint64_t n_reads,
+                                     uint64_t total_bases, gmg_reads **out)
+{
+    int rc = require_init("gmg_reads_wrap_device");
+    if (rc) return rc;
+    if (!d_off || !out || (total_bases && !d_packed) || n_reads >= 0xffffffffull)
+        return gmg_set_error(GMG_EINVAL, "gmg_reads_wrap_device: bad argument");
+    gmg_reads *r = new (std::nothrow) gmg_reads();
+    if (!r) return gmg_set_error(GMG_ENOMEM, "gmg_reads_wrap_device: out of host memory");
+    memset(r, 0, sizeof *r);
+    r->d_packed = d_packed;
+    r->d_off = d_off;
+    r->n_reads = n_reads;
+    r->total_bases = total_bases;
+    r->n_words = (total_bases + 15) / 16;            // caller's buffer: no guard words assumed
+    r->owns = 0;
+    rc = finish_reads(r, nullptr);
+    if (rc) { gmg_reads_free(r); return rc; }
+    *out = r;
+    return GMG_OK;
+}
+
+extern "C" int gmg_reads_free(gmg_reads *r)
+{
+    if (!r) return GMG_OK;
+    if (r->owns) {
+        if (r->d_packed) (void)hipFree((void *)r->d_packed);
+        if (r->d_off) (void)hipFree((void *)r->d_off);
+    }
+    if (r->d_tile_read) (void)hipFree(r->d_tile_read);
+    delete r;
+    return GMG_OK;
+}
+
+extern "C" int gmg_reads_info(const gmg_reads *r, uint64_t *n_reads, uint64_t *total_bases)
+{
+    if (!r) return gmg_set_error(GMG_EINVAL, "gmg_reads_info: NULL reads");
+    if (n_reads) *n_reads = r->n_reads;
+    if (total_bases) *total_bases = r->total_bases;
+    return GMG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// segments
+// ---------------------------------------------------------------------------
+
+extern "C" int gmg_segments_upload(const gmg_reads *reads, const gmg_segment *segs, uint64_t n,
+                                   uint64_t *out_offsets, uint64_t *out_total_len, gmg_segments **out)
+{
+    int rc = require_init("gmg_segments_upload");
+    if (rc) return rc;
+    if (!reads || (!segs && n) || !out) return gmg_set_error(GMG_EINVAL, "gmg_segments_upload: NULL argument");
+    // read lengths are needed for validation: fetch the offsets once
+    std::vector<uint64_t> off(reads->n_reads + 1);
+    GMG_HIP(hipMemcpy(off.data(), reads->d_off, off.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> pre(n + 1);
+    pre[0] = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const gmg_segment &s = segs[i];
+        if (s.read >= reads->n_reads || s.orient > GMG_REVCOMP)
+            return gmg_set_error(GMG_ERANGE, "gmg_segments_upload: segment %llu: bad read %u / orient %u",
+                                 (unsigned long long)i, s.read, s.orient);
+        uint64_t L = off[s.read + 1] - off[s.read];
+        if ((uint64_t)s.lo + s.len > L)
+            return gmg_set_error(GMG_ERANGE, "gmg_segments_upload: segment %llu [%u,+%u) leaves read %u of length %llu",
+                                 (unsigned long long)i, s.lo, s.len, s.read, (unsigned long long)L);
+        pre[i + 1] = pre[i] + s.len;
+    }
+    gmg_segments *g = new (std::nothrow) gmg_segments();
+    if (!g) return gmg_set_error(GMG_ENOMEM, "gmg_segments_upload: out of host memory");
+    memset(g, 0, sizeof *g);
+    g->n = n;
+    g->total_len = pre[n];
+    hipError_t e = hipMalloc((void **)&g->d_segs, (n ? n : 1) * sizeof(gmg_segment));
+    if (e == hipSuccess) e = hipMalloc((void **)&g->d_out_off, (n + 1) * 8);
+    if (e == hipSuccess && n) e = hipMemcpy(g->d_segs, segs, n * sizeof(gmg_segment), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->d_out_off, pre.data(), (n + 1) * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { gmg_segments_free(g); return gmg_set_error(GMG_EHIP, "gmg_segments_upload: %s", hipGetErrorString(e)); }
+    if (out_offsets) memcpy(out_offsets, pre.data(), (n + 1) * 8);
+    if (out_total_len) *out_total_len = pre[n];
+    *out = g;
+    return GMG_OK;
+}
+
+extern "C" int gmg_segments_free(gmg_segments *s)
+{
+    if (!s) return GMG_OK;
+    if (s->d_segs) (void)hipFree(s->d_segs);
+    if (s->d_out_off) (void)hipFree(s->d_out_off);
+    delete s;
+    return GMG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// scoring entry points: argument checks, then the launchers in gmg_kernels.hip
+// ---------------------------------------------------------------------------
+
+static int check_frame(const gmg_model *m, int frame, const char *who)
+{
+    // src/ICM/icm.cc:367-369,875-877: periodicity 1 forces frame 0, otherwise assert(0 <= frame < periodicity)
+    if (m->dev.P == 1) return GMG_OK;
+    if (frame < 0 || frame >= m->dev.P)
+        return gmg_set_error(GMG_EINVAL, "%s: frame %d outside [0,%d)", who, frame, m->dev.P);
+    return GMG_OK;
+}
+
+extern "C" int gmg_frame_score6(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads,
+                                double *d_out, void *stream)
+{
+    int rc = require_init("gmg_frame_score6");
+    if (rc) return rc;
+    if (!gene || !nul || !reads || (!d_out && reads->total_bases))
+        return gmg_set_error(GMG_EINVAL, "gmg_frame_score6: NULL argument");
+    // Score_All_Frames calls Frame_Score with frame 0..2, which asserts frame < periodicity (icm.cc:496)
+    if (gene->dev.P < 3 || nul->dev.P < 3)
+        return gmg_set_error(GMG_EBADMODEL, "gmg_frame_score6: periodicity must be >= 3 (gene %d, null %d)",
+                             gene->dev.P, nul->dev.P);
+    if (reads->total_bases == 0) return GMG_OK;
+    return gmg_launch_frame6(gene, nul, reads, d_out, (hipStream_t)stream);
+}
+
+extern "C" int gmg_segment_frame_score(const gmg_model *m, const gmg_reads *reads, const gmg_segments *segs,
+                                       int frame, double *d_out, void *stream)
+{
+    int rc = require_init("gmg_segment_frame_score");
+    if (rc) return rc;
+    if (!m || !reads || !segs || (!d_out && segs->total_len))
+        return gmg_set_error(GMG_EINVAL, "gmg_segment_frame_score: NULL argument");
+    // Frame_Score asserts the range even for periodicity 1 (src/ICM/icm.cc:496)
+    if (frame < 0 || frame >= m->dev.P)
+        return gmg_set_error(GMG_EINVAL, "gmg_segment_frame_score: frame %d outside [0,%d)", frame, m->dev.P);
+    if (segs->total_len == 0) return GMG_OK;
+    return gmg_launch_seg_frame(m, reads, segs, frame, d_out, (hipStream_t)stream);
+}
+
+extern "C" int gmg_segment_cumscore(const gmg_model *m, const gmg_reads *reads, const gmg_segments *segs,
+                                    int frame0, double *d_out, void *stream)
+{
+    int rc = require_init("gmg_segment_cumscore");
+    if (rc) return rc;
+    if (!m || !reads || !segs || (!d_out && segs->total_len))
+        return gmg_set_error(GMG_EINVAL, "gmg_segment_cumscore: NULL argument");
+    if ((rc = check_frame(m, frame0, "gmg_segment_cumscore"))) return rc;
+    if (segs->n == 0) return GMG_OK;
+    return gmg_launch_seg_cum(m, reads, segs, m->dev.P == 1 ? 0 : frame0, d_out, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int gmg_score_string(const gmg_model *m, const gmg_reads *reads, const gmg_segments *segs,
+                                int frame0, double *d_sums, void *stream)
+{
+    int rc = require_init("gmg_score_string");
+    if (rc) return rc;
+    if (!m || !reads || !segs || (!d_sums && segs->n))
+        return gmg_set_error(GMG_EINVAL, "gmg_score_string: NULL argument");
+    if ((rc = check_frame(m, frame0, "gmg_score_string"))) return rc;
+    if (segs->n == 0) return GMG_OK;
+    return gmg_launch_seg_cum(m, reads, segs, m->dev.P == 1 ? 0 : frame0, nullptr, d_sums, (hipStream_t)stream);
+}
+
+extern "C" int gmg_segment_partial_prob(const gmg_model *m, const gmg_reads *reads, const gmg_segments *segs,
+                                        int frame, double *d_out, void *stream)
+{
+    int rc = require_init("gmg_segment_partial_prob");
+    if (rc) return rc;
+    if (!m || !reads || !segs || (!d_out && segs->n))
+        return gmg_set_error(GMG_EINVAL, "gmg_segment_partial_prob: NULL argument");
+    if (frame < 0 || frame >= m->dev.P)
+        return gmg_set_error(GMG_EINVAL, "gmg_segment_partial_prob: frame %d outside [0,%d)", frame, m->dev.P);
+    if (segs->n == 0) return GMG_OK;
+    return gmg_launch_seg_partial(m, reads, segs, frame, d_out, (hipStream_t)stream);
+}
+
+extern "C" int gmg_all_frame_score(const gmg_model *gene, const gmg_reads *reads, const gmg_segments *segs,
+                                   const uint32_t *d_prefix_len, const int32_t *d_frame, double *d_af,
+                                   void *stream)
+{
+    int rc = require_init("gmg_all_frame_score");
+    if (rc) return rc;
+    if (!gene || !reads || !segs || (segs->n && (!d_prefix_len || !d_frame || !d_af)))
+        return gmg_set_error(GMG_EINVAL, "gmg_all_frame_score: NULL argument");
+    if (gene->dev.P != 3 && gene->dev.P != 1)
+        return gmg_set_error(GMG_EBADMODEL, "gmg_all_frame_score: periodicity must be 3 or 1");
+    if (segs->n == 0) return GMG_OK;
+    return gmg_launch_all_frame(gene, reads, segs, d_prefix_len, d_frame, d_af, (hipStream_t)stream);
+}
+
+extern "C" int gmg_window_distrib(const gmg_model *m, const uint8_t *d_windows, const int32_t *d_frames,
+                                  uint64_t n, float *d_dist4, double *d_prob, void *stream)
+{
+    int rc = require_init("gmg_window_distrib");
+    if (rc) return rc;
+    if (!m || (n && (!d_windows || !d_frames)))
+        return gmg_set_error(GMG_EINVAL, "gmg_window_distrib: NULL argument");
+    if (n == 0) return GMG_OK;
+    return gmg_launch_windows(m, d_windows, d_frames, n, d_dist4, d_prob, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// memory helpers
+// ---------------------------------------------------------------------------
+
+extern "C" int gmg_device_malloc(void **d_ptr, size_t bytes)
+{
+    int rc = require_init("gmg_device_malloc");
+    if (rc) return rc;
+    if (!d_ptr) return gmg_set_error(GMG_EINVAL, "gmg_device_malloc: NULL argument");
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+    if (e != hipSuccess) return gmg_set_error(GMG_ENOMEM, "gmg_device_malloc(%zu): %s", bytes, hipGetErrorString(e));
+    return GMG_OK;
+}
+
+extern "C" int gmg_device_free(void *d_ptr)
+{
+    if (d_ptr) GMG_HIP(hipFree(d_ptr));
+    return GMG_OK;
+}
+
+extern "C" int gmg_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *stream)
+{
+    GMG_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    GMG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return GMG_OK;
+}
+
+extern "C" int gmg_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *stream)
+{
+    GMG_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GMG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return GMG_OK;
+}

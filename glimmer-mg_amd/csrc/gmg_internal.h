@@ -1,0 +1,85 @@
+// gmg_internal.h -- private structures shared by the HIP translation units.
+// gfx950 (MI355X, CDNA4) only: 64-wide wavefronts, 160 KiB LDS per CU.
+#ifndef GMG_INTERNAL_H
+#define GMG_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gmg.h"
+
+#define GMG_MAX_MODEL_LEN 32      // context of W-1 <= 31 bases fits one 64-bit register
+#define GMG_FAST_MAX_LEN 16       // fast kernel: (W-1)*2 bits + predicted base in 32 bits
+#define GMG_FAST_MAX_DEPTH 8
+#define GMG_DENSE_MAX_LEN 6       // 4^6 = 4096-entry direct table for tiny (null) models
+#define GMG_TILE 1024             // bases per tile_read entry
+
+// Device view of one model.  Pointers are HBM.
+struct GmgDevModel {
+    int W, D, P, N;
+    const int8_t *mip;     // [P][N]   mut_info_pos, -2..W-1 (src/ICM/icm.hh:108)
+    const float *prob;     // [P][N][4] ln-probabilities   (src/ICM/icm.hh:112)
+    // --- flattened tables, built once at upload (gmg_model_upload) ---
+    // "completed" tree: every early stop (mip -1 / -2) is expanded down to depth D so that a
+    // full-window descent always takes exactly D steps and ends on a leaf whose row already is
+    // the row the reference would have used (own row, or the parent's for a cut node).
+    const uint8_t *cshift; // [P][cstride]  2*mip of the completed tree, levels 0..D-1, level l at (4^l-1)/3
+    const float *cleaf;    // [P][4^D][4]   rows reached after D steps
+    int cstride;           // bytes per sub-model in cshift (padded to 16)
+    int has_fast;          // cshift/cleaf valid (W <= 16, D <= 8)
+    // direct table for tiny models: dense[p][idx], idx = sum_k code(w[k]) << 2k, full windows only
+    const float *dense;    // [P][4^W]
+    int has_dense;
+};
+
+struct gmg_model {
+    GmgDevModel dev;
+    void *d_blob;          // single allocation backing every table
+    size_t blob_bytes;
+};
+
+struct gmg_reads {
+    const uint32_t *d_packed;
+    const uint64_t *d_off;       // n_reads + 1
+    uint32_t *d_tile_read;       // [n_tiles + 1] read containing base t*GMG_TILE
+    uint64_t n_reads;
+    uint64_t total_bases;
+    uint64_t n_tiles;
+    uint64_t n_words;            // valid words in d_packed (incl. guard)
+    int owns;                    // d_packed / d_off allocated by the library
+    int uniform_len;             // > 0 when every read has this length (fast read lookup)
+};
+
+struct gmg_segments {
+    gmg_segment *d_segs;
+    uint64_t *d_out_off;         // n + 1, exclusive prefix of len
+    uint64_t n;
+    uint64_t total_len;
+};
+
+// error plumbing (gmg_api.hip)
+int gmg_set_error(int code, const char *fmt, ...);
+#define GMG_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return gmg_set_error(GMG_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                                 __FILE__, __LINE__);                                         \
+    } while (0)
+
+// kernel launchers (gmg_kernels.hip)
+int gmg_launch_tile_read(const uint64_t *d_off, uint64_t n_reads, uint64_t n_tiles, uint32_t *d_tile_read,
+                         hipStream_t s);
+int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, double *d_out,
+                      hipStream_t s);
+int gmg_launch_seg_frame(const gmg_model *m, const gmg_reads *r, const gmg_segments *sg, int frame,
+                         double *d_out, hipStream_t s);
+int gmg_launch_seg_cum(const gmg_model *m, const gmg_reads *r, const gmg_segments *sg, int frame0,
+                       double *d_out, double *d_sums, hipStream_t s);
+int gmg_launch_seg_partial(const gmg_model *m, const gmg_reads *r, const gmg_segments *sg, int frame,
+                           double *d_out, hipStream_t s);
+int gmg_launch_all_frame(const gmg_model *m, const gmg_reads *r, const gmg_segments *sg,
+                         const uint32_t *d_prefix, const int32_t *d_frame, double *d_af, hipStream_t s);
+int gmg_launch_windows(const gmg_model *m, const uint8_t *d_windows, const int32_t *d_frames, uint64_t n,
+                       float *d_dist4, double *d_prob, hipStream_t s);
+
+#endif

@@ -1,0 +1,137 @@
+//  icm.hh -- MI355X-native drop-in for the scoring side of the reference's
+//  Interpolated Context Model class.
+//
+//  Same public interface, constants, field names and error behaviour as the
+//  reference's  ICM_t  (src/ICM/icm.hh:26-84,106-180,303), so that code written
+//  against it (src/Glimmer/glimmer3.cc, glimmer-mg.cc, glimmer_base.cc,
+//  src/ICM/score-fixed.cc) recompiles unchanged.  Everything that computes a
+//  score goes through the extern "C" HIP layer declared in include/gmg.h;
+//  there is no CPU scoring path in this class.  Model I/O and the null-model
+//  builder are host code, as in the reference.
+//
+//  Additions (not in the reference) are grouped at the end of the class:
+//  batch entry points and access to the device mirror.
+
+#ifndef GMG_HOST_ICM_HH_INCLUDED
+#define GMG_HOST_ICM_HH_INCLUDED
+
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+struct gmg_model;   // include/gmg.h
+
+// ---- constants of src/ICM/icm.hh:26-80 that callers use ---------------------
+const int  ALPHABET_SIZE = 4;
+const int  ALPHA_SQUARED = (ALPHABET_SIZE * ALPHABET_SIZE);
+const char  ALPHA_STRING [] = "acgt";
+const int  DEFAULT_MODEL_LEN = 12;
+const int  ID_STRING_LEN = 150;
+const int  DEFAULT_MODEL_DEPTH = 7;
+const unsigned  NUM_FIXED_LENGTH_PARAMS = 6;
+const int  DEFAULT_PERIODICITY = 3;
+const char  MAX_MI_CHAR = '*';
+const char  SEPARATOR_CHAR = '|';
+const int  ICM_VERSION_ID = 200;
+
+#define  PARENT(x) ((int) ((x) - 1) / ALPHABET_SIZE)
+
+
+//  src/ICM/icm.hh:106-113 (STORE_MUT_INFO = 1 layout, 24 bytes)
+struct  ICM_Score_Node_t
+  {
+   short int  mut_info_pos;
+   float  mut_info;
+   float  prob [ALPHABET_SIZE];
+  };
+
+
+class  ICM_t
+  {
+  protected:
+   bool  empty;
+   int  model_len;
+   int  model_depth;
+   int  periodicity;
+   int  num_nodes;
+   ICM_Score_Node_t  * * score;
+
+  public:
+   ICM_t
+       (int m = DEFAULT_MODEL_LEN,
+        int d = DEFAULT_MODEL_DEPTH,
+        int p = DEFAULT_PERIODICITY);
+   ~ ICM_t
+       ();
+
+   int  Get_Model_Len
+       (void)
+     { return  model_len; }
+   int  Get_Periodicity
+       (void)
+     { return  periodicity; }
+
+   void  Build_Indep_WO_Stops
+       (double gc_frac, const std::vector <const char *> & stop_codon);
+   void  Build_Reverse_Codon_WO_Stops
+       (double codon_prob [64], const std::vector <const char *> & stop_codon);
+   void  Cumulative_Score
+       (const std::string & s, std::vector <double> & score, int frame)  const;
+   void  Cumulative_Score_String
+       (char * string, int len, int frame, double * score);
+   void  Display
+       (FILE * fp);
+   void  Frame_Score
+       (const std::string & s, std::vector <double> & score, int frame)  const;
+   void  Full_Window_Distrib
+       (char * string, int frame, float * dist);
+   double  Full_Window_Prob
+       (const char * string, int frame)  const;
+   void  Input
+       (FILE * fp);
+   void  Output
+       (FILE * fp, bool binary_form);
+   void  Output_Node
+       (FILE * fp, ICM_Score_Node_t * node, int id, int frame, bool binary_form);
+   double  Partial_Window_Prob
+       (int predict_pos, const char * string, int frame)  const;
+   void  Read
+       (char * path);
+   double  Score_String
+       (const char * string, int len, int frame)  const;
+   void  Set_Label_String
+       (char * label, int id, int frame);
+   void  Write_Header
+       (FILE * fp, bool binary_form);
+   void Copy
+       (ICM_t & icm);
+
+   // ---- additions ---------------------------------------------------------
+   //  Parse an .icm stream without exiting: returns false and sets  err .
+   bool  Try_Input
+       (FILE * fp, std::string & err);
+   //  Flat copies of the tables in the layout gmg_model_upload() takes.
+   void  Export_Tables
+       (std::vector <short> & mip, std::vector <float> & prob4)  const;
+   int  Get_Model_Depth  (void)  const  { return  model_depth; }
+   int  Get_Num_Nodes  (void)  const  { return  num_nodes; }
+   bool  Is_Empty  (void)  const  { return  empty; }
+   //  Device mirror of the tables (uploaded on first use, dropped whenever the
+   //  tables change through this class).  Code that edits  score  directly
+   //  (a training subclass) must call Invalidate_Device_Mirror() afterwards.
+   const gmg_model *  Device_Model  (void)  const;
+   void  Invalidate_Device_Mirror  (void)  const;
+
+  private:
+   mutable gmg_model  * dev_mirror;
+   void  Free_Tables  (void);
+   void  Alloc_Tables  (void);
+   void  Build_From_Codon_Probs
+       (double codon_prob [64], const std::vector <const char *> & stop_codon, const char * who);
+  };
+
+
+int  Subscript
+    (char ch);
+
+#endif

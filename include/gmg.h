@@ -1,0 +1,187 @@
+/*
+ * gmg.h -- C ABI of the MI355X (gfx950) IMM scorer for Glimmer-MG.
+ *
+ * This is the drop-in boundary: a thin extern "C" layer over hand-written HIP
+ * kernels.  Plain pointers and sizes only; no C++ or torch types.  The host
+ * side (glimmer-mg_amd/host/icm.hh, an ICM_t with the reference's public
+ * interface) and any FFI binding call exactly these entry points.
+ *
+ * Each entry point cites the reference interface it replaces
+ * (paths relative to the reference root, davek44/Glimmer-MG).
+ *
+ * Conventions
+ *   - every function returns 0 (GMG_OK) or a negative gmg_status; it never
+ *     calls exit().  gmg_last_error() gives the text for the calling thread.
+ *   - "d_" pointers are device (HBM) pointers owned by the caller (hipMalloc /
+ *     torch); all other pointers are host memory, caller-owned.
+ *   - handles (gmg_model, gmg_reads, gmg_segments) own their device memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     launches are stream-ordered and asynchronous.
+ *   - base code: a=0 c=1 g=2 t=3 (ALPHA_STRING, src/ICM/icm.hh:30), complement
+ *     = 3 - code.  Packed reads hold 16 bases per uint32, base g of the job at
+ *     bits [2*(g%16), 2*(g%16)+1] of word g/16, reads concatenated without
+ *     padding; base_offsets[r] is the job-wide index of read r's first base
+ *     (n_reads+1 entries).
+ */
+#ifndef GMG_H
+#define GMG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gmg_status {
+    GMG_OK = 0,
+    GMG_EINVAL = -1,     /* bad argument (NULL handle, frame out of range, ...)          */
+    GMG_ENODEV = -2,     /* no usable gfx950 device / HIP runtime failure at init         */
+    GMG_ENOMEM = -3,     /* host or device allocation failed                              */
+    GMG_EHIP = -4,       /* a HIP call failed; text in gmg_last_error()                   */
+    GMG_EBADMODEL = -5,  /* model parameters outside what the kernels support             */
+    GMG_ERANGE = -6      /* a segment / window reaches outside its read                   */
+} gmg_status;
+
+typedef struct gmg_model gmg_model;       /* device copy of one ICM_t table set  */
+typedef struct gmg_reads gmg_reads;       /* device copy of a batch of reads     */
+typedef struct gmg_segments gmg_segments; /* device copy of a list of segments   */
+
+/* A scoring buffer cut from a read, in the orientation the reference scores it
+ * (src/Glimmer/glimmer3.cc:1322-1343, src/Glimmer/glimmer-mg.cc:1482,1497):
+ *   GMG_REVERSED     B[j] = S[lo+len-1-j]        Reverse_Transfer     (glimmer_base.cc:2505-2533)
+ *   GMG_COMPLEMENTED B[j] = comp(S[lo+j])        Complement_Transfer  (glimmer_base.cc:410-434)
+ *   GMG_FORWARD      B[j] = S[lo+j]              the string as given  (Score_String on a read)
+ *   GMG_REVCOMP      B[j] = comp(S[lo+len-1-j])  Reverse_Complement_Transfer (glimmer_base.cc:2484-2501)
+ * Context never crosses the start of the buffer: the first model_len-1 bases of
+ * every segment use the partial-window rule (src/ICM/icm.cc:807-842). */
+typedef enum gmg_orient {
+    GMG_FORWARD = 0,
+    GMG_REVERSED = 1,
+    GMG_COMPLEMENTED = 2,
+    GMG_REVCOMP = 3
+} gmg_orient;
+
+typedef struct gmg_segment {
+    uint32_t read;    /* index into the gmg_reads batch            */
+    uint32_t lo;      /* first base of the region, 0-based in read */
+    uint32_t len;     /* number of bases                           */
+    uint32_t orient;  /* gmg_orient                                */
+} gmg_segment;
+
+/* ---- library / device ---------------------------------------------------- */
+
+/* Bind the calling process to HIP device `device` (one process per GPU).  Must
+ * be called before anything else.  Fails with GMG_ENODEV when no GPU or the
+ * device is not gfx950 -- there is no CPU fallback. */
+int gmg_init(int device);
+int gmg_device_count(void);
+const char *gmg_last_error(void);
+const char *gmg_version(void);
+int gmg_synchronize(void *stream);
+
+/* ---- host-side packing helpers (no GPU needed) ---------------------------- */
+
+/* 2-bit code of one character after the reference's load-time normalisation
+ * tolower(Filter(ch)) (src/Glimmer/glimmer3.cc:270-271, src/Common/gene.cc:1139-1175)
+ * followed by Subscript (src/ICM/icm.cc:2008-2027). */
+int gmg_base_code(int ch);
+/* Pack n characters starting at job-wide base index `first_base` into `packed`
+ * (which must be zero-initialised or already hold the preceding bases). */
+int gmg_pack_bases(const char *ascii, uint64_t n, uint64_t first_base, uint32_t *packed);
+/* Number of uint32 words needed for total_bases bases (+ one guard word). */
+uint64_t gmg_packed_words(uint64_t total_bases);
+
+/* ---- models: replaces ICM_t's table (src/ICM/icm.hh:106-129) -------------- */
+
+/* mip[p*num_nodes+n], prob4[(p*num_nodes+n)*4+b] exactly as ICM_t::Input builds
+ * them (src/ICM/icm.cc:614-726) or Build_Indep_WO_Stops (icm.cc:65-216).
+ * Supported: model_len <= 32, mut_info_pos in [-2, model_len-1].
+ * The fast six-frame kernel additionally needs model_len <= 16, model_depth <= 8;
+ * other shapes take the generic kernels (same results). */
+int gmg_model_upload(const int16_t *mip, const float *prob4, int model_len, int model_depth,
+                     int periodicity, int num_nodes, gmg_model **out);
+int gmg_model_free(gmg_model *m);
+int gmg_model_info(const gmg_model *m, int *model_len, int *model_depth, int *periodicity,
+                   int *num_nodes);
+
+/* ---- reads ------------------------------------------------------------------ */
+
+int gmg_reads_upload(const uint32_t *packed2bit, const uint64_t *base_offsets, uint64_t n_reads,
+                     gmg_reads **out);
+/* Wrap packed reads that are ALREADY in HBM (e.g. generated on device); the
+ * library copies nothing and does not free the two buffers. */
+int gmg_reads_wrap_device(const uint32_t *d_packed2bit, const uint64_t *d_base_offsets,
+                          uint64_t n_reads, uint64_t total_bases, gmg_reads **out);
+int gmg_reads_free(gmg_reads *r);
+int gmg_reads_info(const gmg_reads *r, uint64_t *n_reads, uint64_t *total_bases);
+
+/* ---- segments --------------------------------------------------------------- */
+
+/* Validates every segment against the read lengths (GMG_ERANGE otherwise).
+ * out_total_len receives sum(len); per-position outputs of segment i start at
+ * the exclusive prefix sum of the lengths (also returned in out_offsets if not NULL,
+ * n_segments+1 entries). */
+int gmg_segments_upload(const gmg_reads *reads, const gmg_segment *segs, uint64_t n_segments,
+                        uint64_t *out_offsets, uint64_t *out_total_len, gmg_segments **out);
+int gmg_segments_free(gmg_segments *s);
+
+/* ---- scoring ---------------------------------------------------------------- */
+
+/* Six-frame per-position scores of whole reads: replaces Score_All_Frames
+ * (src/Glimmer/glimmer-mg.cc:1468-1510), i.e. 12 x ICM_t::Frame_Score
+ * (src/ICM/icm.cc:485-509) + the gene - null subtraction in double.
+ *   d_out[f*total_bases + base_offsets[r] + p],  f = 0..5, p = 0..len(r)-1
+ * equals Frame_Scores[f][p] of read r bit for bit.  Both models need periodicity
+ * >= 3 (Frame_Score asserts frame < periodicity, src/ICM/icm.cc:496); `null_model`
+ * normally is the (3,2,3) Build_Indep_WO_Stops model. */
+int gmg_frame_score6(const gmg_model *gene, const gmg_model *null_model, const gmg_reads *reads,
+                     double *d_out, void *stream);
+
+/* ICM_t::Frame_Score (src/ICM/icm.cc:485-509) on every segment: one fixed
+ * sub-model `frame` for all positions, no sum.  d_out[offset(i)+j]. */
+int gmg_segment_frame_score(const gmg_model *m, const gmg_reads *reads, const gmg_segments *segs,
+                            int frame, double *d_out, void *stream);
+
+/* ICM_t::Cumulative_Score (src/ICM/icm.cc:354-405) on every segment: running
+ * double sum in reference order, sub-model of base 0 = frame0, cycling.
+ * This is what Score_Orfs calls twice per ORF (src/Glimmer/glimmer3.cc:1346-1347). */
+int gmg_segment_cumscore(const gmg_model *m, const gmg_reads *reads, const gmg_segments *segs,
+                         int frame0, double *d_out, void *stream);
+
+/* ICM_t::Score_String (src/ICM/icm.cc:864-903) on every segment: d_sums[i]. */
+int gmg_score_string(const gmg_model *m, const gmg_reads *reads, const gmg_segments *segs,
+                     int frame0, double *d_sums, void *stream);
+
+/* ICM_t::Partial_Window_Prob (src/ICM/icm.cc:807-842) for the LAST base of every
+ * segment (predict_pos = len-1), with the partial-window rule applied whatever
+ * the length, as the reference does.  d_out[i]; 0.0 for an empty segment. */
+int gmg_segment_partial_prob(const gmg_model *m, const gmg_reads *reads, const gmg_segments *segs,
+                             int frame, double *d_out, void *stream);
+
+/* All_Frame_Score (src/Glimmer/glimmer3.cc:328-359) on every segment: the
+ * segment is the ORF buffer orientation used by Score_Orfs, `d_prefix_len[i]`
+ * (device, uint32) is the number of leading buffer bases to score (best_j-2),
+ * `d_frame[i]` (device, int32 in {1,2,3,-1,-2,-3}) selects Permute_By_Frame
+ * (glimmer3.cc:1013-1088).  d_af[6*i + k]. */
+int gmg_all_frame_score(const gmg_model *gene, const gmg_reads *reads, const gmg_segments *segs,
+                        const uint32_t *d_prefix_len, const int32_t *d_frame, double *d_af,
+                        void *stream);
+
+/* ICM_t::Full_Window_Prob / Full_Window_Distrib (src/ICM/icm.cc:512-610) on
+ * n_windows explicit windows.  d_windows: model_len codes (0..3) per window, one
+ * byte each; d_frames: sub-model per window.  d_dist4[4*i+b] (may be NULL),
+ * d_prob[i] (may be NULL) = (double) dist[code of last window char]. */
+int gmg_window_distrib(const gmg_model *m, const uint8_t *d_windows, const int32_t *d_frames,
+                       uint64_t n_windows, float *d_dist4, double *d_prob, void *stream);
+
+/* ---- device memory helpers (for callers without their own allocator) -------- */
+int gmg_device_malloc(void **d_ptr, size_t bytes);
+int gmg_device_free(void *d_ptr);
+int gmg_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *stream);
+int gmg_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMG_H */

@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REAL reference (oracle/_ref, built by oracle/Makefile from
+/root/reference).  Runs only in the build container; the GPU box and the tests use the committed
+fixtures.  Test infrastructure only.
+
+Inputs copied as DATA fixtures (the reference's own sample-run inputs/outputs):
+  tests/golden/data/seqs.fa, NC_000915.icm, cluster-{0..5}.icm, seqs.cluster-4.run1.filt.gicm,
+  icm-{0..5}.scores.tmp
+
+Vectors produced by oracle/_ref/ref_dump (our driver over the reference's ICM_t):
+  frames_nc.npz     Score_All_Frames (glimmer-mg.cc:1468-1510) for the first 48 reads + sha256 over all 999
+  frames_gicm.npz   same with the small 3-periodic model seqs.cluster-4.run1.filt.gicm, first 16 reads
+  sstring.npz       Score_String (icm.cc:864-903) 999 reads x frames 0,1,2 for NC_000915.icm, cluster-4.icm
+  segs.npz          Cumulative_Score (icm.cc:354-405) gene+indep on ORF-style buffers (glimmer3.cc:1322-1347)
+                    and the six Score_String values of All_Frame_Score (glimmer3.cc:346-354)
+  windows.npz       Full_Window_Prob / Full_Window_Distrib (icm.cc:512-610) on 4096 random 12-mers x 3 frames
+  partial.npz       Partial_Window_Prob (icm.cc:807-842) for every prefix position of 64 reads x 3 frames
+  indep.npz         Build_Indep_WO_Stops tables (icm.cc:65-216) for GC x stop-codon sets
+  predict/*.predict reference CLI outputs on seqs.fa (glimmer3, glimmer3 -X..., glimmer-mg, glimmer-mg -i)
+"""
+import hashlib
+import os
+import shutil
+import struct
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("GMG_REFERENCE", "/root/reference")
+RB = os.path.join(HERE, "_ref")
+GOLD = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(GOLD, "data")
+
+
+def run(*args):
+    return subprocess.run([os.path.join(RB, "ref_dump"), *map(str, args)], check=True,
+                          stdout=subprocess.PIPE).stdout
+
+
+def parse_icm_stream(buf):
+    """Binary .icm stream -> (params, mip[P][N] int16, prob[P][N][4] float32); icm.cc:614-726."""
+    ver, idl, W, D, P, N = struct.unpack_from("<6i", buf, 150)
+    mip = np.zeros((P, N), np.int16)
+    prob = np.zeros((P, N, 4), np.float32)
+    seen = np.zeros((P, N), bool)
+    off, period = 174, -1
+    while True:
+        (nid,) = struct.unpack_from("<i", buf, off)
+        off += 4
+        if nid < 0:
+            break
+        if nid == 0:
+            period += 1
+        prob[period, nid] = struct.unpack_from("<4f", buf, off)
+        (mip[period, nid],) = struct.unpack_from("<h", buf, off + 16)
+        seen[period, nid] = True
+        off += 18
+    mip[~seen] = -2
+    return (W, D, P, N), mip, prob
+
+
+def main():
+    if not os.path.exists(os.path.join(RB, "ref_dump")):
+        sys.exit("build oracle/_ref first:  make -C oracle ref")
+    os.makedirs(DATA, exist_ok=True)
+    os.makedirs(os.path.join(GOLD, "predict"), exist_ok=True)
+    sr = os.path.join(REF, "sample-run")
+    copies = {"seqs.fa": "glimmer-mg/seqs.fa", "NC_000915.icm": "glimmer3/results/NC_000915.icm",
+              "seqs.cluster-4.run1.filt.gicm": "glimmer-mg/results/seqs.cluster-4.run1.filt.gicm"}
+    for i in range(6):
+        copies["cluster-%d.icm" % i] = "glimmer-mg/results/cluster-%d.icm" % i
+        copies["icm-%d.scores.tmp" % i] = "glimmer-mg/results/icm-%d.scores.tmp" % i
+    for dst, src in copies.items():
+        shutil.copyfile(os.path.join(sr, src), os.path.join(DATA, dst))
+        os.chmod(os.path.join(DATA, dst), 0o644)
+
+    fa = os.path.join(DATA, "seqs.fa")
+    nc = os.path.join(DATA, "NC_000915.icm")
+    gicm = os.path.join(DATA, "seqs.cluster-4.run1.filt.gicm")
+    c4 = os.path.join(DATA, "cluster-4.icm")
+    L, NREADS = 500, 999
+
+    (gc,) = struct.unpack("<d", run("gc", fa))
+
+    # ---- frames
+    nf = 48
+    fr = np.frombuffer(run("frames", nc, fa, 0, nf, -1), "<f8").reshape(nf, 6, L)
+    allf = run("frames", nc, fa, 0, NREADS, -1)
+    np.savez_compressed(os.path.join(GOLD, "frames_nc.npz"), frames=fr, gc=gc, n_all=NREADS,
+                        sha256_all=hashlib.sha256(allf).hexdigest())
+    nf2 = 16
+    fr2 = np.frombuffer(run("frames", gicm, fa, 0, nf2, 0.5, "taa,tag"), "<f8").reshape(nf2, 6, L)
+    np.savez_compressed(os.path.join(GOLD, "frames_gicm.npz"), frames=fr2, gc=0.5, stops="taa,tag")
+
+    # ---- Score_String on whole reads
+    ss_nc = np.frombuffer(run("sstring", nc, fa), "<f8").reshape(NREADS, 3)
+    ss_c4 = np.frombuffer(run("sstring", c4, fa), "<f8").reshape(NREADS, 3)
+    np.savez_compressed(os.path.join(GOLD, "sstring.npz"), nc=ss_nc, cluster4=ss_c4)
+
+    # ---- ORF-style segments: (read, lo, len, strand)
+    rng = np.random.default_rng(20260101)
+    segs = []
+    for r in range(24):
+        for _ in range(6):
+            ln = int(rng.integers(1, L + 1))
+            lo = int(rng.integers(0, L - ln + 1))
+            segs.append((r, lo, ln, 1 if rng.integers(2) else -1))
+    for ln in (1, 2, 10, 11, 12, 13, 500):        # edges around model_len-1 = 11
+        segs.append((30, 0, ln, 1))
+        segs.append((31, L - ln, ln, -1))
+    segs = np.array(segs, np.int32)
+    segfile = os.path.join(RB, "segs.txt")
+    np.savetxt(segfile, segs, fmt="%d")
+    raw = np.frombuffer(run("segs", nc, fa, segfile, -1), "<f8")
+    gene_cum, indep_cum, off = [], [], 0
+    for _, _, ln, _ in segs:
+        gene_cum.append(raw[off:off + ln]); off += ln
+        indep_cum.append(raw[off:off + ln]); off += ln
+    assert off == raw.size
+    af = np.frombuffer(run("allframe", nc, fa, segfile), "<f8").reshape(len(segs), 6)
+    np.savez_compressed(os.path.join(GOLD, "segs.npz"), segs=segs, gene_cum=np.concatenate(gene_cum),
+                        indep_cum=np.concatenate(indep_cum), allframe_raw=af, gc=gc)
+
+    # ---- random windows
+    nw = 4096
+    raw = run("windows", nc, 12345, nw)
+    rec = 12 + 3 * (8 + 16)
+    wins = np.frombuffer(raw, np.uint8).reshape(nw, rec)
+    wchars = wins[:, :12].copy()
+    tail = wins[:, 12:].copy().reshape(nw, 3, 24)
+    wprob = tail[:, :, :8].copy().view("<f8").reshape(nw, 3)
+    wdist = tail[:, :, 8:].copy().view("<f4").reshape(nw, 3, 4)
+    np.savez_compressed(os.path.join(GOLD, "windows.npz"), windows=wchars, prob=wprob, dist=wdist)
+
+    # ---- partial windows
+    npart = 64
+    part = np.frombuffer(run("partial", nc, fa, npart), "<f8").reshape(npart, 3, 11)
+    part_c4 = np.frombuffer(run("partial", c4, fa, npart), "<f8").reshape(npart, 1, 11)
+    np.savez_compressed(os.path.join(GOLD, "partial.npz"), nc=part, cluster4=part_c4)
+
+    # ---- null models
+    out = {}
+    for gcv in (0.25, 0.39, 0.5, 0.65, gc):
+        for stops in ("taa,tag,tga", "taa,tag"):
+            _, mip, prob = parse_icm_stream(run("indep", repr(float(gcv)), stops))
+            key = "gc%.17g_%s" % (gcv, stops.replace(",", "-"))
+            out[key + "_prob"] = prob
+            # the writer drops nodes with mip < -1 only; calloc'ed nodes come back as written
+            out[key + "_mip"] = mip
+    np.savez_compressed(os.path.join(GOLD, "indep.npz"), seqs_gc=gc, **out)
+
+    # ---- writer round trip (icm.cc:729-803): reference Read -> Output must reproduce the file
+    tmp = os.path.join(RB, "rewrite.icm")
+    run("rewrite", nc, tmp)
+    assert open(tmp, "rb").read() == open(nc, "rb").read(), "reference writer is not a fixed point?"
+
+    # ---- CLI outputs
+    clis = {
+        "glimmer3.default": ["glimmer3", "-m", nc],
+        "glimmer3.X": ["glimmer3", "-X", "-m", nc],
+        "glimmer-mg.default": ["glimmer-mg", "-m", nc],
+        "glimmer-mg.indel": ["glimmer-mg", "-i", "-m", nc],
+    }
+    for name, cmd in clis.items():
+        tag = os.path.join(RB, "cli_" + name)
+        subprocess.run([os.path.join(RB, cmd[0]), *cmd[1:], fa, tag], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=RB)
+        shutil.copyfile(tag + ".predict", os.path.join(GOLD, "predict", name + ".predict"))
+    print("golden vectors written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,527 @@
+/*
+ * gmg_oracle.c -- CPU ORACLE (test infrastructure, never shipped in the product
+ * path).  See gmg_oracle.h for the parity status and the usage rules.
+ *
+ * Plain-C restatement of the reference algorithm.  It deliberately keeps the
+ * reference's data flow (NUL-terminated lower-case strings, per-call tree
+ * descent, sequential double adds) so that every value is bit-identical to
+ * what the reference computes; it is not meant to be fast.
+ */
+#include "gmg_oracle.h"
+
+#include <ctype.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_ALPHA 4
+#define ORC_ID_STRING_LEN 150 /* icm.hh:46 */
+#define ORC_VERSION_ID 200    /* icm.hh:80 */
+
+/* icm.hh:84  PARENT(x) = (x-1)/4 with C truncation (parent of the root is the root) */
+static int orc_parent(int x) { return (x - 1) / ORC_ALPHA; }
+
+/* ------------------------------------------------------------------------ */
+/* characters                                                               */
+/* ------------------------------------------------------------------------ */
+
+/* gene.cc:1139-1175.  a/c/g/t keep their case; IUPAC codes collapse to one
+ * lower-case base; everything else becomes 'c'. */
+int orc_filter(int ch)
+{
+    switch (tolower(ch)) {
+    case 'a': case 'c': case 'g': case 't': return ch;
+    case 'r': case 'd':                     return 'g';
+    case 'w': case 'k':                     return 't';
+    default:                                return 'c';   /* y s m b h v and anything else */
+    }
+}
+
+/* gene.cc:15-19 table, restated as rules: IUPAC complement with case kept,
+ * a few punctuation marks map to themselves, the rest to 'n'. */
+int orc_complement(int ch)
+{
+    static const char from[] = "acgtrykmbdhvswn";
+    static const char to[]   = "tgcayrmkvhdbswn";
+    const char *p;
+    int lower;
+    if (ch < 32 || ch > 127) return 'n';
+    if (ch == ' ' || ch == '*' || ch == '-' || ch == '.' || ch == '_') return ch;
+    if (!isalpha(ch)) return 'n';
+    lower = tolower(ch);
+    p = strchr(from, lower);
+    if (p == NULL) return (ch == lower) ? 'n' : 'N';
+    return (ch == lower) ? to[p - from] : toupper(to[p - from]);
+}
+
+/* icm.cc:2008-2027.  The reference exits on a bad character; the oracle
+ * returns -1 (unreachable after orc_filter). */
+int orc_subscript(int ch)
+{
+    switch (tolower(orc_filter(ch))) {
+    case 'a': return 0;
+    case 'c': return 1;
+    case 'g': return 2;
+    case 't': return 3;
+    }
+    return -1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* model construction / IO                                                  */
+/* ------------------------------------------------------------------------ */
+
+static int orc_alloc_tables(orc_model *m)
+{
+    size_t n = (size_t)m->periodicity * (size_t)m->num_nodes;
+    m->mip = (int16_t *)calloc(n ? n : 1, sizeof(int16_t));
+    m->prob = (float *)calloc(n ? 4 * n : 4, sizeof(float));
+    return (m->mip && m->prob) ? 0 : -1;
+}
+
+/* icm.cc:24-44: num_nodes = (4^(D+1) - 1) / 3, zero-filled tables */
+orc_model *orc_model_new(int model_len, int model_depth, int periodicity)
+{
+    orc_model *m = (orc_model *)calloc(1, sizeof(*m));
+    int i, pw = 1;
+    if (!m) return NULL;
+    for (i = 0; i < model_depth + 1; i++) pw *= ORC_ALPHA;
+    m->model_len = model_len;
+    m->model_depth = model_depth;
+    m->periodicity = periodicity;
+    m->num_nodes = (pw - 1) / (ORC_ALPHA - 1);
+    if (orc_alloc_tables(m) != 0) { orc_model_free(m); return NULL; }
+    return m;
+}
+
+void orc_model_free(orc_model *m)
+{
+    if (!m) return;
+    free(m->mip);
+    free(m->prob);
+    free(m);
+}
+
+static int32_t rd_i32(const unsigned char *p) { int32_t v; memcpy(&v, p, 4); return v; }
+
+/* icm.cc:614-726.  Layout: 150-byte text header, 6 x int32
+ * {version, id_string_len, model_len, depth, periodicity, num_nodes}, then
+ * records {int32 id, 4 x float prob, int16 mip}; a record with id 0 opens the
+ * next sub-model; ids skipped in between are cut nodes (mip = -2); a negative
+ * id terminates the stream. */
+orc_model *orc_model_from_bytes(const unsigned char *buf, size_t n, char *err, size_t errlen)
+{
+    orc_model *m = NULL;
+    size_t off = 0;
+    int32_t par[6];
+    int i, period = -1, prev_node = 0;
+
+#define ORC_FAIL(...) do { if (err) snprintf(err, errlen, __VA_ARGS__); orc_model_free(m); return NULL; } while (0)
+
+    if (n < ORC_ID_STRING_LEN) ORC_FAIL("ERROR reading ICM header");
+    off = ORC_ID_STRING_LEN;
+    if (n < off + 24) ORC_FAIL("ERROR reading parameters");
+    for (i = 0; i < 6; i++) par[i] = rd_i32(buf + off + 4 * i);
+    off += 24;
+    if (par[0] != ORC_VERSION_ID) ORC_FAIL("Bad ICM version = %d  should be %d", par[0], ORC_VERSION_ID);
+    if (par[1] != ORC_ID_STRING_LEN) ORC_FAIL("Bad ID_STRING_LEN = %d  should be %d", par[1], ORC_ID_STRING_LEN);
+
+    m = (orc_model *)calloc(1, sizeof(*m));
+    if (!m) ORC_FAIL("out of memory");
+    m->model_len = par[2];
+    m->model_depth = par[3];
+    m->periodicity = par[4];
+    m->num_nodes = par[5];
+    if (m->periodicity <= 0 || m->num_nodes <= 0 || m->model_len <= 0 || m->model_depth < 0)
+        ORC_FAIL("ERROR:  bad ICM parameters");
+    if (orc_alloc_tables(m) != 0) ORC_FAIL("out of memory");
+
+    while (off + 4 <= n) {
+        int32_t id = rd_i32(buf + off);
+        size_t slot;
+        off += 4;
+        if (id < 0) break;
+        if (id == 0) period++;
+        if (period < 0 || period >= m->periodicity || id >= m->num_nodes)
+            ORC_FAIL("ERROR reading icm node = %d  period = %d", id, period);
+        if (off + 16 > n) ORC_FAIL("ERROR reading icm node = %d  period = %d", id, period);
+        slot = (size_t)period * m->num_nodes + id;
+        memcpy(m->prob + 4 * slot, buf + off, 16);
+        off += 16;
+        if (off + 2 > n) ORC_FAIL("ERROR reading mut_info_pos for node = %d  period = %d", id, period);
+        memcpy(m->mip + slot, buf + off, 2);
+        off += 2;
+        /* gaps in the id sequence are cut nodes */
+        if (id != 0 && prev_node != id - 1)
+            for (i = prev_node + 1; i < id; i++)
+                m->mip[(size_t)period * m->num_nodes + i] = -2;
+        if (id == 0 && period > 0)
+            for (i = prev_node + 1; i < m->num_nodes; i++)
+                m->mip[(size_t)(period - 1) * m->num_nodes + i] = -2;
+        prev_node = id;
+    }
+    if (period != m->periodicity - 1)
+        ORC_FAIL("ERROR:  Too few nodes for periodicity = %d", m->periodicity);
+    if (prev_node != m->num_nodes - 1)
+        for (i = prev_node + 1; i < m->num_nodes; i++)
+            m->mip[(size_t)period * m->num_nodes + i] = -2;
+#undef ORC_FAIL
+    return m;
+}
+
+orc_model *orc_model_read(const char *path, char *err, size_t errlen)
+{
+    FILE *fp = fopen(path, "rb");
+    unsigned char *buf;
+    long sz;
+    orc_model *m;
+    if (!fp) { if (err) snprintf(err, errlen, "ERROR:  Could not open file  %s", path); return NULL; }
+    fseek(fp, 0, SEEK_END);
+    sz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    buf = (unsigned char *)malloc(sz > 0 ? (size_t)sz : 1);
+    if (!buf || fread(buf, 1, (size_t)sz, fp) != (size_t)sz) {
+        if (err) snprintf(err, errlen, "ERROR reading ICM header");
+        free(buf); fclose(fp); return NULL;
+    }
+    fclose(fp);
+    m = orc_model_from_bytes(buf, (size_t)sz, err, errlen);
+    free(buf);
+    return m;
+}
+
+/* icm.cc:729-753 (Output), :757-773 (Output_Node, binary), :961-998 (Write_Header):
+ * the root of every sub-model is always written, other nodes only when
+ * mip >= -1; int32 -1 closes the file. */
+int orc_model_write(const orc_model *m, const char *path)
+{
+    FILE *fp = fopen(path, "wb");
+    char line[ORC_ID_STRING_LEN];
+    int32_t par[6], endmark = -1;
+    int f, i;
+    if (!fp) return -1;
+    memset(line, 0, sizeof line);
+    snprintf(line, sizeof line, ">ver = %.2f  len = %d  depth = %d  periodicity = %d  nodes = %d\n",
+             ORC_VERSION_ID / 100.0, m->model_len, m->model_depth, m->periodicity, m->num_nodes);
+    fwrite(line, 1, ORC_ID_STRING_LEN, fp);
+    par[0] = ORC_VERSION_ID; par[1] = ORC_ID_STRING_LEN; par[2] = m->model_len;
+    par[3] = m->model_depth; par[4] = m->periodicity; par[5] = m->num_nodes;
+    fwrite(par, 4, 6, fp);
+    for (f = 0; f < m->periodicity; f++)
+        for (i = 0; i < m->num_nodes; i++) {
+            size_t slot = (size_t)f * m->num_nodes + i;
+            int32_t id = i;
+            if (i > 0 && m->mip[slot] < -1) continue;
+            fwrite(&id, 4, 1, fp);
+            fwrite(m->prob + 4 * slot, 4, 4, fp);
+            fwrite(m->mip + slot, 2, 1, fp);
+        }
+    fwrite(&endmark, 4, 1, fp);
+    return fclose(fp) == 0 ? 0 : -1;
+}
+
+/* icm.cc:65-216.  64 codon probabilities from GC%, stop codons (spelled
+ * backwards, because ORFs are scored 3'->5') forced to 1e-20, renormalised,
+ * then marginalised into a 3 x 21-node tree.  The accumulators are the float
+ * prob fields themselves, exactly as in the reference (float += double). */
+int orc_build_indep_wo_stops(orc_model *m, double gc_frac, const char *const *stop_codon, int n_stops)
+{
+    double codon_prob[64], base_prob[4], sum;
+    int i, j, k;
+    static const int pw[3] = {1, 4, 16};
+
+    if (m->model_len != 3 || m->model_depth != 2 || m->periodicity != 3 || m->num_nodes != 21)
+        return -1;
+
+    base_prob[1] = base_prob[2] = gc_frac / 2.0;
+    base_prob[0] = base_prob[3] = 0.5 - base_prob[1];
+    for (i = 0; i < 64; i++)   /* index = 16*first + 4*second + third (icm.cc:99-114) */
+        codon_prob[i] = base_prob[(i >> 4) & 3] * base_prob[(i >> 2) & 3] * base_prob[i & 3];
+
+    for (i = 0; i < n_stops; i++) {
+        j = orc_subscript(stop_codon[i][0]) + 4 * orc_subscript(stop_codon[i][1])
+            + 16 * orc_subscript(stop_codon[i][2]);
+        codon_prob[j] = 1e-20;
+    }
+    sum = 0.0;
+    for (i = 0; i < 64; i++) sum += codon_prob[i];
+    for (i = 0; i < 64; i++) codon_prob[i] /= sum;
+
+    memset(m->prob, 0, sizeof(float) * 4 * 3 * 21);
+    /* NOTE: the reference does not reset mut_info_pos here; it relies on the
+     * constructor's calloc (icm.cc:36-42).  Mirror that for a fresh model. */
+
+    for (i = 0; i < 3; i++) {                       /* roots, icm.cc:149-162 */
+        float *root = m->prob + 4 * (size_t)(i * 21);
+        int d1 = pw[(3 - i) % 3];
+        m->mip[i * 21] = (i == 1) ? -1 : 1;
+        for (j = 0; j < 64; j++) root[(j / d1) % 4] += codon_prob[j];
+    }
+    for (i = 0; i < 3; i++) {                       /* level 1, icm.cc:165-180 */
+        int d1 = pw[(3 - i) % 3], d2 = pw[(4 - i) % 3];
+        for (j = 0; j < 4; j++) m->mip[i * 21 + 1 + j] = (i == 2) ? -1 : 0;
+        if (i != 1)
+            for (j = 0; j < 64; j++)
+                m->prob[4 * (size_t)(i * 21 + 1 + (j / d2) % 4) + (j / d1) % 4] += codon_prob[j];
+    }
+    {                                               /* level 2, sub-model 0 only, icm.cc:185-199 */
+        int d1 = pw[0], d2 = pw[1], d3 = pw[2];
+        for (j = 0; j < 16; j++) m->mip[5 + j] = -1;
+        for (j = 0; j < 64; j++) {
+            k = 4 * ((j / d2) % 4) + (j / d3) % 4;
+            m->prob[4 * (size_t)(5 + k) + (j / d1) % 4] += codon_prob[j];
+        }
+    }
+    for (i = 0; i < 3; i++)                         /* normalise + log, icm.cc:202-211 */
+        for (j = 0; j < 21; j++) {
+            float *p = m->prob + 4 * (size_t)(i * 21 + j);
+            sum = 0.0;
+            for (k = 0; k < 4; k++) sum += p[k];
+            for (k = 0; k < 4; k++) p[k] = (sum == 0.0 ? 0.0 : log(p[k] / sum));
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* per-base scoring                                                          */
+/* ------------------------------------------------------------------------ */
+
+/* shared descent of icm.cc:521-548 / 568-595; returns the node whose row is used */
+static int orc_full_descent(const orc_model *m, const char *s, int frame)
+{
+    const int16_t *mip = m->mip + (size_t)frame * m->num_nodes;
+    int node = 0, i, pos;
+    for (i = 0; i < m->model_depth; i++) {
+        pos = mip[node];
+        if (pos == -1) break;
+        if (pos < -1) { node = orc_parent(node); break; }
+        node = node * ORC_ALPHA + orc_subscript(s[pos]) + 1;
+    }
+    if (mip[node] < -1) node = orc_parent(node);
+    return node;
+}
+
+double orc_full_window_prob(const orc_model *m, const char *s, int frame)
+{
+    int node = orc_full_descent(m, s, frame);
+    int sub = orc_subscript(s[m->model_len - 1]);
+    return (double)m->prob[4 * ((size_t)frame * m->num_nodes + node) + sub];
+}
+
+void orc_full_window_distrib(const orc_model *m, const char *s, int frame, float dist[4])
+{
+    int node = orc_full_descent(m, s, frame);
+    memcpy(dist, m->prob + 4 * ((size_t)frame * m->num_nodes + node), 4 * sizeof(float));
+}
+
+/* icm.cc:807-842: the window would start before the buffer; descend only while
+ * the context position named by the node is inside the buffer. */
+double orc_partial_window_prob(const orc_model *m, int predict_pos, const char *s, int frame)
+{
+    const int16_t *mip = m->mip + (size_t)frame * m->num_nodes;
+    int start = predict_pos - (m->model_len - 1);
+    int node = 0, i, pos;
+    for (i = 0; i < m->model_depth; i++) {
+        pos = start + mip[node];
+        if (pos < 0) break;
+        node = node * ORC_ALPHA + orc_subscript(s[pos]) + 1;
+    }
+    if (mip[node] == -2) node = orc_parent(node);
+    return (double)m->prob[4 * ((size_t)frame * m->num_nodes + node) + orc_subscript(s[predict_pos])];
+}
+
+/* ------------------------------------------------------------------------ */
+/* accumulations                                                             */
+/* ------------------------------------------------------------------------ */
+
+static int orc_next_frame(const orc_model *m, int frame)
+{
+    return (frame == m->periodicity - 1) ? 0 : frame + 1;
+}
+
+/* icm.cc:864-903 */
+double orc_score_string(const orc_model *m, const char *s, int len, int frame)
+{
+    double result = 0.0;
+    int i, start, stop = m->model_len - 1;
+    if (m->periodicity == 1) frame = 0;
+    for (i = 0; i < len && i < m->model_len - 1; i++) {
+        result += orc_partial_window_prob(m, i, s, frame);
+        frame = (frame + 1) % m->periodicity;
+    }
+    for (start = 0; stop < len; start++, stop++) {
+        result += orc_full_window_prob(m, s + start, frame);
+        frame = (frame + 1) % m->periodicity;
+    }
+    return result;
+}
+
+/* icm.cc:354-405 */
+void orc_cumulative_score(const orc_model *m, const char *s, int n, double *score, int frame)
+{
+    double result = 0.0;
+    int i, start, stop;
+    if (m->periodicity == 1) frame = 0;
+    stop = (m->model_len - 1 < n) ? m->model_len - 1 : n;
+    for (i = 0; i < stop; i++) {
+        result += orc_partial_window_prob(m, i, s, frame);
+        frame = orc_next_frame(m, frame);
+        score[i] = result;
+    }
+    for (start = 0; i < n; start++, i++) {
+        result += orc_full_window_prob(m, s + start, frame);
+        frame = orc_next_frame(m, frame);
+        score[i] = result;
+    }
+}
+
+/* icm.cc:409-452: like the above but shifted by one, cum_score[0] = 0, and the
+ * partial loop always runs model_len-1 times (caller guarantees len >= that). */
+void orc_cumulative_score_string(const orc_model *m, const char *s, int len, int frame, double *cum_score)
+{
+    double result;
+    int i, start, stop = m->model_len - 1;
+    if (m->periodicity == 1) frame = 0;
+    result = cum_score[0] = 0.0;
+    for (i = 0; i < m->model_len - 1; i++) {
+        result += orc_partial_window_prob(m, i, s, frame);
+        frame = (frame + 1) % m->periodicity;
+        cum_score[i + 1] = result;
+    }
+    for (start = 0; stop < len; start++, stop++) {
+        result += orc_full_window_prob(m, s + start, frame);
+        frame = (frame + 1) % m->periodicity;
+        cum_score[stop + 1] = result;
+    }
+}
+
+/* icm.cc:485-509: one fixed sub-model for every position, no sum */
+void orc_frame_score(const orc_model *m, const char *s, int n, double *score, int frame)
+{
+    int i, start, stop = (m->model_len - 1 < n) ? m->model_len - 1 : n;
+    for (i = 0; i < stop; i++) score[i] = orc_partial_window_prob(m, i, s, frame);
+    for (start = 0; i < n; start++, i++) score[i] = orc_full_window_prob(m, s + start, frame);
+}
+
+/* ------------------------------------------------------------------------ */
+/* buffers and six-frame loops                                               */
+/* ------------------------------------------------------------------------ */
+
+/* glimmer_base.cc:2505-2533: s[start], s[start-1], ... (wraps below 0) */
+void orc_reverse_transfer(char *buff, const char *s, int n, int start, int len)
+{
+    int j;
+    for (j = 0; j < len; j++, start--) {
+        buff[j] = s[start];
+        if (start <= 0) start += n;
+    }
+    buff[len] = '\0';
+}
+
+/* glimmer_base.cc:410-434: complement of s[start], s[start+1], ... (wraps at n) */
+void orc_complement_transfer(char *buff, const char *s, int n, int start, int len)
+{
+    int j;
+    for (j = 0; j < len; j++, start++) {
+        if (start >= n) start -= n;
+        buff[j] = (char)orc_complement(s[start]);
+    }
+    buff[len] = '\0';
+}
+
+/* glimmer-mg.cc:1468-1510.  Rows 0-2: reversed read, sub-model f, written back
+ * in forward coordinates; rows 3-5: complemented read. */
+void orc_score_all_frames(const orc_model *gene, const orc_model *indep, const char *seq, int L, double *out)
+{
+    char *buff = (char *)malloc((size_t)L + 1);
+    double *g = (double *)malloc(sizeof(double) * (size_t)(L ? L : 1));
+    double *z = (double *)malloc(sizeof(double) * (size_t)(L ? L : 1));
+    int f, i;
+    if (L > 0) {
+        orc_reverse_transfer(buff, seq, L, L - 1, L);
+        for (f = 0; f < 3; f++) {
+            orc_frame_score(gene, buff, L, g, f);
+            orc_frame_score(indep, buff, L, z, f);
+            for (i = 0; i < L; i++) out[(size_t)f * L + i] = g[L - 1 - i] - z[L - 1 - i];
+        }
+        orc_complement_transfer(buff, seq, L, 0, L);
+        for (f = 0; f < 3; f++) {
+            orc_frame_score(gene, buff, L, g, f);
+            orc_frame_score(indep, buff, L, z, f);
+            for (i = 0; i < L; i++) out[(size_t)(3 + f) * L + i] = g[i] - z[i];
+        }
+    }
+    free(buff); free(g); free(z);
+}
+
+/* glimmer-mg.cc:561-604: forward ORF (frame > 0) walks from hi-1 downwards in
+ * rows 1,2,0,...; reverse ORF walks from lo-1 upwards in rows 3+1,3+2,3+0,... */
+void orc_cumulative_frame_score(const double *fs, int L, int frame, int lo, int hi, double *score)
+{
+    double cum = 0;
+    int f = 1, len = hi - lo, i, si;
+    if (frame > 0) {
+        si = hi - 1;
+        for (i = 0; i < len; i++) {
+            score[i] = cum + fs[(size_t)f * L + si];
+            cum = score[i];
+            si--;
+            f = (f == 2) ? 0 : f + 1;
+        }
+    } else {
+        si = lo - 1;
+        for (i = 0; i < len; i++) {
+            score[i] = cum + fs[(size_t)(3 + f) * L + si];
+            cum = score[i];
+            si++;
+            f = (f == 2) ? 0 : f + 1;
+        }
+    }
+}
+
+/* glimmer3.cc:328-359 with Permute_By_Frame (glimmer3.cc:1013-1088) written as
+ * index tables: af_out[i] = af_raw[perm[i]]. */
+void orc_all_frame_score(const orc_model *gene, const char *s, int len, int frame, double af[6])
+{
+    static const int perm_p1[6] = {2, 0, 1, 5, 3, 4};
+    static const int perm_p2[6] = {1, 2, 0, 4, 5, 3};
+    static const int perm_p3[6] = {0, 1, 2, 3, 4, 5};
+    static const int perm_m1[6] = {3, 5, 4, 0, 2, 1};
+    static const int perm_m2[6] = {4, 3, 5, 1, 0, 2};
+    static const int perm_m3[6] = {5, 4, 3, 2, 1, 0};
+    const int *perm = perm_p3;
+    double raw[6];
+    char *rc = (char *)malloc((size_t)len + 1);
+    int i, j;
+
+    raw[0] = orc_score_string(gene, s, len, 1);
+    raw[1] = orc_score_string(gene, s, len, 2);
+    raw[2] = orc_score_string(gene, s, len, 0);
+    /* glimmer_base.cc:2484-2501 Reverse_Complement_Transfer(rc, s, 0, len) */
+    for (j = 0, i = len - 1; i >= 0; j++, i--) rc[j] = (char)orc_complement(s[i]);
+    rc[len] = '\0';
+    raw[3] = orc_score_string(gene, rc, len, 1);
+    raw[4] = orc_score_string(gene, rc, len, 0);
+    raw[5] = orc_score_string(gene, rc, len, 2);
+    free(rc);
+
+    switch (frame) {
+    case 1: perm = perm_p1; break;
+    case 2: perm = perm_p2; break;
+    case 3: perm = perm_p3; break;
+    case -1: perm = perm_m1; break;
+    case -2: perm = perm_m2; break;
+    case -3: perm = perm_m3; break;
+    }
+    for (i = 0; i < 6; i++) af[i] = raw[perm[i]];
+}
+
+long orc_score_reads_6frame(const orc_model *gene, const orc_model *indep, const char *seqs,
+                            int n_reads, int L, double *out)
+{
+    int r;
+    for (r = 0; r < n_reads; r++)
+        orc_score_all_frames(gene, indep, seqs + (size_t)r * L, L, out + (size_t)r * 6 * L);
+    return (long)n_reads * L;
+}

@@ -1,0 +1,103 @@
+/*
+ * gmg_oracle.h -- CPU ORACLE for the Glimmer-MG IMM scoring path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference
+ * algorithm (davek44/Glimmer-MG, src/ICM/icm.cc scoring side and the six-frame
+ * loops of src/Glimmer/glimmer3.cc / glimmer-mg.cc).  Only tests/, the
+ * smoke() entry point and bench.py's cpu_baseline leg may link or call it --
+ * and there only as the checker.  The product path (glimmer-mg_amd/) never
+ * includes, links or falls back to anything in oracle/.
+ *
+ * Parity status: PINNED.  The restatement is checked (tests/test_oracle_*.py)
+ *   - against the reference's own committed outputs
+ *     (sample-run/glimmer-mg/results/icm-N.scores.tmp, 6 x 999 Score_String
+ *     values, copied as data to tests/golden/), and
+ *   - against golden vectors produced in the build container by the real
+ *     reference objects (oracle/_ref, recipe in oracle/Makefile, generator
+ *     oracle/gen_golden.py).
+ *
+ * Every function cites the reference file:line it restates.  Paths are
+ * relative to the reference root.
+ */
+#ifndef GMG_ORACLE_H
+#define GMG_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One interpolated context model: src/ICM/icm.hh:106-129.
+ * mip[p*num_nodes + n]     = mut_info_pos of node n in sub-model p
+ * prob[(p*num_nodes+n)*4+b] = natural-log probability of base b at node n */
+typedef struct orc_model {
+    int model_len;    /* window width W (icm.hh:120)               */
+    int model_depth;  /* max tree depth D (icm.hh:122)             */
+    int periodicity;  /* number of cyclic sub-models P (icm.hh:125)*/
+    int num_nodes;    /* nodes per sub-model (icm.hh:127)          */
+    int16_t *mip;
+    float   *prob;
+} orc_model;
+
+/* character helpers ------------------------------------------------------ */
+int  orc_filter(int ch);       /* src/Common/gene.cc:1139-1175 */
+int  orc_complement(int ch);   /* src/Common/gene.cc:15-19,1084-1091 */
+int  orc_subscript(int ch);    /* src/ICM/icm.cc:2008-2027; -1 on bad char */
+
+/* model construction / IO ------------------------------------------------ */
+orc_model *orc_model_new(int model_len, int model_depth, int periodicity); /* icm.cc:24-44 */
+void       orc_model_free(orc_model *m);                                   /* icm.cc:48-61 */
+/* icm.cc:614-726 (Input) + 846-861 (Read).  Returns NULL and fills err on failure. */
+orc_model *orc_model_read(const char *path, char *err, size_t errlen);
+orc_model *orc_model_from_bytes(const unsigned char *buf, size_t n, char *err, size_t errlen);
+/* icm.cc:729-803,961-998 (binary Output / Write_Header).  0 on success. */
+int        orc_model_write(const orc_model *m, const char *path);
+/* icm.cc:65-216.  stop_codon = n_stops NUL-terminated 3-letter strings.  The
+ * model must be (3,2,3).  0 on success, -1 if incompatible. */
+int        orc_build_indep_wo_stops(orc_model *m, double gc_frac,
+                                    const char *const *stop_codon, int n_stops);
+
+/* per-base scoring -------------------------------------------------------- */
+double orc_full_window_prob(const orc_model *m, const char *s, int frame);     /* icm.cc:557-610 */
+double orc_partial_window_prob(const orc_model *m, int predict_pos,
+                               const char *s, int frame);                      /* icm.cc:807-842 */
+void   orc_full_window_distrib(const orc_model *m, const char *s, int frame,
+                               float dist[4]);                                 /* icm.cc:512-553 */
+
+/* accumulations ----------------------------------------------------------- */
+double orc_score_string(const orc_model *m, const char *s, int len, int frame);           /* icm.cc:864-903 */
+void   orc_cumulative_score(const orc_model *m, const char *s, int n, double *score,
+                            int frame);                                                   /* icm.cc:354-405 */
+void   orc_cumulative_score_string(const orc_model *m, const char *s, int len, int frame,
+                                   double *cum_score /* len+1 */);                        /* icm.cc:409-452 */
+void   orc_frame_score(const orc_model *m, const char *s, int n, double *score,
+                       int frame);                                                        /* icm.cc:485-509 */
+
+/* six-frame loops --------------------------------------------------------- */
+/* src/Glimmer/glimmer-mg.cc:1468-1510 (Score_All_Frames).  seq = filtered lower-case
+ * read of length L.  out = 6 rows of L doubles, row-major (out[f*L+p]). */
+void   orc_score_all_frames(const orc_model *gene, const orc_model *indep,
+                            const char *seq, int L, double *out);
+/* src/Glimmer/glimmer-mg.cc:561-604 (Cumulative_Frame_Score) on a 6xL table. */
+void   orc_cumulative_frame_score(const double *frame_scores, int L, int frame,
+                                  int lo, int hi, double *score /* hi-lo */);
+/* src/Glimmer/glimmer3.cc:328-359 (All_Frame_Score) incl. Permute_By_Frame :1013-1088. */
+void   orc_all_frame_score(const orc_model *gene, const char *s, int len, int frame,
+                           double af[6]);
+/* ORF buffer builders: glimmer_base.cc:2505-2533 (Reverse_Transfer, no wrap needed
+ * when 0 <= start-len+1) and :410-434 (Complement_Transfer). */
+void   orc_reverse_transfer(char *buff, const char *s, int n, int start, int len);
+void   orc_complement_transfer(char *buff, const char *s, int n, int start, int len);
+
+/* Whole-job helper used by bench.py's cpu_baseline leg: score n_reads reads of
+ * fixed length L (concatenated, filtered lower-case) into out[read][6][L].
+ * Returns number of bases scored.  Single-threaded like the reference. */
+long   orc_score_reads_6frame(const orc_model *gene, const orc_model *indep,
+                              const char *seqs, int n_reads, int L, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

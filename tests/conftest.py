@@ -1,0 +1,45 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(GOLD, "data")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gmg():
+    """the glimmer-mg_amd package (ctypes binding over libgmg.so); builds the library if needed"""
+    import _gmg_pkg
+    pkg = _gmg_pkg.load()
+    pkg.build.build_lib()
+    return pkg
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """ctypes binding over the CPU oracle (test infrastructure)"""
+    import oracle_py
+    return oracle_py.load()
+
+
+@pytest.fixture(scope="session")
+def gpu(gmg):
+    """initialised device 0; the -m gpu tests call the product through this"""
+    gmg.init(0)
+    return gmg
+
+
+@pytest.fixture(scope="session")
+def seqs_fa(gmg):
+    hdrs, seqs = gmg.read_fasta(os.path.join(DATA, "seqs.fa"))
+    return hdrs, seqs

@@ -1,0 +1,156 @@
+"""ctypes binding over oracle/libgmg_oracle.so -- the CPU oracle.  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libgmg_oracle.so")
+
+
+class Model(C.Structure):
+    _fields_ = [("model_len", C.c_int), ("model_depth", C.c_int), ("periodicity", C.c_int),
+                ("num_nodes", C.c_int), ("mip", C.POINTER(C.c_int16)), ("prob", C.POINTER(C.c_float))]
+
+
+MP = C.POINTER(Model)
+dp = C.POINTER(C.c_double)
+
+
+def build():
+    src = [os.path.join(ORACLE_DIR, f) for f in ("gmg_oracle.c", "gmg_oracle.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
+        subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, stdout=subprocess.DEVNULL)
+    return LIB
+
+
+class Oracle:
+    def __init__(self):
+        L = C.CDLL(build())
+        self.L = L
+        L.orc_model_new.restype = MP
+        L.orc_model_new.argtypes = [C.c_int] * 3
+        L.orc_model_read.restype = MP
+        L.orc_model_read.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.orc_model_free.argtypes = [MP]
+        L.orc_model_write.argtypes = [MP, C.c_char_p]
+        L.orc_build_indep_wo_stops.argtypes = [MP, C.c_double, C.POINTER(C.c_char_p), C.c_int]
+        L.orc_full_window_prob.restype = C.c_double
+        L.orc_full_window_prob.argtypes = [MP, C.c_char_p, C.c_int]
+        L.orc_partial_window_prob.restype = C.c_double
+        L.orc_partial_window_prob.argtypes = [MP, C.c_int, C.c_char_p, C.c_int]
+        L.orc_full_window_distrib.argtypes = [MP, C.c_char_p, C.c_int, C.POINTER(C.c_float)]
+        L.orc_score_string.restype = C.c_double
+        L.orc_score_string.argtypes = [MP, C.c_char_p, C.c_int, C.c_int]
+        L.orc_cumulative_score.argtypes = [MP, C.c_char_p, C.c_int, dp, C.c_int]
+        L.orc_cumulative_score_string.argtypes = [MP, C.c_char_p, C.c_int, C.c_int, dp]
+        L.orc_frame_score.argtypes = [MP, C.c_char_p, C.c_int, dp, C.c_int]
+        L.orc_score_all_frames.argtypes = [MP, MP, C.c_char_p, C.c_int, dp]
+        L.orc_cumulative_frame_score.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+        L.orc_all_frame_score.argtypes = [MP, C.c_char_p, C.c_int, C.c_int, dp]
+        L.orc_reverse_transfer.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.orc_complement_transfer.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.orc_score_reads_6frame.restype = C.c_long
+        L.orc_score_reads_6frame.argtypes = [MP, MP, C.c_char_p, C.c_int, C.c_int, dp]
+        for f in ("orc_filter", "orc_complement", "orc_subscript"):
+            getattr(L, f).argtypes = [C.c_int]
+
+    # ---- models
+    def read(self, path):
+        err = C.create_string_buffer(256)
+        m = self.L.orc_model_read(str(path).encode(), err, 256)
+        if not m:
+            raise RuntimeError(err.value.decode())
+        return m
+
+    def indep(self, gc, stops=("taa", "tag", "tga")):
+        m = self.L.orc_model_new(3, 2, 3)
+        arr = (C.c_char_p * len(stops))(*[s.encode() for s in stops])
+        assert self.L.orc_build_indep_wo_stops(m, float(gc), arr, len(stops)) == 0
+        return m
+
+    def tables(self, m):
+        c = m.contents
+        n = c.periodicity * c.num_nodes
+        mip = np.ctypeslib.as_array(c.mip, (n,)).reshape(c.periodicity, c.num_nodes).copy()
+        prob = np.ctypeslib.as_array(c.prob, (4 * n,)).reshape(c.periodicity, c.num_nodes, 4).copy()
+        return mip, prob
+
+    # ---- scoring
+    def score_all_frames(self, gene, indep, seq):
+        s = seq.encode() if isinstance(seq, str) else seq
+        out = np.empty((6, len(s)), np.float64)
+        self.L.orc_score_all_frames(gene, indep, s, len(s), out.ctypes.data_as(dp))
+        return out
+
+    def score_string(self, m, s, frame, n=None):
+        s = s.encode() if isinstance(s, str) else s
+        return self.L.orc_score_string(m, s, len(s) if n is None else n, frame)
+
+    def cumulative_score(self, m, s, frame):
+        s = s.encode() if isinstance(s, str) else s
+        out = np.empty(len(s), np.float64)
+        self.L.orc_cumulative_score(m, s, len(s), out.ctypes.data_as(dp), frame)
+        return out
+
+    def frame_score(self, m, s, frame):
+        s = s.encode() if isinstance(s, str) else s
+        out = np.empty(len(s), np.float64)
+        self.L.orc_frame_score(m, s, len(s), out.ctypes.data_as(dp), frame)
+        return out
+
+    def full_window(self, m, w, frame):
+        w = w.encode() if isinstance(w, str) else w
+        dist = (C.c_float * 4)()
+        self.L.orc_full_window_distrib(m, w, frame, dist)
+        return self.L.orc_full_window_prob(m, w, frame), np.array(dist[:], np.float32)
+
+    def partial_window(self, m, pos, s, frame):
+        s = s.encode() if isinstance(s, str) else s
+        return self.L.orc_partial_window_prob(m, pos, s, frame)
+
+    def all_frame_score(self, m, s, n, frame):
+        s = s.encode() if isinstance(s, str) else s
+        out = np.empty(6, np.float64)
+        self.L.orc_all_frame_score(m, s, n, frame, out.ctypes.data_as(dp))
+        return out
+
+    def buffer(self, seq, lo, ln, orient):
+        """the scoring buffer of include/gmg.h's gmg_orient, built with the oracle's transfer routines"""
+        s = seq.encode() if isinstance(seq, str) else seq
+        buf = C.create_string_buffer(ln + 1)
+        if ln == 0:
+            return b""
+        if orient == 1:       # REVERSED
+            self.L.orc_reverse_transfer(buf, s, len(s), lo + ln - 1, ln)
+        elif orient == 2:     # COMPLEMENTED
+            self.L.orc_complement_transfer(buf, s, len(s), lo, ln)
+        elif orient == 0:     # FORWARD
+            return s[lo:lo + ln]
+        else:                 # REVCOMP
+            tmp = C.create_string_buffer(ln + 1)
+            self.L.orc_reverse_transfer(tmp, s, len(s), lo + ln - 1, ln)
+            self.L.orc_complement_transfer(buf, tmp.raw[:ln], ln, 0, ln)
+        return buf.raw[:ln]
+
+    def filter_lower(self, seq):
+        """tolower(Filter(c)) per character (glimmer3.cc:270-271)"""
+        return bytes(ord(chr(self.L.orc_filter(c)).lower()) for c in (seq.encode() if isinstance(seq, str) else seq))
+
+    def score_reads_6frame(self, gene, indep, seqs_bytes, n_reads, L):
+        out = np.empty((n_reads, 6, L), np.float64)
+        self.L.orc_score_reads_6frame(gene, indep, seqs_bytes, n_reads, L, out.ctypes.data_as(dp))
+        return out
+
+
+_inst = None
+
+
+def load():
+    global _inst
+    if _inst is None:
+        _inst = Oracle()
+    return _inst
