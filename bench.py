@@ -77,9 +77,9 @@ def timed_region(step, steps, warmup, sync, dist=None):
     return worst, mine
 
 
-def aggregate(units_per_rank, world, seconds):
-    """whole-job throughput: units all ranks processed / max-over-ranks time"""
-    return units_per_rank * world / seconds
+def aggregate(units_per_rank_per_step, world, steps, seconds):
+    """whole-job throughput: units all ranks processed in the timed region / max-over-ranks time"""
+    return units_per_rank_per_step * world * steps / seconds
 
 
 # ----------------------------------------------------------------------------------------------
@@ -198,7 +198,7 @@ def main():
             check = "oracle unavailable: %s" % e
 
     if rank == 0:
-        value = aggregate(total, world, seconds) / 1e6
+        value = aggregate(total, world, args.steps, seconds) / 1e6
         achieved = ALGO_BYTES_PER_BASE * total / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")

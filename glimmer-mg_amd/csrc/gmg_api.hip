@@ -100,49 +100,37 @@ extern "C" int gmg_pack_bases(const char *ascii, uint64_t n, uint64_t first_base
 
 static inline int parent_of(int x) { return (x - 1) / 4; }   // src/ICM/icm.hh:84, C truncation
 
-// Row the reference uses when a FULL-window descent ends at original node n
-// (src/ICM/icm.cc:568-595).  `by_break` = the loop left through the mip < -1 branch.
-static int full_final_row(const int16_t *mip, int n, bool by_break)
-{
-    if (by_break) n = parent_of(n);
-    if (mip[n] < -1) n = parent_of(n);
-    return n;
-}
+// Row used when a descent (full or partial window) ends at original node n: a cut node
+// (mip -2) hands over to its parent (src/ICM/icm.cc:590-595, 834-835).  mip < -2 is rejected at
+// upload, and a reachable cut node always has a parent with mip >= 0, so the second look the
+// full-window code takes (icm.cc:577-583 then 590) can never move further up.
+static int final_row(const int16_t *mip, int n) { return mip[n] == -2 ? parent_of(n) : n; }
 
-// Expand sub-model tables into the completed tree (see gmg_internal.h).
-static void complete_tree(const int16_t *mip, const float *prob, int D, uint8_t *cshift, float *cleaf)
+// Expand one sub-model into the completed tree (see gmg_internal.h): breadth-first; per node either
+// the original node it mirrors (>= 0) or ~row once the original descent has stopped above it.
+static void complete_tree(const int16_t *mip, const float *prob, int D, uint8_t *cshift, float *crow)
 {
-    // breadth-first over the completed tree; per node: original node (>=0) while still
-    // descending, or ~row (negative) once stopped.
     std::vector<int> cur(1, 0), nxt;
     size_t lvl_base = 0, lvl_size = 1;
-    for (int l = 0; l < D; l++) {
-        nxt.assign(lvl_size * 4, 0);
+    for (int l = 0; l <= D; l++) {
+        if (l < D) nxt.assign(lvl_size * 4, 0);
         for (size_t i = 0; i < lvl_size; i++) {
             int st = cur[i];
+            int row = (st >= 0) ? final_row(mip, st) : ~st;
+            memcpy(crow + 4 * (lvl_base + i), prob + 4 * (size_t)row, 4 * sizeof(float));
+            if (l == D) continue;
             uint8_t sh = 0;
-            if (st >= 0) {
-                int m = mip[st];
-                if (m >= 0) {
-                    sh = (uint8_t)(2 * m);
-                    for (int b = 0; b < 4; b++) nxt[4 * i + b] = 4 * st + 1 + b;
-                } else {
-                    int row = (m == -1) ? st : full_final_row(mip, st, true);
-                    for (int b = 0; b < 4; b++) nxt[4 * i + b] = ~row;
-                }
+            if (st >= 0 && mip[st] >= 0) {
+                sh = (uint8_t)(2 * mip[st]);
+                for (int b = 0; b < 4; b++) nxt[4 * i + b] = 4 * st + 1 + b;
             } else {
-                for (int b = 0; b < 4; b++) nxt[4 * i + b] = st;
+                for (int b = 0; b < 4; b++) nxt[4 * i + b] = ~row;
             }
             cshift[lvl_base + i] = sh;
         }
         lvl_base += lvl_size;
         lvl_size *= 4;
         cur.swap(nxt);
-    }
-    for (size_t i = 0; i < lvl_size; i++) {
-        int st = cur[i];
-        int row = (st >= 0) ? full_final_row(mip, st, false) : ~st;
-        memcpy(cleaf + 4 * i, prob + 4 * (size_t)row, 4 * sizeof(float));
     }
 }
 
@@ -158,6 +146,19 @@ static float dense_entry(const int16_t *mip, const float *prob, int W, int D, ui
     }
     if (mip[node] < -1) node = parent_of(node);
     return prob[4 * (size_t)node + ((idx >> (2 * (W - 1))) & 3)];
+}
+
+// Partial-window value for buffer position j < W-1 (src/ICM/icm.cc:807-842); idx holds B[i] at bits 2i.
+static float dense_part_entry(const int16_t *mip, const float *prob, int W, int D, int j, uint32_t idx)
+{
+    int node = 0, start = j - (W - 1);
+    for (int i = 0; i < D; i++) {
+        int q = start + mip[node];
+        if (q < 0) break;
+        node = 4 * node + (int)((idx >> (2 * q)) & 3) + 1;
+    }
+    if (mip[node] == -2) node = parent_of(node);
+    return prob[4 * (size_t)node + ((idx >> (2 * j)) & 3)];
 }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -184,16 +185,18 @@ extern "C" int gmg_model_upload(const int16_t *mip, const float *prob4, int W, i
     const bool fast = (W <= GMG_FAST_MAX_LEN && D <= GMG_FAST_MAX_DEPTH);
     const bool dense = (W <= GMG_DENSE_MAX_LEN);
     const size_t n_internal = (size_t)((pw / 4 - 1) / 3);   // (4^D - 1) / 3
-    const size_t n_leaf = (size_t)(pw / 4);                  // 4^D
+    const size_t ctot = (size_t)need;                        // (4^(D+1) - 1) / 3
     const size_t cstride = align_up(n_internal ? n_internal : 1, 16);
     const size_t n_dense = dense ? ((size_t)1 << (2 * W)) : 0;
+    const size_t n_part = dense ? (n_dense - 4) / 3 : 0;     // sum_{j<W-1} 4^(j+1)
 
     size_t o_mip = 0;
     size_t o_prob = align_up(o_mip + PN, 256);
     size_t o_cshift = align_up(o_prob + PN * 16, 256);
-    size_t o_cleaf = align_up(o_cshift + (fast ? P * cstride : 0), 256);
-    size_t o_dense = align_up(o_cleaf + (fast ? (size_t)P * n_leaf * 16 : 0), 256);
-    size_t total = align_up(o_dense + (size_t)P * n_dense * 4, 256);
+    size_t o_crow = align_up(o_cshift + (fast ? P * cstride : 0), 256);
+    size_t o_dense = align_up(o_crow + (fast ? (size_t)P * ctot * 16 : 0), 256);
+    size_t o_part = align_up(o_dense + (size_t)P * n_dense * 4, 256);
+    size_t total = align_up(o_part + (size_t)P * n_part * 4 + 4, 256);
 
     std::vector<unsigned char> blob(total, 0);
     int8_t *h_mip = (int8_t *)(blob.data() + o_mip);
@@ -203,12 +206,21 @@ extern "C" int gmg_model_upload(const int16_t *mip, const float *prob4, int W, i
         for (int p = 0; p < P; p++)
             complete_tree(mip + (size_t)p * N, prob4 + 4 * (size_t)p * N, D,
                           blob.data() + o_cshift + p * cstride,
-                          (float *)(blob.data() + o_cleaf) + (size_t)p * n_leaf * 4);
+                          (float *)(blob.data() + o_crow) + (size_t)p * ctot * 4);
     if (dense)
-        for (int p = 0; p < P; p++)
-            for (uint32_t idx = 0; idx < n_dense; idx++)
-                ((float *)(blob.data() + o_dense))[(size_t)p * n_dense + idx] =
-                    dense_entry(mip + (size_t)p * N, prob4 + 4 * (size_t)p * N, W, D, idx);
+        for (int p = 0; p < P; p++) {
+            const int16_t *pm = mip + (size_t)p * N;
+            const float *pp = prob4 + 4 * (size_t)p * N;
+            float *full = (float *)(blob.data() + o_dense) + (size_t)p * n_dense;
+            float *part = (float *)(blob.data() + o_part) + (size_t)p * n_part;
+            for (uint32_t idx = 0; idx < n_dense; idx++) full[idx] = dense_entry(pm, pp, W, D, idx);
+            size_t o = 0;
+            for (int j = 0; j < W - 1; j++) {
+                uint32_t cnt = 1u << (2 * (j + 1));
+                for (uint32_t idx = 0; idx < cnt; idx++) part[o + idx] = dense_part_entry(pm, pp, W, D, j, idx);
+                o += cnt;
+            }
+        }
 
     gmg_model *m = new (std::nothrow) gmg_model();
     if (!m) return gmg_set_error(GMG_ENOMEM, "gmg_model_upload: out of host memory");
@@ -222,10 +234,13 @@ extern "C" int gmg_model_upload(const int16_t *mip, const float *prob4, int W, i
     m->dev.mip = (const int8_t *)(d + o_mip);
     m->dev.prob = (const float *)(d + o_prob);
     m->dev.cshift = fast ? (const uint8_t *)(d + o_cshift) : nullptr;
-    m->dev.cleaf = fast ? (const float *)(d + o_cleaf) : nullptr;
+    m->dev.crow = fast ? (const float *)(d + o_crow) : nullptr;
     m->dev.cstride = (int)cstride;
+    m->dev.ctot = (int)ctot;
     m->dev.has_fast = fast;
     m->dev.dense = dense ? (const float *)(d + o_dense) : nullptr;
+    m->dev.dense_part = dense ? (const float *)(d + o_part) : nullptr;
+    m->dev.n_dense_part = (int)n_part;
     m->dev.has_dense = dense;
     *out = m;
     return GMG_OK;

@@ -22,12 +22,19 @@ struct GmgDevModel {
     // "completed" tree: every early stop (mip -1 / -2) is expanded down to depth D so that a
     // full-window descent always takes exactly D steps and ends on a leaf whose row already is
     // the row the reference would have used (own row, or the parent's for a cut node).
-    const uint8_t *cshift; // [P][cstride]  2*mip of the completed tree, levels 0..D-1, level l at (4^l-1)/3
-    const float *cleaf;    // [P][4^D][4]   rows reached after D steps
+    const uint8_t *cshift; // [P][cstride]  2*mip of the completed tree, levels 0..D-1, level l at (4^l-1)/3;
+                           //               0 for nodes below an original stop
+    const float *crow;     // [P][ctot][4]  row the reference uses when a descent ends at that completed-tree
+                           //               node (own row; the parent's for a cut node; the stopping ancestor's
+                           //               for nodes below a stop).  Leaves (level D) start at (4^D-1)/3.
     int cstride;           // bytes per sub-model in cshift (padded to 16)
-    int has_fast;          // cshift/cleaf valid (W <= 16, D <= 8)
-    // direct table for tiny models: dense[p][idx], idx = sum_k code(w[k]) << 2k, full windows only
-    const float *dense;    // [P][4^W]
+    int ctot;              // (4^(D+1)-1)/3 nodes per sub-model in crow
+    int has_fast;          // cshift/crow valid (W <= 16, D <= 8)
+    // direct tables for tiny models (W <= 6), idx = sum_k code(w[k]) << 2k:
+    const float *dense;      // [P][4^W]            full windows
+    const float *dense_part; // [P][(4^W-4)/3]      partial windows: position j < W-1 at (4^(j+1)-4)/3,
+                             //                     idx = sum_{i<=j} code(B[i]) << 2i
+    int n_dense_part;
     int has_dense;
 };
 
