@@ -286,6 +286,22 @@ static int finish_reads(gmg_reads *r, const uint64_t *h_off /* may be NULL */)
     return GMG_OK;
 }
 
+// Packed reads always live in a library-owned buffer with GMG_GUARD_WORDS zero words on both
+// sides, so that window loads around the first and last bases of the job stay inside it.
+static int alloc_packed(gmg_reads *r, const uint32_t *src, hipMemcpyKind kind)
+{
+    uint64_t data_words = (r->total_bases + 15) / 16;
+    r->n_words = data_words + GMG_GUARD_WORDS;        // words addressable from d_packed upwards
+    uint32_t *alloc = nullptr;
+    hipError_t e = hipMalloc((void **)&alloc, (data_words + 2 * GMG_GUARD_WORDS) * 4);
+    if (e != hipSuccess) return gmg_set_error(GMG_ENOMEM, "gmg_reads: hipMalloc packed: %s", hipGetErrorString(e));
+    r->d_packed_alloc = alloc;
+    r->d_packed = alloc + GMG_GUARD_WORDS;
+    GMG_HIP(hipMemset(alloc, 0, (data_words + 2 * GMG_GUARD_WORDS) * 4));
+    if (data_words) GMG_HIP(hipMemcpy(alloc + GMG_GUARD_WORDS, src, data_words * 4, kind));
+    return GMG_OK;
+}
+
 extern "C" int gmg_reads_upload(const uint32_t *packed, const uint64_t *off, uint64_t n_reads, gmg_reads **out)
 {
     int rc = require_init("gmg_reads_upload");
@@ -302,23 +318,14 @@ extern "C" int gmg_reads_upload(const uint32_t *packed, const uint64_t *off, uin
     memset(r, 0, sizeof *r);
     r->n_reads = n_reads;
     r->total_bases = total;
-    r->owns = 1;
-    uint64_t data_words = (total + 15) / 16;
-    r->n_words = data_words + 4;                      // guard words: window loads never leave the buffer
-    uint32_t *d_packed = nullptr;
+    r->owns_off = 1;
+    rc = alloc_packed(r, packed, hipMemcpyHostToDevice);
+    if (rc) { gmg_reads_free(r); return rc; }
     uint64_t *d_off = nullptr;
-    hipError_t e = hipMalloc((void **)&d_packed, r->n_words * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_off, (n_reads + 1) * 8);
-    if (e != hipSuccess) {
-        if (d_packed) (void)hipFree(d_packed);
-        delete r;
-        return gmg_set_error(GMG_ENOMEM, "gmg_reads_upload: hipMalloc: %s", hipGetErrorString(e));
-    }
-    r->d_packed = d_packed;
+    hipError_t e = hipMalloc((void **)&d_off, (n_reads + 1) * 8);
+    if (e != hipSuccess) { gmg_reads_free(r); return gmg_set_error(GMG_ENOMEM, "gmg_reads_upload: hipMalloc: %s", hipGetErrorString(e)); }
     r->d_off = d_off;
-    e = hipMemset(d_packed, 0, r->n_words * 4);
-    if (e == hipSuccess && data_words) e = hipMemcpy(d_packed, packed, data_words * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_off, off, (n_reads + 1) * 8, hipMemcpyHostToDevice);
+    e = hipMemcpy(d_off, off, (n_reads + 1) * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) { gmg_reads_free(r); return gmg_set_error(GMG_EHIP, "gmg_reads_upload: copy: %s", hipGetErrorString(e)); }
     rc = finish_reads(r, off);
     if (rc) { gmg_reads_free(r); return rc; }
@@ -336,13 +343,21 @@ extern "C" int gmg_reads_wrap_device(const uint32_t *d_packed, const uint64_t *d
     gmg_reads *r = new (std::nothrow) gmg_reads();
     if (!r) return gmg_set_error(GMG_ENOMEM, "gmg_reads_wrap_device: out of host memory");
     memset(r, 0, sizeof *r);
-    r->d_packed = d_packed;
     r->d_off = d_off;
     r->n_reads = n_reads;
     r->total_bases = total_bases;
-    r->n_words = (total_bases + 15) / 16;            // caller's buffer: no guard words assumed
-    r->owns = 0;
-    rc = finish_reads(r, nullptr);
+    r->owns_off = 0;
+    rc = alloc_packed(r, d_packed, hipMemcpyDeviceToDevice);   // one on-device copy into a guarded buffer
+    if (rc) { gmg_reads_free(r); return rc; }
+    // uniform read length is detected from the offsets (a handful of bytes per read, read back once)
+    std::vector<uint64_t> h_off(n_reads + 1);
+    hipError_t e = hipMemcpy(h_off.data(), d_off, (n_reads + 1) * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { gmg_reads_free(r); return gmg_set_error(GMG_EHIP, "gmg_reads_wrap_device: %s", hipGetErrorString(e)); }
+    if (h_off[0] != 0 || h_off[n_reads] != total_bases) {
+        gmg_reads_free(r);
+        return gmg_set_error(GMG_EINVAL, "gmg_reads_wrap_device: base_offsets do not span [0, total_bases]");
+    }
+    rc = finish_reads(r, h_off.data());
     if (rc) { gmg_reads_free(r); return rc; }
     *out = r;
     return GMG_OK;
@@ -351,10 +366,8 @@ extern "C" int gmg_reads_wrap_device(const uint32_t *d_packed, const uint64_t *d
 extern "C" int gmg_reads_free(gmg_reads *r)
 {
     if (!r) return GMG_OK;
-    if (r->owns) {
-        if (r->d_packed) (void)hipFree((void *)r->d_packed);
-        if (r->d_off) (void)hipFree((void *)r->d_off);
-    }
+    if (r->d_packed_alloc) (void)hipFree(r->d_packed_alloc);
+    if (r->owns_off && r->d_off) (void)hipFree((void *)r->d_off);
     if (r->d_tile_read) (void)hipFree(r->d_tile_read);
     delete r;
     return GMG_OK;

@@ -1,4 +1,4 @@
-// gmg_frame6.hip -- k_frame6: six-frame per-position gene - null scores of whole reads on gfx950.
+// gmg_frame6.hip -- k_frame6s: six-frame per-position gene - null scores of whole reads on gfx950.
 // Replaces Score_All_Frames (src/Glimmer/glimmer-mg.cc:1468-1510) = 12 x ICM_t::Frame_Score
 // (src/ICM/icm.cc:485-509) + the double subtraction, for every read of a batch.
 //
@@ -7,24 +7,29 @@
 // Output row 3+f:        complemented read:
 //     window chars w[k] = comp(S[p-(W-1)+k]), predicted comp(S[p]) (glimmer-mg.cc:1497-1509)
 //
-// Mapping: one lane owns one base p of one read and produces its six doubles, so each store
-// instruction writes 64 consecutive doubles of one output row (coalesced).  The kernel is
-// integer/byte work + gathers, no MFMA; what it streams to HBM is 48 B per base.
+// The kernel is integer/byte work + gathers (no MFMA); what it must stream to HBM is 48 B per
+// base, so the design goal is to keep every table access on-chip and every store a full line.
 //
-// Tables (built at upload, gmg_api.hip):
-//   cshift  completed-tree shift table (2*mip, one byte per node, levels 0..D-1) -> LDS.
-//           One descent step is  ds_read_u8 ; v_bfe_u32 ; v_lshl_add_u32 .
-//   crow    row used when a descent ends at a completed-tree node -> gathered from L2 (1 MB).
-//   dense   null model as direct tables (full and partial windows) -> LDS.
-// Context registers CF / CR hold window char k in bits [2k, 2k+1].
+// Work-group specialisation.  The grid is persistent: 3 x nworkers work-groups of 1024 lanes,
+// one per CU.  Work-group type f = blockIdx % 3 owns sub-model f, i.e. output rows f and 3+f.
+// Its LDS (160 KiB, all of a CU) holds for that ONE sub-model
+//   s_leaf   as many leaf rows of the completed tree as fit (16 B each, ~9,600 of 16,384 at D = 7)
+//   s_shift  the completed-tree shift table (2*mip, one byte per node, levels 0..D-1)
+//   s_dense / s_part   the null model as direct tables (full and partial windows).
+// A descent step is  ds_read_u8 ; v_bfe_u32 ; v_lshl_add_u32 ; the leaf row comes from LDS when
+// cached and from the L2-resident crow table otherwise (~41 % of lookups on uniform reads).
+// Each lane owns two adjacent bases of one chunk and scores them on both strands (four
+// independent descents in flight), then writes one 16-byte store per output row: a wave writes
+// 1 KiB of consecutive doubles per row.
 //
 // Partial windows (the first W-1 bases of either scoring buffer, icm.cc:807-842): the reference
 // stops descending as soon as the context position named by a node lies before the buffer,
 // i.e. when mip < (W-1) - j.  In the completed tree that is "shift byte < 2*((W-1)-j)", so waves
 // that contain such lanes run the same loop with one compare per step and remember where they
-// stopped; crow holds the right row for inner nodes too.  Waves without such lanes (most) skip it.
+// stopped; crow holds the right row for inner nodes too.  Waves without such lanes skip that.
 
 #include "gmg_device.h"
+#include <stdlib.h>
 
 struct Frame6Args {
     GmgDevModel gene, nul;
@@ -34,25 +39,19 @@ struct Frame6Args {
     uint64_t total, n_words;
     double *out;
     int uniform_len;
+    int n_cached;          // leaf rows of one sub-model held in LDS
 };
 
-// all 2W-1 bases around job-wide base g: base g-(W-1)+i at bits [2i, 2i+1]
-__device__ __forceinline__ uint64_t dev_window_bits(const uint32_t *__restrict__ packed, uint64_t n_words,
-                                                    int64_t first)
+// Window of packed bases: base `first`+i at bits [2i, 2i+1], 32 bases.  The packed buffer has
+// GMG_GUARD_WORDS zero words on both sides, so `first` may be slightly negative or run past the data.
+__device__ __forceinline__ uint64_t dev_window_bits(const uint32_t *__restrict__ packed, int64_t first)
 {
-    // `first` may be negative or run past the data for lanes whose window leaves the read; those
-    // lanes never use the missing bits, the clamps only keep the loads inside the buffer.
-    int64_t fc = first < 0 ? 0 : first;
-    unsigned deficit = (unsigned)(fc - first);          // bases missing before the start of the job
-    uint64_t w0 = (uint64_t)fc >> 4;
-    uint64_t last = n_words - 1;
-    uint64_t i0 = w0 < last ? w0 : last, i1 = w0 + 1 < last ? w0 + 1 : last, i2 = w0 + 2 < last ? w0 + 2 : last;
-    uint64_t lo = (uint64_t)packed[i0] | ((uint64_t)packed[i1] << 32);
-    uint64_t hi = packed[i2];
-    unsigned sh = 2u * (unsigned)(fc & 15);
+    const int64_t w0 = first >> 4;                      // arithmetic: floor for negatives
+    const unsigned sh = 2u * (unsigned)(first & 15);
+    const uint64_t lo = (uint64_t)packed[w0] | ((uint64_t)packed[w0 + 1] << 32);
+    const uint64_t hi = packed[w0 + 2];
     uint64_t x = lo >> sh;
     if (sh) x |= hi << (64 - sh);
-    x <<= 2u * deficit;                                 // keep base g-(W-1)+i at field i
     return x;
 }
 
@@ -86,86 +85,147 @@ __device__ __forceinline__ uint32_t dev_ctree_node(const uint8_t *__restrict__ t
     return node;
 }
 
-template <int BLOCK, int DT>
-__global__ __launch_bounds__(BLOCK) void k_frame6(Frame6Args a)
+// position of job-wide base g inside its read: p = g - off[r], to_end = off[r+1] - 1 - g
+__device__ __forceinline__ void dev_locate(const Frame6Args &a, uint64_t g, int &p, int &to_end)
 {
-    extern __shared__ uint8_t lds[];
+    uint64_t r = a.tile_read[g / GMG_TILE];
+    uint64_t r_end = a.off[r + 1];
+    while (g >= r_end) { r++; r_end = a.off[r + 1]; }
+    p = (int)(g - a.off[r]);
+    to_end = (int)(r_end - 1 - g);
+}
+
+// DIAG != 0 builds are timing-only ablations (wrong results), selected with GMG_DIAG for profiling:
+//   1 no output stores   2 no leaf-row fetch   4 no descent   8 no packed-read window loads
+template <int BLOCK, int DT, int DIAG = 0>
+__global__ __launch_bounds__(BLOCK) void k_frame6s(Frame6Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int ftype = blockIdx.x % 3;
+    const uint32_t worker = blockIdx.x / 3, nworkers = gridDim.x / 3;
+
+    const int W = a.gene.W, D = DT > 0 ? DT : a.gene.D, Wn = a.nul.W;
     const int cstride = a.gene.cstride;
-    const int shift_bytes = 3 * cstride;
-    const int Wn = a.nul.W;
     const int n_dense = 1 << (2 * Wn);
     const int n_part = a.nul.n_dense_part;
-    uint8_t *s_shift = lds;
-    float *s_dense = (float *)(lds + shift_bytes);        // [3][n_dense]
-    float *s_part = s_dense + 3 * n_dense;                // [3][n_part]
+    const uint32_t n_cached = (uint32_t)a.n_cached;
+    const uint32_t leaf_base = ((1u << (2 * D)) - 1u) / 3u;
 
-    for (int i = threadIdx.x * 16; i < shift_bytes; i += BLOCK * 16)
-        *(uint4 *)(s_shift + i) = *(const uint4 *)(a.gene.cshift + i);
-    for (int i = threadIdx.x; i < 3 * n_dense; i += BLOCK) s_dense[i] = a.nul.dense[i];
-    for (int i = threadIdx.x; i < 3 * n_part; i += BLOCK) s_part[i] = a.nul.dense_part[i];
+    float *s_leaf = (float *)lds;                                   // [n_cached][4]
+    uint8_t *s_shift = lds + (size_t)n_cached * 16;                 // [cstride]
+    float *s_dense = (float *)(s_shift + cstride);                  // [n_dense]
+    float *s_part = s_dense + n_dense;                              // [n_part]
+
+    const float *__restrict__ crow_f = a.gene.crow + (size_t)ftype * a.gene.ctot * 4;
+    {
+        const float4 *src = (const float4 *)(crow_f + (size_t)leaf_base * 4);
+        for (uint32_t i = threadIdx.x; i < n_cached; i += BLOCK) ((float4 *)s_leaf)[i] = src[i];
+        const uint8_t *sh_src = a.gene.cshift + (size_t)ftype * cstride;
+        for (int i = threadIdx.x * 16; i < cstride; i += BLOCK * 16) *(uint4 *)(s_shift + i) = *(const uint4 *)(sh_src + i);
+        for (int i = threadIdx.x; i < n_dense; i += BLOCK) s_dense[i] = a.nul.dense[(size_t)ftype * n_dense + i];
+        for (int i = threadIdx.x; i < n_part; i += BLOCK) s_part[i] = a.nul.dense_part[(size_t)ftype * n_part + i];
+    }
     __syncthreads();
 
-    const int W = a.gene.W, D = a.gene.D;
     const uint32_t ctx_mask = (W >= 16) ? 0xffffffffu : ((1u << (2 * W)) - 1u);
-    const uint32_t ctot = (uint32_t)a.gene.ctot;
-    const float *__restrict__ crow = a.gene.crow;
-    const uint64_t n_chunks = (a.total + BLOCK - 1) / BLOCK;
+    constexpr uint64_t SPAN = 2 * BLOCK;                            // bases per chunk
+    const uint64_t n_chunks = (a.total + SPAN - 1) / SPAN;
+    const uint64_t last_even = (a.total - 1) & ~1ull;
+    const bool pair_store = (a.total & 1) == 0;                     // every row starts 16-byte aligned
+    const int L = a.uniform_len;
 
-    for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const uint64_t g = chunk * BLOCK + threadIdx.x;
-        const bool live = g < a.total;
-        const uint64_t gq = live ? g : a.total - 1;       // idle tail lanes shadow the last base
+    // uniform-length reads: track the lane's offset inside its read across chunks without dividing
+    int pu = 0, step_mod = 0;
+    if (L > 0) {
+        pu = (int)(((uint64_t)worker * SPAN + 2 * threadIdx.x) % (uint64_t)L);
+        step_mod = (int)(((uint64_t)nworkers * SPAN) % (uint64_t)L);
+    }
 
-        // ---- which read, where in it
-        uint64_t r_off, r_end;
-        if (a.uniform_len > 0) {
-            uint64_t r = gq / (uint64_t)a.uniform_len;
-            r_off = r * (uint64_t)a.uniform_len;
-            r_end = r_off + (uint64_t)a.uniform_len;
+    for (uint64_t chunk = worker; chunk < n_chunks; chunk += nworkers) {
+        const uint64_t g0 = chunk * SPAN + 2 * threadIdx.x;         // this lane's bases: g0, g0+1
+        const uint64_t gq = g0 <= last_even ? g0 : last_even;       // idle tail lanes shadow the last pair
+
+        // ---- where the two bases sit in their reads
+        int p[2], to_end[2];
+        if (L > 0) {
+            p[0] = pu;
+            p[1] = (pu + 1 == L) ? 0 : pu + 1;
+            to_end[0] = L - 1 - p[0];
+            to_end[1] = L - 1 - p[1];
+            pu += step_mod;
+            if (pu >= L) pu -= L;
         } else {
-            uint64_t r = a.tile_read[gq / GMG_TILE];
-            r_end = a.off[r + 1];
-            while (gq >= r_end) { r++; r_end = a.off[r + 1]; }
-            r_off = a.off[r];
+            dev_locate(a, gq, p[0], to_end[0]);
+            if (gq + 1 < a.total) dev_locate(a, gq + 1, p[1], to_end[1]);
+            else { p[1] = p[0]; to_end[1] = to_end[0]; }
         }
-        const int L = (int)(r_end - r_off);
-        const int p = (int)(gq - r_off);
 
-        // ---- context registers
-        const uint64_t x = dev_window_bits(a.packed, a.n_words, (int64_t)gq - (W - 1));
-        // fields 0..W-1 of x = S[p-(W-1)..p], fields W-1..2W-2 = S[p..p+W-1]
-        const uint32_t CR = ((uint32_t)x & ctx_mask) ^ ctx_mask;                                // comp(S[p-(W-1)+k])
-        const uint32_t CF = dev_reverse_fields((uint32_t)(x >> (2 * (W - 1))) & ctx_mask, W);  // S[p+W-1-k]
-
+        // ---- context registers.  x field i = base gq-(W-1)+i
+        const uint64_t x = (DIAG & 8) ? (gq * 0x9E3779B97F4A7C15ull) : dev_window_bits(a.packed, (int64_t)gq - (W - 1));
+        uint32_t C[4];
+        int jj[4];
 #pragma unroll
-        for (int strand = 0; strand < 2; strand++) {
-            const uint32_t C = strand ? CR : CF;
-            const int j = strand ? p : L - 1 - p;          // index in the scoring buffer
-            const int thr2 = 2 * ((W - 1) - j);            // > 0  <=>  partial gene window
-            const uint32_t pred = (C >> (2 * (W - 1))) & 3u;
-            const bool any_partial = __any(thr2 > 0);
-
-            // null model: direct tables.  Full window = last Wn chars of the gene window.
-            uint32_t nul_slot;
-            if (j >= Wn - 1) {
-                nul_slot = C >> (2 * (W - Wn));
-            } else {
-                // B[0..j] are gene window chars W-1-j .. W-1; position j's table starts at (4^(j+1)-4)/3
-                nul_slot = (C >> (2 * (W - 1 - j))) + (((1u << (2 * (j + 1))) - 4u) / 3u);
-            }
-            const float *nul_tab = (j >= Wn - 1) ? s_dense : s_part;
-            const int nul_stride = (j >= Wn - 1) ? n_dense : n_part;
-
+        for (int q = 0; q < 2; q++) {
+            const uint64_t xq = x >> (2 * q);
+            // fields 0..W-1 = S[p-(W-1)..p], fields W-1..2W-2 = S[p..p+W-1]
+            C[2 * q + 0] = dev_reverse_fields((uint32_t)(xq >> (2 * (W - 1))) & ctx_mask, W);   // forward rows: S[p+W-1-k]
+            C[2 * q + 1] = ((uint32_t)xq & ctx_mask) ^ ctx_mask;                               // reverse rows: comp(S[p-(W-1)+k])
+            jj[2 * q + 0] = to_end[q];                                                         // index in the reversed buffer
+            jj[2 * q + 1] = p[q];                                                              // index in the complemented buffer
+        }
+        int thr2[4];
+        bool part = false;
 #pragma unroll
-            for (int f = 0; f < 3; f++) {
-                const uint8_t *tab = s_shift + f * cstride;
-                uint32_t node;
-                if (any_partial) node = dev_ctree_node<DT, true>(tab, C, D, thr2);
-                else node = dev_ctree_node<DT, false>(tab, C, D, 0);
-                const float gv = crow[((size_t)f * ctot + node) * 4 + pred];
-                const float nv = nul_tab[f * nul_stride + nul_slot];
-                // glimmer-mg.cc:1493,1508: double(gene) - double(null)
-                if (live) a.out[(uint64_t)(strand * 3 + f) * a.total + g] = (double)gv - (double)nv;
+        for (int c = 0; c < 4; c++) { thr2[c] = 2 * ((W - 1) - jj[c]); part |= thr2[c] > 0; }
+        const bool any_partial = __any(part);
+
+        // ---- four descents
+        uint32_t node[4];
+        if (DIAG & 4) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) node[c] = leaf_base + ((C[c] >> 3) & ((1u << (2 * D)) - 1u));
+        } else if (any_partial) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) node[c] = dev_ctree_node<DT, true>(s_shift, C[c], D, thr2[c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) node[c] = dev_ctree_node<DT, false>(s_shift, C[c], D, 0);
+        }
+
+        // ---- leaf rows, null model, difference
+        double v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t pred = (C[c] >> (2 * (W - 1))) & 3u;
+            const uint32_t rel = node[c] - leaf_base;               // wraps for inner (stopped) nodes
+            float gv;
+            if (DIAG & 2) gv = __uint_as_float(node[c] + pred);
+            else if (rel < n_cached) gv = s_leaf[rel * 4 + pred];
+            else gv = crow_f[(size_t)node[c] * 4 + pred];
+            const int j = jj[c];
+            float nv;
+            if (j >= Wn - 1) nv = s_dense[C[c] >> (2 * (W - Wn))];                 // last Wn chars of the window
+            else nv = s_part[(C[c] >> (2 * (W - 1 - j))) + (((1u << (2 * (j + 1))) - 4u) / 3u)];   // B[0..j]
+            v[c] = (double)gv - (double)nv;                         // glimmer-mg.cc:1493,1508
+        }
+
+        // ---- stores: rows f (forward) and 3+f (reverse), bases g0 and g0+1
+        if (DIAG & 1) {
+            if (v[0] + v[1] + v[2] + v[3] == 1.2345e300) a.out[g0] = v[0];
+        } else {
+            double *row_f = a.out + (uint64_t)ftype * a.total + g0;
+            double *row_r = a.out + (uint64_t)(3 + ftype) * a.total + g0;
+            if (g0 + 1 < a.total) {
+                if (pair_store) {
+                    *(double2 *)row_f = make_double2(v[0], v[2]);
+                    *(double2 *)row_r = make_double2(v[1], v[3]);
+                } else {
+                    row_f[0] = v[0]; row_f[1] = v[2];
+                    row_r[0] = v[1]; row_r[1] = v[3];
+                }
+            } else if (g0 < a.total) {
+                row_f[0] = v[0];
+                row_r[0] = v[1];
             }
         }
     }
@@ -207,30 +267,62 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
     a.n_words = reads->n_words;
     a.out = d_out;
     a.uniform_len = reads->uniform_len;
+    a.n_cached = 0;
 
-    constexpr int BLOCK = 256;
-    const uint64_t n_chunks = (a.total + BLOCK - 1) / BLOCK;
     const bool fast = gene->dev.has_fast && nul->dev.has_dense && nul->dev.W <= gene->dev.W;
-    size_t lds = 0;
-    if (fast) {
-        lds = (size_t)3 * a.gene.cstride + (size_t)3 * ((size_t)1 << (2 * a.nul.W)) * 4 + (size_t)3 * a.nul.n_dense_part * 4;
-    }
-    if (!fast || lds > 150 * 1024) {
+    const size_t lds_max = 160 * 1024;
+    size_t fixed = 0;
+    if (fast) fixed = (size_t)a.gene.cstride + ((size_t)1 << (2 * a.nul.W)) * 4 + (size_t)a.nul.n_dense_part * 4;
+    if (!fast || fixed + 4096 > lds_max) {
+        const uint64_t n_chunks = (a.total + 255) / 256;
         unsigned grid = (unsigned)(n_chunks < 256 * 16 ? n_chunks : 256 * 16);
         hipLaunchKernelGGL(k_frame6_generic, dim3(grid), dim3(256), 0, s, a);
         GMG_HIP(hipGetLastError());
         return GMG_OK;
     }
-    unsigned grid = (unsigned)(n_chunks < 256 * 8 ? n_chunks : 256 * 8);
+    constexpr int BLOCK = 1024;
+    const size_t n_leaf = (size_t)1 << (2 * a.gene.D);
+    size_t n_cached = (lds_max - fixed) / 16;
+    if (n_cached > n_leaf) n_cached = n_leaf;
+    a.n_cached = (int)n_cached;
+    const size_t lds = n_cached * 16 + fixed;
+
+    int dev = 0, n_cu = 256;
+    GMG_HIP(hipGetDevice(&dev));
+    GMG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    // persistent grid: one work-group per CU, a multiple of the 3 sub-model types
+    const uint64_t n_chunks = (a.total + 2 * BLOCK - 1) / (2 * BLOCK);
+    unsigned nworkers = (unsigned)(n_cu / 3);
+    if (nworkers < 1) nworkers = 1;
+    if (nworkers > n_chunks) nworkers = (unsigned)n_chunks;
+    const unsigned grid = 3 * nworkers;
+
+    const char *env = getenv("GMG_DIAG");
+    const int diag = env ? atoi(env) : 0;
+#define GMG_LAUNCH_F6(DT_, DIAG_)                                                                       \
+    do {                                                                                                \
+        GMG_HIP(hipFuncSetAttribute((const void *)k_frame6s<BLOCK, DT_, DIAG_>,                         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
+        hipLaunchKernelGGL((k_frame6s<BLOCK, DT_, DIAG_>), dim3(grid), dim3(BLOCK), lds, s, a);         \
+    } while (0)
     if (a.gene.D == 7) {
-        if (lds > 64 * 1024)
-            GMG_HIP(hipFuncSetAttribute((const void *)k_frame6<BLOCK, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_frame6<BLOCK, 7>), dim3(grid), dim3(BLOCK), lds, s, a);
+        switch (diag) {
+        case 0: GMG_LAUNCH_F6(7, 0); break;
+        case 1: GMG_LAUNCH_F6(7, 1); break;
+        case 2: GMG_LAUNCH_F6(7, 2); break;
+        case 3: GMG_LAUNCH_F6(7, 3); break;
+        case 4: GMG_LAUNCH_F6(7, 4); break;
+        case 6: GMG_LAUNCH_F6(7, 6); break;
+        case 7: GMG_LAUNCH_F6(7, 7); break;
+        case 8: GMG_LAUNCH_F6(7, 8); break;
+        case 14: GMG_LAUNCH_F6(7, 14); break;
+        case 15: GMG_LAUNCH_F6(7, 15); break;
+        default: return gmg_set_error(GMG_EINVAL, "GMG_DIAG=%d is not a built ablation", diag);
+        }
     } else {
-        if (lds > 64 * 1024)
-            GMG_HIP(hipFuncSetAttribute((const void *)k_frame6<BLOCK, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_frame6<BLOCK, 0>), dim3(grid), dim3(BLOCK), lds, s, a);
+        GMG_LAUNCH_F6(0, 0);
     }
+#undef GMG_LAUNCH_F6
     GMG_HIP(hipGetLastError());
     return GMG_OK;
 }

@@ -12,6 +12,7 @@
 #define GMG_FAST_MAX_DEPTH 8
 #define GMG_DENSE_MAX_LEN 6       // 4^6 = 4096-entry direct table for tiny (null) models
 #define GMG_TILE 1024             // bases per tile_read entry
+#define GMG_GUARD_WORDS 8          // zero words before and after the packed reads
 
 // Device view of one model.  Pointers are HBM.
 struct GmgDevModel {
@@ -51,8 +52,9 @@ struct gmg_reads {
     uint64_t n_reads;
     uint64_t total_bases;
     uint64_t n_tiles;
-    uint64_t n_words;            // valid words in d_packed (incl. guard)
-    int owns;                    // d_packed / d_off allocated by the library
+    uint64_t n_words;            // words addressable at d_packed[0 ..) incl. the trailing guard
+    void *d_packed_alloc;        // d_packed - GMG_GUARD_WORDS: the allocation (always library-owned)
+    int owns_off;                // d_off allocated by the library
     int uniform_len;             // > 0 when every read has this length (fast read lookup)
 };
 

@@ -109,8 +109,9 @@ int gmg_model_info(const gmg_model *m, int *model_len, int *model_depth, int *pe
 
 int gmg_reads_upload(const uint32_t *packed2bit, const uint64_t *base_offsets, uint64_t n_reads,
                      gmg_reads **out);
-/* Wrap packed reads that are ALREADY in HBM (e.g. generated on device); the
- * library copies nothing and does not free the two buffers. */
+/* Take packed reads that are ALREADY in HBM (e.g. generated on device): one
+ * device-to-device copy into the library's guarded buffer; the offsets are used
+ * in place and must stay valid until gmg_reads_free.  Neither buffer is freed. */
 int gmg_reads_wrap_device(const uint32_t *d_packed2bit, const uint64_t *d_base_offsets,
                           uint64_t n_reads, uint64_t total_bases, gmg_reads **out);
 int gmg_reads_free(gmg_reads *r);
