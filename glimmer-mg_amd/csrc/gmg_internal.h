@@ -12,7 +12,7 @@
 #define GMG_FAST_MAX_DEPTH 8
 #define GMG_DENSE_MAX_LEN 6       // 4^6 = 4096-entry direct table for tiny (null) models
 #define GMG_TILE 1024             // bases per tile_read entry
-#define GMG_GUARD_WORDS 8          // zero words before and after the packed reads
+#define GMG_GUARD_WORDS 320        // zero words before and after the packed reads (>= one k_frame6s chunk + window)
 
 // Device view of one model.  Pointers are HBM.
 struct GmgDevModel {
