@@ -166,8 +166,9 @@ __global__ __launch_bounds__(BLOCK) void k_frame6s(Frame6Args a)
         step_mod = (int)(((uint64_t)nworkers * SPAN) % (uint64_t)L);
     }
 
-    uint32_t raw_a[3] = {0, 0, 0}, raw_b[3] = {0, 0, 0};            // stage A -> B (ping-pong)
-    F6Pend pend_a, pend_b;                                          // stage B -> C (ping-pong)
+    // rings of three: words loaded one iteration ahead; values retired TWO iterations after issue
+    uint32_t raw_a[3] = {0, 0, 0}, raw_b[3] = {0, 0, 0}, raw_c[3] = {0, 0, 0};     // stage A -> B
+    F6Pend pend_a, pend_b, pend_c;                                                 // stage B -> C
 
     auto load_raw = [&](uint64_t chunk, uint32_t (&w)[3]) __attribute__((always_inline)) {         // stage A
         const uint32_t *base = a.packed + chunk * (SPAN / 16) - 1;  // wave-uniform
@@ -280,27 +281,30 @@ __global__ __launch_bounds__(BLOCK) void k_frame6s(Frame6Args a)
         pd.miss = miss;
 
         // ---- stage C: retire the previous chunk
-        if (have_prev) finish(chunk - nworkers, pd_prev, SPAN);
+        if (have_prev) finish(chunk - 2 * (uint64_t)nworkers, pd_prev, SPAN);
     };
 
     if (worker < n_chunks) {
         load_raw(worker, raw_a);
         uint64_t chunk = worker;
-        bool have_prev = false;
-        int last_par = 0;
+        uint64_t k = 0;                                             // iterations done by this worker
+        int phase = 0;
         while (true) {
-            step(chunk, have_prev, chunk + nworkers < n_chunks, raw_a, raw_b, pend_a, pend_b);
-            have_prev = true;
-            last_par = 0;
-            chunk += nworkers;
+            step(chunk, k >= 2, chunk + nworkers < n_chunks, raw_a, raw_b, pend_a, pend_b);
+            k++; phase = 1; chunk += nworkers;
             if (chunk >= n_chunks) break;
-            step(chunk, true, chunk + nworkers < n_chunks, raw_b, raw_a, pend_b, pend_a);
-            last_par = 1;
-            chunk += nworkers;
+            step(chunk, k >= 2, chunk + nworkers < n_chunks, raw_b, raw_c, pend_b, pend_c);
+            k++; phase = 2; chunk += nworkers;
+            if (chunk >= n_chunks) break;
+            step(chunk, k >= 2, chunk + nworkers < n_chunks, raw_c, raw_a, pend_c, pend_a);
+            k++; phase = 0; chunk += nworkers;
             if (chunk >= n_chunks) break;
         }
-        if (last_par == 0) finish(chunk - nworkers, pend_a, SPAN);
-        else finish(chunk - nworkers, pend_b, SPAN);
+        // drain: the last two issued sets, oldest first.  `chunk` is one stride past the last chunk.
+        const uint64_t c1 = chunk - nworkers, c2 = chunk - 2 * (uint64_t)nworkers;
+        if (phase == 1) { if (k >= 2) finish(c2, pend_c, SPAN); finish(c1, pend_a, SPAN); }
+        else if (phase == 2) { if (k >= 2) finish(c2, pend_a, SPAN); finish(c1, pend_b, SPAN); }
+        else { if (k >= 2) finish(c2, pend_b, SPAN); finish(c1, pend_c, SPAN); }
     }
 
     // the job's last, partial chunk: one worker, no pipelining
@@ -370,6 +374,10 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
     size_t n_cached = (lds_max - ((fixed + 15) & ~(size_t)15)) / 16;
     if (is_static) n_cached = (lds_max - static_lds) / 16;
     if (n_cached > n_leaf) n_cached = n_leaf;
+    if (const char *e = getenv("GMG_NCACHED")) {       // profiling aid: shrink the LDS leaf cache
+        size_t v = (size_t)atol(e);
+        if (v < n_cached) n_cached = v;
+    }
     a.n_cached = (int)n_cached;
     a.leaf_off = is_static ? 0 : (int)((fixed + 15) & ~(size_t)15);
     const size_t lds = (size_t)a.leaf_off + n_cached * 16;      // dynamic part
