@@ -194,7 +194,7 @@ extern "C" int gmg_model_upload(const int16_t *mip, const float *prob4, int W, i
     size_t o_prob = align_up(o_mip + PN, 256);
     size_t o_cshift = align_up(o_prob + PN * 16, 256);
     size_t o_crow = align_up(o_cshift + (fast ? P * cstride : 0), 256);
-    size_t o_dense = align_up(o_crow + (fast ? (size_t)P * ctot * 16 : 0), 256);
+    size_t o_dense = align_up(o_crow + (fast ? (size_t)P * ctot * 16 + 16 : 0), 256);   // + one all-zero row
     size_t o_part = align_up(o_dense + (size_t)P * n_dense * 4, 256);
     size_t total = align_up(o_part + (size_t)P * n_part * 4 + 4, 256);
 

@@ -10,6 +10,10 @@ out = sys.argv[1]
 kern = "k_frame6s"
 for path in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     for row in csv.DictReader(open(path)):
+        if "k_frame6" in row["Name"] and kern not in row["Name"]:
+            print("other kernel: %s calls=%s avg_ns=%s" % (row["Name"][:40], row["Calls"], row["AverageNs"]))
+for path in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for row in csv.DictReader(open(path)):
         if kern in row["Name"]:
             print("kernel_stats: calls=%s avg_ns=%s min_ns=%s max_ns=%s" % (row["Calls"], row["AverageNs"], row["MinNs"], row["MaxNs"]))
 for path in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
