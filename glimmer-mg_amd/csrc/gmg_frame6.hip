@@ -245,6 +245,183 @@ __global__ __launch_bounds__(BLOCK) void k_frame6s(Frame6Args a)
 }
 
 // ---------------------------------------------------------------------------
+// k_frame6t: the main pass with LDS table swapping (no gather from L2 at all).
+//
+// profiles/r01_v6_*: with ~41 % of the leaf lookups served by a 4-byte gather from L2, the per-CU
+// vector-memory pipe (address coalescer: one divergent lane per cycle) and the L2 channels
+// (1.3e9 requests per launch) are what the kernel waits for, and on gfx9 every load also waits for
+// all older stores (one in-order vmcnt).  So this variant keeps ALL table accesses in LDS by
+// holding one HALF of the sub-model's leaf rows at a time (8,192 rows x 16 B = 128 KiB):
+//
+//   round = K chunks of this work-group (K x 2,048 bases):
+//     phase 1  (half h resident)   per chunk: contexts, four descents; a leaf value whose row is in
+//                                  half h is read now, the others keep their row offset; 5 registers
+//                                  per chunk and lane survive the phase (4 values/offsets + flags
+//                                  and null-table indices).
+//     swap     barrier; the other half is streamed L2 -> LDS (coalesced 16-byte loads, 8 per lane);
+//              the packed words of the NEXT round are staged into LDS by the same loads' shadow;
+//              barrier.
+//     phase 2  (other half resident) per chunk: the missing values are read, everything is widened,
+//                                  the null value subtracted, and the chunk is stored (full lines).
+//   The next round starts with the half that is resident now, so there is ONE swap per round.
+//
+// Vector memory sees only coalesced traffic: the half reloads, the staged packed words and the
+// output stores; phase 1 of the next round (pure LDS + VALU) overlaps the draining stores.
+// ---------------------------------------------------------------------------
+template <int BLOCK, int DT, int K, int DIAG, bool PAIR>
+__global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
+{
+    constexpr int CS = f6_cstride(DT);
+    constexpr uint32_t SPAN = 2 * BLOCK;                            // bases per chunk
+    constexpr uint32_t RAWW = SPAN / 16 + 4;                        // packed words staged per chunk (1 before, 3 after)
+    constexpr uint32_t HALF_ROWS = (1u << (2 * DT)) / 2;
+    __shared__ __attribute__((aligned(16))) uint8_t s_shr[CS];     // complemented buffer (rows 3+f): 2*mip
+    __shared__ __attribute__((aligned(16))) uint8_t s_shf[CS];     // reversed buffer (rows f): 2*(W-1-mip)
+    __shared__ __attribute__((aligned(16))) double s_nr[64];        // null model, complemented buffer
+    __shared__ __attribute__((aligned(16))) double s_nf[64];        // null model, reversed buffer
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[K * RAWW];   // packed words of the current round
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_half[];   // [HALF_ROWS][4] floats
+
+    const int ftype = blockIdx.x % 3;
+    const uint32_t worker = blockIdx.x / 3, nworkers = gridDim.x / 3;
+    const int W = a.gene.W;
+    const uint8_t *leaf_rows = (const uint8_t *)(a.gene.crow + ((size_t)ftype * a.gene.ctot + f6_level_base(DT)) * 4);
+
+    const uint64_t n_chunks = a.total / SPAN;                       // full chunks only
+    if (worker >= n_chunks) return;
+    const uint32_t n_mine = (uint32_t)((n_chunks - worker + nworkers - 1) / nworkers);   // chunks worker, worker+nworkers, ...
+
+    auto load_half = [&](uint32_t h) __attribute__((always_inline)) {
+        const float4 *src = (const float4 *)(leaf_rows + (size_t)h * HALF_ROWS * 16);
+        float4 t[HALF_ROWS / BLOCK];
+#pragma unroll
+        for (uint32_t i = 0; i < HALF_ROWS / BLOCK; i++) t[i] = src[i * BLOCK + threadIdx.x];
+#pragma unroll
+        for (uint32_t i = 0; i < HALF_ROWS / BLOCK; i++) ((float4 *)s_half)[i * BLOCK + threadIdx.x] = t[i];
+    };
+    auto load_raw_round = [&](uint32_t j0) __attribute__((always_inline)) {
+        // words [c*SPAN/16 - 1, c*SPAN/16 + RAWW - 1) of every chunk c of the round
+        for (uint32_t t = threadIdx.x; t < K * RAWW; t += BLOCK) {
+            const uint32_t k = t / RAWW, w = t - k * RAWW;
+            const uint32_t j = j0 + k < n_mine ? j0 + k : n_mine - 1;
+            const uint64_t c = worker + (uint64_t)j * nworkers;
+            s_raw[t] = a.packed[c * (SPAN / 16) - 1 + w];
+        }
+    };
+
+    // ---- fill LDS
+    {
+        const uint8_t *sh_src = a.gene.cshift + (size_t)ftype * a.gene.cstride;
+        for (int i = threadIdx.x; i < CS; i += BLOCK) {
+            const uint8_t sh = sh_src[i];
+            s_shr[i] = sh;
+            s_shf[i] = (uint8_t)(2 * (W - 1) - sh);
+        }
+        if (threadIdx.x < 64) {
+            const uint32_t i = threadIdx.x;
+            const uint32_t mirrored = ((i & 3u) << 4) | (i & 12u) | (i >> 4);
+            s_nr[i] = (double)a.nul.dense[(size_t)ftype * 64 + i];
+            s_nf[i] = (double)a.nul.dense[(size_t)ftype * 64 + mirrored];
+        }
+        load_half(0);
+        load_raw_round(0);
+    }
+    __syncthreads();
+    const uint32_t shift0_r = __builtin_amdgcn_readfirstlane((uint32_t)s_shr[0]);
+    const uint32_t shift0_f = __builtin_amdgcn_readfirstlane((uint32_t)s_shf[0]);
+
+    const uint32_t ctx_mask = (1u << (2 * W)) - 1u;                 // W <= 15
+    const uint32_t sh_f = 2u * (uint32_t)(W - 1);                   // bit offset of S[p] in the window word
+    const uint32_t lane_off = 2 * threadIdx.x;
+    const uint32_t first_rel = lane_off + 16u - (uint32_t)(W - 1);
+    const uint32_t wword = first_rel >> 4;
+    const uint32_t wsh = 2u * (first_rel & 15u);
+    double *const out_f = a.out + (uint64_t)ftype * a.total;
+    double *const out_r = a.out + (uint64_t)(3 + ftype) * a.total;
+
+    uint32_t cur = 0;                                               // half resident in LDS
+    for (uint32_t j0 = 0; j0 < n_mine; j0 += K) {
+        const uint32_t kk = n_mine - j0 < (uint32_t)K ? n_mine - j0 : (uint32_t)K;   // chunks in this round
+        uint32_t val[K][4];     // value bits (row in the resident half) or byte offset inside the other half
+        uint32_t meta[K];       // bits 0-3: value present; bits 4+6c .. 9+6c: null-table index of item c
+
+        // ---- phase 1
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if ((uint32_t)k < kk) {
+                const uint32_t *w = s_raw + k * RAWW + wword;
+                const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+                // window of this lane: field i (bits 2i, 2i+1) = base g0-(W-1)+i, 32 fields
+                const uint32_t xl = __builtin_amdgcn_alignbit(w1, w0, wsh);
+                const uint32_t xh = __builtin_amdgcn_alignbit(w2, w1, wsh);
+                uint32_t C[4];
+                C[1] = ~xl & ctx_mask;                                              // complemented buffer
+                C[3] = ~__builtin_amdgcn_alignbit(xh, xl, 2) & ctx_mask;
+                C[0] = __builtin_amdgcn_alignbit(xh, xl, sh_f) & ctx_mask;          // reversed buffer, natural order
+                C[2] = __builtin_amdgcn_alignbit(xh, xl, sh_f + 2) & ctx_mask;
+                uint32_t idx[4];
+                idx[0] = f6_descend<DT>(s_shf, C[0], shift0_f);
+                idx[1] = f6_descend<DT>(s_shr, C[1], shift0_r);
+                idx[2] = f6_descend<DT>(s_shf, C[2], shift0_f);
+                idx[3] = f6_descend<DT>(s_shr, C[3], shift0_r);
+                uint32_t mt = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const bool fwd = (c & 1) == 0;
+                    const uint32_t pred = fwd ? (C[c] & 3u) : (C[c] >> sh_f);
+                    const uint32_t tb = (((idx[c] & (HALF_ROWS - 1)) << 2) | pred) << 2;   // byte offset inside its half
+                    const bool here = (idx[c] >> (2 * DT - 1)) == cur;
+                    const uint32_t got = (DIAG & 2) ? tb : __float_as_uint(*(const float *)(s_half + (here ? tb : 0u)));
+                    val[k][c] = here ? got : tb;
+                    const uint32_t nidx = fwd ? (C[c] & 63u) : (C[c] >> (sh_f - 4));
+                    mt |= (here ? 1u : 0u) << c;
+                    mt |= nidx << (4 + 6 * c);
+                }
+                meta[k] = mt;
+            }
+        }
+
+        // ---- swap halves; stage the next round's packed words
+        __syncthreads();
+        cur ^= 1u;
+        load_half(cur);
+        if (j0 + K < n_mine) load_raw_round(j0 + K);
+        __syncthreads();
+
+        // ---- phase 2
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if ((uint32_t)k < kk) {
+                const uint32_t mt = meta[k];
+                double v[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const bool have = (mt >> c) & 1u;
+                    const uint32_t got = (DIAG & 2) ? val[k][c] : __float_as_uint(*(const float *)(s_half + (have ? 0u : val[k][c])));
+                    const float gv = __uint_as_float(have ? val[k][c] : got);
+                    const uint32_t nidx = (mt >> (4 + 6 * c)) & 63u;
+                    const double nv = (c & 1) == 0 ? s_nf[nidx] : s_nr[nidx];
+                    v[c] = (double)gv - nv;                         // glimmer-mg.cc:1493,1508
+                }
+                const uint64_t chunk = worker + (uint64_t)(j0 + k) * nworkers;
+                if (DIAG & 1) {
+                    if (v[0] + v[1] + v[2] + v[3] == 1.2345e300) a.out[lane_off] = v[0];
+                } else {
+                    double *pf = out_f + chunk * SPAN, *pr = out_r + chunk * SPAN;   // wave-uniform bases + lane offset
+                    if (PAIR) {
+                        *(double2 *)(pf + lane_off) = make_double2(v[0], v[2]);
+                        *(double2 *)(pr + lane_off) = make_double2(v[1], v[3]);
+                    } else {
+                        pf[lane_off] = v[0]; pf[lane_off + 1] = v[2];
+                        pr[lane_off] = v[1]; pr[lane_off + 1] = v[3];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_frame6p: partial windows.  One lane per (read, z): z < W-1 is buffer position j = z of the
 // complemented buffer (rows 3+f, base p = j); z >= W-1 is position j = z-(W-1) of the reversed
 // buffer (rows f, base p = L-1-j).  Uses the partial-window rule of icm.cc:807-842: stop as soon as
@@ -386,19 +563,12 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
 
     constexpr int BLOCK = 1024, DT = 7;
     constexpr uint32_t SPAN = 2 * BLOCK;
-    const size_t lds_max = 160 * 1024;
-    const size_t static_lds = 2 * (size_t)f6_cstride(DT) + 2 * 64 * sizeof(double);
-    size_t n_cached = (lds_max - static_lds) / 16 - 1;   // one more row holds zeros
-    const size_t n_leaf = (size_t)1 << (2 * DT);
-    if (n_cached > n_leaf) n_cached = n_leaf;
-    if (const char *e = getenv("GMG_NCACHED")) {       // profiling aid: shrink the LDS leaf cache
-        size_t v = (size_t)atol(e);
-        if (v >= 1 && v < n_cached) n_cached = v;
-    }
-    a.n_cached = (int)n_cached;
-    const size_t lds = (n_cached + 1) * 16;            // dynamic part: cached rows + the zero row
-
     const uint64_t n_chunks = a.total / SPAN;
+    const char *env = getenv("GMG_DIAG");
+    const int diag = env ? atoi(env) : 0;
+    const bool pair = (a.total & 1) == 0;
+    const char *var = getenv("GMG_F6");                // profiling aid: "gather" selects k_frame6s
+    const bool use_swap = !(var && var[0] == 'g');
     if (n_chunks > 0) {
         int dev = 0, n_cu = 256;
         GMG_HIP(hipGetDevice(&dev));
@@ -408,21 +578,46 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
         if (nworkers < 1) nworkers = 1;
         if (nworkers > n_chunks) nworkers = (unsigned)n_chunks;
         const unsigned grid = 3 * nworkers;
-        const char *env = getenv("GMG_DIAG");
-        const int diag = env ? atoi(env) : 0;
-        const bool pair = (a.total & 1) == 0;
+        if (use_swap) {
+            constexpr int KR = 12;
+            const size_t lds = ((size_t)1 << (2 * DT)) / 2 * 16;       // dynamic part: half of the leaf rows
+#define GMG_LAUNCH_F6T(DIAG_, P_)                                                                       \
+    do {                                                                                                \
+        GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, DIAG_, P_>,                  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
+        hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, DIAG_, P_>), dim3(grid), dim3(BLOCK), lds, s, a);  \
+    } while (0)
+            if (diag == 0) { if (pair) GMG_LAUNCH_F6T(0, true); else GMG_LAUNCH_F6T(0, false); }
+            else if (diag == 1 && pair) GMG_LAUNCH_F6T(1, true);
+            else if (diag == 2 && pair) GMG_LAUNCH_F6T(2, true);
+            else if (diag == 3 && pair) GMG_LAUNCH_F6T(3, true);
+            else return gmg_set_error(GMG_EINVAL, "GMG_DIAG=%d is not a built ablation", diag);
+#undef GMG_LAUNCH_F6T
+        } else {
+            const size_t lds_max = 160 * 1024;
+            const size_t static_lds = 2 * (size_t)f6_cstride(DT) + 2 * 64 * sizeof(double);
+            size_t n_cached = (lds_max - static_lds) / 16 - 1;   // one more row holds zeros
+            const size_t n_leaf = (size_t)1 << (2 * DT);
+            if (n_cached > n_leaf) n_cached = n_leaf;
+            if (const char *e = getenv("GMG_NCACHED")) {       // profiling aid: shrink the LDS leaf cache
+                size_t v = (size_t)atol(e);
+                if (v >= 1 && v < n_cached) n_cached = v;
+            }
+            a.n_cached = (int)n_cached;
+            const size_t lds = (n_cached + 1) * 16;            // dynamic part: cached rows + the zero row
 #define GMG_LAUNCH_F6(DIAG_, P_)                                                                        \
     do {                                                                                                \
         GMG_HIP(hipFuncSetAttribute((const void *)k_frame6s<BLOCK, DT, DIAG_, P_>,                      \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
         hipLaunchKernelGGL((k_frame6s<BLOCK, DT, DIAG_, P_>), dim3(grid), dim3(BLOCK), lds, s, a);      \
     } while (0)
-        if (diag == 0) { if (pair) GMG_LAUNCH_F6(0, true); else GMG_LAUNCH_F6(0, false); }
-        else if (diag == 1 && pair) GMG_LAUNCH_F6(1, true);
-        else if (diag == 2 && pair) GMG_LAUNCH_F6(2, true);
-        else if (diag == 3 && pair) GMG_LAUNCH_F6(3, true);
-        else return gmg_set_error(GMG_EINVAL, "GMG_DIAG=%d is not a built ablation", diag);
+            if (diag == 0) { if (pair) GMG_LAUNCH_F6(0, true); else GMG_LAUNCH_F6(0, false); }
+            else if (diag == 1 && pair) GMG_LAUNCH_F6(1, true);
+            else if (diag == 2 && pair) GMG_LAUNCH_F6(2, true);
+            else if (diag == 3 && pair) GMG_LAUNCH_F6(3, true);
+            else return gmg_set_error(GMG_EINVAL, "GMG_DIAG=%d is not a built ablation", diag);
 #undef GMG_LAUNCH_F6
+        }
         GMG_HIP(hipGetLastError());
     }
     // the last, partial chunk
