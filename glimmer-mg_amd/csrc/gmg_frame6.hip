@@ -447,6 +447,9 @@ __device__ __forceinline__ uint32_t dev_reverse_fields(uint32_t y, int nfields)
     return ((z & 0x55555555u) << 1) | ((z >> 1) & 0x55555555u);
 }
 
+// 32 lanes per read (z = lane & 31 < 2(W-1) <= 28 active): no division, read offsets broadcast.
+// DT > 0: depth known at compile time (unrolled; the three sub-models' descents interleave).
+template <int DT>
 __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_shift[];   // [3][cstride] completed-tree shifts
@@ -455,22 +458,21 @@ __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
         *(uint4 *)(s_shift + i) = *(const uint4 *)(a.gene.cshift + i);
     __syncthreads();
 
-    const int W = a.gene.W, D = a.gene.D, Wn = a.nul.W;
+    const int W = a.gene.W, D = DT > 0 ? DT : a.gene.D, Wn = a.nul.W;
     const uint32_t Z = 2u * (uint32_t)(W - 1);
     const uint32_t ctx_mask = (W >= 16) ? 0xffffffffu : ((1u << (2 * W)) - 1u);
     const int n_dense = 1 << (2 * Wn);
     const int n_part = a.nul.n_dense_part;
-    const uint64_t n_items = a.n_reads * Z;
+    const uint32_t z = threadIdx.x & 31u;
+    const bool rev_buf = z >= (uint32_t)(W - 1);                    // reversed buffer -> rows f
+    const int j = rev_buf ? (int)z - (W - 1) : (int)z;              // position in the scoring buffer
+    const int thr2 = 2 * ((W - 1) - j);                             // > 0: j < W-1
+    const uint64_t reads_per_pass = (uint64_t)gridDim.x * (256 / 32);
 
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_items;
-         e += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = e / Z;
-        const uint32_t z = (uint32_t)(e - r * Z);
+    for (uint64_t r = (uint64_t)blockIdx.x * (256 / 32) + (threadIdx.x >> 5); r < a.n_reads; r += reads_per_pass) {
         const uint64_t r_off = a.off[r];
         const int L = (int)(a.off[r + 1] - r_off);
-        const bool rev_buf = z >= (uint32_t)(W - 1);                // reversed buffer -> rows f
-        const int j = rev_buf ? (int)z - (W - 1) : (int)z;
-        if (j >= L) continue;                                       // reads shorter than W-1
+        if (z >= Z || j >= L) continue;                             // idle lanes; reads shorter than W-1
         const int p = rev_buf ? L - 1 - j : j;
         const uint64_t g = r_off + (uint64_t)p;
 
@@ -478,24 +480,32 @@ __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
         // window char k at bits 2k; chars that fall before the buffer are never looked at
         const uint32_t C = rev_buf ? dev_reverse_fields((uint32_t)(x >> (2 * (W - 1))) & ctx_mask, W)
                                    : (((uint32_t)x & ctx_mask) ^ ctx_mask);
-        const int thr2 = 2 * ((W - 1) - j);                         // > 0: j < W-1
         const uint32_t pred = (C >> (2 * (W - 1))) & 3u;
 
-        for (int f = 0; f < 3; f++) {
-            const uint8_t *tab = s_shift + f * cstride;
-            uint32_t idx = 0, lvl = 0, width = 1, node = 0xffffffffu;
-            for (int l = 0; l < D; l++) {
-                const uint32_t sh = tab[lvl + idx];
-                if (node == 0xffffffffu && (int)sh < thr2) node = lvl + idx;
-                idx = (idx << 2) + ((C >> sh) & 3u);
-                lvl += width;
-                width <<= 2;
+        uint32_t idx[3] = {0, 0, 0}, node[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+        uint32_t lvl = 0, width = 1;
+#pragma unroll
+        for (int l = 0; l < (DT > 0 ? DT : 12); l++) {
+            if (DT == 0 && l >= D) break;
+#pragma unroll
+            for (int f = 0; f < 3; f++) {
+                const uint32_t sh = s_shift[f * cstride + lvl + idx[f]];
+                if (node[f] == 0xffffffffu && (int)sh < thr2) node[f] = lvl + idx[f];
+                idx[f] = (idx[f] << 2) + ((C >> sh) & 3u);
             }
-            if (node == 0xffffffffu) node = lvl + idx;
-            const float gv = a.gene.crow[((size_t)f * a.gene.ctot + node) * 4 + pred];
-            float nv;
-            if (j >= Wn - 1) nv = a.nul.dense[(size_t)f * n_dense + (C >> (2 * (W - Wn)))];
-            else nv = a.nul.dense_part[(size_t)f * n_part + (C >> (2 * (W - 1 - j))) + (((1u << (2 * (j + 1))) - 4u) / 3u)];
+            lvl += width;
+            width <<= 2;
+        }
+        uint32_t nslot;
+        const float *ntab;
+        int nstride;
+        if (j >= Wn - 1) { ntab = a.nul.dense; nstride = n_dense; nslot = C >> (2 * (W - Wn)); }
+        else { ntab = a.nul.dense_part; nstride = n_part; nslot = (C >> (2 * (W - 1 - j))) + (((1u << (2 * (j + 1))) - 4u) / 3u); }
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            if (node[f] == 0xffffffffu) node[f] = lvl + idx[f];
+            const float gv = a.gene.crow[((size_t)f * a.gene.ctot + node[f]) * 4 + pred];
+            const float nv = ntab[(size_t)f * nstride + nslot];
             a.out[(uint64_t)((rev_buf ? 0 : 3) + f) * a.total + g] = (double)gv - (double)nv;
         }
     }
@@ -581,18 +591,25 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
         if (use_swap) {
             constexpr int KR = 12;
             const size_t lds = ((size_t)1 << (2 * DT)) / 2 * 16;       // dynamic part: half of the leaf rows
-#define GMG_LAUNCH_F6T(DIAG_, P_)                                                                       \
+#define GMG_LAUNCH_F6TK(KR_, DIAG_, P_)                                                                 \
     do {                                                                                                \
-        GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, DIAG_, P_>,                  \
+        GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR_, DIAG_, P_>,                 \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, DIAG_, P_>), dim3(grid), dim3(BLOCK), lds, s, a);  \
+        hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR_, DIAG_, P_>), dim3(grid), dim3(BLOCK), lds, s, a); \
     } while (0)
-            if (diag == 0) { if (pair) GMG_LAUNCH_F6T(0, true); else GMG_LAUNCH_F6T(0, false); }
+#define GMG_LAUNCH_F6T(DIAG_, P_) GMG_LAUNCH_F6TK(KR, DIAG_, P_)
+            const char *ke = getenv("GMG_K");               // profiling aid: chunks per round
+            const int kr = ke ? atoi(ke) : KR;
+            if (diag == 0 && pair && kr == 8) GMG_LAUNCH_F6TK(8, 0, true);
+            else if (diag == 0 && pair && kr == 16) GMG_LAUNCH_F6TK(16, 0, true);
+            else if (diag == 0 && pair && kr == 20) GMG_LAUNCH_F6TK(20, 0, true);
+            else if (diag == 0) { if (pair) GMG_LAUNCH_F6T(0, true); else GMG_LAUNCH_F6T(0, false); }
             else if (diag == 1 && pair) GMG_LAUNCH_F6T(1, true);
             else if (diag == 2 && pair) GMG_LAUNCH_F6T(2, true);
             else if (diag == 3 && pair) GMG_LAUNCH_F6T(3, true);
             else return gmg_set_error(GMG_EINVAL, "GMG_DIAG=%d is not a built ablation", diag);
 #undef GMG_LAUNCH_F6T
+#undef GMG_LAUNCH_F6TK
         } else {
             const size_t lds_max = 160 * 1024;
             const size_t static_lds = 2 * (size_t)f6_cstride(DT) + 2 * 64 * sizeof(double);
@@ -625,11 +642,10 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
     if (rc) return rc;
     // partial windows of every read
     if (a.n_reads > 0) {
-        const uint64_t items = a.n_reads * 2 * (uint64_t)(a.gene.W - 1);
-        const uint64_t blocks = (items + 255) / 256;
+        const uint64_t blocks = (a.n_reads + 7) / 8;                // 8 reads (32 lanes each) per block
         const unsigned grid = (unsigned)(blocks < 256 * 8 ? blocks : 256 * 8);
         const size_t lds_p = (size_t)3 * a.gene.cstride;
-        hipLaunchKernelGGL(k_frame6p, dim3(grid), dim3(256), lds_p, s, a);
+        hipLaunchKernelGGL(k_frame6p<7>, dim3(grid), dim3(256), lds_p, s, a);
         GMG_HIP(hipGetLastError());
     }
     return GMG_OK;

@@ -21,7 +21,8 @@
 
 struct gmg_model;   // include/gmg.h
 
-// ---- constants of src/ICM/icm.hh:26-80 that callers use ---------------------
+// ---- constants of src/ICM/icm.hh:21-80 (callers and the training code use them) ----
+#define  STORE_MUT_INFO  1
 const int  ALPHABET_SIZE = 4;
 const int  ALPHA_SQUARED = (ALPHABET_SIZE * ALPHABET_SIZE);
 const char  ALPHA_STRING [] = "acgt";
@@ -33,6 +34,15 @@ const int  DEFAULT_PERIODICITY = 3;
 const char  MAX_MI_CHAR = '*';
 const char  SEPARATOR_CHAR = '|';
 const int  ICM_VERSION_ID = 200;
+//  used by the training side and by glimmer3's Integerize_Scores (glimmer3.cc:627)
+const int  NUM_CHI2_ENTRIES = 7;
+const float  CHI2_VAL [NUM_CHI2_ENTRIES] = {2.37, 4.11, 6.25, 7.81, 9.35, 11.3, 12.8};
+const float  CHI2_SIGNIFICANCE [NUM_CHI2_ENTRIES] = {0.50, 0.75, 0.90, 0.95, 0.975, 0.99, 0.995};
+const double  MUT_INFO_BIAS = 0.03;
+const double  MAX_LOG_DIFF = -46.0;
+const double  MUT_INFO_EPSILON = 1e-4;
+const double  PSEUDO_COUNT = 0.001;
+const int  SAMPLE_SIZE_BOUND = 400;
 
 #define  PARENT(x) ((int) ((x) - 1) / ALPHABET_SIZE)
 

@@ -1,0 +1,35 @@
+"""Drop-in check on the GPU: the reference's own glimmer3 / glimmer-mg sources, compiled unchanged
+against OUR ICM_t (glimmer-mg_amd/host/icm.hh) and linked with libgmg.so (oracle/Makefile target
+`dropin`, built in the build container; the binaries travel in oracle/_ref/), must write .predict files
+byte-identical to the goldens written by the all-reference build.  Every score in these runs comes from
+the HIP layer (one launch per ICM_t call)."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import DATA, GOLD, ROOT
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("glimmer3_dropin", [], "glimmer3.default.predict"),
+    ("glimmer3_dropin", ["-X"], "glimmer3.X.predict"),
+    ("glimmer-mg_dropin", [], "glimmer-mg.default.predict"),
+]
+
+
+@pytest.mark.parametrize("binary,flags,golden", CASES)
+def test_reference_cli_on_our_icm_is_byte_identical(gpu, tmp_path, binary, flags, golden):
+    exe = os.path.join(ROOT, "oracle", "_ref", binary)
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/%s not built (needs /root/reference in the build container)" % binary)
+    tag = str(tmp_path / "out")
+    cmd = [exe, *flags, "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, "seqs.fa"), tag]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    got = open(tag + ".predict", "rb").read()
+    want = open(os.path.join(GOLD, "predict", golden), "rb").read()
+    assert got == want
+    maps_ok = b"libgmg.so" in subprocess.run(["ldd", exe], stdout=subprocess.PIPE).stdout
+    assert maps_ok
