@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-kern = "k_frame6s"
+kern = sys.argv[2] if len(sys.argv) > 2 else "k_frame6t"
 for path in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     for row in csv.DictReader(open(path)):
         if "k_frame6" in row["Name"] and kern not in row["Name"]:
