@@ -253,7 +253,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame6s(Frame6Args a)
 // all older stores (one in-order vmcnt).  So this variant keeps ALL table accesses in LDS by
 // holding one HALF of the sub-model's leaf rows at a time (8,192 rows x 16 B = 128 KiB):
 //
-//   round = K chunks of this work-group (K x 2,048 bases):
+//   round = K chunks of this work-group (K x 2,048 bases; K = 16):
 //     phase 1  (half h resident)   per chunk: contexts, four descents; a leaf value whose row is in
 //                                  half h is read now, the others keep their row offset; 5 registers
 //                                  per chunk and lane survive the phase (4 values/offsets + flags
@@ -320,7 +320,9 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
         if (threadIdx.x < 64) {
             const uint32_t i = threadIdx.x;
             const uint32_t mirrored = ((i & 3u) << 4) | (i & 12u) | (i >> 4);
-            s_nr[i] = (double)a.nul.dense[(size_t)ftype * 64 + i];
+            // both tables are indexed with plain (uncomplemented) read bases: s_nr[i] is the entry of the
+            // complemented window i ^ 63, s_nf[i] the entry of the mirrored window
+            s_nr[i] = (double)a.nul.dense[(size_t)ftype * 64 + (i ^ 63u)];
             s_nf[i] = (double)a.nul.dense[(size_t)ftype * 64 + mirrored];
         }
         load_half(0);
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     for (uint32_t j0 = 0; j0 < n_mine; j0 += K) {
         const uint32_t kk = n_mine - j0 < (uint32_t)K ? n_mine - j0 : (uint32_t)K;   // chunks in this round
         uint32_t val[K][4];     // value bits (row in the resident half) or byte offset inside the other half
-        uint32_t meta[K];       // bits 0-3: value present; bits 4+6c .. 9+6c: null-table index of item c
+        uint32_t meta[K];       // bits 0-3: value present; bits 4-15: read bases S[g0-2 .. g0+3] (null-model windows)
 
         // ---- phase 1
 #pragma unroll
@@ -373,11 +375,10 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
                     const bool here = (idx[c] >> (2 * DT - 1)) == cur;
                     const uint32_t got = (DIAG & 2) ? tb : __float_as_uint(*(const float *)(s_half + (here ? tb : 0u)));
                     val[k][c] = here ? got : tb;
-                    const uint32_t nidx = fwd ? (C[c] & 63u) : (C[c] >> (sh_f - 4));
                     mt |= (here ? 1u : 0u) << c;
-                    mt |= nidx << (4 + 6 * c);
                 }
-                meta[k] = mt;
+                // the four null-model windows are slices of the six bases S[g0-2 .. g0+3] = fields W-3 .. W+2
+                meta[k] = mt | ((__builtin_amdgcn_alignbit(xh, xl, sh_f - 4) & 0xfffu) << 4);
             }
         }
 
@@ -399,7 +400,8 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
                     const bool have = (mt >> c) & 1u;
                     const uint32_t got = (DIAG & 2) ? val[k][c] : __float_as_uint(*(const float *)(s_half + (have ? 0u : val[k][c])));
                     const float gv = __uint_as_float(have ? val[k][c] : got);
-                    const uint32_t nidx = (mt >> (4 + 6 * c)) & 63u;
+                    // item 0: S[g0..g0+2] reversed buffer; 1: S[g0-2..g0] complemented; 2, 3: one base further
+                    const uint32_t nidx = __builtin_amdgcn_ubfe(mt, c == 0 ? 8 : c == 1 ? 4 : c == 2 ? 10 : 6, 6);
                     const double nv = (c & 1) == 0 ? s_nf[nidx] : s_nr[nidx];
                     v[c] = (double)gv - nv;                         // glimmer-mg.cc:1493,1508
                 }
@@ -448,8 +450,10 @@ __device__ __forceinline__ uint32_t dev_reverse_fields(uint32_t y, int nfields)
 }
 
 // 32 lanes per read (z = lane & 31 < 2(W-1) <= 28 active): no division, read offsets broadcast.
-// DT > 0: depth known at compile time (unrolled; the three sub-models' descents interleave).
-template <int DT>
+// The kernel is a chain of dependent latencies (offsets -> packed words -> D LDS steps -> row gather ->
+// store), so every lane keeps U reads in flight (U x 3 interleaved descents).
+// DT > 0: depth known at compile time.
+template <int DT, int U>
 __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_shift[];   // [3][cstride] completed-tree shifts
@@ -469,45 +473,71 @@ __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
     const int thr2 = 2 * ((W - 1) - j);                             // > 0: j < W-1
     const uint64_t reads_per_pass = (uint64_t)gridDim.x * (256 / 32);
 
-    for (uint64_t r = (uint64_t)blockIdx.x * (256 / 32) + (threadIdx.x >> 5); r < a.n_reads; r += reads_per_pass) {
-        const uint64_t r_off = a.off[r];
-        const int L = (int)(a.off[r + 1] - r_off);
-        if (z >= Z || j >= L) continue;                             // idle lanes; reads shorter than W-1
-        const int p = rev_buf ? L - 1 - j : j;
-        const uint64_t g = r_off + (uint64_t)p;
+    // null-model slot of this lane's buffer position (same for every read)
+    const float *ntab = (j >= Wn - 1) ? a.nul.dense : a.nul.dense_part;
+    const int nstride = (j >= Wn - 1) ? n_dense : n_part;
 
-        const uint64_t x = dev_window_bits(a.packed, (int64_t)g - (W - 1));
-        // window char k at bits 2k; chars that fall before the buffer are never looked at
-        const uint32_t C = rev_buf ? dev_reverse_fields((uint32_t)(x >> (2 * (W - 1))) & ctx_mask, W)
-                                   : (((uint32_t)x & ctx_mask) ^ ctx_mask);
-        const uint32_t pred = (C >> (2 * (W - 1))) & 3u;
-
-        uint32_t idx[3] = {0, 0, 0}, node[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+    for (uint64_t r0 = (uint64_t)blockIdx.x * (256 / 32) + (threadIdx.x >> 5); r0 < a.n_reads; r0 += U * reads_per_pass) {
+        bool live[U];
+        uint64_t g[U];
+        uint32_t C[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t r = r0 + u * reads_per_pass;
+            const bool in = r < a.n_reads;
+            const uint64_t rq = in ? r : a.n_reads - 1;
+            const uint64_t r_off = a.off[rq];
+            const int L = (int)(a.off[rq + 1] - r_off);
+            live[u] = in && z < Z && j < L;                         // idle lanes; reads shorter than W-1
+            const int p = rev_buf ? L - 1 - j : j;
+            g[u] = r_off + (uint64_t)(live[u] ? p : 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t x = dev_window_bits(a.packed, (int64_t)g[u] - (W - 1));
+            // window char k at bits 2k; chars that fall before the buffer are never looked at
+            C[u] = rev_buf ? dev_reverse_fields((uint32_t)(x >> (2 * (W - 1))) & ctx_mask, W)
+                           : (((uint32_t)x & ctx_mask) ^ ctx_mask);
+        }
+        uint32_t idx[U][3], node[U][3];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int f = 0; f < 3; f++) { idx[u][f] = 0; node[u][f] = 0xffffffffu; }
         uint32_t lvl = 0, width = 1;
 #pragma unroll
         for (int l = 0; l < (DT > 0 ? DT : 12); l++) {
             if (DT == 0 && l >= D) break;
 #pragma unroll
-            for (int f = 0; f < 3; f++) {
-                const uint32_t sh = s_shift[f * cstride + lvl + idx[f]];
-                if (node[f] == 0xffffffffu && (int)sh < thr2) node[f] = lvl + idx[f];
-                idx[f] = (idx[f] << 2) + ((C >> sh) & 3u);
-            }
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int f = 0; f < 3; f++) {
+                    const uint32_t sh = s_shift[f * cstride + lvl + idx[u][f]];
+                    if (node[u][f] == 0xffffffffu && (int)sh < thr2) node[u][f] = lvl + idx[u][f];
+                    idx[u][f] = (idx[u][f] << 2) + ((C[u] >> sh) & 3u);
+                }
             lvl += width;
             width <<= 2;
         }
-        uint32_t nslot;
-        const float *ntab;
-        int nstride;
-        if (j >= Wn - 1) { ntab = a.nul.dense; nstride = n_dense; nslot = C >> (2 * (W - Wn)); }
-        else { ntab = a.nul.dense_part; nstride = n_part; nslot = (C >> (2 * (W - 1 - j))) + (((1u << (2 * (j + 1))) - 4u) / 3u); }
+        float gv[U][3], nv[U][3];
 #pragma unroll
-        for (int f = 0; f < 3; f++) {
-            if (node[f] == 0xffffffffu) node[f] = lvl + idx[f];
-            const float gv = a.gene.crow[((size_t)f * a.gene.ctot + node[f]) * 4 + pred];
-            const float nv = ntab[(size_t)f * nstride + nslot];
-            a.out[(uint64_t)((rev_buf ? 0 : 3) + f) * a.total + g] = (double)gv - (double)nv;
+        for (int u = 0; u < U; u++) {
+            const uint32_t pred = (C[u] >> (2 * (W - 1))) & 3u;
+            const uint32_t nslot = (j >= Wn - 1) ? (C[u] >> (2 * (W - Wn)))
+                                                 : (C[u] >> (2 * (W - 1 - j))) + (((1u << (2 * (j + 1))) - 4u) / 3u);
+#pragma unroll
+            for (int f = 0; f < 3; f++) {
+                if (node[u][f] == 0xffffffffu) node[u][f] = lvl + idx[u][f];
+                gv[u][f] = a.gene.crow[((size_t)f * a.gene.ctot + node[u][f]) * 4 + pred];
+                nv[u][f] = ntab[(size_t)f * nstride + nslot];
+            }
         }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (live[u])
+#pragma unroll
+                for (int f = 0; f < 3; f++)
+                    a.out[(uint64_t)((rev_buf ? 0 : 3) + f) * a.total + g[u]] = (double)gv[u][f] - (double)nv[u][f];
     }
 }
 
@@ -589,7 +619,7 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
         if (nworkers > n_chunks) nworkers = (unsigned)n_chunks;
         const unsigned grid = 3 * nworkers;
         if (use_swap) {
-            constexpr int KR = 12;
+            constexpr int KR = 16;
             const size_t lds = ((size_t)1 << (2 * DT)) / 2 * 16;       // dynamic part: half of the leaf rows
 #define GMG_LAUNCH_F6TK(KR_, DIAG_, P_)                                                                 \
     do {                                                                                                \
@@ -601,7 +631,7 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
             const char *ke = getenv("GMG_K");               // profiling aid: chunks per round
             const int kr = ke ? atoi(ke) : KR;
             if (diag == 0 && pair && kr == 8) GMG_LAUNCH_F6TK(8, 0, true);
-            else if (diag == 0 && pair && kr == 16) GMG_LAUNCH_F6TK(16, 0, true);
+            else if (diag == 0 && pair && kr == 12) GMG_LAUNCH_F6TK(12, 0, true);
             else if (diag == 0 && pair && kr == 20) GMG_LAUNCH_F6TK(20, 0, true);
             else if (diag == 0) { if (pair) GMG_LAUNCH_F6T(0, true); else GMG_LAUNCH_F6T(0, false); }
             else if (diag == 1 && pair) GMG_LAUNCH_F6T(1, true);
@@ -645,7 +675,7 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
         const uint64_t blocks = (a.n_reads + 7) / 8;                // 8 reads (32 lanes each) per block
         const unsigned grid = (unsigned)(blocks < 256 * 8 ? blocks : 256 * 8);
         const size_t lds_p = (size_t)3 * a.gene.cstride;
-        hipLaunchKernelGGL(k_frame6p<7>, dim3(grid), dim3(256), lds_p, s, a);
+        hipLaunchKernelGGL((k_frame6p<7, 4>), dim3(grid), dim3(256), lds_p, s, a);
         GMG_HIP(hipGetLastError());
     }
     return GMG_OK;
