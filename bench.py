@@ -119,8 +119,8 @@ def cpu_baseline(n_reads, L, seed, gc, packed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
     ap.add_argument("--length", type=int, default=500)
     ap.add_argument("--cpu-reads", type=int, default=20_000, help="reads in the CPU-baseline sample (0 = skip)")
