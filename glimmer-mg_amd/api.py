@@ -277,6 +277,41 @@ def all_frame_score(gene, reads, segs, prefix_len, frames):
     return out
 
 
+ORF_DTYPE = np.dtype([("read", "<u4"), ("frame", "<i4"), ("stop_position", "<i4"), ("orf_len", "<i4")])
+START_DTYPE = np.dtype([("score", "<f8"), ("j", "<i4"), ("pos", "<i4"), ("which", "<i4"), ("truncated", "<i2"),
+                        ("first", "<i2")])
+ORF_RESULT_DTYPE = np.dtype([("gene_score", "<f8"), ("best_score", "<f8"), ("start_begin", "<u4"), ("n_starts", "<u4"),
+                             ("first_j", "<i4"), ("best_j", "<i4"), ("best_pos", "<i4"), ("is_tentative_gene", "<i2"),
+                             ("orf_is_truncated", "<i2")])
+
+
+def score_orfs(gene, null, reads, orfs, min_gene_len=75, allow_truncated=False, use_first_start=False,
+               ignore_score_len=2**31 - 1, start_threshold=-6.0, start_codons=("atg", "gtg", "ttg")):
+    """The scoring part of Score_Orfs (glimmer3.cc:1275-1552) for a batch of ORFs.
+    orfs: rows (read, frame, stop_position, orf_len) as Find_Orfs produced them.
+    -> (results[ORF_RESULT_DTYPE], starts[START_DTYPE]); ORF i's starts are
+       starts[res.start_begin : res.start_begin + res.n_starts]."""
+    rows = np.asarray(orfs)
+    o = np.zeros(len(rows), ORF_DTYPE)
+    if len(rows):
+        o["read"], o["frame"], o["stop_position"], o["orf_len"] = rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3]
+    assert ORF_DTYPE.itemsize == 16 and START_DTYPE.itemsize == 24 and ORF_RESULT_DTYPE.itemsize == 40
+    prm = capi.OrfParams(min_gene_len, int(allow_truncated), int(use_first_start), ignore_score_len,
+                         start_threshold, len(start_codons))
+    for i, c in enumerate(start_codons):
+        prm.start_codon[i].value = c.encode()
+    batch, max_starts = C.c_void_p(), C.c_uint64()
+    _ck(capi.lib().gmg_orfs_upload(reads.h, _ptr(o), len(o), C.byref(max_starts), C.byref(batch)))
+    res = np.zeros(len(o), ORF_RESULT_DTYPE)
+    starts = np.zeros(max(int(max_starts.value), 1), START_DTYPE)
+    try:
+        _ck(capi.lib().gmg_score_orfs(gene.device(), null.device(), reads.h, batch, C.byref(prm), _ptr(res),
+                                      _ptr(starts), None))
+    finally:
+        capi.lib().gmg_orf_batch_free(batch)
+    return res, starts
+
+
 def window_distrib(model, windows, frames):
     """Full_Window_Distrib / Full_Window_Prob (icm.cc:512-610).  windows: uint8 codes [n, model_len]
     -> (dist float32 [n,4], prob float64 [n])"""

@@ -16,6 +16,12 @@ class Segment(C.Structure):
     _fields_ = [("read", C.c_uint32), ("lo", C.c_uint32), ("len", C.c_uint32), ("orient", C.c_uint32)]
 
 
+class OrfParams(C.Structure):
+    _fields_ = [("min_gene_len", C.c_int32), ("allow_truncated", C.c_int32), ("use_first_start", C.c_int32),
+                ("ignore_score_len", C.c_int32), ("start_threshold", C.c_double), ("n_start_codons", C.c_int32),
+                ("start_codon", (C.c_char * 4) * 8)]
+
+
 PROTOTYPES = {
     # include/gmg.h
     "gmg_init": (i32, [i32]),
@@ -42,6 +48,9 @@ PROTOTYPES = {
     "gmg_segment_partial_prob": (i32, [vp, vp, vp, i32, vp, vp]),
     "gmg_all_frame_score": (i32, [vp, vp, vp, vp, vp, vp, vp]),
     "gmg_window_distrib": (i32, [vp, vp, vp, u64, vp, vp, vp]),
+    "gmg_orfs_upload": (i32, [vp, vp, u64, C.POINTER(u64), C.POINTER(vp)]),
+    "gmg_orf_batch_free": (i32, [vp]),
+    "gmg_score_orfs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "gmg_device_malloc": (i32, [C.POINTER(vp), C.c_size_t]),
     "gmg_device_free": (i32, [vp]),
     "gmg_memcpy_h2d": (i32, [vp, vp, C.c_size_t, vp]),

@@ -1,0 +1,248 @@
+// gmg_orfs.hip -- the scoring part of glimmer3's Score_Orfs (src/Glimmer/glimmer3.cc:1275-1552) for a
+// whole batch of ORFs: per ORF the reversed / complemented buffer (glimmer3.cc:1322-1343), the gene and
+// null Cumulative_Score from frame 1 (:1346-1347; k_seg_cum, sequential double adds), then k_orf_scan:
+// the start-codon scan from the 3' end (:1355-1421), first / best start, the Ignore_Score_Len boost
+// (:1464-1466), the tentative-gene test (:1468) and the gene score (:1489).  Only the compact start
+// lists leave the GPU; events, DP and trace-back stay host code (src/Glimmer/glimmer_base.cc).
+
+#include "gmg_device.h"
+
+#include <float.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+struct gmg_orf_batch {
+    gmg_orf *d_orfs;
+    gmg_segments *segs;          // the ORF buffers as segments (REVERSED / COMPLEMENTED)
+    uint64_t *d_start_off;       // [n+1] first slot of each ORF's start list
+    double *d_score, *d_indep;   // cumulative scores, segs->total_len each
+    gmg_orf_result *d_results;
+    gmg_start *d_starts;
+    uint64_t n, max_starts;
+};
+
+struct OrfScanArgs {
+    const uint32_t *packed;
+    const uint64_t *read_off;
+    const gmg_orf *orfs;
+    const uint64_t *cum_off;     // segment output offsets (exclusive prefix of orf_len)
+    const uint64_t *start_off;
+    const double *score, *indep;
+    gmg_orf_result *results;
+    gmg_start *starts;
+    uint64_t n;
+    int min_gene_len, allow_truncated, use_first_start, ignore_score_len;
+    double start_threshold;
+    int n_pat;
+    uint32_t pat[8];             // Codon_t patterns of the start codons, 4 bits per base (gene.cc:62-75)
+};
+
+// Ch_Mask (src/Common/gene.cc:954-995): one bit per base an IUPAC letter can stand for
+static unsigned ch_mask(int ch)
+{
+    switch (ch | 0x20) {
+    case 'a': return 0x1; case 'c': return 0x2; case 'g': return 0x4; case 't': return 0x8;
+    case 'r': return 0x5; case 'y': return 0xA; case 's': return 0x6; case 'w': return 0x9;
+    case 'm': return 0x3; case 'k': return 0xC; case 'b': return 0xE; case 'd': return 0xD;
+    case 'h': return 0xB; case 'v': return 0x7; case 'n': return 0xF;
+    }
+    return 0;
+}
+
+// one lane per ORF
+__global__ __launch_bounds__(256) void k_orf_scan(OrfScanArgs a)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const gmg_orf orf = a.orfs[i];
+        const uint64_t r_off = a.read_off[orf.read];
+        const int L = (int)(a.read_off[orf.read + 1] - r_off);
+        const int len = orf.orf_len;
+        const bool fwd = orf.frame > 0;
+        int lo, hi, k;
+        bool trunc;
+        if (fwd) {                                      // glimmer3.cc:1322-1332
+            hi = orf.stop_position - 1;
+            lo = hi - len;
+            trunc = lo < 3 && a.allow_truncated;
+            k = orf.stop_position - len - 2;
+        } else {                                        // glimmer3.cc:1333-1343
+            lo = orf.stop_position + 2;
+            hi = lo + len;
+            trunc = L - hi < 3 && a.allow_truncated;
+            k = orf.stop_position + len + 4;
+        }
+        const double *score = a.score + a.cum_off[i];
+        const double *indep = a.indep + a.cum_off[i];
+        gmg_start *out = a.starts + a.start_off[i];
+        uint32_t n_starts = 0;
+
+        int first_pos = 0, best_pos = 0, first_j = 0, best_j = 0;
+        bool first_trunc = false, best_trunc = false;
+        double first_score = -DBL_MAX, best_score = -DBL_MAX;
+        uint32_t codon = 0;
+        const int lowest_j = a.min_gene_len - 3 < 3 ? a.min_gene_len - 3 : 3;
+        int jm3 = (len - 1) % 3;
+        for (int j = len - 1; j >= lowest_j && j >= 1; j--) {
+            // buff[j]: forward ORF = S[hi-1-j] (Reverse_Transfer), reverse ORF = comp(S[lo+j]) (Complement_Transfer)
+            const int code = fwd ? dev_code(a.packed, r_off + (uint64_t)(hi - 1 - j))
+                                 : 3 - dev_code(a.packed, r_off + (uint64_t)(lo + j));
+            codon = ((codon & 0xffu) << 4) | (1u << code);      // Codon_t::Shift_In (gene.cc:150-161)
+            if (jm3 == 0) {
+                int which = -1;                                 // Codon_t::Can_Be (gene.cc:39-66)
+                for (int p = 0; p < a.n_pat; p++) {
+                    const uint32_t x = codon & a.pat[p];
+                    if ((x & 0xf00u) && (x & 0xf0u) && (x & 0x0fu)) { which = p; break; }
+                }
+                if ((which >= 0 || (first_pos == 0 && trunc)) && j + 3 >= a.min_gene_len) {
+                    const double next_s = score[j - 1] - indep[j - 1];
+                    // Ignore_Score_Len boost (glimmer3.cc:1464-1466) folded into the push
+                    const double pushed = (j + 2 > a.ignore_score_len && next_s < 0.0) ? 0.0 : next_s;
+                    gmg_start st;
+                    st.score = pushed; st.j = j + 2; st.pos = k; st.first = (first_pos == 0);
+                    if (which >= 0 && first_pos == 0 && trunc) {
+                        st.which = -1; st.truncated = 1;
+                        out[n_starts++] = st;
+                        st.first = 0;
+                    }
+                    st.which = which; st.truncated = (which < 0);
+                    out[n_starts++] = st;
+                    if (first_pos == 0) {
+                        first_score = next_s; first_pos = k; first_j = j + 2;
+                        first_trunc = (first_pos == 0 && trunc);
+                    }
+                    if (next_s > best_score) { best_score = next_s; best_pos = k; best_j = j + 2; best_trunc = st.truncated; }
+                }
+            }
+            k += fwd ? 1 : -1;
+            jm3 = jm3 == 0 ? 2 : jm3 - 1;
+        }
+        if (a.use_first_start) { best_score = first_score; best_pos = first_pos; best_j = first_j; best_trunc = first_trunc; }
+        (void)best_trunc;
+
+        gmg_orf_result res;
+        res.start_begin = (uint32_t)a.start_off[i];
+        res.first_j = first_j; res.best_j = best_j; res.best_pos = best_pos;
+        res.best_score = best_score;
+        res.orf_is_truncated = trunc;
+        if (first_j + 1 < a.min_gene_len) {             // glimmer3.cc:1431: the ORF is dropped
+            res.n_starts = 0; res.is_tentative_gene = 0; res.gene_score = 0.0;
+        } else {
+            res.n_starts = n_starts;
+            res.is_tentative_gene = best_score > a.start_threshold;     // glimmer3.cc:1468
+            res.gene_score = 100.0 * best_score / (best_j - 2);        // glimmer3.cc:1489
+        }
+        a.results[i] = res;
+    }
+}
+
+extern "C" int gmg_orfs_upload(const gmg_reads *reads, const gmg_orf *orfs, uint64_t n, uint64_t *out_max_starts,
+                               gmg_orf_batch **out)
+{
+    if (!reads || (!orfs && n) || !out) return gmg_set_error(GMG_EINVAL, "gmg_orfs_upload: NULL argument");
+    std::vector<uint64_t> off(reads->n_reads + 1);
+    GMG_HIP(hipMemcpy(off.data(), reads->d_off, off.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<gmg_segment> segs(n);
+    std::vector<uint64_t> start_off(n + 1, 0);
+    for (uint64_t i = 0; i < n; i++) {
+        const gmg_orf &o = orfs[i];
+        if (o.read >= reads->n_reads || o.frame == 0 || o.frame > 3 || o.frame < -3 || o.orf_len < 0)
+            return gmg_set_error(GMG_ERANGE, "gmg_orfs_upload: ORF %llu: bad read / frame / length", (unsigned long long)i);
+        const int64_t L = (int64_t)(off[o.read + 1] - off[o.read]);
+        int64_t lo, hi;
+        if (o.frame > 0) { hi = (int64_t)o.stop_position - 1; lo = hi - o.orf_len; }
+        else { lo = (int64_t)o.stop_position + 2; hi = lo + o.orf_len; }
+        if (lo < 0 || hi > L)
+            return gmg_set_error(GMG_ERANGE, "gmg_orfs_upload: ORF %llu [%lld,%lld) leaves its read of length %lld "
+                                 "(circular wrap-around is not supported)", (unsigned long long)i, (long long)lo,
+                                 (long long)hi, (long long)L);
+        segs[i].read = o.read;
+        segs[i].lo = (uint32_t)lo;
+        segs[i].len = (uint32_t)o.orf_len;
+        segs[i].orient = o.frame > 0 ? GMG_REVERSED : GMG_COMPLEMENTED;     // glimmer3.cc:1328,1339
+        start_off[i + 1] = start_off[i] + (uint64_t)o.orf_len / 3 + 2;     // one per in-frame codon + a truncated start
+    }
+    if (start_off[n] >= 0xffffffffull) return gmg_set_error(GMG_EINVAL, "gmg_orfs_upload: batch too large");
+    gmg_orf_batch *b = new (std::nothrow) gmg_orf_batch();
+    if (!b) return gmg_set_error(GMG_ENOMEM, "gmg_orfs_upload: out of host memory");
+    memset(b, 0, sizeof *b);
+    b->n = n;
+    b->max_starts = start_off[n];
+    int rc = gmg_segments_upload(reads, segs.data(), n, nullptr, nullptr, &b->segs);
+    if (rc) { delete b; return rc; }
+    const size_t tl = b->segs->total_len;
+    hipError_t e = hipMalloc((void **)&b->d_orfs, (n ? n : 1) * sizeof(gmg_orf));
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_start_off, (n + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_score, (tl ? tl : 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_indep, (tl ? tl : 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_results, (n ? n : 1) * sizeof(gmg_orf_result));
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_starts, (b->max_starts ? b->max_starts : 1) * sizeof(gmg_start));
+    if (e == hipSuccess && n) e = hipMemcpy(b->d_orfs, orfs, n * sizeof(gmg_orf), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b->d_start_off, start_off.data(), (n + 1) * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { gmg_orf_batch_free(b); return gmg_set_error(GMG_ENOMEM, "gmg_orfs_upload: %s", hipGetErrorString(e)); }
+    if (out_max_starts) *out_max_starts = b->max_starts;
+    *out = b;
+    return GMG_OK;
+}
+
+extern "C" int gmg_orf_batch_free(gmg_orf_batch *b)
+{
+    if (!b) return GMG_OK;
+    if (b->segs) gmg_segments_free(b->segs);
+    void *ptrs[] = {b->d_orfs, b->d_start_off, b->d_score, b->d_indep, b->d_results, b->d_starts};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete b;
+    return GMG_OK;
+}
+
+extern "C" int gmg_score_orfs(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads,
+                              const gmg_orf_batch *b, const gmg_orf_params *prm, gmg_orf_result *results,
+                              gmg_start *starts, void *stream)
+{
+    if (!gene || !nul || !reads || !b || !prm || (b->n && !results) || (b->max_starts && !starts))
+        return gmg_set_error(GMG_EINVAL, "gmg_score_orfs: NULL argument");
+    if (prm->n_start_codons < 0 || prm->n_start_codons > 8 || prm->min_gene_len < 4)
+        return gmg_set_error(GMG_EINVAL, "gmg_score_orfs: need 0..8 start codons and min_gene_len >= 4");
+    // Cumulative_Score(buff, score, 1): frame 1 needs periodicity 1 or > 1 (src/ICM/icm.cc:367-369)
+    if ((gene->dev.P != 1 && gene->dev.P < 2) || (nul->dev.P != 1 && nul->dev.P < 2))
+        return gmg_set_error(GMG_EBADMODEL, "gmg_score_orfs: frame 1 outside the models' periodicity");
+    if (b->n == 0) return GMG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = gmg_launch_seg_cum(gene, reads, b->segs, gene->dev.P == 1 ? 0 : 1, b->d_score, nullptr, s);
+    if (rc) return rc;
+    rc = gmg_launch_seg_cum(nul, reads, b->segs, nul->dev.P == 1 ? 0 : 1, b->d_indep, nullptr, s);
+    if (rc) return rc;
+
+    OrfScanArgs a;
+    a.packed = reads->d_packed;
+    a.read_off = reads->d_off;
+    a.orfs = b->d_orfs;
+    a.cum_off = b->segs->d_out_off;
+    a.start_off = b->d_start_off;
+    a.score = b->d_score;
+    a.indep = b->d_indep;
+    a.results = b->d_results;
+    a.starts = b->d_starts;
+    a.n = b->n;
+    a.min_gene_len = prm->min_gene_len;
+    a.allow_truncated = prm->allow_truncated;
+    a.use_first_start = prm->use_first_start;
+    a.ignore_score_len = prm->ignore_score_len;
+    a.start_threshold = prm->start_threshold;
+    a.n_pat = prm->n_start_codons;
+    for (int p = 0; p < 8; p++) {
+        uint32_t d = 0;                                 // Codon_t::Set_From (gene.cc:133-146)
+        if (p < a.n_pat)
+            for (int c = 0; c < 3 && prm->start_codon[p][c]; c++) d = ((d & 0xffu) << 4) | ch_mask(prm->start_codon[p][c]);
+        a.pat[p] = d;
+    }
+    const uint64_t blocks = (b->n + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 256 * 16 ? blocks : 256 * 16);
+    hipLaunchKernelGGL(k_orf_scan, dim3(grid), dim3(256), 0, s, a);
+    GMG_HIP(hipGetLastError());
+    GMG_HIP(hipMemcpyAsync(results, b->d_results, b->n * sizeof(gmg_orf_result), hipMemcpyDeviceToHost, s));
+    GMG_HIP(hipMemcpyAsync(starts, b->d_starts, b->max_starts * sizeof(gmg_start), hipMemcpyDeviceToHost, s));
+    GMG_HIP(hipStreamSynchronize(s));
+    return GMG_OK;
+}

@@ -176,6 +176,65 @@ int gmg_all_frame_score(const gmg_model *gene, const gmg_reads *reads, const gmg
 int gmg_window_distrib(const gmg_model *m, const uint8_t *d_windows, const int32_t *d_frames,
                        uint64_t n_windows, float *d_dist4, double *d_prob, void *stream);
 
+/* ---- Score_Orfs inner loop (src/Glimmer/glimmer3.cc:1275-1552) ------------------- */
+
+/* One Orf_t as Find_Orfs produced it (src/Common/gene.hh:101-139). */
+typedef struct gmg_orf {
+    uint32_t read;           /* index into the gmg_reads batch                                   */
+    int32_t frame;           /* Orf_t::Get_Frame(): +1..+3 forward, -1..-3 reverse                */
+    int32_t stop_position;   /* Orf_t::Get_Stop_Position(): first base of the stop codon, 1-based */
+    int32_t orf_len;         /* Orf_t::Get_Orf_Len()                                              */
+} gmg_orf;
+
+/* The globals Score_Orfs reads (glimmer3.cc:23,61,71,122,148; glimmer_base.cc:2636-2712). */
+typedef struct gmg_orf_params {
+    int32_t min_gene_len;        /* Min_Gene_Len (default 75)                                    */
+    int32_t allow_truncated;     /* Allow_Truncated_Orfs (-X)                                    */
+    int32_t use_first_start;     /* Use_First_Start_Codon (-f)                                   */
+    int32_t ignore_score_len;    /* Ignore_Score_Len (INT_MAX = never)                           */
+    double start_threshold;      /* Start_Threshold (-6)                                         */
+    int32_t n_start_codons;      /* <= 8                                                         */
+    char start_codon[8][4];      /* Start_Codon strings, e.g. "atg","gtg","ttg" (IUPAC allowed)  */
+} gmg_orf_params;
+
+/* One Start_t (src/Glimmer/glimmer_base.hh:80-88), in the order Score_Orfs pushes them. */
+typedef struct gmg_start {
+    double score;            /* score[j-1] - indep_score[j-1], after the Ignore_Score_Len boost  */
+    int32_t j, pos;
+    int32_t which;           /* index of the matching start codon, -1 for a truncated start      */
+    int16_t truncated, first;
+} gmg_start;
+
+typedef struct gmg_orf_result {
+    double gene_score;       /* 100 * best_score / (best_j - 2)                  (glimmer3.cc:1489) */
+    double best_score;
+    uint32_t start_begin;    /* first entry of this ORF's start list in the starts array          */
+    uint32_t n_starts;
+    int32_t first_j, best_j; /* gene length = best_j + 1                         (glimmer3.cc:1499) */
+    int32_t best_pos;
+    int16_t is_tentative_gene;   /* first_j+1 >= Min_Gene_Len && best_score > Start_Threshold (:1468); only then
+                                    does the reference add the gene and its events (:1494-1548)   */
+    int16_t orf_is_truncated;
+} gmg_orf_result;
+
+typedef struct gmg_orf_batch gmg_orf_batch;
+
+/* Validates the ORFs against their reads (linear sequences only: the reference's circular wrap-around
+ * is refused with GMG_ERANGE) and reserves room for the start lists; *out_max_starts is the number
+ * of gmg_start entries the caller must provide to gmg_score_orfs. */
+int gmg_orfs_upload(const gmg_reads *reads, const gmg_orf *orfs, uint64_t n_orfs,
+                    uint64_t *out_max_starts, gmg_orf_batch **out);
+int gmg_orf_batch_free(gmg_orf_batch *b);
+
+/* The scoring part of Score_Orfs for every ORF of the batch: ORF buffer (Reverse_Transfer /
+ * Complement_Transfer), gene and null Cumulative_Score from frame 1, the start-codon scan from the
+ * 3' end, first/best start, truncated starts, gene score and the tentative-gene test.  `results`
+ * (n_orfs) and `starts` (out_max_starts) are HOST buffers: only these compact lists leave the GPU.
+ * Events / DP / trace-back stay host code (src/Glimmer/glimmer_base.cc). */
+int gmg_score_orfs(const gmg_model *gene, const gmg_model *null_model, const gmg_reads *reads,
+                   const gmg_orf_batch *orfs, const gmg_orf_params *params,
+                   gmg_orf_result *results, gmg_start *starts, void *stream);
+
 /* ---- device memory helpers (for callers without their own allocator) -------- */
 int gmg_device_malloc(void **d_ptr, size_t bytes);
 int gmg_device_free(void *d_ptr);

@@ -169,6 +169,30 @@ def main():
         subprocess.run([os.path.join(RB, cmd[0]), *cmd[1:], fa, tag], check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=RB)
         shutil.copyfile(tag + ".predict", os.path.join(GOLD, "predict", name + ".predict"))
+    # ---- Score_Orfs inner loop (glimmer3.cc:1275-1552): ORFs from Find_Orfs + the start lists handed to Add_Events_*
+    for name, flags in (("orfs_default", []), ("orfs_X", ["-X"]), ("orfs_g90_first", ["-g", "90", "-f", "x"])):
+        txt = subprocess.run([os.path.join(RB, "ref_orfs"), "dump", *flags, "-m", nc, fa, os.path.join(RB, "orfs_tag")],
+                             check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=RB).stdout.decode()
+        orfs, genes, st_i, st_s = [], [], [], []
+        read, base = -1, 0
+        for line in txt.splitlines():
+            p = line.split()
+            if p[0] == "R":
+                read, base = int(p[1]), len(orfs)
+            elif p[0] == "O":
+                orfs.append((read, int(p[1]), int(p[2]), int(p[3])))
+            elif p[0] == "G":
+                genes.append((base + int(p[1]), int(p[3]), int(p[4]), len(st_i), float(p[2])))
+            elif p[0] == "S":
+                st_i.append((int(p[1]), int(p[2]), int(p[4]), int(p[5]), int(p[6])))
+                st_s.append(float.fromhex(p[3]))
+        g = np.array([x[:4] for x in genes], np.int64)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), flags=" ".join(flags),
+                            orfs=np.array(orfs, np.int32),                       # read, frame, stop_position, orf_len
+                            gene_orf=g[:, 0], gene_len=g[:, 1], gene_nstarts=g[:, 2], gene_start_begin=g[:, 3],
+                            gene_score=np.array([x[4] for x in genes], np.float64),
+                            start_int=np.array(st_i, np.int32),                  # j, pos, which, truncated, first
+                            start_score=np.array(st_s, np.float64))
     print("golden vectors written to", GOLD)
 
 

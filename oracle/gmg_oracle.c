@@ -517,6 +517,119 @@ void orc_all_frame_score(const orc_model *gene, const char *s, int len, int fram
     for (i = 0; i < 6; i++) af[i] = raw[perm[i]];
 }
 
+/* ------------------------------------------------------------------------ */
+/* Score_Orfs inner loop                                                     */
+/* ------------------------------------------------------------------------ */
+
+/* gene.cc:954-995: one bit per base a possible IUPAC letter can be */
+unsigned orc_ch_mask(int ch)
+{
+    switch (tolower(ch)) {
+    case 'a': return 0x1; case 'c': return 0x2; case 'g': return 0x4; case 't': return 0x8;
+    case 'r': return 0x5; case 'y': return 0xA; case 's': return 0x6; case 'w': return 0x9;
+    case 'm': return 0x3; case 'k': return 0xC; case 'b': return 0xE; case 'd': return 0xD;
+    case 'h': return 0xB; case 'v': return 0x7; case 'n': return 0xF;
+    }
+    return 0x0;
+}
+
+/* Codon_t::Set_From (gene.cc:133-146): three Shift_In's of a 12-bit register */
+static unsigned orc_codon_from(const char *s)
+{
+    unsigned d = 0;
+    int i;
+    for (i = 0; i < 3 && s[i]; i++) d = ((d & 0xff) << 4) | orc_ch_mask(s[i]);
+    return d;
+}
+
+/* Codon_t::Can_Be (gene.cc:39-66): every base position shares at least one possible letter */
+static int orc_can_be(unsigned data, const unsigned *pat, int n, int *which)
+{
+    int i;
+    for (i = 0; i < n; i++) {
+        unsigned x = data & pat[i];
+        if ((x & 0xf00) && (x & 0xf0) && (x & 0x0f)) { *which = i; return 1; }
+    }
+    *which = -1;
+    return 0;
+}
+
+int orc_score_orf(const orc_model *gene, const orc_model *indep, const char *seq, int seq_len,
+                  int frame, int stop_position, int orf_len, const orc_orf_params *prm,
+                  orc_start *starts, int cap, orc_orf_out *out)
+{
+    unsigned pat[8], codon = 0;
+    int n_pat = prm->n_start_codons, n_starts = 0;
+    int len = orf_len, lo, hi, k, j, m, lowest_j, which = -1, i;
+    int first_pos = 0, best_pos = 0, first_j = 0, best_j = 0;
+    int orf_is_truncated, first_is_truncated = 0, best_is_truncated = 0;
+    double first_score = -1.7976931348623157e308, best_score = -1.7976931348623157e308;   /* -DBL_MAX */
+    char *buff = (char *)malloc((size_t)len + 1);
+    double *score = (double *)malloc(sizeof(double) * (size_t)(len ? len : 1));
+    double *indep_score = (double *)malloc(sizeof(double) * (size_t)(len ? len : 1));
+
+    for (i = 0; i < n_pat; i++) pat[i] = orc_codon_from(prm->start_codon[i]);
+
+    if (frame > 0) {                                    /* glimmer3.cc:1322-1332 */
+        hi = stop_position - 1;
+        lo = hi - len;
+        orc_reverse_transfer(buff, seq, seq_len, hi - 1, len);
+        orf_is_truncated = (lo < 3 && prm->allow_truncated);
+        k = stop_position - len - 2;
+    } else {                                            /* glimmer3.cc:1333-1343 */
+        lo = stop_position + 2;
+        hi = lo + len;
+        orc_complement_transfer(buff, seq, seq_len, lo, len);
+        orf_is_truncated = (seq_len - hi < 3 && prm->allow_truncated);
+        k = stop_position + len + 4;
+    }
+    orc_cumulative_score(gene, buff, len, score, 1);    /* glimmer3.cc:1346-1347 */
+    orc_cumulative_score(indep, buff, len, indep_score, 1);
+    m = len;
+
+    lowest_j = prm->min_gene_len - 3 < 3 ? prm->min_gene_len - 3 : 3;     /* Min (3, Min_Gene_Len - 3) */
+    for (j = m - 1; j >= lowest_j; j--) {               /* glimmer3.cc:1355-1421 */
+        codon = ((codon & 0xff) << 4) | orc_ch_mask(buff[j]);
+        if (j % 3 == 0 && (orc_can_be(codon, pat, n_pat, &which) || (first_pos == 0 && orf_is_truncated))
+            && j + 3 >= prm->min_gene_len) {
+            double next_s = score[j - 1] - indep_score[j - 1];
+            orc_start st;
+            st.j = j + 2; st.pos = k; st.score = next_s; st.first = (first_pos == 0);
+            if (which >= 0 && first_pos == 0 && orf_is_truncated) {
+                st.which = -1; st.truncated = 1;
+                if (n_starts < cap) starts[n_starts] = st;
+                n_starts++;
+                st.first = 0;
+            }
+            st.which = which; st.truncated = (which < 0);
+            if (n_starts < cap) starts[n_starts] = st;
+            n_starts++;
+            if (first_pos == 0) {
+                first_score = next_s; first_pos = k; first_j = j + 2;
+                first_is_truncated = (first_pos == 0 && orf_is_truncated);
+            }
+            if (next_s > best_score) {
+                best_score = next_s; best_pos = k; best_j = j + 2; best_is_truncated = st.truncated;
+            }
+        }
+        if (frame > 0) k++; else k--;
+    }
+    if (prm->use_first_start) {                         /* glimmer3.cc:1423-1429 */
+        best_score = first_score; best_pos = first_pos; best_j = first_j; best_is_truncated = first_is_truncated;
+    }
+    (void)best_is_truncated;
+    free(buff); free(score); free(indep_score);
+    out->first_j = first_j; out->best_j = best_j; out->best_pos = best_pos;
+    out->best_score = best_score; out->orf_is_truncated = orf_is_truncated;
+    out->is_tentative_gene = 0; out->gene_score = 0.0;
+    if (first_j + 1 < prm->min_gene_len) return -1;     /* glimmer3.cc:1431-1432 */
+    for (i = 0; i < n_starts && i < cap; i++)           /* glimmer3.cc:1464-1466 */
+        if (starts[i].j > prm->ignore_score_len && starts[i].score < 0.0) starts[i].score = 0.0;
+    out->is_tentative_gene = (first_j + 1 >= prm->min_gene_len && best_score > prm->start_threshold);
+    out->gene_score = 100.0 * best_score / (best_j - 2);
+    return n_starts;
+}
+
 long orc_score_reads_6frame(const orc_model *gene, const orc_model *indep, const char *seqs,
                             int n_reads, int L, double *out)
 {

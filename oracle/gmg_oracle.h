@@ -91,6 +91,26 @@ void   orc_all_frame_score(const orc_model *gene, const char *s, int len, int fr
 void   orc_reverse_transfer(char *buff, const char *s, int n, int start, int len);
 void   orc_complement_transfer(char *buff, const char *s, int n, int start, int len);
 
+/* Score_Orfs inner loop for ONE ORF (src/Glimmer/glimmer3.cc:1301-1503): buffer, two cumulative
+ * scores from frame 1, start-codon scan from the 3' end, first/best start, gene score.  seq is the
+ * filtered lower-case sequence (linear).  Returns the number of starts written (<= cap), or -1 when the
+ * ORF is skipped before the gene test (first_j + 1 < Min_Gene_Len, glimmer3.cc:1431). */
+typedef struct orc_start { double score; int j, pos, which, truncated, first; } orc_start;
+typedef struct orc_orf_params {
+    int min_gene_len, allow_truncated, use_first_start, ignore_score_len;
+    double start_threshold;
+    int n_start_codons;
+    const char *start_codon[8];
+} orc_orf_params;
+typedef struct orc_orf_out {
+    double gene_score, best_score;
+    int first_j, best_j, best_pos, is_tentative_gene, orf_is_truncated;
+} orc_orf_out;
+unsigned orc_ch_mask(int ch);                                 /* src/Common/gene.cc:954-995 */
+int orc_score_orf(const orc_model *gene, const orc_model *indep, const char *seq, int seq_len,
+                  int frame, int stop_position, int orf_len, const orc_orf_params *prm,
+                  orc_start *starts, int cap, orc_orf_out *out);
+
 /* Whole-job helper used by bench.py's cpu_baseline leg: score n_reads reads of
  * fixed length L (concatenated, filtered lower-case) into out[read][6][L].
  * Returns number of bases scored.  Single-threaded like the reference. */

@@ -16,6 +16,22 @@ class Model(C.Structure):
                 ("num_nodes", C.c_int), ("mip", C.POINTER(C.c_int16)), ("prob", C.POINTER(C.c_float))]
 
 
+class Start(C.Structure):
+    _fields_ = [("score", C.c_double), ("j", C.c_int), ("pos", C.c_int), ("which", C.c_int),
+                ("truncated", C.c_int), ("first", C.c_int)]
+
+
+class OrfParams(C.Structure):
+    _fields_ = [("min_gene_len", C.c_int), ("allow_truncated", C.c_int), ("use_first_start", C.c_int),
+                ("ignore_score_len", C.c_int), ("start_threshold", C.c_double), ("n_start_codons", C.c_int),
+                ("start_codon", C.c_char_p * 8)]
+
+
+class OrfOut(C.Structure):
+    _fields_ = [("gene_score", C.c_double), ("best_score", C.c_double), ("first_j", C.c_int), ("best_j", C.c_int),
+                ("best_pos", C.c_int), ("is_tentative_gene", C.c_int), ("orf_is_truncated", C.c_int)]
+
+
 MP = C.POINTER(Model)
 dp = C.POINTER(C.c_double)
 
@@ -55,6 +71,8 @@ class Oracle:
         L.orc_complement_transfer.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
         L.orc_score_reads_6frame.restype = C.c_long
         L.orc_score_reads_6frame.argtypes = [MP, MP, C.c_char_p, C.c_int, C.c_int, dp]
+        L.orc_score_orf.argtypes = [MP, MP, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(OrfParams),
+                                    C.POINTER(Start), C.c_int, C.POINTER(OrfOut)]
         for f in ("orc_filter", "orc_complement", "orc_subscript"):
             getattr(L, f).argtypes = [C.c_int]
 
@@ -135,6 +153,26 @@ class Oracle:
             self.L.orc_reverse_transfer(tmp, s, len(s), lo + ln - 1, ln)
             self.L.orc_complement_transfer(buf, tmp.raw[:ln], ln, 0, ln)
         return buf.raw[:ln]
+
+    @staticmethod
+    def orf_params(min_gene_len=75, allow_truncated=False, use_first_start=False, ignore_score_len=2**31 - 1,
+                   start_threshold=-6.0, start_codons=("atg", "gtg", "ttg")):
+        """defaults of src/Glimmer/glimmer3.cc:23,61,71,122,148 and glimmer_base.hh DEFAULT_START_CODON"""
+        p = OrfParams(min_gene_len, int(allow_truncated), int(use_first_start), ignore_score_len, start_threshold,
+                      len(start_codons))
+        for i, c in enumerate(start_codons):
+            p.start_codon[i] = c.encode()
+        return p
+
+    def score_orf(self, gene, indep, seq, frame, stop_position, orf_len, prm):
+        """-> (n_starts or -1, OrfOut, [Start])"""
+        s = seq.encode() if isinstance(seq, str) else seq
+        cap = orf_len // 3 + 4
+        starts = (Start * cap)()
+        out = OrfOut()
+        n = self.L.orc_score_orf(gene, indep, s, len(s), frame, stop_position, orf_len, C.byref(prm), starts, cap,
+                                 C.byref(out))
+        return n, out, list(starts[:max(n, 0)])
 
     def filter_lower(self, seq):
         """tolower(Filter(c)) per character (glimmer3.cc:270-271)"""

@@ -33,3 +33,17 @@ def test_reference_cli_on_our_icm_is_byte_identical(gpu, tmp_path, binary, flags
     assert got == want
     maps_ok = b"libgmg.so" in subprocess.run(["ldd", exe], stdout=subprocess.PIPE).stdout
     assert maps_ok
+
+
+@pytest.mark.parametrize("flags,golden", [([], "glimmer3.default.predict"), (["-X"], "glimmer3.X.predict")])
+def test_glimmer3_with_batched_score_orfs_is_byte_identical(gpu, tmp_path, flags, golden):
+    """oracle/_ref/glimmer3_batch: glimmer3's own Find_Orfs / Add_Events / Process_Events / Trace_Back around ONE
+    gmg_score_orfs call that replaces the Score_Orfs inner loops of all 999 reads (oracle/ref_drivers/ref_orfs.cc)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "glimmer3_batch")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/glimmer3_batch not built (needs /root/reference in the build container)")
+    tag = str(tmp_path / "out")
+    cmd = [exe, "batch", *flags, "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, "seqs.fa"), tag]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", golden), "rb").read()

@@ -241,3 +241,34 @@ def test_frame6_full_size_properties(gpu, nc, oracle, o_nc):
     assert np.array_equal(one[:, :L], a[:, r * L:(r + 1) * L])
     assert np.array_equal(one[0:3, L:][:, ::-1], one[3:6, :L])
     assert np.array_equal(one[3:6, L:][:, ::-1], one[0:3, :L])
+
+
+# ---------------------------------------------------------------- a12: Score_Orfs inner loop
+
+@pytest.mark.parametrize("name,kw", [("orfs_default", {}), ("orfs_X", {"allow_truncated": True}),
+                                     ("orfs_g90_first", {"min_gene_len": 90, "use_first_start": True})])
+def test_score_orfs_golden_start_lists(gpu, nc, fa_reads, name, kw):
+    """ORFs from the reference's Find_Orfs on seqs.fa; start lists, gene score and gene length must equal
+    what the reference's Score_Orfs handed to Add_Events_* (tests/golden/orfs_*.npz), bit for bit."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    gc = float(np.load(os.path.join(GOLD, "frames_nc.npz"))["gc"])
+    res, starts = gpu.score_orfs(nc, gpu.Icm.indep(gc), fa_reads, g["orfs"], **kw)
+    accepted = np.zeros(len(res), bool)
+    accepted[g["gene_orf"]] = True
+    assert np.array_equal(res["is_tentative_gene"] != 0, accepted)
+    sel = res[g["gene_orf"]]
+    assert np.array_equal(sel["gene_score"], g["gene_score"])
+    assert np.array_equal(sel["best_j"] + 1, g["gene_len"])
+    assert np.array_equal(sel["n_starts"], g["gene_nstarts"])
+    for r, b, cnt in zip(sel, g["gene_start_begin"], g["gene_nstarts"]):
+        st = starts[r["start_begin"]:r["start_begin"] + r["n_starts"]]
+        assert np.array_equal(st["score"], g["start_score"][b:b + cnt])
+        got = np.stack([st["j"], st["pos"], st["which"], st["truncated"], st["first"]], 1)
+        assert np.array_equal(got, g["start_int"][b:b + cnt])
+
+
+def test_score_orfs_rejects_wrapping_orfs(gpu, nc, fa_reads):
+    with pytest.raises(gpu.GmgError):
+        gpu.score_orfs(nc, gpu.Icm.indep(0.5), fa_reads, np.array([[0, 1, 30, 90]]))     # lo < 0: circular wrap
+    with pytest.raises(gpu.GmgError):
+        gpu.score_orfs(nc, gpu.Icm.indep(0.5), fa_reads, np.array([[0, -1, 450, 90]]))   # hi > L
