@@ -123,9 +123,8 @@ extern "C" int  gmg_icm_device_model  (const gmg_icm * icm, const gmg_model * * 
   {
    if  (icm == NULL || out == NULL)
        return  gmg_set_error (GMG_EINVAL, "gmg_icm_device_model: NULL argument");
-   //  upload through the C ABI so that a failure is a status, not an exit
-   static thread_local int  dummy = 0;
-   (void) dummy;
+   //  ICM_t::Device_Model exits on failure (reference convention); check the one likely cause first
+   //  so that this C entry point returns a status instead
    if  (gmg_device_count () <= 0)
        return  gmg_set_error (GMG_ENODEV, "gmg_icm_device_model: no HIP device; there is no CPU fallback");
    * out = icm -> model . Device_Model ();

@@ -16,11 +16,8 @@ CASES = {
 }
 
 
-def ignore_score_len(gc):
-    """Set_Ignore_Score_Len (src/Glimmer/glimmer_base.cc): not restated -- the goldens were produced with the
-    value glimmer3 derives; it only matters for starts with j above it, and the tests pass it explicitly."""
-    return None
-
+# Ignore_Score_Len: glimmer3 derives it from the GC content (Set_Ignore_Score_Len, glimmer_base.cc); for these
+# 500-bp reads it is far above every ORF length, so the default "never" (INT_MAX) reproduces the goldens.
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_score_orfs_matches_reference_start_lists(oracle, seqs_fa, name):
