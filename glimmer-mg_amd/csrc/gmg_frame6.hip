@@ -12,31 +12,16 @@
 // instructions per base as possible (profiles/r01_v5_*: the kernel is VALU-issue bound).
 //
 // Three launches per call, stream-ordered:
-//   k_frame6s   main pass.  Treats the whole batch as ONE stream of bases and scores every base
-//               with the full-window rule: no read boundaries, no branches, fixed instruction and
-//               memory-operation counts per iteration.  Bases whose window leaves their read (the
-//               first W-1 bases of either scoring buffer of each read) get a meaningless value.
-//   k_frame6_generic  the last < 2048 bases of the batch (the main pass only does full chunks).
+//   k_frame6t   main pass (LDS table swapping, below).  Treats the whole batch as ONE stream of bases and
+//               scores every base with the full-window rule: no read boundaries, no branches.  Bases
+//               whose window leaves their read (the first W-1 bases of either scoring buffer of each
+//               read) get a meaningless value here.
+//   k_frame6_generic  the last < 2048 bases of the batch (the main pass only does full chunks), and
+//               whole batches whose model shape has no fast path.
 //   k_frame6p   partial-window pass: one lane per (read, buffer position < W-1, strand) recomputes
 //               exactly those bases with the reference's partial-window rule (icm.cc:807-842) and
 //               overwrites them.  2(W-1) of every L bases (4.4 % at L = 500).
-//
-// k_frame6s, work-group specialisation: the grid is persistent, 3 x nworkers work-groups of 1024
-// lanes, one per CU.  Work-group type f = blockIdx % 3 owns sub-model f, i.e. output rows f and 3+f.
-// Its LDS (160 KiB, all of a CU) holds for that ONE sub-model
-//   s_shr / s_shf  completed-tree shift tables for the two strands (one byte per node, levels 0..D-1):
-//                  2*mip for the complemented buffer, 2*(W-1-mip) for the reversed one, so that both
-//                  strands' context registers are plain bit-fields of the packed read (no reversal);
-//   s_nr / s_nf    the width-3 null model as 64-entry tables of doubles, one per strand;
-//   leaf rows      as many 16-byte leaf rows of the completed tree as fit (~9,500 of 16,384 at D = 7);
-//                  the others are gathered from the L2-resident crow table.
-// One descent step is  ds_read_u8 ; v_bfe_u32 ; v_lshl_or_b32.  Each lane owns two adjacent bases
-// of a 2048-base chunk and scores them on both strands (four independent descents in flight), then
-// writes one 16-byte store per output row: a wave writes 1 KiB of consecutive doubles per row.
-// The chunk loop is software-pipelined three deep (unrolled by three, no register copies):
-//   stage A (chunk i+2): the three packed-read words of a chunk are loaded two iterations early;
-//   stage B (chunk i)  : contexts, four LDS descents, then leaf-row / null-table reads are ISSUED;
-//   stage C (chunk i-2): the values fetched two iterations ago are widened, subtracted and stored.
+// DESIGN.md section 4.1 has the measurements that led here (gathers from L2 -> table swapping).
 
 #include "gmg_device.h"
 #include <stdlib.h>
@@ -48,18 +33,12 @@ struct Frame6Args {
     const uint32_t *tile_read;
     uint64_t total, n_reads;
     uint64_t first, count;  // k_frame6_generic: range of bases to score
-    double *out;
-    int n_cached;           // leaf rows of one sub-model held in LDS
+    double *out;            // [6][total] gene - null (the Frame_Scores table)
+    float *out_gene;        // gene-only mode (gmg_launch_gene6): [6][total] gene values as fp32
 };
 
 constexpr int f6_cstride(int dt) { return ((((1 << (2 * dt)) - 1) / 3) + 15) & ~15; }
 constexpr int f6_level_base(int l) { return ((1 << (2 * l)) - 1) / 3; }
-
-// values of one chunk between "issued" (stage B) and "stored" (stage C)
-struct F6Pend {
-    float l[4], g[4];   // leaf value from LDS / from L2: one of the two is the value, the other +0.0f
-    double n[4];        // null-model value
-};
 
 // One descent in the completed tree of depth DT: C holds the window, tab the shift table in LDS.
 // Returns the leaf index (0 .. 4^DT-1).
@@ -73,175 +52,6 @@ __device__ __forceinline__ uint32_t f6_descend(const uint8_t *tab, uint32_t C, u
         idx = (idx << 2) | __builtin_amdgcn_ubfe(C, sh, 2);
     }
     return idx;
-}
-
-// DIAG != 0 builds are timing-only ablations (wrong results), selected with GMG_DIAG for profiling:
-//   1 no output stores   2 no leaf-row fetch
-// PAIR: total_bases is even, so every output row is 16-byte aligned.
-template <int BLOCK, int DT, int DIAG, bool PAIR>
-__global__ __launch_bounds__(BLOCK) void k_frame6s(Frame6Args a)
-{
-    constexpr int CS = f6_cstride(DT);
-    __shared__ __attribute__((aligned(16))) uint8_t s_shr[CS];     // complemented buffer (rows 3+f): 2*mip
-    __shared__ __attribute__((aligned(16))) uint8_t s_shf[CS];     // reversed buffer (rows f): 2*(W-1-mip)
-    __shared__ __attribute__((aligned(16))) double s_nr[64];        // null model, complemented buffer
-    __shared__ __attribute__((aligned(16))) double s_nf[64];        // null model, reversed buffer
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_leaf[];   // [n_cached][4] floats
-
-    const int ftype = blockIdx.x % 3;
-    const uint32_t worker = blockIdx.x / 3, nworkers = gridDim.x / 3;
-    const int W = a.gene.W;
-    const uint32_t n_cached = (uint32_t)a.n_cached;
-    const float *__restrict__ leaf_rows = a.gene.crow + ((size_t)ftype * a.gene.ctot + f6_level_base(DT)) * 4;
-
-    // ---- fill LDS
-    {
-        const float4 *src = (const float4 *)leaf_rows;
-        for (uint32_t i = threadIdx.x; i < n_cached; i += BLOCK) ((float4 *)s_leaf)[i] = src[i];
-        if (threadIdx.x == 0) ((float4 *)s_leaf)[n_cached] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const uint8_t *sh_src = a.gene.cshift + (size_t)ftype * a.gene.cstride;
-        for (int i = threadIdx.x; i < CS; i += BLOCK) {
-            const uint8_t sh = sh_src[i];
-            s_shr[i] = sh;
-            s_shf[i] = (uint8_t)(2 * (W - 1) - sh);
-        }
-        if (threadIdx.x < 64) {
-            // dense[idx]: idx = w[0] | w[1] << 2 | w[2] << 4 (window char k at bits 2k)
-            const uint32_t i = threadIdx.x;
-            const uint32_t mirrored = ((i & 3u) << 4) | (i & 12u) | (i >> 4);
-            s_nr[i] = (double)a.nul.dense[(size_t)ftype * 64 + i];
-            s_nf[i] = (double)a.nul.dense[(size_t)ftype * 64 + mirrored];
-        }
-    }
-    __syncthreads();
-    const uint32_t shift0_r = __builtin_amdgcn_readfirstlane((uint32_t)s_shr[0]);
-    const uint32_t shift0_f = __builtin_amdgcn_readfirstlane((uint32_t)s_shf[0]);
-
-    constexpr uint32_t SPAN = 2 * BLOCK;                            // bases per chunk
-    const uint64_t n_chunks = a.total / SPAN;                       // full chunks only
-    const uint32_t ctx_mask = (W >= 16) ? 0xffffffffu : ((1u << (2 * W)) - 1u);
-    const uint32_t sh_f = 2u * (uint32_t)(W - 1);                   // bit offset of S[p] in the window word
-    // A lane takes its leaf value from LDS when the row is cached and from L2 otherwise; the other
-    // source is pointed at a word that holds +0.0f, so the value is simply the OR of the two loads
-    // (no per-lane select, no flags to carry through the pipeline).
-    const uint32_t lds_zero = n_cached * 16u;                       // zero row right after the cached rows
-    const uint32_t l2_zero = (uint32_t)(((size_t)a.gene.P * a.gene.ctot -
-                                         ((size_t)ftype * a.gene.ctot + f6_level_base(DT))) * 16);   // zero row after crow
-
-    // lane constants: this lane's two bases are chunk*SPAN + lane_off (+1); its window starts W-1
-    // bases earlier, at word (chunk*SPAN/16 - 1) + wword, bit wsh (the -1 keeps wword >= 0)
-    const uint32_t lane_off = 2 * threadIdx.x;
-    const uint32_t first_rel = lane_off + 16u - (uint32_t)(W - 1);
-    const uint32_t wword = first_rel >> 4;
-    const uint32_t wsh = 2u * (first_rel & 15u);
-    double *const out_f = a.out + (uint64_t)ftype * a.total;
-    double *const out_r = a.out + (uint64_t)(3 + ftype) * a.total;
-
-    uint32_t raw_a[3] = {0, 0, 0}, raw_b[3] = {0, 0, 0}, raw_c[3] = {0, 0, 0};     // stage A -> B
-    F6Pend pend_a, pend_b, pend_c;                                                 // stage B -> C
-
-    auto load_raw = [&](uint64_t chunk, uint32_t (&w)[3]) __attribute__((always_inline)) {
-        const uint32_t *base = a.packed + chunk * (SPAN / 16) - 1;  // wave-uniform
-        w[0] = base[wword]; w[1] = base[wword + 1]; w[2] = base[wword + 2];
-    };
-
-    auto issue = [&](const uint32_t (&w)[3], F6Pend &pd) __attribute__((always_inline)) {   // stage B
-        // window of this lane: field i (bits 2i, 2i+1) = base g0-(W-1)+i, 32 fields
-        const uint32_t xl = __builtin_amdgcn_alignbit(w[1], w[0], wsh);
-        const uint32_t xh = __builtin_amdgcn_alignbit(w[2], w[1], wsh);
-        uint32_t C[4];
-        // complemented buffer: window char k = comp(S[p-(W-1)+k]) = ~field k
-        C[1] = ~xl & ctx_mask;
-        C[3] = ~__builtin_amdgcn_alignbit(xh, xl, 2) & ctx_mask;
-        // reversed buffer: window char k = S[p+W-1-k] = field (W-1)+(W-1-k); kept in natural order
-        // (field i = S[p+i]) and read through the mirrored shift table
-        C[0] = __builtin_amdgcn_alignbit(xh, xl, sh_f) & ctx_mask;
-        C[2] = __builtin_amdgcn_alignbit(xh, xl, sh_f + 2) & ctx_mask;
-
-        uint32_t idx[4];
-        idx[0] = f6_descend<DT>(s_shf, C[0], shift0_f);
-        idx[1] = f6_descend<DT>(s_shr, C[1], shift0_r);
-        idx[2] = f6_descend<DT>(s_shf, C[2], shift0_f);
-        idx[3] = f6_descend<DT>(s_shr, C[3], shift0_r);
-
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const bool fwd = (c & 1) == 0;
-            // predicted base: S[p] is field 0 of the natural-order word, window char W-1 of the other
-            const uint32_t pred = fwd ? (C[c] & 3u) : (C[c] >> sh_f);
-            const uint32_t tb = ((idx[c] << 2) | pred) << 2;        // byte offset of the value in the leaf rows
-            const bool m = idx[c] >= n_cached;
-            if (DIAG & 2) {
-                pd.l[c] = __uint_as_float(tb);
-                pd.g[c] = 0.f;
-            } else {
-                // both loads are unconditional (fixed load count per iteration)
-                pd.l[c] = *(const float *)(s_leaf + (m ? lds_zero : tb));
-                pd.g[c] = *(const float *)((const uint8_t *)leaf_rows + (m ? tb : l2_zero));
-            }
-            // null model: last three window chars.  complemented: chars W-3..W-1 = fields W-3..W-1;
-            // reversed (natural order): S[p+2], S[p+1], S[p] = fields 2,1,0 through the mirrored table
-            const uint32_t nidx = fwd ? (C[c] & 63u) : (C[c] >> (sh_f - 4));
-            pd.n[c] = fwd ? s_nf[nidx] : s_nr[nidx];
-        }
-    };
-
-    auto finish = [&](uint64_t chunk, const F6Pend &pd) __attribute__((always_inline)) {    // stage C
-        double v[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const float gv = __uint_as_float(__float_as_uint(pd.l[c]) | __float_as_uint(pd.g[c]));
-            v[c] = (double)gv - pd.n[c];                            // glimmer-mg.cc:1493,1508
-        }
-        if (DIAG & 1) {
-            if (v[0] + v[1] + v[2] + v[3] == 1.2345e300) a.out[lane_off] = v[0];
-            return;
-        }
-        double *pf = out_f + chunk * SPAN, *pr = out_r + chunk * SPAN;   // wave-uniform bases + lane offset
-        if (PAIR) {
-            *(double2 *)(pf + lane_off) = make_double2(v[0], v[2]);
-            *(double2 *)(pr + lane_off) = make_double2(v[1], v[3]);
-        } else {
-            pf[lane_off] = v[0]; pf[lane_off + 1] = v[2];
-            pr[lane_off] = v[1]; pr[lane_off + 1] = v[3];
-        }
-    };
-
-    if (worker >= n_chunks) return;
-    const uint64_t stride = nworkers;
-    // Vector-memory operations complete in issue order on gfx9 (one vmcnt for loads and stores), so a
-    // load cannot return before every OLDER store is acknowledged.  Both kinds of load are therefore
-    // issued two iterations before their use (packed words: prefetch distance 2; leaf rows: retired
-    // two iterations later), which leaves the stores of an iteration two iterations to drain.
-    auto chunk_at = [&](uint64_t c) { return c < n_chunks ? c : n_chunks - 1; };   // past the end: re-read, unused
-    load_raw(worker, raw_a);
-    load_raw(chunk_at(worker + stride), raw_b);
-    uint64_t chunk = worker, k = 0;
-    int phase = 0;
-    while (true) {
-        load_raw(chunk_at(chunk + 2 * stride), raw_c);
-        issue(raw_a, pend_a);
-        if (k >= 2) finish(chunk - 2 * stride, pend_b);
-        k++; phase = 1; chunk += stride;
-        if (chunk >= n_chunks) break;
-
-        load_raw(chunk_at(chunk + 2 * stride), raw_a);
-        issue(raw_b, pend_b);
-        if (k >= 2) finish(chunk - 2 * stride, pend_c);
-        k++; phase = 2; chunk += stride;
-        if (chunk >= n_chunks) break;
-
-        load_raw(chunk_at(chunk + 2 * stride), raw_b);
-        issue(raw_c, pend_c);
-        if (k >= 2) finish(chunk - 2 * stride, pend_a);
-        k++; phase = 0; chunk += stride;
-        if (chunk >= n_chunks) break;
-    }
-    // drain: the last two issued sets, oldest first (`chunk` is one stride past the last chunk)
-    const uint64_t c1 = chunk - stride, c2 = chunk - 2 * stride;
-    if (phase == 1) { if (k >= 2) finish(c2, pend_c); finish(c1, pend_a); }
-    else if (phase == 2) { if (k >= 2) finish(c2, pend_a); finish(c1, pend_b); }
-    else { if (k >= 2) finish(c2, pend_b); finish(c1, pend_c); }
 }
 
 // ---------------------------------------------------------------------------
@@ -268,7 +78,9 @@ __global__ __launch_bounds__(BLOCK) void k_frame6s(Frame6Args a)
 // Vector memory sees only coalesced traffic: the half reloads, the staged packed words and the
 // output stores; phase 1 of the next round (pure LDS + VALU) overlaps the draining stores.
 // ---------------------------------------------------------------------------
-template <int BLOCK, int DT, int K, int DIAG, bool PAIR>
+// GENE_ONLY: write the gene model's value alone, as fp32, to a.out_gene (input of the fused Score_Orfs scan,
+// gmg_orfs.hip); the null model is not touched.
+template <int BLOCK, int DT, int K, int DIAG, bool PAIR, bool GENE_ONLY>
 __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
 {
     constexpr int CS = f6_cstride(DT);
@@ -322,8 +134,8 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
             const uint32_t mirrored = ((i & 3u) << 4) | (i & 12u) | (i >> 4);
             // both tables are indexed with plain (uncomplemented) read bases: s_nr[i] is the entry of the
             // complemented window i ^ 63, s_nf[i] the entry of the mirrored window
-            s_nr[i] = (double)a.nul.dense[(size_t)ftype * 64 + (i ^ 63u)];
-            s_nf[i] = (double)a.nul.dense[(size_t)ftype * 64 + mirrored];
+            s_nr[i] = GENE_ONLY ? 0.0 : (double)a.nul.dense[(size_t)ftype * 64 + (i ^ 63u)];
+            s_nf[i] = GENE_ONLY ? 0.0 : (double)a.nul.dense[(size_t)ftype * 64 + mirrored];
         }
         load_half(0);
         load_raw_round(0);
@@ -406,7 +218,20 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
                     v[c] = (double)gv - nv;                         // glimmer-mg.cc:1493,1508
                 }
                 const uint64_t chunk = worker + (uint64_t)(j0 + k) * nworkers;
-                if (DIAG & 1) {
+                if (GENE_ONLY) {
+                    // v[c] = gene value exactly (the null tables hold zeros); rows of floats, 8-byte stores
+                    float *gf = a.out_gene + (uint64_t)ftype * a.total + chunk * SPAN;
+                    float *gr = a.out_gene + (uint64_t)(3 + ftype) * a.total + chunk * SPAN;
+                    if (PAIR) {
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        const f2 x0 = {(float)v[0], (float)v[2]}, x1 = {(float)v[1], (float)v[3]};
+                        __builtin_nontemporal_store(x0, (f2 *)(gf + lane_off));
+                        __builtin_nontemporal_store(x1, (f2 *)(gr + lane_off));
+                    } else {
+                        gf[lane_off] = (float)v[0]; gf[lane_off + 1] = (float)v[2];
+                        gr[lane_off] = (float)v[1]; gr[lane_off + 1] = (float)v[3];
+                    }
+                } else if (DIAG & 1) {
                     if (v[0] + v[1] + v[2] + v[3] == 1.2345e300) a.out[lane_off] = v[0];
                 } else {
                     double *pf = out_f + chunk * SPAN, *pr = out_r + chunk * SPAN;   // wave-uniform bases + lane offset
@@ -567,6 +392,11 @@ __global__ __launch_bounds__(256) void k_frame6_generic(Frame6Args a)
         DevBuf bf = dev_make_buf(a.packed, r_off, 0, (uint32_t)L, GMG_REVERSED);
         DevBuf br = dev_make_buf(a.packed, r_off, 0, (uint32_t)L, GMG_COMPLEMENTED);
         for (int f = 0; f < 3; f++) {
+            if (a.out_gene) {
+                a.out_gene[(uint64_t)f * a.total + g] = dev_score(a.gene, bf, L - 1 - p, f);
+                a.out_gene[(uint64_t)(3 + f) * a.total + g] = dev_score(a.gene, br, p, f);
+                continue;
+            }
             a.out[(uint64_t)f * a.total + g] =
                 (double)dev_score(a.gene, bf, L - 1 - p, f) - (double)dev_score(a.nul, bf, L - 1 - p, f);
             a.out[(uint64_t)(3 + f) * a.total + g] =
@@ -601,7 +431,7 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
     a.first = 0;
     a.count = 0;
     a.out = d_out;
-    a.n_cached = 0;
+    a.out_gene = nullptr;
 
     // the specialised path: completed tree of depth 7 (DEFAULT_MODEL_DEPTH) and the width-3 null model
     const bool fast = gene->dev.has_fast && gene->dev.D == 7 && nul->dev.has_dense && nul->dev.W == 3 &&
@@ -614,8 +444,6 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
     const char *env = getenv("GMG_DIAG");
     const int diag = env ? atoi(env) : 0;
     const bool pair = (a.total & 1) == 0;
-    const char *var = getenv("GMG_F6");                // profiling aid: "gather" selects k_frame6s
-    const bool use_swap = !(var && var[0] == 'g');
     if (n_chunks > 0) {
         int dev = 0, n_cu = 256;
         GMG_HIP(hipGetDevice(&dev));
@@ -625,53 +453,20 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
         if (nworkers < 1) nworkers = 1;
         if (nworkers > n_chunks) nworkers = (unsigned)n_chunks;
         const unsigned grid = 3 * nworkers;
-        if (use_swap) {
-            constexpr int KR = 16;
-            const size_t lds = ((size_t)1 << (2 * DT)) / 2 * 16;       // dynamic part: half of the leaf rows
-#define GMG_LAUNCH_F6TK(KR_, DIAG_, P_)                                                                 \
+        constexpr int KR = 16;                                     // chunks per round (8 / 12 / 20 measured slower)
+        const size_t lds = ((size_t)1 << (2 * DT)) / 2 * 16;       // dynamic part: half of the leaf rows
+#define GMG_LAUNCH_F6T(DIAG_, P_)                                                                       \
     do {                                                                                                \
-        GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR_, DIAG_, P_>,                 \
+        GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, DIAG_, P_, false>,           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR_, DIAG_, P_>), dim3(grid), dim3(BLOCK), lds, s, a); \
+        hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, DIAG_, P_, false>), dim3(grid), dim3(BLOCK), lds, s, a); \
     } while (0)
-#define GMG_LAUNCH_F6T(DIAG_, P_) GMG_LAUNCH_F6TK(KR, DIAG_, P_)
-            const char *ke = getenv("GMG_K");               // profiling aid: chunks per round
-            const int kr = ke ? atoi(ke) : KR;
-            if (diag == 0 && pair && kr == 8) GMG_LAUNCH_F6TK(8, 0, true);
-            else if (diag == 0 && pair && kr == 12) GMG_LAUNCH_F6TK(12, 0, true);
-            else if (diag == 0 && pair && kr == 20) GMG_LAUNCH_F6TK(20, 0, true);
-            else if (diag == 0) { if (pair) GMG_LAUNCH_F6T(0, true); else GMG_LAUNCH_F6T(0, false); }
-            else if (diag == 1 && pair) GMG_LAUNCH_F6T(1, true);
-            else if (diag == 2 && pair) GMG_LAUNCH_F6T(2, true);
-            else if (diag == 3 && pair) GMG_LAUNCH_F6T(3, true);
-            else return gmg_set_error(GMG_EINVAL, "GMG_DIAG=%d is not a built ablation", diag);
+        if (diag == 0) { if (pair) GMG_LAUNCH_F6T(0, true); else GMG_LAUNCH_F6T(0, false); }
+        else if (diag == 1 && pair) GMG_LAUNCH_F6T(1, true);
+        else if (diag == 2 && pair) GMG_LAUNCH_F6T(2, true);
+        else if (diag == 3 && pair) GMG_LAUNCH_F6T(3, true);
+        else return gmg_set_error(GMG_EINVAL, "GMG_DIAG=%d is not a built ablation", diag);
 #undef GMG_LAUNCH_F6T
-#undef GMG_LAUNCH_F6TK
-        } else {
-            const size_t lds_max = 160 * 1024;
-            const size_t static_lds = 2 * (size_t)f6_cstride(DT) + 2 * 64 * sizeof(double);
-            size_t n_cached = (lds_max - static_lds) / 16 - 1;   // one more row holds zeros
-            const size_t n_leaf = (size_t)1 << (2 * DT);
-            if (n_cached > n_leaf) n_cached = n_leaf;
-            if (const char *e = getenv("GMG_NCACHED")) {       // profiling aid: shrink the LDS leaf cache
-                size_t v = (size_t)atol(e);
-                if (v >= 1 && v < n_cached) n_cached = v;
-            }
-            a.n_cached = (int)n_cached;
-            const size_t lds = (n_cached + 1) * 16;            // dynamic part: cached rows + the zero row
-#define GMG_LAUNCH_F6(DIAG_, P_)                                                                        \
-    do {                                                                                                \
-        GMG_HIP(hipFuncSetAttribute((const void *)k_frame6s<BLOCK, DT, DIAG_, P_>,                      \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        hipLaunchKernelGGL((k_frame6s<BLOCK, DT, DIAG_, P_>), dim3(grid), dim3(BLOCK), lds, s, a);      \
-    } while (0)
-            if (diag == 0) { if (pair) GMG_LAUNCH_F6(0, true); else GMG_LAUNCH_F6(0, false); }
-            else if (diag == 1 && pair) GMG_LAUNCH_F6(1, true);
-            else if (diag == 2 && pair) GMG_LAUNCH_F6(2, true);
-            else if (diag == 3 && pair) GMG_LAUNCH_F6(3, true);
-            else return gmg_set_error(GMG_EINVAL, "GMG_DIAG=%d is not a built ablation", diag);
-#undef GMG_LAUNCH_F6
-        }
         GMG_HIP(hipGetLastError());
     }
     // the last, partial chunk
@@ -686,4 +481,51 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
         GMG_HIP(hipGetLastError());
     }
     return GMG_OK;
+}
+
+// Gene-only per-position values of every base, fp32, rows [6][total] like Frame_Scores: the values
+// ICM_t::Frame_Score(buffer, f) gives with the gene model alone for the reversed (rows 0-2) and the
+// complemented (rows 3-5) read.  Bases whose window leaves their read hold a meaningless value
+// (no partial-window pass here): the caller (gmg_score_orfs) never reads them.
+// Returns GMG_EBADMODEL when the model shape has no fast path (the caller then takes its exact path).
+int gmg_launch_gene6(const gmg_model *gene, const gmg_reads *reads, float *d_gene, hipStream_t s)
+{
+    if (!(gene->dev.has_fast && gene->dev.D == 7 && gene->dev.W >= 3 && gene->dev.W <= 15 && gene->dev.P >= 3))
+        return GMG_EBADMODEL;
+    Frame6Args a;
+    a.gene = gene->dev;
+    a.nul = gene->dev;                                 // not used in gene-only mode
+    a.packed = reads->d_packed;
+    a.off = reads->d_off;
+    a.tile_read = reads->d_tile_read;
+    a.total = reads->total_bases;
+    a.n_reads = reads->n_reads;
+    a.first = 0;
+    a.count = 0;
+    a.out = nullptr;
+    a.out_gene = d_gene;
+    constexpr int BLOCK = 1024, DT = 7, KR = 16;
+    constexpr uint32_t SPAN = 2 * BLOCK;
+    const uint64_t n_chunks = a.total / SPAN;
+    if (n_chunks > 0) {
+        int dev = 0, n_cu = 256;
+        GMG_HIP(hipGetDevice(&dev));
+        GMG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        unsigned nworkers = (unsigned)(n_cu / 3);
+        if (nworkers < 1) nworkers = 1;
+        if (nworkers > n_chunks) nworkers = (unsigned)n_chunks;
+        const unsigned grid = 3 * nworkers;
+        const size_t lds = ((size_t)1 << (2 * DT)) / 2 * 16;
+        if ((a.total & 1) == 0) {
+            GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, true, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, 0, true, true>), dim3(grid), dim3(BLOCK), lds, s, a);
+        } else {
+            GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, false, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, 0, false, true>), dim3(grid), dim3(BLOCK), lds, s, a);
+        }
+        GMG_HIP(hipGetLastError());
+    }
+    return launch_generic(a, n_chunks * SPAN, a.total - n_chunks * SPAN, s);
 }

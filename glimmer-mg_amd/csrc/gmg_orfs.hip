@@ -7,18 +7,30 @@
 
 #include "gmg_device.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <float.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <vector>
 
+struct OrfTmp { double s; int32_t which, pad; };   // one in-frame position of the ascending pass
+
 struct gmg_orf_batch {
+    float *d_gene6;              // fused path: per-base gene values, [6][total_bases] (allocated on first use)
+    OrfTmp *d_tmp;               // fused path: one slot per in-frame position, same offsets as the start lists
     gmg_orf *d_orfs;
     gmg_segments *segs;          // the ORF buffers as segments (REVERSED / COMPLEMENTED)
     uint64_t *d_start_off;       // [n+1] first slot of each ORF's start list
     double *d_score, *d_indep;   // cumulative scores, segs->total_len each
     gmg_orf_result *d_results;
-    gmg_start *d_starts;
+    gmg_start *d_starts;         // one region of orf_len/3+2 slots per ORF, filled from its front
+    uint32_t *d_nst, *d_coff;    // [n+1] starts per ORF and their exclusive prefix sum (compaction)
+    void *d_scan_tmp;
+    size_t scan_tmp_bytes;
+    gmg_start *d_compact;        // the used slots back to back: what leaves the GPU (grown on demand)
+    uint64_t compact_cap;
     uint64_t n, max_starts;
 };
 
@@ -31,6 +43,7 @@ struct OrfScanArgs {
     const double *score, *indep;
     gmg_orf_result *results;
     gmg_start *starts;
+    uint32_t *nst;
     uint64_t n;
     int min_gene_len, allow_truncated, use_first_start, ignore_score_len;
     double start_threshold;
@@ -50,7 +63,162 @@ static unsigned ch_mask(int ch)
     return 0;
 }
 
-// one lane per ORF
+// ---------------------------------------------------------------------------
+// Fused path (default 12/7/3 gene model + width-3 null model): no per-base scratch at all.
+//   k_frame6t<GENE_ONLY> (gmg_frame6.hip) first writes the gene model's per-base values of the whole
+//   batch as fp32 rows [6][total] at the six-frame kernel's speed; buffer positions j >= W-1 of any ORF
+//   see exactly the whole-read window, so their value is row (1+j)%3 (+3 for reverse ORFs) at that base.
+//   k_orf_fused, one lane per ORF, walks the buffer ONCE from j = 0: the first W-1 values by the
+//   partial-window descent (shift tables in LDS, row from crow), the rest from the rows; null values
+//   from the 64-entry tables; both running sums in double in reference order (bit-identical to
+//   Cumulative_Score).  At every in-frame position it parks score[j-1]-indep[j-1] and the start-codon
+//   match in a small temp list, then replays that list from the 3' end with the reference's
+//   first / best / truncated-start logic (glimmer3.cc:1355-1429).
+// ---------------------------------------------------------------------------
+struct OrfFusedArgs {
+    OrfScanArgs sc;
+    GmgDevModel gene, nul;
+    const float *gene6;
+    uint64_t total;
+    OrfTmp *tmp;
+};
+
+__global__ __launch_bounds__(256) void k_orf_fused(OrfFusedArgs fa)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
+    const OrfScanArgs &a = fa.sc;
+    const int cstride = fa.gene.cstride;
+    uint8_t *s_shift = s_lds;                                       // [3][cstride]
+    float *s_dense = (float *)(s_lds + 3 * cstride);                // [3][64]
+    float *s_part = s_dense + 3 * 64;                               // [3][20]
+    for (int i = threadIdx.x * 16; i < 3 * cstride; i += 256 * 16) *(uint4 *)(s_shift + i) = *(const uint4 *)(fa.gene.cshift + i);
+    for (int i = threadIdx.x; i < 3 * 64; i += 256) s_dense[i] = fa.nul.dense[i];
+    for (int i = threadIdx.x; i < 3 * 20; i += 256) s_part[i] = fa.nul.dense_part[i];
+    __syncthreads();
+
+    const int W = fa.gene.W, D = fa.gene.D;
+    const uint32_t sh_top = 2u * (uint32_t)(W - 1);
+    const uint32_t ctot = (uint32_t)fa.gene.ctot;
+
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const gmg_orf orf = a.orfs[i];
+        const uint64_t r_off = a.read_off[orf.read];
+        const int L = (int)(a.read_off[orf.read + 1] - r_off);
+        const int len = orf.orf_len;
+        const bool fwd = orf.frame > 0;
+        int lo, hi, k0;
+        bool trunc;
+        if (fwd) { hi = orf.stop_position - 1; lo = hi - len; trunc = lo < 3 && a.allow_truncated; k0 = orf.stop_position - len - 2; }
+        else { lo = orf.stop_position + 2; hi = lo + len; trunc = L - hi < 3 && a.allow_truncated; k0 = orf.stop_position + len + 4; }
+        OrfTmp *tmp = fa.tmp + a.start_off[i];
+        const int lowest_j = a.min_gene_len - 3 < 3 ? a.min_gene_len - 3 : 3;
+        const float *rows = fa.gene6 + (fwd ? 0 : 3) * fa.total;
+        // in-frame positions that can carry a start: j % 3 == 0, j >= lowest_j (>= 1), j + 3 >= Min_Gene_Len
+        int j_lo = lowest_j > 1 ? lowest_j : 1;
+        if (j_lo + 3 < a.min_gene_len) j_lo = a.min_gene_len - 3;
+        j_lo = (j_lo + 2) / 3 * 3;
+
+        // ---- pass 1, ascending: running sums, one temp entry per in-frame position (entry t <-> j_lo + 3t)
+        double gsum = 0.0, nsum = 0.0;
+        uint32_t C = 0;              // window register: char k of the window ending at j in bits [2k, 2k+1]
+        uint32_t masks = 0;          // Ch_Mask nibbles of the last three buffer chars, newest in bits 8-11
+        int f = 1, jm3 = 0, n_tmp = 0;
+        uint64_t g = r_off + (uint64_t)(fwd ? hi - 1 : lo);         // base of buffer position 0
+        for (int j = 0; j < len; j++) {
+            const int code0 = dev_code(a.packed, g);
+            const int code = fwd ? code0 : 3 - code0;
+            C = (C >> 2) | ((uint32_t)code << sh_top);
+            masks = (masks >> 4) | ((1u << code) << 8);
+            // the codon that starts at in-frame position j-2 is (buff[j], buff[j-1], buff[j-2]) as Codon_t holds it
+            // after Shift_In of buff[m-1] .. buff[j-2]: buff[j] in bits 8-11, buff[j-2] in bits 0-3 == masks
+            if (jm3 == 2 && j - 2 >= j_lo) {
+                int which = -1;                                     // Codon_t::Can_Be (gene.cc:39-66)
+                for (int p = 0; p < a.n_pat; p++) {
+                    const uint32_t x = masks & a.pat[p];
+                    if ((x & 0xf00u) && (x & 0xf0u) && (x & 0x0fu)) { which = p; break; }
+                }
+                tmp[n_tmp - 1].which = which;
+            }
+            if (jm3 == 0 && j >= j_lo) {
+                tmp[n_tmp].s = gsum - nsum;                          // score[j-1] - indep_score[j-1]
+                tmp[n_tmp].which = -1;                               // until buff[j+2] has been seen
+                n_tmp++;
+            }
+            // gene value of buffer position j under sub-model f
+            float gv;
+            if (j >= W - 1) {
+                gv = rows[(uint64_t)f * fa.total + g];
+            } else {
+                const uint8_t *tab = s_shift + f * cstride;
+                const int thr2 = 2 * ((W - 1) - j);
+                uint32_t idx = 0, lvl = 0, width = 1, node = 0xffffffffu;
+                for (int l = 0; l < D; l++) {
+                    const uint32_t sh = tab[lvl + idx];
+                    if (node == 0xffffffffu && (int)sh < thr2) node = lvl + idx;
+                    idx = (idx << 2) + ((C >> sh) & 3u);
+                    lvl += width;
+                    width <<= 2;
+                }
+                if (node == 0xffffffffu) node = lvl + idx;
+                gv = fa.gene.crow[((size_t)f * ctot + node) * 4 + code];
+            }
+            // null value: last three buffer chars (window char k at bits 2k), partial tables for j < 2
+            float nv;
+            if (j >= 2) nv = s_dense[f * 64 + (C >> (sh_top - 4))];
+            else if (j == 1) nv = s_part[f * 20 + 4 + (C >> (sh_top - 2))];
+            else nv = s_part[f * 20 + code];
+            gsum += (double)gv;
+            nsum += (double)nv;
+            f = f == 2 ? 0 : f + 1;
+            jm3 = jm3 == 2 ? 0 : jm3 + 1;
+            g += fwd ? (uint64_t)-1 : (uint64_t)1;
+        }
+
+        // ---- pass 2, from the 3' end: the reference's scan over the in-frame positions (glimmer3.cc:1355-1429)
+        gmg_start *out = a.starts + a.start_off[i];
+        uint32_t n_starts = 0;
+        int first_pos = 0, best_pos = 0, first_j = 0, best_j = 0;
+        bool first_trunc = false, best_trunc = false;
+        double first_score = -DBL_MAX, best_score = -DBL_MAX;
+        for (int t = n_tmp - 1; t >= 0; t--) {
+            const int j = j_lo + 3 * t;
+            const int k = fwd ? k0 + (len - 1 - j) : k0 - (len - 1 - j);
+            const int which = tmp[t].which;
+            if (which >= 0 || (first_pos == 0 && trunc)) {
+                const double next_s = tmp[t].s;
+                const double pushed = (j + 2 > a.ignore_score_len && next_s < 0.0) ? 0.0 : next_s;
+                gmg_start st;
+                st.score = pushed; st.j = j + 2; st.pos = k; st.first = (first_pos == 0);
+                if (which >= 0 && first_pos == 0 && trunc) {
+                    st.which = -1; st.truncated = 1;
+                    out[n_starts++] = st;
+                    st.first = 0;
+                }
+                st.which = which; st.truncated = (which < 0);
+                out[n_starts++] = st;
+                if (first_pos == 0) { first_score = next_s; first_pos = k; first_j = j + 2; first_trunc = (first_pos == 0 && trunc); }
+                if (next_s > best_score) { best_score = next_s; best_pos = k; best_j = j + 2; best_trunc = st.truncated; }
+            }
+        }
+        if (a.use_first_start) { best_score = first_score; best_pos = first_pos; best_j = first_j; best_trunc = first_trunc; }
+        (void)best_trunc;
+        gmg_orf_result res;
+        res.start_begin = (uint32_t)a.start_off[i];
+        res.first_j = first_j; res.best_j = best_j; res.best_pos = best_pos;
+        res.best_score = best_score;
+        res.orf_is_truncated = trunc;
+        if (first_j + 1 < a.min_gene_len) { res.n_starts = 0; res.is_tentative_gene = 0; res.gene_score = 0.0; }
+        else {
+            res.n_starts = n_starts;
+            res.is_tentative_gene = best_score > a.start_threshold;
+            res.gene_score = 100.0 * best_score / (best_j - 2);
+        }
+        a.results[i] = res;
+        a.nst[i] = res.n_starts;
+    }
+}
+
+// exact any-shape path: cumulative scores in scratch (k_seg_cum), then one lane per ORF scans them
 __global__ __launch_bounds__(256) void k_orf_scan(OrfScanArgs a)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -133,6 +301,19 @@ __global__ __launch_bounds__(256) void k_orf_scan(OrfScanArgs a)
             res.gene_score = 100.0 * best_score / (best_j - 2);        // glimmer3.cc:1489
         }
         a.results[i] = res;
+        a.nst[i] = res.n_starts;
+    }
+}
+
+// start lists -> back to back, in ORF order; start_begin now indexes the compact array
+__global__ __launch_bounds__(256) void k_orf_compact(const gmg_start *sparse, const uint64_t *start_off, const uint32_t *coff,
+                                                     gmg_orf_result *results, gmg_start *compact, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t cnt = results[i].n_starts, dst = coff[i];
+        const gmg_start *src = sparse + start_off[i];
+        for (uint32_t t = 0; t < cnt; t++) compact[dst + t] = src[t];
+        results[i].start_begin = dst;
     }
 }
 
@@ -162,7 +343,7 @@ extern "C" int gmg_orfs_upload(const gmg_reads *reads, const gmg_orf *orfs, uint
         segs[i].orient = o.frame > 0 ? GMG_REVERSED : GMG_COMPLEMENTED;     // glimmer3.cc:1328,1339
         start_off[i + 1] = start_off[i] + (uint64_t)o.orf_len / 3 + 2;     // one per in-frame codon + a truncated start
     }
-    if (start_off[n] >= 0xffffffffull) return gmg_set_error(GMG_EINVAL, "gmg_orfs_upload: batch too large");
+    if (start_off[n] >= 0xffffffffull || n >= 0x7fffffffull) return gmg_set_error(GMG_EINVAL, "gmg_orfs_upload: batch too large");
     gmg_orf_batch *b = new (std::nothrow) gmg_orf_batch();
     if (!b) return gmg_set_error(GMG_ENOMEM, "gmg_orfs_upload: out of host memory");
     memset(b, 0, sizeof *b);
@@ -170,13 +351,15 @@ extern "C" int gmg_orfs_upload(const gmg_reads *reads, const gmg_orf *orfs, uint
     b->max_starts = start_off[n];
     int rc = gmg_segments_upload(reads, segs.data(), n, nullptr, nullptr, &b->segs);
     if (rc) { delete b; return rc; }
-    const size_t tl = b->segs->total_len;
     hipError_t e = hipMalloc((void **)&b->d_orfs, (n ? n : 1) * sizeof(gmg_orf));
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_start_off, (n + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&b->d_score, (tl ? tl : 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&b->d_indep, (tl ? tl : 1) * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_results, (n ? n : 1) * sizeof(gmg_orf_result));
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_starts, (b->max_starts ? b->max_starts : 1) * sizeof(gmg_start));
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_nst, (n + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_coff, (n + 1) * 4);
+    if (e == hipSuccess) e = hipMemset(b->d_nst, 0, (n + 1) * 4);
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(nullptr, b->scan_tmp_bytes, b->d_nst, b->d_coff, (int)(n + 1));
+    if (e == hipSuccess) e = hipMalloc(&b->d_scan_tmp, b->scan_tmp_bytes ? b->scan_tmp_bytes : 1);
     if (e == hipSuccess && n) e = hipMemcpy(b->d_orfs, orfs, n * sizeof(gmg_orf), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_start_off, start_off.data(), (n + 1) * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) { gmg_orf_batch_free(b); return gmg_set_error(GMG_ENOMEM, "gmg_orfs_upload: %s", hipGetErrorString(e)); }
@@ -189,7 +372,8 @@ extern "C" int gmg_orf_batch_free(gmg_orf_batch *b)
 {
     if (!b) return GMG_OK;
     if (b->segs) gmg_segments_free(b->segs);
-    void *ptrs[] = {b->d_orfs, b->d_start_off, b->d_score, b->d_indep, b->d_results, b->d_starts};
+    void *ptrs[] = {b->d_orfs, b->d_start_off, b->d_score, b->d_indep, b->d_results, b->d_starts, b->d_gene6, b->d_tmp,
+                    b->d_nst, b->d_coff, b->d_scan_tmp, b->d_compact};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete b;
@@ -209,10 +393,29 @@ extern "C" int gmg_score_orfs(const gmg_model *gene, const gmg_model *nul, const
         return gmg_set_error(GMG_EBADMODEL, "gmg_score_orfs: frame 1 outside the models' periodicity");
     if (b->n == 0) return GMG_OK;
     hipStream_t s = (hipStream_t)stream;
-    int rc = gmg_launch_seg_cum(gene, reads, b->segs, gene->dev.P == 1 ? 0 : 1, b->d_score, nullptr, s);
-    if (rc) return rc;
-    rc = gmg_launch_seg_cum(nul, reads, b->segs, nul->dev.P == 1 ? 0 : 1, b->d_indep, nullptr, s);
-    if (rc) return rc;
+    gmg_orf_batch *mb = const_cast<gmg_orf_batch *>(b);            // scratch is allocated on first use
+    const bool fused = gene->dev.has_fast && gene->dev.D == 7 && gene->dev.P == 3 && gene->dev.W >= 3 && gene->dev.W <= 15 &&
+                       nul->dev.has_dense && nul->dev.W == 3 && nul->dev.P == 3 && !getenv("GMG_ORFS_EXACT_PATH");
+    if (fused) {
+        if (!mb->d_gene6) {
+            hipError_t e = hipMalloc((void **)&mb->d_gene6, (size_t)6 * reads->total_bases * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc((void **)&mb->d_tmp, (b->max_starts ? b->max_starts : 1) * sizeof(OrfTmp));
+            if (e != hipSuccess) return gmg_set_error(GMG_ENOMEM, "gmg_score_orfs: scratch: %s", hipGetErrorString(e));
+        }
+        int rc = gmg_launch_gene6(gene, reads, mb->d_gene6, s);
+        if (rc) return gmg_set_error(rc, "gmg_score_orfs: gene-only pass refused the model");
+    } else {
+        const size_t tl = b->segs->total_len;
+        if (!mb->d_score) {
+            hipError_t e = hipMalloc((void **)&mb->d_score, (tl ? tl : 1) * 8);
+            if (e == hipSuccess) e = hipMalloc((void **)&mb->d_indep, (tl ? tl : 1) * 8);
+            if (e != hipSuccess) return gmg_set_error(GMG_ENOMEM, "gmg_score_orfs: scratch: %s", hipGetErrorString(e));
+        }
+        int rc = gmg_launch_seg_cum(gene, reads, b->segs, gene->dev.P == 1 ? 0 : 1, b->d_score, nullptr, s);
+        if (rc) return rc;
+        rc = gmg_launch_seg_cum(nul, reads, b->segs, nul->dev.P == 1 ? 0 : 1, b->d_indep, nullptr, s);
+        if (rc) return rc;
+    }
 
     OrfScanArgs a;
     a.packed = reads->d_packed;
@@ -224,6 +427,7 @@ extern "C" int gmg_score_orfs(const gmg_model *gene, const gmg_model *nul, const
     a.indep = b->d_indep;
     a.results = b->d_results;
     a.starts = b->d_starts;
+    a.nst = b->d_nst;
     a.n = b->n;
     a.min_gene_len = prm->min_gene_len;
     a.allow_truncated = prm->allow_truncated;
@@ -239,10 +443,42 @@ extern "C" int gmg_score_orfs(const gmg_model *gene, const gmg_model *nul, const
     }
     const uint64_t blocks = (b->n + 255) / 256;
     const unsigned grid = (unsigned)(blocks < 256 * 16 ? blocks : 256 * 16);
-    hipLaunchKernelGGL(k_orf_scan, dim3(grid), dim3(256), 0, s, a);
+    if (fused) {
+        OrfFusedArgs fa;
+        fa.sc = a;
+        fa.gene = gene->dev;
+        fa.nul = nul->dev;
+        fa.gene6 = b->d_gene6;
+        fa.total = reads->total_bases;
+        fa.tmp = b->d_tmp;
+        const size_t lds = (size_t)3 * gene->dev.cstride + (3 * 64 + 3 * 20) * sizeof(float);
+        hipLaunchKernelGGL(k_orf_fused, dim3(grid), dim3(256), lds, s, fa);
+    } else {
+        hipLaunchKernelGGL(k_orf_scan, dim3(grid), dim3(256), 0, s, a);
+    }
+    GMG_HIP(hipGetLastError());
+    // only the used slots leave the GPU: prefix sum of the per-ORF counts, then pack the lists back to back
+    size_t tmp_bytes = b->scan_tmp_bytes;
+    GMG_HIP(hipcub::DeviceScan::ExclusiveSum(b->d_scan_tmp, tmp_bytes, b->d_nst, b->d_coff, (int)(b->n + 1), s));
+    uint32_t total = 0;
+    GMG_HIP(hipMemcpyAsync(&total, b->d_coff + b->n, 4, hipMemcpyDeviceToHost, s));
+    GMG_HIP(hipStreamSynchronize(s));
+    if (total > b->max_starts) return gmg_set_error(GMG_EHIP, "gmg_score_orfs: %u starts in %llu slots", total,
+                                                    (unsigned long long)b->max_starts);
+    if (total > b->compact_cap) {
+        if (mb->d_compact) (void)hipFree(mb->d_compact);
+        mb->d_compact = nullptr;
+        mb->compact_cap = 0;
+        const uint64_t cap = (uint64_t)total + total / 8 + 1024;
+        hipError_t e = hipMalloc((void **)&mb->d_compact, cap * sizeof(gmg_start));
+        if (e != hipSuccess) return gmg_set_error(GMG_ENOMEM, "gmg_score_orfs: start lists: %s", hipGetErrorString(e));
+        mb->compact_cap = cap;
+    }
+    hipLaunchKernelGGL(k_orf_compact, dim3(grid), dim3(256), 0, s, b->d_starts, b->d_start_off, b->d_coff, b->d_results,
+                       b->d_compact, b->n);
     GMG_HIP(hipGetLastError());
     GMG_HIP(hipMemcpyAsync(results, b->d_results, b->n * sizeof(gmg_orf_result), hipMemcpyDeviceToHost, s));
-    GMG_HIP(hipMemcpyAsync(starts, b->d_starts, b->max_starts * sizeof(gmg_start), hipMemcpyDeviceToHost, s));
+    if (total) GMG_HIP(hipMemcpyAsync(starts, b->d_compact, (size_t)total * sizeof(gmg_start), hipMemcpyDeviceToHost, s));
     GMG_HIP(hipStreamSynchronize(s));
     return GMG_OK;
 }

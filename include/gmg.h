@@ -229,7 +229,9 @@ int gmg_orf_batch_free(gmg_orf_batch *b);
 /* The scoring part of Score_Orfs for every ORF of the batch: ORF buffer (Reverse_Transfer /
  * Complement_Transfer), gene and null Cumulative_Score from frame 1, the start-codon scan from the
  * 3' end, first/best start, truncated starts, gene score and the tentative-gene test.  `results`
- * (n_orfs) and `starts` (out_max_starts) are HOST buffers: only these compact lists leave the GPU.
+ * (n_orfs) and `starts` (room for out_max_starts entries) are HOST buffers.  The start lists are packed
+ * back to back in ORF order on the device, so only sum(n_starts) entries are copied into `starts`
+ * (typically ~5 % of out_max_starts); results[i].start_begin indexes that packed array.
  * Events / DP / trace-back stay host code (src/Glimmer/glimmer_base.cc). */
 int gmg_score_orfs(const gmg_model *gene, const gmg_model *null_model, const gmg_reads *reads,
                    const gmg_orf_batch *orfs, const gmg_orf_params *params,

@@ -247,9 +247,15 @@ def test_frame6_full_size_properties(gpu, nc, oracle, o_nc):
 
 @pytest.mark.parametrize("name,kw", [("orfs_default", {}), ("orfs_X", {"allow_truncated": True}),
                                      ("orfs_g90_first", {"min_gene_len": 90, "use_first_start": True})])
-def test_score_orfs_golden_start_lists(gpu, nc, fa_reads, name, kw):
+@pytest.mark.parametrize("path", ["fused", "exact"])
+def test_score_orfs_golden_start_lists(gpu, nc, fa_reads, name, kw, path, monkeypatch):
     """ORFs from the reference's Find_Orfs on seqs.fa; start lists, gene score and gene length must equal
-    what the reference's Score_Orfs handed to Add_Events_* (tests/golden/orfs_*.npz), bit for bit."""
+    what the reference's Score_Orfs handed to Add_Events_* (tests/golden/orfs_*.npz), bit for bit --
+    through the fused path (gene-only six-frame pass + k_orf_fused) and the exact any-model path."""
+    if path == "exact":
+        monkeypatch.setenv("GMG_ORFS_EXACT_PATH", "1")
+    else:
+        monkeypatch.delenv("GMG_ORFS_EXACT_PATH", raising=False)
     g = np.load(os.path.join(GOLD, name + ".npz"))
     gc = float(np.load(os.path.join(GOLD, "frames_nc.npz"))["gc"])
     res, starts = gpu.score_orfs(nc, gpu.Icm.indep(gc), fa_reads, g["orfs"], **kw)
