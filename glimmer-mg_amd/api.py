@@ -312,6 +312,41 @@ def score_orfs(gene, null, reads, orfs, min_gene_len=75, allow_truncated=False, 
     return res, starts
 
 
+MG_ORF_DTYPE = np.dtype([("read", "<u4"), ("frame", "<i4"), ("stop_position", "<i4"), ("orf_len", "<i4"),
+                         ("gene_len", "<i4"), ("lo", "<i4"), ("hi", "<i4"), ("first_j", "<i4"),
+                         ("start_begin", "<u4"), ("n_starts", "<u4"), ("accepted", "<i2"),
+                         ("orf_is_truncated", "<i2"), ("reserved", "<i4"), ("best_score", "<f8")])
+
+
+def mg_score_reads(gene, null, reads, min_gene_len=75, allow_truncated=True, ignore_score_len=2**31 - 1,
+                   start_threshold=-6.0, start_codons=("atg", "gtg", "ttg"), stop_codons=("taa", "tag", "tga"),
+                   frame_scores=None):
+    """glimmer-mg's front half for a batch of reads (include/gmg.h: gmg_mg_score_reads): Score_All_Frames,
+    Find_Orfs, Score_Orf_Starts and the filter of Score_Orfs_Errors.
+    -> (orfs[MG_ORF_DTYPE], starts[START_DTYPE], read_orf_off[uint64 n_reads+1]).
+    frame_scores: optional _DeviceBuffer of 6*total_bases doubles that receives the Frame_Scores table."""
+    assert MG_ORF_DTYPE.itemsize == 56
+    prm = capi.MgParams(min_gene_len, int(allow_truncated), ignore_score_len, len(start_codons), len(stop_codons), 0,
+                        start_threshold)
+    for i, c in enumerate(start_codons):
+        prm.start_codon[i].value = c.encode()
+    for i, c in enumerate(stop_codons):
+        prm.stop_codon[i].value = c.encode()
+    res = C.c_void_p()
+    _ck(capi.lib().gmg_mg_score_reads(gene.device(), null.device(), reads.h, C.byref(prm),
+                                      frame_scores.ptr if frame_scores is not None else None, C.byref(res), None))
+    try:
+        n_orfs, n_starts = C.c_uint64(), C.c_uint64()
+        _ck(capi.lib().gmg_mg_result_info(res, C.byref(n_orfs), C.byref(n_starts)))
+        orfs = np.zeros(max(n_orfs.value, 1), MG_ORF_DTYPE)
+        starts = np.zeros(max(n_starts.value, 1), START_DTYPE)
+        off = np.zeros(reads.n_reads + 1, np.uint64)
+        _ck(capi.lib().gmg_mg_result_fetch(res, _ptr(orfs), _ptr(starts), _ptr(off)))
+    finally:
+        capi.lib().gmg_mg_result_free(res)
+    return orfs[:n_orfs.value], starts[:n_starts.value], off
+
+
 def window_distrib(model, windows, frames):
     """Full_Window_Distrib / Full_Window_Prob (icm.cc:512-610).  windows: uint8 codes [n, model_len]
     -> (dist float32 [n,4], prob float64 [n])"""

@@ -22,6 +22,13 @@ class OrfParams(C.Structure):
                 ("start_codon", (C.c_char * 4) * 8)]
 
 
+class MgParams(C.Structure):
+    _fields_ = [("min_gene_len", C.c_int32), ("allow_truncated", C.c_int32), ("ignore_score_len", C.c_int32),
+                ("n_start_codons", C.c_int32), ("n_stop_codons", C.c_int32), ("reserved", C.c_int32),
+                ("start_threshold", C.c_double), ("start_codon", (C.c_char * 4) * 8),
+                ("stop_codon", (C.c_char * 4) * 8)]
+
+
 PROTOTYPES = {
     # include/gmg.h
     "gmg_init": (i32, [i32]),
@@ -48,6 +55,10 @@ PROTOTYPES = {
     "gmg_segment_partial_prob": (i32, [vp, vp, vp, i32, vp, vp]),
     "gmg_all_frame_score": (i32, [vp, vp, vp, vp, vp, vp, vp]),
     "gmg_window_distrib": (i32, [vp, vp, vp, u64, vp, vp, vp]),
+    "gmg_mg_score_reads": (i32, [vp, vp, vp, vp, vp, C.POINTER(vp), vp]),
+    "gmg_mg_result_info": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
+    "gmg_mg_result_fetch": (i32, [vp, vp, vp, vp]),
+    "gmg_mg_result_free": (i32, [vp]),
     "gmg_orfs_upload": (i32, [vp, vp, u64, C.POINTER(u64), C.POINTER(vp)]),
     "gmg_orf_batch_free": (i32, [vp]),
     "gmg_score_orfs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),

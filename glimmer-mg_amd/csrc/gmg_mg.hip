@@ -1,0 +1,507 @@
+// gmg_mg.hip -- glimmer-mg's front half on gfx950: from packed reads to the start lists that
+// Score_Orfs_Errors (src/Glimmer/glimmer-mg.cc:1605-1689) hands to Add_Events_*.  Default mode only
+// (Allow_Indels = Allow_Subs = false, glimmer-mg.cc:100-102), linear sequences, no ignore regions.
+//
+//   1. gmg_launch_frame6        Score_All_Frames (glimmer-mg.cc:1468-1510): Frame_Scores[6][total] in HBM
+//   2. k_mg_find_orfs<count>    Find_Orfs (glimmer_base.cc:638-779), one lane per read: ORFs per read
+//      exclusive scan, k_mg_find_orfs<write>: the Orf_t records + lo / hi of Score_Orf_Starts
+//   3. k_mg_starts<count>       one lane per ORF: number of entries Score_Orf_Starts will push
+//      exclusive scan, k_mg_starts<write>: Cumulative_Frame_Score (glimmer-mg.cc:561-604) as sequential
+//      double adds over the ORF, the start list in push order, boost, first_j, best score, threshold.
+// Integer / byte work except the one running sum; no table of Save_Prev_Stops (glimmer-mg.cc:675-729) is
+// materialised -- the ORF scan already knows the previous / next in-frame stop of every ORF it emits:
+//   forward ORF ended by the stop whose last base is i (class c = i % 3):
+//       hi = end_point = i - 2;   lo = Fwd_Prev_Stops[i-3] + 1 = (last forward stop index of class c, or
+//       {0, 1, -1}[c] when there is none) + 1
+//   reverse ORF closed by the reverse stop whose last base is i:   lo = orf_stop + 3;
+//       hi = Rev_Next_Stops[orf_stop+2] + 1 = (i - 2) + 1        (the closing stop starts at i-2, same class)
+//   reverse ORF closed by the end of the read (Finish_Orfs):  e = orf_stop + 2;
+//       hi = e + 1 if e >= n, else {n-1, n-2, n}[(n-1-e) % 3] + 1 (no further stop in that class)
+// tests/test_gpu_mg.py checks these against the oracle's literal tables and the reference's own output.
+
+#include "gmg_device.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <float.h>
+#include <limits.h>
+#include <string.h>
+#include <new>
+
+struct gmg_mg_result {
+    gmg_mg_orf *d_orfs;
+    gmg_start *d_starts;
+    uint64_t *d_read_orf_off;    // [n_reads + 1]
+    uint64_t n_reads, n_orfs, n_starts;
+};
+
+struct MgArgs {
+    const uint32_t *packed;
+    const uint64_t *read_off;
+    uint64_t n_reads, total;
+    const double *fs;            // Frame_Scores [6][total]
+    // codon tests as 64-bit sets over idx6 = code(oldest) << 4 | code << 2 | code(newest)
+    uint64_t fwd_start, rev_start, fwd_stop, rev_stop;
+    int8_t which[64];            // index of the first matching start codon, -1 for none (Codon_t::Can_Be)
+    int min_gene_len, allow_truncated, ignore_score_len;
+    double start_threshold;
+    uint32_t *read_cnt;          // [n_reads + 1] ORFs per read -> exclusive scan in read_orf_off
+    const uint64_t *read_orf_off;
+    gmg_mg_orf *orfs;
+    uint64_t n_orfs;
+    uint32_t *orf_cnt;           // [n_orfs + 1] starts per ORF
+    const uint64_t *start_off;   // its exclusive scan
+    gmg_start *starts;
+};
+
+// Ch_Mask (src/Common/gene.cc:954-995)
+static unsigned mg_ch_mask(int ch)
+{
+    switch (ch | 0x20) {
+    case 'a': return 0x1; case 'c': return 0x2; case 'g': return 0x4; case 't': return 0x8;
+    case 'r': return 0x5; case 'y': return 0xA; case 's': return 0x6; case 'w': return 0x9;
+    case 'm': return 0x3; case 'k': return 0xC; case 'b': return 0xE; case 'd': return 0xD;
+    case 'h': return 0xB; case 'v': return 0x7; case 'n': return 0xF;
+    }
+    return 0;
+}
+
+// sequential reader of 2-bit codes, one 32-bit word per 16 bases; DIR = +1 / -1
+template <int DIR>
+struct BaseStream {
+    const uint32_t *packed;
+    uint64_t g;
+    uint32_t w;
+    __device__ __forceinline__ void init(const uint32_t *p, uint64_t g0) { packed = p; g = g0; w = p[g0 >> 4]; }
+    __device__ __forceinline__ int next()
+    {
+        const int code = (int)((w >> (2u * (unsigned)(g & 15))) & 3u);
+        if (DIR > 0) { g++; if ((g & 15) == 0) w = packed[g >> 4]; }        // the guard words make one word past the end readable
+        else { if ((g & 15) == 0) w = packed[(g >> 4) - 1]; g--; }
+        return code;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Find_Orfs: one lane per read.  Class c = i % 3 is static in the unrolled loop, so the per-class state
+// (glimmer_base.cc:647-652) lives in registers.
+// ---------------------------------------------------------------------------------------------------
+struct MgClass {
+    int first_fwd_start, last_rev_start, prev_fwd_stop, prev_rev_stop;
+    int fwd_last;                // Save_Prev_Stops' last_stops for the forward scan (glimmer-mg.cc:685-699)
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t off = a.read_off[r];
+        const int n = (int)(a.read_off[r + 1] - off);
+        const int mgl = a.min_gene_len;
+        const bool trunc = a.allow_truncated != 0;
+        uint32_t cnt = 0;
+        gmg_mg_orf *out = WRITE ? a.orfs + a.read_orf_off[r] : nullptr;
+
+        auto emit = [&](int stop_position, int frame, int gene_len, int orf_len, int lo, int hi) __attribute__((always_inline)) {
+            if (gene_len >= mgl) {                      // glimmer_base.cc:494,528,806 (no indel / substitution branch)
+                if (WRITE) {
+                    gmg_mg_orf o;
+                    o.read = (uint32_t)r; o.frame = frame; o.stop_position = stop_position;
+                    o.orf_len = orf_len; o.gene_len = gene_len; o.lo = lo; o.hi = hi;
+                    o.first_j = 0; o.start_begin = 0; o.n_starts = 0; o.accepted = 0; o.orf_is_truncated = 0;
+                    o.reserved = 0; o.best_score = -DBL_MAX;
+                    out[cnt] = o;
+                }
+                cnt++;
+            }
+        };
+        // Do_Fwd_Stop_Codon (glimmer_base.cc:460-504) + Handle_First_Forward_Stop, linear (:970-982)
+        auto fwd_stop = [&](int i, MgClass &S, int cls) __attribute__((always_inline)) {
+            int gene_len, orf_len;
+            if (S.prev_fwd_stop == 0) {
+                const int pos = i - 1;
+                orf_len = pos - 1;                      // first_base = 1
+                orf_len -= orf_len % 3;
+                gene_len = S.first_fwd_start == INT_MAX ? 0 : pos - S.first_fwd_start;
+                if (trunc && gene_len < mgl) gene_len = orf_len;
+            } else {
+                gene_len = (i - S.first_fwd_start) - 1;
+                orf_len = i - S.prev_fwd_stop - 4;
+            }
+            emit(i - 1, 1 + (cls + 1) % 3, gene_len, orf_len, S.fwd_last + 1, i - 2);
+            S.first_fwd_start = INT_MAX;
+            S.prev_fwd_stop = i - 1;
+        };
+        // Do_Rev_Stop_Codon (glimmer_base.cc:506-537) + Handle_First_Reverse_Stop (:989-1015)
+        auto rev_stop = [&](int i, MgClass &S, int cls) __attribute__((always_inline)) {
+            int gene_len, orf_stop = 0;
+            if (S.prev_rev_stop == 0) {
+                if (!trunc) gene_len = 0;
+                else {
+                    orf_stop = (i - 1) % 3;
+                    if (orf_stop > 0) orf_stop -= 3;
+                    gene_len = S.last_rev_start - orf_stop;
+                }
+            } else {
+                orf_stop = S.prev_rev_stop;
+                gene_len = S.last_rev_start - orf_stop;
+            }
+            emit(orf_stop, -1 - (cls + 1) % 3, gene_len, i - orf_stop - 4, orf_stop + 3, i - 1);
+            S.last_rev_start = 0;
+            S.prev_rev_stop = i - 1;
+        };
+
+        if (n >= mgl) {                                 // glimmer_base.cc:676-677
+            MgClass cs[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                cs[c].first_fwd_start = INT_MAX;
+                cs[c].last_rev_start = cs[c].prev_fwd_stop = cs[c].prev_rev_stop = 0;
+            }
+            cs[0].fwd_last = 0; cs[1].fwd_last = 1; cs[2].fwd_last = -1;
+            BaseStream<1> bs;
+            bs.init(a.packed, off);
+            uint32_t idx6 = 0;
+            for (int i0 = 0; i0 < n; i0 += 3) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const int i = i0 + c;
+                    if (i < n) {
+                        idx6 = ((idx6 << 2) | (uint32_t)bs.next()) & 63u;
+                        if (i >= 2) {                   // a Codon_t with an empty position matches nothing (gene.cc:56,85)
+                            const uint64_t bit = 1ull << idx6;
+                            if ((a.fwd_start & bit) && cs[c].first_fwd_start == INT_MAX) cs[c].first_fwd_start = i - 1;
+                            if (a.rev_start & bit) cs[c].last_rev_start = i - 1;
+                            if (a.fwd_stop & bit) { fwd_stop(i, cs[c], c); cs[c].fwd_last = i; }
+                            if (a.rev_stop & bit) rev_stop(i, cs[c], c);
+                        }
+                    }
+                }
+            }
+            // Finish_Orfs (glimmer_base.cc:783-817) + Handle_Last_Reverse_Stop, linear (:1053-1066)
+#pragma unroll
+            for (int fr = 0; fr < 3; fr++) {
+                const MgClass &S = cs[fr];
+                const int orf_stop = S.prev_rev_stop == 0 ? (fr == 0 ? -1 : fr == 1 ? 0 : -2) : S.prev_rev_stop;
+                int orf_len = n - orf_stop - 2;
+                orf_len -= orf_len % 3;
+                int gene_len = S.last_rev_start == 0 ? 0 : S.last_rev_start - orf_stop;
+                if (trunc && gene_len < mgl) gene_len = orf_len;
+                const int e = orf_stop + 2;             // Rev_Next_Stop (glimmer-mg.cc:1436-1445), no stop left in the class
+                int hi;
+                if (e >= n) hi = e + 1;
+                else { const int rc = (n - 1 - e) % 3; hi = (rc == 0 ? n - 1 : rc == 1 ? n - 2 : n) + 1; }
+                emit(orf_stop, -1 - (fr + 1) % 3, gene_len, orf_len, orf_stop + 3, hi);
+            }
+            if (trunc)                                  // glimmer_base.cc:765-776: 3 bp past the end count as stops
+                for (int i = n; i < n + 3; i++) {
+                    const int c = i % 3;
+                    if (c == 0) fwd_stop(i, cs[0], 0);
+                    else if (c == 1) fwd_stop(i, cs[1], 1);
+                    else fwd_stop(i, cs[2], 2);
+                }
+        }
+        if (!WRITE) a.read_cnt[r] = cnt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Score_Orf_Starts without errors (glimmer-mg.cc:1693-1861) + the per-ORF part of Score_Orfs_Errors
+// (:1632-1685): one lane per ORF, ONE pass from buffer position 0 (the 3' end) upwards.
+//   * running sum in reference order: score[j] = score[j-1] + Frame_Scores[f][si], f = 1,2,0,...
+//   * the reference scans j downwards; "first" there is the LAST qualifying position here, so entries are
+//     produced in ascending j and stored at mirrored slots: entry t of n goes to slot n-1-t, which is the
+//     order Score_Orf_Starts pushed them (the count pass supplied n).
+//   * a truncated ORF (glimmer-mg.cc:1741,1761) pushes its highest in-frame position unconditionally as a
+//     truncated start (slot 0), followed by the real start at the same position if there is one.
+// ---------------------------------------------------------------------------------------------------
+template <bool WRITE, bool FWD>
+__device__ __forceinline__ void mg_starts_one(const MgArgs &a, uint64_t i, const int8_t *s_which)
+{
+    gmg_mg_orf o = a.orfs[i];
+    const uint64_t off = a.read_off[o.read];
+    const int n = (int)(a.read_off[o.read + 1] - off);
+    const int lo = o.lo, hi = o.hi, m = hi - lo;
+    const bool trunc = a.allow_truncated && (FWD ? lo < 3 : n - (hi - 1) < 3);
+    const int mgl = a.min_gene_len;
+    int j_lo = mgl - 3 > 1 ? mgl - 3 : 1;              // j >= lowest_j = Min (3, mgl-3), j >= 1 (j-1 is read), j+3 >= mgl
+    j_lo = (j_lo + 2) / 3 * 3;
+    const int jmax = m >= 1 ? (m - 1) / 3 * 3 : -1;     // highest in-frame position of the buffer
+    const bool has_trunc = trunc && jmax >= j_lo;
+    const uint32_t n_total = WRITE ? (uint32_t)(a.start_off[i + 1] - a.start_off[i]) : 0;
+    gmg_start *out = WRITE ? a.starts + a.start_off[i] : nullptr;
+    const int k_base = FWD ? lo - 1 + (m - 1) : hi + 1 - (m - 1);      // pos of j: k_base -/+ j (glimmer-mg.cc:1742,1762,1855-1858)
+
+    uint32_t t = 0;                                     // real starts so far (ascending j)
+    double cum = 0.0, pend = 0.0, best = -DBL_MAX, s_jmax = 0.0;
+    int last_j = -1;
+    if (m > 0) {
+        BaseStream<FWD ? -1 : 1> bs;
+        const uint64_t g0 = off + (uint64_t)(FWD ? hi - 1 : lo - 1);    // base of buffer position 0
+        bs.init(a.packed, g0);
+        const double *row = a.fs + (FWD ? 0 : 3) * a.total + g0;
+        uint32_t idx6 = 0;
+        int f = 1, jm3 = 0;
+        for (int j = 0; j < m; j++) {
+            const int c0 = bs.next();
+            const int code = FWD ? c0 : 3 - c0;         // Reverse_Transfer / Complement_Transfer (glimmer-mg.cc:1735,1756)
+            idx6 = (idx6 >> 2) | ((uint32_t)code << 4); // buff[j] oldest <-> highest: (buff[j], buff[j-1], buff[j-2]) as Codon_t holds them
+            if (jm3 == 2 && j - 2 >= j_lo) {            // codon of in-frame position j-2 is complete
+                const int which = s_which[idx6];
+                if (which >= 0) {
+                    if (WRITE) {
+                        const double sc = (j > a.ignore_score_len && 0.0 > pend) ? 0.0 : pend;   // j-2+2 > Ignore_Score_Len: Max (0.0, score)
+                        gmg_start st;
+                        st.score = sc; st.j = j; st.pos = FWD ? k_base - (j - 2) : k_base + (j - 2);
+                        st.which = which; st.truncated = 0; st.first = 0;
+                        out[n_total - 1 - t] = st;
+                        if (sc > best) best = sc;
+                    }
+                    t++;
+                    last_j = j - 2;
+                }
+            }
+            if (WRITE) {
+                if (jm3 == 0) { pend = cum; if (j == jmax) s_jmax = cum; }   // score[j-1]
+                cum += row[FWD ? -(int64_t)j + (int64_t)f * (int64_t)a.total : (int64_t)j + (int64_t)f * (int64_t)a.total];
+            }
+            f = f == 2 ? 0 : f + 1;
+            jm3 = jm3 == 2 ? 0 : jm3 + 1;
+        }
+    }
+    const uint32_t n_starts = t + (has_trunc ? 1u : 0u);
+    if (!WRITE) { a.orf_cnt[i] = n_starts; return; }
+
+    int first_j = 0;
+    if (has_trunc) {
+        const double sc = (jmax + 2 > a.ignore_score_len && 0.0 > s_jmax) ? 0.0 : s_jmax;
+        gmg_start st;
+        st.score = sc; st.j = jmax + 2; st.pos = FWD ? k_base - jmax : k_base + jmax;
+        st.which = -1; st.truncated = 1; st.first = 1;
+        out[0] = st;
+        if (sc > best) best = sc;
+        first_j = jmax + 2;
+    } else if (t > 0) {
+        out[0].first = 1;                               // the last real start found is the first the reference pushes
+        first_j = last_j + 2;
+    }
+    o.orf_is_truncated = trunc;
+    o.start_begin = (uint32_t)a.start_off[i];
+    o.n_starts = n_starts;
+    o.first_j = first_j;
+    o.best_score = -DBL_MAX;
+    o.accepted = 0;
+    if (n_starts > 0 && first_j + 1 >= mgl) {           // glimmer-mg.cc:1656-1676
+        o.best_score = best;
+        o.accepted = best > a.start_threshold;
+    }
+    a.orfs[i] = o;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_mg_starts(MgArgs a)
+{
+    __shared__ int8_t s_which[64];
+    if (threadIdx.x < 64) s_which[threadIdx.x] = a.which[threadIdx.x];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (a.orfs[i].frame > 0) mg_starts_one<WRITE, true>(a, i, s_which);
+        else mg_starts_one<WRITE, false>(a, i, s_which);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mg_widen(const uint32_t *in, uint64_t *out, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static unsigned mg_codon_from(const char *s)            // Codon_t::Set_From (gene.cc:133-146)
+{
+    unsigned d = 0;
+    for (int i = 0; i < 3 && s[i]; i++) d = ((d & 0xffu) << 4) | mg_ch_mask(s[i]);
+    return d;
+}
+static unsigned mg_codon_revcomp(unsigned data)         // Codon_t::Reverse_Complement (gene.cc:96-113)
+{
+    unsigned x = 0;
+    for (int i = 0; i < 12; i++) { x = (x << 1) | (data & 1u); data >>= 1; }
+    return x;
+}
+
+static unsigned grid_for(uint64_t n)
+{
+    const uint64_t blocks = (n + 255) / 256;
+    return (unsigned)(blocks < 256 * 16 ? (blocks ? blocks : 1) : 256 * 16);
+}
+
+// exclusive sum of cnt[0..n] (cnt[n] = 0) into off[0..n] as 64-bit offsets; *total = off[n]
+static int mg_scan(uint32_t *d_cnt, uint64_t *d_off, uint64_t n, uint64_t *total, hipStream_t s)
+{
+    uint64_t *d_wide = nullptr;
+    void *d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    GMG_HIP(hipMalloc((void **)&d_wide, (n + 1) * 8));
+    hipLaunchKernelGGL(k_mg_widen, dim3(grid_for(n + 1)), dim3(256), 0, s, d_cnt, d_wide, n + 1);
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_wide, d_off, (int)(n + 1), s);
+    if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_wide, d_off, (int)(n + 1), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(total, d_off + n, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_wide);
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (e != hipSuccess) return gmg_set_error(GMG_EHIP, "gmg_mg_score_reads: scan: %s", hipGetErrorString(e));
+    return GMG_OK;
+}
+
+extern "C" int gmg_mg_result_free(gmg_mg_result *r)
+{
+    if (!r) return GMG_OK;
+    void *ptrs[] = {r->d_orfs, r->d_starts, r->d_read_orf_off};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete r;
+    return GMG_OK;
+}
+
+extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads,
+                                  const gmg_mg_params *prm, double *d_frame_scores, gmg_mg_result **out, void *stream)
+{
+    if (!gene || !nul || !reads || !prm || !out) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: NULL argument");
+    if (prm->n_start_codons < 0 || prm->n_start_codons > 8 || prm->n_stop_codons < 0 || prm->n_stop_codons > 8 ||
+        prm->min_gene_len < 4)
+        return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: need 0..8 start / stop codons and min_gene_len >= 4");
+    if (gene->dev.P != 3 || nul->dev.P != 3)
+        return gmg_set_error(GMG_EBADMODEL, "gmg_mg_score_reads: Score_All_Frames needs models of periodicity 3");
+    if (reads->n_reads >= 0x7fffffffull) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large");
+    hipStream_t s = (hipStream_t)stream;
+
+    MgArgs a;
+    memset(&a, 0, sizeof a);
+    a.packed = reads->d_packed;
+    a.read_off = reads->d_off;
+    a.n_reads = reads->n_reads;
+    a.total = reads->total_bases;
+    a.min_gene_len = prm->min_gene_len;
+    a.allow_truncated = prm->allow_truncated;
+    a.ignore_score_len = prm->ignore_score_len;
+    a.start_threshold = prm->start_threshold;
+    {   // Set_Start_And_Stop_Codons (glimmer_base.cc:2683-2704) -> one bit / one byte per definite codon
+        unsigned f_start[8], r_start[8], f_stop[8], r_stop[8];
+        for (int p = 0; p < prm->n_start_codons; p++) { f_start[p] = mg_codon_from(prm->start_codon[p]); r_start[p] = mg_codon_revcomp(f_start[p]); }
+        for (int p = 0; p < prm->n_stop_codons; p++) { f_stop[p] = mg_codon_from(prm->stop_codon[p]); r_stop[p] = mg_codon_revcomp(f_stop[p]); }
+        for (unsigned idx = 0; idx < 64; idx++) {
+            const unsigned data = (1u << ((idx >> 4) & 3)) << 8 | (1u << ((idx >> 2) & 3)) << 4 | (1u << (idx & 3));
+            auto can_be = [&](const unsigned *pat, int np) {       // Codon_t::Can_Be (gene.cc:39-66)
+                for (int p = 0; p < np; p++) { const unsigned x = data & pat[p]; if ((x & 0xf00) && (x & 0xf0) && (x & 0xf)) return p; }
+                return -1;
+            };
+            auto must_be = [&](const unsigned *pat, int np) {      // Codon_t::Must_Be (gene.cc:70-92)
+                for (int p = 0; p < np; p++) if ((data & pat[p]) == data) return true;
+                return false;
+            };
+            a.which[idx] = (int8_t)can_be(f_start, prm->n_start_codons);
+            if (a.which[idx] >= 0) a.fwd_start |= 1ull << idx;
+            if (can_be(r_start, prm->n_start_codons) >= 0) a.rev_start |= 1ull << idx;
+            if (must_be(f_stop, prm->n_stop_codons)) a.fwd_stop |= 1ull << idx;
+            if (must_be(r_stop, prm->n_stop_codons)) a.rev_stop |= 1ull << idx;
+        }
+    }
+
+    gmg_mg_result *res = new (std::nothrow) gmg_mg_result();
+    if (!res) return gmg_set_error(GMG_ENOMEM, "gmg_mg_score_reads: out of host memory");
+    memset(res, 0, sizeof *res);
+    res->n_reads = reads->n_reads;
+    double *d_fs_own = nullptr;
+    uint32_t *d_read_cnt = nullptr, *d_orf_cnt = nullptr;
+    uint64_t *d_start_off = nullptr;
+    int rc = GMG_OK;
+    auto fail = [&](int code) {
+        if (d_fs_own) (void)hipFree(d_fs_own);
+        if (d_read_cnt) (void)hipFree(d_read_cnt);
+        if (d_orf_cnt) (void)hipFree(d_orf_cnt);
+        if (d_start_off) (void)hipFree(d_start_off);
+        gmg_mg_result_free(res);
+        return code;
+    };
+#define MG_TRY(call)                                                                                            \
+    do {                                                                                                        \
+        hipError_t e_ = (call);                                                                                 \
+        if (e_ != hipSuccess)                                                                                   \
+            return fail(gmg_set_error(e_ == hipErrorOutOfMemory ? GMG_ENOMEM : GMG_EHIP, "gmg_mg_score_reads: %s: %s", \
+                                      #call, hipGetErrorString(e_)));                                           \
+    } while (0)
+
+    // 1. Frame_Scores
+    if (!d_frame_scores && a.total) {
+        MG_TRY(hipMalloc((void **)&d_fs_own, (size_t)6 * a.total * sizeof(double)));
+        d_frame_scores = d_fs_own;
+    }
+    if (a.total) {
+        rc = gmg_launch_frame6(gene, nul, reads, d_frame_scores, s);
+        if (rc) return fail(rc);
+    }
+    a.fs = d_frame_scores;
+
+    // 2. ORFs of every read
+    const uint64_t nr = a.n_reads;
+    MG_TRY(hipMalloc((void **)&d_read_cnt, (nr + 1) * 4));
+    MG_TRY(hipMemsetAsync(d_read_cnt, 0, (nr + 1) * 4, s));
+    MG_TRY(hipMalloc((void **)&res->d_read_orf_off, (nr + 1) * 8));
+    a.read_cnt = d_read_cnt;
+    if (nr) hipLaunchKernelGGL(k_mg_find_orfs<false>, dim3(grid_for(nr)), dim3(256), 0, s, a);
+    MG_TRY(hipGetLastError());
+    rc = mg_scan(d_read_cnt, res->d_read_orf_off, nr, &res->n_orfs, s);
+    if (rc) return fail(rc);
+    if (res->n_orfs >= 0x7fffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
+    const uint64_t no = res->n_orfs;
+    MG_TRY(hipMalloc((void **)&res->d_orfs, (no ? no : 1) * sizeof(gmg_mg_orf)));
+    a.read_orf_off = res->d_read_orf_off;
+    a.orfs = res->d_orfs;
+    a.n_orfs = no;
+    if (nr) hipLaunchKernelGGL(k_mg_find_orfs<true>, dim3(grid_for(nr)), dim3(256), 0, s, a);
+    MG_TRY(hipGetLastError());
+
+    // 3. start lists
+    MG_TRY(hipMalloc((void **)&d_orf_cnt, (no + 1) * 4));
+    MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s));
+    MG_TRY(hipMalloc((void **)&d_start_off, (no + 1) * 8));
+    a.orf_cnt = d_orf_cnt;
+    if (no) hipLaunchKernelGGL(k_mg_starts<false>, dim3(grid_for(no)), dim3(256), 0, s, a);
+    MG_TRY(hipGetLastError());
+    rc = mg_scan(d_orf_cnt, d_start_off, no, &res->n_starts, s);
+    if (rc) return fail(rc);
+    if (res->n_starts >= 0xffffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
+    MG_TRY(hipMalloc((void **)&res->d_starts, (res->n_starts ? res->n_starts : 1) * sizeof(gmg_start)));
+    a.start_off = d_start_off;
+    a.starts = res->d_starts;
+    if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
+    MG_TRY(hipGetLastError());
+    MG_TRY(hipStreamSynchronize(s));
+#undef MG_TRY
+    if (d_fs_own) (void)hipFree(d_fs_own);
+    (void)hipFree(d_read_cnt);
+    (void)hipFree(d_orf_cnt);
+    (void)hipFree(d_start_off);
+    *out = res;
+    return GMG_OK;
+}
+
+extern "C" int gmg_mg_result_info(const gmg_mg_result *r, uint64_t *n_orfs, uint64_t *n_starts)
+{
+    if (!r) return gmg_set_error(GMG_EINVAL, "gmg_mg_result_info: NULL result");
+    if (n_orfs) *n_orfs = r->n_orfs;
+    if (n_starts) *n_starts = r->n_starts;
+    return GMG_OK;
+}
+
+extern "C" int gmg_mg_result_fetch(const gmg_mg_result *r, gmg_mg_orf *orfs, gmg_start *starts, uint64_t *read_orf_off)
+{
+    if (!r || (r->n_orfs && !orfs) || (r->n_starts && !starts)) return gmg_set_error(GMG_EINVAL, "gmg_mg_result_fetch: NULL argument");
+    if (r->n_orfs) GMG_HIP(hipMemcpy(orfs, r->d_orfs, r->n_orfs * sizeof(gmg_mg_orf), hipMemcpyDeviceToHost));
+    if (r->n_starts) GMG_HIP(hipMemcpy(starts, r->d_starts, r->n_starts * sizeof(gmg_start), hipMemcpyDeviceToHost));
+    if (read_orf_off) GMG_HIP(hipMemcpy(read_orf_off, r->d_read_orf_off, (r->n_reads + 1) * 8, hipMemcpyDeviceToHost));
+    return GMG_OK;
+}

@@ -237,6 +237,57 @@ int gmg_score_orfs(const gmg_model *gene, const gmg_model *null_model, const gmg
                    const gmg_orf_batch *orfs, const gmg_orf_params *params,
                    gmg_orf_result *results, gmg_start *starts, void *stream);
 
+/* ---- glimmer-mg front half on the device -------------------------------------------
+ * Everything between the reads and Add_Events_* for glimmer-mg's default mode (no -i / -s branch):
+ *   Score_All_Frames      src/Glimmer/glimmer-mg.cc:1468-1510   (gmg_frame_score6's kernels)
+ *   Find_Orfs             src/Glimmer/glimmer_base.cc:638-779   (linear sequences, no ignore regions)
+ *   Save_Prev_Stops       src/Glimmer/glimmer-mg.cc:675-729     (folded into the ORF scan: lo / hi per ORF)
+ *   Score_Orf_Starts      src/Glimmer/glimmer-mg.cc:1693-1861   with Cumulative_Frame_Score :561-604
+ *   Score_Orfs_Errors     src/Glimmer/glimmer-mg.cc:1632-1685   boost, first_j, best score, threshold
+ * The 48 B/base Frame_Scores table never leaves HBM; what comes back is one record per ORF and the start
+ * lists.  The caller sorts each accepted ORF's list with Start_Cmp (glimmer_base.hh:90) and hands it to
+ * Add_Events_Fwd / Add_Events_Rev exactly as Score_Orfs_Errors does. */
+typedef struct gmg_mg_params {
+    int32_t min_gene_len;        /* Min_Gene_Len (>= 4)                                           */
+    int32_t allow_truncated;     /* Allow_Truncated_Orfs (glimmer-mg default: true)               */
+    int32_t ignore_score_len;    /* Ignore_Score_Len                                              */
+    int32_t n_start_codons;      /* <= 8                                                          */
+    int32_t n_stop_codons;       /* <= 8                                                          */
+    int32_t reserved;
+    double start_threshold;      /* Start_Threshold                                               */
+    char start_codon[8][4];      /* Start_Codon strings (IUPAC allowed)                           */
+    char stop_codon[8][4];       /* Stop_Codon strings                                            */
+} gmg_mg_params;
+
+typedef struct gmg_mg_orf {
+    uint32_t read;               /* index into the gmg_reads batch                                */
+    int32_t frame, stop_position, orf_len, gene_len;     /* the Orf_t Find_Orfs built             */
+    int32_t lo, hi;              /* Score_Orf_Starts' bounds (glimmer-mg.cc:1730-1757)            */
+    int32_t first_j;             /* j of the first start (after the sort: front / back)           */
+    uint32_t start_begin, n_starts;      /* its start list: starts[start_begin .. +n_starts), in the
+                                            order Score_Orf_Starts pushed them, boost applied      */
+    int16_t accepted;            /* non-empty, first_j+1 >= Min_Gene_Len, best_score > Start_Threshold
+                                    (glimmer-mg.cc:1656-1676): the ORF goes to Add_Events_*        */
+    int16_t orf_is_truncated;
+    int32_t reserved;
+    double best_score;           /* max over the boosted start scores, -DBL_MAX if none           */
+} gmg_mg_orf;
+
+typedef struct gmg_mg_result gmg_mg_result;
+
+/* Runs the whole front half for every read of the batch.  d_frame_scores: device buffer of
+ * 6 * total_bases doubles that receives the Frame_Scores table (the caller may want it), or NULL to let
+ * the call allocate and release its own.  Needs a gene model of periodicity 3. */
+int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *null_model, const gmg_reads *reads,
+                       const gmg_mg_params *params, double *d_frame_scores, gmg_mg_result **out,
+                       void *stream);
+/* Sizes of the result: ORFs of all reads (Find_Orfs order, read by read) and start entries. */
+int gmg_mg_result_info(const gmg_mg_result *r, uint64_t *n_orfs, uint64_t *n_starts);
+/* Copies the result to HOST buffers: orfs[n_orfs], starts[n_starts] and, if not NULL,
+ * read_orf_off[n_reads + 1] (ORFs of read i are orfs[read_orf_off[i] .. read_orf_off[i+1])). */
+int gmg_mg_result_fetch(const gmg_mg_result *r, gmg_mg_orf *orfs, gmg_start *starts, uint64_t *read_orf_off);
+int gmg_mg_result_free(gmg_mg_result *r);
+
 /* ---- device memory helpers (for callers without their own allocator) -------- */
 int gmg_device_malloc(void **d_ptr, size_t bytes);
 int gmg_device_free(void *d_ptr);

@@ -163,6 +163,8 @@ def main():
         "glimmer3.X": ["glimmer3", "-X", "-m", nc],
         "glimmer-mg.default": ["glimmer-mg", "-m", nc],
         "glimmer-mg.indel": ["glimmer-mg", "-i", "-m", nc],
+        "glimmer-mg.g120": ["glimmer-mg", "-g", "120", "-m", nc],
+        "glimmer-mg.Z2": ["glimmer-mg", "-Z", "taa,tag", "-m", nc],
     }
     for name, cmd in clis.items():
         tag = os.path.join(RB, "cli_" + name)
@@ -192,6 +194,30 @@ def main():
                             gene_orf=g[:, 0], gene_len=g[:, 1], gene_nstarts=g[:, 2], gene_start_begin=g[:, 3],
                             gene_score=np.array([x[4] for x in genes], np.float64),
                             start_int=np.array(st_i, np.int32),                  # j, pos, which, truncated, first
+                            start_score=np.array(st_s, np.float64))
+    # ---- glimmer-mg front half (Find_Orfs + Score_Orfs_Errors, glimmer-mg.cc:1605-1861): every ORF of Find_Orfs and
+    #      the sorted start lists handed to Add_Events_*
+    for name, flags in (("mg_orfs_default", []), ("mg_orfs_g120", ["-g", "120"]), ("mg_orfs_Z2", ["-Z", "taa,tag"])):
+        txt = subprocess.run([os.path.join(RB, "ref_mg_orfs"), "dump", *flags, "-m", nc, fa, os.path.join(RB, "mg_tag")],
+                             check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=RB).stdout.decode()
+        orfs, genes, st_i, st_s = [], [], [], []
+        read, base = -1, 0
+        for line in txt.splitlines():
+            p = line.split()
+            if p[0] == "R":
+                read, base = int(p[1]), len(orfs)
+            elif p[0] == "O":
+                orfs.append((read, int(p[1]), int(p[2]), int(p[3]), int(p[4])))
+            elif p[0] == "G":
+                genes.append((base + int(p[1]), int(p[2]), len(st_i)))
+            elif p[0] == "S":
+                st_i.append((int(p[1]), int(p[2]), int(p[4]), int(p[5]), int(p[6])))
+                st_s.append(float.fromhex(p[3]))
+        g = np.array(genes, np.int64)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), flags=" ".join(flags),
+                            orfs=np.array(orfs, np.int32),                 # read, frame, stop_position, gene_len, orf_len
+                            gene_orf=g[:, 0], gene_nstarts=g[:, 1], gene_start_begin=g[:, 2],
+                            start_int=np.array(st_i, np.int32),            # j, pos, which, truncated, first (sorted by pos)
                             start_score=np.array(st_s, np.float64))
     print("golden vectors written to", GOLD)
 

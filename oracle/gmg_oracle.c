@@ -630,6 +630,244 @@ int orc_score_orf(const orc_model *gene, const orc_model *indep, const char *seq
     return n_starts;
 }
 
+/* ======================================================================================================
+ * glimmer-mg front half: Find_Orfs, Save_Prev_Stops, Score_Orf_Starts (no errors), Score_Orfs_Errors filter
+ * ==================================================================================================== */
+
+/* Codon_t::Must_Be (gene.cc:70-92): every string this codon could be matches the pattern */
+static int orc_must_be(unsigned data, const unsigned *pat, int n)
+{
+    int i;
+    for (i = 0; i < n; i++)
+        if ((data & pat[i]) == data && (data & 0xf00) && (data & 0xf0) && (data & 0x0f)) return 1;
+    return 0;
+}
+
+/* Codon_t::Reverse_Complement (gene.cc:96-113): the 12 bits mirrored */
+static unsigned orc_codon_revcomp(unsigned data)
+{
+    unsigned x = 0;
+    int i;
+    for (i = 0; i < 12; i++) { x = (x << 1) | (data & 1u); data >>= 1; }
+    return x;
+}
+
+#define ORC_INT_MAX 2147483647
+
+typedef struct orc_find_state {
+    const orc_mg_params *prm;
+    orc_orf *orfs;
+    int cap, n_orfs;
+    int first_fwd_start[3], last_rev_start[3], prev_fwd_stop[3], prev_rev_stop[3];
+} orc_find_state;
+
+static void orc_push_orf(orc_find_state *st, int stop_position, int frame, int gene_len, int orf_len)
+{
+    /* glimmer_base.cc:494,528,806 with Allow_Indels = Allow_Subs = false */
+    if (gene_len >= st->prm->min_gene_len) {
+        if (st->n_orfs < st->cap) {
+            orc_orf *o = &st->orfs[st->n_orfs];
+            o->stop_position = stop_position; o->frame = frame; o->gene_len = gene_len; o->orf_len = orf_len;
+        }
+        st->n_orfs++;
+    }
+}
+
+/* Do_Fwd_Stop_Codon (glimmer_base.cc:460-504) + Handle_First_Forward_Stop without wrap-around (:946-985) */
+static void orc_do_fwd_stop(orc_find_state *st, int i, int frame)
+{
+    int gene_len, orf_len;
+    if (st->prev_fwd_stop[frame] == 0) {
+        const int pos = i - 1, start_pos = st->first_fwd_start[frame], first_base = 1;
+        orf_len = pos - first_base;
+        orf_len -= orf_len % 3;
+        gene_len = (start_pos == ORC_INT_MAX) ? 0 : pos - start_pos;
+        if (st->prm->allow_truncated && gene_len < st->prm->min_gene_len) gene_len = orf_len;
+    } else {
+        gene_len = i - st->first_fwd_start[frame] - 1;
+        orf_len = i - st->prev_fwd_stop[frame] - 4;
+    }
+    orc_push_orf(st, i - 1, 1 + (frame + 1) % 3, gene_len, orf_len);
+    st->first_fwd_start[frame] = ORC_INT_MAX;
+    st->prev_fwd_stop[frame] = i - 1;
+}
+
+/* Do_Rev_Stop_Codon (glimmer_base.cc:506-537) + Handle_First_Reverse_Stop (:989-1015) */
+static void orc_do_rev_stop(orc_find_state *st, int i, int frame)
+{
+    int gene_len, orf_len, orf_stop = 0;
+    if (st->prev_rev_stop[frame] == 0) {
+        if (!st->prm->allow_truncated) gene_len = 0;
+        else {
+            orf_stop = (i - 1) % 3;
+            if (orf_stop > 0) orf_stop -= 3;
+            gene_len = st->last_rev_start[frame] - orf_stop;
+        }
+    } else {
+        orf_stop = st->prev_rev_stop[frame];
+        gene_len = st->last_rev_start[frame] - orf_stop;
+    }
+    orf_len = i - orf_stop - 4;
+    orc_push_orf(st, orf_stop, -1 - (frame + 1) % 3, gene_len, orf_len);
+    st->last_rev_start[frame] = 0;
+    st->prev_rev_stop[frame] = i - 1;
+}
+
+int orc_find_orfs(const char *seq, int n, const orc_mg_params *prm, orc_orf *orfs, int cap)
+{
+    orc_find_state st;
+    unsigned fwd_start[8], rev_start[8], fwd_stop[8], rev_stop[8], codon = 0;
+    int i, frame, fr;
+    st.prm = prm; st.orfs = orfs; st.cap = cap; st.n_orfs = 0;
+    for (i = 0; i < 3; i++) {
+        st.first_fwd_start[i] = ORC_INT_MAX;
+        st.last_rev_start[i] = st.prev_fwd_stop[i] = st.prev_rev_stop[i] = 0;
+    }
+    for (i = 0; i < prm->n_start_codons; i++) {       /* Set_Start_And_Stop_Codons, glimmer_base.cc:2688-2704 */
+        fwd_start[i] = orc_codon_from(prm->start_codon[i]);
+        rev_start[i] = orc_codon_revcomp(fwd_start[i]);
+    }
+    for (i = 0; i < prm->n_stop_codons; i++) {
+        fwd_stop[i] = orc_codon_from(prm->stop_codon[i]);
+        rev_stop[i] = orc_codon_revcomp(fwd_stop[i]);
+    }
+    if (n < prm->min_gene_len) return 0;                /* glimmer_base.cc:676-677 */
+
+    frame = 0;
+    for (i = 0; i < n; i++) {                           /* glimmer_base.cc:701-757, no ignore regions */
+        int which;
+        codon = ((codon & 0xff) << 4) | orc_ch_mask(seq[i]);
+        if (orc_can_be(codon, fwd_start, prm->n_start_codons, &which) && st.first_fwd_start[frame] == ORC_INT_MAX)
+            st.first_fwd_start[frame] = i - 1;
+        if (orc_can_be(codon, rev_start, prm->n_start_codons, &which)) st.last_rev_start[frame] = i - 1;
+        if (orc_must_be(codon, fwd_stop, prm->n_stop_codons)) orc_do_fwd_stop(&st, i, frame);
+        if (orc_must_be(codon, rev_stop, prm->n_stop_codons)) orc_do_rev_stop(&st, i, frame);
+        frame = frame == 2 ? 0 : frame + 1;
+    }
+    /* Finish_Orfs (glimmer_base.cc:783-817) + Handle_Last_Reverse_Stop without wrap-around (:1019-1072) */
+    for (fr = 0; fr < 3; fr++) {
+        int orf_stop, orf_len, gene_len;
+        if (st.prev_rev_stop[fr] == 0) orf_stop = fr == 0 ? -1 : fr == 1 ? 0 : -2;
+        else orf_stop = st.prev_rev_stop[fr];
+        orf_len = n - orf_stop - 2;
+        orf_len -= orf_len % 3;
+        gene_len = st.last_rev_start[fr] == 0 ? 0 : st.last_rev_start[fr] - orf_stop;
+        if (prm->allow_truncated && gene_len < prm->min_gene_len) gene_len = orf_len;
+        orc_push_orf(&st, orf_stop, -1 - (fr + 1) % 3, gene_len, orf_len);
+    }
+    if (prm->allow_truncated)                           /* glimmer_base.cc:765-776: 3 bp past the end are stops */
+        for (; i < n + 3; i++) {
+            orc_do_fwd_stop(&st, i, frame);
+            frame = frame == 2 ? 0 : frame + 1;
+        }
+    return st.n_orfs;
+}
+
+void orc_save_prev_stops(const char *seq, int n, const orc_mg_params *prm, int *fwd_prev, int *rev_next)
+{
+    unsigned fwd_stop[8], codon = 0;                    /* one Codon_t for both loops, like the reference */
+    int last_stops[3] = {0, 1, -1}, frame = 0, i;
+    for (i = 0; i < prm->n_stop_codons; i++) fwd_stop[i] = orc_codon_from(prm->stop_codon[i]);
+    for (i = 0; i < n; i++) {                           /* glimmer-mg.cc:689-702 */
+        codon = ((codon & 0xff) << 4) | orc_ch_mask(seq[i]);
+        if (i >= 2 && orc_must_be(codon, fwd_stop, prm->n_stop_codons)) last_stops[frame] = i;
+        fwd_prev[i] = last_stops[frame];
+        frame = (frame + 1) % 3;
+    }
+    last_stops[0] = n - 1; last_stops[1] = n - 2; last_stops[2] = n;      /* glimmer-mg.cc:708-710 */
+    frame = 0;
+    for (i = n - 1; i >= 0; i--) {                      /* glimmer-mg.cc:714-728 */
+        codon = ((codon & 0xff) << 4) | orc_ch_mask(orc_complement(seq[i]));
+        if (i <= n - 3 && orc_must_be(codon, fwd_stop, prm->n_stop_codons)) last_stops[frame] = i;
+        rev_next[i] = last_stops[frame];
+        frame = (frame + 1) % 3;
+    }
+}
+
+int orc_mg_score_orf(const double *frame_scores, const char *seq, int n, const int *fwd_prev, const int *rev_next,
+                     int frame, int stop_position, const orc_mg_params *prm, orc_start *starts, int cap,
+                     orc_mg_out *out)
+{
+    unsigned pat[8], codon = 0;
+    int n_pat = prm->n_start_codons, n_starts = 0, i;
+    int end_point, lo, hi, len, k, j, m, lowest_j, which = -1, first_pos = 0, orf_is_truncated;
+    char *buff;
+    double *score;
+    for (i = 0; i < n_pat; i++) pat[i] = orc_codon_from(prm->start_codon[i]);
+
+    if (frame > 0) {                                    /* glimmer-mg.cc:1637-1640, 1721-1742 */
+        int e;
+        end_point = stop_position - 1;
+        hi = end_point;
+        e = end_point - 1;                              /* Fwd_Prev_Stop, :642-652 */
+        lo = ((e >= 0 && e < n) ? fwd_prev[e] : e) + 1;
+        len = hi - lo;
+        orf_is_truncated = (lo < 3 && prm->allow_truncated);
+        k = lo - 1;
+    } else {                                            /* glimmer-mg.cc:1744-1763 */
+        int e;
+        end_point = stop_position + 3;
+        lo = end_point;
+        e = end_point - 1;                              /* Rev_Next_Stop, :1436-1445 */
+        hi = ((e >= 0 && e < n) ? rev_next[e] : e) + 1;
+        len = hi - lo;
+        orf_is_truncated = (n - (hi - 1) < 3 && prm->allow_truncated);
+        k = hi + 1;
+    }
+    out->lo = lo; out->hi = hi; out->orf_is_truncated = orf_is_truncated;
+    out->first_j = 0; out->accepted = 0; out->best_score = -1.7976931348623157e308;
+    if (len < 0) return 0;
+    buff = (char *)malloc((size_t)len + 1);
+    score = (double *)malloc(sizeof(double) * (size_t)(len ? len : 1));
+    if (frame > 0) orc_reverse_transfer(buff, seq, n, hi - 1, len);
+    else orc_complement_transfer(buff, seq, n, lo - 1, len);
+    orc_cumulative_frame_score(frame_scores, n, frame, lo, hi, score);     /* indep_score is all zero */
+
+    m = len;
+    lowest_j = prm->min_gene_len - 3 < 3 ? prm->min_gene_len - 3 : 3;
+    for (j = m - 1; j >= lowest_j; j--) {               /* glimmer-mg.cc:1813-1860, suffix_j = 0, suffix_score = 0 */
+        codon = ((codon & 0xff) << 4) | orc_ch_mask(buff[j]);
+        if (j % 3 == 0 && (orc_can_be(codon, pat, n_pat, &which) || (first_pos == 0 && orf_is_truncated))
+            && j + 3 >= prm->min_gene_len) {
+            orc_start st;
+            st.score = score[j - 1] - 0.0;
+            st.j = j + 2; st.pos = k; st.first = (first_pos == 0);
+            if (which >= 0 && first_pos == 0 && orf_is_truncated) {
+                st.which = -1; st.truncated = 1;
+                if (n_starts < cap) starts[n_starts] = st;
+                n_starts++;
+                st.first = 0;
+            }
+            st.which = which; st.truncated = (which < 0);
+            if (n_starts < cap) starts[n_starts] = st;
+            n_starts++;
+            if (first_pos == 0) first_pos = k;
+        }
+        if (frame > 0) k++; else k--;
+    }
+    free(buff); free(score);
+
+    /* Score_Orfs_Errors (glimmer-mg.cc:1647-1683) */
+    for (i = 0; i < n_starts && i < cap; i++)           /* boost long ORFs: score = Max (0.0, score) */
+        if (starts[i].j > prm->ignore_score_len && 0.0 > starts[i].score) starts[i].score = 0.0;
+    if (n_starts > 0 && n_starts <= cap) {
+        /* after sort by pos: forward -> front() has the lowest pos, reverse -> back() has the highest;
+         * entries with equal pos (truncated + real start at the same codon) share their j */
+        int pick = 0;
+        double best = -1.7976931348623157e308;
+        for (i = 1; i < n_starts; i++)
+            if (frame > 0 ? starts[i].pos < starts[pick].pos : starts[i].pos > starts[pick].pos) pick = i;
+        out->first_j = starts[pick].j;
+        if (out->first_j + 1 >= prm->min_gene_len) {
+            for (i = 0; i < n_starts; i++)
+                if (starts[i].score > best) best = starts[i].score;
+            out->best_score = best;
+            out->accepted = best > prm->start_threshold;
+        }
+    }
+    return n_starts;
+}
+
 long orc_score_reads_6frame(const orc_model *gene, const orc_model *indep, const char *seqs,
                             int n_reads, int L, double *out)
 {

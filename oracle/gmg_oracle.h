@@ -111,6 +111,31 @@ int orc_score_orf(const orc_model *gene, const orc_model *indep, const char *seq
                   int frame, int stop_position, int orf_len, const orc_orf_params *prm,
                   orc_start *starts, int cap, orc_orf_out *out);
 
+/* ---- glimmer-mg front half: ORF discovery + start scan on the six-frame table ---------------------
+ * Linear sequences, no ignore regions, no indel / substitution branch (Allow_Indels = Allow_Subs = false,
+ * the default of glimmer-mg; src/Glimmer/glimmer-mg.cc:100-102). */
+typedef struct orc_orf { int frame, stop_position, gene_len, orf_len; } orc_orf;
+typedef struct orc_mg_params {
+    int min_gene_len, allow_truncated, ignore_score_len;
+    double start_threshold;
+    int n_start_codons, n_stop_codons;
+    const char *start_codon[8], *stop_codon[8];
+} orc_mg_params;
+/* Find_Orfs (src/Glimmer/glimmer_base.cc:638-779) with Do_Fwd_Stop_Codon :460-504, Do_Rev_Stop_Codon :506-537,
+ * Finish_Orfs :783-817, Handle_First_Forward_Stop :946-985, Handle_First_Reverse_Stop :989-1015,
+ * Handle_Last_Reverse_Stop :1019-1072.  Returns the number of ORFs (only the first cap are written). */
+int orc_find_orfs(const char *seq, int n, const orc_mg_params *prm, orc_orf *orfs, int cap);
+/* Save_Prev_Stops (src/Glimmer/glimmer-mg.cc:675-729): fwd_prev[n], rev_next[n] */
+void orc_save_prev_stops(const char *seq, int n, const orc_mg_params *prm, int *fwd_prev, int *rev_next);
+typedef struct orc_mg_out { int lo, hi, first_j, accepted, orf_is_truncated; double best_score; } orc_mg_out;
+/* Score_Orf_Starts without errors (glimmer-mg.cc:1693-1861) on frame_scores[6][n] (Cumulative_Frame_Score
+ * :561-604), then the per-ORF part of Score_Orfs_Errors (:1632-1685): Ignore_Score_Len boost, first_j, best
+ * score, threshold.  starts come back in the order Score_Orf_Starts pushed them (the reference then sorts
+ * them by pos with std::sort, Start_Cmp glimmer_base.hh:90).  Returns the number of starts. */
+int orc_mg_score_orf(const double *frame_scores, const char *seq, int n, const int *fwd_prev, const int *rev_next,
+                     int frame, int stop_position, const orc_mg_params *prm, orc_start *starts, int cap,
+                     orc_mg_out *out);
+
 /* Whole-job helper used by bench.py's cpu_baseline leg: score n_reads reads of
  * fixed length L (concatenated, filtered lower-case) into out[read][6][L].
  * Returns number of bases scored.  Single-threaded like the reference. */

@@ -1,0 +1,206 @@
+// ref_mg_orfs.cc -- golden vectors for glimmer-mg's front half (Find_Orfs, src/Glimmer/glimmer_base.cc:638-779;
+// Score_Orfs_Errors / Score_Orf_Starts, src/Glimmer/glimmer-mg.cc:1605-1861) and the integration demo of
+// gmg_mg_score_reads.  Test infrastructure only; built by oracle/Makefile into oracle/_ref/.
+//
+// This file is ours.  It pulls the reference's glimmer-mg.cc translation unit in WHOLE (from /root/reference,
+// via the include path; nothing is copied) with its main() renamed, so that the file-static functions
+// Parse_Command_Line / Score_Orfs_Errors / Trace_Back are callable, and it intercepts Add_Events_Fwd /
+// Add_Events_Rev with the linker (--wrap) to see the start lists Score_Orfs_Errors hands over.
+// Only the user-ICM mode (-m <icm>, no -c classifications, no -i / -s error branch) is driven.
+//
+//   ref_mg_orfs dump  <glimmer-mg options...> <fasta> <tag>     text dump on stdout:
+//        R <read index> <n_orfs>
+//        O <frame> <stop_position> <gene_len> <orf_len>          every ORF Find_Orfs produced, in order
+//        G <orf index> <n_starts>                                every ORF Score_Orfs_Errors accepted
+//        S <j> <pos> <score %a> <which> <truncated> <first>      its start list as handed to Add_Events_* (sorted)
+//   ref_mg_orfs batch <glimmer-mg options...> <fasta> <tag>     (built with -DGMG_BATCH, links libgmg.so)
+//        same pipeline as glimmer-mg's main, but Find_Orfs + Score_Orfs_Errors of ALL reads are replaced by
+//        ONE gmg_mg_score_reads call; writes <tag>.predict, which must equal the reference's byte for byte.
+
+#define main glimmer_mg_reference_main
+#include "glimmer-mg.cc"
+#undef main
+
+#include <map>
+
+#ifdef GMG_BATCH
+#include "gmg.h"
+#endif
+
+void real_Add_Events_Fwd(const Orf_t &, vector<Start_t> &, int &)
+    asm("__real__Z14Add_Events_FwdRK5Orf_tRSt6vectorI7Start_tSaIS3_EERi");
+void real_Add_Events_Rev(const Orf_t &, vector<Start_t> &, int &)
+    asm("__real__Z14Add_Events_RevRK5Orf_tRSt6vectorI7Start_tSaIS3_EERi");
+void wrap_Add_Events_Fwd(const Orf_t &, vector<Start_t> &, int &)
+    asm("__wrap__Z14Add_Events_FwdRK5Orf_tRSt6vectorI7Start_tSaIS3_EERi");
+void wrap_Add_Events_Rev(const Orf_t &, vector<Start_t> &, int &)
+    asm("__wrap__Z14Add_Events_RevRK5Orf_tRSt6vectorI7Start_tSaIS3_EERi");
+
+static bool Capture = false;
+static vector<pair<Orf_t, vector<Start_t> > > Captured;
+
+void wrap_Add_Events_Fwd(const Orf_t &orf, vector<Start_t> &sl, int &id)
+{
+    if (Capture) Captured.push_back(make_pair(orf, sl));
+    real_Add_Events_Fwd(orf, sl, id);
+}
+void wrap_Add_Events_Rev(const Orf_t &orf, vector<Start_t> &sl, int &id)
+{
+    if (Capture) Captured.push_back(make_pair(orf, sl));
+    real_Add_Events_Rev(orf, sl, id);
+}
+
+// ---- the set-up steps of glimmer-mg's main for -m <icm> (glimmer-mg.cc:241-316), in the same order ----
+static void setup(int argc, char **argv)
+{
+    Verbose = 0;
+    Parse_Command_Line(argc, argv);
+    Set_Start_And_Stop_Codons();
+    if (Feature_File != NULL) Parse_Features(Feature_File);
+    if (!User_ICM || !classifications.empty() || Allow_Indels || Allow_Subs || Detail_Log) {
+        fprintf(stderr, "ref_mg_orfs: only -m <icm> without -c / -i / -s / detail log is driven here\n");
+        exit(2);
+    }
+    if (!GC_Frac_Set) Set_GC_Fraction();
+    Indep_Model.Build_Indep_WO_Stops(Indep_GC_Frac, Stop_Codon);
+    Set_Ignore_Score_Len();
+    if (User_RBS) {
+        LogOdds_PWM = Ribosome_PWM;
+        LogOdds_PWM.Make_Log_Odds_WRT_GC(Indep_GC_Frac);
+    }
+    Gene_ICM.Read(ICM_File_Name);
+}
+
+static void load_sequence(const vector<string> &seq_list, const vector<string> &hdr_list, int i)
+{
+    Fasta_Header = hdr_list[i].c_str();
+    Sequence = seq_list[i];
+    Sequence_Len = Sequence.length();
+    for (int k = 0; k < Sequence_Len; k++) Sequence[k] = tolower(Filter(Sequence[k]));   // glimmer-mg.cc:381-382
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) { fprintf(stderr, "usage: ref_mg_orfs dump|batch <glimmer-mg args>\n"); return 2; }
+    string mode = argv[1];
+    try {
+        setup(argc - 1, argv + 1);
+        vector<string> seq_list, hdr_list;
+        {
+            FILE *fp = File_Open(Sequence_File_Name, "r", __FILE__, __LINE__);
+            string s, h;
+            while (Fasta_Read(fp, s, h)) { seq_list.push_back(s); hdr_list.push_back(h); }
+            fclose(fp);
+        }
+        const int n_seq = seq_list.size();
+        vector<Orf_t> orf_list;
+
+        if (mode == "dump") {
+            for (int i = 0; i < n_seq; i++) {
+                load_sequence(seq_list, hdr_list, i);
+                Initialize_Terminal_Events(First_Event, Final_Event, Best_Event, Last_Event);
+                Find_Orfs(orf_list);
+                printf("R %d %d\n", i, (int)orf_list.size());
+                map<pair<int, int>, int> index_of;      // (frame, stop_position) -> position in orf_list
+                for (size_t o = 0; o < orf_list.size(); o++) {
+                    printf("O %d %d %d %d\n", orf_list[o].Get_Frame(), orf_list[o].Get_Stop_Position(),
+                           orf_list[o].Get_Gene_Len(), orf_list[o].Get_Orf_Len());
+                    index_of[make_pair(orf_list[o].Get_Frame(), orf_list[o].Get_Stop_Position())] = o;
+                }
+                Capture = true;
+                Captured.clear();
+                Score_Orfs_Errors(orf_list, NULL);
+                Capture = false;
+                for (size_t c = 0; c < Captured.size(); c++) {
+                    const Orf_t &orf = Captured[c].first;
+                    const vector<Start_t> &sl = Captured[c].second;
+                    printf("G %d %d\n", index_of[make_pair(orf.Get_Frame(), orf.Get_Stop_Position())], (int)sl.size());
+                    for (size_t s = 0; s < sl.size(); s++)
+                        printf("S %d %d %a %d %d %d\n", sl[s].j, sl[s].pos, sl[s].score, (int)sl[s].which,
+                               (int)sl[s].truncated, (int)sl[s].first);
+                }
+                orf_list.clear();
+                Clear_Events();
+            }
+            return 0;
+        }
+#ifdef GMG_BATCH
+        if (mode == "batch") {
+            const char *dev = getenv("GMG_DEVICE");
+            if (gmg_init(dev ? atoi(dev) : 0) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+            // pack every read (Filter + tolower + 2 bit, glimmer-mg.cc:381-382) and upload once
+            vector<uint64_t> off(n_seq + 1, 0);
+            for (int i = 0; i < n_seq; i++) off[i + 1] = off[i] + seq_list[i].length();
+            vector<uint32_t> packed(gmg_packed_words(off[n_seq]), 0);
+            for (int i = 0; i < n_seq; i++) gmg_pack_bases(seq_list[i].data(), seq_list[i].length(), off[i], packed.data());
+            gmg_reads *reads = NULL;
+            if (gmg_reads_upload(packed.data(), off.data(), n_seq, &reads) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+            // ONE call: Score_All_Frames + Find_Orfs + Score_Orf_Starts + the filter of Score_Orfs_Errors, all reads
+            gmg_mg_params prm;
+            memset(&prm, 0, sizeof prm);
+            prm.min_gene_len = Min_Gene_Len;
+            prm.allow_truncated = Allow_Truncated_Orfs;
+            prm.ignore_score_len = Ignore_Score_Len;
+            prm.start_threshold = Start_Threshold;
+            prm.n_start_codons = Start_Codon.size();
+            prm.n_stop_codons = Stop_Codon.size();
+            for (size_t s = 0; s < Start_Codon.size() && s < 8; s++) memcpy(prm.start_codon[s], Start_Codon[s], 3);
+            for (size_t s = 0; s < Stop_Codon.size() && s < 8; s++) memcpy(prm.stop_codon[s], Stop_Codon[s], 3);
+            gmg_mg_result *res = NULL;
+            if (gmg_mg_score_reads(Gene_ICM.Device_Model(), Indep_Model.Device_Model(), reads, &prm, NULL, &res, NULL) != GMG_OK) {
+                fprintf(stderr, "%s\n", gmg_last_error());
+                return 1;
+            }
+            uint64_t n_orfs = 0, n_starts = 0;
+            gmg_mg_result_info(res, &n_orfs, &n_starts);
+            vector<gmg_mg_orf> orfs(n_orfs ? n_orfs : 1);
+            vector<gmg_start> starts(n_starts ? n_starts : 1);
+            vector<uint64_t> read_orf_off(n_seq + 1);
+            if (gmg_mg_result_fetch(res, orfs.data(), starts.data(), read_orf_off.data()) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+            gmg_mg_result_free(res);
+            gmg_reads_free(reads);
+            // events, DP and trace-back per read: host, unchanged reference code (glimmer-mg.cc:400-441, 1620-1685)
+            string filename = Output_Tag;
+            filename.append(".predict");
+            FILE *predict_fp = File_Open(filename, "w", __FILE__, __LINE__);
+            for (int i = 0; i < n_seq; i++) {
+                load_sequence(seq_list, hdr_list, i);
+                fprintf(predict_fp, ">%s\n", Fasta_Header);
+                Initialize_Terminal_Events(First_Event, Final_Event, Best_Event, Last_Event);
+                Meta_PWM_Save.resize(2 * Sequence_Len);                    // glimmer-mg.cc:1622-1627
+                for (unsigned int si = 0; si < 2 * Sequence_Len; si++) Meta_PWM_Save[si] = pair<double, int>(0.0, 999);
+                int id = 0;
+                for (uint64_t o = read_orf_off[i]; o < read_orf_off[i + 1]; o++) {
+                    const gmg_mg_orf &g = orfs[o];
+                    if (!g.accepted) continue;
+                    Orf_t orf;
+                    orf.Set_Stop_Position(g.stop_position);
+                    orf.Set_Frame(g.frame);
+                    orf.Set_Gene_Len(g.gene_len);
+                    orf.Set_Orf_Len(g.orf_len);
+                    vector<Start_t> sl(g.n_starts);
+                    for (uint32_t s = 0; s < g.n_starts; s++) {
+                        const gmg_start &t = starts[g.start_begin + s];
+                        sl[s].j = t.j; sl[s].pos = t.pos; sl[s].score = t.score; sl[s].rate = 0.0; sl[s].which = t.which;
+                        sl[s].truncated = t.truncated; sl[s].first = t.first;
+                    }
+                    sort(sl.begin(), sl.end(), Start_Cmp);                 // glimmer-mg.cc:1659
+                    if (g.frame > 0) real_Add_Events_Fwd(orf, sl, id);
+                    else real_Add_Events_Rev(orf, sl, id);
+                }
+                Process_Events();
+                Set_Final_Event(Final_Event, Best_Event, Sequence_Len);
+                Trace_Back(predict_fp, Final_Event);
+                Clear_Events();
+            }
+            fclose(predict_fp);
+            return 0;
+        }
+#endif
+        fprintf(stderr, "unknown mode %s\n", mode.c_str());
+        return 2;
+    } catch (std::exception &e) {
+        cerr << "** Standard Exception **" << endl << e << endl;
+        return 1;
+    }
+}

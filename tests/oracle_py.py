@@ -36,6 +36,21 @@ MP = C.POINTER(Model)
 dp = C.POINTER(C.c_double)
 
 
+class Orf(C.Structure):
+    _fields_ = [("frame", C.c_int), ("stop_position", C.c_int), ("gene_len", C.c_int), ("orf_len", C.c_int)]
+
+
+class MgParams(C.Structure):
+    _fields_ = [("min_gene_len", C.c_int), ("allow_truncated", C.c_int), ("ignore_score_len", C.c_int),
+                ("start_threshold", C.c_double), ("n_start_codons", C.c_int), ("n_stop_codons", C.c_int),
+                ("start_codon", C.c_char_p * 8), ("stop_codon", C.c_char_p * 8)]
+
+
+class MgOut(C.Structure):
+    _fields_ = [("lo", C.c_int), ("hi", C.c_int), ("first_j", C.c_int), ("accepted", C.c_int),
+                ("orf_is_truncated", C.c_int), ("best_score", C.c_double)]
+
+
 def build():
     src = [os.path.join(ORACLE_DIR, f) for f in ("gmg_oracle.c", "gmg_oracle.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
@@ -73,6 +88,11 @@ class Oracle:
         L.orc_score_reads_6frame.argtypes = [MP, MP, C.c_char_p, C.c_int, C.c_int, dp]
         L.orc_score_orf.argtypes = [MP, MP, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(OrfParams),
                                     C.POINTER(Start), C.c_int, C.POINTER(OrfOut)]
+        ip = C.POINTER(C.c_int)
+        L.orc_find_orfs.argtypes = [C.c_char_p, C.c_int, C.POINTER(MgParams), C.POINTER(Orf), C.c_int]
+        L.orc_save_prev_stops.argtypes = [C.c_char_p, C.c_int, C.POINTER(MgParams), ip, ip]
+        L.orc_mg_score_orf.argtypes = [dp, C.c_char_p, C.c_int, ip, ip, C.c_int, C.c_int, C.POINTER(MgParams),
+                                       C.POINTER(Start), C.c_int, C.POINTER(MgOut)]
         for f in ("orc_filter", "orc_complement", "orc_subscript"):
             getattr(L, f).argtypes = [C.c_int]
 
@@ -173,6 +193,57 @@ class Oracle:
         n = self.L.orc_score_orf(gene, indep, s, len(s), frame, stop_position, orf_len, C.byref(prm), starts, cap,
                                  C.byref(out))
         return n, out, list(starts[:max(n, 0)])
+
+    # ---- glimmer-mg front half
+    @staticmethod
+    def mg_params(min_gene_len=75, allow_truncated=True, ignore_score_len=2**31 - 1, start_threshold=-6.0,
+                  start_codons=("atg", "gtg", "ttg"), stop_codons=("taa", "tag", "tga")):
+        p = MgParams(min_gene_len, int(allow_truncated), ignore_score_len, start_threshold, len(start_codons),
+                     len(stop_codons))
+        for i, c in enumerate(start_codons):
+            p.start_codon[i] = c.encode()
+        for i, c in enumerate(stop_codons):
+            p.stop_codon[i] = c.encode()
+        return p
+
+    def find_orfs(self, seq, prm):
+        """Find_Orfs -> int32 [n, 4]: frame, stop_position, gene_len, orf_len"""
+        s = seq.encode() if isinstance(seq, str) else seq
+        cap = 2 * len(s) + 16
+        buf = (Orf * cap)()
+        n = self.L.orc_find_orfs(s, len(s), C.byref(prm), buf, cap)
+        assert n <= cap
+        return np.array([(o.frame, o.stop_position, o.gene_len, o.orf_len) for o in buf[:n]], np.int32).reshape(-1, 4)
+
+    def save_prev_stops(self, seq, prm):
+        s = seq.encode() if isinstance(seq, str) else seq
+        fwd, rev = np.zeros(max(len(s), 1), np.int32), np.zeros(max(len(s), 1), np.int32)
+        ip = C.POINTER(C.c_int)
+        self.L.orc_save_prev_stops(s, len(s), C.byref(prm), fwd.ctypes.data_as(ip), rev.ctypes.data_as(ip))
+        return fwd, rev
+
+    def mg_score_orf(self, frame_scores, seq, fwd_prev, rev_next, frame, stop_position, prm):
+        """-> (MgOut, [Start] in push order)"""
+        s = seq.encode() if isinstance(seq, str) else seq
+        fs = np.ascontiguousarray(frame_scores, np.float64)
+        cap = len(s) // 3 + 8
+        starts = (Start * cap)()
+        out = MgOut()
+        ip = C.POINTER(C.c_int)
+        n = self.L.orc_mg_score_orf(fs.ctypes.data_as(dp), s, len(s), fwd_prev.ctypes.data_as(ip),
+                                    rev_next.ctypes.data_as(ip), frame, stop_position, C.byref(prm), starts, cap,
+                                    C.byref(out))
+        assert n <= cap
+        return out, list(starts[:n])
+
+    def mg_read(self, gene, indep, seq, prm):
+        """whole front half for one read: -> (orfs [n,4], [(MgOut, [Start])])"""
+        orfs = self.find_orfs(seq, prm)
+        if len(orfs) == 0:
+            return orfs, []
+        fs = self.score_all_frames(gene, indep, seq)
+        fwd, rev = self.save_prev_stops(seq, prm)
+        return orfs, [self.mg_score_orf(fs, seq, fwd, rev, int(o[0]), int(o[1]), prm) for o in orfs]
 
     def filter_lower(self, seq):
         """tolower(Filter(c)) per character (glimmer3.cc:270-271)"""

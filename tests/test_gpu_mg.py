@@ -1,0 +1,134 @@
+"""glimmer-mg's front half on the device (include/gmg.h: gmg_mg_score_reads) against
+  * the reference's own Find_Orfs + Score_Orfs_Errors on seqs.fa (tests/golden/mg_orfs_*.npz, written by
+    oracle/_ref/ref_mg_orfs, which pulls the reference's glimmer-mg.cc in whole),
+  * the oracle on seeded random reads of ragged lengths (edge cases: reads shorter than Min_Gene_Len, no stop at
+    all, truncated ORFs off, the Ignore_Score_Len boost, IUPAC start codons, two stop codons),
+  * the reference CLI: oracle/_ref/glimmer-mg_batch = glimmer-mg's own events / DP / trace-back around ONE
+    gmg_mg_score_reads call must write byte-identical .predict files.
+Integer fields and double scores must be equal bit for bit."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLD, ROOT
+from test_oracle_mg import CASES, golden_rows, ignore_score_len, mg_case, sorted_starts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nc(gpu):
+    return gpu.Icm.open(os.path.join(DATA, "NC_000915.icm"))
+
+
+def dev_rows(starts):
+    rows = [(int(s["pos"]), int(s["which"]), int(s["j"]), int(s["truncated"]), int(s["first"]), float(s["score"]))
+            for s in starts]
+    return sorted(rows, key=lambda r: (r[0], r[1]))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_mg_front_half_matches_reference_goldens(gpu, oracle, nc, seqs_fa, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    _, _, kw = mg_case(oracle, name)
+    gc = float(np.load(os.path.join(GOLD, "frames_nc.npz"))["gc"])
+    stops = kw.get("stop_codons", ("taa", "tag", "tga"))
+    reads = gpu.Reads.from_strings(seqs_fa[1])
+    orfs, starts, off = gpu.mg_score_reads(nc, gpu.Icm.indep(gc, stops), reads, **kw)
+    got = np.stack([orfs["read"].astype(np.int32), orfs["frame"], orfs["stop_position"], orfs["gene_len"],
+                    orfs["orf_len"]], 1)
+    assert np.array_equal(got, g["orfs"])                               # Find_Orfs, every read, in order
+    assert np.array_equal(off, np.searchsorted(g["orfs"][:, 0], np.arange(len(seqs_fa[1]) + 1)))
+    accepted = np.zeros(len(orfs), bool)
+    accepted[g["gene_orf"]] = True
+    assert np.array_equal(orfs["accepted"] != 0, accepted)              # what goes to Add_Events_*
+    for oi, b, cnt in zip(g["gene_orf"], g["gene_start_begin"], g["gene_nstarts"]):
+        o = orfs[oi]
+        assert o["n_starts"] == cnt
+        st = starts[o["start_begin"]:o["start_begin"] + o["n_starts"]]
+        assert dev_rows(st) == golden_rows(g, int(b), int(cnt))
+
+
+def random_reads(rng, lengths):
+    return ["".join("acgt"[c] for c in rng.integers(0, 4, size=n)) for n in lengths]
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(allow_truncated=False),
+    dict(min_gene_len=90, ignore_score_len=150),
+    dict(min_gene_len=30, start_codons=("atg", "rtg", "ttg", "ctg"), stop_codons=("taa", "tag"), start_threshold=-2.0),
+    dict(min_gene_len=4, ignore_score_len=10, start_threshold=-1e300),
+])
+def test_mg_front_half_matches_oracle_on_random_ragged_reads(gpu, oracle, nc, kw):
+    rng = np.random.default_rng(20260102)
+    lengths = list(rng.integers(1, 700, size=300)) + [1, 2, 3, 4, 5, 29, 30, 74, 75, 76, 89, 90, 91, 500, 1500]
+    seqs = random_reads(rng, lengths)
+    seqs.append("acg" * 200)                                            # no stop codon in any forward frame
+    seqs.append("taa" * 100 + "a")                                      # stops back to back
+    seqs.append("atg" + "gct" * 150 + "taa" + "cc")                     # one clean forward gene
+    seqs.append("gg" + "tta" + "agc" * 150 + "cat" + "g")               # its reverse-strand twin
+    stops = kw.get("stop_codons", ("taa", "tag", "tga"))
+    o_nc = oracle.read(os.path.join(DATA, "NC_000915.icm"))
+    o_indep = oracle.indep(0.45, stops)
+    prm = oracle.mg_params(**kw)
+    reads = gpu.Reads.from_strings(seqs)
+    orfs, starts, off = gpu.mg_score_reads(nc, gpu.Icm.indep(0.45, stops), reads, **kw)
+    n_acc = n_trunc = n_boost = 0
+    for r, seq in enumerate(seqs):
+        want_orfs, scored = oracle.mg_read(o_nc, o_indep, seq.encode(), prm)
+        mine = orfs[int(off[r]):int(off[r + 1])]
+        got = np.stack([mine["frame"], mine["stop_position"], mine["gene_len"], mine["orf_len"]], 1).reshape(-1, 4)
+        assert np.array_equal(got, want_orfs), "Find_Orfs differs on read %d (len %d)" % (r, len(seq))
+        assert np.all(mine["read"] == r)
+        for o, (out, want) in zip(mine, scored):
+            assert (o["lo"], o["hi"], o["orf_is_truncated"]) == (out.lo, out.hi, out.orf_is_truncated)
+            st = starts[o["start_begin"]:o["start_begin"] + o["n_starts"]]
+            assert len(st) == len(want)
+            for s, w in zip(st, want):                                  # push order, field by field
+                assert (s["j"], s["pos"], s["which"], s["truncated"], s["first"]) == (w.j, w.pos, w.which, w.truncated, w.first)
+                assert s["score"] == w.score
+                n_boost += int(w.j > prm.ignore_score_len and w.score == 0.0)
+            assert (o["first_j"], o["accepted"] != 0) == (out.first_j, bool(out.accepted))
+            assert o["best_score"] == out.best_score
+            n_acc += int(out.accepted)
+            n_trunc += out.orf_is_truncated
+    assert n_acc > 10
+    if kw.get("allow_truncated", True):
+        assert n_trunc > 50
+    if "ignore_score_len" in kw:
+        assert n_boost > 0
+
+
+def test_mg_frame_scores_are_handed_back_and_empty_batches_work(gpu, nc, seqs_fa):
+    reads = gpu.Reads.from_strings(seqs_fa[1][:40])
+    indep = gpu.Icm.indep(0.5)
+    buf = gpu.api._DeviceBuffer(6 * reads.total_bases * 8)
+    orfs, starts, off = gpu.mg_score_reads(nc, indep, reads, frame_scores=buf)
+    table = buf.to_host(np.float64, 6 * reads.total_bases).reshape(6, -1)
+    assert np.array_equal(table, gpu.frame_score6(nc, indep, reads))
+    buf.free()
+    assert len(orfs) == off[-1] > 100
+    short = gpu.Reads.from_strings(["acgt", "ac"])                      # nothing reaches Min_Gene_Len
+    orfs, starts, off = gpu.mg_score_reads(nc, indep, short)
+    assert len(orfs) == 0 and len(starts) == 0 and list(off) == [0, 0, 0]
+    with pytest.raises(gpu.GmgError):
+        gpu.mg_score_reads(gpu.Icm.open(os.path.join(DATA, "cluster-4.icm")), indep, reads)     # periodicity 1
+
+
+@pytest.mark.parametrize("flags,golden", [([], "glimmer-mg.default.predict"), (["-g", "120"], "glimmer-mg.g120.predict"),
+                                          (["-Z", "taa,tag"], "glimmer-mg.Z2.predict")])
+def test_glimmer_mg_with_device_front_half_is_byte_identical(gpu, tmp_path, flags, golden):
+    """oracle/_ref/glimmer-mg_batch: glimmer-mg's own Add_Events / Process_Events / Trace_Back around ONE
+    gmg_mg_score_reads call that replaces Score_All_Frames, Find_Orfs and Score_Orfs_Errors of all 999 reads
+    (oracle/ref_drivers/ref_mg_orfs.cc)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "glimmer-mg_batch")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/glimmer-mg_batch not built (needs /root/reference in the build container)")
+    tag = str(tmp_path / "out")
+    cmd = [exe, "batch", *flags, "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, "seqs.fa"), tag]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", golden), "rb").read()
