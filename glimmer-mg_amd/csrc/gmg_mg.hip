@@ -5,9 +5,12 @@
 //   1. gmg_launch_frame6        Score_All_Frames (glimmer-mg.cc:1468-1510): Frame_Scores[6][total] in HBM
 //   2. k_mg_find_orfs<count>    Find_Orfs (glimmer_base.cc:638-779), one lane per read: ORFs per read
 //      exclusive scan, k_mg_find_orfs<write>: the Orf_t records + lo / hi of Score_Orf_Starts
-//   3. k_mg_starts<count>       one lane per ORF: number of entries Score_Orf_Starts will push
-//      exclusive scan, k_mg_starts<write>: Cumulative_Frame_Score (glimmer-mg.cc:561-604) as sequential
-//      double adds over the ORF, the start list in push order, boost, first_j, best score, threshold.
+//   3. k_mg_cum                 Cumulative_Frame_Score (glimmer-mg.cc:561-604) for EVERY possible ORF at once:
+//      one lane per (read, strand) walks the read once with three running sums (one per reading-frame
+//      class), each reset at the in-class stop codons, and stores the sum at every in-frame position.
+//   4. k_mg_starts<count>       one lane per ORF: number of entries Score_Orf_Starts will push
+//      exclusive scan, k_mg_starts<write>: the start list in push order (scores = one read of the running
+//      sums per start codon), boost, first_j, best score, threshold.
 // Integer / byte work except the one running sum; no table of Save_Prev_Stops (glimmer-mg.cc:675-729) is
 // materialised -- the ORF scan already knows the previous / next in-frame stop of every ORF it emits:
 //   forward ORF ended by the stop whose last base is i (class c = i % 3):
@@ -40,6 +43,7 @@ struct MgArgs {
     const uint64_t *read_off;
     uint64_t n_reads, total;
     const double *fs;            // Frame_Scores [6][total]
+    double *cum;                 // [2][total]: score[j-1] of the ORF for which this base is in frame (k_mg_cum)
     // codon tests as 64-bit sets over idx6 = code(oldest) << 4 | code << 2 | code(newest)
     uint64_t fwd_start, rev_start, fwd_stop, rev_stop;
     int8_t which[64];            // index of the first matching start codon, -1 for none (Codon_t::Can_Be)
@@ -206,6 +210,88 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Cumulative_Frame_Score (glimmer-mg.cc:561-604) for every ORF a read can have, in ONE walk per strand.
+//
+// A forward ORF with bounds (lo, hi) sums Frame_Scores[f][si] for si = hi-1, hi-2, ... with f = 1,2,0,...;
+// a reverse ORF sums Frame_Scores[3+f][si] for si = lo-1, lo, ... .  Both start right behind an in-frame
+// stop codon (a real one, or the virtual ones Find_Orfs / Save_Prev_Stops put around the read:
+// glimmer_base.cc:765-776, 1035-1042; glimmer-mg.cc:685,708-710), and ORFs of one reading-frame class do
+// not overlap.  So three running sums per strand, one per class, each set to zero when the walk steps
+// over a stop codon of its class, hold score[j-1] of whichever ORF is open in that class -- with exactly
+// the reference's sequence of double additions, because every sum restarts from 0 at the ORF's own first
+// base.  Seen from the walk, the class that is in frame now (j % 3 == 0) takes row 1, the class in frame
+// at the next step (j % 3 == 2) row 0, the third (j % 3 == 1) row 2; then the roles rotate.  At every
+// base the in-frame class stores its sum BEFORE adding: that is score[j-1] of glimmer-mg.cc:1826.
+// One lane per (read, strand); 64-byte loads per row and lane (8 positions), 64-byte stores.
+// ---------------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(8))) MgD4 { double v[4]; };
+
+template <bool FWD>
+__device__ __forceinline__ void mg_cum_one(const MgArgs &a, uint64_t r)
+{
+    const int64_t off = (int64_t)a.read_off[r];
+    const int n = (int)((int64_t)a.read_off[r + 1] - off);
+    if (n <= 0) return;
+    const double *row0 = a.fs + (FWD ? 0 : 3) * a.total + off;
+    const double *row1 = row0 + a.total, *row2 = row1 + a.total;
+    double *ctab = a.cum + (FWD ? 0 : a.total) + off;
+    const uint64_t stopmask = FWD ? a.fwd_stop : a.rev_stop;
+    int64_t g = off + (FWD ? n - 1 : 0);
+    uint32_t w = a.packed[g >> 4];
+    uint32_t idx6 = 0;
+    double A = 0.0, B = 0.0, C = 0.0;
+
+    // one base: r0/r1/r2 = rows 0,1,2 (+3) at this base; returns what the in-frame class stores
+    auto step = [&](bool warm, double r0, double r1, double r2) __attribute__((always_inline)) {
+        const bool reset = warm || ((stopmask >> idx6) & 1ull);          // the three bases just passed are a stop of this class
+        A = reset ? 0.0 : A;
+        const double keep = A;
+        A += r1; B += r0; C += r2;
+        const uint32_t code = (w >> (2u * (unsigned)(g & 15))) & 3u;
+        const int64_t g2 = g + (FWD ? -1 : 1);
+        if ((g ^ g2) >> 4) w = a.packed[g2 >> 4];
+        g = g2;
+        // the last three bases passed, indexed as Find_Orfs indexes a codon (first base of the forward reading highest)
+        idx6 = FWD ? (idx6 >> 2) | (code << 4) : ((idx6 << 2) | code) & 63u;
+        const double tA = A; A = B; B = C; C = tA;
+        return keep;
+    };
+
+    int t = 0;
+    for (; t + 24 <= n; t += 24) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int64_t first = FWD ? (int64_t)n - 1 - (t + 8 * u) : (int64_t)(t + 8 * u);   // base of the group's first step
+            const int64_t base = FWD ? first - 7 : first;
+            MgD4 x0[2], x1[2], x2[2], y[2];
+            x0[0] = *(const MgD4 *)(row0 + base); x0[1] = *(const MgD4 *)(row0 + base + 4);
+            x1[0] = *(const MgD4 *)(row1 + base); x1[1] = *(const MgD4 *)(row1 + base + 4);
+            x2[0] = *(const MgD4 *)(row2 + base); x2[1] = *(const MgD4 *)(row2 + base + 4);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int e = FWD ? 7 - k : k;
+                y[e >> 2].v[e & 3] = step(t + 8 * u + k < 3, x0[e >> 2].v[e & 3], x1[e >> 2].v[e & 3], x2[e >> 2].v[e & 3]);
+            }
+            *(MgD4 *)(ctab + base) = y[0];
+            *(MgD4 *)(ctab + base + 4) = y[1];
+        }
+    }
+    for (; t < n; t++) {
+        const int64_t si = FWD ? (int64_t)n - 1 - t : (int64_t)t;
+        ctab[si] = step(t < 3, row0[si], row1[si], row2[si]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mg_cum(MgArgs a)
+{
+    // lanes [0, n_reads): forward strand; [n_reads, 2 n_reads): reverse strand (wave-uniform but for one wave)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * a.n_reads; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (i < a.n_reads) mg_cum_one<true>(a, i);
+        else mg_cum_one<false>(a, i - a.n_reads);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Score_Orf_Starts without errors (glimmer-mg.cc:1693-1861) + the per-ORF part of Score_Orfs_Errors
 // (:1632-1685): one lane per ORF, ONE pass from buffer position 0 (the 3' end) upwards.
 //   * running sum in reference order: score[j] = score[j-1] + Frame_Scores[f][si], f = 1,2,0,...
@@ -215,14 +301,15 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
 //   * a truncated ORF (glimmer-mg.cc:1741,1761) pushes its highest in-frame position unconditionally as a
 //     truncated start (slot 0), followed by the real start at the same position if there is one.
 // ---------------------------------------------------------------------------------------------------
-template <bool WRITE, bool FWD>
+template <bool WRITE>
 __device__ __forceinline__ void mg_starts_one(const MgArgs &a, uint64_t i, const int8_t *s_which)
 {
     gmg_mg_orf o = a.orfs[i];
+    const bool fwd = o.frame > 0;                       // direction is data, not a code path: the lanes of a wave mix both strands
     const uint64_t off = a.read_off[o.read];
     const int n = (int)(a.read_off[o.read + 1] - off);
     const int lo = o.lo, hi = o.hi, m = hi - lo;
-    const bool trunc = a.allow_truncated && (FWD ? lo < 3 : n - (hi - 1) < 3);
+    const bool trunc = a.allow_truncated && (fwd ? lo < 3 : n - (hi - 1) < 3);
     const int mgl = a.min_gene_len;
     int j_lo = mgl - 3 > 1 ? mgl - 3 : 1;              // j >= lowest_j = Min (3, mgl-3), j >= 1 (j-1 is read), j+3 >= mgl
     j_lo = (j_lo + 2) / 3 * 3;
@@ -230,44 +317,47 @@ __device__ __forceinline__ void mg_starts_one(const MgArgs &a, uint64_t i, const
     const bool has_trunc = trunc && jmax >= j_lo;
     const uint32_t n_total = WRITE ? (uint32_t)(a.start_off[i + 1] - a.start_off[i]) : 0;
     gmg_start *out = WRITE ? a.starts + a.start_off[i] : nullptr;
-    const int k_base = FWD ? lo - 1 + (m - 1) : hi + 1 - (m - 1);      // pos of j: k_base -/+ j (glimmer-mg.cc:1742,1762,1855-1858)
+    const int k_base = fwd ? lo - 1 + (m - 1) : hi + 1 - (m - 1);      // pos of j: k_base -/+ j (glimmer-mg.cc:1742,1762,1855-1858)
+    const int64_t dir = fwd ? -1 : 1;
+    const uint32_t comp = fwd ? 0u : 3u;                // Reverse_Transfer / Complement_Transfer (glimmer-mg.cc:1735,1756)
 
     uint32_t t = 0;                                     // real starts so far (ascending j)
-    double cum = 0.0, pend = 0.0, best = -DBL_MAX, s_jmax = 0.0;
+    double best = -DBL_MAX, s_jmax = 0.0;
     int last_j = -1;
     if (m > 0) {
-        BaseStream<FWD ? -1 : 1> bs;
-        const uint64_t g0 = off + (uint64_t)(FWD ? hi - 1 : lo - 1);    // base of buffer position 0
-        bs.init(a.packed, g0);
-        const double *row = a.fs + (FWD ? 0 : 3) * a.total + g0;
-        uint32_t idx6 = 0;
-        int f = 1, jm3 = 0;
-        for (int j = 0; j < m; j++) {
-            const int c0 = bs.next();
-            const int code = FWD ? c0 : 3 - c0;         // Reverse_Transfer / Complement_Transfer (glimmer-mg.cc:1735,1756)
-            idx6 = (idx6 >> 2) | ((uint32_t)code << 4); // buff[j] oldest <-> highest: (buff[j], buff[j-1], buff[j-2]) as Codon_t holds them
-            if (jm3 == 2 && j - 2 >= j_lo) {            // codon of in-frame position j-2 is complete
-                const int which = s_which[idx6];
+        int64_t g = (int64_t)off + (fwd ? hi - 1 : lo - 1);             // base of buffer position 0 (signed: steps to -1 at the very front)
+        uint32_t w = a.packed[g >> 4];
+        auto next_code = [&]() __attribute__((always_inline)) {
+            const uint32_t c = ((w >> (2u * (unsigned)(g & 15))) & 3u) ^ comp;
+            const int64_t g2 = g + dir;
+            if ((g ^ g2) >> 4) w = a.packed[g2 >> 4];   // word -1 / one word past the end: the guard words of gmg_reads
+            g = g2;
+            return c;
+        };
+        // score[j-1] of every in-frame position j: k_mg_cum left it at the base of buffer position j
+        const double *ctab = a.cum + (fwd ? 0 : a.total);
+        const int64_t g0 = g;
+        int j = 0;
+        for (; j + 2 < m; j += 3) {                     // one whole codon per trip: in-frame position j and its two followers
+            const uint32_t c0 = next_code(), c1 = next_code(), c2 = next_code();
+            if (j >= j_lo) {
+                const int which = s_which[c2 << 4 | c1 << 2 | c0];     // (buff[j+2], buff[j+1], buff[j]) as Codon_t holds them
                 if (which >= 0) {
                     if (WRITE) {
-                        const double sc = (j > a.ignore_score_len && 0.0 > pend) ? 0.0 : pend;   // j-2+2 > Ignore_Score_Len: Max (0.0, score)
+                        const double pend = ctab[g0 + dir * j];        // score[j-1] - indep_score[j-1], indep_score == 0
+                        const double sc = (j + 2 > a.ignore_score_len && 0.0 > pend) ? 0.0 : pend;   // Max (0.0, score), :1644-1646
                         gmg_start st;
-                        st.score = sc; st.j = j; st.pos = FWD ? k_base - (j - 2) : k_base + (j - 2);
+                        st.score = sc; st.j = j + 2; st.pos = fwd ? k_base - j : k_base + j;
                         st.which = which; st.truncated = 0; st.first = 0;
                         out[n_total - 1 - t] = st;
                         if (sc > best) best = sc;
                     }
                     t++;
-                    last_j = j - 2;
+                    last_j = j;
                 }
             }
-            if (WRITE) {
-                if (jm3 == 0) { pend = cum; if (j == jmax) s_jmax = cum; }   // score[j-1]
-                cum += row[FWD ? -(int64_t)j + (int64_t)f * (int64_t)a.total : (int64_t)j + (int64_t)f * (int64_t)a.total];
-            }
-            f = f == 2 ? 0 : f + 1;
-            jm3 = jm3 == 2 ? 0 : jm3 + 1;
         }
+        if (WRITE && has_trunc) s_jmax = ctab[g0 + dir * jmax];
     }
     const uint32_t n_starts = t + (has_trunc ? 1u : 0u);
     if (!WRITE) { a.orf_cnt[i] = n_starts; return; }
@@ -276,7 +366,7 @@ __device__ __forceinline__ void mg_starts_one(const MgArgs &a, uint64_t i, const
     if (has_trunc) {
         const double sc = (jmax + 2 > a.ignore_score_len && 0.0 > s_jmax) ? 0.0 : s_jmax;
         gmg_start st;
-        st.score = sc; st.j = jmax + 2; st.pos = FWD ? k_base - jmax : k_base + jmax;
+        st.score = sc; st.j = jmax + 2; st.pos = fwd ? k_base - jmax : k_base + jmax;
         st.which = -1; st.truncated = 1; st.first = 1;
         out[0] = st;
         if (sc > best) best = sc;
@@ -305,8 +395,7 @@ __global__ __launch_bounds__(256) void k_mg_starts(MgArgs a)
     if (threadIdx.x < 64) s_which[threadIdx.x] = a.which[threadIdx.x];
     __syncthreads();
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (a.orfs[i].frame > 0) mg_starts_one<WRITE, true>(a, i, s_which);
-        else mg_starts_one<WRITE, false>(a, i, s_which);
+        mg_starts_one<WRITE>(a, i, s_which);
     }
 }
 
@@ -417,12 +506,14 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
     double *d_fs_own = nullptr;
     uint32_t *d_read_cnt = nullptr, *d_orf_cnt = nullptr;
     uint64_t *d_start_off = nullptr;
+    double *d_cum = nullptr;
     int rc = GMG_OK;
     auto fail = [&](int code) {
         if (d_fs_own) (void)hipFree(d_fs_own);
         if (d_read_cnt) (void)hipFree(d_read_cnt);
         if (d_orf_cnt) (void)hipFree(d_orf_cnt);
         if (d_start_off) (void)hipFree(d_start_off);
+        if (d_cum) (void)hipFree(d_cum);
         gmg_mg_result_free(res);
         return code;
     };
@@ -444,6 +535,11 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
         if (rc) return fail(rc);
     }
     a.fs = d_frame_scores;
+    // running sums of every reading-frame class (what Cumulative_Frame_Score would give any ORF)
+    MG_TRY(hipMalloc((void **)&d_cum, (size_t)2 * (a.total ? a.total : 1) * sizeof(double)));
+    a.cum = d_cum;
+    if (a.n_reads) hipLaunchKernelGGL(k_mg_cum, dim3(grid_for(2 * a.n_reads)), dim3(256), 0, s, a);
+    MG_TRY(hipGetLastError());
 
     // 2. ORFs of every read
     const uint64_t nr = a.n_reads;
@@ -485,6 +581,7 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
     (void)hipFree(d_read_cnt);
     (void)hipFree(d_orf_cnt);
     (void)hipFree(d_start_off);
+    (void)hipFree(d_cum);
     *out = res;
     return GMG_OK;
 }

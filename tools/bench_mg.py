@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Secondary measurement: gmg_mg_score_reads (glimmer-mg's front half: Score_All_Frames + Find_Orfs +
+Score_Orf_Starts + the filter of Score_Orfs_Errors) on synthetic 500-bp reads, with the reads
+resident in HBM.  Prints one JSON line: Mbases/s of read bases through the whole front half, the sizes of what
+leaves the GPU, and the CPU oracle's rate for the same steps on a sample."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _gmg_pkg  # noqa: E402
+
+gmg = _gmg_pkg.load()
+api, capi = gmg.api, gmg.capi
+
+n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+L = 500
+gmg.init(0)
+model = os.path.join(ROOT, "tests", "golden", "data", "NC_000915.icm")
+gene, indep = gmg.Icm.open(model), gmg.Icm.indep(0.5)
+packed, off = gmg.synth.packed_reads(n_reads, L, 7)
+reads = gmg.Reads(packed, off)
+lib = capi.lib()
+prm = capi.MgParams(75, 1, 2**31 - 1, 3, 3, 0, -6.0)
+for i, c in enumerate(("atg", "gtg", "ttg")):
+    prm.start_codon[i].value = c.encode()
+for i, c in enumerate(("taa", "tag", "tga")):
+    prm.stop_codon[i].value = c.encode()
+fs = api._DeviceBuffer(6 * reads.total_bases * 8)      # the Frame_Scores table stays on the device
+
+
+def run():
+    res = C.c_void_p()
+    api._ck(lib.gmg_mg_score_reads(gene.device(), indep.device(), reads.h, C.byref(prm), fs.ptr, C.byref(res), None))
+    n_orfs, n_starts = C.c_uint64(), C.c_uint64()
+    api._ck(lib.gmg_mg_result_info(res, C.byref(n_orfs), C.byref(n_starts)))
+    lib.gmg_mg_result_free(res)
+    return n_orfs.value, n_starts.value
+
+
+n_orfs, n_starts = run()
+t0 = time.perf_counter()
+for _ in range(reps):
+    run()
+dt = (time.perf_counter() - t0) / reps
+out = {"reads": n_reads, "read_bases": reads.total_bases, "orfs": n_orfs, "starts": n_starts,
+       "ms": dt * 1e3, "mbases_per_s": reads.total_bases / dt / 1e6,
+       "result_bytes": n_orfs * 56 + n_starts * 24, "frame_scores_bytes": 6 * reads.total_bases * 8}
+# the oracle on a sample: the same steps on one core
+import oracle_py  # noqa: E402
+orc = oracle_py.load()
+og, oi = orc.read(model), orc.indep(0.5)
+oprm = orc.mg_params()
+sample = 2000
+t0 = time.perf_counter()
+for r in range(sample):
+    orc.mg_read(og, oi, gmg.synth.unpack_ascii(packed, r * L, L), oprm)
+out["cpu_port_mbases_per_s"] = sample * L / (time.perf_counter() - t0) / 1e6
+print(json.dumps(out))
