@@ -59,6 +59,7 @@ PROTOTYPES = {
     "gmg_mg_result_info": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
     "gmg_mg_result_fetch": (i32, [vp, vp, vp, vp]),
     "gmg_mg_result_free": (i32, [vp]),
+    "gmg_trim_cache": (i32, []),
     "gmg_orfs_upload": (i32, [vp, vp, u64, C.POINTER(u64), C.POINTER(vp)]),
     "gmg_orf_batch_free": (i32, [vp]),
     "gmg_score_orfs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),

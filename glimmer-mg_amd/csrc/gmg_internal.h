@@ -56,6 +56,7 @@ struct gmg_reads {
     void *d_packed_alloc;        // d_packed - GMG_GUARD_WORDS: the allocation (always library-owned)
     int owns_off;                // d_off allocated by the library
     int uniform_len;             // > 0 when every read has this length (fast read lookup)
+    uint64_t max_len, min_len;   // longest / shortest read of the batch
 };
 
 struct gmg_segments {

@@ -28,8 +28,13 @@
 
 #include <float.h>
 #include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <chrono>
+#include <mutex>
 #include <new>
+#include <vector>
 
 struct gmg_mg_result {
     gmg_mg_orf *d_orfs;
@@ -41,9 +46,16 @@ struct gmg_mg_result {
 struct MgArgs {
     const uint32_t *packed;
     const uint64_t *read_off;
+    const uint32_t *tile_read;   // read containing base t * GMG_TILE (gmg_reads)
     uint64_t n_reads, total;
     const double *fs;            // Frame_Scores [6][total]
-    double *cum;                 // [2][total]: score[j-1] of the ORF for which this base is in frame (k_mg_cum)
+    double *cum;                 // [2][total]: score[j-1] of the ORF for which this base is in frame (k_mg_cum*)
+    // tiling of k_mg_cum_tiled: uniform batches take reads_per_tile reads per block; ragged batches the reads
+    // that start inside the block's window of tile_window bases
+    int uniform_len, reads_per_tile;
+    uint64_t tile_window, n_tiles;
+    int lanes_only_unfit;        // k_mg_cum: skip the reads the tiled kernel has done
+    int tile_cap;                // bases per tile of the tiled kernel
     // codon tests as 64-bit sets over idx6 = code(oldest) << 4 | code << 2 | code(newest)
     uint64_t fwd_start, rev_start, fwd_stop, rev_stop;
     int8_t which[64];            // index of the first matching start codon, -1 for none (Codon_t::Can_Be)
@@ -282,12 +294,214 @@ __device__ __forceinline__ void mg_cum_one(const MgArgs &a, uint64_t r)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_mg_cum_tiled: the same sums with coalesced traffic.  A block stages the three rows of one strand of a
+// few consecutive reads (<= MG_CAP bases) in LDS with contiguous loads, lists the places where a running
+// sum starts -- behind a stop codon of its class, real or virtual -- and gives every such region (up to the
+// next stop of the class) to one lane: one sum per lane, f = 1,2,0,..., on the staged rows.  The value the
+// reference calls score[j-1] overwrites the row-1 entry it was about to consume (each entry is consumed
+// exactly once), so row 1 of the tile becomes the output and leaves with contiguous stores.
+// Which reads a tile takes is a pure function of the offsets (mg_tile_reads), so that k_mg_cum can pick up
+// the reads that do not fit (longer than the tile, or more than MG_TILE_READS in one window).
+// ---------------------------------------------------------------------------------------------------
+#define MG_TILE_READS 64         // reads per tile
+
+// first read r in [0, n_reads] with read_off[r] >= key; the table of the read at every 1024th base (gmg_reads)
+// narrows the search to the reads of one 1024-base stretch
+__device__ __forceinline__ uint64_t mg_lower_bound(const MgArgs &a, uint64_t key)
+{
+    if (key >= a.total) return key > a.total ? a.n_reads + 1 : a.n_reads;  // read_off[n_reads] == total
+    const uint64_t t = key / GMG_TILE;
+    uint64_t lo = a.tile_read[t];                                        // read_off[lo] <= t * 1024 <= key
+    uint64_t hi = (t + 1) * GMG_TILE < a.total ? (uint64_t)a.tile_read[t + 1] + 1 : a.n_reads;   // read_off[hi] > key, or the end
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (a.read_off[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// reads [first, first + nfit) of tile k
+__device__ __forceinline__ void mg_tile_reads(const MgArgs &a, uint64_t k, uint64_t &first, uint32_t &nfit, const uint32_t cap)
+{
+    uint64_t end;
+    if (a.uniform_len > 0) {
+        first = k * (uint64_t)a.reads_per_tile;
+        end = first + (uint64_t)a.reads_per_tile < a.n_reads ? first + (uint64_t)a.reads_per_tile : a.n_reads;
+        nfit = first < end ? (uint32_t)(end - first) : 0;
+        return;
+    }
+    first = mg_lower_bound(a, k * a.tile_window);
+    end = mg_lower_bound(a, (k + 1) * a.tile_window);
+    if (end > a.n_reads) end = a.n_reads;
+    nfit = 0;
+    if (first >= a.n_reads) return;
+    const uint64_t w0 = a.read_off[first];
+    while (first + nfit < end && nfit < MG_TILE_READS && a.read_off[first + nfit + 1] - w0 <= cap) nfit++;
+}
+
+template <int MG_CAP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_fs[];       // [3][MG_CAP]: rows 0,1,2 of one strand
+    __shared__ uint16_t s_list[MG_CAP];                                 // tile bases where a running sum starts
+    __shared__ uint32_t s_fbits[(MG_CAP + 32 + BLOCK) / 32 + 2];        // the same as one bit per base, bit 32 + b
+    __shared__ uint32_t s_packed[MG_CAP / 16 + 3];
+    __shared__ uint32_t s_roff[MG_TILE_READS + 1];                      // read starts relative to the tile
+    __shared__ uint32_t s_nlist;
+    constexpr int PER = (MG_CAP + BLOCK - 1) / BLOCK;                   // doubles per lane and row
+    constexpr int PW = (MG_CAP / 16 + 3 + BLOCK - 1) / BLOCK;           // packed words per lane
+    constexpr int PR = (MG_TILE_READS + 1 + BLOCK - 1) / BLOCK;         // read offsets per lane
+
+    struct Tile { uint64_t first, w0; uint32_t nfit, span; };
+    double tmp[3][PER];
+    uint32_t tpk[PW], tro[PR];
+    auto meta = [&](uint64_t k, Tile &t) __attribute__((always_inline)) {
+        t.nfit = 0; t.span = 0; t.first = 0; t.w0 = 0;
+        if (k >= 2 * a.n_tiles) return;
+        mg_tile_reads(a, k >> 1, t.first, t.nfit, MG_CAP);
+        if (t.nfit == 0) return;
+        t.w0 = a.read_off[t.first];
+        t.span = (uint32_t)(a.read_off[t.first + t.nfit] - t.w0);
+    };
+    // every global load of a tile is issued here, one tile ahead: they are in flight while the block works on the
+    // tile before
+    auto issue = [&](uint64_t k, const Tile &t) __attribute__((always_inline)) {
+        if (t.nfit == 0) return;
+        const bool fwd = (k & 1) == 0;
+#pragma unroll
+        for (int row = 0; row < 3; row++) {
+            const double *src = a.fs + (uint64_t)((fwd ? 0 : 3) + row) * a.total + t.w0;
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
+                tmp[row][u] = i < t.span ? src[i] : 0.0;
+            }
+        }
+        const uint32_t n_words = ((uint32_t)(t.w0 & 15) + t.span + 15) / 16;
+#pragma unroll
+        for (int u = 0; u < PW; u++) {
+            const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
+            tpk[u] = i < n_words ? a.packed[(t.w0 >> 4) + i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < PR; u++) {
+            const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
+            tro[u] = i <= t.nfit ? (uint32_t)(a.read_off[t.first + i] - t.w0) : 0u;
+        }
+    };
+
+    uint64_t k = blockIdx.x;
+    Tile cur;
+    meta(k, cur);
+    issue(k, cur);
+    for (; k < 2 * a.n_tiles; k += gridDim.x) {         // (tile, strand)
+        const bool fwd = (k & 1) == 0;
+        const uint32_t nfit = cur.nfit, span = cur.span;
+        const uint64_t w0 = cur.w0;
+        __syncthreads();                                // the previous tile has left the LDS
+        if (nfit) {
+#pragma unroll
+            for (int row = 0; row < 3; row++)
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
+                    if (i < span) s_fs[row * MG_CAP + i] = tmp[row][u];
+                }
+#pragma unroll
+            for (int u = 0; u < PW; u++) {
+                const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
+                if (i < MG_CAP / 16 + 3) s_packed[i] = tpk[u];
+            }
+#pragma unroll
+            for (int u = 0; u < PR; u++) {
+                const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
+                if (i <= nfit) s_roff[i] = tro[u];
+            }
+        }
+        if (threadIdx.x == 0) s_nlist = 0;
+        Tile nxt;
+        meta(k + gridDim.x, nxt);
+        issue(k + gridDim.x, nxt);
+        __syncthreads();
+        if (nfit) {
+        const uint32_t shift = (uint32_t)(w0 & 15);     // tile base b is bit pair shift + b of s_packed
+        auto codon = [&](uint32_t b) __attribute__((always_inline)) {      // tile bases b, b+1, b+2 as Find_Orfs indexes a codon
+            const uint32_t x = shift + b;
+            const uint64_t two = (uint64_t)s_packed[x >> 4] | (uint64_t)s_packed[(x >> 4) + 1] << 32;
+            const uint32_t c = (uint32_t)(two >> (2u * (x & 15u))) & 63u;   // base b lowest
+            return (c & 3u) << 4 | (c & 12u) | c >> 4;
+        };
+        // 1. where do running sums start?  forward strand: the walk goes down and starts below a forward stop codon
+        //    (bases si+1..si+3) or below the virtual ones past the end of the read (glimmer_base.cc:765-776); reverse
+        //    strand: it goes up and starts behind a reverse stop codon (bases si-3..si-1) or the virtual ones before
+        //    the read (:1001-1003, 1035-1042).  One flag bit per tile base (bit 32 + b), all ones around the tile: the
+        //    last three bases of a read (forward) / its first three (reverse) are always starts, so a walk can never
+        //    step over a read boundary without meeting a flag.
+        for (uint32_t b0 = 0; b0 < MG_CAP + 32; b0 += BLOCK) {
+            const uint32_t b = b0 + threadIdx.x;
+            bool st = true;
+            if (b < span) {
+                int rs, n;
+                if (a.uniform_len > 0) { rs = (int)(b / (uint32_t)a.uniform_len) * a.uniform_len; n = a.uniform_len; }
+                else {
+                    uint32_t lo = 0, hi = nfit;         // last r with s_roff[r] <= b
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_roff[mid] <= b) lo = mid; else hi = mid; }
+                    rs = (int)s_roff[lo];
+                    n = (int)s_roff[lo + 1] - rs;
+                }
+                const int si = (int)b - rs;
+                if (fwd) st = si + 3 >= n || ((a.fwd_stop >> codon((uint32_t)(rs + si + 1))) & 1ull);
+                else st = si < 3 || ((a.rev_stop >> codon((uint32_t)(rs + si - 3))) & 1ull);
+                if (st) s_list[atomicAdd(&s_nlist, 1u)] = (uint16_t)b;
+            }
+            const uint64_t bits = __ballot(st);
+            if ((threadIdx.x & 63u) == 0 && b < MG_CAP + 32) {
+                s_fbits[(b + 32) >> 5] = (uint32_t)bits;
+                s_fbits[((b + 32) >> 5) + 1] = (uint32_t)(bits >> 32);
+            }
+        }
+        if (threadIdx.x == 0) s_fbits[0] = 0xffffffffu;
+        __syncthreads();
+        // 2. one lane per region: a single sum, f = 1,2,0,...; score[j-1] takes the place of the row-1 entry it
+        //    precedes.  What a trip adds beyond the end of its read is never used: the next flag ends the walk.
+        const uint32_t n_list = s_nlist;
+        double *r0 = s_fs, *r1 = s_fs + MG_CAP, *r2 = s_fs + 2 * MG_CAP;
+        const int dir = fwd ? -1 : 1;
+        for (uint32_t e = threadIdx.x; e < n_list; e += BLOCK) {
+            int b = (int)s_list[e];
+            double cum = 0.0;
+            for (;;) {                                  // (prefetching the next trip's operands was measured slower)
+                int i2 = b + dir, i0 = b + 2 * dir;
+                i2 = i2 < 0 ? 0 : i2 >= MG_CAP ? MG_CAP - 1 : i2;
+                i0 = i0 < 0 ? 0 : i0 >= MG_CAP ? MG_CAP - 1 : i0;
+                const int nx = b + 3 * dir;
+                const double v1 = r1[b], v2 = r2[i2], v0 = r0[i0];
+                const uint32_t fw = s_fbits[(uint32_t)(nx + 32) >> 5];
+                r1[b] = cum;
+                cum += v1; cum += v2; cum += v0;
+                if ((fw >> ((uint32_t)(nx + 32) & 31u)) & 1u) break;      // the next region belongs to another lane
+                b = nx;
+            }
+        }
+        __syncthreads();
+        double *dst = a.cum + (fwd ? 0 : a.total) + w0;
+        for (uint32_t i = threadIdx.x; i < span; i += BLOCK) dst[i] = r1[i];
+        }
+        cur = nxt;
+    }
+}
+
+// the per-lane walk, for the reads the tiles leave (lanes_only_unfit) or for everything
 __global__ __launch_bounds__(256) void k_mg_cum(MgArgs a)
 {
     // lanes [0, n_reads): forward strand; [n_reads, 2 n_reads): reverse strand (wave-uniform but for one wave)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * a.n_reads; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (i < a.n_reads) mg_cum_one<true>(a, i);
-        else mg_cum_one<false>(a, i - a.n_reads);
+        const uint64_t r = i < a.n_reads ? i : i - a.n_reads;
+        if (a.lanes_only_unfit) {
+            uint64_t first; uint32_t nfit;
+            mg_tile_reads(a, a.read_off[r] / a.tile_window, first, nfit, (uint32_t)a.tile_cap);
+            if (r >= first && r < first + nfit) continue;
+        }
+        if (i < a.n_reads) mg_cum_one<true>(a, r);
+        else mg_cum_one<false>(a, r);
     }
 }
 
@@ -420,6 +634,59 @@ static unsigned mg_codon_revcomp(unsigned data)         // Codon_t::Reverse_Comp
     return x;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Scratch and result buffers come from a small cache of device blocks: hipMalloc / hipFree of GB-sized
+// buffers cost up to hundreds of milliseconds now and then (measured: tools/bench_mg.py), far more than the
+// kernels.  A released block is kept and handed to the next request it fits (size <= block <= 2 x size);
+// gmg_trim_cache() gives everything back to the driver.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct PoolBlock { void *p; size_t bytes; bool busy; };
+std::mutex g_pool_mutex;
+std::vector<PoolBlock> g_pool;
+
+hipError_t pool_alloc(void **out, size_t bytes)
+{
+    if (bytes == 0) bytes = 1;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    int best = -1;
+    for (size_t i = 0; i < g_pool.size(); i++)
+        if (!g_pool[i].busy && g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + 4096 &&
+            (best < 0 || g_pool[i].bytes < g_pool[best].bytes))
+            best = (int)i;
+    if (best >= 0) { g_pool[best].busy = true; *out = g_pool[best].p; return hipSuccess; }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {                              // make room: drop the idle blocks and try once more
+        for (size_t i = 0; i < g_pool.size();)
+            if (!g_pool[i].busy) { (void)hipFree(g_pool[i].p); g_pool.erase(g_pool.begin() + i); } else i++;
+        (void)hipGetLastError();
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return e;
+    }
+    g_pool.push_back({p, bytes, true});
+    *out = p;
+    return hipSuccess;
+}
+
+void pool_release(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (auto &b : g_pool)
+        if (b.p == p) { b.busy = false; return; }
+    (void)hipFree(p);                                   // not ours
+}
+}  // namespace
+
+extern "C" int gmg_trim_cache(void)
+{
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (size_t i = 0; i < g_pool.size();)
+        if (!g_pool[i].busy) { (void)hipFree(g_pool[i].p); g_pool.erase(g_pool.begin() + i); } else i++;
+    return GMG_OK;
+}
+
 static unsigned grid_for(uint64_t n)
 {
     const uint64_t blocks = (n + 255) / 256;
@@ -432,15 +699,15 @@ static int mg_scan(uint32_t *d_cnt, uint64_t *d_off, uint64_t n, uint64_t *total
     uint64_t *d_wide = nullptr;
     void *d_tmp = nullptr;
     size_t tmp_bytes = 0;
-    GMG_HIP(hipMalloc((void **)&d_wide, (n + 1) * 8));
+    GMG_HIP(pool_alloc((void **)&d_wide, (n + 1) * 8));
     hipLaunchKernelGGL(k_mg_widen, dim3(grid_for(n + 1)), dim3(256), 0, s, d_cnt, d_wide, n + 1);
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_wide, d_off, (int)(n + 1), s);
-    if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+    if (e == hipSuccess) e = pool_alloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
     if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_wide, d_off, (int)(n + 1), s);
     if (e == hipSuccess) e = hipMemcpyAsync(total, d_off + n, 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d_wide);
-    if (d_tmp) (void)hipFree(d_tmp);
+    pool_release(d_wide);
+    if (d_tmp) pool_release(d_tmp);
     if (e != hipSuccess) return gmg_set_error(GMG_EHIP, "gmg_mg_score_reads: scan: %s", hipGetErrorString(e));
     return GMG_OK;
 }
@@ -450,10 +717,26 @@ extern "C" int gmg_mg_result_free(gmg_mg_result *r)
     if (!r) return GMG_OK;
     void *ptrs[] = {r->d_orfs, r->d_starts, r->d_read_orf_off};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) pool_release(p);
     delete r;
     return GMG_OK;
 }
+
+// GMG_MG_TIMING=1: wall time of every stage on stderr (synchronises after each stage)
+struct MgTimer {
+    bool on;
+    hipStream_t s;
+    std::chrono::steady_clock::time_point t0;
+    MgTimer(hipStream_t st) : on(getenv("GMG_MG_TIMING") != nullptr), s(st), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char *what)
+    {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gmg_mg] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = std::chrono::steady_clock::now();
+    }
+};
 
 extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads,
                                   const gmg_mg_params *prm, double *d_frame_scores, gmg_mg_result **out, void *stream)
@@ -471,6 +754,7 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
     memset(&a, 0, sizeof a);
     a.packed = reads->d_packed;
     a.read_off = reads->d_off;
+    a.tile_read = reads->d_tile_read;
     a.n_reads = reads->n_reads;
     a.total = reads->total_bases;
     a.min_gene_len = prm->min_gene_len;
@@ -509,11 +793,12 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
     double *d_cum = nullptr;
     int rc = GMG_OK;
     auto fail = [&](int code) {
-        if (d_fs_own) (void)hipFree(d_fs_own);
-        if (d_read_cnt) (void)hipFree(d_read_cnt);
-        if (d_orf_cnt) (void)hipFree(d_orf_cnt);
-        if (d_start_off) (void)hipFree(d_start_off);
-        if (d_cum) (void)hipFree(d_cum);
+        (void)hipStreamSynchronize(s);                  // nothing may still use the blocks that go back to the cache
+        if (d_fs_own) pool_release(d_fs_own);
+        if (d_read_cnt) pool_release(d_read_cnt);
+        if (d_orf_cnt) pool_release(d_orf_cnt);
+        if (d_start_off) pool_release(d_start_off);
+        if (d_cum) pool_release(d_cum);
         gmg_mg_result_free(res);
         return code;
     };
@@ -525,9 +810,10 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
                                       #call, hipGetErrorString(e_)));                                           \
     } while (0)
 
+    MgTimer tm(s);
     // 1. Frame_Scores
     if (!d_frame_scores && a.total) {
-        MG_TRY(hipMalloc((void **)&d_fs_own, (size_t)6 * a.total * sizeof(double)));
+        MG_TRY(pool_alloc((void **)&d_fs_own, (size_t)6 * a.total * sizeof(double)));
         d_frame_scores = d_fs_own;
     }
     if (a.total) {
@@ -535,17 +821,56 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
         if (rc) return fail(rc);
     }
     a.fs = d_frame_scores;
+    tm.lap("frame scores");
     // running sums of every reading-frame class (what Cumulative_Frame_Score would give any ORF)
-    MG_TRY(hipMalloc((void **)&d_cum, (size_t)2 * (a.total ? a.total : 1) * sizeof(double)));
+    MG_TRY(pool_alloc((void **)&d_cum, (size_t)2 * (a.total ? a.total : 1) * sizeof(double)));
     a.cum = d_cum;
-    if (a.n_reads) hipLaunchKernelGGL(k_mg_cum, dim3(grid_for(2 * a.n_reads)), dim3(256), 0, s, a);
-    MG_TRY(hipGetLastError());
-
+    tm.lap("alloc running sums");
+    if (a.n_reads && a.total) {
+        // tile shape: one wave and <= 512 bases (12 KB of LDS, many blocks per CU in different phases) when the reads
+        // allow it, else four waves and 1504 bases (39.8 KB, four blocks per CU)
+        const char *env = getenv("GMG_MG_TILE");
+        const bool small = env ? atoi(env) == 512 : reads->max_len <= 512;
+        const uint32_t cap = small ? 512 : 1504;
+        a.tile_cap = (int)cap;
+        bool tiled = false, rest = true;
+        if (reads->uniform_len > 0) {                  // every tile takes cap / L whole reads
+            if ((uint32_t)reads->uniform_len <= cap) {
+                a.uniform_len = reads->uniform_len;
+                a.reads_per_tile = cap / reads->uniform_len < MG_TILE_READS ? cap / reads->uniform_len : MG_TILE_READS;
+                a.n_tiles = (a.n_reads + a.reads_per_tile - 1) / a.reads_per_tile;
+                tiled = true; rest = false;
+            }
+        } else {                                        // the reads that start inside a window of tile_window bases
+            const uint64_t longest = reads->max_len < cap / 2 ? reads->max_len : cap / 2;
+            a.tile_window = cap - longest;
+            a.n_tiles = a.total / a.tile_window + 1;
+            tiled = true;
+            rest = reads->max_len > longest || reads->min_len * MG_TILE_READS < a.tile_window;
+        }
+        if (tiled) {
+            const size_t lds = (size_t)3 * cap * sizeof(double);
+            const unsigned grid = (unsigned)(2 * a.n_tiles < 256 * 256 ? 2 * a.n_tiles : 256 * 256);
+            if (small) {
+                hipLaunchKernelGGL((k_mg_cum_tiled<512, 64>), dim3(grid), dim3(64), lds, s, a);
+            } else {
+                MG_TRY(hipFuncSetAttribute((const void *)k_mg_cum_tiled<1504, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_mg_cum_tiled<1504, 256>), dim3(grid), dim3(256), lds, s, a);
+            }
+            MG_TRY(hipGetLastError());
+        }
+        if (rest) {
+            a.lanes_only_unfit = tiled;
+            hipLaunchKernelGGL(k_mg_cum, dim3(grid_for(2 * a.n_reads)), dim3(256), 0, s, a);
+            MG_TRY(hipGetLastError());
+        }
+    }
+    tm.lap("running sums");
     // 2. ORFs of every read
     const uint64_t nr = a.n_reads;
-    MG_TRY(hipMalloc((void **)&d_read_cnt, (nr + 1) * 4));
+    MG_TRY(pool_alloc((void **)&d_read_cnt, (nr + 1) * 4));
     MG_TRY(hipMemsetAsync(d_read_cnt, 0, (nr + 1) * 4, s));
-    MG_TRY(hipMalloc((void **)&res->d_read_orf_off, (nr + 1) * 8));
+    MG_TRY(pool_alloc((void **)&res->d_read_orf_off, (nr + 1) * 8));
     a.read_cnt = d_read_cnt;
     if (nr) hipLaunchKernelGGL(k_mg_find_orfs<false>, dim3(grid_for(nr)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
@@ -553,35 +878,38 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
     if (rc) return fail(rc);
     if (res->n_orfs >= 0x7fffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
     const uint64_t no = res->n_orfs;
-    MG_TRY(hipMalloc((void **)&res->d_orfs, (no ? no : 1) * sizeof(gmg_mg_orf)));
+    MG_TRY(pool_alloc((void **)&res->d_orfs, (no ? no : 1) * sizeof(gmg_mg_orf)));
     a.read_orf_off = res->d_read_orf_off;
     a.orfs = res->d_orfs;
     a.n_orfs = no;
     if (nr) hipLaunchKernelGGL(k_mg_find_orfs<true>, dim3(grid_for(nr)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
 
+    tm.lap("find orfs");
     // 3. start lists
-    MG_TRY(hipMalloc((void **)&d_orf_cnt, (no + 1) * 4));
+    MG_TRY(pool_alloc((void **)&d_orf_cnt, (no + 1) * 4));
     MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s));
-    MG_TRY(hipMalloc((void **)&d_start_off, (no + 1) * 8));
+    MG_TRY(pool_alloc((void **)&d_start_off, (no + 1) * 8));
     a.orf_cnt = d_orf_cnt;
     if (no) hipLaunchKernelGGL(k_mg_starts<false>, dim3(grid_for(no)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
     rc = mg_scan(d_orf_cnt, d_start_off, no, &res->n_starts, s);
     if (rc) return fail(rc);
     if (res->n_starts >= 0xffffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
-    MG_TRY(hipMalloc((void **)&res->d_starts, (res->n_starts ? res->n_starts : 1) * sizeof(gmg_start)));
+    MG_TRY(pool_alloc((void **)&res->d_starts, (res->n_starts ? res->n_starts : 1) * sizeof(gmg_start)));
     a.start_off = d_start_off;
     a.starts = res->d_starts;
     if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
     MG_TRY(hipStreamSynchronize(s));
+    tm.lap("start lists");
 #undef MG_TRY
-    if (d_fs_own) (void)hipFree(d_fs_own);
-    (void)hipFree(d_read_cnt);
-    (void)hipFree(d_orf_cnt);
-    (void)hipFree(d_start_off);
-    (void)hipFree(d_cum);
+    if (d_fs_own) pool_release(d_fs_own);
+    pool_release(d_read_cnt);
+    pool_release(d_orf_cnt);
+    pool_release(d_start_off);
+    pool_release(d_cum);
+    tm.lap("free scratch");
     *out = res;
     return GMG_OK;
 }

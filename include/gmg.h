@@ -287,6 +287,9 @@ int gmg_mg_result_info(const gmg_mg_result *r, uint64_t *n_orfs, uint64_t *n_sta
  * read_orf_off[n_reads + 1] (ORFs of read i are orfs[read_orf_off[i] .. read_orf_off[i+1])). */
 int gmg_mg_result_fetch(const gmg_mg_result *r, gmg_mg_orf *orfs, gmg_start *starts, uint64_t *read_orf_off);
 int gmg_mg_result_free(gmg_mg_result *r);
+/* gmg_mg_* keeps released device buffers for the next call (allocation of GB-sized buffers is slow);
+ * this returns the idle ones to the driver. */
+int gmg_trim_cache(void);
 
 /* ---- device memory helpers (for callers without their own allocator) -------- */
 int gmg_device_malloc(void **d_ptr, size_t bytes);
