@@ -14,6 +14,8 @@ Extra objects on that line:
   roofline      dominant kernel (k_frame6) vs the HBM roof: achieved = 48.25 algorithmic bytes per base
                 (0.25 B packed input + 6 x 8 B fp64 Frame_Scores) x bases per launch / mean
                 launch duration measured with HIP events on the launch stream.
+                roofline.measured_fill_GBps = what a plain fill of a same-sized buffer reaches on this GPU (a
+                write-only stream's practical ceiling; reported beside, never instead of, the 8 TB/s peak).
   cpu_baseline  the same six-frame loop timed on this box's host cores on a bounded sample of the same
                 reads: the real reference's ICM_t (oracle/_ref/ref_bench, "reference") when that build
                 is present, else the plain-C oracle ("port").  Rank 0, N = 1 only.
@@ -181,6 +183,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         kern_ms = float(t.item())
 
+    # what a plain write stream into the same buffer reaches on this GPU (outside the timed region; rank 0 reports it):
+    # the practical ceiling of a kernel that must write 48 of its 48.25 B/base
+    fill_gbps = None
+    if rank == 0:
+        probe = torch.empty_like(out)
+        best = None
+        for _ in range(4):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            probe.fill_(1.0)
+            b.record(stream)
+            b.synchronize()
+            ms = a.elapsed_time(b)
+            best = ms if best is None or ms < best else best
+        fill_gbps = probe.numel() * 8 / (best * 1e-3) / 1e9
+        del probe
+
     # cheap end-of-run sanity check against the oracle (outside the timed region)
     check = None
     if rank == 0:
@@ -218,7 +237,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_frame6", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE},
+                         "algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE,
+                         "measured_fill_GBps": round(fill_gbps, 1) if fill_gbps else None},
             "check": check,
         }
         if world == 1 and args.cpu_reads > 0:

@@ -132,3 +132,42 @@ def test_glimmer_mg_with_device_front_half_is_byte_identical(gpu, tmp_path, flag
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", golden), "rb").read()
+
+
+def test_mg_full_size_properties(gpu, oracle, nc):
+    """BASELINE configs[1] shape: 1M x 500 bp (24 GB of Frame_Scores + 8 GB of running sums on the device, 0.8 GB of
+    results).  Properties: (1) determinism: two calls give identical bytes; (2) bookkeeping: ORFs are stored read by
+    read, start lists are back to back and exactly sum(n_starts) long, bounds lie inside the reads; (3) locality: a
+    read scored alone gives the same records as its slice of the batch; (4) sampled reads equal the oracle."""
+    n, L, seed = 1_000_000, 500, 7
+    packed, off = gpu.synth.packed_reads(n, L, seed)
+    reads = gpu.Reads(packed, off)
+    indep = gpu.Icm.indep(0.5)
+    orfs, starts, first = gpu.mg_score_reads(nc, indep, reads)
+    orfs2, starts2, first2 = gpu.mg_score_reads(nc, indep, reads)
+    assert orfs.tobytes() == orfs2.tobytes() and starts.tobytes() == starts2.tobytes() and np.array_equal(first, first2)
+    del orfs2, starts2
+    assert len(orfs) == first[-1] > 5 * n and np.all(np.diff(first.astype(np.int64)) >= 0)
+    assert np.array_equal(orfs["read"], np.repeat(np.arange(n, dtype=np.uint32), np.diff(first.astype(np.int64))))
+    assert int(orfs["n_starts"].sum()) == len(starts)
+    assert np.array_equal(orfs["start_begin"], np.concatenate([[0], np.cumsum(orfs["n_starts"], dtype=np.uint64)[:-1]]))
+    assert np.all(orfs["lo"] >= 0) and np.all(orfs["hi"] <= L + 1) and np.all(orfs["hi"] - orfs["lo"] >= 0)
+    assert np.all(orfs["accepted"][orfs["n_starts"] == 0] == 0)
+    o_nc, o_indep, prm = oracle.read(os.path.join(DATA, "NC_000915.icm")), oracle.indep(0.5), oracle.mg_params()
+    rng = np.random.default_rng(11)
+    sample = [0, 1, n - 1] + [int(x) for x in rng.integers(0, n, 40)]
+    alone = gpu.Reads.from_strings([gpu.synth.unpack_ascii(packed, r * L, L).decode() for r in sample])
+    a_orfs, a_starts, a_first = gpu.mg_score_reads(nc, indep, alone)
+    for k, r in enumerate(sample):
+        mine = orfs[int(first[r]):int(first[r + 1])]
+        solo = a_orfs[int(a_first[k]):int(a_first[k + 1])]
+        cols = ["frame", "stop_position", "orf_len", "gene_len", "lo", "hi", "first_j", "n_starts", "accepted", "best_score"]
+        assert all(np.array_equal(mine[c], solo[c]) for c in cols)
+        want_orfs, scored = oracle.mg_read(o_nc, o_indep, gpu.synth.unpack_ascii(packed, r * L, L), prm)
+        assert np.array_equal(np.stack([mine["frame"], mine["stop_position"], mine["gene_len"], mine["orf_len"]], 1), want_orfs)
+        for o, so, (out, want) in zip(mine, solo, scored):
+            st = starts[o["start_begin"]:o["start_begin"] + o["n_starts"]]
+            assert st.tobytes() == a_starts[so["start_begin"]:so["start_begin"] + so["n_starts"]].tobytes()
+            assert [(s["j"], s["pos"], s["which"], s["truncated"], s["first"], s["score"]) for s in st] == \
+                   [(w.j, w.pos, w.which, w.truncated, w.first, w.score) for w in want]
+            assert (o["first_j"], bool(o["accepted"]), o["best_score"]) == (out.first_j, bool(out.accepted), out.best_score)

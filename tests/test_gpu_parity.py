@@ -273,6 +273,52 @@ def test_score_orfs_golden_start_lists(gpu, nc, fa_reads, name, kw, path, monkey
         assert np.array_equal(got, g["start_int"][b:b + cnt])
 
 
+@pytest.mark.parametrize("path", ["fused", "exact"])
+def test_score_orfs_random_orfs_on_ragged_reads_vs_oracle(gpu, nc, oracle, o_nc, path, monkeypatch):
+    """random in-range ORFs (both strands, lengths 3..read length, also not a multiple of 3) on reads of ragged lengths:
+    every field of every start and of the per-ORF result must equal the oracle's Score_Orfs restatement"""
+    if path == "exact":
+        monkeypatch.setenv("GMG_ORFS_EXACT_PATH", "1")
+    else:
+        monkeypatch.delenv("GMG_ORFS_EXACT_PATH", raising=False)
+    rng = np.random.default_rng(77)
+    lengths = [int(x) for x in rng.integers(40, 900, size=120)] + [12, 13, 30, 500, 2100]
+    seqs = ["".join("acgt"[c] for c in rng.integers(0, 4, size=n)) for n in lengths]
+    reads = gpu.Reads.from_strings(seqs)
+    rows = []
+    for r, n in enumerate(lengths):
+        for _ in range(6):
+            ln = int(rng.integers(3, n + 1))
+            if rng.random() < 0.8:
+                ln -= ln % 3
+            lo = int(rng.integers(0, n - ln + 1))
+            if rng.random() < 0.5:
+                rows.append((r, 1 + lo % 3, lo + ln + 1, ln))        # forward: hi = stop - 1, lo = hi - len
+            else:
+                rows.append((r, -1 - lo % 3, lo - 2, ln))            # reverse: lo = stop + 2
+    rows = np.array(rows)
+    kw = dict(min_gene_len=30, allow_truncated=True, ignore_score_len=200)
+    res, starts = gpu.score_orfs(nc, gpu.Icm.indep(0.4), reads, rows, **kw)
+    o_indep = oracle.indep(0.4)
+    prm = oracle.orf_params(**kw)
+    n_genes = 0
+    for (r, frame, stop, ln), got in zip(rows, res):
+        n, out, want = oracle.score_orf(o_nc, o_indep, seqs[r], int(frame), int(stop), int(ln), prm)
+        assert (got["first_j"], got["best_j"], got["best_pos"], got["orf_is_truncated"]) == \
+               (out.first_j, out.best_j, out.best_pos, out.orf_is_truncated)
+        assert got["best_score"] == out.best_score
+        if n < 0:
+            assert got["n_starts"] == 0 and not got["is_tentative_gene"]
+            continue
+        assert got["n_starts"] == n and bool(got["is_tentative_gene"]) == bool(out.is_tentative_gene)
+        assert got["gene_score"] == out.gene_score or (np.isnan(got["gene_score"]) and np.isnan(out.gene_score))
+        st = starts[got["start_begin"]:got["start_begin"] + n]
+        assert [(s["j"], s["pos"], s["which"], s["truncated"], s["first"], s["score"]) for s in st] == \
+               [(w.j, w.pos, w.which, w.truncated, w.first, w.score) for w in want]
+        n_genes += int(out.is_tentative_gene)
+    assert n_genes > 20
+
+
 def test_score_orfs_rejects_wrapping_orfs(gpu, nc, fa_reads):
     with pytest.raises(gpu.GmgError):
         gpu.score_orfs(nc, gpu.Icm.indep(0.5), fa_reads, np.array([[0, 1, 30, 90]]))     # lo < 0: circular wrap
