@@ -179,6 +179,36 @@ class Reads:
     def from_strings(cls, seqs):
         return cls(*pack_strings(seqs))
 
+    @classmethod
+    def from_fasta_bytes(cls, data):
+        """gmg_fasta_ingest: the file's bytes are parsed on the device (Fasta_Read + Filter + tolower + 2-bit packing).
+        -> (Reads, headers [bytes], gc_count)"""
+        data = bytes(data)
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        index = C.c_void_p()
+        _ck(capi.lib().gmg_fasta_ingest(data, len(data), C.byref(self.h), C.byref(index)))
+        try:
+            n, total, gc = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            _ck(capi.lib().gmg_fasta_info(index, C.byref(n), C.byref(total), C.byref(gc)))
+            hb, he = np.zeros(max(n.value, 1), np.uint64), np.zeros(max(n.value, 1), np.uint64)
+            _ck(capi.lib().gmg_fasta_headers(index, _ptr(hb), _ptr(he)))
+        finally:
+            capi.lib().gmg_fasta_free(index)
+        self.n_reads, self.total_bases = int(n.value), int(total.value)
+        self.offsets = None                              # live on the device only
+        headers = [data[int(b):int(e)] for b, e in zip(hb[:n.value], he[:n.value])]
+        return self, headers, int(gc.value)
+
+    def download(self):
+        """-> (packed uint32 words, offsets uint64): the batch as it sits in HBM (tests)"""
+        n, total = C.c_uint64(), C.c_uint64()
+        _ck(capi.lib().gmg_reads_info(self.h, C.byref(n), C.byref(total)))
+        words = int(capi.lib().gmg_packed_words(total.value))
+        packed, off = np.zeros(max(words, 1), np.uint32), np.zeros(n.value + 1, np.uint64)
+        _ck(capi.lib().gmg_reads_download(self.h, _ptr(packed), _ptr(off)))
+        return packed[:words], off
+
     def close(self):
         if self.h:
             capi.lib().gmg_reads_free(self.h)

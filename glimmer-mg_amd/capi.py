@@ -46,6 +46,7 @@ PROTOTYPES = {
     "gmg_reads_wrap_device": (i32, [vp, vp, u64, u64, C.POINTER(vp)]),
     "gmg_reads_free": (i32, [vp]),
     "gmg_reads_info": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
+    "gmg_reads_download": (i32, [vp, vp, vp]),
     "gmg_segments_upload": (i32, [vp, vp, u64, vp, C.POINTER(u64), C.POINTER(vp)]),
     "gmg_segments_free": (i32, [vp]),
     "gmg_frame_score6": (i32, [vp, vp, vp, vp, vp]),
@@ -60,6 +61,12 @@ PROTOTYPES = {
     "gmg_mg_result_fetch": (i32, [vp, vp, vp, vp]),
     "gmg_mg_result_free": (i32, [vp]),
     "gmg_trim_cache": (i32, []),
+    "gmg_host_register": (i32, [vp, C.c_size_t]),
+    "gmg_host_unregister": (i32, [vp]),
+    "gmg_fasta_ingest": (i32, [C.c_char_p, u64, C.POINTER(vp), C.POINTER(vp)]),
+    "gmg_fasta_info": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
+    "gmg_fasta_headers": (i32, [vp, vp, vp]),
+    "gmg_fasta_free": (i32, [vp]),
     "gmg_orfs_upload": (i32, [vp, vp, u64, C.POINTER(u64), C.POINTER(vp)]),
     "gmg_orf_batch_free": (i32, [vp]),
     "gmg_score_orfs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <mutex>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -388,6 +389,15 @@ extern "C" int gmg_reads_info(const gmg_reads *r, uint64_t *n_reads, uint64_t *t
     return GMG_OK;
 }
 
+extern "C" int gmg_reads_download(const gmg_reads *r, uint32_t *packed, uint64_t *off)
+{
+    if (!r || !off || (r->total_bases && !packed)) return gmg_set_error(GMG_EINVAL, "gmg_reads_download: NULL argument");
+    if (r->total_bases)
+        GMG_HIP(hipMemcpy(packed, r->d_packed, gmg_packed_words(r->total_bases) * 4, hipMemcpyDeviceToHost));
+    GMG_HIP(hipMemcpy(off, r->d_off, (r->n_reads + 1) * 8, hipMemcpyDeviceToHost));
+    return GMG_OK;
+}
+
 // ---------------------------------------------------------------------------
 // segments
 // ---------------------------------------------------------------------------
@@ -574,5 +584,76 @@ extern "C" int gmg_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *
 {
     GMG_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     GMG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return GMG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Scratch and result buffers come from a small cache of device blocks: hipMalloc / hipFree of GB-sized
+// buffers cost up to hundreds of milliseconds now and then (measured: tools/bench_mg.py), far more than the
+// kernels.  A released block is kept and handed to the next request it fits (size <= block <= 2 x size);
+// gmg_trim_cache() gives everything back to the driver.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct PoolBlock { void *p; size_t bytes; bool busy; };
+std::mutex g_pool_mutex;
+std::vector<PoolBlock> g_pool;
+
+}  // namespace
+
+hipError_t gmg_pool_alloc(void **out, size_t bytes)
+{
+    if (bytes == 0) bytes = 1;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    int best = -1;
+    for (size_t i = 0; i < g_pool.size(); i++)
+        if (!g_pool[i].busy && g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + 4096 &&
+            (best < 0 || g_pool[i].bytes < g_pool[best].bytes))
+            best = (int)i;
+    if (best >= 0) { g_pool[best].busy = true; *out = g_pool[best].p; return hipSuccess; }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {                              // make room: drop the idle blocks and try once more
+        for (size_t i = 0; i < g_pool.size();)
+            if (!g_pool[i].busy) { (void)hipFree(g_pool[i].p); g_pool.erase(g_pool.begin() + i); } else i++;
+        (void)hipGetLastError();
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return e;
+    }
+    g_pool.push_back({p, bytes, true});
+    *out = p;
+    return hipSuccess;
+}
+
+void gmg_pool_release(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (auto &b : g_pool)
+        if (b.p == p) { b.busy = false; return; }
+    (void)hipFree(p);                                   // not ours
+}
+
+extern "C" int gmg_trim_cache(void)
+{
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (size_t i = 0; i < g_pool.size();)
+        if (!g_pool[i].busy) { (void)hipFree(g_pool[i].p); g_pool.erase(g_pool.begin() + i); } else i++;
+    return GMG_OK;
+}
+
+
+// Page-lock a host buffer the caller already owns (file bytes, result arrays): copies to and from it then run at
+// PCIe speed instead of through the runtime's staging buffers.
+extern "C" int gmg_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return gmg_set_error(GMG_EINVAL, "gmg_host_register: empty buffer");
+    GMG_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return GMG_OK;
+}
+
+extern "C" int gmg_host_unregister(void *ptr)
+{
+    if (!ptr) return GMG_OK;
+    GMG_HIP(hipHostUnregister(ptr));
     return GMG_OK;
 }

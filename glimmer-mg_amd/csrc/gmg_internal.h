@@ -76,6 +76,11 @@ int gmg_set_error(int code, const char *fmt, ...);
                                  __FILE__, __LINE__);                                         \
     } while (0)
 
+// cache of device blocks for scratch and result buffers (gmg_api.hip): hipMalloc / hipFree of GB-sized buffers cost up
+// to hundreds of milliseconds now and then; a released block is handed to the next request it fits
+hipError_t gmg_pool_alloc(void **out, size_t bytes);
+void gmg_pool_release(void *p);
+
 // kernel launchers (gmg_kernels.hip)
 int gmg_launch_tile_read(const uint64_t *d_off, uint64_t n_reads, uint64_t n_tiles, uint32_t *d_tile_read,
                          hipStream_t s);

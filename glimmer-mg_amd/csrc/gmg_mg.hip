@@ -32,7 +32,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
-#include <mutex>
 #include <new>
 #include <vector>
 
@@ -634,59 +633,7 @@ static unsigned mg_codon_revcomp(unsigned data)         // Codon_t::Reverse_Comp
     return x;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Scratch and result buffers come from a small cache of device blocks: hipMalloc / hipFree of GB-sized
-// buffers cost up to hundreds of milliseconds now and then (measured: tools/bench_mg.py), far more than the
-// kernels.  A released block is kept and handed to the next request it fits (size <= block <= 2 x size);
-// gmg_trim_cache() gives everything back to the driver.
-// ---------------------------------------------------------------------------------------------------
-namespace {
-struct PoolBlock { void *p; size_t bytes; bool busy; };
-std::mutex g_pool_mutex;
-std::vector<PoolBlock> g_pool;
-
-hipError_t pool_alloc(void **out, size_t bytes)
-{
-    if (bytes == 0) bytes = 1;
-    std::lock_guard<std::mutex> lock(g_pool_mutex);
-    int best = -1;
-    for (size_t i = 0; i < g_pool.size(); i++)
-        if (!g_pool[i].busy && g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + 4096 &&
-            (best < 0 || g_pool[i].bytes < g_pool[best].bytes))
-            best = (int)i;
-    if (best >= 0) { g_pool[best].busy = true; *out = g_pool[best].p; return hipSuccess; }
-    void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) {                              // make room: drop the idle blocks and try once more
-        for (size_t i = 0; i < g_pool.size();)
-            if (!g_pool[i].busy) { (void)hipFree(g_pool[i].p); g_pool.erase(g_pool.begin() + i); } else i++;
-        (void)hipGetLastError();
-        e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) return e;
-    }
-    g_pool.push_back({p, bytes, true});
-    *out = p;
-    return hipSuccess;
-}
-
-void pool_release(void *p)
-{
-    if (!p) return;
-    std::lock_guard<std::mutex> lock(g_pool_mutex);
-    for (auto &b : g_pool)
-        if (b.p == p) { b.busy = false; return; }
-    (void)hipFree(p);                                   // not ours
-}
-}  // namespace
-
-extern "C" int gmg_trim_cache(void)
-{
-    std::lock_guard<std::mutex> lock(g_pool_mutex);
-    for (size_t i = 0; i < g_pool.size();)
-        if (!g_pool[i].busy) { (void)hipFree(g_pool[i].p); g_pool.erase(g_pool.begin() + i); } else i++;
-    return GMG_OK;
-}
-
+// scratch and result buffers come from the library's cache of device blocks (gmg_pool_alloc, gmg_api.hip)
 static unsigned grid_for(uint64_t n)
 {
     const uint64_t blocks = (n + 255) / 256;
@@ -699,15 +646,15 @@ static int mg_scan(uint32_t *d_cnt, uint64_t *d_off, uint64_t n, uint64_t *total
     uint64_t *d_wide = nullptr;
     void *d_tmp = nullptr;
     size_t tmp_bytes = 0;
-    GMG_HIP(pool_alloc((void **)&d_wide, (n + 1) * 8));
+    GMG_HIP(gmg_pool_alloc((void **)&d_wide, (n + 1) * 8));
     hipLaunchKernelGGL(k_mg_widen, dim3(grid_for(n + 1)), dim3(256), 0, s, d_cnt, d_wide, n + 1);
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_wide, d_off, (int)(n + 1), s);
-    if (e == hipSuccess) e = pool_alloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+    if (e == hipSuccess) e = gmg_pool_alloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
     if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_wide, d_off, (int)(n + 1), s);
     if (e == hipSuccess) e = hipMemcpyAsync(total, d_off + n, 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    pool_release(d_wide);
-    if (d_tmp) pool_release(d_tmp);
+    gmg_pool_release(d_wide);
+    if (d_tmp) gmg_pool_release(d_tmp);
     if (e != hipSuccess) return gmg_set_error(GMG_EHIP, "gmg_mg_score_reads: scan: %s", hipGetErrorString(e));
     return GMG_OK;
 }
@@ -717,7 +664,7 @@ extern "C" int gmg_mg_result_free(gmg_mg_result *r)
     if (!r) return GMG_OK;
     void *ptrs[] = {r->d_orfs, r->d_starts, r->d_read_orf_off};
     for (void *p : ptrs)
-        if (p) pool_release(p);
+        if (p) gmg_pool_release(p);
     delete r;
     return GMG_OK;
 }
@@ -794,11 +741,11 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
     int rc = GMG_OK;
     auto fail = [&](int code) {
         (void)hipStreamSynchronize(s);                  // nothing may still use the blocks that go back to the cache
-        if (d_fs_own) pool_release(d_fs_own);
-        if (d_read_cnt) pool_release(d_read_cnt);
-        if (d_orf_cnt) pool_release(d_orf_cnt);
-        if (d_start_off) pool_release(d_start_off);
-        if (d_cum) pool_release(d_cum);
+        if (d_fs_own) gmg_pool_release(d_fs_own);
+        if (d_read_cnt) gmg_pool_release(d_read_cnt);
+        if (d_orf_cnt) gmg_pool_release(d_orf_cnt);
+        if (d_start_off) gmg_pool_release(d_start_off);
+        if (d_cum) gmg_pool_release(d_cum);
         gmg_mg_result_free(res);
         return code;
     };
@@ -813,7 +760,7 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
     MgTimer tm(s);
     // 1. Frame_Scores
     if (!d_frame_scores && a.total) {
-        MG_TRY(pool_alloc((void **)&d_fs_own, (size_t)6 * a.total * sizeof(double)));
+        MG_TRY(gmg_pool_alloc((void **)&d_fs_own, (size_t)6 * a.total * sizeof(double)));
         d_frame_scores = d_fs_own;
     }
     if (a.total) {
@@ -823,7 +770,7 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
     a.fs = d_frame_scores;
     tm.lap("frame scores");
     // running sums of every reading-frame class (what Cumulative_Frame_Score would give any ORF)
-    MG_TRY(pool_alloc((void **)&d_cum, (size_t)2 * (a.total ? a.total : 1) * sizeof(double)));
+    MG_TRY(gmg_pool_alloc((void **)&d_cum, (size_t)2 * (a.total ? a.total : 1) * sizeof(double)));
     a.cum = d_cum;
     tm.lap("alloc running sums");
     if (a.n_reads && a.total) {
@@ -868,9 +815,9 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
     tm.lap("running sums");
     // 2. ORFs of every read
     const uint64_t nr = a.n_reads;
-    MG_TRY(pool_alloc((void **)&d_read_cnt, (nr + 1) * 4));
+    MG_TRY(gmg_pool_alloc((void **)&d_read_cnt, (nr + 1) * 4));
     MG_TRY(hipMemsetAsync(d_read_cnt, 0, (nr + 1) * 4, s));
-    MG_TRY(pool_alloc((void **)&res->d_read_orf_off, (nr + 1) * 8));
+    MG_TRY(gmg_pool_alloc((void **)&res->d_read_orf_off, (nr + 1) * 8));
     a.read_cnt = d_read_cnt;
     if (nr) hipLaunchKernelGGL(k_mg_find_orfs<false>, dim3(grid_for(nr)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
@@ -878,7 +825,7 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
     if (rc) return fail(rc);
     if (res->n_orfs >= 0x7fffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
     const uint64_t no = res->n_orfs;
-    MG_TRY(pool_alloc((void **)&res->d_orfs, (no ? no : 1) * sizeof(gmg_mg_orf)));
+    MG_TRY(gmg_pool_alloc((void **)&res->d_orfs, (no ? no : 1) * sizeof(gmg_mg_orf)));
     a.read_orf_off = res->d_read_orf_off;
     a.orfs = res->d_orfs;
     a.n_orfs = no;
@@ -887,16 +834,16 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
 
     tm.lap("find orfs");
     // 3. start lists
-    MG_TRY(pool_alloc((void **)&d_orf_cnt, (no + 1) * 4));
+    MG_TRY(gmg_pool_alloc((void **)&d_orf_cnt, (no + 1) * 4));
     MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s));
-    MG_TRY(pool_alloc((void **)&d_start_off, (no + 1) * 8));
+    MG_TRY(gmg_pool_alloc((void **)&d_start_off, (no + 1) * 8));
     a.orf_cnt = d_orf_cnt;
     if (no) hipLaunchKernelGGL(k_mg_starts<false>, dim3(grid_for(no)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
     rc = mg_scan(d_orf_cnt, d_start_off, no, &res->n_starts, s);
     if (rc) return fail(rc);
     if (res->n_starts >= 0xffffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
-    MG_TRY(pool_alloc((void **)&res->d_starts, (res->n_starts ? res->n_starts : 1) * sizeof(gmg_start)));
+    MG_TRY(gmg_pool_alloc((void **)&res->d_starts, (res->n_starts ? res->n_starts : 1) * sizeof(gmg_start)));
     a.start_off = d_start_off;
     a.starts = res->d_starts;
     if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
@@ -904,11 +851,11 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
     MG_TRY(hipStreamSynchronize(s));
     tm.lap("start lists");
 #undef MG_TRY
-    if (d_fs_own) pool_release(d_fs_own);
-    pool_release(d_read_cnt);
-    pool_release(d_orf_cnt);
-    pool_release(d_start_off);
-    pool_release(d_cum);
+    if (d_fs_own) gmg_pool_release(d_fs_own);
+    gmg_pool_release(d_read_cnt);
+    gmg_pool_release(d_orf_cnt);
+    gmg_pool_release(d_start_off);
+    gmg_pool_release(d_cum);
     tm.lap("free scratch");
     *out = res;
     return GMG_OK;

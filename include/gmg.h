@@ -116,6 +116,8 @@ int gmg_reads_wrap_device(const uint32_t *d_packed2bit, const uint64_t *d_base_o
                           uint64_t n_reads, uint64_t total_bases, gmg_reads **out);
 int gmg_reads_free(gmg_reads *r);
 int gmg_reads_info(const gmg_reads *r, uint64_t *n_reads, uint64_t *total_bases);
+/* Copies the batch back to HOST buffers: packed2bit[gmg_packed_words(total_bases)], base_offsets[n_reads + 1]. */
+int gmg_reads_download(const gmg_reads *reads, uint32_t *packed2bit, uint64_t *base_offsets);
 
 /* ---- segments --------------------------------------------------------------- */
 
@@ -291,11 +293,31 @@ int gmg_mg_result_free(gmg_mg_result *r);
  * this returns the idle ones to the driver. */
 int gmg_trim_cache(void);
 
+/* ---- FASTA ingest on the device -----------------------------------------------------
+ * Replaces the loop  while (Fasta_Read (fp, seq, hdr))  (src/Common/fasta.cc:236-286) + the per-base
+ * tolower (Filter (ch)) of the callers (src/Glimmer/glimmer3.cc:270-271, glimmer-mg.cc:381-382) + the g/c count of
+ * Set_GC_Fraction (src/Glimmer/glimmer_base.cc:2564-2595).  `bytes` is the whole file (host memory, < 2^31 bytes);
+ * it is copied to the device once and parsed there.  Records follow Fasta_Read exactly: a '>' anywhere outside a
+ * header line starts a record, the header runs to the end of that line, every non-isspace byte up to the next '>'
+ * is a base, bytes in front of the first '>' are skipped.  *reads is ready for every scoring call;
+ * *index keeps the counts and, per read, the extent of its header line in `bytes`. */
+typedef struct gmg_fasta gmg_fasta;
+int gmg_fasta_ingest(const char *bytes, uint64_t n_bytes, gmg_reads **reads, gmg_fasta **index);
+/* n_reads, bases of all reads, and how many of them are g or c after filtering (Indep_GC_Frac = gc / total) */
+int gmg_fasta_info(const gmg_fasta *index, uint64_t *n_reads, uint64_t *total_bases, uint64_t *gc_count);
+/* hdr string of read i = bytes[hdr_begin[i] .. hdr_end[i])  (HOST arrays of n_reads entries) */
+int gmg_fasta_headers(const gmg_fasta *index, uint64_t *hdr_begin, uint64_t *hdr_end);
+int gmg_fasta_free(gmg_fasta *index);
+
 /* ---- device memory helpers (for callers without their own allocator) -------- */
 int gmg_device_malloc(void **d_ptr, size_t bytes);
 int gmg_device_free(void *d_ptr);
 int gmg_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *stream);
 int gmg_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *stream);
+/* Page-lock / release a host buffer the caller owns (file bytes, result arrays), so that the copies the library
+ * makes from / to it run at PCIe speed. */
+int gmg_host_register(void *ptr, size_t bytes);
+int gmg_host_unregister(void *ptr);
 
 #ifdef __cplusplus
 }

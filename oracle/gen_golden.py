@@ -219,6 +219,19 @@ def main():
                             gene_orf=g[:, 0], gene_nstarts=g[:, 1], gene_start_begin=g[:, 2],
                             start_int=np.array(st_i, np.int32),            # j, pos, which, truncated, first (sorted by pos)
                             start_score=np.array(st_s, np.float64))
+    # ---- FASTA ingest (Fasta_Read, fasta.cc:236-286): a deliberately awkward file, parsed by the reference
+    nasty = (b"junk before the first record\n>  first read  with spaces \nACGTacgt\nNNRYKM\n\n  acgt \t ggg\r\n"
+             b">second>has>gt in header\nacgtacgtacgtacgtacgtacgtacgtacgtacgt\n"
+             b">empty\n>also empty\n\n\n>mid line gt\nacgt>weird  \naaa\nccc\n"
+             b">iupac\nRYSWKMBDHVNrysw kmbdhvn*-.0123xXuU\n>crlf\r\nac\r\ngt\r\n>tabs\tin\theader\nT\tT\tT\vG\fG\n"
+             b">long\n" + b"\n".join(bytes((b"acgt"[(i * 7 + j * 3) % 4]) for j in range(61)) for i in range(40)) +
+             b"\n>last record without newline\nacgtn")
+    fpath = os.path.join(GOLD, "data", "nasty.fa")
+    open(fpath, "wb").write(nasty)
+    txt = subprocess.run([os.path.join(RB, "ref_dump"), "fasta", fpath], check=True, stdout=subprocess.PIPE).stdout
+    open(os.path.join(GOLD, "nasty.fasta_read.txt"), "wb").write(txt)
+    txt = subprocess.run([os.path.join(RB, "ref_dump"), "fasta", fa], check=True, stdout=subprocess.PIPE).stdout
+    open(os.path.join(GOLD, "seqs.fasta_read.sha256"), "w").write(hashlib.sha256(txt).hexdigest() + "\n")
     print("golden vectors written to", GOLD)
 
 

@@ -868,6 +868,46 @@ int orc_mg_score_orf(const double *frame_scores, const char *seq, int n, const i
     return n_starts;
 }
 
+/* Fasta_Read (fasta.cc:236-286): fgetc / ungetc restated as an index into a buffer */
+int orc_fasta_next(const char *buf, long n, long *pos, long *hdr_begin, long *hdr_end, char *seq, long *seq_len)
+{
+    long i = *pos, k = 0;
+    while (i < n && buf[i] != '>') i++;                 /* skip till next '>' if necessary */
+    if (i >= n) { *pos = n; return 0; }
+    i++;
+    while (i < n && buf[i] == ' ') i++;                 /* skip spaces if any */
+    if (i >= n) { *pos = n; return 0; }
+    *hdr_begin = i;
+    while (i < n && buf[i] != '\n') i++;                /* rest of line into hdr */
+    *hdr_end = i;
+    if (i < n) i++;
+    while (i < n && buf[i] != '>') {                    /* everything up till next '>' into s */
+        if (!isspace((unsigned char)buf[i])) seq[k++] = buf[i];
+        i++;
+    }
+    *seq_len = k;
+    *pos = i;                                           /* the '>' is pushed back */
+    return 1;
+}
+
+long orc_fasta_all(const char *buf, long n, char *out, long *n_bases, long *gc)
+{
+    long pos = 0, hb, he, sl, recs = 0, total = 0, ct = 0, k;
+    char *seq = (char *)malloc((size_t)n + 1);
+    while (orc_fasta_next(buf, n, &pos, &hb, &he, seq, &sl)) {
+        for (k = 0; k < sl; k++) {
+            const int ch = tolower(orc_filter(seq[k]));    /* glimmer3.cc:270-271 */
+            if (out) out[total + k] = (char)ch;
+            ct += (ch == 'g' || ch == 'c');
+        }
+        total += sl;
+        recs++;
+    }
+    free(seq);
+    *n_bases = total; *gc = ct;
+    return recs;
+}
+
 long orc_score_reads_6frame(const orc_model *gene, const orc_model *indep, const char *seqs,
                             int n_reads, int L, double *out)
 {

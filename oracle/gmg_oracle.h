@@ -136,6 +136,15 @@ int orc_mg_score_orf(const double *frame_scores, const char *seq, int n, const i
                      int frame, int stop_position, const orc_mg_params *prm, orc_start *starts, int cap,
                      orc_mg_out *out);
 
+/* Fasta_Read (src/Common/fasta.cc:236-286) on a memory buffer.  Starts at *pos; returns 0 at the end of the
+ * input, else 1 with the header extent [*hdr_begin, *hdr_end) in buf, the raw sequence characters (every
+ * non-isspace byte up to the next '>') in seq[0 .. *seq_len) (seq needs room for n - *pos bytes), *pos advanced. */
+int orc_fasta_next(const char *buf, long n, long *pos, long *hdr_begin, long *hdr_end, char *seq, long *seq_len);
+
+/* The ingest loop of the reference in one call (timing baseline): every record through orc_fasta_next, every base
+ * through tolower (Filter (ch)) into out (may be NULL), g/c counted.  Returns the number of records. */
+long orc_fasta_all(const char *buf, long n, char *out, long *n_bases, long *gc);
+
 /* Whole-job helper used by bench.py's cpu_baseline leg: score n_reads reads of
  * fixed length L (concatenated, filtered lower-case) into out[read][6][L].
  * Returns number of bases scored.  Single-threaded like the reference. */

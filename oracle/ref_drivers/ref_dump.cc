@@ -16,6 +16,7 @@
 //   ref_dump indep    <gc> <stop1,stop2,...>                   63 x {int16 mip, 4 float}
 //   ref_dump gc       <fasta>                                  1 double (Set_GC_Fraction semantics)
 //   ref_dump rewrite  <icm> <out.icm>                          ICM_t::Read then ::Output(binary)
+//   ref_dump fasta    <fasta>                                  text: per record "H <hdr>" and "S <tolower(Filter(seq))>", then "G <gc count> <total>"
 
 #include "icm.hh"
 #include "fasta.hh"
@@ -112,6 +113,18 @@ int main(int argc, char **argv)
     if (argc < 2) { fprintf(stderr, "usage: ref_dump <cmd> ...\n"); return 2; }
     string cmd = argv[1];
 
+    if (cmd == "fasta") {                               // Fasta_Read (fasta.cc:236-286) + the callers' filter + Set_GC_Fraction's count
+        Read_Set rs;
+        load_reads(argv[2], rs);
+        unsigned long ct = 0, total = 0;
+        for (size_t i = 0; i < rs.seq.size(); i++) {
+            printf("H %s\nS %s\n", rs.hdr[i].c_str(), rs.seq[i].c_str());
+            total += rs.seq[i].length();
+            for (size_t k = 0; k < rs.seq[i].length(); k++) ct += (rs.seq[i][k] == 'g' || rs.seq[i][k] == 'c');
+        }
+        printf("G %lu %lu\n", ct, total);
+        return 0;
+    }
     if (cmd == "gc") {
         put_d(gc_fraction(argv[2]));
         return 0;

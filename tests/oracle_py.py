@@ -93,6 +93,10 @@ class Oracle:
         L.orc_save_prev_stops.argtypes = [C.c_char_p, C.c_int, C.POINTER(MgParams), ip, ip]
         L.orc_mg_score_orf.argtypes = [dp, C.c_char_p, C.c_int, ip, ip, C.c_int, C.c_int, C.POINTER(MgParams),
                                        C.POINTER(Start), C.c_int, C.POINTER(MgOut)]
+        lp = C.POINTER(C.c_long)
+        L.orc_fasta_next.argtypes = [C.c_char_p, C.c_long, lp, lp, lp, C.c_char_p, lp]
+        L.orc_fasta_all.restype = C.c_long
+        L.orc_fasta_all.argtypes = [C.c_char_p, C.c_long, C.c_char_p, lp, lp]
         for f in ("orc_filter", "orc_complement", "orc_subscript"):
             getattr(L, f).argtypes = [C.c_int]
 
@@ -244,6 +248,24 @@ class Oracle:
         fs = self.score_all_frames(gene, indep, seq)
         fwd, rev = self.save_prev_stops(seq, prm)
         return orfs, [self.mg_score_orf(fs, seq, fwd, rev, int(o[0]), int(o[1]), prm) for o in orfs]
+
+    def fasta_records(self, data):
+        """the loop  while (Fasta_Read (fp, s, hdr))  -> [(hdr bytes, tolower(Filter(s)) bytes)], gc count"""
+        data = bytes(data)
+        pos, hb, he, sl = C.c_long(0), C.c_long(), C.c_long(), C.c_long()
+        buf = C.create_string_buffer(len(data) + 1)
+        out, gc = [], 0
+        while self.L.orc_fasta_next(data, len(data), C.byref(pos), C.byref(hb), C.byref(he), buf, C.byref(sl)):
+            seq = self.filter_lower(buf.raw[:sl.value])
+            gc += seq.count(b"g") + seq.count(b"c")
+            out.append((data[hb.value:he.value], seq))
+        return out, gc
+
+    def fasta_all(self, data):
+        """-> (n_records, n_bases, gc count): the reference's ingest loop in C (timing baseline)"""
+        nb, gc = C.c_long(), C.c_long()
+        n = self.L.orc_fasta_all(data, len(data), None, C.byref(nb), C.byref(gc))
+        return n, nb.value, gc.value
 
     def filter_lower(self, seq):
         """tolower(Filter(c)) per character (glimmer3.cc:270-271)"""

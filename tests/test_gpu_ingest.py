@@ -1,0 +1,63 @@
+"""FASTA ingest on the device (include/gmg.h: gmg_fasta_ingest) against the reference's Fasta_Read
+(tests/golden/nasty.fasta_read.txt, seqs.fasta_read.sha256: dumps of the real reference) and against the oracle's
+restatement on seeded random byte soup.  Records, headers, every base after tolower (Filter (ch)), offsets and the
+g/c count must be identical."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLD
+from test_oracle_fasta import dump
+
+pytestmark = pytest.mark.gpu
+
+
+def device_records(gpu, data):
+    reads, headers, gc = gpu.Reads.from_fasta_bytes(data)
+    packed, off = reads.download()
+    assert len(off) == reads.n_reads + 1 == len(headers) + 1 and off[0] == 0 and off[-1] == reads.total_bases
+    seqs = [gpu.synth.unpack_ascii(packed, int(off[r]), int(off[r + 1] - off[r])) for r in range(reads.n_reads)]
+    return reads, list(zip(headers, seqs)), gc
+
+
+def test_ingest_nasty_file_matches_reference(gpu):
+    data = open(os.path.join(DATA, "nasty.fa"), "rb").read()
+    _, records, gc = device_records(gpu, data)
+    assert dump(records, gc) == open(os.path.join(GOLD, "nasty.fasta_read.txt"), "rb").read()
+
+
+def test_ingest_seqs_fa_matches_reference_and_scores_like_the_host_path(gpu, seqs_fa):
+    data = open(os.path.join(DATA, "seqs.fa"), "rb").read()
+    reads, records, gc = device_records(gpu, data)
+    want = open(os.path.join(GOLD, "seqs.fasta_read.sha256")).read().strip()
+    assert hashlib.sha256(dump(records, gc)).hexdigest() == want
+    assert abs(gc / reads.total_bases - float(np.load(os.path.join(GOLD, "frames_nc.npz"))["gc"])) < 1e-15
+    nc, indep = gpu.Icm.open(os.path.join(DATA, "NC_000915.icm")), gpu.Icm.indep(0.5)
+    a = gpu.frame_score6(nc, indep, reads)
+    b = gpu.frame_score6(nc, indep, gpu.Reads.from_strings(seqs_fa[1]))
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_ingest_random_byte_soup_vs_oracle(gpu, oracle, seed):
+    rng = np.random.default_rng(seed)
+    alphabet = np.frombuffer(b"acgtACGTnNrRyYkKmM>>>\n\n\n\n\r\t  x*-0", np.uint8)
+    pieces = []
+    for _ in range(400):
+        pieces.append(alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 200)))].tobytes())
+        if rng.random() < 0.3:
+            pieces.append(b">hdr %d  \n" % rng.integers(0, 1000) + b"acgt" * int(rng.integers(0, 300)))
+    tail = [b"", b">", b">   ", b"> x", b"\n", b"acgt", b">h\n"][seed % 7]
+    data = b"".join(pieces) + tail
+    _, records, gc = device_records(gpu, data)
+    want, want_gc = oracle.fasta_records(data)
+    assert records == want and gc == want_gc and len(want) > 50
+
+
+def test_ingest_edge_inputs(gpu, oracle):
+    for data in [b"", b"no record at all\nacgt\n", b">", b">only a header", b">h\n", b">a\nA", b"\n\n>  \n\n", b">x\nacgt>y\n>z"]:
+        reads, records, gc = device_records(gpu, data)
+        want, want_gc = oracle.fasta_records(data)
+        assert records == want and gc == want_gc, data
