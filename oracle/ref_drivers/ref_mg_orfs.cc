@@ -51,7 +51,7 @@ void wrap_Add_Events_Rev(const Orf_t &orf, vector<Start_t> &sl, int &id)
 }
 
 // ---- the set-up steps of glimmer-mg's main for -m <icm> (glimmer-mg.cc:241-316), in the same order ----
-static void setup(int argc, char **argv)
+static void setup_options(int argc, char **argv)
 {
     Verbose = 0;
     Parse_Command_Line(argc, argv);
@@ -61,6 +61,10 @@ static void setup(int argc, char **argv)
         fprintf(stderr, "ref_mg_orfs: only -m <icm> without -c / -i / -s / detail log is driven here\n");
         exit(2);
     }
+}
+
+static void setup_models(void)
+{
     if (!GC_Frac_Set) Set_GC_Fraction();
     Indep_Model.Build_Indep_WO_Stops(Indep_GC_Frac, Stop_Codon);
     Set_Ignore_Score_Len();
@@ -84,18 +88,19 @@ int main(int argc, char **argv)
     if (argc < 4) { fprintf(stderr, "usage: ref_mg_orfs dump|batch <glimmer-mg args>\n"); return 2; }
     string mode = argv[1];
     try {
-        setup(argc - 1, argv + 1);
+        setup_options(argc - 1, argv + 1);
         vector<string> seq_list, hdr_list;
-        {
-            FILE *fp = File_Open(Sequence_File_Name, "r", __FILE__, __LINE__);
-            string s, h;
-            while (Fasta_Read(fp, s, h)) { seq_list.push_back(s); hdr_list.push_back(h); }
-            fclose(fp);
-        }
-        const int n_seq = seq_list.size();
         vector<Orf_t> orf_list;
 
         if (mode == "dump") {
+            setup_models();
+            {
+                FILE *fp = File_Open(Sequence_File_Name, "r", __FILE__, __LINE__);
+                string s, h;
+                while (Fasta_Read(fp, s, h)) { seq_list.push_back(s); hdr_list.push_back(h); }
+                fclose(fp);
+            }
+            const int n_seq = seq_list.size();
             for (int i = 0; i < n_seq; i++) {
                 load_sequence(seq_list, hdr_list, i);
                 Initialize_Terminal_Events(First_Event, Final_Event, Best_Event, Last_Event);
@@ -128,13 +133,41 @@ int main(int argc, char **argv)
         if (mode == "batch") {
             const char *dev = getenv("GMG_DEVICE");
             if (gmg_init(dev ? atoi(dev) : 0) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
-            // pack every read (Filter + tolower + 2 bit, glimmer-mg.cc:381-382) and upload once
-            vector<uint64_t> off(n_seq + 1, 0);
-            for (int i = 0; i < n_seq; i++) off[i + 1] = off[i] + seq_list[i].length();
-            vector<uint32_t> packed(gmg_packed_words(off[n_seq]), 0);
-            for (int i = 0; i < n_seq; i++) gmg_pack_bases(seq_list[i].data(), seq_list[i].length(), off[i], packed.data());
+            // the file's bytes go to the device as they are: Fasta_Read, tolower (Filter ()) and the 2-bit packing happen
+            // there (gmg_fasta_ingest); the host keeps the header extents and gets the filtered bases back for the
+            // event / DP code, which reads the global Sequence
+            string file_bytes;
+            {
+                FILE *fp = File_Open(Sequence_File_Name, "rb", __FILE__, __LINE__);
+                char buf[1 << 16];
+                size_t got;
+                while ((got = fread(buf, 1, sizeof buf, fp)) > 0) file_bytes.append(buf, got);
+                fclose(fp);
+            }
             gmg_reads *reads = NULL;
-            if (gmg_reads_upload(packed.data(), off.data(), n_seq, &reads) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+            gmg_fasta *fasta = NULL;
+            if (gmg_fasta_ingest(file_bytes.data(), file_bytes.size(), &reads, &fasta) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+            uint64_t n_ing = 0, total_bases = 0, gc_ct = 0;
+            gmg_fasta_info(fasta, &n_ing, &total_bases, &gc_ct);
+            const int n_seq = (int)n_ing;
+            if (!GC_Frac_Set) {                         // Set_GC_Fraction (glimmer_base.cc:2564-2595) without reading the file again
+                Indep_GC_Frac = double(gc_ct) / total_bases;
+                GC_Frac_Set = true;
+            }
+            setup_models();
+            seq_list.resize(n_seq);
+            hdr_list.resize(n_seq);
+            vector<uint64_t> hb(n_ing), he(n_ing), off(n_ing + 1);
+            gmg_fasta_headers(fasta, hb.data(), he.data());
+            vector<uint32_t> packed(gmg_packed_words(total_bases) + 1, 0);
+            gmg_reads_download(reads, packed.data(), off.data());
+            gmg_fasta_free(fasta);
+            for (int i = 0; i < n_seq; i++) {            // replace what the host parser produced by what came back from the device
+                hdr_list[i] = file_bytes.substr(hb[i], he[i] - hb[i]);
+                string &sq = seq_list[i];
+                sq.resize(off[i + 1] - off[i]);
+                for (uint64_t k = 0; k < sq.size(); k++) { const uint64_t g = off[i] + k; sq[k] = "acgt"[(packed[g >> 4] >> (2 * (g & 15))) & 3]; }
+            }
             // ONE call: Score_All_Frames + Find_Orfs + Score_Orf_Starts + the filter of Score_Orfs_Errors, all reads
             gmg_mg_params prm;
             memset(&prm, 0, sizeof prm);
