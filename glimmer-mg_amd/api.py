@@ -377,6 +377,18 @@ def mg_score_reads(gene, null, reads, min_gene_len=75, allow_truncated=True, ign
     return orfs[:n_orfs.value], starts[:n_starts.value], off
 
 
+def score_reads_strings(models, reads):
+    """gmg_score_reads_strings: whole-read Score_String (frame 0) of every read and of its reverse complement under
+    every model -> float64 [n_models, n_reads, 2]"""
+    n = len(models)
+    arr = (C.c_void_p * max(n, 1))(*[m.device() for m in models])
+    buf = _DeviceBuffer(max(n * reads.n_reads * 2, 1) * 8)
+    _ck(capi.lib().gmg_score_reads_strings(arr, n, reads.h, buf.ptr, None))
+    out = buf.to_host(np.float64, n * reads.n_reads * 2).reshape(n, reads.n_reads, 2)
+    buf.free()
+    return out
+
+
 def window_distrib(model, windows, frames):
     """Full_Window_Distrib / Full_Window_Prob (icm.cc:512-610).  windows: uint8 codes [n, model_len]
     -> (dist float32 [n,4], prob float64 [n])"""

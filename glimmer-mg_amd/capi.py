@@ -61,6 +61,7 @@ PROTOTYPES = {
     "gmg_mg_result_fetch": (i32, [vp, vp, vp, vp]),
     "gmg_mg_result_free": (i32, [vp]),
     "gmg_trim_cache": (i32, []),
+    "gmg_score_reads_strings": (i32, [vp, i32, vp, vp, vp]),
     "gmg_host_register": (i32, [vp, C.c_size_t]),
     "gmg_host_unregister": (i32, [vp]),
     "gmg_fasta_ingest": (i32, [C.c_char_p, u64, C.POINTER(vp), C.POINTER(vp)]),

@@ -79,4 +79,23 @@ __device__ __forceinline__ float dev_score(const GmgDevModel &m, const DevBuf &b
 }
 
 
+// window of 32 packed bases starting at job-wide base `first` (may be slightly negative / past the
+// end: the packed buffer has GMG_GUARD_WORDS zero words on both sides)
+__device__ __forceinline__ uint64_t dev_window_bits(const uint32_t *__restrict__ packed, int64_t first)
+{
+    const int64_t w0 = first >> 4;                      // arithmetic shift: floor for negatives
+    const unsigned sh = 2u * (unsigned)(first & 15);
+    const uint64_t lo = (uint64_t)packed[w0] | ((uint64_t)packed[w0 + 1] << 32);
+    const uint64_t hi = packed[w0 + 2];
+    return (lo >> sh) | ((hi << 1) << (63 - sh));
+}
+
+// reverse the order of `nfields` 2-bit fields held in the low bits of y
+__device__ __forceinline__ uint32_t dev_reverse_fields(uint32_t y, int nfields)
+{
+    uint32_t z = __brev(y) >> (32 - 2 * nfields);
+    return ((z & 0x55555555u) << 1) | ((z >> 1) & 0x55555555u);
+}
+
+
 #endif

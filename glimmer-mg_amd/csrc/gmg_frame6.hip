@@ -80,7 +80,12 @@ __device__ __forceinline__ uint32_t f6_descend(const uint8_t *tab, uint32_t C, u
 // ---------------------------------------------------------------------------
 // GENE_ONLY: write the gene model's value alone, as fp32, to a.out_gene (input of the fused Score_Orfs scan,
 // gmg_orfs.hip); the null model is not touched.
-template <int BLOCK, int DT, int K, int DIAG, bool PAIR, bool GENE_ONLY>
+// STRINGS (with GENE_ONLY, periodicity-1 models): the two strings scoreReadsGlim / Score_String look at instead of
+// the two scoring buffers of Score_All_Frames -- the read as it is (row 0: window = the W-1 bases in front of p,
+// nothing complemented) and its reverse complement (row 1, stored at forward coordinates: window = the complements
+// of the W-1 bases behind p).  Same geometry as the complemented / reversed buffers with the complement swapped;
+// every work-group works on sub-model 0.
+template <int BLOCK, int DT, int K, int DIAG, bool PAIR, bool GENE_ONLY, bool STRINGS = false>
 __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
 {
     constexpr int CS = f6_cstride(DT);
@@ -94,8 +99,8 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[K * RAWW];   // packed words of the current round
     extern __shared__ __attribute__((aligned(16))) uint8_t s_half[];   // [HALF_ROWS][4] floats
 
-    const int ftype = blockIdx.x % 3;
-    const uint32_t worker = blockIdx.x / 3, nworkers = gridDim.x / 3;
+    const int ftype = STRINGS ? 0 : blockIdx.x % 3;
+    const uint32_t worker = STRINGS ? blockIdx.x : blockIdx.x / 3, nworkers = STRINGS ? gridDim.x : gridDim.x / 3;
     const int W = a.gene.W;
     const uint8_t *leaf_rows = (const uint8_t *)(a.gene.crow + ((size_t)ftype * a.gene.ctot + f6_level_base(DT)) * 4);
 
@@ -169,10 +174,11 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
                 const uint32_t xl = __builtin_amdgcn_alignbit(w1, w0, wsh);
                 const uint32_t xh = __builtin_amdgcn_alignbit(w2, w1, wsh);
                 uint32_t C[4];
-                C[1] = ~xl & ctx_mask;                                              // complemented buffer
-                C[3] = ~__builtin_amdgcn_alignbit(xh, xl, 2) & ctx_mask;
-                C[0] = __builtin_amdgcn_alignbit(xh, xl, sh_f) & ctx_mask;          // reversed buffer, natural order
-                C[2] = __builtin_amdgcn_alignbit(xh, xl, sh_f + 2) & ctx_mask;
+                const uint32_t flip_r = STRINGS ? 0u : ctx_mask, flip_f = STRINGS ? ctx_mask : 0u;
+                C[1] = (xl ^ flip_r) & ctx_mask;                                    // complemented buffer (STRINGS: the read itself)
+                C[3] = (__builtin_amdgcn_alignbit(xh, xl, 2) ^ flip_r) & ctx_mask;
+                C[0] = (__builtin_amdgcn_alignbit(xh, xl, sh_f) ^ flip_f) & ctx_mask;   // reversed buffer, natural order (STRINGS: complemented)
+                C[2] = (__builtin_amdgcn_alignbit(xh, xl, sh_f + 2) ^ flip_f) & ctx_mask;
                 uint32_t idx[4];
                 idx[0] = f6_descend<DT>(s_shf, C[0], shift0_f);
                 idx[1] = f6_descend<DT>(s_shr, C[1], shift0_r);
@@ -220,8 +226,8 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
                 const uint64_t chunk = worker + (uint64_t)(j0 + k) * nworkers;
                 if (GENE_ONLY) {
                     // v[c] = gene value exactly (the null tables hold zeros); rows of floats, 8-byte stores
-                    float *gf = a.out_gene + (uint64_t)ftype * a.total + chunk * SPAN;
-                    float *gr = a.out_gene + (uint64_t)(3 + ftype) * a.total + chunk * SPAN;
+                    float *gf = a.out_gene + (uint64_t)(STRINGS ? 1 : ftype) * a.total + chunk * SPAN;
+                    float *gr = a.out_gene + (uint64_t)(STRINGS ? 0 : 3 + ftype) * a.total + chunk * SPAN;
                     if (PAIR) {
                         typedef float f2 __attribute__((ext_vector_type(2)));
                         const f2 x0 = {(float)v[0], (float)v[2]}, x1 = {(float)v[1], (float)v[3]};
@@ -261,24 +267,6 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
 // the context position named by a node lies before the buffer, i.e. mip < (W-1)-j, which in the
 // completed tree reads "shift byte < 2*((W-1)-j)"; crow holds the right row for inner nodes too.
 // ---------------------------------------------------------------------------
-
-// window of 32 packed bases starting at job-wide base `first` (may be slightly negative / past the
-// end: the packed buffer has GMG_GUARD_WORDS zero words on both sides)
-__device__ __forceinline__ uint64_t dev_window_bits(const uint32_t *__restrict__ packed, int64_t first)
-{
-    const int64_t w0 = first >> 4;                      // arithmetic shift: floor for negatives
-    const unsigned sh = 2u * (unsigned)(first & 15);
-    const uint64_t lo = (uint64_t)packed[w0] | ((uint64_t)packed[w0 + 1] << 32);
-    const uint64_t hi = packed[w0 + 2];
-    return (lo >> sh) | ((hi << 1) << (63 - sh));
-}
-
-// reverse the order of `nfields` 2-bit fields held in the low bits of y
-__device__ __forceinline__ uint32_t dev_reverse_fields(uint32_t y, int nfields)
-{
-    uint32_t z = __brev(y) >> (32 - 2 * nfields);
-    return ((z & 0x55555555u) << 1) | ((z >> 1) & 0x55555555u);
-}
 
 // 32 lanes per read (z = lane & 31 < 2(W-1) <= 28 active): no division, read offsets broadcast.
 // The kernel is a chain of dependent latencies (offsets -> packed words -> D LDS steps -> row gather ->
@@ -528,4 +516,47 @@ int gmg_launch_gene6(const gmg_model *gene, const gmg_reads *reads, float *d_gen
         GMG_HIP(hipGetLastError());
     }
     return launch_generic(a, n_chunks * SPAN, a.total - n_chunks * SPAN, s);
+}
+
+// Per-base values of the two strings scoreReadsGlim scores with a periodicity-1 ICM (the read, and its reverse
+// complement stored at forward coordinates), fp32 rows [2][total], full-window rule, full chunks only: the caller
+// (k_string_sum, gmg_strings.hip) recomputes the first W-1 positions of either string and the last < 2,048 bases
+// of the batch itself.  *tail_start = first base the main pass did not write.
+int gmg_launch_strings(const gmg_model *m, const gmg_reads *reads, float *d_vals, uint64_t *tail_start, hipStream_t s)
+{
+    if (!(m->dev.has_fast && m->dev.D == 7 && m->dev.W >= 3 && m->dev.W <= 15 && m->dev.P == 1)) return GMG_EBADMODEL;
+    Frame6Args a;
+    a.gene = m->dev;
+    a.nul = m->dev;                                    // not used in gene-only mode
+    a.packed = reads->d_packed;
+    a.off = reads->d_off;
+    a.tile_read = reads->d_tile_read;
+    a.total = reads->total_bases;
+    a.n_reads = reads->n_reads;
+    a.first = 0;
+    a.count = 0;
+    a.out = nullptr;
+    a.out_gene = d_vals;
+    constexpr int BLOCK = 1024, DT = 7, KR = 16;
+    constexpr uint32_t SPAN = 2 * BLOCK;
+    const uint64_t n_chunks = a.total / SPAN;
+    *tail_start = n_chunks * SPAN;
+    if (n_chunks == 0) return GMG_OK;
+    int dev = 0, n_cu = 256;
+    GMG_HIP(hipGetDevice(&dev));
+    GMG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    unsigned grid = (unsigned)n_cu;                    // one persistent work-group per CU, all on sub-model 0
+    if (grid > n_chunks) grid = (unsigned)n_chunks;
+    const size_t lds = ((size_t)1 << (2 * DT)) / 2 * 16;
+    if ((a.total & 1) == 0) {
+        GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, true, true, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, 0, true, true, true>), dim3(grid), dim3(BLOCK), lds, s, a);
+    } else {
+        GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, false, true, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, 0, false, true, true>), dim3(grid), dim3(BLOCK), lds, s, a);
+    }
+    GMG_HIP(hipGetLastError());
+    return GMG_OK;
 }

@@ -1,0 +1,218 @@
+// gmg_strings.hip -- whole-read Score_String of many ICMs on both strands: what Phymm's scoreReadsGlim.pl asks of
+// simple-score (scripts/scoreReadsGlim.pl:450,482: every read and its reverse complement against every genome's ICM;
+// ICM_t::Score_String, src/ICM/icm.cc:864-903, frame 0, periodicity-1 models).  BASELINE configs[3].
+//
+// Per model two passes:
+//   k_frame6t<STRINGS> (gmg_frame6.hip)  per-base values of both strings for the whole batch, fp32 rows [2][total], at the
+//                                        six-frame kernel's rate (LDS table swapping, no read boundaries)
+//   k_string_sum                         one lane per (read, strand): the first W-1 positions of the string by the
+//                                        partial-window rule (plain descent on the original tables, icm.cc:807-842), the rest
+//                                        from the rows (streamed through LDS in contiguous slabs); ONE running sum of doubles
+//                                        in string order -- the reference's sequence of additions, so the sums are
+//                                        bit-identical.
+// Models the fast pass does not cover (periodicity 3, other depths) go through k_seg_cum (exact, any shape).
+
+#include "gmg_device.h"
+
+#include <string.h>
+#include <vector>
+
+struct StringSumArgs {
+    GmgDevModel m;
+    const uint32_t *packed;
+    const uint64_t *read_off;
+    uint64_t n_reads, total, tail_start;
+    const float *vals;           // [2][total]
+    double *sums;                // [n_reads][2]: forward string, reverse complement
+};
+
+struct __attribute__((packed, aligned(4))) StrF4 { float v[4]; };
+
+// One work-group = one wave = STR_READS consecutive reads of one strand.  Their values are ONE contiguous run of the
+// row, so the wave streams it through LDS in slabs of STR_SLAB floats with fully coalesced 16-byte loads (memory order =
+// load order: this is what keeps HBM pages open; 64-byte pieces per read ran at 1.1 TB/s), and the lane that owns a
+// read adds the part of its read inside the slab, in string order, carrying its sum from slab to slab.  Forward
+// strings walk the slabs upwards, reverse complements downwards.  Reads of any length work (a long read simply spans
+// several slabs).
+#define STR_READS 16
+#define STR_SLAB 4096
+
+__global__ __launch_bounds__(64) void k_string_sum(StringSumArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float s_v[STR_SLAB];
+    __shared__ __attribute__((aligned(16))) uint8_t s_shift[5472];       // completed-tree shifts of sub-model 0, depth 7
+    __shared__ float s_head[STR_READS][16];                             // the first W-1 values of every string of the group
+    const uint32_t lane = threadIdx.x;
+    const uint64_t groups = (a.n_reads + STR_READS - 1) / STR_READS;
+    const int W = a.m.W, D = a.m.D;
+    for (int i = lane * 16; i < a.m.cstride && i < 5472; i += 64 * 16) *(uint4 *)(s_shift + i) = *(const uint4 *)(a.m.cshift + i);
+    const uint32_t ctx_mask = (1u << (2 * W)) - 1u;
+    for (uint64_t blk = blockIdx.x; blk < 2 * groups; blk += gridDim.x) {
+        const bool rc = blk >= groups;                  // reverse complement: string position q <-> read position n-1-q
+        const uint64_t r0 = (rc ? blk - groups : blk) * STR_READS;
+        const uint64_t r1 = r0 + STR_READS < a.n_reads ? r0 + STR_READS : a.n_reads;
+        const uint64_t g_lo = a.read_off[r0], g_hi = a.read_off[r1];       // the group's run of the row
+        const uint64_t r = r0 + lane;
+        const bool live = lane < STR_READS && r < r1;
+        const uint64_t off = live ? a.read_off[r] : 0;
+        const int n = live ? (int)(a.read_off[r + 1] - off) : 0;
+        const DevBuf b = dev_make_buf(a.packed, off, 0, (uint32_t)n, rc ? GMG_REVCOMP : GMG_FORWARD);
+        const int head = n < W - 1 ? n : W - 1;
+        // partial windows (icm.cc:883-888, 807-842): the W-1 first positions of the 16 strings, all lanes in parallel,
+        // on the completed tree (shift bytes in LDS; "stop when the context position lies before the string" reads
+        // "shift byte < 2 ((W-1) - j)"; crow has the row for inner nodes too)
+        __syncthreads();
+        for (uint32_t idx = lane; idx < STR_READS * (uint32_t)(W - 1); idx += 64) {
+            const uint32_t k = idx / (uint32_t)(W - 1);
+            const int j = (int)(idx - k * (uint32_t)(W - 1));
+            if (r0 + k >= r1) continue;
+            const uint64_t off_k = a.read_off[r0 + k];
+            const int n_k = (int)(a.read_off[r0 + k + 1] - off_k);
+            if (j >= n_k) continue;
+            uint32_t C;                                 // window ending at string position j: char i at bits 2i
+            if (!rc) C = (uint32_t)dev_window_bits(a.packed, (int64_t)off_k + j - (W - 1)) & ctx_mask;
+            else C = (dev_reverse_fields((uint32_t)dev_window_bits(a.packed, (int64_t)off_k + n_k - 1 - j) & ctx_mask, W) ^ ctx_mask);
+            const int thr2 = 2 * ((W - 1) - j);
+            uint32_t tidx = 0, lvl = 0, width = 1, node = 0xffffffffu;
+            for (int l = 0; l < D; l++) {
+                const uint32_t sh = s_shift[lvl + tidx];
+                if (node == 0xffffffffu && (int)sh < thr2) node = lvl + tidx;
+                tidx = (tidx << 2) + ((C >> sh) & 3u);
+                lvl += width;
+                width <<= 2;
+            }
+            if (node == 0xffffffffu) node = lvl + tidx;
+            s_head[k][j] = a.m.crow[(size_t)node * 4 + ((C >> (2 * (W - 1))) & 3u)];
+        }
+        __syncthreads();
+        double sum = 0.0;                               // icm.cc:871
+        if (live) for (int q = 0; q < head; q++) sum += (double)s_head[lane][q];
+        int q = head;                                   // next string position of this lane's read
+        const float *row = a.vals + (rc ? a.total : 0);
+        const uint64_t n_slabs = (g_hi - g_lo + STR_SLAB - 1) / STR_SLAB;
+        // slab [s_lo, s_hi) of the row, from the bottom (forward) or from the top (reverse complement)
+        auto slab_lo = [&](uint64_t sl) __attribute__((always_inline)) {
+            return rc ? (g_hi > (sl + 1) * STR_SLAB + g_lo ? g_hi - (sl + 1) * STR_SLAB : g_lo) : g_lo + sl * STR_SLAB;
+        };
+        auto slab_hi = [&](uint64_t sl) __attribute__((always_inline)) {
+            return rc ? g_hi - sl * STR_SLAB : (g_lo + (sl + 1) * STR_SLAB < g_hi ? g_lo + (sl + 1) * STR_SLAB : g_hi);
+        };
+        StrF4 x[STR_SLAB / 256];
+        auto issue = [&](uint64_t sl) __attribute__((always_inline)) {
+            const uint64_t lo = slab_lo(sl), hi = slab_hi(sl);
+#pragma unroll
+            for (int i = 0; i < STR_SLAB / 256; i++) {
+                const uint64_t g = lo + 4 * (lane + 64u * i);
+                StrF4 t = {{0.f, 0.f, 0.f, 0.f}};
+                if (g + 3 < hi) t = *(const StrF4 *)(row + g);
+                else
+                    for (int e = 0; e < 4; e++)
+                        if (g + e < hi) t.v[e] = row[g + e];
+                x[i] = t;
+            }
+        };
+        if (n_slabs) issue(0);
+        for (uint64_t sl = 0; sl < n_slabs; sl++) {
+            const uint64_t s_lo = slab_lo(sl), s_hi = slab_hi(sl);
+            __syncthreads();                            // the previous slab has been summed
+#pragma unroll
+            for (int i = 0; i < STR_SLAB / 256; i++) *(StrF4 *)(s_v + 4 * (lane + 64u * i)) = x[i];
+            if (sl + 1 < n_slabs) issue(sl + 1);        // in flight while this slab is summed
+            __syncthreads();
+            if (live && q < n) {
+                // string positions q .. q_end-1 of this read have their base inside the slab
+                int q_end;
+                if (!rc) q_end = off + (uint64_t)n <= s_hi ? n : (int)(s_hi - off);
+                else q_end = off >= s_lo ? n : n - (int)(s_lo - off);
+                const uint64_t g_first = off + (uint64_t)(rc ? n - 1 - q : q);
+                if (q_end > q && g_first >= s_lo && g_first < s_hi) {
+                    const uint64_t g_last = off + (uint64_t)(rc ? n - q_end : q_end - 1);
+                    const uint64_t g_top = rc ? g_first : g_last;
+                    if (g_top < a.tail_start) {         // the usual case: a tight loop of LDS reads and additions
+                        const float *v = s_v + (g_first - s_lo);
+                        const int cnt = q_end - q;
+                        const int dir = rc ? -1 : 1;
+                        int e = 0;
+                        for (; e + 16 <= cnt; e += 16) {            // 16 LDS reads in flight, then the additions in order
+                            float t[16];
+#pragma unroll
+                            for (int u = 0; u < 16; u++) t[u] = v[dir * (e + u)];
+#pragma unroll
+                            for (int u = 0; u < 16; u++) sum += (double)t[u];
+                        }
+                        for (; e < cnt; e++) sum += (double)v[dir * e];
+                    } else {
+                        // the last < 2,048 bases of the batch are not in the rows (the main pass does whole chunks): plain descent
+                        for (int qq = q; qq < q_end; qq++) {
+                            const uint64_t g = off + (uint64_t)(rc ? n - 1 - qq : qq);
+                            sum += g < a.tail_start ? (double)s_v[g - s_lo] : (double)dev_score(a.m, b, qq, 0);
+                        }
+                    }
+                    q = q_end;
+                }
+            }
+        }
+        if (live) a.sums[2 * r + (rc ? 1 : 0)] = sum;
+    }
+}
+
+extern "C" int gmg_score_reads_strings(const gmg_model *const *models, int n_models, const gmg_reads *reads,
+                                       double *d_sums, void *stream)
+{
+    if (!models || n_models < 0 || !reads || (!d_sums && n_models && reads->n_reads))
+        return gmg_set_error(GMG_EINVAL, "gmg_score_reads_strings: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t nr = reads->n_reads;
+    if (nr == 0 || n_models == 0) return GMG_OK;
+    float *d_vals = nullptr;
+    gmg_segments *segs = nullptr;                       // built on demand for models without the fast pass
+    int rc = GMG_OK;
+    for (int k = 0; k < n_models && rc == GMG_OK; k++) {
+        const gmg_model *m = models[k];
+        if (!m) { rc = gmg_set_error(GMG_EINVAL, "gmg_score_reads_strings: model %d is NULL", k); break; }
+        double *out = d_sums + (size_t)k * nr * 2;
+        uint64_t tail_start = 0;
+        if (!d_vals && reads->total_bases) {
+            hipError_t e = gmg_pool_alloc((void **)&d_vals, (size_t)2 * reads->total_bases * sizeof(float));
+            if (e != hipSuccess) { rc = gmg_set_error(GMG_ENOMEM, "gmg_score_reads_strings: %s", hipGetErrorString(e)); break; }
+        }
+        const int fast = gmg_launch_strings(m, reads, d_vals, &tail_start, s);
+        if (fast == GMG_OK) {
+            StringSumArgs a;
+            a.m = m->dev;
+            a.packed = reads->d_packed;
+            a.read_off = reads->d_off;
+            a.n_reads = nr;
+            a.total = reads->total_bases;
+            a.tail_start = tail_start;
+            a.vals = d_vals;
+            a.sums = out;
+            const uint64_t blocks = 2 * ((nr + STR_READS - 1) / STR_READS);
+            hipLaunchKernelGGL(k_string_sum, dim3((unsigned)(blocks < 256 * 256 ? blocks : 256 * 256)), dim3(64), 0, s, a);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) rc = gmg_set_error(GMG_EHIP, "gmg_score_reads_strings: %s", hipGetErrorString(e));
+            continue;
+        }
+        if (fast != GMG_EBADMODEL) { rc = fast; break; }
+        // any other model shape: the exact segment kernel on (read, FORWARD) and (read, REVCOMP) segments
+        if (!segs) {
+            std::vector<uint64_t> off(nr + 1);
+            hipError_t e = hipMemcpy(off.data(), reads->d_off, (nr + 1) * 8, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { rc = gmg_set_error(GMG_EHIP, "gmg_score_reads_strings: %s", hipGetErrorString(e)); break; }
+            std::vector<gmg_segment> sg(2 * nr);
+            for (uint64_t r = 0; r < nr; r++) {
+                const uint32_t len = (uint32_t)(off[r + 1] - off[r]);
+                sg[2 * r] = {(uint32_t)r, 0, len, GMG_FORWARD};
+                sg[2 * r + 1] = {(uint32_t)r, 0, len, GMG_REVCOMP};
+            }
+            rc = gmg_segments_upload(reads, sg.data(), 2 * nr, nullptr, nullptr, &segs);
+            if (rc) break;
+        }
+        rc = gmg_score_string(m, reads, segs, 0, out, s);
+    }
+    hipError_t e = hipStreamSynchronize(s);            // the scratch goes back to the cache: nothing may still use it
+    if (d_vals) gmg_pool_release(d_vals);
+    if (segs) gmg_segments_free(segs);
+    if (rc == GMG_OK && e != hipSuccess) rc = gmg_set_error(GMG_EHIP, "gmg_score_reads_strings: %s", hipGetErrorString(e));
+    return rc;
+}

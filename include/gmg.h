@@ -156,6 +156,15 @@ int gmg_segment_cumscore(const gmg_model *m, const gmg_reads *reads, const gmg_s
 int gmg_score_string(const gmg_model *m, const gmg_reads *reads, const gmg_segments *segs,
                      int frame0, double *d_sums, void *stream);
 
+/* Whole-read ICM_t::Score_String (src/ICM/icm.cc:864-903, frame 0) of every read AND of its reverse complement
+ * under each of n_models models -- what Phymm's scoreReadsGlim.pl asks of `simple-score` for every genome's ICM
+ * (scripts/scoreReadsGlim.pl:450,482; BASELINE configs[3]).  d_sums (device): [n_models][n_reads][2] doubles,
+ * [..][0] = the read, [..][1] = its reverse complement.  Periodicity-1 models of the default shape (depth 7,
+ * window <= 15) take a batched path at the six-frame kernel's rate; any other model goes through the exact
+ * segment kernel.  Sums are sequential double additions in string order (bit-identical to the reference). */
+int gmg_score_reads_strings(const gmg_model *const *models, int n_models, const gmg_reads *reads,
+                            double *d_sums, void *stream);
+
 /* ICM_t::Partial_Window_Prob (src/ICM/icm.cc:807-842) for the LAST base of every
  * segment (predict_pos = len-1), with the partial-window rule applied whatever
  * the length, as the reference does.  d_out[i]; 0.0 for an empty segment. */
