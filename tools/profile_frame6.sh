@@ -1,5 +1,5 @@
 #!/bin/bash
-# Profile k_frame6s on the GPU box: kernel trace + PMC passes (counters in their own runs, as the
+# Profile the six-frame kernels on the GPU box: kernel trace + PMC passes (counters in their own runs, as the
 # MI355X guide prescribes).  Usage: tools/profile_frame6.sh <tag> [extra bench args]
 # Writes gpurun_out/prof_<tag>/{trace,pmc1..6}/...csv and gpurun_out/prof_<tag>/summary.txt
 set -u
@@ -8,7 +8,8 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 BENCH="python3 bench.py --steps 5 --warmup 2 --cpu-reads 0 $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
+# the kernel trace runs the DEFAULT bench command (steps 20, warmup 5), so that its averages are the ones bench.py reports
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --cpu-reads 0 $* > "$OUT/trace.log" 2>&1
 i=1
 for set in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
@@ -21,4 +22,6 @@ for set in \
   i=$((i+1))
 done
 python3 tools/summarize_pmc.py "$OUT" > "$OUT/summary.txt" 2>&1
+python3 tools/summarize_pmc.py "$OUT" k_frame6p > "$OUT/summary_k_frame6p.txt" 2>&1
 cat "$OUT/summary.txt"
+tail -1 "$OUT/trace.log"
