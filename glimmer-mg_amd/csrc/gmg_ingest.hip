@@ -216,12 +216,13 @@ extern "C" int gmg_fasta_ingest(const char *bytes, uint64_t n_bytes, gmg_reads *
     FA_TRY(dev.alloc(&d_packed, (n_words + 1) * 4));
     FA_TRY(hipMemset(d_packed, 0, (n_words + 1) * 4));
     FA_TRY(hipMalloc((void **)&d_off, (n_reads + 1) * 8));                   // goes to the gmg_reads
+    struct OffGuard { uint64_t *&p; ~OffGuard() { if (p) (void)hipFree(p); } } off_guard = {d_off};   // until then it is ours
     hipError_t e2 = dev.alloc(&d_hb, n_reads * 8);
     if (e2 == hipSuccess) e2 = dev.alloc(&d_he, n_reads * 8);
     if (e2 == hipSuccess) e2 = dev.alloc(&d_gc, 8);
     if (e2 == hipSuccess) e2 = hipMemset(d_gc, 0, 8);
     if (e2 == hipSuccess) e2 = hipMemcpy(d_off + n_reads, &total, 8, hipMemcpyHostToDevice);
-    if (e2 != hipSuccess) { (void)hipFree(d_off); delete idx; return gmg_set_error(GMG_ENOMEM, "gmg_fasta_ingest: %s", hipGetErrorString(e2)); }
+    if (e2 != hipSuccess) { delete idx; return gmg_set_error(GMG_ENOMEM, "gmg_fasta_ingest: %s", hipGetErrorString(e2)); }
     if (n_reads) {
         const uint64_t blocks = (n_reads + 255) / 256;
         hipLaunchKernelGGL(k_fa_fill, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, 0, d_he, n_reads, n_bytes);
@@ -239,7 +240,7 @@ extern "C" int gmg_fasta_ingest(const char *bytes, uint64_t n_bytes, gmg_reads *
     if (e2 == hipSuccess && n_reads) e2 = hipMemcpy(idx->hdr_begin.data(), d_hb, n_reads * 8, hipMemcpyDeviceToHost);
     if (e2 == hipSuccess && n_reads) e2 = hipMemcpy(idx->hdr_end.data(), d_he, n_reads * 8, hipMemcpyDeviceToHost);
     if (e2 == hipSuccess) e2 = hipMemcpy(&gc, d_gc, 8, hipMemcpyDeviceToHost);
-    if (e2 != hipSuccess) { (void)hipFree(d_off); delete idx; return gmg_set_error(GMG_EHIP, "gmg_fasta_ingest: %s", hipGetErrorString(e2)); }
+    if (e2 != hipSuccess) { delete idx; return gmg_set_error(GMG_EHIP, "gmg_fasta_ingest: %s", hipGetErrorString(e2)); }
     // Fasta_Read: the blanks behind '>' are not part of the header; a record that is only "> <blanks> EOF" does not exist
     for (uint64_t r = 0; r < n_reads; r++) {
         uint64_t b = idx->hdr_begin[r];
@@ -253,8 +254,9 @@ extern "C" int gmg_fasta_ingest(const char *bytes, uint64_t n_bytes, gmg_reads *
     }
     gmg_reads *reads = nullptr;
     int rc = gmg_reads_wrap_device(d_packed, d_off, n_reads, total, &reads);    // copies the words into the guarded buffer
-    if (rc) { (void)hipFree(d_off); delete idx; return rc; }
+    if (rc) { delete idx; return rc; }
     reads->owns_off = 1;                                // the offsets now belong to the reads
+    d_off = nullptr;
     idx->n_reads = n_reads;
     idx->total_bases = total;
     idx->gc_count = gc;
