@@ -65,6 +65,11 @@ PROTOTYPES = {
     "gmg_host_register": (i32, [vp, C.c_size_t]),
     "gmg_host_unregister": (i32, [vp]),
     "gmg_fasta_ingest": (i32, [C.c_char_p, u64, C.POINTER(vp), C.POINTER(vp)]),
+    "gmg_fasta_ingest_on": (i32, [C.c_char_p, u64, C.POINTER(vp), C.POINTER(vp), vp]),
+    "gmg_fasta_split": (i32, [C.c_char_p, u64, u64, vp, i32]),
+    "gmg_mg_result_fetch_on": (i32, [vp, vp, vp, vp, vp]),
+    "gmg_stream_create": (i32, [C.POINTER(vp)]),
+    "gmg_stream_destroy": (i32, [vp]),
     "gmg_fasta_info": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
     "gmg_fasta_headers": (i32, [vp, vp, vp]),
     "gmg_fasta_free": (i32, [vp]),

@@ -657,3 +657,22 @@ extern "C" int gmg_host_unregister(void *ptr)
     GMG_HIP(hipHostUnregister(ptr));
     return GMG_OK;
 }
+
+// Streams for callers that overlap the stages of a pipeline (ingest of the next piece of a file, scoring, copying the
+// previous results back) without a HIP binding of their own.  Non-blocking: no implicit ordering with the null stream.
+extern "C" int gmg_stream_create(void **stream)
+{
+    int rc = require_init("gmg_stream_create");
+    if (rc) return rc;
+    if (!stream) return gmg_set_error(GMG_EINVAL, "gmg_stream_create: NULL argument");
+    hipStream_t s;
+    GMG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return GMG_OK;
+}
+
+extern "C" int gmg_stream_destroy(void *stream)
+{
+    if (stream) GMG_HIP(hipStreamDestroy((hipStream_t)stream));
+    return GMG_OK;
+}

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void k_fa_fill(uint64_t *p, uint64_t n, uint64
 
 struct DevFree {                                       // temporaries, from the library's cache of device blocks
     std::vector<void *> v;
-    ~DevFree() { (void)hipDeviceSynchronize(); for (void *p : v) gmg_pool_release(p); }
+    hipStream_t st = nullptr;
+    ~DevFree() { (void)hipStreamSynchronize(st); for (void *p : v) gmg_pool_release(p); }
     template <class T> hipError_t alloc(T **p, size_t bytes) { hipError_t e = gmg_pool_alloc((void **)p, bytes); if (e == hipSuccess) v.push_back(*p); return e; }
 };
 
@@ -156,12 +157,39 @@ extern "C" int gmg_fasta_free(gmg_fasta *f)
 
 extern "C" int gmg_fasta_ingest(const char *bytes, uint64_t n_bytes, gmg_reads **out_reads, gmg_fasta **out_index)
 {
+    return gmg_fasta_ingest_on(bytes, n_bytes, out_reads, out_index, nullptr);
+}
+
+// Safe places to cut a big file into pieces for gmg_fasta_ingest: a '>' that directly follows a newline is never
+// inside a header line, so it always starts a record.  cuts[0] = 0, then the first such position at or behind every
+// multiple of chunk_bytes, at last n_bytes; returns the number of pieces (cuts has pieces + 1 entries).
+extern "C" int gmg_fasta_split(const char *bytes, uint64_t n_bytes, uint64_t chunk_bytes, uint64_t *cuts, int max_pieces)
+{
+    if ((!bytes && n_bytes) || !cuts || max_pieces < 1 || chunk_bytes == 0) return gmg_set_error(GMG_EINVAL, "gmg_fasta_split: bad argument");
+    int n = 0;
+    cuts[0] = 0;
+    uint64_t want = chunk_bytes;
+    while (want < n_bytes && n + 1 < max_pieces) {
+        uint64_t i = want;
+        while (i < n_bytes && !(bytes[i] == '>' && bytes[i - 1] == '\n')) i++;
+        if (i >= n_bytes) break;
+        if (i > cuts[n]) cuts[++n] = i;
+        want = i + chunk_bytes;
+    }
+    cuts[++n] = n_bytes;
+    return n;
+}
+
+extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_reads **out_reads, gmg_fasta **out_index, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
     if ((!bytes && n_bytes) || !out_reads || !out_index) return gmg_set_error(GMG_EINVAL, "gmg_fasta_ingest: NULL argument");
     if (n_bytes >= 0x7fffffffull) return gmg_set_error(GMG_EINVAL, "gmg_fasta_ingest: at most 2^31 - 2 bytes per call");
     gmg_fasta *idx = new (std::nothrow) gmg_fasta();
     if (!idx) return gmg_set_error(GMG_ENOMEM, "gmg_fasta_ingest: out of host memory");
     idx->n_reads = idx->total_bases = idx->gc_count = 0;
     DevFree dev;
+    dev.st = st;
     uint8_t *d_bytes = nullptr, *d_func = nullptr;
     uint64_t *d_count = nullptr, *d_off = nullptr, *d_hb = nullptr, *d_he = nullptr;
     uint32_t *d_packed = nullptr;
@@ -182,7 +210,7 @@ extern "C" int gmg_fasta_ingest(const char *bytes, uint64_t n_bytes, gmg_reads *
         FA_TRY(dev.alloc(&d_bytes, n));
         FA_TRY(dev.alloc(&d_func, n));
         FA_TRY(dev.alloc(&d_count, (n + 1) * 8));
-        FA_TRY(hipMemcpy(d_bytes, bytes, n, hipMemcpyHostToDevice));
+        FA_TRY(hipMemcpyAsync(d_bytes, bytes, n, hipMemcpyHostToDevice, st));
         // 1. the state behind every byte
         hipcub::TransformInputIterator<uint8_t, FaFuncOf, const uint8_t *> func_in(d_bytes, FaFuncOf());
         size_t tmp_bytes = 0, tmp2 = 0;
@@ -195,14 +223,15 @@ extern "C" int gmg_fasta_ingest(const char *bytes, uint64_t n_bytes, gmg_reads *
         if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
         FA_TRY(dev.alloc(&d_tmp, tmp_bytes));
         size_t tb = tmp_bytes;
-        FA_TRY(hipcub::DeviceScan::InclusiveScan(d_tmp, tb, func_in, d_func, FaCompose(), (int)n));
+        FA_TRY(hipcub::DeviceScan::InclusiveScan(d_tmp, tb, func_in, d_func, FaCompose(), (int)n, st));
         tb = tmp_bytes;
-        FA_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, count_in, d_count, (int)n));
+        FA_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, count_in, d_count, (int)n, st));
         uint64_t last_excl = 0;
         uint8_t last_func = 0, last_byte = 0, prev_func = 0;
-        FA_TRY(hipMemcpy(&last_excl, d_count + (n - 1), 8, hipMemcpyDeviceToHost));
-        FA_TRY(hipMemcpy(&last_func, d_func + (n - 1), 1, hipMemcpyDeviceToHost));
-        if (n > 1) FA_TRY(hipMemcpy(&prev_func, d_func + (n - 2), 1, hipMemcpyDeviceToHost));
+        FA_TRY(hipMemcpyAsync(&last_excl, d_count + (n - 1), 8, hipMemcpyDeviceToHost, st));
+        FA_TRY(hipMemcpyAsync(&last_func, d_func + (n - 1), 1, hipMemcpyDeviceToHost, st));
+        if (n > 1) FA_TRY(hipMemcpyAsync(&prev_func, d_func + (n - 2), 1, hipMemcpyDeviceToHost, st));
+        FA_TRY(hipStreamSynchronize(st));
         last_byte = (uint8_t)bytes[n - 1];
         const unsigned st_last = n > 1 ? (prev_func & 3u) : (unsigned)ST_PRE;
         n_reads = (last_excl >> FA_REC_SHIFT) + ((last_byte == '>' && st_last != ST_HDR) ? 1 : 0);
@@ -214,32 +243,33 @@ extern "C" int gmg_fasta_ingest(const char *bytes, uint64_t n_bytes, gmg_reads *
     // 3. pack, offsets, header extents, g/c count
     const uint64_t n_words = gmg_packed_words(total);
     FA_TRY(dev.alloc(&d_packed, (n_words + 1) * 4));
-    FA_TRY(hipMemset(d_packed, 0, (n_words + 1) * 4));
+    FA_TRY(hipMemsetAsync(d_packed, 0, (n_words + 1) * 4, st));
     FA_TRY(hipMalloc((void **)&d_off, (n_reads + 1) * 8));                   // goes to the gmg_reads
     struct OffGuard { uint64_t *&p; ~OffGuard() { if (p) (void)hipFree(p); } } off_guard = {d_off};   // until then it is ours
     hipError_t e2 = dev.alloc(&d_hb, n_reads * 8);
     if (e2 == hipSuccess) e2 = dev.alloc(&d_he, n_reads * 8);
     if (e2 == hipSuccess) e2 = dev.alloc(&d_gc, 8);
-    if (e2 == hipSuccess) e2 = hipMemset(d_gc, 0, 8);
-    if (e2 == hipSuccess) e2 = hipMemcpy(d_off + n_reads, &total, 8, hipMemcpyHostToDevice);
+    if (e2 == hipSuccess) e2 = hipMemsetAsync(d_gc, 0, 8, st);
+    if (e2 == hipSuccess) e2 = hipMemcpyAsync(d_off + n_reads, &total, 8, hipMemcpyHostToDevice, st);
     if (e2 != hipSuccess) { delete idx; return gmg_set_error(GMG_ENOMEM, "gmg_fasta_ingest: %s", hipGetErrorString(e2)); }
     if (n_reads) {
         const uint64_t blocks = (n_reads + 255) / 256;
-        hipLaunchKernelGGL(k_fa_fill, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, 0, d_he, n_reads, n_bytes);
+        hipLaunchKernelGGL(k_fa_fill, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, d_he, n_reads, n_bytes);
     }
     if (n) {
         FaPackArgs a = {d_bytes, d_func, d_count, n, d_packed, d_off, d_hb, d_he, d_gc};
         const uint64_t blocks = (n / 16 + 255) / 256 + 1;
-        hipLaunchKernelGGL(k_fa_pack, dim3((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32)), dim3(256), 0, 0, a);
+        hipLaunchKernelGGL(k_fa_pack, dim3((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32)), dim3(256), 0, st, a);
     }
     e2 = hipGetLastError();
-    if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
     idx->hdr_begin.resize(n_reads);
     idx->hdr_end.resize(n_reads);
     unsigned long long gc = 0;
-    if (e2 == hipSuccess && n_reads) e2 = hipMemcpy(idx->hdr_begin.data(), d_hb, n_reads * 8, hipMemcpyDeviceToHost);
-    if (e2 == hipSuccess && n_reads) e2 = hipMemcpy(idx->hdr_end.data(), d_he, n_reads * 8, hipMemcpyDeviceToHost);
-    if (e2 == hipSuccess) e2 = hipMemcpy(&gc, d_gc, 8, hipMemcpyDeviceToHost);
+    if (e2 == hipSuccess && n_reads) e2 = hipMemcpyAsync(idx->hdr_begin.data(), d_hb, n_reads * 8, hipMemcpyDeviceToHost, st);
+    if (e2 == hipSuccess && n_reads) e2 = hipMemcpyAsync(idx->hdr_end.data(), d_he, n_reads * 8, hipMemcpyDeviceToHost, st);
+    if (e2 == hipSuccess) e2 = hipMemcpyAsync(&gc, d_gc, 8, hipMemcpyDeviceToHost, st);
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
     if (e2 != hipSuccess) { delete idx; return gmg_set_error(GMG_EHIP, "gmg_fasta_ingest: %s", hipGetErrorString(e2)); }
     // Fasta_Read: the blanks behind '>' are not part of the header; a record that is only "> <blanks> EOF" does not exist
     for (uint64_t r = 0; r < n_reads; r++) {

@@ -871,9 +871,17 @@ extern "C" int gmg_mg_result_info(const gmg_mg_result *r, uint64_t *n_orfs, uint
 
 extern "C" int gmg_mg_result_fetch(const gmg_mg_result *r, gmg_mg_orf *orfs, gmg_start *starts, uint64_t *read_orf_off)
 {
+    return gmg_mg_result_fetch_on(r, orfs, starts, read_orf_off, nullptr);
+}
+
+extern "C" int gmg_mg_result_fetch_on(const gmg_mg_result *r, gmg_mg_orf *orfs, gmg_start *starts, uint64_t *read_orf_off,
+                                      void *stream)
+{
     if (!r || (r->n_orfs && !orfs) || (r->n_starts && !starts)) return gmg_set_error(GMG_EINVAL, "gmg_mg_result_fetch: NULL argument");
-    if (r->n_orfs) GMG_HIP(hipMemcpy(orfs, r->d_orfs, r->n_orfs * sizeof(gmg_mg_orf), hipMemcpyDeviceToHost));
-    if (r->n_starts) GMG_HIP(hipMemcpy(starts, r->d_starts, r->n_starts * sizeof(gmg_start), hipMemcpyDeviceToHost));
-    if (read_orf_off) GMG_HIP(hipMemcpy(read_orf_off, r->d_read_orf_off, (r->n_reads + 1) * 8, hipMemcpyDeviceToHost));
+    hipStream_t s = (hipStream_t)stream;
+    if (r->n_orfs) GMG_HIP(hipMemcpyAsync(orfs, r->d_orfs, r->n_orfs * sizeof(gmg_mg_orf), hipMemcpyDeviceToHost, s));
+    if (r->n_starts) GMG_HIP(hipMemcpyAsync(starts, r->d_starts, r->n_starts * sizeof(gmg_start), hipMemcpyDeviceToHost, s));
+    if (read_orf_off) GMG_HIP(hipMemcpyAsync(read_orf_off, r->d_read_orf_off, (r->n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
+    GMG_HIP(hipStreamSynchronize(s));
     return GMG_OK;
 }

@@ -297,6 +297,9 @@ int gmg_mg_result_info(const gmg_mg_result *r, uint64_t *n_orfs, uint64_t *n_sta
 /* Copies the result to HOST buffers: orfs[n_orfs], starts[n_starts] and, if not NULL,
  * read_orf_off[n_reads + 1] (ORFs of read i are orfs[read_orf_off[i] .. read_orf_off[i+1])). */
 int gmg_mg_result_fetch(const gmg_mg_result *r, gmg_mg_orf *orfs, gmg_start *starts, uint64_t *read_orf_off);
+/* the same copies on `stream` (they then overlap the scoring of the next batch on another stream) */
+int gmg_mg_result_fetch_on(const gmg_mg_result *r, gmg_mg_orf *orfs, gmg_start *starts, uint64_t *read_orf_off,
+                           void *stream);
 int gmg_mg_result_free(gmg_mg_result *r);
 /* gmg_mg_* keeps released device buffers for the next call (allocation of GB-sized buffers is slow);
  * this returns the idle ones to the driver. */
@@ -312,6 +315,12 @@ int gmg_trim_cache(void);
  * *index keeps the counts and, per read, the extent of its header line in `bytes`. */
 typedef struct gmg_fasta gmg_fasta;
 int gmg_fasta_ingest(const char *bytes, uint64_t n_bytes, gmg_reads **reads, gmg_fasta **index);
+/* the same, with every copy and kernel on `stream` (a pipeline ingests piece i+1 while piece i is scored) */
+int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_reads **reads, gmg_fasta **index, void *stream);
+/* Places where a big file can be cut into pieces of about chunk_bytes for separate gmg_fasta_ingest calls: a '>' that
+ * directly follows a newline always starts a record.  cuts[0] = 0 ... cuts[pieces] = n_bytes; returns the number of pieces
+ * (at most max_pieces; cuts needs max_pieces + 1 entries). */
+int gmg_fasta_split(const char *bytes, uint64_t n_bytes, uint64_t chunk_bytes, uint64_t *cuts, int max_pieces);
 /* n_reads, bases of all reads, and how many of them are g or c after filtering (Indep_GC_Frac = gc / total) */
 int gmg_fasta_info(const gmg_fasta *index, uint64_t *n_reads, uint64_t *total_bases, uint64_t *gc_count);
 /* hdr string of read i = bytes[hdr_begin[i] .. hdr_end[i])  (HOST arrays of n_reads entries) */
@@ -327,6 +336,9 @@ int gmg_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *stream);
  * makes from / to it run at PCIe speed. */
 int gmg_host_register(void *ptr, size_t bytes);
 int gmg_host_unregister(void *ptr);
+/* Non-blocking streams for callers without a HIP binding of their own (every `void *stream` parameter takes one). */
+int gmg_stream_create(void **stream);
+int gmg_stream_destroy(void *stream);
 
 #ifdef __cplusplus
 }

@@ -115,3 +115,18 @@ def test_no_gpu_means_loud_failure_not_fallback(gmg):
         gmg.Reads.from_strings(["acgt"])
     with pytest.raises(gmg.GmgError):
         gmg.Icm.open(os.path.join(DATA, "cluster-4.icm")).device()
+
+
+def test_fasta_split_cuts_only_where_a_record_starts(gmg):
+    """gmg_fasta_split is host code: every cut is a '>' directly behind a newline, the pieces tile the file"""
+    import ctypes as C
+    import numpy as np
+    lib = gmg.capi.lib()
+    data = b"junk\n" + b"".join(b">r%d has > inside\nACGT>mid%d\nAC\nGT\n\n" % (i, i) for i in range(200))
+    cuts = np.zeros(64, np.uint64)
+    n = lib.gmg_fasta_split(data, len(data), 700, cuts.ctypes.data_as(C.c_void_p), 63)
+    assert 5 < n <= 63 and cuts[0] == 0 and cuts[n] == len(data)
+    for c in cuts[1:n]:
+        assert data[int(c) - 1:int(c) + 1] == b"\n>"
+    assert np.all(np.diff(cuts[:n + 1].astype(np.int64)) > 0)
+    assert lib.gmg_fasta_split(data, len(data), 10**9, cuts.ctypes.data_as(C.c_void_p), 63) == 1 and cuts[1] == len(data)
