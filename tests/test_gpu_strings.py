@@ -66,3 +66,14 @@ def test_strings_full_size_slice_properties(gpu, oracle):
             assert a[k, r, 0] == alone[k, j, 0] == oracle.score_string(m, s, 0)
             assert a[k, r, 1] == alone[k, j, 1] == oracle.score_string(m, revcomp(s), 0)
             assert (alone[k, len(strs) + j, 0], alone[k, len(strs) + j, 1]) == (a[k, r, 1], a[k, r, 0])
+
+
+def test_strings_edge_batches(gpu, oracle):
+    m = gpu.Icm.open(os.path.join(DATA, "cluster-2.icm"))
+    om = oracle.read(os.path.join(DATA, "cluster-2.icm"))
+    assert gpu.score_reads_strings([], gpu.Reads.from_strings(["acgt"])).shape == (0, 1, 2)
+    seqs = ["a", "ac", "acgtacgtacg", "acgtacgtacgt", "t" * 2047, "g" * 2048, "c" * 2049]      # around the window and the chunk size
+    got = gpu.score_reads_strings([m, m], gpu.Reads.from_strings(seqs))
+    for r, s in enumerate(seqs):
+        assert got[0, r, 0] == got[1, r, 0] == oracle.score_string(om, s, 0)
+        assert got[0, r, 1] == got[1, r, 1] == oracle.score_string(om, revcomp(s), 0)
