@@ -11,7 +11,7 @@
 // base, so the goal is: every table access on-chip, every store a full line, and as few vector
 // instructions per base as possible (profiles/r01_v5_*: the kernel is VALU-issue bound).
 //
-// Three launches per call, stream-ordered:
+// Two launches per call, stream-ordered (the tail rides in the partial-window launch as extra blocks):
 //   k_frame6t   main pass (LDS table swapping, below).  Treats the whole batch as ONE stream of bases and
 //               scores every base with the full-window rule: no read boundaries, no branches.  Bases
 //               whose window leaves their read (the first W-1 bases of either scoring buffer of each
@@ -33,6 +33,7 @@ struct Frame6Args {
     const uint32_t *tile_read;
     uint64_t total, n_reads;
     uint64_t first, count;  // k_frame6_generic: range of bases to score
+    uint32_t p_blocks;      // k_frame6p: blocks [0, p_blocks) do partial windows, the rest the tail [first, first+count)
     double *out;            // [6][total] gene - null (the Frame_Scores table)
     float *out_gene;        // gene-only mode (gmg_launch_gene6): [6][total] gene values as fp32
 };
@@ -268,6 +269,33 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
 // completed tree reads "shift byte < 2*((W-1)-j)"; crow holds the right row for inner nodes too.
 // ---------------------------------------------------------------------------
 
+// Exact plain descent on the original tables for both models: bases [a.first, a.first + a.count), lane i0 of every n_lanes.
+__device__ __forceinline__ void f6_generic_range(const Frame6Args &a, uint64_t i0, uint64_t n_lanes)
+{
+    for (uint64_t i = i0; i < a.count; i += n_lanes) {
+        const uint64_t g = a.first + i;
+        uint64_t r = a.tile_read[g / GMG_TILE];
+        uint64_t r_end = a.off[r + 1];
+        while (g >= r_end) { r++; r_end = a.off[r + 1]; }
+        const uint64_t r_off = a.off[r];
+        const int L = (int)(r_end - r_off);
+        const int p = (int)(g - r_off);
+        DevBuf bf = dev_make_buf(a.packed, r_off, 0, (uint32_t)L, GMG_REVERSED);
+        DevBuf br = dev_make_buf(a.packed, r_off, 0, (uint32_t)L, GMG_COMPLEMENTED);
+        for (int f = 0; f < 3; f++) {
+            if (a.out_gene) {
+                a.out_gene[(uint64_t)f * a.total + g] = dev_score(a.gene, bf, L - 1 - p, f);
+                a.out_gene[(uint64_t)(3 + f) * a.total + g] = dev_score(a.gene, br, p, f);
+                continue;
+            }
+            a.out[(uint64_t)f * a.total + g] =
+                (double)dev_score(a.gene, bf, L - 1 - p, f) - (double)dev_score(a.nul, bf, L - 1 - p, f);
+            a.out[(uint64_t)(3 + f) * a.total + g] =
+                (double)dev_score(a.gene, br, p, f) - (double)dev_score(a.nul, br, p, f);
+        }
+    }
+}
+
 // 32 lanes per read (z = lane & 31 < 2(W-1) <= 28 active): no division, read offsets broadcast.
 // The kernel is a chain of dependent latencies (offsets -> packed words -> D LDS steps -> row gather ->
 // store), so every lane keeps U reads in flight (U x 3 interleaved descents).
@@ -276,6 +304,12 @@ template <int DT, int U>
 __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_shift[];   // [3][cstride] completed-tree shifts
+    if (blockIdx.x >= a.p_blocks) {
+        // the last < 2,048 bases of the batch (the main pass does whole chunks), in the same launch.  The partial-window
+        // positions in there are written by both kinds of blocks, with identical bits.
+        f6_generic_range(a, (uint64_t)(blockIdx.x - a.p_blocks) * blockDim.x + threadIdx.x, (uint64_t)(gridDim.x - a.p_blocks) * blockDim.x);
+        return;
+    }
     const int cstride = a.gene.cstride;
     for (int i = threadIdx.x * 16; i < 3 * cstride; i += 256 * 16)
         *(uint4 *)(s_shift + i) = *(const uint4 *)(a.gene.cshift + i);
@@ -290,7 +324,7 @@ __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
     const bool rev_buf = z >= (uint32_t)(W - 1);                    // reversed buffer -> rows f
     const int j = rev_buf ? (int)z - (W - 1) : (int)z;              // position in the scoring buffer
     const int thr2 = 2 * ((W - 1) - j);                             // > 0: j < W-1
-    const uint64_t reads_per_pass = (uint64_t)gridDim.x * (256 / 32);
+    const uint64_t reads_per_pass = (uint64_t)a.p_blocks * (256 / 32);
 
     // null-model slot of this lane's buffer position (same for every read)
     const float *ntab = (j >= Wn - 1) ? a.nul.dense : a.nul.dense_part;
@@ -368,29 +402,7 @@ __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_frame6_generic(Frame6Args a)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.count;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t g = a.first + i;
-        uint64_t r = a.tile_read[g / GMG_TILE];
-        uint64_t r_end = a.off[r + 1];
-        while (g >= r_end) { r++; r_end = a.off[r + 1]; }
-        const uint64_t r_off = a.off[r];
-        const int L = (int)(r_end - r_off);
-        const int p = (int)(g - r_off);
-        DevBuf bf = dev_make_buf(a.packed, r_off, 0, (uint32_t)L, GMG_REVERSED);
-        DevBuf br = dev_make_buf(a.packed, r_off, 0, (uint32_t)L, GMG_COMPLEMENTED);
-        for (int f = 0; f < 3; f++) {
-            if (a.out_gene) {
-                a.out_gene[(uint64_t)f * a.total + g] = dev_score(a.gene, bf, L - 1 - p, f);
-                a.out_gene[(uint64_t)(3 + f) * a.total + g] = dev_score(a.gene, br, p, f);
-                continue;
-            }
-            a.out[(uint64_t)f * a.total + g] =
-                (double)dev_score(a.gene, bf, L - 1 - p, f) - (double)dev_score(a.nul, bf, L - 1 - p, f);
-            a.out[(uint64_t)(3 + f) * a.total + g] =
-                (double)dev_score(a.gene, br, p, f) - (double)dev_score(a.nul, br, p, f);
-        }
-    }
+    f6_generic_range(a, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
 }
 
 static int launch_generic(Frame6Args a, uint64_t first, uint64_t count, hipStream_t s)
@@ -457,15 +469,16 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
 #undef GMG_LAUNCH_F6T
         GMG_HIP(hipGetLastError());
     }
-    // the last, partial chunk
-    int rc = launch_generic(a, n_chunks * SPAN, a.total - n_chunks * SPAN, s);
-    if (rc) return rc;
-    // partial windows of every read
+    // partial windows of every read + the last, partial chunk: one launch
     if (a.n_reads > 0) {
         const uint64_t blocks = (a.n_reads + 7) / 8;                // 8 reads (32 lanes each) per block
         const unsigned grid = (unsigned)(blocks < 256 * 8 ? blocks : 256 * 8);
         const size_t lds_p = (size_t)3 * a.gene.cstride;
-        hipLaunchKernelGGL((k_frame6p<7, 4>), dim3(grid), dim3(256), lds_p, s, a);
+        a.first = n_chunks * SPAN;
+        a.count = a.total - n_chunks * SPAN;
+        a.p_blocks = grid;
+        const unsigned tail_blocks = (unsigned)((a.count + 255) / 256);
+        hipLaunchKernelGGL((k_frame6p<7, 4>), dim3(grid + tail_blocks), dim3(256), lds_p, s, a);
         GMG_HIP(hipGetLastError());
     }
     return GMG_OK;
