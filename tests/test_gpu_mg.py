@@ -171,3 +171,26 @@ def test_mg_full_size_properties(gpu, oracle, nc):
             assert [(s["j"], s["pos"], s["which"], s["truncated"], s["first"], s["score"]) for s in st] == \
                    [(w.j, w.pos, w.which, w.truncated, w.first, w.score) for w in want]
             assert (o["first_j"], bool(o["accepted"]), o["best_score"]) == (out.first_j, bool(out.accepted), out.best_score)
+
+
+@pytest.mark.parametrize("L", [7, 60, 100, 150, 512, 513, 1504, 1505])
+def test_mg_uniform_read_lengths_exercise_every_tile_shape(gpu, oracle, nc, L):
+    """uniform batches take whole reads per tile (several short reads per tile, one 512-bp read, 1,504-base tiles, and the
+    per-lane kernel beyond that); every start score must still equal the oracle's"""
+    rng = np.random.default_rng(L)
+    n = 300 if L < 600 else 60
+    seqs = ["".join("acgt"[c] for c in rng.integers(0, 4, size=L)) for _ in range(n)]
+    kw = dict(min_gene_len=30 if L >= 30 else 4)
+    orfs, starts, off = gpu.mg_score_reads(nc, gpu.Icm.indep(0.5), gpu.Reads.from_strings(seqs), **kw)
+    o_nc, o_indep, prm = oracle.read(os.path.join(DATA, "NC_000915.icm")), oracle.indep(0.5), oracle.mg_params(**kw)
+    n_starts = 0
+    for r in range(0, n, 7):
+        want_orfs, scored = oracle.mg_read(o_nc, o_indep, seqs[r].encode(), prm)
+        mine = orfs[int(off[r]):int(off[r + 1])]
+        assert np.array_equal(np.stack([mine["frame"], mine["stop_position"], mine["gene_len"], mine["orf_len"]], 1).reshape(-1, 4), want_orfs)
+        for o, (out, want) in zip(mine, scored):
+            st = starts[o["start_begin"]:o["start_begin"] + o["n_starts"]]
+            assert [(s["j"], s["pos"], s["which"], s["score"]) for s in st] == [(w.j, w.pos, w.which, w.score) for w in want]
+            assert o["best_score"] == out.best_score and bool(o["accepted"]) == bool(out.accepted)
+            n_starts += len(want)
+    assert n_starts > 0 or L < 30
