@@ -348,6 +348,27 @@ MG_ORF_DTYPE = np.dtype([("read", "<u4"), ("frame", "<i4"), ("stop_position", "<
                          ("orf_is_truncated", "<i2"), ("reserved", "<i4"), ("best_score", "<f8")])
 
 
+def find_orfs(reads, min_gene_len=75, allow_truncated=False, start_codons=("atg", "gtg", "ttg"),
+              stop_codons=("taa", "tag", "tga")):
+    """gmg_find_orfs: Find_Orfs for every read -> (orfs[MG_ORF_DTYPE], read_orf_off[uint64 n_reads+1])"""
+    prm = capi.MgParams(min_gene_len, int(allow_truncated), 2**31 - 1, len(start_codons), len(stop_codons), 0, 0.0)
+    for i, c in enumerate(start_codons):
+        prm.start_codon[i].value = c.encode()
+    for i, c in enumerate(stop_codons):
+        prm.stop_codon[i].value = c.encode()
+    res = C.c_void_p()
+    _ck(capi.lib().gmg_find_orfs(reads.h, C.byref(prm), C.byref(res), None))
+    try:
+        n_orfs, n_starts = C.c_uint64(), C.c_uint64()
+        _ck(capi.lib().gmg_mg_result_info(res, C.byref(n_orfs), C.byref(n_starts)))
+        orfs = np.zeros(max(n_orfs.value, 1), MG_ORF_DTYPE)
+        off = np.zeros(reads.n_reads + 1, np.uint64)
+        _ck(capi.lib().gmg_mg_result_fetch(res, _ptr(orfs), None, _ptr(off)))
+    finally:
+        capi.lib().gmg_mg_result_free(res)
+    return orfs[:n_orfs.value], off
+
+
 def mg_score_reads(gene, null, reads, min_gene_len=75, allow_truncated=True, ignore_score_len=2**31 - 1,
                    start_threshold=-6.0, start_codons=("atg", "gtg", "ttg"), stop_codons=("taa", "tag", "tga"),
                    frame_scores=None):

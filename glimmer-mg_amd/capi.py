@@ -57,6 +57,7 @@ PROTOTYPES = {
     "gmg_all_frame_score": (i32, [vp, vp, vp, vp, vp, vp, vp]),
     "gmg_window_distrib": (i32, [vp, vp, vp, u64, vp, vp, vp]),
     "gmg_mg_score_reads": (i32, [vp, vp, vp, vp, vp, C.POINTER(vp), vp]),
+    "gmg_find_orfs": (i32, [vp, vp, C.POINTER(vp), vp]),
     "gmg_mg_result_info": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
     "gmg_mg_result_fetch": (i32, [vp, vp, vp, vp]),
     "gmg_mg_result_free": (i32, [vp]),

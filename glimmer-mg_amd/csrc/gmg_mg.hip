@@ -685,14 +685,14 @@ struct MgTimer {
     }
 };
 
-extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads,
-                                  const gmg_mg_params *prm, double *d_frame_scores, gmg_mg_result **out, void *stream)
+static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, const gmg_mg_params *prm,
+                  double *d_frame_scores, gmg_mg_result **out, void *stream, const bool find_only)
 {
-    if (!gene || !nul || !reads || !prm || !out) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: NULL argument");
+    if ((!find_only && (!gene || !nul)) || !reads || !prm || !out) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: NULL argument");
     if (prm->n_start_codons < 0 || prm->n_start_codons > 8 || prm->n_stop_codons < 0 || prm->n_stop_codons > 8 ||
         prm->min_gene_len < 4)
         return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: need 0..8 start / stop codons and min_gene_len >= 4");
-    if (gene->dev.P != 3 || nul->dev.P != 3)
+    if (!find_only && (gene->dev.P != 3 || nul->dev.P != 3))
         return gmg_set_error(GMG_EBADMODEL, "gmg_mg_score_reads: Score_All_Frames needs models of periodicity 3");
     if (reads->n_reads >= 0x7fffffffull) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large");
     hipStream_t s = (hipStream_t)stream;
@@ -759,6 +759,7 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
 
     MgTimer tm(s);
     // 1. Frame_Scores
+    if (!find_only) {
     if (!d_frame_scores && a.total) {
         MG_TRY(gmg_pool_alloc((void **)&d_fs_own, (size_t)6 * a.total * sizeof(double)));
         d_frame_scores = d_fs_own;
@@ -813,6 +814,7 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
         }
     }
     tm.lap("running sums");
+    }
     // 2. ORFs of every read
     const uint64_t nr = a.n_reads;
     MG_TRY(gmg_pool_alloc((void **)&d_read_cnt, (nr + 1) * 4));
@@ -834,6 +836,7 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
 
     tm.lap("find orfs");
     // 3. start lists
+    if (!find_only) {
     MG_TRY(gmg_pool_alloc((void **)&d_orf_cnt, (no + 1) * 4));
     MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s));
     MG_TRY(gmg_pool_alloc((void **)&d_start_off, (no + 1) * 8));
@@ -848,17 +851,29 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
     a.starts = res->d_starts;
     if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
+    }
     MG_TRY(hipStreamSynchronize(s));
     tm.lap("start lists");
 #undef MG_TRY
     if (d_fs_own) gmg_pool_release(d_fs_own);
     gmg_pool_release(d_read_cnt);
-    gmg_pool_release(d_orf_cnt);
-    gmg_pool_release(d_start_off);
-    gmg_pool_release(d_cum);
+    if (d_orf_cnt) gmg_pool_release(d_orf_cnt);
+    if (d_start_off) gmg_pool_release(d_start_off);
+    if (d_cum) gmg_pool_release(d_cum);
     tm.lap("free scratch");
     *out = res;
     return GMG_OK;
+}
+
+extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads,
+                                  const gmg_mg_params *prm, double *d_frame_scores, gmg_mg_result **out, void *stream)
+{
+    return mg_run(gene, nul, reads, prm, d_frame_scores, out, stream, false);
+}
+
+extern "C" int gmg_find_orfs(const gmg_reads *reads, const gmg_mg_params *prm, gmg_mg_result **out, void *stream)
+{
+    return mg_run(nullptr, nullptr, reads, prm, nullptr, out, stream, true);
 }
 
 extern "C" int gmg_mg_result_info(const gmg_mg_result *r, uint64_t *n_orfs, uint64_t *n_starts)

@@ -292,6 +292,11 @@ typedef struct gmg_mg_result gmg_mg_result;
 int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *null_model, const gmg_reads *reads,
                        const gmg_mg_params *params, double *d_frame_scores, gmg_mg_result **out,
                        void *stream);
+/* Find_Orfs alone (src/Glimmer/glimmer_base.cc:638-779; linear sequences, no ignore regions) for every read of the
+ * batch -- the ORF list glimmer3's Score_Orfs / gmg_score_orfs and glimmer-mg's Score_Orfs_Errors start from.  Uses
+ * min_gene_len, allow_truncated and the codon lists of `params`; the result holds the Orf_t fields (and lo / hi), no
+ * start lists (n_starts = 0). */
+int gmg_find_orfs(const gmg_reads *reads, const gmg_mg_params *params, gmg_mg_result **out, void *stream);
 /* Sizes of the result: ORFs of all reads (Find_Orfs order, read by read) and start entries. */
 int gmg_mg_result_info(const gmg_mg_result *r, uint64_t *n_orfs, uint64_t *n_starts);
 /* Copies the result to HOST buffers: orfs[n_orfs], starts[n_starts] and, if not NULL,

@@ -12,8 +12,9 @@
 //        G <orf index> <gene_score %.17g> <gene_len> <n_starts>   every ORF Score_Orfs accepted
 //        S <j> <pos> <score %a> <which> <truncated> <first>  its start list as handed to Add_Events_*
 //   ref_orfs batch <glimmer3 options...> <fasta> <tag>     (built with -DGMG_BATCH, links libgmg.so)
-//        same pipeline as glimmer3's main, but Score_Orfs is replaced by ONE gmg_score_orfs call over
-//        the ORFs of all reads; writes <tag>.predict, which must equal the reference's byte for byte.
+//        same pipeline as glimmer3's main, but the input is parsed on the device (gmg_fasta_ingest), Find_Orfs of all
+//        reads is ONE gmg_find_orfs call and Score_Orfs ONE gmg_score_orfs call; events, DP and trace-back stay the
+//        reference's host code; writes <tag>.predict, which must equal the reference's byte for byte.
 
 #define main glimmer3_reference_main
 #include "glimmer3.cc"
@@ -50,13 +51,17 @@ void wrap_Add_Events_Rev(const Orf_t &orf, vector<Start_t> &sl, int &id)
 }
 
 // ---- the set-up steps of glimmer3's main (glimmer3.cc:175-223), in the same order ---------------------
-static void setup(int argc, char **argv)
+static void setup_options(int argc, char **argv)
 {
     Verbose = 0;
     Parse_Command_Line(argc, argv);
     Set_Start_And_Stop_Codons();
     Prob_To_Logs(Start_Prob);
     if (Feature_File != NULL) Parse_Features(Feature_File);
+}
+
+static void setup_models(void)
+{
     if (!GC_Frac_Set) Set_GC_Fraction();
     Indep_Model.Build_Indep_WO_Stops(Indep_GC_Frac, Stop_Codon);
     Set_Ignore_Score_Len();
@@ -78,15 +83,16 @@ int main(int argc, char **argv)
     if (argc < 4) { fprintf(stderr, "usage: ref_orfs dump|batch <glimmer3 args>\n"); return 2; }
     string mode = argv[1];
     try {
-        setup(argc - 1, argv + 1);
+        setup_options(argc - 1, argv + 1);
         vector<string> seq_list, hdr_list;
-        FILE *fp = File_Open(Sequence_File_Name, "r", __FILE__, __LINE__);
-        Read_Sequences(fp, seq_list, hdr_list, Sequence_Ct);
-        fclose(fp);
         vector<Orf_t> orf_list;
         vector<Gene_t> gene_list;
 
         if (mode == "dump") {
+            setup_models();
+            FILE *fp = File_Open(Sequence_File_Name, "r", __FILE__, __LINE__);
+            Read_Sequences(fp, seq_list, hdr_list, Sequence_Ct);
+            fclose(fp);
             for (int i = 0; i < Sequence_Ct; i++) {
                 load_sequence(seq_list, hdr_list, i);
                 Initialize_Terminal_Events(First_Event, Final_Event, Best_Event, Last_Event);
@@ -119,29 +125,72 @@ int main(int argc, char **argv)
         }
 #ifdef GMG_BATCH
         if (mode == "batch") {
-            // pass 1: ORFs of every read (host, unchanged reference code)
-            vector<vector<Orf_t> > all_orfs(Sequence_Ct);
-            vector<uint64_t> off(Sequence_Ct + 1, 0);
-            for (int i = 0; i < Sequence_Ct; i++) {
-                load_sequence(seq_list, hdr_list, i);
-                Find_Orfs(all_orfs[i]);
-                off[i + 1] = off[i] + Sequence_Len;
-            }
-            // ONE batch call for the Score_Orfs inner loops of all reads
+            // pass 1, on the device: the file's bytes are parsed there (gmg_fasta_ingest = Fasta_Read + tolower (Filter ()) +
+            // packing + the g/c count of Set_GC_Fraction) and Find_Orfs runs for every read at once (gmg_find_orfs)
             const char *dev = getenv("GMG_DEVICE");
             if (gmg_init(dev ? atoi(dev) : 0) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
-            vector<uint32_t> packed(gmg_packed_words(off[Sequence_Ct]), 0);
-            for (int i = 0; i < Sequence_Ct; i++)
-                gmg_pack_bases(seq_list[i].data(), seq_list[i].length(), off[i], packed.data());
+            string file_bytes;
+            {
+                FILE *fp = File_Open(Sequence_File_Name, "rb", __FILE__, __LINE__);
+                char buf[1 << 16];
+                size_t got;
+                while ((got = fread(buf, 1, sizeof buf, fp)) > 0) file_bytes.append(buf, got);
+                fclose(fp);
+            }
             gmg_reads *reads = NULL;
-            if (gmg_reads_upload(packed.data(), off.data(), Sequence_Ct, &reads) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+            gmg_fasta *fasta = NULL;
+            if (gmg_fasta_ingest(file_bytes.data(), file_bytes.size(), &reads, &fasta) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+            uint64_t n_ing = 0, total_bases = 0, gc_ct = 0;
+            gmg_fasta_info(fasta, &n_ing, &total_bases, &gc_ct);
+            Sequence_Ct = (int)n_ing;
+            if (!GC_Frac_Set) {                         // Set_GC_Fraction (glimmer_base.cc:2564-2595) without reading the file again
+                Indep_GC_Frac = double(gc_ct) / total_bases;
+                GC_Frac_Set = true;
+            }
+            setup_models();
+            vector<uint64_t> hb(n_ing), he(n_ing), off(n_ing + 1);
+            gmg_fasta_headers(fasta, hb.data(), he.data());
+            vector<uint32_t> packed(gmg_packed_words(total_bases) + 1, 0);
+            gmg_reads_download(reads, packed.data(), off.data());
+            gmg_fasta_free(fasta);
+            seq_list.resize(Sequence_Ct);
+            hdr_list.resize(Sequence_Ct);
+            for (int i = 0; i < Sequence_Ct; i++) {     // the event / DP code reads the global Sequence: filtered bases back from the device
+                hdr_list[i] = file_bytes.substr(hb[i], he[i] - hb[i]);
+                string &sq = seq_list[i];
+                sq.resize(off[i + 1] - off[i]);
+                for (uint64_t k = 0; k < sq.size(); k++) { const uint64_t g = off[i] + k; sq[k] = "acgt"[(packed[g >> 4] >> (2 * (g & 15))) & 3]; }
+            }
+            gmg_mg_params fprm;
+            memset(&fprm, 0, sizeof fprm);
+            fprm.min_gene_len = Min_Gene_Len;
+            fprm.allow_truncated = Allow_Truncated_Orfs;
+            fprm.n_start_codons = Start_Codon.size();
+            fprm.n_stop_codons = Stop_Codon.size();
+            for (size_t c = 0; c < Start_Codon.size() && c < 8; c++) memcpy(fprm.start_codon[c], Start_Codon[c], 3);
+            for (size_t c = 0; c < Stop_Codon.size() && c < 8; c++) memcpy(fprm.stop_codon[c], Stop_Codon[c], 3);
+            gmg_mg_result *found = NULL;
+            if (gmg_find_orfs(reads, &fprm, &found, NULL) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+            uint64_t n_found = 0;
+            gmg_mg_result_info(found, &n_found, NULL);
+            vector<gmg_mg_orf> frec(n_found ? n_found : 1);
+            vector<uint64_t> first(Sequence_Ct + 1);
+            if (gmg_mg_result_fetch(found, frec.data(), NULL, first.data()) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+            gmg_mg_result_free(found);
+            vector<vector<Orf_t> > all_orfs(Sequence_Ct);
             vector<gmg_orf> orfs;
             for (int i = 0; i < Sequence_Ct; i++)
-                for (size_t o = 0; o < all_orfs[i].size(); o++) {
-                    gmg_orf g = {(uint32_t)i, all_orfs[i][o].Get_Frame(), all_orfs[i][o].Get_Stop_Position(),
-                                 all_orfs[i][o].Get_Orf_Len()};
+                for (uint64_t o = first[i]; o < first[i + 1]; o++) {
+                    Orf_t orf;
+                    orf.Set_Stop_Position(frec[o].stop_position);
+                    orf.Set_Frame(frec[o].frame);
+                    orf.Set_Gene_Len(frec[o].gene_len);
+                    orf.Set_Orf_Len(frec[o].orf_len);
+                    all_orfs[i].push_back(orf);
+                    gmg_orf g = {(uint32_t)i, frec[o].frame, frec[o].stop_position, frec[o].orf_len};
                     orfs.push_back(g);
                 }
+            // ONE batch call for the Score_Orfs inner loops of all reads
             gmg_orf_params prm;
             memset(&prm, 0, sizeof prm);
             prm.min_gene_len = Min_Gene_Len;

@@ -194,3 +194,14 @@ def test_mg_uniform_read_lengths_exercise_every_tile_shape(gpu, oracle, nc, L):
             assert o["best_score"] == out.best_score and bool(o["accepted"]) == bool(out.accepted)
             n_starts += len(want)
     assert n_starts > 0 or L < 30
+
+
+@pytest.mark.parametrize("name,trunc", [("orfs_default", False), ("orfs_X", True)])
+def test_find_orfs_alone_matches_glimmer3_goldens(gpu, seqs_fa, name, trunc):
+    """gmg_find_orfs against the ORF lists the reference's own Find_Orfs produced inside glimmer3 (tests/golden/orfs_*.npz)"""
+    g = np.load(os.path.join(GOLD, name + ".npz"))["orfs"]          # read, frame, stop_position, orf_len
+    orfs, off = gpu.find_orfs(gpu.Reads.from_strings(seqs_fa[1]), min_gene_len=75, allow_truncated=trunc)
+    got = np.stack([orfs["read"].astype(np.int32), orfs["frame"], orfs["stop_position"], orfs["orf_len"]], 1)
+    assert np.array_equal(got, g)
+    assert np.array_equal(off, np.searchsorted(g[:, 0], np.arange(len(seqs_fa[1]) + 1)))
+    assert np.all(orfs["n_starts"] == 0)

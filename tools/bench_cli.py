@@ -40,6 +40,8 @@ with tempfile.TemporaryDirectory() as tmp:
             raise SystemExit(res.stderr.decode()[-2000:])
         return dt, hashlib.md5(open(os.path.join(tmp, tag + ".predict"), "rb").read()).hexdigest()
 
+    t3_ref, md5_3ref = run([os.path.join(REF, "glimmer3"), "-m", ICM], "g3ref")
+    t3_dev, md5_3dev = min(run([os.path.join(REF, "glimmer3_batch"), "batch", "-m", ICM], "g3dev%d" % i) for i in range(2))
     t_ref, md5_ref = run([os.path.join(REF, "glimmer-mg"), "-m", ICM], "ref")
     t_dev, md5_dev = run([os.path.join(REF, "glimmer-mg_batch"), "batch", "-m", ICM], "dev")
     t_dev2, md5_dev2 = run([os.path.join(REF, "glimmer-mg_batch"), "batch", "-m", ICM], "dev2")
@@ -49,5 +51,7 @@ print(json.dumps({"reads": n_reads, "bases": n_reads * L, "genes_predicted": gen
                   "reference_cli_s": round(t_ref, 3), "reference_cli_mbases_per_s": round(n_reads * L / t_ref / 1e6, 3),
                   "device_front_half_cli_s": round(min(t_dev, t_dev2), 3),
                   "device_front_half_cli_mbases_per_s": round(n_reads * L / min(t_dev, t_dev2) / 1e6, 3),
+                  "glimmer3_predict_identical": md5_3ref == md5_3dev, "glimmer3_reference_cli_s": round(t3_ref, 3),
+                  "glimmer3_device_front_half_cli_s": round(t3_dev, 3),
                   "note": "process start to exit, one host thread each; the device run includes HIP start-up (~1 s), and "
                           "its events / DP / trace-back are the reference's own host code"}))
