@@ -1,4 +1,5 @@
 """Build lib/libgmg.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+import fcntl
 import os
 import shutil
 import subprocess
@@ -24,11 +25,24 @@ def build_lib(force=False, verbose=False):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc, *FLAGS, "-o", LIB, *SOURCES]
-    res = subprocess.run(cmd, cwd=PKG, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if verbose or res.returncode != 0:
-        print(" ".join(cmd))
-        print(res.stdout)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed building libgmg.so")
+    # several ranks of one job may get here at once (bench.py under torch.distributed.run): one of them builds, into a
+    # temporary file that replaces the library atomically; the others wait for the lock and find the library fresh
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not stale():
+                return LIB
+            tmp = "%s.tmp.%d" % (LIB, os.getpid())
+            cmd = [hipcc, *FLAGS, "-o", tmp, *SOURCES]
+            res = subprocess.run(cmd, cwd=PKG, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if verbose or res.returncode != 0:
+                print(" ".join(cmd))
+                print(res.stdout)
+            if res.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("hipcc failed building libgmg.so")
+            os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
