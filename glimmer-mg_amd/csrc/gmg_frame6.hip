@@ -16,8 +16,9 @@
 //               scores every base with the full-window rule: no read boundaries, no branches.  Bases
 //               whose window leaves their read (the first W-1 bases of either scoring buffer of each
 //               read) get a meaningless value here.
-//   k_frame6_generic  the last < 2048 bases of the batch (the main pass only does full chunks), and
-//               whole batches whose model shape has no fast path.
+//   k_frame6_generic  whole batches whose model shape has no fast path; the same exact code (f6_generic_range) scores
+//               the last < 2048 bases of every batch as extra blocks of the k_frame6p launch (the main pass only
+//               does full chunks).
 //   k_frame6p   partial-window pass: one lane per (read, buffer position < W-1, strand) recomputes
 //               exactly those bases with the reference's partial-window rule (icm.cc:807-842) and
 //               overwrites them.  2(W-1) of every L bases (4.4 % at L = 500).
