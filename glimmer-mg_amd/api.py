@@ -371,14 +371,14 @@ def find_orfs(reads, min_gene_len=75, allow_truncated=False, start_codons=("atg"
 
 def mg_score_reads(gene, null, reads, min_gene_len=75, allow_truncated=True, ignore_score_len=2**31 - 1,
                    start_threshold=-6.0, start_codons=("atg", "gtg", "ttg"), stop_codons=("taa", "tag", "tga"),
-                   frame_scores=None):
+                   frame_scores=None, accepted_only=False):
     """glimmer-mg's front half for a batch of reads (include/gmg.h: gmg_mg_score_reads): Score_All_Frames,
     Find_Orfs, Score_Orf_Starts and the filter of Score_Orfs_Errors.
     -> (orfs[MG_ORF_DTYPE], starts[START_DTYPE], read_orf_off[uint64 n_reads+1]).
     frame_scores: optional _DeviceBuffer of 6*total_bases doubles that receives the Frame_Scores table."""
     assert MG_ORF_DTYPE.itemsize == 56
-    prm = capi.MgParams(min_gene_len, int(allow_truncated), ignore_score_len, len(start_codons), len(stop_codons), 0,
-                        start_threshold)
+    prm = capi.MgParams(min_gene_len, int(allow_truncated), ignore_score_len, len(start_codons), len(stop_codons),
+                        1 if accepted_only else 0, start_threshold)
     for i, c in enumerate(start_codons):
         prm.start_codon[i].value = c.encode()
     for i, c in enumerate(stop_codons):

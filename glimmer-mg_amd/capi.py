@@ -24,7 +24,7 @@ class OrfParams(C.Structure):
 
 class MgParams(C.Structure):
     _fields_ = [("min_gene_len", C.c_int32), ("allow_truncated", C.c_int32), ("ignore_score_len", C.c_int32),
-                ("n_start_codons", C.c_int32), ("n_stop_codons", C.c_int32), ("reserved", C.c_int32),
+                ("n_start_codons", C.c_int32), ("n_stop_codons", C.c_int32), ("flags", C.c_int32),
                 ("start_threshold", C.c_double), ("start_codon", (C.c_char * 4) * 8),
                 ("stop_codon", (C.c_char * 4) * 8)]
 

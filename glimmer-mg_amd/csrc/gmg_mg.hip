@@ -612,6 +612,37 @@ __global__ __launch_bounds__(256) void k_mg_starts(MgArgs a)
     }
 }
 
+// GMG_MG_ACCEPTED_ONLY: keep the ORFs that go to Add_Events_* and their start lists, packed, in the same order
+__global__ __launch_bounds__(256) void k_mg_keep_counts(const gmg_mg_orf *orfs, uint64_t n, uint32_t *keep, uint32_t *keep_starts)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const bool k = orfs[i].accepted != 0;
+        keep[i] = k ? 1u : 0u;
+        keep_starts[i] = k ? orfs[i].n_starts : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mg_keep_gather(const gmg_mg_orf *orfs, const gmg_start *starts, uint64_t n,
+                                                        const uint64_t *new_orf, const uint64_t *new_start,
+                                                        gmg_mg_orf *out_orfs, gmg_start *out_starts)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        gmg_mg_orf o = orfs[i];
+        if (!o.accepted) continue;
+        const gmg_start *src = starts + o.start_begin;
+        gmg_start *dst = out_starts + new_start[i];
+        for (uint32_t t = 0; t < o.n_starts; t++) dst[t] = src[t];
+        o.start_begin = (uint32_t)new_start[i];
+        out_orfs[new_orf[i]] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mg_keep_reads(const uint64_t *read_orf_off, uint64_t n_reads, const uint64_t *new_orf, uint64_t *out)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_reads; r += (uint64_t)gridDim.x * blockDim.x)
+        out[r] = new_orf[read_orf_off[r]];              // new_orf has n_orfs + 1 entries: the last one is the total
+}
+
 __global__ __launch_bounds__(256) void k_mg_widen(const uint32_t *in, uint64_t *out, uint64_t n)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = in[i];
@@ -851,6 +882,54 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     a.starts = res->d_starts;
     if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
+    }
+    if (!find_only && (prm->flags & GMG_MG_ACCEPTED_ONLY)) {
+        // 4. only what Add_Events_* will see leaves the GPU: two prefix sums over the accepted flags, one gather
+        uint32_t *d_keep = nullptr, *d_keep_st = nullptr;
+        uint64_t *d_new_orf = nullptr, *d_new_st = nullptr, *d_new_first = nullptr;
+        gmg_mg_orf *d_orfs2 = nullptr;
+        gmg_start *d_starts2 = nullptr;
+        uint64_t n_keep = 0, n_keep_st = 0;
+        hipError_t e = gmg_pool_alloc((void **)&d_keep, (no + 1) * 4);
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_keep_st, (no + 1) * 4);
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_new_orf, (no + 1) * 8);
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_new_st, (no + 1) * 8);
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_new_first, (nr + 1) * 8);
+        if (e == hipSuccess) e = hipMemsetAsync(d_keep + no, 0, 4, s);
+        if (e == hipSuccess) e = hipMemsetAsync(d_keep_st + no, 0, 4, s);
+        int rc2 = GMG_OK;
+        if (e == hipSuccess) {
+            if (no) hipLaunchKernelGGL(k_mg_keep_counts, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, no, d_keep, d_keep_st);
+            rc2 = mg_scan(d_keep, d_new_orf, no, &n_keep, s);
+            if (!rc2) rc2 = mg_scan(d_keep_st, d_new_st, no, &n_keep_st, s);
+            if (!rc2) e = gmg_pool_alloc((void **)&d_orfs2, (n_keep ? n_keep : 1) * sizeof(gmg_mg_orf));
+            if (!rc2 && e == hipSuccess) e = gmg_pool_alloc((void **)&d_starts2, (n_keep_st ? n_keep_st : 1) * sizeof(gmg_start));
+            if (!rc2 && e == hipSuccess) {
+                if (no) hipLaunchKernelGGL(k_mg_keep_gather, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, res->d_starts, no, d_new_orf,
+                                           d_new_st, d_orfs2, d_starts2);
+                hipLaunchKernelGGL(k_mg_keep_reads, dim3(grid_for(nr + 1)), dim3(256), 0, s, res->d_read_orf_off, nr, d_new_orf, d_new_first);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipStreamSynchronize(s);
+            }
+        }
+        if (d_keep) gmg_pool_release(d_keep);
+        if (d_keep_st) gmg_pool_release(d_keep_st);
+        if (d_new_orf) gmg_pool_release(d_new_orf);
+        if (d_new_st) gmg_pool_release(d_new_st);
+        if (rc2 || e != hipSuccess) {
+            if (d_orfs2) gmg_pool_release(d_orfs2);
+            if (d_starts2) gmg_pool_release(d_starts2);
+            if (d_new_first) gmg_pool_release(d_new_first);
+            return fail(rc2 ? rc2 : gmg_set_error(GMG_EHIP, "gmg_mg_score_reads: packing the accepted ORFs: %s", hipGetErrorString(e)));
+        }
+        gmg_pool_release(res->d_orfs);
+        gmg_pool_release(res->d_starts);
+        gmg_pool_release(res->d_read_orf_off);
+        res->d_orfs = d_orfs2;
+        res->d_starts = d_starts2;
+        res->d_read_orf_off = d_new_first;
+        res->n_orfs = n_keep;
+        res->n_starts = n_keep_st;
     }
     MG_TRY(hipStreamSynchronize(s));
     tm.lap("start lists");

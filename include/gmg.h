@@ -258,13 +258,17 @@ int gmg_score_orfs(const gmg_model *gene, const gmg_model *null_model, const gmg
  * The 48 B/base Frame_Scores table never leaves HBM; what comes back is one record per ORF and the start
  * lists.  The caller sorts each accepted ORF's list with Start_Cmp (glimmer_base.hh:90) and hands it to
  * Add_Events_Fwd / Add_Events_Rev exactly as Score_Orfs_Errors does. */
+/* gmg_mg_params.flags: return only the ORFs Score_Orfs_Errors would hand to Add_Events_* (accepted != 0) and their start
+ * lists -- same order, packed on the device, read_orf_off counting the kept ORFs; typically a few per cent of all ORFs */
+#define GMG_MG_ACCEPTED_ONLY 1
+
 typedef struct gmg_mg_params {
     int32_t min_gene_len;        /* Min_Gene_Len (>= 4)                                           */
     int32_t allow_truncated;     /* Allow_Truncated_Orfs (glimmer-mg default: true)               */
     int32_t ignore_score_len;    /* Ignore_Score_Len                                              */
     int32_t n_start_codons;      /* <= 8                                                          */
     int32_t n_stop_codons;       /* <= 8                                                          */
-    int32_t reserved;
+    int32_t flags;               /* GMG_MG_ACCEPTED_ONLY or 0                                     */
     double start_threshold;      /* Start_Threshold                                               */
     char start_codon[8][4];      /* Start_Codon strings (IUPAC allowed)                           */
     char stop_codon[8][4];       /* Stop_Codon strings                                            */

@@ -175,6 +175,7 @@ int main(int argc, char **argv)
             prm.allow_truncated = Allow_Truncated_Orfs;
             prm.ignore_score_len = Ignore_Score_Len;
             prm.start_threshold = Start_Threshold;
+            prm.flags = GMG_MG_ACCEPTED_ONLY;           // only what Add_Events_* will see comes back
             prm.n_start_codons = Start_Codon.size();
             prm.n_stop_codons = Stop_Codon.size();
             for (size_t s = 0; s < Start_Codon.size() && s < 8; s++) memcpy(prm.start_codon[s], Start_Codon[s], 3);

@@ -205,3 +205,25 @@ def test_find_orfs_alone_matches_glimmer3_goldens(gpu, seqs_fa, name, trunc):
     assert np.array_equal(got, g)
     assert np.array_equal(off, np.searchsorted(g[:, 0], np.arange(len(seqs_fa[1]) + 1)))
     assert np.all(orfs["n_starts"] == 0)
+
+
+def test_mg_accepted_only_is_the_filtered_full_result(gpu, nc, seqs_fa):
+    """GMG_MG_ACCEPTED_ONLY: the same records and start lists as the full result restricted to accepted ORFs, same order,
+    start lists re-packed, read offsets counting the kept ORFs"""
+    rng = np.random.default_rng(9)
+    seqs = list(seqs_fa[1][:200]) + ["".join("acgt"[c] for c in rng.integers(0, 4, size=int(n))) for n in rng.integers(1, 800, size=150)]
+    reads = gpu.Reads.from_strings(seqs)
+    indep = gpu.Icm.indep(0.42)
+    orfs, starts, first = gpu.mg_score_reads(nc, indep, reads)
+    k_orfs, k_starts, k_first = gpu.mg_score_reads(nc, indep, reads, accepted_only=True)
+    keep = orfs["accepted"] != 0
+    assert 0 < keep.sum() == len(k_orfs) < len(orfs)
+    cols = ["read", "frame", "stop_position", "orf_len", "gene_len", "lo", "hi", "first_j", "n_starts", "accepted", "orf_is_truncated", "best_score"]
+    assert all(np.array_equal(orfs[c][keep], k_orfs[c]) for c in cols)
+    assert np.array_equal(k_orfs["start_begin"], np.concatenate([[0], np.cumsum(k_orfs["n_starts"], dtype=np.uint64)[:-1]]))
+    assert len(k_starts) == int(k_orfs["n_starts"].sum())
+    for o, k in zip(orfs[keep], k_orfs):
+        assert starts[o["start_begin"]:o["start_begin"] + o["n_starts"]].tobytes() == \
+               k_starts[k["start_begin"]:k["start_begin"] + k["n_starts"]].tobytes()
+    assert np.array_equal(k_first, np.concatenate([[0], np.cumsum(np.add.reduceat(keep.astype(np.int64), first[:-1].astype(np.int64))
+                                                                   * (np.diff(first.astype(np.int64)) > 0))]).astype(np.uint64))

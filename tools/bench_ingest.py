@@ -81,7 +81,8 @@ api._ck(lib.gmg_host_register(out_orfs.ctypes.data, out_orfs.nbytes))
 api._ck(lib.gmg_host_register(out_starts.ctypes.data, out_starts.nbytes))
 
 
-def front_half():
+def front_half(accepted_only=False):
+    prm.flags = 1 if accepted_only else 0            # GMG_MG_ACCEPTED_ONLY
     reads, index = ingest()
     n, total, gc = C.c_uint64(), C.c_uint64(), C.c_uint64()
     api._ck(lib.gmg_fasta_info(index, C.byref(n), C.byref(total), C.byref(gc)))
@@ -105,6 +106,13 @@ for _ in range(5):
     stats = front_half()
     times.append(time.perf_counter() - t0)
 t_all = sorted(times)[len(times) // 2]
+front_half(True)
+times = []
+for _ in range(5):
+    t0 = time.perf_counter()
+    stats_acc = front_half(True)
+    times.append(time.perf_counter() - t0)
+t_acc = sorted(times)[len(times) // 2]
 
 import oracle_py  # noqa: E402
 orc = oracle_py.load()
@@ -116,5 +124,7 @@ print(json.dumps({"file_bytes": n_data, "ingest_pageable_ms": t_ing_pageable * 1
                   "ingest_ms": t_ing * 1e3, "ingest_GBps": n_data / t_ing / 1e9,
                   "ingest_mbases_per_s": stats[1] / t_ing / 1e6,
                   "file_to_start_lists_ms": t_all * 1e3, "file_to_start_lists_mbases_per_s": stats[1] / t_all / 1e6,
+                  "file_to_accepted_lists_ms": t_acc * 1e3, "file_to_accepted_lists_mbases_per_s": stats[1] / t_acc / 1e6,
+                  "accepted_orfs": stats_acc[2], "accepted_starts": stats_acc[3],
                   "cpu_port_ingest_GBps": len(sample) / t_cpu / 1e9,
                   "note": "ingest and front half include the H2D copy of the file and the D2H copy of the results (host buffers page-locked with gmg_host_register)"}))
