@@ -589,7 +589,7 @@ extern "C" int gmg_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *
 
 // ---------------------------------------------------------------------------------------------------
 // Scratch and result buffers come from a small cache of device blocks: hipMalloc / hipFree of GB-sized
-// buffers cost up to hundreds of milliseconds now and then (measured: tools/bench_mg.py), far more than the
+// buffers cost up to hundreds of milliseconds now and then (measured: tests/bench/bench_mg.py), far more than the
 // kernels.  A released block is kept and handed to the next request it fits (size <= block <= 2 x size);
 // gmg_trim_cache() gives everything back to the driver.
 // ---------------------------------------------------------------------------------------------------

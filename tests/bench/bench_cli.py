@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = os.path.join(ROOT, "oracle", "_ref")
 ICM = os.path.join(ROOT, "tests", "golden", "data", "NC_000915.icm")
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000
