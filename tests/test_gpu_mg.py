@@ -227,3 +227,28 @@ def test_mg_accepted_only_is_the_filtered_full_result(gpu, nc, seqs_fa):
                k_starts[k["start_begin"]:k["start_begin"] + k["n_starts"]].tobytes()
     assert np.array_equal(k_first, np.concatenate([[0], np.cumsum(np.add.reduceat(keep.astype(np.int64), first[:-1].astype(np.int64))
                                                                    * (np.diff(first.astype(np.int64)) > 0))]).astype(np.uint64))
+
+
+def test_empty_reads_inside_a_batch_are_harmless(gpu, oracle, nc):
+    """FASTA files do contain empty records (Fasta_Read returns them): zero-length reads anywhere in a batch must not
+    disturb their neighbours in any of the batch entry points"""
+    rng = np.random.default_rng(4)
+    body = ["".join("acgt"[c] for c in rng.integers(0, 4, size=int(n))) for n in (300, 520, 90, 700)]
+    seqs = ["", body[0], "", "", body[1], body[2], "", body[3], ""]
+    reads = gpu.Reads.from_strings(seqs)
+    indep = gpu.Icm.indep(0.5)
+    dense = gpu.Reads.from_strings(body)
+    a = gpu.frame_score6(nc, indep, reads)
+    assert np.array_equal(a, gpu.frame_score6(nc, indep, dense))                 # same bases, same table
+    orfs, starts, first = gpu.mg_score_reads(nc, indep, reads, min_gene_len=60)
+    d_orfs, d_starts, d_first = gpu.mg_score_reads(nc, indep, dense, min_gene_len=60)
+    assert len(orfs) == len(d_orfs) > 10 and starts.tobytes() == d_starts.tobytes()
+    assert np.array_equal(orfs["read"], np.array([1, 4, 5, 7])[d_orfs["read"]])
+    for c in ("frame", "stop_position", "lo", "hi", "n_starts", "accepted", "best_score"):
+        assert np.array_equal(orfs[c], d_orfs[c])
+    assert list(np.diff(first.astype(np.int64))[[0, 2, 3, 6, 8]]) == [0, 0, 0, 0, 0]
+    m = gpu.Icm.open(os.path.join(DATA, "cluster-1.icm"))
+    s = gpu.score_reads_strings([m], reads)[0]
+    assert np.all(s[[0, 2, 3, 6, 8]] == 0.0) and np.array_equal(s[[1, 4, 5, 7]], gpu.score_reads_strings([m], dense)[0])
+    f_orfs, f_first = gpu.find_orfs(reads, min_gene_len=60, allow_truncated=True)
+    assert np.array_equal(f_orfs["stop_position"], orfs["stop_position"]) and np.array_equal(f_first, first)
