@@ -47,3 +47,32 @@ def test_glimmer3_with_batched_score_orfs_is_byte_identical(gpu, tmp_path, flags
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", golden), "rb").read()
+
+
+@pytest.mark.parametrize("ref,dev", [("glimmer3", "glimmer3_batch"), ("glimmer-mg", "glimmer-mg_batch")])
+def test_long_and_tiny_sequences_through_the_device_front_halves(gpu, tmp_path, ref, dev):
+    """one 30 kb sequence, one of 10 bases, one of 5 kb, an empty record: the all-reference CLI and the device front half
+    (ingest + Find_Orfs + scoring on the GPU, the reference's events / DP / trace-back on the host) must write the same bytes.
+    (The reference's glimmer-mg aborts on an empty record -- assertion in Complement_Transfer, glimmer_base.cc:422 -- so
+    that case is left to glimmer3.)"""
+    import numpy as np
+    exe_ref, exe_dev = (os.path.join(ROOT, "oracle", "_ref", x) for x in (ref, dev))
+    if not (os.access(exe_ref, os.X_OK) and os.access(exe_dev, os.X_OK)):
+        pytest.skip("oracle/_ref binaries not built (needs /root/reference in the build container)")
+    rng = np.random.default_rng(8)
+    fa = tmp_path / "mixed.fa"
+    with open(fa, "w") as f:
+        for name, n in (("long", 30000), ("tiny", 10), ("empty", 0), ("mid", 5000)):
+            if n == 0 and ref == "glimmer-mg":
+                continue
+            s = "".join("acgt"[c] for c in rng.integers(0, 4, size=n))
+            f.write(">%s some description\n" % name)
+            for i in range(0, n, 60):
+                f.write(s[i:i + 60] + "\n")
+    icm = os.path.join(DATA, "NC_000915.icm")
+    out = []
+    for exe, extra, tag in ((exe_ref, [], "a"), (exe_dev, ["batch"], "b")):
+        res = subprocess.run([exe, *extra, "-m", icm, str(fa), str(tmp_path / tag)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert res.returncode == 0, res.stderr.decode()[-2000:]
+        out.append(open(str(tmp_path / tag) + ".predict", "rb").read())
+    assert out[0] == out[1] and out[0].count(b"orf") >= 1
