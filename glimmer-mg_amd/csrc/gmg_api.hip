@@ -285,10 +285,12 @@ static int finish_reads(gmg_reads *r, const uint64_t *h_off /* may be NULL */)
         if (uni) r->uniform_len = (int)L;
     }
     r->max_len = 0;
+    r->n_over_512 = 0;
     r->min_len = r->n_reads ? ~0ull : 0;
     for (uint64_t i = 0; h_off && i < r->n_reads; i++) {
         const uint64_t len = h_off[i + 1] - h_off[i];
         if (len > r->max_len) r->max_len = len;
+        if (len > 512) r->n_over_512++;
         if (len < r->min_len) r->min_len = len;
     }
     return GMG_OK;

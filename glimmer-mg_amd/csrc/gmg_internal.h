@@ -57,6 +57,7 @@ struct gmg_reads {
     int owns_off;                // d_off allocated by the library
     int uniform_len;             // > 0 when every read has this length (fast read lookup)
     uint64_t max_len, min_len;   // longest / shortest read of the batch
+    uint64_t n_over_512;         // reads longer than 512 bases (tile shape of the mg running-sum kernel)
 };
 
 struct gmg_segments {

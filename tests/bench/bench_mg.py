@@ -25,7 +25,13 @@ L = 500
 gmg.init(0)
 model = os.path.join(ROOT, "tests", "golden", "data", "NC_000915.icm")
 gene, indep = gmg.Icm.open(model), gmg.Icm.indep(0.5)
-packed, off = gmg.synth.packed_reads(n_reads, L, 7)
+ragged = len(sys.argv) > 3 and sys.argv[3] == "ragged"
+if ragged:                                              # BASELINE configs[4] shape: lengths ~ N(400, 60^2), clipped
+    lens = np.clip(np.random.default_rng(12).normal(400, 60, n_reads).round(), 100, 700).astype(np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    packed, _ = gmg.synth.packed_reads(1, int(off[-1]), 7)
+else:
+    packed, off = gmg.synth.packed_reads(n_reads, L, 7)
 reads = gmg.Reads(packed, off)
 lib = capi.lib()
 prm = capi.MgParams(75, 1, 2**31 - 1, 3, 3, 0, -6.0)
@@ -63,6 +69,7 @@ oprm = orc.mg_params()
 sample = 2000
 t0 = time.perf_counter()
 for r in range(sample):
-    orc.mg_read(og, oi, gmg.synth.unpack_ascii(packed, r * L, L), oprm)
-out["cpu_port_mbases_per_s"] = sample * L / (time.perf_counter() - t0) / 1e6
+    orc.mg_read(og, oi, gmg.synth.unpack_ascii(packed, int(off[r]), int(off[r + 1] - off[r])), oprm)
+out["cpu_port_mbases_per_s"] = int(off[sample]) / (time.perf_counter() - t0) / 1e6
+out["ragged"] = ragged
 print(json.dumps(out))
