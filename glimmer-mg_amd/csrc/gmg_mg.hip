@@ -33,6 +33,7 @@
 #include <string.h>
 #include <chrono>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 struct gmg_mg_result {
@@ -362,9 +363,11 @@ struct MgTileNonEmpty {
 template <int MG_CAP, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double s_fs[];       // [3][MG_CAP]: rows 0,1,2 of one strand
+    constexpr int RS = MG_CAP + 8;                                      // row stride: 4 guard entries on both sides, so that
+                                                                        // the walk needs no index clamps
+    extern __shared__ __attribute__((aligned(16))) double s_fs[];       // [3][RS]: rows 0,1,2 of one strand, base b at 4 + b
     __shared__ uint16_t s_list[MG_CAP];                                 // tile bases where a running sum starts
-    __shared__ uint32_t s_fbits[(MG_CAP + 32 + BLOCK) / 32 + 2];        // the same as one bit per base, bit 32 + b
+    __shared__ uint8_t s_flag[RS + BLOCK];                              // the same as one byte per base (4 + b), ones around the tile
     __shared__ uint32_t s_packed[MG_CAP / 16 + 3];
     __shared__ uint32_t s_roff[MG_TILE_READS + 1];                      // read starts relative to the tile
     __shared__ uint32_t s_nlist;
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
                     const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
-                    if (i < span) s_fs[row * MG_CAP + i] = tmp[row][u];
+                    if (i < span) s_fs[row * RS + 4 + i] = tmp[row][u];
                 }
 #pragma unroll
             for (int u = 0; u < PW; u++) {
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
         //    the read (:1001-1003, 1035-1042).  One flag bit per tile base (bit 32 + b), all ones around the tile: the
         //    last three bases of a read (forward) / its first three (reverse) are always starts, so a walk can never
         //    step over a read boundary without meeting a flag.
-        for (uint32_t b0 = 0; b0 < MG_CAP + 32; b0 += BLOCK) {
+        for (uint32_t b0 = 0; b0 < MG_CAP + 4; b0 += BLOCK) {
             const uint32_t b = b0 + threadIdx.x;
             bool st = true;
             if (b < span) {
@@ -479,38 +482,37 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
                 else st = si < 3 || ((a.rev_stop >> codon((uint32_t)(rs + si - 3))) & 1ull);
                 if (st) s_list[atomicAdd(&s_nlist, 1u)] = (uint16_t)b;
             }
-            const uint64_t bits = __ballot(st);
-            if ((threadIdx.x & 63u) == 0 && b < MG_CAP + 32) {
-                s_fbits[(b + 32) >> 5] = (uint32_t)bits;
-                s_fbits[((b + 32) >> 5) + 1] = (uint32_t)(bits >> 32);
-            }
+            if (b < MG_CAP + 4) s_flag[4 + b] = st ? 1 : 0;
         }
-        if (threadIdx.x == 0) s_fbits[0] = 0xffffffffu;
+        if (threadIdx.x < 4) s_flag[threadIdx.x] = 1;
         __syncthreads();
         // 2. one lane per region: a single sum, f = 1,2,0,...; score[j-1] takes the place of the row-1 entry it
         //    precedes.  What a trip adds beyond the end of its read is never used: the next flag ends the walk.
         const uint32_t n_list = s_nlist;
-        double *r0 = s_fs, *r1 = s_fs + MG_CAP, *r2 = s_fs + 2 * MG_CAP;
-        const int dir = fwd ? -1 : 1;
-        for (uint32_t e = threadIdx.x; e < n_list; e += BLOCK) {
-            int b = (int)s_list[e];
-            double cum = 0.0;
-            for (;;) {                                  // (prefetching the next trip's operands was measured slower)
-                int i2 = b + dir, i0 = b + 2 * dir;
-                i2 = i2 < 0 ? 0 : i2 >= MG_CAP ? MG_CAP - 1 : i2;
-                i0 = i0 < 0 ? 0 : i0 >= MG_CAP ? MG_CAP - 1 : i0;
-                const int nx = b + 3 * dir;
-                const double v1 = r1[b], v2 = r2[i2], v0 = r0[i0];
-                const uint32_t fw = s_fbits[(uint32_t)(nx + 32) >> 5];
-                r1[b] = cum;
-                cum += v1; cum += v2; cum += v0;
-                if ((fw >> ((uint32_t)(nx + 32) & 31u)) & 1u) break;      // the next region belongs to another lane
-                b = nx;
+        // one pointer per lane (q = &row0[b]) and compile-time offsets: ~12 instructions per codon.  This loop is what the
+        // kernel's VALU time goes to (3.5e9 wave-instructions per 1M x 500 bp before the clamps and index arithmetic went)
+        auto walk = [&](auto DIR_) __attribute__((always_inline)) {
+            constexpr int DIR = decltype(DIR_)::value;
+            for (uint32_t e = threadIdx.x; e < n_list; e += BLOCK) {
+                const int b = (int)s_list[e];
+                double *q = s_fs + 4 + b;
+                const uint8_t *fl = s_flag + 4 + b + 3 * DIR;
+                double cum = 0.0;
+                for (;;) {
+                    const double v1 = q[RS], v2 = q[2 * RS + DIR], v0 = q[2 * DIR];
+                    const uint8_t f = *fl;
+                    q[RS] = cum;
+                    cum += v1; cum += v2; cum += v0;
+                    if (f) break;                       // the next region belongs to another lane
+                    q += 3 * DIR;
+                    fl += 3 * DIR;
+                }
             }
-        }
+        };
+        if (fwd) walk(std::integral_constant<int, -1>()); else walk(std::integral_constant<int, 1>());
         __syncthreads();
         double *dst = a.cum + (fwd ? 0 : a.total) + w0;
-        for (uint32_t i = threadIdx.x; i < span; i += BLOCK) dst[i] = r1[i];
+        for (uint32_t i = threadIdx.x; i < span; i += BLOCK) dst[i] = s_fs[RS + 4 + i];
         }
         cur = nxt;
     }
@@ -882,7 +884,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             a.n_tiles = n_sel;
         }
         if (tiled && a.n_tiles) {
-            const size_t lds = (size_t)3 * cap * sizeof(double);
+            const size_t lds = (size_t)3 * (cap + 8) * sizeof(double);
             const unsigned grid = (unsigned)(2 * a.n_tiles < 256 * 256 ? 2 * a.n_tiles : 256 * 256);
             if (small) {
                 hipLaunchKernelGGL((k_mg_cum_tiled<512, 64>), dim3(grid), dim3(64), lds, s, a);
