@@ -58,6 +58,7 @@ struct MgArgs {
     uint64_t tile_window, n_tiles;
     int lanes_only_unfit;        // k_mg_cum: skip the reads the tiled kernel has done
     const struct MgTile *tiles;  // ragged batches: the non-empty tiles, one entry each (k_mg_tile_table + select)
+    const uint32_t *n_tiles_dev; // ... and how many there are (stays on the device: no host round trip before the launch)
     int tile_cap;                // bases per tile of the tiled kernel
     // codon tests as 64-bit sets over idx6 = code(oldest) << 4 | code << 2 | code(newest)
     uint64_t fwd_start, rev_start, fwd_stop, rev_stop;
@@ -376,11 +377,12 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
     constexpr int PR = (MG_TILE_READS + 1 + BLOCK - 1) / BLOCK;         // read offsets per lane
 
     struct Tile { uint64_t first, w0; uint32_t nfit, span; };
+    const uint64_t n_tiles = a.n_tiles_dev ? (uint64_t)*a.n_tiles_dev : a.n_tiles;
     double tmp[3][PER];
     uint32_t tpk[PW], tro[PR];
     auto meta = [&](uint64_t k, Tile &t) __attribute__((always_inline)) {
         t.nfit = 0; t.span = 0; t.first = 0; t.w0 = 0;
-        if (k >= 2 * a.n_tiles) return;
+        if (k >= 2 * n_tiles) return;
         if (a.tiles) {                                  // ragged batch: precomputed, non-empty
             const MgTile e = a.tiles[k >> 1];
             t.first = e.first; t.nfit = e.nfit; t.w0 = e.w0; t.span = e.span;
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
     Tile cur;
     meta(k, cur);
     issue(k, cur);
-    for (; k < 2 * a.n_tiles; k += gridDim.x) {         // (tile, strand)
+    for (; k < 2 * n_tiles; k += gridDim.x) {           // (tile, strand)
         const bool fwd = (k & 1) == 0;
         const uint32_t nfit = cur.nfit, span = cur.span;
         const uint64_t w0 = cur.w0;
@@ -799,16 +801,21 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     uint32_t *d_read_cnt = nullptr, *d_orf_cnt = nullptr;
     uint64_t *d_start_off = nullptr;
     double *d_cum = nullptr;
-    MgTile *d_tiles = nullptr;
+    MgTile *d_tiles = nullptr, *d_all = nullptr;
+    uint32_t *d_ntiles = nullptr;
+    void *d_sel_tmp = nullptr;
     int rc = GMG_OK;
     auto fail = [&](int code) {
-        (void)hipStreamSynchronize(s);                  // nothing may still use the blocks that go back to the cache
+        (void)hipDeviceSynchronize();                   // nothing (either stream) may still use the blocks that go back to the cache
         if (d_fs_own) gmg_pool_release(d_fs_own);
         if (d_read_cnt) gmg_pool_release(d_read_cnt);
         if (d_orf_cnt) gmg_pool_release(d_orf_cnt);
         if (d_start_off) gmg_pool_release(d_start_off);
         if (d_cum) gmg_pool_release(d_cum);
         if (d_tiles) gmg_pool_release(d_tiles);
+        if (d_ntiles) gmg_pool_release(d_ntiles);
+        if (d_all) gmg_pool_release(d_all);
+        if (d_sel_tmp) gmg_pool_release(d_sel_tmp);
         gmg_mg_result_free(res);
         return code;
     };
@@ -860,8 +867,6 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             tiled = true;
             rest = reads->max_len > longest || reads->min_len * MG_TILE_READS < a.tile_window;
             if (n_windows >= 0x7fffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
-            MgTile *d_all = nullptr;
-            void *d_sel_tmp = nullptr;
             uint32_t *d_n = nullptr;
             size_t sel_bytes = 0;
             hipError_t e = gmg_pool_alloc((void **)&d_all, n_windows * sizeof(MgTile));
@@ -873,15 +878,11 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             }
             if (e == hipSuccess) e = gmg_pool_alloc(&d_sel_tmp, sel_bytes);
             if (e == hipSuccess) e = hipcub::DeviceSelect::If(d_sel_tmp, sel_bytes, d_all, d_tiles, d_n, (int)n_windows, MgTileNonEmpty(), s);
-            uint32_t n_sel = 0;
-            if (e == hipSuccess) e = hipMemcpyAsync(&n_sel, d_n, 4, hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-            if (d_all) gmg_pool_release(d_all);
-            if (d_sel_tmp) gmg_pool_release(d_sel_tmp);
-            if (d_n) gmg_pool_release(d_n);
+            d_ntiles = d_n;                                 // (all of these go back to the cache after the call's final synchronise)
             if (e != hipSuccess) return fail(gmg_set_error(GMG_EHIP, "gmg_mg_score_reads: tile table: %s", hipGetErrorString(e)));
             a.tiles = d_tiles;
-            a.n_tiles = n_sel;
+            a.n_tiles_dev = d_n;
+            a.n_tiles = n_windows;                          // upper bound, for the grid
         }
         if (tiled && a.n_tiles) {
             const size_t lds = (size_t)3 * (cap + 8) * sizeof(double);
@@ -902,15 +903,27 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     }
     tm.lap("running sums");
     }
-    // 2. ORFs of every read
+    // 2. ORFs of every read.  Find_Orfs and the count pass of the start scan need only the packed reads: they run on a second
+    //    stream beside the six-frame and running-sum kernels (light kernels without LDS, they fit next to the main pass's
+    //    work-groups) and join the caller's stream before the start lists are written.
+    static thread_local hipStream_t side = nullptr;
+    static thread_local hipEvent_t side_done = nullptr;
+    hipStream_t s2 = s;
+    if (!find_only && !tm.on && !getenv("GMG_MG_ONE_STREAM")) {
+        if (!side) {
+            MG_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            MG_TRY(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
+        }
+        s2 = side;
+    }
     const uint64_t nr = a.n_reads;
     MG_TRY(gmg_pool_alloc((void **)&d_read_cnt, (nr + 1) * 4));
-    MG_TRY(hipMemsetAsync(d_read_cnt, 0, (nr + 1) * 4, s));
+    MG_TRY(hipMemsetAsync(d_read_cnt, 0, (nr + 1) * 4, s2));
     MG_TRY(gmg_pool_alloc((void **)&res->d_read_orf_off, (nr + 1) * 8));
     a.read_cnt = d_read_cnt;
-    if (nr) hipLaunchKernelGGL(k_mg_find_orfs<false>, dim3(grid_for(nr)), dim3(256), 0, s, a);
+    if (nr) hipLaunchKernelGGL(k_mg_find_orfs<false>, dim3(grid_for(nr)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
-    rc = mg_scan(d_read_cnt, res->d_read_orf_off, nr, &res->n_orfs, s);
+    rc = mg_scan(d_read_cnt, res->d_read_orf_off, nr, &res->n_orfs, s2);
     if (rc) return fail(rc);
     if (res->n_orfs >= 0x7fffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
     const uint64_t no = res->n_orfs;
@@ -918,24 +931,28 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     a.read_orf_off = res->d_read_orf_off;
     a.orfs = res->d_orfs;
     a.n_orfs = no;
-    if (nr) hipLaunchKernelGGL(k_mg_find_orfs<true>, dim3(grid_for(nr)), dim3(256), 0, s, a);
+    if (nr) hipLaunchKernelGGL(k_mg_find_orfs<true>, dim3(grid_for(nr)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
 
     tm.lap("find orfs");
     // 3. start lists
     if (!find_only) {
     MG_TRY(gmg_pool_alloc((void **)&d_orf_cnt, (no + 1) * 4));
-    MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s));
+    MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
     MG_TRY(gmg_pool_alloc((void **)&d_start_off, (no + 1) * 8));
     a.orf_cnt = d_orf_cnt;
-    if (no) hipLaunchKernelGGL(k_mg_starts<false>, dim3(grid_for(no)), dim3(256), 0, s, a);
+    if (no) hipLaunchKernelGGL(k_mg_starts<false>, dim3(grid_for(no)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
-    rc = mg_scan(d_orf_cnt, d_start_off, no, &res->n_starts, s);
+    rc = mg_scan(d_orf_cnt, d_start_off, no, &res->n_starts, s2);
     if (rc) return fail(rc);
     if (res->n_starts >= 0xffffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
     MG_TRY(gmg_pool_alloc((void **)&res->d_starts, (res->n_starts ? res->n_starts : 1) * sizeof(gmg_start)));
     a.start_off = d_start_off;
     a.starts = res->d_starts;
+    if (s2 != s) {                                      // (mg_scan has synchronised the side stream already; the event keeps
+        MG_TRY(hipEventRecord(side_done, s2));          //  the ordering explicit)
+        MG_TRY(hipStreamWaitEvent(s, side_done, 0));
+    }
     if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
     }
@@ -996,6 +1013,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (d_start_off) gmg_pool_release(d_start_off);
     if (d_cum) gmg_pool_release(d_cum);
     if (d_tiles) gmg_pool_release(d_tiles);
+    if (d_ntiles) gmg_pool_release(d_ntiles);
+    if (d_all) gmg_pool_release(d_all);
+    if (d_sel_tmp) gmg_pool_release(d_sel_tmp);
     tm.lap("free scratch");
     *out = res;
     return GMG_OK;
