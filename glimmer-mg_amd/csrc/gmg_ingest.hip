@@ -24,7 +24,10 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <new>
 #include <vector>
 
@@ -115,7 +118,9 @@ __global__ __launch_bounds__(256) void k_fa_pack(FaPackArgs a)
             const uint8_t ch = a.bytes[i];
             if (ch == '>' && st != ST_HDR) {            // a record starts: its bases begin at `base`, its header behind the '>'
                 a.read_off[rec] = base;
-                a.hdr_begin[rec] = i + 1;
+                uint64_t hb = i + 1;                    // Fasta_Read skips the blanks behind '>' (fasta.cc:258-260)
+                while (hb < a.n_bytes && a.bytes[hb] == ' ') hb++;
+                a.hdr_begin[rec] = hb;
                 rec++;
             } else if (ch == '\n' && st == ST_HDR) {
                 a.hdr_end[rec - 1] = i;                 // the header line of the record that is open
@@ -183,6 +188,15 @@ extern "C" int gmg_fasta_split(const char *bytes, uint64_t n_bytes, uint64_t chu
 extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_reads **out_reads, gmg_fasta **out_index, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
+    const bool timing = getenv("GMG_INGEST_TIMING") != nullptr;         // wall time of every stage on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gmg_ingest] %-24s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = std::chrono::steady_clock::now();
+    };
     if ((!bytes && n_bytes) || !out_reads || !out_index) return gmg_set_error(GMG_EINVAL, "gmg_fasta_ingest: NULL argument");
     if (n_bytes >= 0x7fffffffull) return gmg_set_error(GMG_EINVAL, "gmg_fasta_ingest: at most 2^31 - 2 bytes per call");
     gmg_fasta *idx = new (std::nothrow) gmg_fasta();
@@ -210,7 +224,9 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
         FA_TRY(dev.alloc(&d_bytes, n));
         FA_TRY(dev.alloc(&d_func, n));
         FA_TRY(dev.alloc(&d_count, (n + 1) * 8));
+        lap("alloc");
         FA_TRY(hipMemcpyAsync(d_bytes, bytes, n, hipMemcpyHostToDevice, st));
+        lap("copy file to device");
         // 1. the state behind every byte
         hipcub::TransformInputIterator<uint8_t, FaFuncOf, const uint8_t *> func_in(d_bytes, FaFuncOf());
         size_t tmp_bytes = 0, tmp2 = 0;
@@ -232,6 +248,7 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
         FA_TRY(hipMemcpyAsync(&last_func, d_func + (n - 1), 1, hipMemcpyDeviceToHost, st));
         if (n > 1) FA_TRY(hipMemcpyAsync(&prev_func, d_func + (n - 2), 1, hipMemcpyDeviceToHost, st));
         FA_TRY(hipStreamSynchronize(st));
+        lap("two scans");
         last_byte = (uint8_t)bytes[n - 1];
         const unsigned st_last = n > 1 ? (prev_func & 3u) : (unsigned)ST_PRE;
         n_reads = (last_excl >> FA_REC_SHIFT) + ((last_byte == '>' && st_last != ST_HDR) ? 1 : 0);
@@ -263,6 +280,7 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
     }
     e2 = hipGetLastError();
     if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+    lap("pack kernel");
     idx->hdr_begin.resize(n_reads);
     idx->hdr_end.resize(n_reads);
     unsigned long long gc = 0;
@@ -271,12 +289,8 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
     if (e2 == hipSuccess) e2 = hipMemcpyAsync(&gc, d_gc, 8, hipMemcpyDeviceToHost, st);
     if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
     if (e2 != hipSuccess) { delete idx; return gmg_set_error(GMG_EHIP, "gmg_fasta_ingest: %s", hipGetErrorString(e2)); }
-    // Fasta_Read: the blanks behind '>' are not part of the header; a record that is only "> <blanks> EOF" does not exist
-    for (uint64_t r = 0; r < n_reads; r++) {
-        uint64_t b = idx->hdr_begin[r];
-        while (b < idx->hdr_end[r] && bytes[b] == ' ') b++;
-        idx->hdr_begin[r] = b;
-    }
+    lap("headers to host");
+    // Fasta_Read: a record that is only "> <blanks> EOF" does not exist (the blanks were skipped on the device)
     if (n_reads && idx->hdr_begin[n_reads - 1] == n_bytes && idx->hdr_end[n_reads - 1] == n_bytes) {
         n_reads--;                                      // fasta.cc:258-261: EOF while skipping the blanks -> return false
         idx->hdr_begin.pop_back();
@@ -285,6 +299,7 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
     gmg_reads *reads = nullptr;
     int rc = gmg_reads_wrap_device(d_packed, d_off, n_reads, total, &reads);    // copies the words into the guarded buffer
     if (rc) { delete idx; return rc; }
+    lap("wrap reads");
     reads->owns_off = 1;                                // the offsets now belong to the reads
     d_off = nullptr;
     idx->n_reads = n_reads;
