@@ -845,7 +845,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     a.cum = d_cum;
     tm.lap("alloc running sums");
     if (a.n_reads && a.total) {
-        // tile shape: one wave and <= 512 bases (12 KB of LDS, many blocks per CU in different phases) when the reads
+        // tile shape: two waves and <= 512 bases (12 KB of LDS, many blocks per CU in different phases) when the reads
         // allow it, else four waves and 1504 bases (39.8 KB, four blocks per CU)
         const char *env = getenv("GMG_MG_TILE");
         // (ragged batches: the few reads beyond 512 bases go to the per-lane kernel; measured 9.6 vs 10.6 ms on 1M x ~400 bp)
@@ -886,9 +886,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         }
         if (tiled && a.n_tiles) {
             const size_t lds = (size_t)3 * (cap + 8) * sizeof(double);
-            const unsigned grid = (unsigned)(2 * a.n_tiles < 256 * 256 ? 2 * a.n_tiles : 256 * 256);
+            const unsigned grid = (unsigned)(2 * a.n_tiles < 256 * 1024 ? 2 * a.n_tiles : 256 * 1024);
             if (small) {
-                hipLaunchKernelGGL((k_mg_cum_tiled<512, 64>), dim3(grid), dim3(64), lds, s, a);
+                hipLaunchKernelGGL((k_mg_cum_tiled<512, 128>), dim3(grid), dim3(128), lds, s, a);     // two waves per tile: 7.1 ms; one: 8.0; four: 9.0
             } else {
                 MG_TRY(hipFuncSetAttribute((const void *)k_mg_cum_tiled<1504, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_mg_cum_tiled<1504, 256>), dim3(grid), dim3(256), lds, s, a);
