@@ -846,7 +846,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     tm.lap("alloc running sums");
     if (a.n_reads && a.total) {
         // tile shape: two waves and <= 512 bases (12 KB of LDS, many blocks per CU in different phases) when the reads
-        // allow it, else four waves and 1504 bases (39.8 KB, four blocks per CU)
+        // allow it, else eight waves and 1504 bases (39.8 KB, four blocks per CU)
         const char *env = getenv("GMG_MG_TILE");
         // (ragged batches: the few reads beyond 512 bases go to the per-lane kernel; measured 9.6 vs 10.6 ms on 1M x ~400 bp)
         const bool small = env ? atoi(env) == 512 : (reads->max_len <= 512 || (reads->uniform_len == 0 && reads->n_over_512 * 10 <= reads->n_reads));
@@ -890,8 +890,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             if (small) {
                 hipLaunchKernelGGL((k_mg_cum_tiled<512, 128>), dim3(grid), dim3(128), lds, s, a);     // two waves per tile: 7.1 ms; one: 8.0; four: 9.0
             } else {
-                MG_TRY(hipFuncSetAttribute((const void *)k_mg_cum_tiled<1504, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((k_mg_cum_tiled<1504, 256>), dim3(grid), dim3(256), lds, s, a);
+                // eight waves per tile: 8.8 ms per 400k x 1000 bp; four: 9.7; two: 11.1; twelve: 13.3
+                MG_TRY(hipFuncSetAttribute((const void *)k_mg_cum_tiled<1504, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_mg_cum_tiled<1504, 512>), dim3(grid), dim3(512), lds, s, a);
             }
             MG_TRY(hipGetLastError());
         }

@@ -21,7 +21,7 @@ api, capi = gmg.api, gmg.capi
 
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-L = 500
+L = int(os.environ.get("BENCH_READ_LEN", "500"))
 gmg.init(0)
 model = os.path.join(ROOT, "tests", "golden", "data", "NC_000915.icm")
 gene, indep = gmg.Icm.open(model), gmg.Icm.indep(0.5)
