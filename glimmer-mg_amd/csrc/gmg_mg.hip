@@ -907,15 +907,19 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     // 2. ORFs of every read.  Find_Orfs and the count pass of the start scan need only the packed reads: they run on a second
     //    stream beside the six-frame and running-sum kernels (light kernels without LDS, they fit next to the main pass's
     //    work-groups) and join the caller's stream before the start lists are written.
-    static thread_local hipStream_t side = nullptr;
-    static thread_local hipEvent_t side_done = nullptr;
+    static thread_local hipStream_t side_of[16] = {};   // one per device this host thread has used
+    static thread_local hipEvent_t done_of[16] = {};
     hipStream_t s2 = s;
-    if (!find_only && !tm.on && !getenv("GMG_MG_ONE_STREAM")) {
-        if (!side) {
-            MG_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-            MG_TRY(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
+    hipEvent_t side_done = nullptr;
+    int dev_id = 0;
+    MG_TRY(hipGetDevice(&dev_id));
+    if (!find_only && !tm.on && !getenv("GMG_MG_ONE_STREAM") && dev_id >= 0 && dev_id < 16) {
+        if (!side_of[dev_id]) {
+            MG_TRY(hipStreamCreateWithFlags(&side_of[dev_id], hipStreamNonBlocking));
+            MG_TRY(hipEventCreateWithFlags(&done_of[dev_id], hipEventDisableTiming));
         }
-        s2 = side;
+        s2 = side_of[dev_id];
+        side_done = done_of[dev_id];
     }
     const uint64_t nr = a.n_reads;
     MG_TRY(gmg_pool_alloc((void **)&d_read_cnt, (nr + 1) * 4));
