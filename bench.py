@@ -144,7 +144,7 @@ def main():
         args.gpus = world
     dist = None
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("GMG_BENCH_FORCE_DIST"):     # (the switch lets a 1-GPU box exercise the RCCL plumbing)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,

@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 
@@ -15,6 +16,7 @@ import json, os, sys, time
 sys.path.insert(0, sys.argv[1])
 import torch.distributed as dist
 import numpy as np
+import pytest
 import bench, _gmg_pkg
 gmg = _gmg_pkg.load()
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -68,3 +70,21 @@ def test_shard_plan_covers_everything_once():
         assert all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
         sizes = [hi - lo for lo, hi in plan]
         assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_with_rccl_on_one_gpu(tmp_path):
+    """the launch line the driver uses for N > 1, with N = 1 and the process group forced on: init over RCCL, the timing
+    barrier, the MAX reductions and the JSON contract on a real GPU"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, GMG_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--reads", "50000", "--cpu-reads", "0"]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    line = json.loads([ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 1000
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
