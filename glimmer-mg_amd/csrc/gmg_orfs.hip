@@ -91,9 +91,19 @@ __global__ __launch_bounds__(256) void k_orf_fused(OrfFusedArgs fa)
     uint8_t *s_shift = s_lds;                                       // [3][cstride]
     float *s_dense = (float *)(s_lds + 3 * cstride);                // [3][64]
     float *s_part = s_dense + 3 * 64;                               // [3][20]
+    __shared__ int8_t s_which[64];                                  // start pattern index of a codon (buff[j+2], buff[j+1], buff[j]), -1: none
     for (int i = threadIdx.x * 16; i < 3 * cstride; i += 256 * 16) *(uint4 *)(s_shift + i) = *(const uint4 *)(fa.gene.cshift + i);
     for (int i = threadIdx.x; i < 3 * 64; i += 256) s_dense[i] = fa.nul.dense[i];
     for (int i = threadIdx.x; i < 3 * 20; i += 256) s_part[i] = fa.nul.dense_part[i];
+    if (threadIdx.x < 64) {                                         // Codon_t::Can_Be (gene.cc:39-66) for every definite codon
+        const uint32_t c = threadIdx.x, m = (1u << ((c >> 4) & 3u)) << 8 | (1u << ((c >> 2) & 3u)) << 4 | (1u << (c & 3u));
+        int which = -1;
+        for (int p = a.n_pat - 1; p >= 0; p--) {
+            const uint32_t x = m & a.pat[p];
+            if ((x & 0xf00u) && (x & 0xf0u) && (x & 0x0fu)) which = p;
+        }
+        s_which[c] = (int8_t)which;
+    }
     __syncthreads();
 
     const int W = fa.gene.W, D = fa.gene.D;
@@ -120,58 +130,74 @@ __global__ __launch_bounds__(256) void k_orf_fused(OrfFusedArgs fa)
 
         // ---- pass 1, ascending: running sums, one temp entry per in-frame position (entry t <-> j_lo + 3t)
         double gsum = 0.0, nsum = 0.0;
+        int n_tmp = 0;
+        const int64_t dirg = fwd ? -1 : 1;
+        int64_t g = (int64_t)r_off + (fwd ? hi - 1 : lo);           // base of buffer position 0
+        uint32_t w = a.packed[g >> 4];
+        const uint32_t comp = fwd ? 0u : 3u;
+        auto next_code = [&]() __attribute__((always_inline)) {     // codes stream from a register, one word per 16 bases
+            const uint32_t c = ((w >> (2u * (unsigned)(g & 15))) & 3u) ^ comp;
+            const int64_t g2 = g + dirg;
+            if ((g ^ g2) >> 4) w = a.packed[g2 >> 4];   // word -1 / one past the end: the guard words of gmg_reads
+            g = g2;
+            return c;
+        };
+        // (a) the first W-1 positions: partial windows, descent on the completed tree
         uint32_t C = 0;              // window register: char k of the window ending at j in bits [2k, 2k+1]
-        uint32_t masks = 0;          // Ch_Mask nibbles of the last three buffer chars, newest in bits 8-11
-        int f = 1, jm3 = 0, n_tmp = 0;
-        uint64_t g = r_off + (uint64_t)(fwd ? hi - 1 : lo);         // base of buffer position 0
-        for (int j = 0; j < len; j++) {
-            const int code0 = dev_code(a.packed, g);
-            const int code = fwd ? code0 : 3 - code0;
-            C = (C >> 2) | ((uint32_t)code << sh_top);
-            masks = (masks >> 4) | ((1u << code) << 8);
-            // the codon that starts at in-frame position j-2 is (buff[j], buff[j-1], buff[j-2]) as Codon_t holds it
-            // after Shift_In of buff[m-1] .. buff[j-2]: buff[j] in bits 8-11, buff[j-2] in bits 0-3 == masks
-            if (jm3 == 2 && j - 2 >= j_lo) {
-                int which = -1;                                     // Codon_t::Can_Be (gene.cc:39-66)
-                for (int p = 0; p < a.n_pat; p++) {
-                    const uint32_t x = masks & a.pat[p];
-                    if ((x & 0xf00u) && (x & 0xf0u) && (x & 0x0fu)) { which = p; break; }
-                }
-                tmp[n_tmp - 1].which = which;
-            }
-            if (jm3 == 0 && j >= j_lo) {
-                tmp[n_tmp].s = gsum - nsum;                          // score[j-1] - indep_score[j-1]
-                tmp[n_tmp].which = -1;                               // until buff[j+2] has been seen
+        uint32_t n6 = 0;             // the last three buffer chars, newest in bits 4-5 (index of the null tables; with the
+                                     //  chars of in-frame position j-2 .. j it is also the Codon_t of position j-2)
+        int j = 0, f = 1;
+        double pend = 0.0;           // score[j-1] - indep[j-1] of the in-frame position whose codon is not complete yet
+        const int head = len < W - 1 ? len : W - 1;
+        auto in_frame_bookkeeping = [&](int jj, uint32_t codon6) __attribute__((always_inline)) {
+            const int m3 = jj % 3;
+            if (m3 == 2 && jj - 2 >= j_lo) {                        // the codon of in-frame position jj-2 is complete
+                tmp[n_tmp].s = pend;
+                tmp[n_tmp].which = s_which[codon6];
                 n_tmp++;
             }
-            // gene value of buffer position j under sub-model f
-            float gv;
-            if (j >= W - 1) {
-                gv = rows[(uint64_t)f * fa.total + g];
-            } else {
-                const uint8_t *tab = s_shift + f * cstride;
-                const int thr2 = 2 * ((W - 1) - j);
-                uint32_t idx = 0, lvl = 0, width = 1, node = 0xffffffffu;
-                for (int l = 0; l < D; l++) {
-                    const uint32_t sh = tab[lvl + idx];
-                    if (node == 0xffffffffu && (int)sh < thr2) node = lvl + idx;
-                    idx = (idx << 2) + ((C >> sh) & 3u);
-                    lvl += width;
-                    width <<= 2;
-                }
-                if (node == 0xffffffffu) node = lvl + idx;
-                gv = fa.gene.crow[((size_t)f * ctot + node) * 4 + code];
+            if (m3 == 0) pend = gsum - nsum;                        // score[jj-1] - indep_score[jj-1]
+        };
+        for (; j < head; j++) {
+            const uint32_t code = next_code();
+            C = (C >> 2) | (code << sh_top);
+            n6 = (n6 >> 2) | (code << 4);
+            in_frame_bookkeeping(j, n6);
+            const uint8_t *tab = s_shift + f * cstride;
+            const int thr2 = 2 * ((W - 1) - j);
+            uint32_t idx = 0, lvl = 0, width = 1, node = 0xffffffffu;
+            for (int l = 0; l < D; l++) {
+                const uint32_t sh = tab[lvl + idx];
+                if (node == 0xffffffffu && (int)sh < thr2) node = lvl + idx;
+                idx = (idx << 2) + ((C >> sh) & 3u);
+                lvl += width;
+                width <<= 2;
             }
-            // null value: last three buffer chars (window char k at bits 2k), partial tables for j < 2
+            if (node == 0xffffffffu) node = lvl + idx;
+            const float gv = fa.gene.crow[((size_t)f * ctot + node) * 4 + code];
+            // null value: last three buffer chars, partial tables for j < 2
             float nv;
-            if (j >= 2) nv = s_dense[f * 64 + (C >> (sh_top - 4))];
-            else if (j == 1) nv = s_part[f * 20 + 4 + (C >> (sh_top - 2))];
+            if (j >= 2) nv = s_dense[f * 64 + n6];
+            else if (j == 1) nv = s_part[f * 20 + 4 + (n6 >> 2)];
             else nv = s_part[f * 20 + code];
             gsum += (double)gv;
             nsum += (double)nv;
             f = f == 2 ? 0 : f + 1;
-            jm3 = jm3 == 2 ? 0 : jm3 + 1;
-            g += fwd ? (uint64_t)-1 : (uint64_t)1;
+        }
+        // (b) everything else: the whole-read window lies inside the ORF, so the value is row f of the gene-only pass
+        for (; j < len; j++) {
+            const float gv = rows[(uint64_t)f * fa.total + (uint64_t)g];
+            const uint32_t code = next_code();
+            n6 = (n6 >> 2) | (code << 4);
+            in_frame_bookkeeping(j, n6);
+            gsum += (double)gv;
+            nsum += (double)s_dense[f * 64 + n6];
+            f = f == 2 ? 0 : f + 1;
+        }
+        // an in-frame position whose codon never completed (len % 3 != 0) still counts, without a start codon
+        {
+            const int last_in = len >= 1 ? (len - 1) / 3 * 3 : -1;
+            if (last_in >= j_lo && last_in + 2 > len - 1) { tmp[n_tmp].s = pend; tmp[n_tmp].which = -1; n_tmp++; }
         }
 
         // ---- pass 2, from the 3' end: the reference's scan over the in-frame positions (glimmer3.cc:1355-1429)
