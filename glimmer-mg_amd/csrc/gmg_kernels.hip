@@ -15,6 +15,8 @@
 
 #include "gmg_device.h"
 
+#include <stdlib.h>
+
 // ---------------------------------------------------------------------------
 // tile -> read table
 // ---------------------------------------------------------------------------
@@ -93,6 +95,61 @@ __global__ __launch_bounds__(256) void k_seg_cum(SegArgs a, int frame0, double *
             result += (double)dev_score(a.m, b, j, f);
             f = (f == a.m.P - 1) ? 0 : f + 1;
             if (out) out[o + j] = result;
+        }
+        if (sums) sums[i] = result;
+    }
+}
+
+// The same for models with a completed tree (gmg_internal.h: W <= 16, D <= 8): the shift bytes of all sub-models sit in LDS,
+// the window is a register that takes one 2-bit code per base (the codes stream from a packed word held in a register), and
+// the only global access per base is the gather of the row entry.  The plain kernel above needs ~15 dependent global loads
+// per base (mip and packed word at every level); this one 1.
+__global__ __launch_bounds__(256) void k_seg_cum_fast(SegArgs a, int frame0, double *__restrict__ out,
+                                                      double *__restrict__ sums)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_shift[];       // [P][cstride]
+    const int P = a.m.P, cstride = a.m.cstride, W = a.m.W, D = a.m.D;
+    for (int i = threadIdx.x * 16; i < P * cstride; i += 256 * 16) *(uint4 *)(s_shift + i) = *(const uint4 *)(a.m.cshift + i);
+    __syncthreads();
+    const uint32_t sh_top = 2u * (uint32_t)(W - 1);
+    const uint32_t ctot = (uint32_t)a.m.ctot;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_segs;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const gmg_segment sg = a.segs[i];
+        const bool rev = sg.orient == GMG_REVERSED || sg.orient == GMG_REVCOMP;
+        const uint32_t comp = (sg.orient == GMG_COMPLEMENTED || sg.orient == GMG_REVCOMP) ? 3u : 0u;
+        const int len = (int)sg.len;
+        const int64_t dirg = rev ? -1 : 1;
+        int64_t g = (int64_t)a.off[sg.read] + sg.lo + (rev ? len - 1 : 0);     // base of buffer position 0
+        const uint64_t o = a.out_off[i];
+        double result = 0.0;
+        if (len > 0) {
+            uint32_t w = a.packed[g >> 4];
+            uint32_t C = 0;                             // char k of the window that ends at j in bits [2k, 2k+1]
+            int f = frame0;
+            for (int j = 0; j < len; j++) {
+                const uint32_t code = ((w >> (2u * (unsigned)(g & 15))) & 3u) ^ comp;
+                const int64_t g2 = g + dirg;
+                if ((g ^ g2) >> 4) w = a.packed[g2 >> 4];               // word -1 / one past the end: the guard words of gmg_reads
+                g = g2;
+                C = (C >> 2) | (code << sh_top);
+                const uint8_t *tab = s_shift + f * cstride;
+                // full window (icm.cc:568-595) for j >= W-1; before that the partial rule (icm.cc:818-835): stop at the first
+                // node whose context position lies in front of the buffer, i.e. whose shift byte is < 2 ((W-1) - j)
+                const int thr2 = j >= W - 1 ? 0 : 2 * ((W - 1) - j);
+                uint32_t idx = 0, lvl = 0, width = 1, node = 0xffffffffu;
+                for (int l = 0; l < D; l++) {
+                    const uint32_t sh = tab[lvl + idx];
+                    if (node == 0xffffffffu && (int)sh < thr2) node = lvl + idx;
+                    idx = (idx << 2) + ((C >> sh) & 3u);
+                    lvl += width;
+                    width <<= 2;
+                }
+                if (node == 0xffffffffu) node = lvl + idx;
+                result += (double)a.m.crow[((size_t)f * ctot + node) * 4 + code];
+                f = (f == P - 1) ? 0 : f + 1;
+                if (out) out[o + j] = result;
+            }
         }
         if (sums) sums[i] = result;
     }
@@ -226,6 +283,13 @@ int gmg_launch_seg_cum(const gmg_model *m, const gmg_reads *r, const gmg_segment
                        double *d_out, double *d_sums, hipStream_t s)
 {
     SegArgs a = make_seg_args(m, r, sg);
+    if (m->dev.has_fast && m->dev.W <= 15 && m->dev.D <= 8 && (size_t)m->dev.P * m->dev.cstride <= 96 * 1024 && !getenv("GMG_SEG_PLAIN")) {
+        const size_t lds = (size_t)m->dev.P * m->dev.cstride;
+        if (lds > 48 * 1024) GMG_HIP(hipFuncSetAttribute((const void *)k_seg_cum_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_seg_cum_fast, dim3(grid_for(a.n_segs, 256)), dim3(256), lds, s, a, frame0, d_out, d_sums);
+        GMG_HIP(hipGetLastError());
+        return GMG_OK;
+    }
     hipLaunchKernelGGL(k_seg_cum, dim3(grid_for(a.n_segs, 256)), dim3(256), 0, s, a, frame0, d_out, d_sums);
     GMG_HIP(hipGetLastError());
     return GMG_OK;
