@@ -59,6 +59,9 @@ struct MgArgs {
     int lanes_only_unfit;        // k_mg_cum: skip the reads the tiled kernel has done
     const struct MgTile *tiles;  // ragged batches: the non-empty tiles, one entry each (k_mg_tile_table + select)
     const uint32_t *n_tiles_dev; // ... and how many there are (stays on the device: no host round trip before the launch)
+    const struct MgTile *windows;// ragged batches: the tile of EVERY window (k_mg_tile_table), for the unfit test
+    uint32_t *unfit;             // [n_reads] reads no tile took + their number in unfit_n (k_mg_unfit_list)
+    uint32_t *unfit_n;
     int tile_cap;                // bases per tile of the tiled kernel
     // codon tests as 64-bit sets over idx6 = code(oldest) << 4 | code << 2 | code(newest)
     uint64_t fwd_start, rev_start, fwd_stop, rev_stop;
@@ -520,18 +523,27 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
     }
 }
 
-// the per-lane walk, for the reads the tiles leave (lanes_only_unfit) or for everything
+// the reads no tile took (longer than a tile, or more than MG_TILE_READS in one window): a short list, so that the per-lane
+// kernel below runs over exactly those instead of testing every read
+__global__ __launch_bounds__(256) void k_mg_unfit_list(MgArgs a)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        if (a.read_off[r + 1] == a.read_off[r]) continue;               // nothing to sum
+        const MgTile t = a.windows[a.read_off[r] / a.tile_window];
+        if (t.nfit && r >= t.first && r < (uint64_t)t.first + t.nfit) continue;
+        a.unfit[atomicAdd(a.unfit_n, 1u)] = (uint32_t)r;
+    }
+}
+
+// the per-lane walk: for the listed reads (lanes_only_unfit) or for every read
 __global__ __launch_bounds__(256) void k_mg_cum(MgArgs a)
 {
-    // lanes [0, n_reads): forward strand; [n_reads, 2 n_reads): reverse strand (wave-uniform but for one wave)
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * a.n_reads; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = i < a.n_reads ? i : i - a.n_reads;
-        if (a.lanes_only_unfit) {
-            uint64_t first; uint32_t nfit;
-            mg_tile_reads(a, a.read_off[r] / a.tile_window, first, nfit, (uint32_t)a.tile_cap);
-            if (r >= first && r < first + nfit) continue;
-        }
-        if (i < a.n_reads) mg_cum_one<true>(a, r);
+    const uint64_t n = a.lanes_only_unfit ? (uint64_t)*a.unfit_n : a.n_reads;
+    // lanes [0, n): forward strand; [n, 2n): reverse strand (wave-uniform but for one wave)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t e = i < n ? i : i - n;
+        const uint64_t r = a.lanes_only_unfit ? a.unfit[e] : e;
+        if (i < n) mg_cum_one<true>(a, r);
         else mg_cum_one<false>(a, r);
     }
 }
@@ -802,6 +814,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     uint64_t *d_start_off = nullptr;
     double *d_cum = nullptr;
     MgTile *d_tiles = nullptr, *d_all = nullptr;
+    uint32_t *d_unfit = nullptr;
     uint32_t *d_ntiles = nullptr;
     void *d_sel_tmp = nullptr;
     int rc = GMG_OK;
@@ -816,6 +829,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (d_ntiles) gmg_pool_release(d_ntiles);
         if (d_all) gmg_pool_release(d_all);
         if (d_sel_tmp) gmg_pool_release(d_sel_tmp);
+        if (d_unfit) gmg_pool_release(d_unfit);
         gmg_mg_result_free(res);
         return code;
     };
@@ -881,6 +895,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             d_ntiles = d_n;                                 // (all of these go back to the cache after the call's final synchronise)
             if (e != hipSuccess) return fail(gmg_set_error(GMG_EHIP, "gmg_mg_score_reads: tile table: %s", hipGetErrorString(e)));
             a.tiles = d_tiles;
+            a.windows = d_all;
             a.n_tiles_dev = d_n;
             a.n_tiles = n_windows;                          // upper bound, for the grid
         }
@@ -897,7 +912,15 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             MG_TRY(hipGetLastError());
         }
         if (rest) {
-            a.lanes_only_unfit = tiled;
+            a.lanes_only_unfit = tiled && a.windows != nullptr;
+            if (a.lanes_only_unfit) {
+                MG_TRY(gmg_pool_alloc((void **)&d_unfit, (a.n_reads + 1) * 4));
+                a.unfit = d_unfit + 1;
+                a.unfit_n = d_unfit;
+                MG_TRY(hipMemsetAsync(d_unfit, 0, 4, s));
+                hipLaunchKernelGGL(k_mg_unfit_list, dim3(grid_for(a.n_reads)), dim3(256), 0, s, a);
+                MG_TRY(hipGetLastError());
+            }
             hipLaunchKernelGGL(k_mg_cum, dim3(grid_for(2 * a.n_reads)), dim3(256), 0, s, a);
             MG_TRY(hipGetLastError());
         }
@@ -1021,6 +1044,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (d_ntiles) gmg_pool_release(d_ntiles);
     if (d_all) gmg_pool_release(d_all);
     if (d_sel_tmp) gmg_pool_release(d_sel_tmp);
+    if (d_unfit) gmg_pool_release(d_unfit);
     tm.lap("free scratch");
     *out = res;
     return GMG_OK;
