@@ -35,7 +35,8 @@ struct Frame6Args {
     uint64_t total, n_reads;
     uint64_t first, count;  // k_frame6_generic: range of bases to score
     uint32_t p_blocks;      // k_frame6p: blocks [0, p_blocks) do partial windows, the rest the tail [first, first+count)
-    double *out;            // [6][total] gene - null (the Frame_Scores table)
+    double *out;            // [6][stride] gene - null (the Frame_Scores table); stride = total for the public entry point
+    uint64_t stride;        // distance between the rows of `out` in doubles (>= total)
     float *out_gene;        // gene-only mode (gmg_launch_gene6): [6][total] gene values as fp32
 };
 
@@ -157,8 +158,8 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     const uint32_t first_rel = lane_off + 16u - (uint32_t)(W - 1);
     const uint32_t wword = first_rel >> 4;
     const uint32_t wsh = 2u * (first_rel & 15u);
-    double *const out_f = a.out + (uint64_t)ftype * a.total;
-    double *const out_r = a.out + (uint64_t)(3 + ftype) * a.total;
+    double *const out_f = a.out + (uint64_t)ftype * a.stride;
+    double *const out_r = a.out + (uint64_t)(3 + ftype) * a.stride;
 
     uint32_t cur = 0;                                               // half resident in LDS
     for (uint32_t j0 = 0; j0 < n_mine; j0 += K) {
@@ -289,9 +290,9 @@ __device__ __forceinline__ void f6_generic_range(const Frame6Args &a, uint64_t i
                 a.out_gene[(uint64_t)(3 + f) * a.total + g] = dev_score(a.gene, br, p, f);
                 continue;
             }
-            a.out[(uint64_t)f * a.total + g] =
+            a.out[(uint64_t)f * a.stride + g] =
                 (double)dev_score(a.gene, bf, L - 1 - p, f) - (double)dev_score(a.nul, bf, L - 1 - p, f);
-            a.out[(uint64_t)(3 + f) * a.total + g] =
+            a.out[(uint64_t)(3 + f) * a.stride + g] =
                 (double)dev_score(a.gene, br, p, f) - (double)dev_score(a.nul, br, p, f);
         }
     }
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
 #pragma unroll
                 for (int f = 0; f < 3; f++)
                     __builtin_nontemporal_store((double)gv[u][f] - (double)nv[u][f],
-                                                a.out + (uint64_t)((rev_buf ? 0 : 3) + f) * a.total + g[u]);
+                                                a.out + (uint64_t)((rev_buf ? 0 : 3) + f) * a.stride + g[u]);
     }
 }
 
@@ -421,6 +422,14 @@ static int launch_generic(Frame6Args a, uint64_t first, uint64_t count, hipStrea
 int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, double *d_out,
                       hipStream_t s)
 {
+    return gmg_launch_frame6_strided(gene, nul, reads, d_out, reads->total_bases, s);
+}
+
+// rows of the table `stride` doubles apart (the mg pipeline pads its own table so that every row starts on a 128-byte
+// line whatever the number of bases: 16-byte stores, full lines)
+int gmg_launch_frame6_strided(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, double *d_out,
+                              uint64_t stride, hipStream_t s)
+{
     Frame6Args a;
     a.gene = gene->dev;
     a.nul = nul->dev;
@@ -432,6 +441,7 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
     a.first = 0;
     a.count = 0;
     a.out = d_out;
+    a.stride = stride;
     a.out_gene = nullptr;
 
     // the specialised path: completed tree of depth 7 (DEFAULT_MODEL_DEPTH) and the width-3 null model
@@ -444,7 +454,7 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
     const uint64_t n_chunks = a.total / SPAN;
     const char *env = getenv("GMG_DIAG");
     const int diag = env ? atoi(env) : 0;
-    const bool pair = (a.total & 1) == 0;
+    const bool pair = (a.stride & 1) == 0;          // every row 16-byte aligned
     if (n_chunks > 0) {
         int dev = 0, n_cu = 256;
         GMG_HIP(hipGetDevice(&dev));

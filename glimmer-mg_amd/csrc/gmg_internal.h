@@ -87,6 +87,8 @@ int gmg_launch_tile_read(const uint64_t *d_off, uint64_t n_reads, uint64_t n_til
                          hipStream_t s);
 int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, double *d_out,
                       hipStream_t s);
+int gmg_launch_frame6_strided(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, double *d_out,
+                              uint64_t stride, hipStream_t s);
 int gmg_launch_gene6(const gmg_model *gene, const gmg_reads *reads, float *d_gene, hipStream_t s);
 int gmg_launch_strings(const gmg_model *m, const gmg_reads *reads, float *d_vals, uint64_t *tail_start, hipStream_t s);
 int gmg_launch_seg_frame(const gmg_model *m, const gmg_reads *r, const gmg_segments *sg, int frame,

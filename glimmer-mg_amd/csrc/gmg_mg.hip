@@ -50,7 +50,8 @@ struct MgArgs {
     const uint64_t *read_off;
     const uint32_t *tile_read;   // read containing base t * GMG_TILE (gmg_reads)
     uint64_t n_reads, total;
-    const double *fs;            // Frame_Scores [6][total]
+    const double *fs;            // Frame_Scores [6][fs_stride]
+    uint64_t fs_stride;          // = total for a caller's table; the call's own table pads its rows to 128-byte lines
     double *cum;                 // [2][total]: score[j-1] of the ORF for which this base is in frame (k_mg_cum*)
     // tiling of k_mg_cum_tiled: uniform batches take reads_per_tile reads per block; ragged batches the reads
     // that start inside the block's window of tile_window bases
@@ -251,8 +252,8 @@ __device__ __forceinline__ void mg_cum_one(const MgArgs &a, uint64_t r)
     const int64_t off = (int64_t)a.read_off[r];
     const int n = (int)((int64_t)a.read_off[r + 1] - off);
     if (n <= 0) return;
-    const double *row0 = a.fs + (FWD ? 0 : 3) * a.total + off;
-    const double *row1 = row0 + a.total, *row2 = row1 + a.total;
+    const double *row0 = a.fs + (FWD ? 0 : 3) * a.fs_stride + off;
+    const double *row1 = row0 + a.fs_stride, *row2 = row1 + a.fs_stride;
     double *ctab = a.cum + (FWD ? 0 : a.total) + off;
     const uint64_t stopmask = FWD ? a.fwd_stop : a.rev_stop;
     int64_t g = off + (FWD ? n - 1 : 0);
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
         const bool fwd = (k & 1) == 0;
 #pragma unroll
         for (int row = 0; row < 3; row++) {
-            const double *src = a.fs + (uint64_t)((fwd ? 0 : 3) + row) * a.total + t.w0;
+            const double *src = a.fs + (uint64_t)((fwd ? 0 : 3) + row) * a.fs_stride + t.w0;
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
@@ -844,12 +845,14 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     MgTimer tm(s);
     // 1. Frame_Scores
     if (!find_only) {
+    a.fs_stride = a.total;
     if (!d_frame_scores && a.total) {
-        MG_TRY(gmg_pool_alloc((void **)&d_fs_own, (size_t)6 * a.total * sizeof(double)));
+        a.fs_stride = (a.total + 15) & ~15ull;          // our own table: every row on a 128-byte line
+        MG_TRY(gmg_pool_alloc((void **)&d_fs_own, (size_t)6 * a.fs_stride * sizeof(double)));
         d_frame_scores = d_fs_own;
     }
     if (a.total) {
-        rc = gmg_launch_frame6(gene, nul, reads, d_frame_scores, s);
+        rc = gmg_launch_frame6_strided(gene, nul, reads, d_frame_scores, a.fs_stride, s);
         if (rc) return fail(rc);
     }
     a.fs = d_frame_scores;
