@@ -250,17 +250,19 @@ class Segments:
             pass
 
 
-def frame_score6(gene, null, reads, d_out=None, stream=None):
+def frame_score6(gene, null, reads, d_out=None, stream=None, row_stride=None):
     """Score_All_Frames (glimmer-mg.cc:1468-1510) for every read.  With d_out (a device pointer to
-    6*total_bases doubles) the call is asynchronous on `stream` and returns None; otherwise the
-    result comes back as a float64 array [6, total_bases]."""
+    6*row_stride doubles) the call is asynchronous on `stream` and returns None; otherwise the
+    result comes back as a float64 array [6, total_bases].  row_stride (default total_bases) is the
+    distance between the six rows in doubles (gmg_frame_score6_strided)."""
+    stride = reads.total_bases if row_stride is None else int(row_stride)
     if d_out is not None:
-        _ck(capi.lib().gmg_frame_score6(gene.device(), null.device(), reads.h, C.c_void_p(d_out), stream))
+        _ck(capi.lib().gmg_frame_score6_strided(gene.device(), null.device(), reads.h, C.c_void_p(d_out), stride, stream))
         return None
-    buf = _DeviceBuffer(6 * reads.total_bases * 8)
-    _ck(capi.lib().gmg_frame_score6(gene.device(), null.device(), reads.h, buf.ptr, stream))
+    buf = _DeviceBuffer(6 * max(stride, 1) * 8)
+    _ck(capi.lib().gmg_frame_score6_strided(gene.device(), null.device(), reads.h, buf.ptr, stride, stream))
     _ck(capi.lib().gmg_synchronize(stream))
-    out = buf.to_host(np.float64, 6 * reads.total_bases).reshape(6, reads.total_bases)
+    out = buf.to_host(np.float64, 6 * stride).reshape(6, stride)[:, :reads.total_bases].copy()
     buf.free()
     return out
 

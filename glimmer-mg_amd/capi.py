@@ -50,6 +50,7 @@ PROTOTYPES = {
     "gmg_segments_upload": (i32, [vp, vp, u64, vp, C.POINTER(u64), C.POINTER(vp)]),
     "gmg_segments_free": (i32, [vp]),
     "gmg_frame_score6": (i32, [vp, vp, vp, vp, vp]),
+    "gmg_frame_score6_strided": (i32, [vp, vp, vp, vp, u64, vp]),
     "gmg_segment_frame_score": (i32, [vp, vp, vp, i32, vp, vp]),
     "gmg_segment_cumscore": (i32, [vp, vp, vp, i32, vp, vp]),
     "gmg_score_string": (i32, [vp, vp, vp, i32, vp, vp]),

@@ -479,6 +479,23 @@ extern "C" int gmg_frame_score6(const gmg_model *gene, const gmg_model *nul, con
     return gmg_launch_frame6(gene, nul, reads, d_out, (hipStream_t)stream);
 }
 
+extern "C" int gmg_frame_score6_strided(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads,
+                                        double *d_out, uint64_t row_stride, void *stream)
+{
+    int rc = require_init("gmg_frame_score6_strided");
+    if (rc) return rc;
+    if (!gene || !nul || !reads || (!d_out && reads->total_bases))
+        return gmg_set_error(GMG_EINVAL, "gmg_frame_score6_strided: NULL argument");
+    if (row_stride < reads->total_bases)
+        return gmg_set_error(GMG_EINVAL, "gmg_frame_score6_strided: row stride %llu < total_bases %llu",
+                             (unsigned long long)row_stride, (unsigned long long)reads->total_bases);
+    if (gene->dev.P < 3 || nul->dev.P < 3)
+        return gmg_set_error(GMG_EBADMODEL, "gmg_frame_score6_strided: periodicity must be >= 3 (gene %d, null %d)",
+                             gene->dev.P, nul->dev.P);
+    if (reads->total_bases == 0) return GMG_OK;
+    return gmg_launch_frame6_strided(gene, nul, reads, d_out, row_stride, (hipStream_t)stream);
+}
+
 extern "C" int gmg_segment_frame_score(const gmg_model *m, const gmg_reads *reads, const gmg_segments *segs,
                                        int frame, double *d_out, void *stream)
 {

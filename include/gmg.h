@@ -140,6 +140,13 @@ int gmg_segments_free(gmg_segments *s);
  * normally is the (3,2,3) Build_Indep_WO_Stops model. */
 int gmg_frame_score6(const gmg_model *gene, const gmg_model *null_model, const gmg_reads *reads,
                      double *d_out, void *stream);
+/* The same table with its six rows row_stride (>= total_bases) doubles apart:
+ *   d_out[f*row_stride + base_offsets[r] + p].
+ * The kernel stores two doubles per lane when every row starts on a 16-byte boundary (d_out 16-byte aligned and
+ * row_stride even), one at a time otherwise (about 15% slower); a batch of ragged reads has an odd total_bases half of
+ * the time, so a caller that owns the table should round the stride up (gmg_mg_score_reads does for its own table). */
+int gmg_frame_score6_strided(const gmg_model *gene, const gmg_model *null_model, const gmg_reads *reads,
+                             double *d_out, uint64_t row_stride, void *stream);
 
 /* ICM_t::Frame_Score (src/ICM/icm.cc:485-509) on every segment: one fixed
  * sub-model `frame` for all positions, no sum.  d_out[offset(i)+j]. */

@@ -40,11 +40,12 @@ for i, c in enumerate(("atg", "gtg", "ttg")):
 for i, c in enumerate(("taa", "tag", "tga")):
     prm.stop_codon[i].value = c.encode()
 fs = api._DeviceBuffer(6 * reads.total_bases * 8)      # the Frame_Scores table stays on the device
+fs_ptr = None if os.environ.get("BENCH_OWN_TABLE") else fs.ptr    # (or let the call use its own, row-padded table)
 
 
 def run():
     res = C.c_void_p()
-    api._ck(lib.gmg_mg_score_reads(gene.device(), indep.device(), reads.h, C.byref(prm), fs.ptr, C.byref(res), None))
+    api._ck(lib.gmg_mg_score_reads(gene.device(), indep.device(), reads.h, C.byref(prm), fs_ptr, C.byref(res), None))
     n_orfs, n_starts = C.c_uint64(), C.c_uint64()
     api._ck(lib.gmg_mg_result_info(res, C.byref(n_orfs), C.byref(n_starts)))
     lib.gmg_mg_result_free(res)

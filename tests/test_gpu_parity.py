@@ -70,6 +70,20 @@ def test_frame6_ragged_and_tiny_reads_vs_oracle(gpu, nc, oracle, o_nc):
         assert np.array_equal(out[:, lo:hi], exp), "read %d len %d" % (r, len(s))
 
 
+def test_frame6_row_stride_does_not_change_the_table(gpu, nc):
+    """gmg_frame_score6_strided: the same six rows whatever their distance (odd strides take the one-double-per-lane
+    stores, even ones the paired stores; both cover the batch tail and the partial-window heads)."""
+    rng = np.random.default_rng(11)
+    lens = [int(x) for x in rng.integers(0, 700, 301)]
+    reads = gpu.Reads.from_strings(["".join(rng.choice(list("acgt"), n)) for n in lens])
+    total = reads.total_bases
+    base = gpu.frame_score6(nc, gpu.Icm.indep(0.5), reads)
+    for stride in (total, total + 1, total + 2, total + 7, (total + 15) // 16 * 16 + 16):
+        assert np.array_equal(gpu.frame_score6(nc, gpu.Icm.indep(0.5), reads, row_stride=stride), base), stride
+    with pytest.raises(gpu.GmgError):
+        gpu.frame_score6(nc, gpu.Icm.indep(0.5), reads, row_stride=total - 1)
+
+
 def test_frame6_empty_batch(gpu, nc):
     reads = gpu.Reads.from_strings([])
     assert gpu.frame_score6(nc, gpu.Icm.indep(0.5), reads).shape == (6, 0)
