@@ -219,6 +219,47 @@ def main():
                             gene_orf=g[:, 0], gene_nstarts=g[:, 1], gene_start_begin=g[:, 2],
                             start_int=np.array(st_i, np.int32),            # j, pos, which, truncated, first (sorted by pos)
                             start_score=np.array(st_s, np.float64))
+    # ---- glimmer-mg's error branch (-i indels, -s substitutions, -q quality file; Score_Indels / Score_Orf_Starts,
+    #      glimmer-mg.cc:1513-1861): the start lists in PUSH order (seen right before the reference's sort) with errors
+    recs = open(fa).read().split(">")[1:]
+    sub_fa, sub_q = os.path.join(GOLD, "data", "seqs80.fa"), os.path.join(GOLD, "data", "seqs80.qual")
+    rng = np.random.default_rng(20260102)
+    with open(sub_fa, "w") as f, open(sub_q, "w") as q:
+        for rec in recs[:80]:
+            hdr, seq = rec.split("\n", 1)
+            seq = seq.replace("\n", "")
+            f.write(">%s\n%s\n" % (hdr, seq))
+            # Phred values, one in ten at or below the indel threshold, incl. 0 (Clean_Quality_454 lifts those to 1)
+            vals = np.where(rng.random(len(seq)) < 0.1, rng.integers(0, 19, len(seq)), rng.integers(19, 41, len(seq)))
+            q.write(">%s\n" % hdr)
+            for a in range(0, len(vals), 25):
+                q.write(" ".join(str(int(v)) for v in vals[a:a + 25]) + "\n")
+    for name, flags in (("mg_err_indel", ["-i"]), ("mg_err_sub", ["-s"]), ("mg_err_indel_q", ["-i", "-q", sub_q]),
+                        ("mg_err_indel_g90", ["-i", "-g", "90", "-Z", "taa,tag"])):
+        txt = subprocess.run([os.path.join(RB, "ref_mg_orfs"), "dump", *flags, "-m", nc, sub_fa, os.path.join(RB, "mg_tag")],
+                             check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=RB).stdout.decode()
+        orfs, genes, st_i, st_s = [], [], [], []
+        read, base = -1, 0
+        for line in txt.splitlines():
+            p = line.split()
+            if p[0] == "R":
+                read, base = int(p[1]), len(orfs)
+            elif p[0] == "O":
+                orfs.append((read, int(p[1]), int(p[2]), int(p[3]), int(p[4])))
+            elif p[0] == "G":
+                genes.append((base + int(p[1]), int(p[2]), len(st_i)))
+            elif p[0] == "S":
+                ne = int(p[7])
+                err = [int(x) for x in p[8:8 + 2 * ne]] + [0] * (4 - 2 * ne)
+                st_i.append((int(p[1]), int(p[2]), int(p[4]), int(p[5]), int(p[6]), ne, *err))
+                st_s.append(float.fromhex(p[3]))
+        g = np.array(genes, np.int64)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), flags=" ".join(os.path.basename(x) for x in flags),
+                            orfs=np.array(orfs, np.int32),                 # read, frame, stop_position, gene_len, orf_len
+                            gene_orf=g[:, 0], gene_nstarts=g[:, 1], gene_start_begin=g[:, 2],
+                            # j, pos, which, truncated, first, n_errors, (pos, type) x 2 -- in push order
+                            start_int=np.array(st_i, np.int32),
+                            start_score=np.array(st_s, np.float64))
     # ---- FASTA ingest (Fasta_Read, fasta.cc:236-286): a deliberately awkward file, parsed by the reference
     nasty = (b"junk before the first record\n>  first read  with spaces \nACGTacgt\nNNRYKM\n\n  acgt \t ggg\r\n"
              b">second>has>gt in header\nacgtacgtacgtacgtacgtacgtacgtacgtacgt\n"

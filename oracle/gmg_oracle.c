@@ -658,13 +658,14 @@ typedef struct orc_find_state {
     const orc_mg_params *prm;
     orc_orf *orfs;
     int cap, n_orfs;
+    int min_indel_orf_len;                              /* < 0: Allow_Indels = Allow_Subs = false */
     int first_fwd_start[3], last_rev_start[3], prev_fwd_stop[3], prev_rev_stop[3];
 } orc_find_state;
 
 static void orc_push_orf(orc_find_state *st, int stop_position, int frame, int gene_len, int orf_len)
 {
-    /* glimmer_base.cc:494,528,806 with Allow_Indels = Allow_Subs = false */
-    if (gene_len >= st->prm->min_gene_len) {
+    /* glimmer_base.cc:494,528,806 */
+    if (gene_len >= st->prm->min_gene_len || (st->min_indel_orf_len >= 0 && orf_len >= st->min_indel_orf_len)) {
         if (st->n_orfs < st->cap) {
             orc_orf *o = &st->orfs[st->n_orfs];
             o->stop_position = stop_position; o->frame = frame; o->gene_len = gene_len; o->orf_len = orf_len;
@@ -715,10 +716,15 @@ static void orc_do_rev_stop(orc_find_state *st, int i, int frame)
 
 int orc_find_orfs(const char *seq, int n, const orc_mg_params *prm, orc_orf *orfs, int cap)
 {
+    return orc_find_orfs_err(seq, n, prm, -1, orfs, cap);
+}
+
+int orc_find_orfs_err(const char *seq, int n, const orc_mg_params *prm, int min_indel_orf_len, orc_orf *orfs, int cap)
+{
     orc_find_state st;
     unsigned fwd_start[8], rev_start[8], fwd_stop[8], rev_stop[8], codon = 0;
     int i, frame, fr;
-    st.prm = prm; st.orfs = orfs; st.cap = cap; st.n_orfs = 0;
+    st.prm = prm; st.orfs = orfs; st.cap = cap; st.n_orfs = 0; st.min_indel_orf_len = min_indel_orf_len;
     for (i = 0; i < 3; i++) {
         st.first_fwd_start[i] = ORC_INT_MAX;
         st.last_rev_start[i] = st.prev_fwd_stop[i] = st.prev_rev_stop[i] = 0;
@@ -866,6 +872,242 @@ int orc_mg_score_orf(const double *frame_scores, const char *seq, int n, const i
         }
     }
     return n_starts;
+}
+
+
+/* ======================================================================================================
+ * glimmer-mg's error branch: Score_Orf_Starts with indels (-i) or substitutions (-s), glimmer-mg.cc:1513-1861
+ * ==================================================================================================== */
+
+/* Set_Quality_454 (glimmer-mg.cc:1865-1906): the last base of a homopolymer run of length r gets
+ * 31 - 5 r (r < 6) or 6; the bases inside a run 31 */
+void orc_set_quality_454(const char *seq, int n, int *q)
+{
+    int run_q[6], i, run = 0;
+    char last = ' ';
+    for (i = 0; i < 6; i++) run_q[i] = 31 - 5 * i;
+    if (n <= 0) return;
+    for (i = 0; i < n; i++) {
+        if (seq[i] != last) {
+            if (i > 0) q[i - 1] = run < 6 ? run_q[run] : run_q[5];
+            run = 1;
+        } else {
+            q[i - 1] = 31;
+            run++;
+        }
+        last = seq[i];
+    }
+    q[n - 1] = run < 6 ? run_q[run] : run_q[5];
+}
+
+/* Clean_Quality_454 (glimmer-mg.cc:519-546) */
+void orc_clean_quality_454(const char *seq, int n, int *q, int indel_quality_threshold)
+{
+    int i;
+    for (i = 0; i < n; i++)
+        if (q[i] <= 0) q[i] = 1;
+    for (i = 1; i < n; i++)
+        if (seq[i] == seq[i - 1] && q[i - 1] < indel_quality_threshold + 1) q[i - 1] = indel_quality_threshold + 1;
+}
+
+typedef struct orc_err_ctx {
+    const double *fs; const char *seq; int n; const int *fwd_prev, *rev_next, *quality;
+    int frame, stop_position;
+    const orc_mg_params *prm; const orc_mg_err_params *ep;
+    unsigned pat[8];
+    orc_start_err *starts; int cap, n_starts;
+    int lo0, hi0, trunc0, have0;
+} orc_err_ctx;
+
+/* Pass_Stop_Penalty (glimmer-mg.cc:961-995) without a quality file (with -s the reference never loads
+ * Quality_Values, :384-392, so only default_p is defined behaviour) */
+static double orc_pass_stop_penalty(const orc_err_ctx *c, int lo, int hi)
+{
+    const double default_p = 0.999;
+    double codon_p[3], p_stop;
+    int stop_i[3];
+    codon_p[0] = codon_p[1] = codon_p[2] = default_p;
+    stop_i[0] = lo - 3; stop_i[1] = lo - 2; stop_i[2] = lo - 1;
+    if (c->frame < 0) { stop_i[0] = hi + 1; stop_i[1] = hi; stop_i[2] = hi - 1; }
+    p_stop = codon_p[0];
+    /* (an index outside the read reads outside the reference's string; callers keep it inside, see the test) */
+    if ((c->frame > 0 && stop_i[1] >= 0 && stop_i[1] < c->n && c->seq[stop_i[1]] == 'a') ||
+        (c->frame < 0 && stop_i[1] >= 0 && stop_i[1] < c->n && c->seq[stop_i[1]] == 't'))
+        p_stop *= 2.0 / 3.0 * codon_p[1] + 1.0 / 3.0;
+    else
+        p_stop *= codon_p[1];
+    if ((c->frame > 0 && stop_i[2] >= 0 && stop_i[2] < c->n && c->seq[stop_i[2]] == 'a') ||
+        (c->frame < 0 && stop_i[2] >= 0 && stop_i[2] < c->n && c->seq[stop_i[2]] == 't'))
+        p_stop *= 2.0 / 3.0 * codon_p[2] + 1.0 / 3.0;
+    else
+        p_stop *= codon_p[2];
+    return log(1.0 - p_stop) - log(p_stop);
+}
+
+/* Score_Orf_Starts (glimmer-mg.cc:1693-1861), recursive exactly like the reference */
+static void orc_score_orf_starts(orc_err_ctx *c, int end_point, double suffix_score, int suffix_j,
+                                 const int *err_pos, const int *err_type, int num_errors)
+{
+    const orc_mg_params *prm = c->prm;
+    const orc_mg_err_params *ep = c->ep;
+    const int frame = c->frame, n = c->n;
+    unsigned codon = 0;
+    int lo, hi, len, k, j, m, lowest_j, which = -1, first_pos = 0, orf_is_truncated, e;
+    char *buff;
+    int *qbuf;
+    double *score;
+    int epos[ORC_MAX_ERRORS], etype[ORC_MAX_ERRORS];
+    for (e = 0; e < num_errors; e++) { epos[e] = err_pos[e]; etype[e] = err_type[e]; }
+
+    if (frame > 0) {                                    /* :1721-1742 */
+        hi = end_point;
+        e = end_point - 1;
+        lo = ((e >= 0 && e < n) ? c->fwd_prev[e] : e) + 1;
+        len = hi - lo;
+        orf_is_truncated = (lo < 3 && prm->allow_truncated);
+        k = lo - 1;
+    } else {                                            /* :1744-1763 */
+        lo = end_point;
+        e = end_point - 1;
+        hi = ((e >= 0 && e < n) ? c->rev_next[e] : e) + 1;
+        len = hi - lo;
+        orf_is_truncated = (n - (hi - 1) < 3 && prm->allow_truncated);
+        k = hi + 1;
+    }
+    if (!c->have0) { c->lo0 = lo; c->hi0 = hi; c->trunc0 = orf_is_truncated; c->have0 = 1; }
+    if (len < 0) len = 0;
+    buff = (char *)malloc((size_t)len + 1);
+    qbuf = (int *)malloc(sizeof(int) * (size_t)(len + 1));
+    score = (double *)malloc(sizeof(double) * (size_t)(len + 1));
+    if (frame > 0) {
+        orc_reverse_transfer(buff, c->seq, n, hi - 1, len);
+        for (j = 0; j < len; j++) qbuf[j] = c->quality ? c->quality[hi - 1 - j] : 0;       /* Reverse_Transfer_Qual */
+    } else {
+        if (lo - 1 < n) orc_complement_transfer(buff, c->seq, n, lo - 1, len);
+        for (j = 0; j < len; j++) qbuf[j] = c->quality ? c->quality[lo - 1 + j] : 0;       /* Complement_Transfer_Qual */
+    }
+    orc_cumulative_frame_score(c->fs, n, frame, lo, hi, score);
+
+    if (ep->allow_subs && num_errors < 1) {             /* mutate the previous stop codon, :1771-1806 */
+        int error_end_point, error_pos;
+        if (frame > 0) { error_end_point = lo - 3; error_pos = lo - 2; }
+        else { error_end_point = hi + 3; error_pos = hi + 2; }
+        if (error_end_point >= 0 && error_end_point - 2 < n) {
+            const int error_suffix_j = suffix_j + len;
+            double error_suffix_score = suffix_score + orc_pass_stop_penalty(c, lo, hi);
+            if (len > 0) error_suffix_score += score[len - 1] - 0.0;
+            epos[num_errors] = error_pos; etype[num_errors] = 2;
+            orc_score_orf_starts(c, error_end_point, error_suffix_score, error_suffix_j, epos, etype, num_errors + 1);
+        }
+    }
+
+    m = len;
+    lowest_j = prm->min_gene_len - 3 < 3 ? prm->min_gene_len - 3 : 3;
+    for (j = m - 1; j >= lowest_j; j--) {               /* :1813-1860 */
+        if (ep->allow_indels && qbuf[j] <= ep->indel_quality_threshold && num_errors < ep->indel_max) {
+            /* Score_Indels (:1513-1602) */
+            const int q = qbuf[j];
+            const double prob_err = pow(10.0, -(double)q / 10.0);
+            const double score_penalty = log(prob_err / 2.0) - log(1.0 - prob_err);
+            double es;
+            if (frame > 0) {
+                es = suffix_score + score[j] - 0.0 + score_penalty;
+                if (es > ep->indel_suffix_score_threshold) {
+                    epos[num_errors] = k + 3; etype[num_errors] = 1;
+                    orc_score_orf_starts(c, k + (j % 3), es, suffix_j + j + 2 - (j % 3), epos, etype, num_errors + 1);
+                }
+                es = suffix_score + score[j - 1] - 0.0 + score_penalty;
+                if (es > ep->indel_suffix_score_threshold) {
+                    epos[num_errors] = k + 2; etype[num_errors] = 0;
+                    orc_score_orf_starts(c, k - (2 - (j % 3)), es, suffix_j + j + 2 - (j % 3), epos, etype, num_errors + 1);
+                }
+            } else {
+                es = suffix_score + score[j] - 0.0 + score_penalty;
+                if (es > ep->indel_suffix_score_threshold) {
+                    epos[num_errors] = k - 1; etype[num_errors] = 1;
+                    orc_score_orf_starts(c, k - (j % 3), es, suffix_j + j + 2 - (j % 3), epos, etype, num_errors + 1);
+                }
+                es = suffix_score + score[j - 1] - 0.0 + score_penalty;
+                if (es > ep->indel_suffix_score_threshold) {
+                    epos[num_errors] = k - 2; etype[num_errors] = 0;
+                    orc_score_orf_starts(c, k + 2 - (j % 3), es, suffix_j + j + 2 - (j % 3), epos, etype, num_errors + 1);
+                }
+            }
+        }
+        codon = ((codon & 0xff) << 4) | orc_ch_mask(buff[j]);
+        if (j % 3 == 0 && (orc_can_be(codon, c->pat, prm->n_start_codons, &which) || (first_pos == 0 && orf_is_truncated))
+            && j + 3 + suffix_j >= prm->min_gene_len) {
+            orc_start_err st;
+            const double next_s = score[j - 1] - 0.0;
+            st.s.j = j + 2 + suffix_j; st.s.pos = k;
+            st.s.score = next_s + suffix_score;
+            st.s.first = (first_pos == 0);
+            st.n_errors = num_errors;
+            for (e = 0; e < ORC_MAX_ERRORS; e++) { st.err_pos[e] = e < num_errors ? epos[e] : 0; st.err_type[e] = e < num_errors ? etype[e] : 0; }
+            if (which >= 0 && first_pos == 0 && orf_is_truncated) {
+                st.s.which = -1; st.s.truncated = 1;
+                if (c->n_starts < c->cap) c->starts[c->n_starts] = st;
+                c->n_starts++;
+                st.s.first = 0;
+            }
+            st.s.which = which; st.s.truncated = (which < 0);
+            if (c->n_starts < c->cap) c->starts[c->n_starts] = st;
+            c->n_starts++;
+            if (first_pos == 0) first_pos = k;
+        }
+        if (frame > 0) k++; else k--;
+    }
+    free(buff); free(qbuf); free(score);
+}
+
+int orc_mg_score_orf_errors(const double *frame_scores, const char *seq, int n, const int *fwd_prev, const int *rev_next,
+                            const int *quality, int frame, int stop_position, const orc_mg_params *prm,
+                            const orc_mg_err_params *ep, orc_start_err *starts, int cap, orc_mg_out *out)
+{
+    orc_err_ctx c;
+    int i, lo_pos, hi_pos, amb = 0, pick = -1;
+    double best = -1.7976931348623157e308;
+    memset(&c, 0, sizeof c);
+    c.fs = frame_scores; c.seq = seq; c.n = n; c.fwd_prev = fwd_prev; c.rev_next = rev_next; c.quality = quality;
+    c.frame = frame; c.stop_position = stop_position; c.prm = prm; c.ep = ep; c.starts = starts; c.cap = cap;
+    for (i = 0; i < prm->n_start_codons; i++) c.pat[i] = orc_codon_from(prm->start_codon[i]);
+    /* Score_Orfs_Errors (:1632-1646) */
+    orc_score_orf_starts(&c, frame > 0 ? stop_position - 1 : stop_position + 3, 0, 0, NULL, NULL, 0);
+    out->lo = c.lo0; out->hi = c.hi0; out->orf_is_truncated = c.trunc0;
+    out->first_j = 0; out->accepted = 0; out->best_score = -1.7976931348623157e308;
+    if (c.n_starts > cap) return c.n_starts;
+    for (i = 0; i < c.n_starts; i++)
+        if (starts[i].s.j > prm->ignore_score_len && 0.0 > starts[i].s.score) starts[i].s.score = 0.0;
+    if (c.n_starts > 0) {
+        /* first_j is the j of front() (forward) / back() (reverse) after std::sort by pos -- an unstable sort: when
+         * several entries share the extreme pos with different j, only the real sort can tell (accepted = 2 if the
+         * answer matters) */
+        lo_pos = hi_pos = starts[0].s.pos;
+        for (i = 1; i < c.n_starts; i++) {
+            if (starts[i].s.pos < lo_pos) lo_pos = starts[i].s.pos;
+            if (starts[i].s.pos > hi_pos) hi_pos = starts[i].s.pos;
+        }
+        {
+            int jmin = 2147483647, jmax = -2147483647 - 1;
+            for (i = 0; i < c.n_starts; i++)
+                if (starts[i].s.pos == (frame > 0 ? lo_pos : hi_pos)) {
+                    if (pick < 0) pick = i;
+                    if (starts[i].s.j < jmin) jmin = starts[i].s.j;
+                    if (starts[i].s.j > jmax) jmax = starts[i].s.j;
+                }
+            for (i = 0; i < c.n_starts; i++)
+                if (starts[i].s.score > best) best = starts[i].s.score;
+            out->first_j = starts[pick].s.j;
+            if (jmin + 1 >= prm->min_gene_len) amb = 0;                     /* whichever comes first passes */
+            else if (jmax + 1 < prm->min_gene_len) amb = -1;                /* none passes */
+            else amb = 1;
+            if (amb >= 0) {
+                out->best_score = best;
+                out->accepted = best > prm->start_threshold ? (amb ? 2 : 1) : 0;
+            }
+        }
+    }
+    return c.n_starts;
 }
 
 /* Fasta_Read (fasta.cc:236-286): fgetc / ungetc restated as an index into a buffer */

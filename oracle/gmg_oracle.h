@@ -136,6 +136,27 @@ int orc_mg_score_orf(const double *frame_scores, const char *seq, int n, const i
                      int frame, int stop_position, const orc_mg_params *prm, orc_start *starts, int cap,
                      orc_mg_out *out);
 
+/* ---- glimmer-mg's error branch (-i indels / -s substitutions) -------------------------------------- */
+#define ORC_MAX_ERRORS 4
+typedef struct orc_mg_err_params {
+    int allow_indels, allow_subs;                       /* Allow_Indels / Allow_Subs (glimmer-mg.cc:100-102), exclusive (:952) */
+    int indel_quality_threshold, indel_max;             /* glimmer-mg.cc:136,138 (18, 2) */
+    double indel_suffix_score_threshold;                /* glimmer-mg.cc:134 (-12) */
+} orc_mg_err_params;
+typedef struct orc_start_err { orc_start s; int n_errors; int err_pos[ORC_MAX_ERRORS], err_type[ORC_MAX_ERRORS]; } orc_start_err;
+/* Find_Orfs with the error modes' extra ORFs: orf_len >= Min_Indel_ORF_Len also qualifies (glimmer_base.cc:494,528,806;
+ * min_indel_orf_len < 0 switches that off) */
+int orc_find_orfs_err(const char *seq, int n, const orc_mg_params *prm, int min_indel_orf_len, orc_orf *orfs, int cap);
+void orc_set_quality_454(const char *seq, int n, int *q);                                  /* glimmer-mg.cc:1865-1906 */
+void orc_clean_quality_454(const char *seq, int n, int *q, int indel_quality_threshold);   /* glimmer-mg.cc:519-546 */
+/* Score_Orf_Starts with Score_Indels / the substitution branch (glimmer-mg.cc:1513-1602, 1693-1861, recursive) and
+ * the per-ORF part of Score_Orfs_Errors.  quality: Quality_Values of the read (after Set_ / Clean_Quality_454) or
+ * NULL.  Starts come back in push order with their Error_t lists.  out->accepted: 1 accepted, 0 not, 2 = accepted if
+ * the reference's (unstable) sort puts an entry with j + 1 >= Min_Gene_Len first -- entries tie on pos.  */
+int orc_mg_score_orf_errors(const double *frame_scores, const char *seq, int n, const int *fwd_prev, const int *rev_next,
+                            const int *quality, int frame, int stop_position, const orc_mg_params *prm,
+                            const orc_mg_err_params *ep, orc_start_err *starts, int cap, orc_mg_out *out);
+
 /* Fasta_Read (src/Common/fasta.cc:236-286) on a memory buffer.  Starts at *pos; returns 0 at the end of the
  * input, else 1 with the header extent [*hdr_begin, *hdr_end) in buf, the raw sequence characters (every
  * non-isspace byte up to the next '>') in seq[0 .. *seq_len) (seq needs room for n - *pos bytes), *pos advanced. */

@@ -6,20 +6,38 @@
 // via the include path; nothing is copied) with its main() renamed, so that the file-static functions
 // Parse_Command_Line / Score_Orfs_Errors / Trace_Back are callable, and it intercepts Add_Events_Fwd /
 // Add_Events_Rev with the linker (--wrap) to see the start lists Score_Orfs_Errors hands over.
-// Only the user-ICM mode (-m <icm>, no -c classifications, no -i / -s error branch) is driven.
+// Only the user-ICM mode (-m <icm>, no -c classifications) is driven; the error branch (-i indels, -s substitutions,
+// -q quality file) is.
 //
 //   ref_mg_orfs dump  <glimmer-mg options...> <fasta> <tag>     text dump on stdout:
 //        R <read index> <n_orfs>
 //        O <frame> <stop_position> <gene_len> <orf_len>          every ORF Find_Orfs produced, in order
 //        G <orf index> <n_starts>                                every ORF Score_Orfs_Errors accepted
 //        S <j> <pos> <score %a> <which> <truncated> <first>      its start list as handed to Add_Events_* (sorted)
+//   with -i / -s the S lines come in the order Score_Orf_Starts PUSHED them (the list as it was right before
+//   Score_Orfs_Errors' sort, seen through a hook on that sort call) and carry the Error_t list:
+//        S <j> <pos> <score %a> <which> <truncated> <first> <n_errors> {<pos> <type>}...
 //   ref_mg_orfs batch <glimmer-mg options...> <fasta> <tag>     (built with -DGMG_BATCH, links libgmg.so)
 //        same pipeline as glimmer-mg's main, but Find_Orfs + Score_Orfs_Errors of ALL reads are replaced by
 //        ONE gmg_mg_score_reads call; writes <tag>.predict, which must equal the reference's byte for byte.
 
+#include "glimmer-mg.hh"
+
+// The reference sorts each start list with an unqualified sort(..., Start_Cmp) (glimmer-mg.cc:1659); seeing the list
+// right before that call gives the push order of Score_Orf_Starts without touching the reference.
+static vector<Start_t> Presort_List;
+template <class It> inline void gmg_hooked_sort(It a, It b) { std::sort(a, b); }
+template <class It, class Cmp> inline void gmg_hooked_sort(It a, It b, Cmp c) { std::sort(a, b, c); }
+inline void gmg_hooked_sort(vector<Start_t>::iterator a, vector<Start_t>::iterator b, bool (*c)(const Start_t &, const Start_t &))
+{
+    Presort_List.assign(a, b);
+    std::sort(a, b, c);
+}
+#define sort(...) gmg_hooked_sort(__VA_ARGS__)
 #define main glimmer_mg_reference_main
 #include "glimmer-mg.cc"
 #undef main
+#undef sort
 
 #include <map>
 
@@ -38,15 +56,16 @@ void wrap_Add_Events_Rev(const Orf_t &, vector<Start_t> &, int &)
 
 static bool Capture = false;
 static vector<pair<Orf_t, vector<Start_t> > > Captured;
+static bool Error_Mode = false;                         // -i / -s: capture the push order instead of the sorted list
 
 void wrap_Add_Events_Fwd(const Orf_t &orf, vector<Start_t> &sl, int &id)
 {
-    if (Capture) Captured.push_back(make_pair(orf, sl));
+    if (Capture) Captured.push_back(make_pair(orf, Error_Mode ? Presort_List : sl));
     real_Add_Events_Fwd(orf, sl, id);
 }
 void wrap_Add_Events_Rev(const Orf_t &orf, vector<Start_t> &sl, int &id)
 {
-    if (Capture) Captured.push_back(make_pair(orf, sl));
+    if (Capture) Captured.push_back(make_pair(orf, Error_Mode ? Presort_List : sl));
     real_Add_Events_Rev(orf, sl, id);
 }
 
@@ -57,10 +76,31 @@ static void setup_options(int argc, char **argv)
     Parse_Command_Line(argc, argv);
     Set_Start_And_Stop_Codons();
     if (Feature_File != NULL) Parse_Features(Feature_File);
-    if (!User_ICM || !classifications.empty() || Allow_Indels || Allow_Subs || Detail_Log) {
-        fprintf(stderr, "ref_mg_orfs: only -m <icm> without -c / -i / -s / detail log is driven here\n");
+    if (!User_ICM || !classifications.empty() || Detail_Log) {
+        fprintf(stderr, "ref_mg_orfs: only -m <icm> without -c / detail log is driven here\n");
         exit(2);
     }
+    Error_Mode = Allow_Indels || Allow_Subs;
+}
+
+// quality values of every read, as glimmer-mg's main reads them (glimmer-mg.cc:339-341)
+static void read_qualities(vector<vector<int> > &qual_list, size_t n_seq)
+{
+    qual_list.assign(n_seq, vector<int>());
+    if (Quality_File_Name == NULL) return;
+    FILE *fp = File_Open(Quality_File_Name, "r", __FILE__, __LINE__);
+    string header;
+    for (size_t i = 0; i < n_seq; i++) Fasta_Qual_Vec_Read(fp, qual_list[i], header);
+    fclose(fp);
+}
+
+// glimmer-mg.cc:384-392
+static void load_quality(vector<vector<int> > &qual_list, int i)
+{
+    if (!Allow_Indels) return;
+    Quality_Values = qual_list[i];
+    if (Quality_File_Name == NULL) Set_Quality_454();
+    else Clean_Quality_454();
 }
 
 static void setup_models(void)
@@ -101,8 +141,11 @@ int main(int argc, char **argv)
                 fclose(fp);
             }
             const int n_seq = seq_list.size();
+            vector<vector<int> > qual_list;
+            read_qualities(qual_list, n_seq);
             for (int i = 0; i < n_seq; i++) {
                 load_sequence(seq_list, hdr_list, i);
+                load_quality(qual_list, i);
                 Initialize_Terminal_Events(First_Event, Final_Event, Best_Event, Last_Event);
                 Find_Orfs(orf_list);
                 printf("R %d %d\n", i, (int)orf_list.size());
@@ -120,9 +163,15 @@ int main(int argc, char **argv)
                     const Orf_t &orf = Captured[c].first;
                     const vector<Start_t> &sl = Captured[c].second;
                     printf("G %d %d\n", index_of[make_pair(orf.Get_Frame(), orf.Get_Stop_Position())], (int)sl.size());
-                    for (size_t s = 0; s < sl.size(); s++)
-                        printf("S %d %d %a %d %d %d\n", sl[s].j, sl[s].pos, sl[s].score, (int)sl[s].which,
+                    for (size_t s = 0; s < sl.size(); s++) {
+                        printf("S %d %d %a %d %d %d", sl[s].j, sl[s].pos, sl[s].score, (int)sl[s].which,
                                (int)sl[s].truncated, (int)sl[s].first);
+                        if (Error_Mode) {
+                            printf(" %d", (int)sl[s].errors.size());
+                            for (size_t e = 0; e < sl[s].errors.size(); e++) printf(" %d %d", sl[s].errors[e].pos, sl[s].errors[e].type);
+                        }
+                        printf("\n");
+                    }
                 }
                 orf_list.clear();
                 Clear_Events();

@@ -51,6 +51,15 @@ class MgOut(C.Structure):
                 ("orf_is_truncated", C.c_int), ("best_score", C.c_double)]
 
 
+class MgErrParams(C.Structure):
+    _fields_ = [("allow_indels", C.c_int), ("allow_subs", C.c_int), ("indel_quality_threshold", C.c_int),
+                ("indel_max", C.c_int), ("indel_suffix_score_threshold", C.c_double)]
+
+
+class StartErr(C.Structure):
+    _fields_ = [("s", Start), ("n_errors", C.c_int), ("err_pos", C.c_int * 4), ("err_type", C.c_int * 4)]
+
+
 def build():
     src = [os.path.join(ORACLE_DIR, f) for f in ("gmg_oracle.c", "gmg_oracle.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
@@ -91,6 +100,11 @@ class Oracle:
         ip = C.POINTER(C.c_int)
         L.orc_find_orfs.argtypes = [C.c_char_p, C.c_int, C.POINTER(MgParams), C.POINTER(Orf), C.c_int]
         L.orc_save_prev_stops.argtypes = [C.c_char_p, C.c_int, C.POINTER(MgParams), ip, ip]
+        L.orc_find_orfs_err.argtypes = [C.c_char_p, C.c_int, C.POINTER(MgParams), C.c_int, C.POINTER(Orf), C.c_int]
+        L.orc_set_quality_454.argtypes = [C.c_char_p, C.c_int, ip]
+        L.orc_clean_quality_454.argtypes = [C.c_char_p, C.c_int, ip, C.c_int]
+        L.orc_mg_score_orf_errors.argtypes = [dp, C.c_char_p, C.c_int, ip, ip, ip, C.c_int, C.c_int, C.POINTER(MgParams),
+                                              C.POINTER(MgErrParams), C.POINTER(StartErr), C.c_int, C.POINTER(MgOut)]
         L.orc_mg_score_orf.argtypes = [dp, C.c_char_p, C.c_int, ip, ip, C.c_int, C.c_int, C.POINTER(MgParams),
                                        C.POINTER(Start), C.c_int, C.POINTER(MgOut)]
         lp = C.POINTER(C.c_long)
@@ -248,6 +262,59 @@ class Oracle:
         fs = self.score_all_frames(gene, indep, seq)
         fwd, rev = self.save_prev_stops(seq, prm)
         return orfs, [self.mg_score_orf(fs, seq, fwd, rev, int(o[0]), int(o[1]), prm) for o in orfs]
+
+    # ---- glimmer-mg's error branch (-i / -s)
+    @staticmethod
+    def mg_err_params(allow_indels=False, allow_subs=False, indel_quality_threshold=18, indel_max=2,
+                      indel_suffix_score_threshold=-12.0):
+        """defaults of src/Glimmer/glimmer-mg.cc:134-138"""
+        return MgErrParams(int(allow_indels), int(allow_subs), indel_quality_threshold, indel_max, indel_suffix_score_threshold)
+
+    def find_orfs_err(self, seq, prm, min_indel_orf_len=15):
+        s = seq.encode() if isinstance(seq, str) else seq
+        cap = 2 * len(s) + 16
+        buf = (Orf * cap)()
+        n = self.L.orc_find_orfs_err(s, len(s), C.byref(prm), min_indel_orf_len, buf, cap)
+        assert n <= cap
+        return np.array([(o.frame, o.stop_position, o.gene_len, o.orf_len) for o in buf[:n]], np.int32).reshape(-1, 4)
+
+    def quality_454(self, seq, user=None, indel_quality_threshold=18):
+        """Quality_Values of a read: Set_Quality_454 (no file) or Clean_Quality_454 of the user's values -> int32 [n]"""
+        s = seq.encode() if isinstance(seq, str) else seq
+        q = np.zeros(max(len(s), 1), np.int32) if user is None else np.ascontiguousarray(user, np.int32).copy()
+        ip = C.POINTER(C.c_int)
+        if user is None:
+            self.L.orc_set_quality_454(s, len(s), q.ctypes.data_as(ip))
+        else:
+            assert len(q) == len(s)
+            self.L.orc_clean_quality_454(s, len(s), q.ctypes.data_as(ip), indel_quality_threshold)
+        return q[:len(s)]
+
+    def mg_score_orf_errors(self, frame_scores, seq, fwd_prev, rev_next, quality, frame, stop_position, prm, ep, cap=1 << 16):
+        """-> (MgOut, [StartErr] in push order)"""
+        s = seq.encode() if isinstance(seq, str) else seq
+        fs = np.ascontiguousarray(frame_scores, np.float64)
+        ip = C.POINTER(C.c_int)
+        qp = None if quality is None else np.ascontiguousarray(quality, np.int32).ctypes.data_as(ip)
+        while True:
+            starts = (StartErr * cap)()
+            out = MgOut()
+            n = self.L.orc_mg_score_orf_errors(fs.ctypes.data_as(dp), s, len(s), fwd_prev.ctypes.data_as(ip),
+                                               rev_next.ctypes.data_as(ip), qp, frame, stop_position, C.byref(prm),
+                                               C.byref(ep), starts, cap, C.byref(out))
+            if n <= cap:
+                return out, list(starts[:n])
+            cap = n
+
+    def mg_read_errors(self, gene, indep, seq, prm, ep, user_quality=None, min_indel_orf_len=15):
+        """front half of one read with the error branch: -> (orfs [n,4], quality, [(MgOut, [StartErr])])"""
+        orfs = self.find_orfs_err(seq, prm, min_indel_orf_len)
+        quality = self.quality_454(seq, user_quality, ep.indel_quality_threshold) if ep.allow_indels else None
+        if len(orfs) == 0:
+            return orfs, quality, []
+        fs = self.score_all_frames(gene, indep, seq)
+        fwd, rev = self.save_prev_stops(seq, prm)
+        return orfs, quality, [self.mg_score_orf_errors(fs, seq, fwd, rev, quality, int(o[0]), int(o[1]), prm, ep) for o in orfs]
 
     def fasta_records(self, data):
         """the loop  while (Fasta_Read (fp, s, hdr))  -> [(hdr bytes, tolower(Filter(s)) bytes)], gc count"""

@@ -109,3 +109,81 @@ def test_prev_stop_tables_match_a_plain_scan(oracle, seqs_fa):
                 want = b
                 break
         assert rev[i] == want
+
+
+# ---- the error branch (-i indels / -s substitutions): Score_Indels + the recursive Score_Orf_Starts ----
+ERR_CASES = {
+    "mg_err_indel": (dict(), dict(allow_indels=True), False),
+    "mg_err_sub": (dict(), dict(allow_subs=True), False),
+    "mg_err_indel_q": (dict(), dict(allow_indels=True), True),
+    "mg_err_indel_g90": (dict(min_gene_len=90, stop_codons=("taa", "tag")), dict(allow_indels=True), False),
+}
+
+
+def read_fasta_file(path):
+    recs = open(path).read().split(">")[1:]
+    return [r.split("\n", 1)[1].replace("\n", "") for r in recs]
+
+
+def read_qual_file(path):
+    recs = open(path).read().split(">")[1:]
+    return [np.array(r.split("\n", 1)[1].split(), np.int32) for r in recs]
+
+
+def err_case(oracle, name):
+    kw, ekw, with_q = ERR_CASES[name]
+    kw = dict(kw)
+    reads = [oracle.filter_lower(s) for s in read_fasta_file(os.path.join(DATA, "seqs80.fa"))]
+    ct = sum(s.count(b"g") + s.count(b"c") for s in reads)
+    gc = float(ct) / sum(len(s) for s in reads)                     # Set_GC_Fraction on the file the reference was given
+    stops = kw.get("stop_codons", ("taa", "tag", "tga"))
+    kw["ignore_score_len"] = ignore_score_len(gc, stops)
+    quals = read_qual_file(os.path.join(DATA, "seqs80.qual")) if with_q else [None] * len(reads)
+    return reads, quals, oracle.mg_params(**kw), oracle.mg_err_params(**ekw), oracle.indep(gc, stops), gc, kw, ekw
+
+
+def err_rows(starts):
+    return [(s.s.j, s.s.pos, s.s.which, s.s.truncated, s.s.first, s.n_errors, s.err_pos[0], s.err_type[0],
+             s.err_pos[1], s.err_type[1], s.s.score) for s in starts]
+
+
+def err_golden_rows(g, b, cnt):
+    return [tuple(int(x) for x in r) + (float(s),) for r, s in zip(g["start_int"][b:b + cnt], g["start_score"][b:b + cnt])]
+
+
+@pytest.mark.parametrize("name", sorted(ERR_CASES))
+def test_mg_error_branch_matches_reference_push_order(oracle, name):
+    """every accepted ORF's start list, IN THE ORDER Score_Orf_Starts pushed it (the reference's list right before its
+    sort, oracle/ref_drivers/ref_mg_orfs.cc), with the Error_t entries and the double scores: exact equality"""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    nc = oracle.read(os.path.join(DATA, "NC_000915.icm"))
+    reads, quals, prm, ep, indep, _, _, _ = err_case(oracle, name)
+    gold_orfs = g["orfs"]
+    accepted = {int(o): i for i, o in enumerate(g["gene_orf"])}
+    base = n_checked = n_amb = 0
+    for r, seq in enumerate(reads):
+        orfs, _, scored = oracle.mg_read_errors(nc, indep, seq, prm, ep, quals[r])
+        want = gold_orfs[gold_orfs[:, 0] == r][:, 1:]
+        assert np.array_equal(orfs, want), "Find_Orfs differs on read %d" % r
+        for k, (out, starts) in enumerate(scored):
+            oi = base + k
+            if oi in accepted:
+                gi = accepted[oi]
+                assert out.accepted in (1, 2)
+                assert err_rows(starts) == err_golden_rows(g, int(g["gene_start_begin"][gi]), int(g["gene_nstarts"][gi])), (r, k)
+                n_checked += 1
+            else:
+                assert out.accepted in (0, 2)       # 2: ties on pos leave first_j to the reference's unstable sort
+            n_amb += out.accepted == 2
+        base += len(orfs)
+    assert base == len(gold_orfs)
+    assert n_checked == len(accepted) > 20
+    assert n_amb * 20 <= base
+
+
+def test_quality_454_definitions(oracle):
+    """Set_Quality_454: 31 inside a homopolymer run, 31 - 5 r (r < 6, else 6) on its last base"""
+    q = oracle.quality_454(b"acccgttttttttaag")
+    assert list(q) == [26, 31, 31, 16, 26, 31, 31, 31, 31, 31, 31, 31, 6, 31, 21, 26]
+    q = oracle.quality_454(b"aacg", user=[0, 5, 40, -3])
+    assert list(q) == [19, 5, 40, 1]
