@@ -371,16 +371,33 @@ def find_orfs(reads, min_gene_len=75, allow_truncated=False, start_codons=("atg"
     return orfs[:n_orfs.value], off
 
 
+START_ERRORS_DTYPE = np.dtype([("pos", "<i4", (2,)), ("type", "i1", (2,)), ("n", "i1"), ("reserved", "i1")])
+MG_ACCEPTED_ONLY, MG_ALLOW_INDELS, MG_ALLOW_SUBS = 1, 2, 4
+
+
 def mg_score_reads(gene, null, reads, min_gene_len=75, allow_truncated=True, ignore_score_len=2**31 - 1,
                    start_threshold=-6.0, start_codons=("atg", "gtg", "ttg"), stop_codons=("taa", "tag", "tga"),
-                   frame_scores=None, accepted_only=False):
+                   frame_scores=None, accepted_only=False, allow_indels=False, allow_subs=False, quality=None,
+                   min_indel_orf_len=15, indel_quality_threshold=18, indel_max=2, indel_suffix_score_threshold=-12.0):
     """glimmer-mg's front half for a batch of reads (include/gmg.h: gmg_mg_score_reads): Score_All_Frames,
     Find_Orfs, Score_Orf_Starts and the filter of Score_Orfs_Errors.
     -> (orfs[MG_ORF_DTYPE], starts[START_DTYPE], read_orf_off[uint64 n_reads+1]).
-    frame_scores: optional _DeviceBuffer of 6*total_bases doubles that receives the Frame_Scores table."""
-    assert MG_ORF_DTYPE.itemsize == 56
+    frame_scores: optional _DeviceBuffer of 6*total_bases doubles that receives the Frame_Scores table.
+    allow_indels / allow_subs: glimmer-mg's error branch (-i / -s); the starts' Error_t lists come back as a fourth
+    array (START_ERRORS_DTYPE, parallel to starts).  quality: uint8 Phred values of all bases (the -q file), or None
+    for Set_Quality_454."""
+    assert MG_ORF_DTYPE.itemsize == 56 and START_ERRORS_DTYPE.itemsize == 12
+    err = bool(allow_indels or allow_subs)
+    flags = (MG_ACCEPTED_ONLY if accepted_only else 0) | (MG_ALLOW_INDELS if allow_indels else 0) | (MG_ALLOW_SUBS if allow_subs else 0)
     prm = capi.MgParams(min_gene_len, int(allow_truncated), ignore_score_len, len(start_codons), len(stop_codons),
-                        1 if accepted_only else 0, start_threshold)
+                        flags, start_threshold)
+    prm.min_indel_orf_len, prm.indel_quality_threshold, prm.indel_max = min_indel_orf_len, indel_quality_threshold, indel_max
+    prm.indel_suffix_score_threshold = indel_suffix_score_threshold
+    if quality is not None:
+        quality = np.ascontiguousarray(quality, np.uint8)
+        if quality.size != reads.total_bases:
+            raise ValueError("quality needs one value per base of the batch")
+        prm.quality = quality.ctypes.data
     for i, c in enumerate(start_codons):
         prm.start_codon[i].value = c.encode()
     for i, c in enumerate(stop_codons):
@@ -395,8 +412,13 @@ def mg_score_reads(gene, null, reads, min_gene_len=75, allow_truncated=True, ign
         starts = np.zeros(max(n_starts.value, 1), START_DTYPE)
         off = np.zeros(reads.n_reads + 1, np.uint64)
         _ck(capi.lib().gmg_mg_result_fetch(res, _ptr(orfs), _ptr(starts), _ptr(off)))
+        if err:
+            errs = np.zeros(max(n_starts.value, 1), START_ERRORS_DTYPE)
+            _ck(capi.lib().gmg_mg_result_fetch_errors(res, _ptr(errs)))
     finally:
         capi.lib().gmg_mg_result_free(res)
+    if err:
+        return orfs[:n_orfs.value], starts[:n_starts.value], off, errs[:n_starts.value]
     return orfs[:n_orfs.value], starts[:n_starts.value], off
 
 

@@ -26,7 +26,10 @@ class MgParams(C.Structure):
     _fields_ = [("min_gene_len", C.c_int32), ("allow_truncated", C.c_int32), ("ignore_score_len", C.c_int32),
                 ("n_start_codons", C.c_int32), ("n_stop_codons", C.c_int32), ("flags", C.c_int32),
                 ("start_threshold", C.c_double), ("start_codon", (C.c_char * 4) * 8),
-                ("stop_codon", (C.c_char * 4) * 8)]
+                ("stop_codon", (C.c_char * 4) * 8),
+                # the error branch (GMG_MG_ALLOW_INDELS / GMG_MG_ALLOW_SUBS)
+                ("min_indel_orf_len", C.c_int32), ("indel_quality_threshold", C.c_int32), ("indel_max", C.c_int32),
+                ("reserved", C.c_int32), ("indel_suffix_score_threshold", C.c_double), ("quality", C.c_void_p)]
 
 
 PROTOTYPES = {
@@ -61,6 +64,7 @@ PROTOTYPES = {
     "gmg_find_orfs": (i32, [vp, vp, C.POINTER(vp), vp]),
     "gmg_mg_result_info": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
     "gmg_mg_result_fetch": (i32, [vp, vp, vp, vp]),
+    "gmg_mg_result_fetch_errors": (i32, [vp, vp]),
     "gmg_mg_result_free": (i32, [vp]),
     "gmg_trim_cache": (i32, []),
     "gmg_score_reads_strings": (i32, [vp, i32, vp, vp, vp]),

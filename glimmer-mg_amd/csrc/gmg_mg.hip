@@ -28,6 +28,7 @@
 
 #include <float.h>
 #include <limits.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -39,6 +40,7 @@
 struct gmg_mg_result {
     gmg_mg_orf *d_orfs;
     gmg_start *d_starts;
+    gmg_start_errors *d_errs;    // error branch only: parallel to d_starts
     uint64_t *d_read_orf_off;    // [n_reads + 1]
     uint64_t n_reads, n_orfs, n_starts;
 };
@@ -76,6 +78,14 @@ struct MgArgs {
     uint32_t *orf_cnt;           // [n_orfs + 1] starts per ORF
     const uint64_t *start_off;   // its exclusive scan
     gmg_start *starts;
+    // the error branch (glimmer-mg -i / -s), k_mg_err_starts
+    int err_mode;                // 0 off, 1 indels, 2 substitutions
+    int min_indel_orf_len, indel_q_thr, indel_max;
+    double indel_suffix_thr;
+    const uint8_t *qual;         // [total] Quality_Values after Set_ / Clean_Quality_454 (k_mg_quality)
+    const double *pen;           // [256] Score_Indels' score_penalty by quality value (host libm, like the reference)
+    double pass_stop[4];         // Pass_Stop_Penalty by (second base is a/t) * 2 + (third base is a/t)
+    gmg_start_errors *errs;
 };
 
 // Ch_Mask (src/Common/gene.cc:954-995)
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
         gmg_mg_orf *out = WRITE ? a.orfs + a.read_orf_off[r] : nullptr;
 
         auto emit = [&](int stop_position, int frame, int gene_len, int orf_len, int lo, int hi) __attribute__((always_inline)) {
-            if (gene_len >= mgl) {                      // glimmer_base.cc:494,528,806 (no indel / substitution branch)
+            if (gene_len >= mgl || (a.err_mode && orf_len >= a.min_indel_orf_len)) {   // glimmer_base.cc:494,528,806
                 if (WRITE) {
                     gmg_mg_orf o;
                     o.read = (uint32_t)r; o.frame = frame; o.stop_position = stop_position;
@@ -657,6 +667,234 @@ __global__ __launch_bounds__(256) void k_mg_starts(MgArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The error branch: Score_Orf_Starts with Score_Indels (-i) or the substitution branch (-s),
+// src/Glimmer/glimmer-mg.cc:1513-1602, 1693-1861.  The reference recurses: while it scans an ORF from the 5'
+// end to the 3' end it branches, at every low-quality base (-i) or once through the previous stop codon (-s),
+// into another Score_Orf_Starts that starts in another reading frame with the score of the suffix kept so far;
+// every call pushes its starts onto ONE list.  Each call sums Frame_Scores sequentially from ITS OWN end point
+// (Cumulative_Frame_Score, :561-604), so no shared running sums: one lane per ORF walks the whole call tree.
+//
+// The lane walks every call from the 3' end to the 5' end (the direction of the sum; the end of the region is
+// the first in-frame stop codon it meets, which is what the Fwd_Prev_Stops / Rev_Next_Stops tables hold,
+// :675-729) -- the REVERSE of the reference's scan.  So it visits the call tree in exactly reversed order
+// (per position: own start, insertion branch, deletion branch; the substitution branch last) and fills the
+// ORF's slice of the start array from the back: entry by entry that reproduces the reference's push order,
+// which the caller needs because the reference sorts the list with an unstable sort on pos alone
+// (glimmer_base.hh:90) and paths tie on pos.  A count pass sizes the slices.
+//   * an in-frame codon is handled one codon late, when it is known whether it was the last of the region: the
+//     truncated start (:1818-1846) goes between the real start of that codon and its indel branches;
+//   * "first" (:1833) is the 5'-most start of a call: the last one this walk emits, patched at the end.
+// ---------------------------------------------------------------------------------------------------
+#define MG_NO_SLOT 0xffffffffu
+
+struct MgErrRun {                // what one ORF's walk accumulates
+    uint32_t count, end;         // starts so far; WRITE: one past the next free slot (filled backwards)
+    double best;                 // best boosted score
+    int ext_pos, ext_jmin, ext_jmax;     // the extreme pos (lowest forward, highest reverse) and the j's seen there
+    int m0, trunc0;              // the ORF's own call: region length and orf_is_truncated
+};
+
+// Set_Quality_454 (glimmer-mg.cc:1865-1906) / Clean_Quality_454 (:519-546): one lane per base
+__global__ __launch_bounds__(256) void k_mg_quality(MgArgs a, const uint8_t *user, uint8_t *out)
+{
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = mg_lower_bound(a, g + 1) - 1;                 // the read that holds base g
+        const uint64_t b = a.read_off[r], e = a.read_off[r + 1];
+        auto code = [&](uint64_t x) { return (a.packed[x >> 4] >> (2u * (unsigned)(x & 15))) & 3u; };
+        const uint32_t c = code(g);
+        const bool inside = g + 1 < e && code(g + 1) == c;              // not the last base of its homopolymer run
+        int q;
+        if (user) {
+            q = user[g];
+            if (q <= 0) q = 1;
+            if (inside && q < a.indel_q_thr + 1) q = a.indel_q_thr + 1;
+        } else if (inside) q = 31;
+        else {
+            int run = 1;
+            while (run < 6 && g >= b + run && code(g - run) == c) run++;
+            q = run < 6 ? 31 - 5 * run : 6;
+        }
+        out[g] = (uint8_t)(q > 255 ? 255 : q);
+    }
+}
+
+template <bool WRITE, int LEVEL>
+__device__ void mg_err_walk(const MgArgs &a, const int8_t *s_which, MgErrRun &R, const bool fwd, const int64_t off, const int n,
+                            const int end_point, const double suffix_score, const int suffix_j,
+                            const int e0pos, const int e0type, const int e1pos, const int e1type)
+{
+    const int mgl = a.min_gene_len;
+    const int lowest_j = mgl - 3 < 3 ? mgl - 3 : 3;
+    const int anchor = end_point - 1;                   // read index of buffer position 0 (Reverse_ / Complement_Transfer, :1733,1754)
+    if (anchor < 0 || anchor >= n) {
+        // Fwd_Prev_Stop / Rev_Next_Stop outside the read return their argument (:642-652, 1436-1445): an empty region.
+        // (the substitution branch starts from level 0 only, whose end points lie inside the read)
+        return;
+    }
+    const int avail = fwd ? anchor + 1 : n - anchor;    // bases from the anchor to the end of the read, walking direction
+    const int64_t dir = fwd ? -1 : 1;
+    const uint32_t comp = fwd ? 0u : 3u;
+    const int64_t g0 = off + anchor;
+    const double *row[3];                               // Frame_Scores row of buffer position j: f = 1, 2, 0, ... (:561-604)
+    row[0] = a.fs + (uint64_t)(fwd ? 1 : 4) * a.fs_stride;
+    row[1] = a.fs + (uint64_t)(fwd ? 2 : 5) * a.fs_stride;
+    row[2] = a.fs + (uint64_t)(fwd ? 0 : 3) * a.fs_stride;
+
+    int64_t g = g0;
+    uint32_t w = a.packed[g >> 4];
+    auto next_code = [&]() __attribute__((always_inline)) {
+        const uint32_t c = ((w >> (2u * (unsigned)(g & 15))) & 3u) ^ comp;
+        const int64_t g2 = g + dir;
+        if ((g ^ g2) >> 4) w = a.packed[g2 >> 4];       // word -1 / one past the end: the guard words of gmg_reads
+        g = g2;
+        return c;
+    };
+
+    double sum = 0.0;
+    uint32_t last_own = MG_NO_SLOT;
+    bool first_done = false, trunc = false;
+
+    auto emit = [&](double raw, int j_full, int pos, int which, int truncated, int first) __attribute__((always_inline)) -> uint32_t {
+        const double sc = (j_full > a.ignore_score_len && 0.0 > raw) ? 0.0 : raw;       // Max (0.0, score), :1644-1646
+        if (R.count == 0 || (fwd ? pos < R.ext_pos : pos > R.ext_pos)) { R.ext_pos = pos; R.ext_jmin = R.ext_jmax = j_full; }
+        else if (pos == R.ext_pos) { if (j_full < R.ext_jmin) R.ext_jmin = j_full; if (j_full > R.ext_jmax) R.ext_jmax = j_full; }
+        if (sc > R.best) R.best = sc;
+        R.count++;
+        uint32_t slot = MG_NO_SLOT;
+        if (WRITE) {
+            slot = --R.end;
+            gmg_start st;
+            st.score = sc; st.j = j_full; st.pos = pos; st.which = which; st.truncated = (int16_t)truncated; st.first = (int16_t)first;
+            a.starts[slot] = st;
+            gmg_start_errors er;
+            er.pos[0] = LEVEL > 0 ? e0pos : 0; er.pos[1] = LEVEL > 1 ? e1pos : 0;
+            er.type[0] = (int8_t)(LEVEL > 0 ? e0type : 0); er.type[1] = (int8_t)(LEVEL > 1 ? e1type : 0);
+            er.n = LEVEL; er.reserved = 0;
+            a.errs[slot] = er;
+        }
+        return slot;
+    };
+
+    // the three positions of in-frame codon t; idx = (buff[3t+2], buff[3t+1], buff[3t]) as Codon_t holds them
+    auto codon = [&](const int t, const uint32_t idx, const bool is_last) __attribute__((always_inline)) {
+#pragma unroll 1
+        for (int jj = 0; jj < 3; jj++) {
+            const int j = 3 * t + jj;
+            const int64_t gj = g0 + dir * j;
+            const double prev = sum;
+            sum = prev + row[jj][gj];                   // score[j] = cum_score + Frame_Scores[f][si]
+            if (j < lowest_j) continue;
+            const int k = fwd ? end_point - 2 - j : end_point + 2 + j;       // :1742,1762,1855-1858
+            if (jj == 0 && j + 3 + suffix_j >= mgl) {
+                const int which = s_which[idx];
+                const double raw = (prev - 0.0) + suffix_score;             // next_s + suffix_score, :1826-1834
+                if (which >= 0) last_own = emit(raw, j + 2 + suffix_j, k, which, 0, 0);
+                if (is_last && trunc) { emit(raw, j + 2 + suffix_j, k, -1, 1, 1); first_done = true; }
+            }
+            if constexpr (LEVEL < 2) {
+                if (a.err_mode == 1 && LEVEL < a.indel_max) {
+                    const int q = a.qual[gj];
+                    if (q <= a.indel_q_thr) {           // Score_Indels (:1513-1602); reversed order: insertion, then deletion
+                        const double pen = a.pen[q];
+                        const int sj = suffix_j + j + 2 - jj;
+#pragma unroll 1
+                        for (int br = 0; br < 2; br++) {
+                            const double es = ((suffix_score + (br == 0 ? prev : sum)) - 0.0) + pen;
+                            if (!(es > a.indel_suffix_thr)) continue;
+                            int ep, epos;
+                            if (br == 0) { ep = fwd ? k - (2 - jj) : k + 2 - jj; epos = fwd ? k + 2 : k - 2; }
+                            else { ep = fwd ? k + jj : k - jj; epos = fwd ? k + 3 : k - 1; }
+                            mg_err_walk<WRITE, LEVEL + 1>(a, s_which, R, fwd, off, n, ep, es, sj,
+                                                                          LEVEL == 0 ? epos : e0pos, LEVEL == 0 ? br : e0type,
+                                                                          LEVEL == 1 ? epos : 0, LEVEL == 1 ? br : 0);
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    uint32_t pidx = 0;
+    bool pending = false;
+    int t = 0;
+    for (;; t++) {
+        bool end = avail - 3 * t < 3;                   // no whole codon left: the virtual stop around the read (:685,708-710)
+        uint32_t idx = 0;
+        if (end) trunc = a.allow_truncated != 0;        // :1741,1761 -- lo < 3 / Sequence_Len - (hi-1) < 3 exactly when no real stop closed the region
+        else {
+            const uint32_t c0 = next_code(), c1 = next_code(), c2 = next_code();
+            idx = c2 << 4 | c1 << 2 | c0;
+            end = (a.fwd_stop >> idx) & 1;              // Must_Be (Fwd_Stop_Pattern) on the buffer's codon, both strands (:689-728)
+        }
+        if (pending) codon(t - 1, pidx, end);
+        if (end) break;
+        pidx = idx;
+        pending = true;
+    }
+    const int m = 3 * t;                                // len = hi - lo
+    if (LEVEL == 0) { R.m0 = m; R.trunc0 = trunc; }
+
+    if constexpr (LEVEL == 0) if (a.err_mode == 2) {    // mutate the previous stop codon (:1771-1806); first in the reference's order
+        const int lo = fwd ? end_point - m : end_point, hi = fwd ? end_point : end_point + m;
+        const int eep = fwd ? lo - 3 : hi + 3;
+        if (eep >= 0 && eep - 2 < n) {
+            auto base = [&](int i) { const int64_t x = off + i; return (a.packed[x >> 4] >> (2u * (unsigned)(x & 15))) & 3u; };
+            const uint32_t want = fwd ? 0u : 3u;        // 'a' forward, 't' reverse (Pass_Stop_Penalty, :961-995)
+            const int a1 = base(fwd ? lo - 2 : hi) == want, a2 = base(fwd ? lo - 1 : hi - 1) == want;
+            double es = suffix_score + a.pass_stop[a1 * 2 + a2];
+            if (m > 0) es += sum - 0.0;
+            mg_err_walk<WRITE, 1>(a, s_which, R, fwd, off, n, eep, es, suffix_j + m, fwd ? lo - 2 : hi + 2, 2, 0, 0);
+        }
+    }
+    if (WRITE && !first_done && last_own != MG_NO_SLOT) a.starts[last_own].first = 1;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_mg_err_starts(MgArgs a)
+{
+    __shared__ int8_t s_which[64];
+    if (threadIdx.x < 64) s_which[threadIdx.x] = a.which[threadIdx.x];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x) {
+        gmg_mg_orf o = a.orfs[i];
+        const bool fwd = o.frame > 0;
+        const int64_t off = (int64_t)a.read_off[o.read];
+        const int n = (int)(a.read_off[o.read + 1] - a.read_off[o.read]);
+        MgErrRun R;
+        R.count = 0; R.end = WRITE ? (uint32_t)a.start_off[i + 1] : 0; R.best = -DBL_MAX; R.ext_pos = 0; R.ext_jmin = R.ext_jmax = 0;
+        R.m0 = 0; R.trunc0 = 0;
+        // Score_Orfs_Errors (:1637-1642): end_point = stop - 1 forward, stop + 3 reverse
+        mg_err_walk<WRITE, 0>(a, s_which, R, fwd, off, n, fwd ? o.stop_position - 1 : o.stop_position + 3, 0.0, 0, 0, 0, 0, 0);
+        if (!WRITE) { a.orf_cnt[i] = R.count; continue; }
+        // Score_Orf_Starts' own bounds (:1730-1757): Find_Orfs also emits ORFs whose stop position is a placeholder
+        // (Do_Rev_Stop_Codon without truncated ORFs, glimmer_base.cc:515-519), for which the scan's lo / hi do not apply
+        if (fwd) { o.hi = o.stop_position - 1; o.lo = o.hi - R.m0; }
+        else { o.lo = o.stop_position + 3; o.hi = o.lo + R.m0; }
+        o.orf_is_truncated = (int16_t)R.trunc0;
+        o.start_begin = (uint32_t)a.start_off[i];
+        o.n_starts = R.count;
+        o.first_j = R.count ? R.ext_jmin : 0;
+        o.best_score = -DBL_MAX;
+        o.accepted = 0;
+        if (R.count > 0 && R.ext_jmax + 1 >= a.min_gene_len) {          // glimmer-mg.cc:1656-1676
+            o.best_score = R.best;
+            if (R.best > a.start_threshold) o.accepted = R.ext_jmin + 1 >= a.min_gene_len ? 1 : 2;
+        }
+        a.orfs[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mg_keep_gather_errs(const gmg_mg_orf *orfs, const gmg_start_errors *errs, uint64_t n,
+                                                             const uint64_t *new_start, gmg_start_errors *out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const gmg_mg_orf o = orfs[i];
+        if (!o.accepted) continue;
+        for (uint32_t t = 0; t < o.n_starts; t++) out[new_start[i] + t] = errs[o.start_begin + t];
+    }
+}
+
 // GMG_MG_ACCEPTED_ONLY: keep the ORFs that go to Add_Events_* and their start lists, packed, in the same order
 __global__ __launch_bounds__(256) void k_mg_keep_counts(const gmg_mg_orf *orfs, uint64_t n, uint32_t *keep, uint32_t *keep_starts)
 {
@@ -738,7 +976,7 @@ static int mg_scan(uint32_t *d_cnt, uint64_t *d_off, uint64_t n, uint64_t *total
 extern "C" int gmg_mg_result_free(gmg_mg_result *r)
 {
     if (!r) return GMG_OK;
-    void *ptrs[] = {r->d_orfs, r->d_starts, r->d_read_orf_off};
+    void *ptrs[] = {r->d_orfs, r->d_starts, r->d_read_orf_off, r->d_errs};
     for (void *p : ptrs)
         if (p) gmg_pool_release(p);
     delete r;
@@ -771,6 +1009,11 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (!find_only && (gene->dev.P != 3 || nul->dev.P != 3))
         return gmg_set_error(GMG_EBADMODEL, "gmg_mg_score_reads: Score_All_Frames needs models of periodicity 3");
     if (reads->n_reads >= 0x7fffffffull) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large");
+    const int err_mode = (prm->flags & GMG_MG_ALLOW_INDELS) ? 1 : (prm->flags & GMG_MG_ALLOW_SUBS) ? 2 : 0;
+    if ((prm->flags & GMG_MG_ALLOW_INDELS) && (prm->flags & GMG_MG_ALLOW_SUBS))     // glimmer-mg.cc:952-955
+        return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: cannot use indels and substitutions simultaneously");
+    if (err_mode && (prm->indel_max < 0 || prm->indel_max > 2 || prm->indel_quality_threshold < 0 || prm->indel_quality_threshold > 254))
+        return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: need indel_max in 0..2 and indel_quality_threshold in 0..254");
     hipStream_t s = (hipStream_t)stream;
 
     MgArgs a;
@@ -784,6 +1027,25 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     a.allow_truncated = prm->allow_truncated;
     a.ignore_score_len = prm->ignore_score_len;
     a.start_threshold = prm->start_threshold;
+    a.err_mode = err_mode;
+    double pen_host[256];
+    if (err_mode) {
+        a.min_indel_orf_len = prm->min_indel_orf_len;
+        a.indel_q_thr = prm->indel_quality_threshold;
+        a.indel_max = prm->indel_max;
+        a.indel_suffix_thr = prm->indel_suffix_score_threshold;
+        for (int q = 0; q < 256; q++) {                 // Score_Indels (glimmer-mg.cc:1522-1523), the host's libm like the reference
+            const double prob_err = pow(10.0, -(double)q / 10.0);
+            pen_host[q] = log(prob_err / 2.0) - log(1.0 - prob_err);
+        }
+        for (int k = 0; k < 4; k++) {                   // Pass_Stop_Penalty (glimmer-mg.cc:961-995) without quality values
+            const double default_p = 0.999;
+            double p_stop = default_p;
+            if (k & 2) p_stop *= 2.0 / 3.0 * default_p + 1.0 / 3.0; else p_stop *= default_p;
+            if (k & 1) p_stop *= 2.0 / 3.0 * default_p + 1.0 / 3.0; else p_stop *= default_p;
+            a.pass_stop[k] = log(1.0 - p_stop) - log(p_stop);
+        }
+    }
     {   // Set_Start_And_Stop_Codons (glimmer_base.cc:2683-2704) -> one bit / one byte per definite codon
         unsigned f_start[8], r_start[8], f_stop[8], r_stop[8];
         for (int p = 0; p < prm->n_start_codons; p++) { f_start[p] = mg_codon_from(prm->start_codon[p]); r_start[p] = mg_codon_revcomp(f_start[p]); }
@@ -818,6 +1080,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     uint32_t *d_unfit = nullptr;
     uint32_t *d_ntiles = nullptr;
     void *d_sel_tmp = nullptr;
+    uint8_t *d_qual = nullptr, *d_user_q = nullptr;
+    double *d_pen = nullptr;
     int rc = GMG_OK;
     auto fail = [&](int code) {
         (void)hipDeviceSynchronize();                   // nothing (either stream) may still use the blocks that go back to the cache
@@ -831,6 +1095,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (d_all) gmg_pool_release(d_all);
         if (d_sel_tmp) gmg_pool_release(d_sel_tmp);
         if (d_unfit) gmg_pool_release(d_unfit);
+        if (d_qual) gmg_pool_release(d_qual);
+        if (d_user_q) gmg_pool_release(d_user_q);
+        if (d_pen) gmg_pool_release(d_pen);
         gmg_mg_result_free(res);
         return code;
     };
@@ -857,11 +1124,30 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     }
     a.fs = d_frame_scores;
     tm.lap("frame scores");
+    if (err_mode) {                                     // the error branch sums per call (k_mg_err_starts); it needs the qualities
+        MG_TRY(gmg_pool_alloc((void **)&d_pen, sizeof pen_host));
+        MG_TRY(hipMemcpyAsync(d_pen, pen_host, sizeof pen_host, hipMemcpyHostToDevice, s));
+        a.pen = d_pen;
+        if (err_mode == 1 && a.total) {
+            MG_TRY(gmg_pool_alloc((void **)&d_qual, a.total));
+            if (prm->quality) {
+                MG_TRY(gmg_pool_alloc((void **)&d_user_q, a.total));
+                MG_TRY(hipMemcpyAsync(d_user_q, prm->quality, a.total, hipMemcpyHostToDevice, s));
+            }
+            hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(a.total)), dim3(256), 0, s, a, d_user_q, d_qual);
+            MG_TRY(hipGetLastError());
+            a.qual = d_qual;
+        }
+        MG_TRY(hipStreamSynchronize(s));                // (pen_host is a stack buffer)
+        tm.lap("quality values");
+    }
     // running sums of every reading-frame class (what Cumulative_Frame_Score would give any ORF)
+    if (!err_mode) {
     MG_TRY(gmg_pool_alloc((void **)&d_cum, (size_t)2 * (a.total ? a.total : 1) * sizeof(double)));
     a.cum = d_cum;
     tm.lap("alloc running sums");
-    if (a.n_reads && a.total) {
+    }
+    if (!err_mode && a.n_reads && a.total) {
         // tile shape: two waves and <= 512 bases (12 KB of LDS, many blocks per CU in different phases) when the reads
         // allow it, else eight waves and 1504 bases (39.8 KB, four blocks per CU)
         const char *env = getenv("GMG_MG_TILE");
@@ -939,7 +1225,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     hipEvent_t side_done = nullptr;
     int dev_id = 0;
     MG_TRY(hipGetDevice(&dev_id));
-    if (!find_only && !tm.on && !getenv("GMG_MG_ONE_STREAM") && dev_id >= 0 && dev_id < 16) {
+    if (!find_only && !err_mode && !tm.on && !getenv("GMG_MG_ONE_STREAM") && dev_id >= 0 && dev_id < 16) {
         if (!side_of[dev_id]) {
             MG_TRY(hipStreamCreateWithFlags(&side_of[dev_id], hipStreamNonBlocking));
             MG_TRY(hipEventCreateWithFlags(&done_of[dev_id], hipEventDisableTiming));
@@ -972,7 +1258,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
     MG_TRY(gmg_pool_alloc((void **)&d_start_off, (no + 1) * 8));
     a.orf_cnt = d_orf_cnt;
-    if (no) hipLaunchKernelGGL(k_mg_starts<false>, dim3(grid_for(no)), dim3(256), 0, s2, a);
+    if (no && err_mode) hipLaunchKernelGGL(k_mg_err_starts<false>, dim3(grid_for(no)), dim3(256), 0, s2, a);
+    else if (no) hipLaunchKernelGGL(k_mg_starts<false>, dim3(grid_for(no)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
     rc = mg_scan(d_orf_cnt, d_start_off, no, &res->n_starts, s2);
     if (rc) return fail(rc);
@@ -980,11 +1267,16 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     MG_TRY(gmg_pool_alloc((void **)&res->d_starts, (res->n_starts ? res->n_starts : 1) * sizeof(gmg_start)));
     a.start_off = d_start_off;
     a.starts = res->d_starts;
+    if (err_mode) {
+        MG_TRY(gmg_pool_alloc((void **)&res->d_errs, (res->n_starts ? res->n_starts : 1) * sizeof(gmg_start_errors)));
+        a.errs = res->d_errs;
+    }
     if (s2 != s) {                                      // (mg_scan has synchronised the side stream already; the event keeps
         MG_TRY(hipEventRecord(side_done, s2));          //  the ordering explicit)
         MG_TRY(hipStreamWaitEvent(s, side_done, 0));
     }
-    if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
+    if (no && err_mode) hipLaunchKernelGGL(k_mg_err_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
+    else if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
     }
     if (!find_only && (prm->flags & GMG_MG_ACCEPTED_ONLY)) {
@@ -993,6 +1285,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         uint64_t *d_new_orf = nullptr, *d_new_st = nullptr, *d_new_first = nullptr;
         gmg_mg_orf *d_orfs2 = nullptr;
         gmg_start *d_starts2 = nullptr;
+        gmg_start_errors *d_errs2 = nullptr;
         uint64_t n_keep = 0, n_keep_st = 0;
         hipError_t e = gmg_pool_alloc((void **)&d_keep, (no + 1) * 4);
         if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_keep_st, (no + 1) * 4);
@@ -1008,7 +1301,10 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             if (!rc2) rc2 = mg_scan(d_keep_st, d_new_st, no, &n_keep_st, s);
             if (!rc2) e = gmg_pool_alloc((void **)&d_orfs2, (n_keep ? n_keep : 1) * sizeof(gmg_mg_orf));
             if (!rc2 && e == hipSuccess) e = gmg_pool_alloc((void **)&d_starts2, (n_keep_st ? n_keep_st : 1) * sizeof(gmg_start));
+            if (!rc2 && e == hipSuccess && err_mode) e = gmg_pool_alloc((void **)&d_errs2, (n_keep_st ? n_keep_st : 1) * sizeof(gmg_start_errors));
             if (!rc2 && e == hipSuccess) {
+                if (no && err_mode) hipLaunchKernelGGL(k_mg_keep_gather_errs, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, res->d_errs, no,
+                                                       d_new_st, d_errs2);
                 if (no) hipLaunchKernelGGL(k_mg_keep_gather, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, res->d_starts, no, d_new_orf,
                                            d_new_st, d_orfs2, d_starts2);
                 hipLaunchKernelGGL(k_mg_keep_reads, dim3(grid_for(nr + 1)), dim3(256), 0, s, res->d_read_orf_off, nr, d_new_orf, d_new_first);
@@ -1023,12 +1319,15 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (rc2 || e != hipSuccess) {
             if (d_orfs2) gmg_pool_release(d_orfs2);
             if (d_starts2) gmg_pool_release(d_starts2);
+            if (d_errs2) gmg_pool_release(d_errs2);
             if (d_new_first) gmg_pool_release(d_new_first);
             return fail(rc2 ? rc2 : gmg_set_error(GMG_EHIP, "gmg_mg_score_reads: packing the accepted ORFs: %s", hipGetErrorString(e)));
         }
         gmg_pool_release(res->d_orfs);
         gmg_pool_release(res->d_starts);
         gmg_pool_release(res->d_read_orf_off);
+        if (res->d_errs) gmg_pool_release(res->d_errs);
+        res->d_errs = d_errs2;
         res->d_orfs = d_orfs2;
         res->d_starts = d_starts2;
         res->d_read_orf_off = d_new_first;
@@ -1048,6 +1347,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (d_all) gmg_pool_release(d_all);
     if (d_sel_tmp) gmg_pool_release(d_sel_tmp);
     if (d_unfit) gmg_pool_release(d_unfit);
+    if (d_qual) gmg_pool_release(d_qual);
+    if (d_user_q) gmg_pool_release(d_user_q);
+    if (d_pen) gmg_pool_release(d_pen);
     tm.lap("free scratch");
     *out = res;
     return GMG_OK;
@@ -1069,6 +1371,15 @@ extern "C" int gmg_mg_result_info(const gmg_mg_result *r, uint64_t *n_orfs, uint
     if (!r) return gmg_set_error(GMG_EINVAL, "gmg_mg_result_info: NULL result");
     if (n_orfs) *n_orfs = r->n_orfs;
     if (n_starts) *n_starts = r->n_starts;
+    return GMG_OK;
+}
+
+extern "C" int gmg_mg_result_fetch_errors(const gmg_mg_result *r, gmg_start_errors *errs)
+{
+    if (!r || (r->n_starts && !errs)) return gmg_set_error(GMG_EINVAL, "gmg_mg_result_fetch_errors: NULL argument");
+    if (!r->n_starts) return GMG_OK;
+    if (!r->d_errs) { memset(errs, 0, r->n_starts * sizeof(gmg_start_errors)); return GMG_OK; }
+    GMG_HIP(hipMemcpy(errs, r->d_errs, r->n_starts * sizeof(gmg_start_errors), hipMemcpyDeviceToHost));
     return GMG_OK;
 }
 

@@ -268,6 +268,12 @@ int gmg_score_orfs(const gmg_model *gene, const gmg_model *null_model, const gmg
 /* gmg_mg_params.flags: return only the ORFs Score_Orfs_Errors would hand to Add_Events_* (accepted != 0) and their start
  * lists -- same order, packed on the device, read_orf_off counting the kept ORFs; typically a few per cent of all ORFs */
 #define GMG_MG_ACCEPTED_ONLY 1
+/* glimmer-mg's error branch (src/Glimmer/glimmer-mg.cc:1513-1602 Score_Indels, :1771-1806 the substitution branch of
+ * Score_Orf_Starts; exclusive, :952): Find_Orfs also keeps every ORF of orf_len >= Min_Indel_ORF_Len
+ * (glimmer_base.cc:494,528,806), Score_Orf_Starts recurses through frame shifts at low-quality bases (-i) or through
+ * the previous stop codon (-s), and every start carries the Error_t list of its path (gmg_mg_result_fetch_errors). */
+#define GMG_MG_ALLOW_INDELS 2    /* glimmer-mg -i / --indel */
+#define GMG_MG_ALLOW_SUBS 4      /* glimmer-mg -s / --sub   */
 
 typedef struct gmg_mg_params {
     int32_t min_gene_len;        /* Min_Gene_Len (>= 4)                                           */
@@ -275,11 +281,29 @@ typedef struct gmg_mg_params {
     int32_t ignore_score_len;    /* Ignore_Score_Len                                              */
     int32_t n_start_codons;      /* <= 8                                                          */
     int32_t n_stop_codons;       /* <= 8                                                          */
-    int32_t flags;               /* GMG_MG_ACCEPTED_ONLY or 0                                     */
+    int32_t flags;               /* GMG_MG_ACCEPTED_ONLY | GMG_MG_ALLOW_INDELS or GMG_MG_ALLOW_SUBS, or 0 */
     double start_threshold;      /* Start_Threshold                                               */
     char start_codon[8][4];      /* Start_Codon strings (IUPAC allowed)                           */
     char stop_codon[8][4];       /* Stop_Codon strings                                            */
+    /* the error branch; read only when flags has GMG_MG_ALLOW_INDELS or GMG_MG_ALLOW_SUBS */
+    int32_t min_indel_orf_len;   /* Min_Indel_ORF_Len (glimmer_base.cc:40: 15)                    */
+    int32_t indel_quality_threshold;     /* Indel_Quality_Threshold (glimmer-mg.cc:136: 18)       */
+    int32_t indel_max;           /* Indel_Max (glimmer-mg.cc:138: 2); 0..2                        */
+    int32_t reserved;
+    double indel_suffix_score_threshold; /* Indel_Suffix_Score_Threshold (glimmer-mg.cc:134: -12) */
+    const uint8_t *quality;      /* HOST, one Phred value per base, reads back to back (total_bases): the user's quality
+                                    file (-q), Clean_Quality_454 (glimmer-mg.cc:519-546) is applied on the device;
+                                    NULL: Set_Quality_454 (:1865-1906, homopolymer runs).  Indels only: with -s the
+                                    reference never loads the values (:384-392)                    */
 } gmg_mg_params;
+
+/* the Error_t list (src/Common/gene.hh:138-146) of one start: type 0 insertion, 1 deletion, 2 substitution */
+typedef struct gmg_start_errors {
+    int32_t pos[2];
+    int8_t type[2];
+    int8_t n;                    /* 0..2 entries                                                  */
+    int8_t reserved;
+} gmg_start_errors;
 
 typedef struct gmg_mg_orf {
     uint32_t read;               /* index into the gmg_reads batch                                */
@@ -289,7 +313,10 @@ typedef struct gmg_mg_orf {
     uint32_t start_begin, n_starts;      /* its start list: starts[start_begin .. +n_starts), in the
                                             order Score_Orf_Starts pushed them, boost applied      */
     int16_t accepted;            /* non-empty, first_j+1 >= Min_Gene_Len, best_score > Start_Threshold
-                                    (glimmer-mg.cc:1656-1676): the ORF goes to Add_Events_*        */
+                                    (glimmer-mg.cc:1656-1676): the ORF goes to Add_Events_*.  Error branch only: 2 =
+                                    best_score passes, but the starts at the extreme pos differ in j and only some
+                                    pass the length test -- first_j is whichever of them the reference's unstable
+                                    sort puts first, so the caller decides after ITS sort (first_j here: the smallest) */
     int16_t orf_is_truncated;
     int32_t reserved;
     double best_score;           /* max over the boosted start scores, -DBL_MAX if none           */
@@ -313,6 +340,8 @@ int gmg_mg_result_info(const gmg_mg_result *r, uint64_t *n_orfs, uint64_t *n_sta
 /* Copies the result to HOST buffers: orfs[n_orfs], starts[n_starts] and, if not NULL,
  * read_orf_off[n_reads + 1] (ORFs of read i are orfs[read_orf_off[i] .. read_orf_off[i+1])). */
 int gmg_mg_result_fetch(const gmg_mg_result *r, gmg_mg_orf *orfs, gmg_start *starts, uint64_t *read_orf_off);
+/* Error branch: errs[n_starts], parallel to starts (all-zero entries without the error flags). */
+int gmg_mg_result_fetch_errors(const gmg_mg_result *r, gmg_start_errors *errs);
 /* the same copies on `stream` (they then overlap the scoring of the next batch on another stream) */
 int gmg_mg_result_fetch_on(const gmg_mg_result *r, gmg_mg_orf *orfs, gmg_start *starts, uint64_t *read_orf_off,
                            void *stream);

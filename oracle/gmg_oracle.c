@@ -1097,7 +1097,7 @@ int orc_mg_score_orf_errors(const double *frame_scores, const char *seq, int n, 
                 }
             for (i = 0; i < c.n_starts; i++)
                 if (starts[i].s.score > best) best = starts[i].s.score;
-            out->first_j = starts[pick].s.j;
+            out->first_j = jmin;                                            /* (the smallest of the candidates) */
             if (jmin + 1 >= prm->min_gene_len) amb = 0;                     /* whichever comes first passes */
             else if (jmax + 1 < prm->min_gene_len) amb = -1;                /* none passes */
             else amb = 1;

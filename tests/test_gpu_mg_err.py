@@ -1,0 +1,112 @@
+"""glimmer-mg's error branch on the device (gmg_mg_score_reads with GMG_MG_ALLOW_INDELS / GMG_MG_ALLOW_SUBS;
+Score_Indels and the recursive Score_Orf_Starts, src/Glimmer/glimmer-mg.cc:1513-1861) against
+  * the reference's own start lists in PUSH order with their Error_t entries (tests/golden/mg_err_*.npz: the list as it
+    was right before Score_Orfs_Errors' sort, oracle/ref_drivers/ref_mg_orfs.cc) -- -i, -s, -i with a quality file,
+    -i with other gene length / stop codons;
+  * the oracle on seeded random reads of ragged lengths, EVERY ORF (also the rejected ones).
+Integer fields, error lists, order and double scores must be equal bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLD
+from test_oracle_mg import ERR_CASES, err_case, err_golden_rows, err_rows, ignore_score_len
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nc(gpu):
+    return gpu.Icm.open(os.path.join(DATA, "NC_000915.icm"))
+
+
+def dev_err_rows(starts, errs):
+    return [(int(s["j"]), int(s["pos"]), int(s["which"]), int(s["truncated"]), int(s["first"]), int(e["n"]),
+             int(e["pos"][0]), int(e["type"][0]), int(e["pos"][1]), int(e["type"][1]), float(s["score"]))
+            for s, e in zip(starts, errs)]
+
+
+def quality_array(quals):
+    return None if quals[0] is None else np.concatenate(quals).astype(np.uint8)
+
+
+@pytest.mark.parametrize("name", sorted(ERR_CASES))
+def test_error_branch_matches_reference_push_order(gpu, oracle, nc, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    seqs, quals, _, _, _, gc, kw, ekw = err_case(oracle, name)
+    stops = kw.get("stop_codons", ("taa", "tag", "tga"))
+    reads = gpu.Reads.from_strings([s.decode() for s in seqs])
+    orfs, starts, off, errs = gpu.mg_score_reads(nc, gpu.Icm.indep(gc, stops), reads, quality=quality_array(quals), **kw, **ekw)
+    got = np.stack([orfs["read"].astype(np.int32), orfs["frame"], orfs["stop_position"], orfs["gene_len"], orfs["orf_len"]], 1)
+    assert np.array_equal(got, g["orfs"])                               # Find_Orfs with the Min_Indel_ORF_Len rule
+    accepted = np.zeros(len(orfs), bool)
+    accepted[g["gene_orf"]] = True
+    sure = orfs["accepted"] != 2                                        # 2: left to the caller's sort (ties on pos)
+    assert np.array_equal((orfs["accepted"] == 1)[sure], accepted[sure])
+    assert (~sure).sum() * 20 <= len(orfs)
+    for oi, b, cnt in zip(g["gene_orf"], g["gene_start_begin"], g["gene_nstarts"]):
+        o = orfs[oi]
+        assert o["n_starts"] == cnt
+        sl = slice(o["start_begin"], o["start_begin"] + o["n_starts"])
+        assert dev_err_rows(starts[sl], errs[sl]) == err_golden_rows(g, int(b), int(cnt)), oi
+
+
+@pytest.mark.parametrize("ekw,with_q", [
+    (dict(allow_indels=True), False),
+    (dict(allow_indels=True), True),
+    (dict(allow_indels=True, indel_max=1, indel_quality_threshold=21, indel_suffix_score_threshold=-6.0), False),
+    (dict(allow_subs=True), False),
+])
+@pytest.mark.parametrize("kw", [dict(), dict(allow_truncated=False, min_gene_len=60), dict(ignore_score_len=150, start_codons=("atg", "rtg"))])
+def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q):
+    rng = np.random.default_rng(99)
+    lengths = [0, 1, 5, 14, 15, 16, 17, 18, 33, 74, 75, 76, 99, 150, 231, 300, 301, 302, 400, 523, 700]
+    seqs = ["".join("acgt"[c] for c in rng.integers(0, 4, size=n)) for n in lengths]
+    seqs.append("acg" * 120)                                            # no stop codon at all
+    seqs.append("a" * 40 + "".join("acgt"[c] for c in rng.integers(0, 4, size=200)) + "tttttttt" + "gggg" * 9)   # long runs
+    quals = [np.where(rng.random(len(s)) < 0.12, rng.integers(0, 19, len(s)), rng.integers(19, 41, len(s))).astype(np.int32)
+             for s in seqs] if with_q else [None] * len(seqs)
+    gc, stops = 0.5, kw.get("stop_codons", ("taa", "tag", "tga"))
+    reads = gpu.Reads.from_strings(seqs)
+    okw = {k: v for k, v in ekw.items() if k != "min_indel_orf_len"}
+    prm, ep = oracle.mg_params(**kw), oracle.mg_err_params(**okw)
+    o_nc, o_indep = oracle.read(os.path.join(DATA, "NC_000915.icm")), oracle.indep(gc, stops)
+    orfs, starts, off, errs = gpu.mg_score_reads(nc, gpu.Icm.indep(gc, stops), reads,
+                                                 quality=np.concatenate(quals).astype(np.uint8) if with_q else None, **kw, **ekw)
+    n_starts = n_children = 0
+    for r, s in enumerate(seqs):
+        want_orfs, _, scored = oracle.mg_read_errors(o_nc, o_indep, s.encode(), prm, ep, quals[r])
+        mine = orfs[int(off[r]):int(off[r + 1])]
+        assert np.array_equal(np.stack([mine["frame"], mine["stop_position"], mine["gene_len"], mine["orf_len"]], 1).reshape(-1, 4), want_orfs)
+        for o, (out, want) in zip(mine, scored):
+            sl = slice(o["start_begin"], o["start_begin"] + o["n_starts"])
+            assert dev_err_rows(starts[sl], errs[sl]) == err_rows(want), (r, o)
+            assert (int(o["lo"]), int(o["hi"]), int(o["accepted"])) == (out.lo, out.hi, out.accepted)
+            if out.accepted:
+                assert float(o["best_score"]) == out.best_score and int(o["first_j"]) == out.first_j
+            n_starts += len(want)
+            n_children += sum(1 for w in want if w.n_errors)
+    assert n_starts > 50 and n_children > 10
+
+
+def test_error_branch_accepted_only_and_flag_errors(gpu, oracle, nc):
+    seqs, _, _, _, _, gc, kw, _ = err_case(oracle, "mg_err_indel")
+    reads = gpu.Reads.from_strings([s.decode() for s in seqs])
+    full = gpu.mg_score_reads(nc, gpu.Icm.indep(gc), reads, allow_indels=True, **kw)
+    kept = gpu.mg_score_reads(nc, gpu.Icm.indep(gc), reads, allow_indels=True, accepted_only=True, **kw)
+    keep = full[0]["accepted"] != 0
+    assert len(kept[0]) == keep.sum() > 20
+    for a, b in zip(full[0][keep], kept[0]):
+        sa = slice(a["start_begin"], a["start_begin"] + a["n_starts"])
+        sb = slice(b["start_begin"], b["start_begin"] + b["n_starts"])
+        assert (a["read"], a["frame"], a["stop_position"], a["n_starts"]) == (b["read"], b["frame"], b["stop_position"], b["n_starts"])
+        assert np.array_equal(full[1][sa], kept[1][sb]) and np.array_equal(full[3][sa], kept[3][sb])
+    assert np.array_equal(kept[2], np.concatenate([[0], np.cumsum(keep)])[full[2].astype(np.int64)])
+    with pytest.raises(gpu.GmgError):                                   # glimmer-mg.cc:952: not both
+        gpu.mg_score_reads(nc, gpu.Icm.indep(gc), reads, allow_indels=True, allow_subs=True, **kw)
+    with pytest.raises(gpu.GmgError):
+        gpu.mg_score_reads(nc, gpu.Icm.indep(gc), reads, allow_indels=True, indel_max=3, **kw)
+    # the plain mode is untouched by the new fields, and find_orfs follows the flag
+    plain = gpu.mg_score_reads(nc, gpu.Icm.indep(gc), reads, **kw)
+    assert len(plain[0]) < len(full[0])
