@@ -165,6 +165,7 @@ def main():
         "glimmer-mg.indel": ["glimmer-mg", "-i", "-m", nc],
         "glimmer-mg.g120": ["glimmer-mg", "-g", "120", "-m", nc],
         "glimmer-mg.Z2": ["glimmer-mg", "-Z", "taa,tag", "-m", nc],
+        "glimmer-mg.sub": ["glimmer-mg", "-s", "-m", nc],
     }
     for name, cmd in clis.items():
         tag = os.path.join(RB, "cli_" + name)
@@ -234,6 +235,10 @@ def main():
             q.write(">%s\n" % hdr)
             for a in range(0, len(vals), 25):
                 q.write(" ".join(str(int(v)) for v in vals[a:a + 25]) + "\n")
+    tag = os.path.join(RB, "cli_glimmer-mg.indel_q80")                  # -i with the quality file, through the whole CLI
+    subprocess.run([os.path.join(RB, "glimmer-mg"), "-i", "-q", sub_q, "-m", nc, sub_fa, tag], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=RB)
+    shutil.copyfile(tag + ".predict", os.path.join(GOLD, "predict", "glimmer-mg.indel_q80.predict"))
     for name, flags in (("mg_err_indel", ["-i"]), ("mg_err_sub", ["-s"]), ("mg_err_indel_q", ["-i", "-q", sub_q]),
                         ("mg_err_indel_g90", ["-i", "-g", "90", "-Z", "taa,tag"])):
         txt = subprocess.run([os.path.join(RB, "ref_mg_orfs"), "dump", *flags, "-m", nc, sub_fa, os.path.join(RB, "mg_tag")],

@@ -225,6 +225,27 @@ int main(int argc, char **argv)
             prm.ignore_score_len = Ignore_Score_Len;
             prm.start_threshold = Start_Threshold;
             prm.flags = GMG_MG_ACCEPTED_ONLY;           // only what Add_Events_* will see comes back
+            vector<uint8_t> qual_all;
+            if (Error_Mode) {                           // -i / -s: Score_Indels / the substitution branch run on the device too
+                prm.flags |= Allow_Indels ? GMG_MG_ALLOW_INDELS : GMG_MG_ALLOW_SUBS;
+                prm.min_indel_orf_len = Min_Indel_ORF_Len;
+                prm.indel_quality_threshold = Indel_Quality_Threshold;
+                prm.indel_max = Indel_Max;
+                prm.indel_suffix_score_threshold = Indel_Suffix_Score_Threshold;
+                if (Allow_Indels && Quality_File_Name != NULL) {       // the user's Phred values, one byte per base
+                    vector<vector<int> > qual_list;
+                    read_qualities(qual_list, n_seq);
+                    qual_all.reserve(total_bases);
+                    for (int i = 0; i < n_seq; i++) {
+                        if (qual_list[i].size() != seq_list[i].size()) {   // Clean_Quality_454's check (glimmer-mg.cc:534-537)
+                            fprintf(stderr, "ERROR:  %s sequence length does not match quality values length\n", hdr_list[i].c_str());
+                            return 1;
+                        }
+                        for (size_t k = 0; k < qual_list[i].size(); k++) qual_all.push_back(qual_list[i][k] > 255 ? 255 : qual_list[i][k] < 0 ? 0 : qual_list[i][k]);
+                    }
+                    prm.quality = qual_all.data();
+                }
+            }
             prm.n_start_codons = Start_Codon.size();
             prm.n_stop_codons = Stop_Codon.size();
             for (size_t s = 0; s < Start_Codon.size() && s < 8; s++) memcpy(prm.start_codon[s], Start_Codon[s], 3);
@@ -239,7 +260,9 @@ int main(int argc, char **argv)
             vector<gmg_mg_orf> orfs(n_orfs ? n_orfs : 1);
             vector<gmg_start> starts(n_starts ? n_starts : 1);
             vector<uint64_t> read_orf_off(n_seq + 1);
+            vector<gmg_start_errors> errs(Error_Mode ? (n_starts ? n_starts : 1) : 0);
             if (gmg_mg_result_fetch(res, orfs.data(), starts.data(), read_orf_off.data()) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+            if (Error_Mode && gmg_mg_result_fetch_errors(res, errs.data()) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
             gmg_mg_result_free(res);
             gmg_reads_free(reads);
             // events, DP and trace-back per read: host, unchanged reference code (glimmer-mg.cc:400-441, 1620-1685)
@@ -266,8 +289,16 @@ int main(int argc, char **argv)
                         const gmg_start &t = starts[g.start_begin + s];
                         sl[s].j = t.j; sl[s].pos = t.pos; sl[s].score = t.score; sl[s].rate = 0.0; sl[s].which = t.which;
                         sl[s].truncated = t.truncated; sl[s].first = t.first;
+                        if (Error_Mode) {
+                            const gmg_start_errors &e = errs[g.start_begin + s];
+                            for (int k = 0; k < e.n; k++) sl[s].errors.push_back(Error_t(e.pos[k], e.type[k]));
+                        }
                     }
-                    sort(sl.begin(), sl.end(), Start_Cmp);                 // glimmer-mg.cc:1659
+                    std::sort(sl.begin(), sl.end(), Start_Cmp);            // glimmer-mg.cc:1659: same algorithm on the same push order
+                    if (g.accepted == 2) {                                 // ties on pos: first_j is the sort's to decide (:1661-1666)
+                        const int first_j = g.frame > 0 ? sl.front().j : sl.back().j;
+                        if (first_j + 1 < Min_Gene_Len) continue;
+                    }
                     if (g.frame > 0) real_Add_Events_Fwd(orf, sl, id);
                     else real_Add_Events_Rev(orf, sl, id);
                 }

@@ -118,9 +118,13 @@ def test_mg_frame_scores_are_handed_back_and_empty_batches_work(gpu, nc, seqs_fa
         gpu.mg_score_reads(gpu.Icm.open(os.path.join(DATA, "cluster-4.icm")), indep, reads)     # periodicity 1
 
 
-@pytest.mark.parametrize("flags,golden", [([], "glimmer-mg.default.predict"), (["-g", "120"], "glimmer-mg.g120.predict"),
-                                          (["-Z", "taa,tag"], "glimmer-mg.Z2.predict")])
-def test_glimmer_mg_with_device_front_half_is_byte_identical(gpu, tmp_path, flags, golden):
+@pytest.mark.parametrize("flags,golden,fasta", [
+    ([], "glimmer-mg.default.predict", "seqs.fa"), (["-g", "120"], "glimmer-mg.g120.predict", "seqs.fa"),
+    (["-Z", "taa,tag"], "glimmer-mg.Z2.predict", "seqs.fa"),
+    # the error branch: indels (predictions with I: / D: lists), substitutions (S:), indels with a quality file
+    (["-i"], "glimmer-mg.indel.predict", "seqs.fa"), (["-s"], "glimmer-mg.sub.predict", "seqs.fa"),
+    (["-i", "-q", os.path.join(DATA, "seqs80.qual")], "glimmer-mg.indel_q80.predict", "seqs80.fa")])
+def test_glimmer_mg_with_device_front_half_is_byte_identical(gpu, tmp_path, flags, golden, fasta):
     """oracle/_ref/glimmer-mg_batch: glimmer-mg's own Add_Events / Process_Events / Trace_Back around ONE
     gmg_mg_score_reads call that replaces Score_All_Frames, Find_Orfs and Score_Orfs_Errors of all 999 reads
     (oracle/ref_drivers/ref_mg_orfs.cc)."""
@@ -128,7 +132,7 @@ def test_glimmer_mg_with_device_front_half_is_byte_identical(gpu, tmp_path, flag
     if not os.access(exe, os.X_OK):
         pytest.skip("oracle/_ref/glimmer-mg_batch not built (needs /root/reference in the build container)")
     tag = str(tmp_path / "out")
-    cmd = [exe, "batch", *flags, "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, "seqs.fa"), tag]
+    cmd = [exe, "batch", *flags, "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, fasta), tag]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", golden), "rb").read()
