@@ -25,6 +25,7 @@
 #include "gmg_device.h"
 
 #include <hipcub/hipcub.hpp>
+#include <hipcub/device/device_segmented_sort.hpp>
 
 #include <float.h>
 #include <limits.h>
@@ -44,6 +45,16 @@ struct gmg_mg_result {
     uint64_t *d_read_orf_off;    // [n_reads + 1]
     uint64_t n_reads, n_orfs, n_starts;
 };
+
+struct MgCall {                  // one Score_Orf_Starts call waiting to be walked
+    double suffix_score;
+    uint64_t key;                // order of its starts among the ORF's: the fields of the levels above it
+    uint32_t orf;
+    int32_t end_point, suffix_j;
+    uint32_t e0, e1;             // Error_t entries of the path: (pos + 8) << 2 | type
+    uint32_t level;
+};
+struct MgOrfAgg { unsigned long long best, ext_a, ext_b; uint32_t cnt, m0; };
 
 struct MgTile { uint64_t w0; uint32_t first, nfit, span, pad; };   // reads [first, first + nfit), bases [w0, w0 + span)
 
@@ -86,6 +97,16 @@ struct MgArgs {
     const double *pen;           // [256] Score_Indels' score_penalty by quality value (host libm, like the reference)
     double pass_stop[4];         // Pass_Stop_Penalty by (second base is a/t) * 2 + (third base is a/t)
     gmg_start_errors *errs;
+    uint64_t *keys;              // [n_starts] order of a start inside its ORF's list (k_mg_err_queue), ascending = push order
+    uint8_t *read_fit;           // [n_reads] 1: the per-read kernel (k_mg_err_queue) takes the read, 0: k_mg_err_flat does
+    uint32_t *err_flag;          // set when a write pass could not finish a read (the call then repeats on the exact path)
+    int queue_len;               // bases per read the per-read kernel holds in LDS
+    // level by level (k_mg_err_level): the calls of level 1 and 2 wait in two arrays
+    struct MgCall *calls[2];
+    unsigned long long *n_calls; // [2] entries used
+    uint64_t call_cap;           // entries per array
+    struct MgOrfAgg *agg;        // [n_orfs] what the calls of an ORF add up to
+    uint32_t *fill;              // [n_orfs] write pass: slots handed out inside the ORF's slice
 };
 
 // Ch_Mask (src/Common/gene.cc:954-995)
@@ -885,13 +906,826 @@ __global__ __launch_bounds__(256) void k_mg_err_starts(MgArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void k_mg_keep_gather_errs(const gmg_mg_orf *orfs, const gmg_start_errors *errs, uint64_t n,
-                                                             const uint64_t *new_start, gmg_start_errors *out)
+// ---------------------------------------------------------------------------------------------------
+// The same walk without nested loops.  In k_mg_err_starts a lane that enters a branch runs the whole inner call
+// while the other 63 lanes of its wave wait at the call site, at every step of every level: the wave's time is
+// the PRODUCT of the levels' lengths, not the longest lane (measured: 0.3 % of the lanes busy).  Here the call
+// tree is walked by ONE loop whose every trip advances every lane by one buffer position of whatever call it is
+// in; a branch pushes the caller's state (two levels at most ever wait: 0 and 1) onto a stack in LDS and a
+// finished call pops it.  Same visiting order, same arithmetic, same slots as mg_err_walk.
+// ---------------------------------------------------------------------------------------------------
+#define MG_ERR_BLOCK 256
+
+struct MgErrStack {              // saved callers, [level][lane]
+    double sum[2][MG_ERR_BLOCK], prev[2][MG_ERR_BLOCK], suffix_score[2][MG_ERR_BLOCK];
+    int end_point[2][MG_ERR_BLOCK], tp[2][MG_ERR_BLOCK], suffix_j[2][MG_ERR_BLOCK];
+    uint32_t bits[2][MG_ERR_BLOCK], last_own[2][MG_ERR_BLOCK];
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(MG_ERR_BLOCK) void k_mg_err_flat(MgArgs a, const int accepted_only, const int only_unfit)
+{
+    __shared__ int8_t s_which[64];
+    __shared__ MgErrStack st;
+    if (threadIdx.x < 64) s_which[threadIdx.x] = a.which[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const int mgl = a.min_gene_len;
+    const int lowest_j = mgl - 3 < 3 ? mgl - 3 : 3;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x) {
+        gmg_mg_orf o = a.orfs[i];
+        if (only_unfit && a.read_fit[o.read]) continue;                  // the per-read kernel has this read
+        if (WRITE && accepted_only && !o.accepted) continue;             // the count pass has judged it; nothing of it leaves the GPU
+        const bool fwd = o.frame > 0;
+        const int64_t off = (int64_t)a.read_off[o.read];
+        const int n = (int)(a.read_off[o.read + 1] - a.read_off[o.read]);
+        const int64_t dir = fwd ? -1 : 1;
+        const uint32_t comp = fwd ? 0u : 3u;
+        const double *row0 = a.fs + (uint64_t)(fwd ? 1 : 4) * a.fs_stride;      // rows of buffer positions j % 3 = 0, 1, 2 (:561-604)
+        const double *row1 = a.fs + (uint64_t)(fwd ? 2 : 5) * a.fs_stride;
+        const double *row2 = a.fs + (uint64_t)(fwd ? 0 : 3) * a.fs_stride;
+
+        MgErrRun R;
+        R.count = 0; R.end = WRITE ? (uint32_t)a.start_off[i + 1] : 0; R.best = -DBL_MAX; R.ext_pos = 0; R.ext_jmin = R.ext_jmax = 0;
+        R.m0 = 0; R.trunc0 = 0;
+
+        // the call being walked
+        int level = 0, end_point = fwd ? o.stop_position - 1 : o.stop_position + 3, suffix_j = 0;
+        double suffix_score = 0.0, sum = 0.0, prev = 0.0;
+        int tp = 0, jj = 0, br = 0;                     // codon, position in it, next branch to try (0 insertion, 1 deletion, 2 none)
+        uint32_t pidx = 0, nidx = 0, last_own = MG_NO_SLOT;
+        bool is_last = false, trunc = false, first_done = false, walking = false;
+        int e_pos[2] = {0, 0}, e_type[2] = {0, 0};
+        int64_t g0 = 0, g = 0;
+        uint32_t w = 0;
+        int avail = 0;
+
+        auto fetch = [&](int t, uint32_t &idx) __attribute__((always_inline)) -> bool {     // codon t of the buffer; true: the region ends before it
+            if (avail - 3 * t < 3) { trunc = a.allow_truncated != 0; return true; }
+            uint32_t c[3];
+#pragma unroll
+            for (int x = 0; x < 3; x++) {
+                c[x] = ((w >> (2u * (unsigned)(g & 15))) & 3u) ^ comp;
+                const int64_t g2 = g + dir;
+                if ((g ^ g2) >> 4) w = a.packed[g2 >> 4];
+                g = g2;
+            }
+            idx = c[2] << 4 | c[1] << 2 | c[0];
+            return (a.fwd_stop >> idx) & 1;
+        };
+        auto enter = [&]() __attribute__((always_inline)) {          // start the call (end_point, suffix_score, suffix_j) at `level`
+            sum = 0.0; prev = 0.0; tp = 0; jj = 0; br = 0; last_own = MG_NO_SLOT;
+            is_last = false; trunc = false; first_done = false;
+            const int anchor = end_point - 1;
+            walking = false;
+            if (anchor < 0 || anchor >= n) { avail = 0; return; }   // an empty region (Fwd_Prev_Stop / Rev_Next_Stop outside the read)
+            avail = fwd ? anchor + 1 : n - anchor;
+            g0 = off + anchor;
+            g = g0;
+            w = a.packed[g >> 4];
+            if (fetch(0, pidx)) return;                 // m = 0
+            walking = true;
+        };
+        auto emit = [&](double raw, int j_full, int pos, int which, int truncated, int first) __attribute__((always_inline)) -> uint32_t {
+            const double sc = (j_full > a.ignore_score_len && 0.0 > raw) ? 0.0 : raw;
+            if (R.count == 0 || (fwd ? pos < R.ext_pos : pos > R.ext_pos)) { R.ext_pos = pos; R.ext_jmin = R.ext_jmax = j_full; }
+            else if (pos == R.ext_pos) { if (j_full < R.ext_jmin) R.ext_jmin = j_full; if (j_full > R.ext_jmax) R.ext_jmax = j_full; }
+            if (sc > R.best) R.best = sc;
+            R.count++;
+            uint32_t slot = MG_NO_SLOT;
+            if (WRITE) {
+                slot = --R.end;
+                gmg_start s1;
+                s1.score = sc; s1.j = j_full; s1.pos = pos; s1.which = which; s1.truncated = (int16_t)truncated; s1.first = (int16_t)first;
+                a.starts[slot] = s1;
+                gmg_start_errors er;
+                er.pos[0] = level > 0 ? e_pos[0] : 0; er.pos[1] = level > 1 ? e_pos[1] : 0;
+                er.type[0] = (int8_t)(level > 0 ? e_type[0] : 0); er.type[1] = (int8_t)(level > 1 ? e_type[1] : 0);
+                er.n = (int8_t)level; er.reserved = 0;
+                a.errs[slot] = er;
+                if (a.keys) a.keys[slot] = slot - (uint32_t)a.start_off[i];     // already in push order
+            }
+            return slot;
+        };
+        auto push = [&](int child_end, double child_score, int child_sj, int epos, int etype) __attribute__((always_inline)) {
+            st.sum[level][lane] = sum; st.prev[level][lane] = prev; st.suffix_score[level][lane] = suffix_score;
+            st.end_point[level][lane] = end_point; st.tp[level][lane] = tp; st.suffix_j[level][lane] = suffix_j;
+            st.bits[level][lane] = (uint32_t)jj | (uint32_t)br << 2 | pidx << 4 | nidx << 10 | (uint32_t)is_last << 16 | (uint32_t)trunc << 17 |
+                                   (uint32_t)first_done << 18 | (uint32_t)walking << 19;
+            st.last_own[level][lane] = last_own;
+            e_pos[level] = epos; e_type[level] = etype;
+            level++;
+            end_point = child_end; suffix_score = child_score; suffix_j = child_sj;
+            enter();
+        };
+        auto pop = [&]() __attribute__((always_inline)) {
+            level--;
+            if (level < 0) return;
+            sum = st.sum[level][lane]; prev = st.prev[level][lane]; suffix_score = st.suffix_score[level][lane];
+            end_point = st.end_point[level][lane]; tp = st.tp[level][lane]; suffix_j = st.suffix_j[level][lane];
+            const uint32_t b = st.bits[level][lane];
+            jj = b & 3; br = (b >> 2) & 3; pidx = (b >> 4) & 63; nidx = (b >> 10) & 63;
+            is_last = (b >> 16) & 1; trunc = (b >> 17) & 1; first_done = (b >> 18) & 1; walking = (b >> 19) & 1;
+            last_own = st.last_own[level][lane];
+            const int anchor = end_point - 1;           // (a caller always has a region: it branched from inside it)
+            avail = fwd ? anchor + 1 : n - anchor;
+            g0 = off + anchor;
+            g = g0 + dir * 3 * (tp + 2);                // the stream stands behind the look-ahead codon
+            w = a.packed[g >> 4];
+        };
+
+        enter();
+        while (level >= 0) {
+            if (walking) {
+                const int j = 3 * tp + jj;
+                const int64_t gj = g0 + dir * j;
+                const int k = fwd ? end_point - 2 - j : end_point + 2 + j;
+                if (br == 0) {                          // first visit of this position
+                    if (jj == 0) is_last = fetch(tp + 1, nidx);      // is codon tp the last of the region?
+                    prev = sum;
+                    sum = prev + (jj == 0 ? row0 : jj == 1 ? row1 : row2)[gj];
+                    if (jj == 0 && j >= lowest_j && j + 3 + suffix_j >= mgl) {
+                        const int which = s_which[pidx];
+                        const double raw = (prev - 0.0) + suffix_score;
+                        if (which >= 0) last_own = emit(raw, j + 2 + suffix_j, k, which, 0, 0);
+                        if (is_last && trunc) { emit(raw, j + 2 + suffix_j, k, -1, 1, 1); first_done = true; }
+                    }
+                }
+                bool pushed = false;
+                if (a.err_mode == 1 && level < 2 && level < a.indel_max && j >= lowest_j) {
+                    const int q = a.qual[gj];
+                    if (q <= a.indel_q_thr) {           // Score_Indels, reversed order: insertion, then deletion
+                        const double pen = a.pen[q];
+                        while (br < 2) {
+                            const int b = br++;
+                            const double es = ((suffix_score + (b == 0 ? prev : sum)) - 0.0) + pen;
+                            if (es > a.indel_suffix_thr) {
+                                int ep, epos;
+                                if (b == 0) { ep = fwd ? k - (2 - jj) : k + 2 - jj; epos = fwd ? k + 2 : k - 2; }
+                                else { ep = fwd ? k + jj : k - jj; epos = fwd ? k + 3 : k - 1; }
+                                push(ep, es, suffix_j + j + 2 - jj, epos, b);
+                                pushed = true;
+                                break;
+                            }
+                        }
+                    }
+                }
+                if (pushed) continue;
+                br = 0;
+                if (++jj == 3) {
+                    jj = 0;
+                    if (is_last) walking = false;       // the region is done; tp + 1 codons
+                    else pidx = nidx;
+                    tp++;
+                }
+                continue;
+            }
+            // the region is finished: m = 3 * tp (tp counts the codons walked; 0 for an empty region)
+            if (br != 3) {
+                const int m = 3 * tp;
+                if (level == 0) { R.m0 = m; R.trunc0 = trunc; }
+                br = 3;                                 // (marks "substitution branch done" for the way back)
+                if (level == 0 && a.err_mode == 2) {    // mutate the previous stop codon (:1771-1806)
+                    const int lo = fwd ? end_point - m : end_point, hi = fwd ? end_point : end_point + m;
+                    const int eep = fwd ? lo - 3 : hi + 3;
+                    if (end_point - 1 >= 0 && end_point - 1 < n && eep >= 0 && eep - 2 < n) {
+                        auto base = [&](int x) { const int64_t y = off + x; return (a.packed[y >> 4] >> (2u * (unsigned)(y & 15))) & 3u; };
+                        const uint32_t want = fwd ? 0u : 3u;
+                        const int a1 = base(fwd ? lo - 2 : hi) == want, a2 = base(fwd ? lo - 1 : hi - 1) == want;
+                        double es = suffix_score + a.pass_stop[a1 * 2 + a2];
+                        if (m > 0) es += sum - 0.0;
+                        push(eep, es, suffix_j + m, fwd ? lo - 2 : hi + 2, 2);
+                        continue;
+                    }
+                }
+            }
+            if (WRITE && !first_done && last_own != MG_NO_SLOT) a.starts[last_own].first = 1;
+            pop();
+        }
+
+        if (fwd) { o.hi = o.stop_position - 1; o.lo = o.hi - R.m0; }
+        else { o.lo = o.stop_position + 3; o.hi = o.lo + R.m0; }
+        o.orf_is_truncated = (int16_t)R.trunc0;
+        o.n_starts = R.count;
+        o.first_j = R.count ? R.ext_jmin : 0;
+        o.best_score = -DBL_MAX;
+        o.accepted = 0;
+        if (R.count > 0 && R.ext_jmax + 1 >= a.min_gene_len) {          // glimmer-mg.cc:1656-1676
+            o.best_score = R.best;
+            if (R.best > a.start_threshold) o.accepted = R.ext_jmin + 1 >= a.min_gene_len ? 1 : 2;
+        }
+        if (!WRITE) {
+            a.orf_cnt[i] = (accepted_only && !o.accepted) ? 0u : R.count;
+            o.start_begin = 0;
+        } else o.start_begin = (uint32_t)a.start_off[i];
+        a.orfs[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The error branch, one wave per read (the default).  Two things held the per-ORF walks back: every lane
+// followed its own 3 Frame_Scores rows through HBM (one 64-byte sector per 8-byte value: ~300 GB per pass for
+// 200k reads), and an ORF's call tree is lopsided (33 ORFs per read, ~200 calls, a few of them long).  Here a
+// wave stages its read's six rows, qualities and codes in LDS once and its lanes take CALLS, not ORFs, from a
+// queue in LDS: the ORFs' own calls first, then every branch a walking lane meets is appended and picked up by
+// the next idle lane.  One trip of the loop = one buffer position for every busy lane; queue traffic is
+// wave-synchronous (ballot + rank, no atomics).
+// Calls finish in no particular order, so a start cannot know its slot in the reference's push order.  It
+// carries the order instead: key = (position, kind) of each level of its path, most significant first, each
+// field inverted -- ascending keys are the reference's push order (reverse of the visiting order described at
+// mg_err_walk).  Slots inside the ORF's slice are handed out by an LDS counter; a segmented sort by key
+// (mg_order_starts) puts the slice in order afterwards.  Per-ORF results (count, best score, the j's at the
+// extreme pos) are merged with 64-bit LDS atomics when a call ends.
+// Reads that do not fit (longer than the staged length, more ORFs than the table, a queue overflow) are left to
+// k_mg_err_flat, which writes the exact slots (and keys = slot).
+// ---------------------------------------------------------------------------------------------------
+#define MGQ_CAP 128              // queue entries (ring)
+#define MGQ_ORFS 128             // ORFs of one read
+
+__device__ __forceinline__ uint64_t mg_ord(double x)    // order-preserving map double -> uint64
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double mg_unord(uint64_t u)
+{
+    return __longlong_as_double((long long)((u >> 63) ? (u & 0x7fffffffffffffffull) : ~u));
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_mg_err_queue(MgArgs a, const int accepted_only)
+{
+    extern __shared__ double mgq_smem[];
+    const int LP = a.queue_len;
+    double *s_fs = mgq_smem;                            // [6][LP]
+    double *q_score = s_fs + (size_t)6 * LP;            // the queue, structure of arrays
+    uint64_t *q_key = (uint64_t *)(q_score + MGQ_CAP);
+    uint64_t *o_best = q_key + MGQ_CAP;                 // per ORF of the read
+    uint64_t *o_ext_a = o_best + MGQ_ORFS, *o_ext_b = o_ext_a + MGQ_ORFS;
+    int *q_end = (int *)(o_ext_b + MGQ_ORFS), *q_sj = q_end + MGQ_CAP;
+    uint32_t *q_e0 = (uint32_t *)(q_sj + MGQ_CAP), *q_e1 = q_e0 + MGQ_CAP, *q_meta = q_e1 + MGQ_CAP;
+    uint32_t *o_cnt = q_meta + MGQ_CAP, *o_m0 = o_cnt + MGQ_ORFS;
+    uint8_t *s_qual = (uint8_t *)(o_m0 + MGQ_ORFS), *s_code = s_qual + LP;
+    __shared__ int8_t s_which[64];
+    __shared__ double s_pen[64];                        // score_penalty of the quality values that can branch (<= threshold < 64; else a.pen)
+    const int lane = threadIdx.x;
+    const uint64_t lt = (1ull << lane) - 1;
+    s_which[lane] = a.which[lane];
+    s_pen[lane] = a.err_mode == 1 ? a.pen[lane] : 0.0;
+    const bool pen_lds = a.indel_q_thr < 64;
+    const int mgl = a.min_gene_len;
+    const int lowest_j = mgl - 3 < 3 ? mgl - 3 : 3;
+
+    for (uint64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+        const uint64_t first_orf = a.read_orf_off[r];
+        const int n_orf = (int)(a.read_orf_off[r + 1] - first_orf);
+        if (n_orf == 0) { if (!WRITE && lane == 0) a.read_fit[r] = 1; continue; }
+        const int64_t off = (int64_t)a.read_off[r];
+        const int n = (int)(a.read_off[r + 1] - a.read_off[r]);
+        if (!WRITE) { if (n > LP || n_orf > MGQ_ORFS) { if (lane == 0) a.read_fit[r] = 0; continue; } }
+        else if (!a.read_fit[r]) continue;
+        if (WRITE && accepted_only) {                   // nothing of a read without an accepted ORF leaves the GPU
+            bool any = false;
+            for (int o = lane; o < n_orf; o += 64) any |= a.orfs[first_orf + o].accepted != 0;
+            if (!__ballot(any)) continue;
+        }
+        __syncthreads();                                // (one wave: orders this read's LDS traffic behind the previous read's)
+        for (int f = 0; f < 6; f++)
+            for (int p = lane; p < n; p += 64) s_fs[(size_t)f * LP + p] = a.fs[(uint64_t)f * a.fs_stride + off + p];
+        for (int p = lane; p < n; p += 64) {
+            const int64_t x = off + p;
+            s_code[p] = (uint8_t)((a.packed[x >> 4] >> (2u * (unsigned)(x & 15))) & 3u);
+            s_qual[p] = a.qual ? a.qual[x] : 255;
+        }
+        uint32_t head = 0, tail = 0;                    // uniform: every lane computes the same values
+        for (int o0 = 0; o0 < n_orf; o0 += 64) {        // the ORFs' own calls (Score_Orfs_Errors, :1637-1642)
+            const int o = o0 + lane;
+            bool want = o < n_orf;
+            gmg_mg_orf rec;
+            if (want) {
+                rec = a.orfs[first_orf + o];
+                const bool fwd = rec.frame > 0;
+                o_cnt[o] = 0; o_m0[o] = 0; o_best[o] = mg_ord(-DBL_MAX);
+                o_ext_a[o] = o_ext_b[o] = fwd ? ~0ull : 0ull;
+                if (WRITE && accepted_only && !rec.accepted) want = false;
+            }
+            const uint64_t m = __ballot(want);
+            if (want) {
+                const uint32_t slot = (tail + __popcll(m & lt)) % MGQ_CAP;
+                q_score[slot] = 0.0; q_key[slot] = 0; q_sj[slot] = 0; q_e0[slot] = 0; q_e1[slot] = 0;
+                q_end[slot] = rec.frame > 0 ? rec.stop_position - 1 : rec.stop_position + 3;
+                q_meta[slot] = (uint32_t)o << 3 | (rec.frame > 0 ? 4u : 0u);            // orf, forward flag, level 0
+            }
+            tail += __popcll(m);
+        }
+        __syncthreads();
+
+        // the call this lane is walking
+        bool active = false, fwd = false, walking = false, is_last = false, trunc = false, first_done = false;
+        int orf = 0, level = 0, end_point = 0, suffix_j = 0, anchor = 0, avail = 0, dir = 1;
+        int tp = 0, jj = 0, br = 0;
+        uint32_t e0 = 0, e1 = 0, pidx = 0, nidx = 0, last_own = MG_NO_SLOT, cnt = 0, comp = 0;
+        uint64_t key = 0, ext_a = 0, ext_b = 0;
+        double suffix_score = 0.0, sum = 0.0, prev = 0.0, best = -DBL_MAX;
+        const double *row0 = s_fs, *row1 = s_fs, *row2 = s_fs;
+        bool overflow = false;
+
+        auto fetch = [&](int t, uint32_t &idx) __attribute__((always_inline)) -> bool {
+            if (avail - 3 * t < 3) { trunc = a.allow_truncated != 0; return true; }
+            const int p0 = anchor + dir * 3 * t;
+            const uint32_t c0 = s_code[p0] ^ comp, c1 = s_code[p0 + dir] ^ comp, c2 = s_code[p0 + 2 * dir] ^ comp;
+            idx = c2 << 4 | c1 << 2 | c0;
+            return (a.fwd_stop >> idx) & 1;
+        };
+        auto emit = [&](double raw, int j_full, int pos, int which, int truncated, int first, uint32_t kind) __attribute__((always_inline)) -> uint32_t {
+            const double sc = (j_full > a.ignore_score_len && 0.0 > raw) ? 0.0 : raw;
+            const uint64_t pa = (uint64_t)(uint32_t)(pos + 16) << 32 | (uint32_t)j_full, pb = (uint64_t)(uint32_t)(pos + 16) << 32 | (0xffffffffu - (uint32_t)j_full);
+            if (fwd) { if (pa < ext_a) ext_a = pa; if (pb < ext_b) ext_b = pb; }
+            else { if (pa > ext_a) ext_a = pa; if (pb > ext_b) ext_b = pb; }
+            if (sc > best) best = sc;
+            uint32_t slot = MG_NO_SLOT;
+            if (WRITE) {
+                slot = (uint32_t)a.start_off[first_orf + orf] + atomicAdd(&o_cnt[orf], 1u);
+                gmg_start s1;
+                s1.score = sc; s1.j = j_full; s1.pos = pos; s1.which = which; s1.truncated = (int16_t)truncated; s1.first = (int16_t)first;
+                a.starts[slot] = s1;
+                gmg_start_errors er;
+                er.pos[0] = level > 0 ? (int)(e0 >> 2) - 8 : 0; er.pos[1] = level > 1 ? (int)(e1 >> 2) - 8 : 0;
+                er.type[0] = (int8_t)(level > 0 ? (e0 & 3) : 0); er.type[1] = (int8_t)(level > 1 ? (e1 & 3) : 0);
+                er.n = (int8_t)level; er.reserved = 0;
+                a.errs[slot] = er;
+                const int j_loc = j_full - 2 - suffix_j;
+                a.keys[slot] = key | (uint64_t)((uint32_t)(2047 - j_loc) << 2 | kind) << (26 - 13 * level);
+            } else cnt++;
+            return slot;
+        };
+
+        for (;;) {
+            // 1. idle lanes take the next calls of the queue
+            {
+                const uint64_t idle = __ballot(!active);
+                const uint32_t availq = tail - head, rank = __popcll(idle & lt);
+                if (!active && rank < availq) {
+                    const uint32_t slot = (head + rank) % MGQ_CAP;
+                    const uint32_t meta = q_meta[slot];
+                    orf = meta >> 3; fwd = (meta >> 2) & 1; level = meta & 3;
+                    end_point = q_end[slot]; suffix_score = q_score[slot]; suffix_j = q_sj[slot];
+                    key = q_key[slot]; e0 = q_e0[slot]; e1 = q_e1[slot];
+                    active = true;
+                    dir = fwd ? -1 : 1; comp = fwd ? 0u : 3u;
+                    row0 = s_fs + (size_t)(fwd ? 1 : 4) * LP; row1 = s_fs + (size_t)(fwd ? 2 : 5) * LP; row2 = s_fs + (size_t)(fwd ? 0 : 3) * LP;
+                    sum = 0.0; prev = 0.0; tp = 0; jj = 0; br = 0; last_own = MG_NO_SLOT; cnt = 0; best = -DBL_MAX;
+                    ext_a = ext_b = fwd ? ~0ull : 0ull;
+                    is_last = false; trunc = false; first_done = false; walking = false;
+                    anchor = end_point - 1;
+                    if (anchor >= 0 && anchor < n) {
+                        avail = fwd ? anchor + 1 : n - anchor;
+                        walking = !fetch(0, pidx);
+                    } else avail = 0;
+                }
+                const uint32_t n_idle = __popcll(idle);
+                head += n_idle < availq ? n_idle : availq;
+            }
+            if (!__ballot(active)) break;               // no call running, none queued
+
+            // 2. one buffer position (or the end of the call) per busy lane
+            bool want_push = false;
+            int c_end = 0, c_sj = 0;
+            uint32_t c_err = 0, c_kind = 0;
+            double c_score = 0.0;
+            int c_j = 0;
+            if (active) {
+                if (walking) {
+                    const int j = 3 * tp + jj;
+                    const int p = anchor + dir * j;
+                    const int k = fwd ? end_point - 2 - j : end_point + 2 + j;
+                    if (br == 0) {
+                        if (jj == 0) is_last = fetch(tp + 1, nidx);
+                        prev = sum;
+                        sum = prev + (jj == 0 ? row0 : jj == 1 ? row1 : row2)[p];
+                        if (jj == 0 && j >= lowest_j && j + 3 + suffix_j >= mgl) {
+                            const int which = s_which[pidx];
+                            const double raw = (prev - 0.0) + suffix_score;
+                            if (which >= 0) last_own = emit(raw, j + 2 + suffix_j, k, which, 0, 0, 3u);
+                            if (is_last && trunc) { emit(raw, j + 2 + suffix_j, k, -1, 1, 1, 2u); first_done = true; }
+                        }
+                    }
+                    if (a.err_mode == 1 && level < 2 && level < a.indel_max && j >= lowest_j) {
+                        const int q = s_qual[p];
+                        if (q <= a.indel_q_thr) {
+                            const double pen = pen_lds ? s_pen[q] : a.pen[q];
+                            while (br < 2) {
+                                const int b = br++;
+                                const double es = ((suffix_score + (b == 0 ? prev : sum)) - 0.0) + pen;
+                                if (es > a.indel_suffix_thr) {
+                                    int epos;
+                                    if (b == 0) { c_end = fwd ? k - (2 - jj) : k + 2 - jj; epos = fwd ? k + 2 : k - 2; }
+                                    else { c_end = fwd ? k + jj : k - jj; epos = fwd ? k + 3 : k - 1; }
+                                    c_score = es; c_sj = suffix_j + j + 2 - jj; c_err = (uint32_t)(epos + 8) << 2 | (uint32_t)b;
+                                    c_kind = b == 0 ? 1u : 0u;              // push order at one position: deletion, insertion, truncated, real
+                                    c_j = j;
+                                    want_push = true;
+                                    break;
+                                }
+                            }
+                        }
+                    }
+                    if (!want_push) {
+                        br = 0;
+                        if (++jj == 3) {
+                            jj = 0;
+                            if (is_last) walking = false;
+                            else pidx = nidx;
+                            tp++;
+                        }
+                    }
+                } else {
+                    const int m = 3 * tp;
+                    bool done = true;
+                    if (br != 3) {
+                        br = 3;
+                        if (level == 0) {
+                            o_m0[orf] = (uint32_t)m << 1 | (trunc ? 1u : 0u);
+                            if (a.err_mode == 2) {      // the substitution branch: first in push order = the highest key field
+                                const int lo = fwd ? end_point - m : end_point, hi = fwd ? end_point : end_point + m;
+                                const int eep = fwd ? lo - 3 : hi + 3;
+                                if (anchor >= 0 && anchor < n && eep >= 0 && eep - 2 < n) {
+                                    const uint32_t want = fwd ? 0u : 3u;
+                                    const int a1 = s_code[fwd ? lo - 2 : hi] == want, a2 = s_code[fwd ? lo - 1 : hi - 1] == want;
+                                    double es = suffix_score + a.pass_stop[a1 * 2 + a2];
+                                    if (m > 0) es += sum - 0.0;
+                                    c_end = eep; c_score = es; c_sj = suffix_j + m;
+                                    c_err = (uint32_t)((fwd ? lo - 2 : hi + 2) + 8) << 2 | 2u;
+                                    c_kind = 0u; c_j = 2047;        // inverted position 0: before every position of the call
+                                    want_push = true;
+                                    done = false;
+                                }
+                            }
+                        }
+                    }
+                    if (done) {                         // the call is finished: its results join the ORF's
+                        if (WRITE) { if (!first_done && last_own != MG_NO_SLOT) a.starts[last_own].first = 1; }
+                        else if (cnt) atomicAdd(&o_cnt[orf], cnt);
+                        if (best > -DBL_MAX) {
+                            atomicMax((unsigned long long *)&o_best[orf], (unsigned long long)mg_ord(best));
+                            if (fwd) { atomicMin((unsigned long long *)&o_ext_a[orf], (unsigned long long)ext_a); atomicMin((unsigned long long *)&o_ext_b[orf], (unsigned long long)ext_b); }
+                            else { atomicMax((unsigned long long *)&o_ext_a[orf], (unsigned long long)ext_a); atomicMax((unsigned long long *)&o_ext_b[orf], (unsigned long long)ext_b); }
+                        }
+                        active = false;
+                    }
+                }
+            }
+
+            // 3. the branches met in this trip join the queue
+            const uint64_t pm = __ballot(want_push);
+            if (pm) {
+                const uint32_t np = __popcll(pm);
+                if (tail + np - head > MGQ_CAP) { overflow = true; break; }
+                if (want_push) {
+                    const uint32_t slot = (tail + __popcll(pm & lt)) % MGQ_CAP;
+                    q_score[slot] = c_score; q_end[slot] = c_end; q_sj[slot] = c_sj;
+                    q_key[slot] = key | (uint64_t)((uint32_t)(2047 - c_j) << 2 | c_kind) << (26 - 13 * level);
+                    q_e0[slot] = level == 0 ? c_err : e0; q_e1[slot] = level == 1 ? c_err : 0;
+                    q_meta[slot] = (uint32_t)orf << 3 | (fwd ? 4u : 0u) | (uint32_t)(level + 1);
+                }
+                tail += np;
+            }
+            __syncthreads();
+        }
+
+        if (overflow) {                                 // too many pending calls: the exact path takes the read
+            if (!WRITE) { if (lane == 0) a.read_fit[r] = 0; }
+            else if (lane == 0) atomicOr(a.err_flag, 1u);
+            continue;
+        }
+        __syncthreads();
+        if (!WRITE && lane == 0) a.read_fit[r] = 1;
+        for (int o = lane; o < n_orf; o += 64) {        // Score_Orfs_Errors' verdict per ORF (:1647-1683)
+            gmg_mg_orf rec = a.orfs[first_orf + o];
+            if (WRITE && accepted_only && !rec.accepted) continue;
+            const bool f = rec.frame > 0;
+            const uint32_t count = o_cnt[o];
+            const int m0 = (int)(o_m0[o] >> 1);
+            if (f) { rec.hi = rec.stop_position - 1; rec.lo = rec.hi - m0; }
+            else { rec.lo = rec.stop_position + 3; rec.hi = rec.lo + m0; }
+            rec.orf_is_truncated = (int16_t)(o_m0[o] & 1);
+            rec.n_starts = count;
+            rec.first_j = 0; rec.best_score = -DBL_MAX; rec.accepted = 0;
+            if (count) {
+                const uint32_t ja = (uint32_t)o_ext_a[o], jb = 0xffffffffu - (uint32_t)o_ext_b[o];
+                const int jmin = (int)(f ? ja : jb), jmax = (int)(f ? jb : ja);
+                rec.first_j = jmin;
+                if (jmax + 1 >= mgl) {
+                    rec.best_score = mg_unord(o_best[o]);
+                    if (rec.best_score > a.start_threshold) rec.accepted = jmin + 1 >= mgl ? 1 : 2;
+                }
+            }
+            if (!WRITE) { a.orf_cnt[first_orf + o] = (accepted_only && !rec.accepted) ? 0u : count; rec.start_begin = 0; }
+            else rec.start_begin = (uint32_t)a.start_off[first_orf + o];
+            a.orfs[first_orf + o] = rec;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The error branch level by level (the default).  One lane per CALL: level 0 = the ORFs' own calls, and every
+// branch a walk meets is appended to the array of the next level (one atomic per wave), which the next launch
+// walks -- three launches per pass.  A lane does one plain walk of one region: no stack, no queue, lanes of a
+// wave stay in step, and the occupancy of a kernel without LDS hides the latency of the scattered 8-byte reads.
+// The calls found by the count pass stay in their arrays; the write pass walks them again (only those of the
+// accepted ORFs when that is all the caller wants).  Order: keys + segmented sort as in k_mg_err_queue; per-ORF
+// results through 64-bit atomics on MgOrfAgg.  Reads too long for the key fields (>= 2040 bases) and a full
+// call array are left to k_mg_err_flat.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mg_err_prepare(MgArgs a)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x) {
+        const bool fwd = a.orfs[i].frame > 0;
+        MgOrfAgg g;
+        g.best = mg_ord(-DBL_MAX); g.ext_a = g.ext_b = fwd ? ~0ull : 0ull; g.cnt = 0; g.m0 = 0;
+        a.agg[i] = g;
+        a.fill[i] = 0;
+    }
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += (uint64_t)gridDim.x * blockDim.x)
+        a.read_fit[r] = a.read_off[r + 1] - a.read_off[r] < 2040;
+}
+
+#define MG_CALL_CHUNK 256
+
+template <bool WRITE, int LEVEL>
+__global__ __launch_bounds__(256) void k_mg_err_level(MgArgs a, const int accepted_only)
+{
+    __shared__ int8_t s_which[64];
+    __shared__ double s_pen[64];
+    if (threadIdx.x < 64) { s_which[threadIdx.x] = a.which[threadIdx.x]; s_pen[threadIdx.x] = a.err_mode == 1 ? a.pen[threadIdx.x] : 0.0; }
+    __syncthreads();
+    const bool pen_lds = a.indel_q_thr < 64;
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt = (1ull << lane) - 1;
+    const int mgl = a.min_gene_len;
+    const int lowest_j = mgl - 3 < 3 ? mgl - 3 : 3;
+    uint64_t n_in = LEVEL == 0 ? a.n_orfs : (uint64_t)a.n_calls[LEVEL - 1];
+    if (LEVEL > 0 && n_in > a.call_cap) n_in = a.call_cap;
+    const uint64_t n_round = (n_in + 63) & ~63ull;      // whole waves: the lanes of a wave leave the loop together (ballots inside)
+    uint64_t chunk_base = 0;                            // the wave's chunk of the next level's array (uniform over the wave)
+    uint32_t chunk_used = MG_CALL_CHUNK;                // none yet
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * blockDim.x) {
+        bool active = i < n_in;
+        uint32_t orf = 0;
+        int end_point = 0, suffix_j = 0;
+        double suffix_score = 0.0;
+        uint64_t key = 0;
+        uint32_t e0 = 0, e1 = 0;
+        gmg_mg_orf rec;
+        if (active) {
+            if (LEVEL == 0) { orf = (uint32_t)i; rec = a.orfs[i]; end_point = rec.frame > 0 ? rec.stop_position - 1 : rec.stop_position + 3; }
+            else {
+                const MgCall c = a.calls[LEVEL - 1][i];
+                if (c.level == 0) active = false;                               // the unused end of a wave's chunk
+                else {
+                    orf = c.orf; end_point = c.end_point; suffix_j = c.suffix_j; suffix_score = c.suffix_score; key = c.key; e0 = c.e0; e1 = c.e1;
+                    rec = a.orfs[orf];
+                }
+            }
+            if (active && !a.read_fit[rec.read]) active = false;            // k_mg_err_flat has the read
+            if (active && WRITE && accepted_only && !rec.accepted) active = false;
+        }
+        const bool fwd = active && rec.frame > 0;
+        const int64_t off = active ? (int64_t)a.read_off[rec.read] : 0;
+        const int n = active ? (int)(a.read_off[rec.read + 1] - a.read_off[rec.read]) : 0;
+        const int64_t dir = fwd ? -1 : 1;
+        const uint32_t comp = fwd ? 0u : 3u;
+        const double *row0 = a.fs + (uint64_t)(fwd ? 1 : 4) * a.fs_stride, *row1 = a.fs + (uint64_t)(fwd ? 2 : 5) * a.fs_stride,
+                     *row2 = a.fs + (uint64_t)(fwd ? 0 : 3) * a.fs_stride;
+        const int anchor = end_point - 1;
+        const int avail = fwd ? anchor + 1 : n - anchor;
+        const int64_t g0 = off + anchor;
+        int64_t g = g0;
+        uint32_t w = 0;
+        bool walking = false, is_last = false, trunc = false, first_done = false;
+        int tp = 0, jj = 0, br = 0;
+        uint32_t pidx = 0, nidx = 0, last_own = MG_NO_SLOT, cnt = 0;
+        uint64_t ext_a = fwd ? ~0ull : 0ull, ext_b = ext_a;
+        double sum = 0.0, prev = 0.0, best = -DBL_MAX;
+
+        auto fetch = [&](int t, uint32_t &idx) __attribute__((always_inline)) -> bool {
+            if (avail - 3 * t < 3) { trunc = a.allow_truncated != 0; return true; }
+            uint32_t c[3];
+#pragma unroll
+            for (int x = 0; x < 3; x++) {
+                c[x] = ((w >> (2u * (unsigned)(g & 15))) & 3u) ^ comp;
+                const int64_t g2 = g + dir;
+                if ((g ^ g2) >> 4) w = a.packed[g2 >> 4];
+                g = g2;
+            }
+            idx = c[2] << 4 | c[1] << 2 | c[0];
+            return (a.fwd_stop >> idx) & 1;
+        };
+        auto emit = [&](double raw, int j_loc, int pos, int which, int truncated, int first, uint32_t kind) __attribute__((always_inline)) -> uint32_t {
+            const int j_full = j_loc + 2 + suffix_j;
+            const double sc = (j_full > a.ignore_score_len && 0.0 > raw) ? 0.0 : raw;
+            uint32_t slot = MG_NO_SLOT;
+            if (WRITE) {
+                slot = (uint32_t)a.start_off[orf] + atomicAdd(&a.fill[orf], 1u);
+                gmg_start s1;
+                s1.score = sc; s1.j = j_full; s1.pos = pos; s1.which = which; s1.truncated = (int16_t)truncated; s1.first = (int16_t)first;
+                a.starts[slot] = s1;
+                gmg_start_errors er;
+                er.pos[0] = LEVEL > 0 ? (int)(e0 >> 2) - 8 : 0; er.pos[1] = LEVEL > 1 ? (int)(e1 >> 2) - 8 : 0;
+                er.type[0] = (int8_t)(LEVEL > 0 ? (e0 & 3) : 0); er.type[1] = (int8_t)(LEVEL > 1 ? (e1 & 3) : 0);
+                er.n = LEVEL; er.reserved = 0;
+                a.errs[slot] = er;
+                a.keys[slot] = key | (uint64_t)((uint32_t)(2047 - j_loc) << 2 | kind) << (26 - 13 * LEVEL);
+            } else {
+                const uint64_t pa = (uint64_t)(uint32_t)(pos + 16) << 32 | (uint32_t)j_full, pb = (uint64_t)(uint32_t)(pos + 16) << 32 | (0xffffffffu - (uint32_t)j_full);
+                if (fwd) { if (pa < ext_a) ext_a = pa; if (pb < ext_b) ext_b = pb; }
+                else { if (pa > ext_a) ext_a = pa; if (pb > ext_b) ext_b = pb; }
+                if (sc > best) best = sc;
+                cnt++;
+            }
+            return slot;
+        };
+
+        if (active && anchor >= 0 && anchor < n) {
+            w = a.packed[g >> 4];
+            walking = !fetch(0, pidx);
+        }
+        bool finishing = active;                        // the end-of-call work is still to do
+        while (__ballot(walking || finishing)) {
+            bool want_push = false;
+            MgCall child;
+            if (walking) {
+                const int j = 3 * tp + jj;
+                const int64_t gj = g0 + dir * j;
+                const int k = fwd ? end_point - 2 - j : end_point + 2 + j;
+                if (br == 0) {
+                    if (jj == 0) is_last = fetch(tp + 1, nidx);
+                    prev = sum;
+                    sum = prev + (jj == 0 ? row0 : jj == 1 ? row1 : row2)[gj];
+                    if (jj == 0 && j >= lowest_j && j + 3 + suffix_j >= mgl) {
+                        const int which = s_which[pidx];
+                        const double raw = (prev - 0.0) + suffix_score;
+                        if (which >= 0) last_own = emit(raw, j, k, which, 0, 0, 3u);
+                        if (is_last && trunc) { emit(raw, j, k, -1, 1, 1, 2u); first_done = true; }
+                    }
+                }
+                if (LEVEL < 2 && !WRITE && a.err_mode == 1 && LEVEL < a.indel_max && j >= lowest_j) {
+                    const int q = a.qual[gj];
+                    if (q <= a.indel_q_thr) {
+                        const double pen = pen_lds ? s_pen[q] : a.pen[q];
+                        while (br < 2) {
+                            const int b = br++;
+                            const double es = ((suffix_score + (b == 0 ? prev : sum)) - 0.0) + pen;
+                            if (es > a.indel_suffix_thr) {
+                                int epos;
+                                if (b == 0) { child.end_point = fwd ? k - (2 - jj) : k + 2 - jj; epos = fwd ? k + 2 : k - 2; }
+                                else { child.end_point = fwd ? k + jj : k - jj; epos = fwd ? k + 3 : k - 1; }
+                                child.suffix_score = es; child.suffix_j = suffix_j + j + 2 - jj;
+                                const uint32_t ce = (uint32_t)(epos + 8) << 2 | (uint32_t)b;
+                                child.e0 = LEVEL == 0 ? ce : e0; child.e1 = LEVEL == 1 ? ce : 0;
+                                child.key = key | (uint64_t)((uint32_t)(2047 - j) << 2 | (b == 0 ? 1u : 0u)) << (26 - 13 * LEVEL);
+                                want_push = true;
+                                break;
+                            }
+                        }
+                    }
+                }
+                if (!want_push) {
+                    br = 0;
+                    if (++jj == 3) {
+                        jj = 0;
+                        if (is_last) walking = false;
+                        else pidx = nidx;
+                        tp++;
+                    }
+                }
+            } else if (finishing) {
+                finishing = false;
+                const int m = 3 * tp;
+                if (LEVEL == 0 && !WRITE) {
+                    a.agg[orf].m0 = (uint32_t)m << 1 | (trunc ? 1u : 0u);
+                    if (a.err_mode == 2) {              // the substitution branch (:1771-1806)
+                        const int lo = fwd ? end_point - m : end_point, hi = fwd ? end_point : end_point + m;
+                        const int eep = fwd ? lo - 3 : hi + 3;
+                        if (anchor >= 0 && anchor < n && eep >= 0 && eep - 2 < n) {
+                            auto base = [&](int x) { const int64_t y = off + x; return (a.packed[y >> 4] >> (2u * (unsigned)(y & 15))) & 3u; };
+                            const uint32_t want = fwd ? 0u : 3u;
+                            const int a1 = base(fwd ? lo - 2 : hi) == want, a2 = base(fwd ? lo - 1 : hi - 1) == want;
+                            double es = suffix_score + a.pass_stop[a1 * 2 + a2];
+                            if (m > 0) es += sum - 0.0;
+                            child.end_point = eep; child.suffix_score = es; child.suffix_j = suffix_j + m;
+                            child.e0 = (uint32_t)((fwd ? lo - 2 : hi + 2) + 8) << 2 | 2u; child.e1 = 0;
+                            child.key = key | (uint64_t)(0u << 2 | 0u) << 26;      // before every position of the call
+                            want_push = true;
+                        }
+                    }
+                }
+                if (WRITE) { if (!first_done && last_own != MG_NO_SLOT) a.starts[last_own].first = 1; }
+                else if (cnt) {
+                    MgOrfAgg *g2 = a.agg + orf;
+                    atomicAdd(&g2->cnt, cnt);
+                    atomicMax(&g2->best, (unsigned long long)mg_ord(best));
+                    if (fwd) { atomicMin(&g2->ext_a, (unsigned long long)ext_a); atomicMin(&g2->ext_b, (unsigned long long)ext_b); }
+                    else { atomicMax(&g2->ext_a, (unsigned long long)ext_a); atomicMax(&g2->ext_b, (unsigned long long)ext_b); }
+                }
+            }
+            if (LEVEL < 2 && !WRITE) {
+                // the branches of this trip go to the next level's array.  The wave owns a chunk of MG_CALL_CHUNK entries at a time
+                // (ONE atomic on the shared counter per chunk -- one per trip made the counter the bottleneck: 73 -> 9 ms); what is
+                // left of a chunk when it is given up is marked empty (level 0) and skipped by the next launch
+                const uint64_t pm = __ballot(want_push);
+                if (pm) {
+                    const uint32_t np = __popcll(pm);
+                    if (chunk_used + np > MG_CALL_CHUNK) {
+                        for (uint32_t x = chunk_used + lane; x < MG_CALL_CHUNK; x += 64)
+                            if (chunk_base + x < a.call_cap) a.calls[LEVEL][chunk_base + x].level = 0;
+                        unsigned long long base = 0;
+                        if (lane == 0) base = atomicAdd(&a.n_calls[LEVEL], (unsigned long long)MG_CALL_CHUNK);
+                        chunk_base = __shfl(base, 0);
+                        chunk_used = 0;
+                        if (chunk_base + MG_CALL_CHUNK > a.call_cap && lane == 0) atomicOr(a.err_flag, 1u);
+                    }
+                    if (want_push) {
+                        const uint64_t slot = chunk_base + chunk_used + __popcll(pm & lt);
+                        if (slot < a.call_cap) { child.orf = orf; child.level = LEVEL + 1; a.calls[LEVEL][slot] = child; }
+                    }
+                    chunk_used += np;
+                }
+            }
+        }
+    }
+    if (LEVEL < 2 && !WRITE)                            // give the rest of the last chunk back as empty entries
+        for (uint32_t x = chunk_used + lane; x < MG_CALL_CHUNK; x += 64)
+            if (chunk_base + x < a.call_cap) a.calls[LEVEL][chunk_base + x].level = 0;
+}
+
+// Score_Orfs_Errors' verdict per ORF (:1647-1683) from what its calls added up to
+__global__ __launch_bounds__(256) void k_mg_err_verdict(MgArgs a, const int accepted_only)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x) {
+        gmg_mg_orf rec = a.orfs[i];
+        if (!a.read_fit[rec.read]) continue;
+        const MgOrfAgg g = a.agg[i];
+        const bool f = rec.frame > 0;
+        const int m0 = (int)(g.m0 >> 1);
+        if (f) { rec.hi = rec.stop_position - 1; rec.lo = rec.hi - m0; }
+        else { rec.lo = rec.stop_position + 3; rec.hi = rec.lo + m0; }
+        rec.orf_is_truncated = (int16_t)(g.m0 & 1);
+        rec.n_starts = g.cnt;
+        rec.first_j = 0; rec.best_score = -DBL_MAX; rec.accepted = 0;
+        if (g.cnt) {
+            const uint32_t ja = (uint32_t)g.ext_a, jb = 0xffffffffu - (uint32_t)g.ext_b;
+            const int jmin = (int)(f ? ja : jb), jmax = (int)(f ? jb : ja);
+            rec.first_j = jmin;
+            if (jmax + 1 >= a.min_gene_len) {
+                rec.best_score = mg_unord(g.best);
+                if (rec.best_score > a.start_threshold) rec.accepted = jmin + 1 >= a.min_gene_len ? 1 : 2;
+            }
+        }
+        a.orf_cnt[i] = (accepted_only && !rec.accepted) ? 0u : g.cnt;
+        rec.start_begin = 0;
+        a.orfs[i] = rec;
+    }
+}
+
+// (after the scan) where each ORF's slice begins
+__global__ __launch_bounds__(256) void k_mg_err_begin(MgArgs a)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x)
+        if (a.read_fit[a.orfs[i].read]) a.orfs[i].start_begin = (uint32_t)a.start_off[i];
+}
+
+__global__ __launch_bounds__(256) void k_mg_seg_bounds(const gmg_mg_orf *orfs, uint64_t n, uint32_t *seg_begin, uint32_t *seg_end)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        seg_begin[i] = orfs[i].start_begin;
+        seg_end[i] = orfs[i].start_begin + orfs[i].n_starts;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mg_iota(uint32_t *v, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_mg_permute_starts(const uint32_t *idx, uint64_t n, const gmg_start *s_in, const gmg_start_errors *e_in,
+                                                           gmg_start *s_out, gmg_start_errors *e_out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        s_out[i] = s_in[idx[i]];
+        e_out[i] = e_in[idx[i]];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mg_keep_gather_errs(const gmg_mg_orf *orfs, const gmg_start_errors *errs, const uint64_t *keys,
+                                                             uint64_t n, const uint64_t *new_start, gmg_start_errors *out, uint64_t *keys_out)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const gmg_mg_orf o = orfs[i];
         if (!o.accepted) continue;
         for (uint32_t t = 0; t < o.n_starts; t++) out[new_start[i] + t] = errs[o.start_begin + t];
+        if (keys)
+            for (uint32_t t = 0; t < o.n_starts; t++) keys_out[new_start[i] + t] = keys[o.start_begin + t];
     }
 }
 
@@ -1080,8 +1914,12 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     uint32_t *d_unfit = nullptr;
     uint32_t *d_ntiles = nullptr;
     void *d_sel_tmp = nullptr;
-    uint8_t *d_qual = nullptr, *d_user_q = nullptr;
+    uint8_t *d_qual = nullptr, *d_user_q = nullptr, *d_read_fit = nullptr;
     double *d_pen = nullptr;
+    uint64_t *d_keys = nullptr;
+    uint32_t *d_err_flag = nullptr, *d_fill = nullptr;
+    MgCall *d_calls[2] = {nullptr, nullptr};
+    MgOrfAgg *d_agg = nullptr;
     int rc = GMG_OK;
     auto fail = [&](int code) {
         (void)hipDeviceSynchronize();                   // nothing (either stream) may still use the blocks that go back to the cache
@@ -1098,6 +1936,13 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (d_qual) gmg_pool_release(d_qual);
         if (d_user_q) gmg_pool_release(d_user_q);
         if (d_pen) gmg_pool_release(d_pen);
+        if (d_read_fit) gmg_pool_release(d_read_fit);
+        if (d_keys) gmg_pool_release(d_keys);
+        if (d_err_flag) gmg_pool_release(d_err_flag);
+        if (d_fill) gmg_pool_release(d_fill);
+        if (d_calls[0]) gmg_pool_release(d_calls[0]);
+        if (d_calls[1]) gmg_pool_release(d_calls[1]);
+        if (d_agg) gmg_pool_release(d_agg);
         gmg_mg_result_free(res);
         return code;
     };
@@ -1258,26 +2103,99 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
     MG_TRY(gmg_pool_alloc((void **)&d_start_off, (no + 1) * 8));
     a.orf_cnt = d_orf_cnt;
-    if (no && err_mode) hipLaunchKernelGGL(k_mg_err_starts<false>, dim3(grid_for(no)), dim3(256), 0, s2, a);
+    const int err_acc_only = (prm->flags & GMG_MG_ACCEPTED_ONLY) ? 1 : 0;
+    // error branch: 0 = level by level, one lane per call (k_mg_err_level; default), 3 = one wave per read with a call queue in
+    // LDS (k_mg_err_queue), 1 = one lane per ORF with an explicit stack (k_mg_err_flat: exact slots, also the fallback of 0 and 3),
+    // 2 = one lane per ORF, nested calls (the first version).  1-3 stay for A/B runs and as cross-checks in the tests.
+    int err_path = getenv("GMG_MG_ERR_RECURSIVE") ? 2 : getenv("GMG_MG_ERR_FLAT") ? 1 : getenv("GMG_MG_ERR_WAVE") ? 3 : 0;
+    const bool any_unfit = err_path == 3 || reads->max_len >= 2040;
+    if (res->n_orfs && err_mode && (err_path == 0 || err_path == 3)) {
+        // LDS per wave = 50 bytes per staged base + 8.5 KB: the shorter the staged length, the more reads a CU walks at once.
+        // A batch whose reads beyond 512 bases are few (< 2 %) leaves those to the per-ORF kernel.
+        uint64_t longest = reads->max_len < 1024 ? reads->max_len : 1024;
+        if (longest > 512 && reads->n_over_512 * 50 <= reads->n_reads) longest = 512;
+        if (const char *env = getenv("GMG_MG_ERR_STAGE")) longest = (uint64_t)atoi(env) < 16 ? 16 : (uint64_t)atoi(env) > 2040 ? 2040 : (uint64_t)atoi(env);
+        a.queue_len = (int)((longest + 7) & ~7ull);
+        MG_TRY(gmg_pool_alloc((void **)&d_read_fit, nr ? nr : 1));
+        MG_TRY(gmg_pool_alloc((void **)&d_err_flag, 32));           // the flag + the two call counters
+        MG_TRY(hipMemsetAsync(d_err_flag, 0, 32, s2));
+        a.read_fit = d_read_fit;
+        a.err_flag = d_err_flag;
+        if (err_path == 0) {
+            a.n_calls = (unsigned long long *)(d_err_flag + 2);
+            a.call_cap = a.total / 2 > 65536 ? a.total / 2 : 65536;
+            if (const char *env = getenv("GMG_MG_ERR_CALLS")) a.call_cap = (uint64_t)atoll(env);     // (tests: force the fallback)
+            MG_TRY(gmg_pool_alloc((void **)&d_calls[0], a.call_cap * sizeof(MgCall)));
+            MG_TRY(gmg_pool_alloc((void **)&d_calls[1], a.call_cap * sizeof(MgCall)));
+            MG_TRY(gmg_pool_alloc((void **)&d_agg, no * sizeof(MgOrfAgg)));
+            MG_TRY(gmg_pool_alloc((void **)&d_fill, no * 4));
+            a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; a.agg = d_agg; a.fill = d_fill;
+        }
+    }
+    const size_t queue_lds = (size_t)50 * a.queue_len + 8 * (2 * MGQ_CAP + 3 * MGQ_ORFS) + 4 * (5 * MGQ_CAP + 2 * MGQ_ORFS);
+    const unsigned queue_grid = (unsigned)(nr < 256 * 16 ? (nr ? nr : 1) : 256 * 16);
+    for (int attempt = 0; attempt < 2; attempt++) {
+    const dim3 lvl_grid(256 * 16);
+    if (no && err_mode && err_path == 0) {
+        hipLaunchKernelGGL(k_mg_err_prepare, dim3(grid_for(no > nr ? no : nr)), dim3(256), 0, s2, a);
+        hipLaunchKernelGGL((k_mg_err_level<false, 0>), dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only);
+        hipLaunchKernelGGL((k_mg_err_level<false, 1>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
+        hipLaunchKernelGGL((k_mg_err_level<false, 2>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
+        hipLaunchKernelGGL(k_mg_err_verdict, dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only);
+        if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 1);
+    } else if (no && err_mode && err_path == 3) {
+        MG_TRY(hipFuncSetAttribute((const void *)k_mg_err_queue<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)queue_lds));
+        MG_TRY(hipFuncSetAttribute((const void *)k_mg_err_queue<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)queue_lds));
+        hipLaunchKernelGGL(k_mg_err_queue<false>, dim3(queue_grid), dim3(64), queue_lds, s2, a, err_acc_only);
+        hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 1);
+    } else if (no && err_mode && err_path == 1) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 0);
+    else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_starts<false>, dim3(grid_for(no)), dim3(256), 0, s2, a);
     else if (no) hipLaunchKernelGGL(k_mg_starts<false>, dim3(grid_for(no)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
+    tm.lap("start lists: count");
     rc = mg_scan(d_orf_cnt, d_start_off, no, &res->n_starts, s2);
     if (rc) return fail(rc);
-    if (res->n_starts >= 0xffffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
+    if (res->n_starts >= 0x7fffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
     MG_TRY(gmg_pool_alloc((void **)&res->d_starts, (res->n_starts ? res->n_starts : 1) * sizeof(gmg_start)));
     a.start_off = d_start_off;
     a.starts = res->d_starts;
     if (err_mode) {
         MG_TRY(gmg_pool_alloc((void **)&res->d_errs, (res->n_starts ? res->n_starts : 1) * sizeof(gmg_start_errors)));
         a.errs = res->d_errs;
+        if (err_path == 0 || err_path == 3) {
+            MG_TRY(gmg_pool_alloc((void **)&d_keys, (res->n_starts ? res->n_starts : 1) * 8));
+            a.keys = d_keys;
+        }
     }
     if (s2 != s) {                                      // (mg_scan has synchronised the side stream already; the event keeps
         MG_TRY(hipEventRecord(side_done, s2));          //  the ordering explicit)
         MG_TRY(hipStreamWaitEvent(s, side_done, 0));
     }
-    if (no && err_mode) hipLaunchKernelGGL(k_mg_err_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
+    if (no && err_mode && err_path == 0) {
+        hipLaunchKernelGGL(k_mg_err_begin, dim3(grid_for(no)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_mg_err_level<true, 0>), dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
+        hipLaunchKernelGGL((k_mg_err_level<true, 1>), lvl_grid, dim3(256), 0, s, a, err_acc_only);
+        hipLaunchKernelGGL((k_mg_err_level<true, 2>), lvl_grid, dim3(256), 0, s, a, err_acc_only);
+        if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 1);
+    } else if (no && err_mode && err_path == 3) {
+        hipLaunchKernelGGL(k_mg_err_queue<true>, dim3(queue_grid), dim3(64), queue_lds, s, a, err_acc_only);
+        hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 1);
+    } else if (no && err_mode && err_path == 1) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 0);
+    else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
     else if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
+    if (!(no && err_mode && (err_path == 0 || err_path == 3))) break;
+    uint32_t flag = 0;                                  // a read whose queue held in the count pass overflowed in the write pass?
+    MG_TRY(hipMemcpyAsync(&flag, d_err_flag, 4, hipMemcpyDeviceToHost, s));
+    MG_TRY(hipStreamSynchronize(s));
+    tm.lap("start lists: write");
+    if (!flag) break;
+    gmg_pool_release(res->d_starts); res->d_starts = nullptr;      // (not seen so far) -> everything again on the exact path
+    gmg_pool_release(res->d_errs); res->d_errs = nullptr;
+    gmg_pool_release(d_keys); d_keys = nullptr; a.keys = nullptr;
+    err_path = 1;
+    MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
+    }
     }
     if (!find_only && (prm->flags & GMG_MG_ACCEPTED_ONLY)) {
         // 4. only what Add_Events_* will see leaves the GPU: two prefix sums over the accepted flags, one gather
@@ -1286,6 +2204,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         gmg_mg_orf *d_orfs2 = nullptr;
         gmg_start *d_starts2 = nullptr;
         gmg_start_errors *d_errs2 = nullptr;
+        uint64_t *d_keys2 = nullptr;
         uint64_t n_keep = 0, n_keep_st = 0;
         hipError_t e = gmg_pool_alloc((void **)&d_keep, (no + 1) * 4);
         if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_keep_st, (no + 1) * 4);
@@ -1302,9 +2221,10 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             if (!rc2) e = gmg_pool_alloc((void **)&d_orfs2, (n_keep ? n_keep : 1) * sizeof(gmg_mg_orf));
             if (!rc2 && e == hipSuccess) e = gmg_pool_alloc((void **)&d_starts2, (n_keep_st ? n_keep_st : 1) * sizeof(gmg_start));
             if (!rc2 && e == hipSuccess && err_mode) e = gmg_pool_alloc((void **)&d_errs2, (n_keep_st ? n_keep_st : 1) * sizeof(gmg_start_errors));
+            if (!rc2 && e == hipSuccess && d_keys) e = gmg_pool_alloc((void **)&d_keys2, (n_keep_st ? n_keep_st : 1) * 8);
             if (!rc2 && e == hipSuccess) {
-                if (no && err_mode) hipLaunchKernelGGL(k_mg_keep_gather_errs, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, res->d_errs, no,
-                                                       d_new_st, d_errs2);
+                if (no && err_mode) hipLaunchKernelGGL(k_mg_keep_gather_errs, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, res->d_errs, d_keys, no,
+                                                       d_new_st, d_errs2, d_keys2);
                 if (no) hipLaunchKernelGGL(k_mg_keep_gather, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, res->d_starts, no, d_new_orf,
                                            d_new_st, d_orfs2, d_starts2);
                 hipLaunchKernelGGL(k_mg_keep_reads, dim3(grid_for(nr + 1)), dim3(256), 0, s, res->d_read_orf_off, nr, d_new_orf, d_new_first);
@@ -1320,6 +2240,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             if (d_orfs2) gmg_pool_release(d_orfs2);
             if (d_starts2) gmg_pool_release(d_starts2);
             if (d_errs2) gmg_pool_release(d_errs2);
+            if (d_keys2) gmg_pool_release(d_keys2);
             if (d_new_first) gmg_pool_release(d_new_first);
             return fail(rc2 ? rc2 : gmg_set_error(GMG_EHIP, "gmg_mg_score_reads: packing the accepted ORFs: %s", hipGetErrorString(e)));
         }
@@ -1328,11 +2249,58 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         gmg_pool_release(res->d_read_orf_off);
         if (res->d_errs) gmg_pool_release(res->d_errs);
         res->d_errs = d_errs2;
+        if (d_keys) { gmg_pool_release(d_keys); d_keys = d_keys2; }
         res->d_orfs = d_orfs2;
         res->d_starts = d_starts2;
         res->d_read_orf_off = d_new_first;
         res->n_orfs = n_keep;
         res->n_starts = n_keep_st;
+    }
+    if (d_keys && res->n_starts) {
+        // 5. error branch, per-read kernel: every ORF's slice of the start array into the reference's push order
+        //    (segmented sort of (key, index) pairs, segments = ORFs, then one permuting copy)
+        const uint64_t ns = res->n_starts, nseg = res->n_orfs;
+        uint32_t *d_seg = nullptr, *d_idx = nullptr, *d_idx2 = nullptr;
+        uint64_t *d_keys_sorted = nullptr;
+        gmg_start *d_starts3 = nullptr;
+        gmg_start_errors *d_errs3 = nullptr;
+        void *d_tmp = nullptr;
+        size_t tmp_bytes = 0;
+        hipError_t e = gmg_pool_alloc((void **)&d_seg, (2 * nseg + 2) * 4);
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_idx, ns * 4);
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_idx2, ns * 4);
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_keys_sorted, ns * 8);
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_starts3, ns * sizeof(gmg_start));
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_errs3, ns * sizeof(gmg_start_errors));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_mg_seg_bounds, dim3(grid_for(nseg)), dim3(256), 0, s, res->d_orfs, nseg, d_seg, d_seg + nseg + 1);
+            hipLaunchKernelGGL(k_mg_iota, dim3(grid_for(ns)), dim3(256), 0, s, d_idx, ns);
+            e = hipcub::DeviceSegmentedSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys_sorted, d_idx, d_idx2, (int)ns, (int)nseg, d_seg,
+                                                       d_seg + nseg + 1, s);
+        }
+        if (e == hipSuccess) e = gmg_pool_alloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+        if (e == hipSuccess) e = hipcub::DeviceSegmentedSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_idx, d_idx2, (int)ns, (int)nseg,
+                                                                        d_seg, d_seg + nseg + 1, s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_mg_permute_starts, dim3(grid_for(ns)), dim3(256), 0, s, d_idx2, ns, res->d_starts, res->d_errs, d_starts3, d_errs3);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (d_seg) gmg_pool_release(d_seg);
+        if (d_idx) gmg_pool_release(d_idx);
+        if (d_idx2) gmg_pool_release(d_idx2);
+        if (d_keys_sorted) gmg_pool_release(d_keys_sorted);
+        if (d_tmp) gmg_pool_release(d_tmp);
+        if (e != hipSuccess) {
+            if (d_starts3) gmg_pool_release(d_starts3);
+            if (d_errs3) gmg_pool_release(d_errs3);
+            return fail(gmg_set_error(e == hipErrorOutOfMemory ? GMG_ENOMEM : GMG_EHIP, "gmg_mg_score_reads: ordering the start lists: %s", hipGetErrorString(e)));
+        }
+        gmg_pool_release(res->d_starts);
+        gmg_pool_release(res->d_errs);
+        res->d_starts = d_starts3;
+        res->d_errs = d_errs3;
+        tm.lap("start lists: push order");
     }
     MG_TRY(hipStreamSynchronize(s));
     tm.lap("start lists");
@@ -1350,6 +2318,13 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (d_qual) gmg_pool_release(d_qual);
     if (d_user_q) gmg_pool_release(d_user_q);
     if (d_pen) gmg_pool_release(d_pen);
+    if (d_read_fit) gmg_pool_release(d_read_fit);
+    if (d_keys) gmg_pool_release(d_keys);
+    if (d_err_flag) gmg_pool_release(d_err_flag);
+    if (d_fill) gmg_pool_release(d_fill);
+    if (d_calls[0]) gmg_pool_release(d_calls[0]);
+    if (d_calls[1]) gmg_pool_release(d_calls[1]);
+    if (d_agg) gmg_pool_release(d_agg);
     tm.lap("free scratch");
     *out = res;
     return GMG_OK;

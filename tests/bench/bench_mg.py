@@ -2,7 +2,9 @@
 """Secondary measurement: gmg_mg_score_reads (glimmer-mg's front half: Score_All_Frames + Find_Orfs +
 Score_Orf_Starts + the filter of Score_Orfs_Errors) on synthetic 500-bp reads, with the reads
 resident in HBM.  Prints one JSON line: Mbases/s of read bases through the whole front half, the sizes of what
-leaves the GPU, and the CPU oracle's rate for the same steps on a sample."""
+leaves the GPU, and the CPU oracle's rate for the same steps on a sample.
+BENCH_ERR=indel|sub: the error branch (glimmer-mg -i / -s; BASELINE configs[4] with the ragged reads and
+Set_Quality_454's homopolymer qualities), accepted ORFs only."""
 import ctypes as C
 import json
 import os
@@ -34,7 +36,9 @@ else:
     packed, off = gmg.synth.packed_reads(n_reads, L, 7)
 reads = gmg.Reads(packed, off)
 lib = capi.lib()
-prm = capi.MgParams(75, 1, 2**31 - 1, 3, 3, 0, -6.0)
+err = os.environ.get("BENCH_ERR", "")
+prm = capi.MgParams(75, 1, 2**31 - 1, 3, 3, {"": 0, "indel": 1 | 2, "sub": 1 | 4}[err], -6.0)
+prm.min_indel_orf_len, prm.indel_quality_threshold, prm.indel_max, prm.indel_suffix_score_threshold = 15, 18, 2, -12.0
 for i, c in enumerate(("atg", "gtg", "ttg")):
     prm.start_codon[i].value = c.encode()
 for i, c in enumerate(("taa", "tag", "tga")):
@@ -67,10 +71,17 @@ import oracle_py  # noqa: E402
 orc = oracle_py.load()
 og, oi = orc.read(model), orc.indep(0.5)
 oprm = orc.mg_params()
-sample = 2000
+oerr = orc.mg_err_params(allow_indels=err == "indel", allow_subs=err == "sub")
+sample = 200 if err == "indel" else 2000
 t0 = time.perf_counter()
 for r in range(sample):
-    orc.mg_read(og, oi, gmg.synth.unpack_ascii(packed, int(off[r]), int(off[r + 1] - off[r])), oprm)
+    seq = gmg.synth.unpack_ascii(packed, int(off[r]), int(off[r + 1] - off[r]))
+    if err:
+        orc.mg_read_errors(og, oi, seq, oprm, oerr)
+    else:
+        orc.mg_read(og, oi, seq, oprm)
 out["cpu_port_mbases_per_s"] = int(off[sample]) / (time.perf_counter() - t0) / 1e6
 out["ragged"] = ragged
+out["error_branch"] = err or None
+out["cpu_sample_reads"] = sample
 print(json.dumps(out))
