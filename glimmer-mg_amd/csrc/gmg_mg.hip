@@ -107,6 +107,9 @@ struct MgArgs {
     uint64_t call_cap;           // entries per array
     struct MgOrfAgg *agg;        // [n_orfs] what the calls of an ORF add up to
     uint32_t *fill;              // [n_orfs] write pass: slots handed out inside the ORF's slice
+    const double *walk;          // [6][walk_stride] Frame_Scores in walking order (k_mg_walk_tables)
+    const uint8_t *walk_q;       // [total + 8] the qualities, last base first (forward walks; reverse walks read a.qual)
+    uint64_t walk_stride;
 };
 
 // Ch_Mask (src/Common/gene.cc:954-995)
@@ -276,6 +279,7 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
 // One lane per (read, strand); 64-byte loads per row and lane (8 positions), 64-byte stores.
 // ---------------------------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(8))) MgD4 { double v[4]; };
+struct __attribute__((packed)) MgU4 { uint32_t v; };    // four quality values at any byte address
 
 template <bool FWD>
 __device__ __forceinline__ void mg_cum_one(const MgArgs &a, uint64_t r)
@@ -1437,6 +1441,32 @@ __global__ __launch_bounds__(64) void k_mg_err_queue(MgArgs a, const int accepte
 // results through 64-bit atomics on MgOrfAgg.  Reads too long for the key fields (>= 2040 bases) and a full
 // call array are left to k_mg_err_flat.
 // ---------------------------------------------------------------------------------------------------
+// A walk that starts at global base ga reads Frame_Scores[1], [2], [0], [1], ... at ga, ga -/+ 1, ...: three rows, 24 bytes
+// apart in time, 8 useful bytes per 64-byte sector each -- with ~500k lanes walking, no cache keeps a sector until its next
+// use and the level kernels drew ~6 TB/s for 9 useful bytes per step.  Here the table is rewritten once (96 B / base) in
+// walking order: for every class c = ga % 3 one row in which consecutive steps of such a walk are consecutive doubles,
+//   forward:  walk[c][total-1-g]  = Frame_Scores[((c - g) mod 3 + 1) % 3][g]        (the walk runs down the read: reversed)
+//   reverse:  walk[3+c][g]        = Frame_Scores[3 + ((g - c) mod 3 + 1) % 3][g]
+// so a lane streams 32 bytes per four steps from one address range.
+__global__ __launch_bounds__(256) void k_mg_walk_tables(MgArgs a, double *walk, uint8_t *walk_q)
+{
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (uint64_t)gridDim.x * blockDim.x) {
+        double v[6];
+#pragma unroll
+        for (int f = 0; f < 6; f++) v[f] = a.fs[(uint64_t)f * a.fs_stride + g];
+        const int m = (int)(g % 3);
+        const uint64_t rg = a.total - 1 - g;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int tf = (c - m + 3) % 3, tr = (m - c + 3) % 3;
+            const int rf = (tf + 1) % 3, rr = (tr + 1) % 3;
+            walk[(uint64_t)c * a.walk_stride + rg] = rf == 0 ? v[0] : rf == 1 ? v[1] : v[2];
+            walk[(uint64_t)(3 + c) * a.walk_stride + g] = rr == 0 ? v[3] : rr == 1 ? v[4] : v[5];
+        }
+        if (walk_q) walk_q[rg] = a.qual[g];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_mg_err_prepare(MgArgs a)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -1451,9 +1481,15 @@ __global__ __launch_bounds__(256) void k_mg_err_prepare(MgArgs a)
 }
 
 #define MG_CALL_CHUNK 256
+#define MG_LEVEL_TILE 512        // calls a wave works through before it moves on
+
+#ifndef MG_LEVEL_WAVES
+#define MG_LEVEL_WAVES 4         // waves per SIMD the level kernels are compiled for: 128 VGPRs.  Level 1 wants 131 (3 waves:
+                                 // 214 ms per 1M reads instead of 190); asking for 5 / 6 / 8 waves spills inside the walk: 457 / 688 / 1202 ms
+#endif
 
 template <bool WRITE, int LEVEL>
-__global__ __launch_bounds__(256) void k_mg_err_level(MgArgs a, const int accepted_only)
+__global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, const int accepted_only)
 {
     __shared__ int8_t s_which[64];
     __shared__ double s_pen[64];
@@ -1466,46 +1502,33 @@ __global__ __launch_bounds__(256) void k_mg_err_level(MgArgs a, const int accept
     const int lowest_j = mgl - 3 < 3 ? mgl - 3 : 3;
     uint64_t n_in = LEVEL == 0 ? a.n_orfs : (uint64_t)a.n_calls[LEVEL - 1];
     if (LEVEL > 0 && n_in > a.call_cap) n_in = a.call_cap;
-    const uint64_t n_round = (n_in + 63) & ~63ull;      // whole waves: the lanes of a wave leave the loop together (ballots inside)
     uint64_t chunk_base = 0;                            // the wave's chunk of the next level's array (uniform over the wave)
     uint32_t chunk_used = MG_CALL_CHUNK;                // none yet
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * blockDim.x) {
-        bool active = i < n_in;
+    // A wave owns MG_LEVEL_TILE consecutive calls at a time and its lanes take them one by one: a lane that has finished its
+    // call starts the next one of the tile instead of waiting for the longest call of the wave (calls run from 0 to ~500
+    // positions; with one call per lane per round 60 % of the lane-trips were idle).
+    const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t tile = wave_id * MG_LEVEL_TILE; tile < n_in; tile += n_waves * MG_LEVEL_TILE) {
+        uint64_t next = tile;
+        const uint64_t tile_end = tile + MG_LEVEL_TILE < n_in ? tile + MG_LEVEL_TILE : n_in;
+        // the call a lane is walking
         uint32_t orf = 0;
         int end_point = 0, suffix_j = 0;
         double suffix_score = 0.0;
         uint64_t key = 0;
         uint32_t e0 = 0, e1 = 0;
-        gmg_mg_orf rec;
-        if (active) {
-            if (LEVEL == 0) { orf = (uint32_t)i; rec = a.orfs[i]; end_point = rec.frame > 0 ? rec.stop_position - 1 : rec.stop_position + 3; }
-            else {
-                const MgCall c = a.calls[LEVEL - 1][i];
-                if (c.level == 0) active = false;                               // the unused end of a wave's chunk
-                else {
-                    orf = c.orf; end_point = c.end_point; suffix_j = c.suffix_j; suffix_score = c.suffix_score; key = c.key; e0 = c.e0; e1 = c.e1;
-                    rec = a.orfs[orf];
-                }
-            }
-            if (active && !a.read_fit[rec.read]) active = false;            // k_mg_err_flat has the read
-            if (active && WRITE && accepted_only && !rec.accepted) active = false;
-        }
-        const bool fwd = active && rec.frame > 0;
-        const int64_t off = active ? (int64_t)a.read_off[rec.read] : 0;
-        const int n = active ? (int)(a.read_off[rec.read + 1] - a.read_off[rec.read]) : 0;
-        const int64_t dir = fwd ? -1 : 1;
-        const uint32_t comp = fwd ? 0u : 3u;
-        const double *row0 = a.fs + (uint64_t)(fwd ? 1 : 4) * a.fs_stride, *row1 = a.fs + (uint64_t)(fwd ? 2 : 5) * a.fs_stride,
-                     *row2 = a.fs + (uint64_t)(fwd ? 0 : 3) * a.fs_stride;
-        const int anchor = end_point - 1;
-        const int avail = fwd ? anchor + 1 : n - anchor;
-        const int64_t g0 = off + anchor;
-        int64_t g = g0;
-        uint32_t w = 0;
-        bool walking = false, is_last = false, trunc = false, first_done = false;
+        bool fwd = false;
+        int64_t off = 0, dir = 1, g0 = 0, g = 0;
+        int n = 0, anchor = 0, avail = 0;
+        uint32_t comp = 0, w = 0;
+        const double *wp = a.walk;                      // the call's stream of Frame_Scores, four doubles at a time
+        const uint8_t *qp = a.qual;
+        double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        uint32_t qw = 0;
+        bool walking = false, finishing = false, is_last = false, trunc = false, first_done = false;
         int tp = 0, jj = 0, br = 0;
         uint32_t pidx = 0, nidx = 0, last_own = MG_NO_SLOT, cnt = 0;
-        uint64_t ext_a = fwd ? ~0ull : 0ull, ext_b = ext_a;
+        uint64_t ext_a = 0, ext_b = 0;
         double sum = 0.0, prev = 0.0, best = -DBL_MAX;
 
         auto fetch = [&](int t, uint32_t &idx) __attribute__((always_inline)) -> bool {
@@ -1546,22 +1569,75 @@ __global__ __launch_bounds__(256) void k_mg_err_level(MgArgs a, const int accept
             return slot;
         };
 
-        if (active && anchor >= 0 && anchor < n) {
-            w = a.packed[g >> 4];
-            walking = !fetch(0, pidx);
-        }
-        bool finishing = active;                        // the end-of-call work is still to do
-        while (__ballot(walking || finishing)) {
+        for (;;) {
+            {   // idle lanes take the next calls of the tile
+                const bool idle = !(walking || finishing);
+                const uint64_t im = __ballot(idle);
+                const uint64_t left = tile_end - next;
+                const uint32_t rank = __popcll(im & lt);
+                if (idle && rank < left) {
+                    const uint64_t i = next + rank;
+                    bool active = true;
+                    gmg_mg_orf rec;
+                    suffix_j = 0; suffix_score = 0.0; key = 0; e0 = e1 = 0;
+                    if (LEVEL == 0) { orf = (uint32_t)i; rec = a.orfs[i]; end_point = rec.frame > 0 ? rec.stop_position - 1 : rec.stop_position + 3; }
+                    else {
+                        const MgCall c = a.calls[LEVEL - 1][i];
+                        if (c.level == 0) active = false;                       // the unused end of a wave's chunk
+                        else {
+                            orf = c.orf; end_point = c.end_point; suffix_j = c.suffix_j; suffix_score = c.suffix_score; key = c.key; e0 = c.e0; e1 = c.e1;
+                            rec = a.orfs[orf];
+                        }
+                    }
+                    if (active && !a.read_fit[rec.read]) active = false;        // k_mg_err_flat has the read
+                    if (active && WRITE && accepted_only && !rec.accepted) active = false;
+                    if (active) {
+                        fwd = rec.frame > 0;
+                        off = (int64_t)a.read_off[rec.read];
+                        n = (int)(a.read_off[rec.read + 1] - a.read_off[rec.read]);
+                        dir = fwd ? -1 : 1; comp = fwd ? 0u : 3u;
+                        anchor = end_point - 1;
+                        avail = fwd ? anchor + 1 : n - anchor;
+                        g0 = off + anchor; g = g0;
+                        if (anchor >= 0 && anchor < n) {
+                            const uint64_t ga = (uint64_t)g0;
+                            wp = a.walk + (uint64_t)((fwd ? 0 : 3) + (int)(ga % 3)) * a.walk_stride + (fwd ? a.total - 1 - ga : ga);
+                            qp = fwd ? a.walk_q + (a.total - 1 - ga) : a.qual + ga;
+                        }
+                        is_last = false; trunc = false; first_done = false; walking = false;
+                        tp = 0; jj = 0; br = 0; last_own = MG_NO_SLOT; cnt = 0;
+                        ext_a = ext_b = fwd ? ~0ull : 0ull;
+                        sum = 0.0; prev = 0.0; best = -DBL_MAX;
+                        if (anchor >= 0 && anchor < n) {
+                            w = a.packed[g >> 4];
+                            walking = !fetch(0, pidx);
+                        }
+                        finishing = true;               // the end-of-call work is still to do
+                    }
+                }
+                const uint32_t n_idle = __popcll(im);
+                next += n_idle < left ? n_idle : left;
+            }
+            if (!__ballot(walking || finishing)) {
+                if (next >= tile_end) break;
+                continue;                               // (the calls just taken were all empty entries)
+            }
+            {
             bool want_push = false;
             MgCall child;
             if (walking) {
                 const int j = 3 * tp + jj;
-                const int64_t gj = g0 + dir * j;
                 const int k = fwd ? end_point - 2 - j : end_point + 2 + j;
+                const int ph = j & 3;
                 if (br == 0) {
                     if (jj == 0) is_last = fetch(tp + 1, nidx);
+                    if (ph == 0) {                      // the next four values of the stream (the tables end in 8 spare entries)
+                        const MgD4 d = *(const MgD4 *)(wp + j);
+                        b0 = d.v[0]; b1 = d.v[1]; b2 = d.v[2]; b3 = d.v[3];
+                        if (LEVEL < 2 && !WRITE && a.err_mode == 1) qw = ((const MgU4 *)(qp + j))->v;
+                    }
                     prev = sum;
-                    sum = prev + (jj == 0 ? row0 : jj == 1 ? row1 : row2)[gj];
+                    sum = prev + (ph == 0 ? b0 : ph == 1 ? b1 : ph == 2 ? b2 : b3);
                     if (jj == 0 && j >= lowest_j && j + 3 + suffix_j >= mgl) {
                         const int which = s_which[pidx];
                         const double raw = (prev - 0.0) + suffix_score;
@@ -1570,7 +1646,7 @@ __global__ __launch_bounds__(256) void k_mg_err_level(MgArgs a, const int accept
                     }
                 }
                 if (LEVEL < 2 && !WRITE && a.err_mode == 1 && LEVEL < a.indel_max && j >= lowest_j) {
-                    const int q = a.qual[gj];
+                    const int q = (int)((qw >> (8 * ph)) & 255u);
                     if (q <= a.indel_q_thr) {
                         const double pen = pen_lds ? s_pen[q] : a.pen[q];
                         while (br < 2) {
@@ -1651,6 +1727,7 @@ __global__ __launch_bounds__(256) void k_mg_err_level(MgArgs a, const int accept
                     }
                     chunk_used += np;
                 }
+            }
             }
         }
     }
@@ -1920,6 +1997,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     uint32_t *d_err_flag = nullptr, *d_fill = nullptr;
     MgCall *d_calls[2] = {nullptr, nullptr};
     MgOrfAgg *d_agg = nullptr;
+    double *d_walk = nullptr;
+    uint8_t *d_walk_q = nullptr;
     int rc = GMG_OK;
     auto fail = [&](int code) {
         (void)hipDeviceSynchronize();                   // nothing (either stream) may still use the blocks that go back to the cache
@@ -1943,6 +2022,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (d_calls[0]) gmg_pool_release(d_calls[0]);
         if (d_calls[1]) gmg_pool_release(d_calls[1]);
         if (d_agg) gmg_pool_release(d_agg);
+        if (d_walk) gmg_pool_release(d_walk);
+        if (d_walk_q) gmg_pool_release(d_walk_q);
         gmg_mg_result_free(res);
         return code;
     };
@@ -1974,7 +2055,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         MG_TRY(hipMemcpyAsync(d_pen, pen_host, sizeof pen_host, hipMemcpyHostToDevice, s));
         a.pen = d_pen;
         if (err_mode == 1 && a.total) {
-            MG_TRY(gmg_pool_alloc((void **)&d_qual, a.total));
+            MG_TRY(gmg_pool_alloc((void **)&d_qual, a.total + 8));     // (+8: the level kernels read four values at a time)
             if (prm->quality) {
                 MG_TRY(gmg_pool_alloc((void **)&d_user_q, a.total));
                 MG_TRY(hipMemcpyAsync(d_user_q, prm->quality, a.total, hipMemcpyHostToDevice, s));
@@ -2130,6 +2211,13 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             MG_TRY(gmg_pool_alloc((void **)&d_agg, no * sizeof(MgOrfAgg)));
             MG_TRY(gmg_pool_alloc((void **)&d_fill, no * 4));
             a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; a.agg = d_agg; a.fill = d_fill;
+            a.walk_stride = ((a.total + 15) & ~15ull) + 16;
+            MG_TRY(gmg_pool_alloc((void **)&d_walk, (size_t)6 * a.walk_stride * sizeof(double)));
+            if (err_mode == 1) MG_TRY(gmg_pool_alloc((void **)&d_walk_q, a.total + 8));
+            hipLaunchKernelGGL(k_mg_walk_tables, dim3(grid_for(a.total)), dim3(256), 0, s2, a, d_walk, d_walk_q);
+            MG_TRY(hipGetLastError());
+            a.walk = d_walk; a.walk_q = d_walk_q;
+            tm.lap("walk-order tables");
         }
     }
     const size_t queue_lds = (size_t)50 * a.queue_len + 8 * (2 * MGQ_CAP + 3 * MGQ_ORFS) + 4 * (5 * MGQ_CAP + 2 * MGQ_ORFS);
@@ -2325,6 +2413,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (d_calls[0]) gmg_pool_release(d_calls[0]);
     if (d_calls[1]) gmg_pool_release(d_calls[1]);
     if (d_agg) gmg_pool_release(d_agg);
+    if (d_walk) gmg_pool_release(d_walk);
+    if (d_walk_q) gmg_pool_release(d_walk_q);
     tm.lap("free scratch");
     *out = res;
     return GMG_OK;

@@ -290,7 +290,7 @@ class Oracle:
             self.L.orc_clean_quality_454(s, len(s), q.ctypes.data_as(ip), indel_quality_threshold)
         return q[:len(s)]
 
-    def mg_score_orf_errors(self, frame_scores, seq, fwd_prev, rev_next, quality, frame, stop_position, prm, ep, cap=1 << 16):
+    def mg_score_orf_errors(self, frame_scores, seq, fwd_prev, rev_next, quality, frame, stop_position, prm, ep, cap=1 << 10):
         """-> (MgOut, [StartErr] in push order)"""
         s = seq.encode() if isinstance(seq, str) else seq
         fs = np.ascontiguousarray(frame_scores, np.float64)

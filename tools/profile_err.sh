@@ -1,8 +1,11 @@
+#!/bin/bash
+# Kernel trace of the error branch (glimmer-mg -i) on the GPU box: tools/profile_err.sh [reads]
+# (counters: collect them per kernel in short separate runs -- a --pmc pass over the whole bench serialises the long
+#  walking kernels and takes tens of minutes)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-export BENCH_ERR=indel
+N=${1:-1000000}
 OUT=gpurun_out/prof_err
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tests/bench/bench_mg.py 200000 1 ragged > $OUT/trace.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc1 -- python3 tests/bench/bench_mg.py 200000 1 ragged > $OUT/pmc1.log 2>&1
-rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OUT/pmc2 -- python3 tests/bench/bench_mg.py 200000 1 ragged > $OUT/pmc2.log 2>&1
-find $OUT -name "*kernel_stats.csv" | head -1 | xargs head -12 | cut -c1-200
+BENCH_ERR=${BENCH_ERR:-indel} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tests/bench/bench_mg.py $N 2 ragged > $OUT/trace.log 2>&1
+tail -1 $OUT/trace.log | cut -c1-400
+find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs head -16 | cut -d, -f1-4 | cut -c1-160
