@@ -1,6 +1,8 @@
 // gmg_mg.hip -- glimmer-mg's front half on gfx950: from packed reads to the start lists that
-// Score_Orfs_Errors (src/Glimmer/glimmer-mg.cc:1605-1689) hands to Add_Events_*.  Default mode only
-// (Allow_Indels = Allow_Subs = false, glimmer-mg.cc:100-102), linear sequences, no ignore regions.
+// Score_Orfs_Errors (src/Glimmer/glimmer-mg.cc:1605-1689) hands to Add_Events_*.  Linear sequences, no ignore
+// regions.  Steps 3 and 4 below are the default mode (Allow_Indels = Allow_Subs = false, glimmer-mg.cc:100-102);
+// with -i / -s they are replaced by the error branch further down (k_mg_err_*: Score_Indels and the recursive
+// Score_Orf_Starts, one lane per call, level by level).
 //
 //   1. gmg_launch_frame6        Score_All_Frames (glimmer-mg.cc:1468-1510): Frame_Scores[6][total] in HBM
 //   2. k_mg_find_orfs<count>    Find_Orfs (glimmer_base.cc:638-779), one lane per read: ORFs per read

@@ -256,7 +256,7 @@ int gmg_score_orfs(const gmg_model *gene, const gmg_model *null_model, const gmg
                    gmg_orf_result *results, gmg_start *starts, void *stream);
 
 /* ---- glimmer-mg front half on the device -------------------------------------------
- * Everything between the reads and Add_Events_* for glimmer-mg's default mode (no -i / -s branch):
+ * Everything between the reads and Add_Events_* for glimmer-mg's user-ICM mode (the -i / -s error branch: see the flags below):
  *   Score_All_Frames      src/Glimmer/glimmer-mg.cc:1468-1510   (gmg_frame_score6's kernels)
  *   Find_Orfs             src/Glimmer/glimmer_base.cc:638-779   (linear sequences, no ignore regions)
  *   Save_Prev_Stops       src/Glimmer/glimmer-mg.cc:675-729     (folded into the ORF scan: lo / hi per ORF)
