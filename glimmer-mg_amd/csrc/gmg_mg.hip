@@ -281,6 +281,7 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
 // One lane per (read, strand); 64-byte loads per row and lane (8 positions), 64-byte stores.
 // ---------------------------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(8))) MgD4 { double v[4]; };
+struct __attribute__((packed, aligned(8))) MgD3 { double v[3]; };
 struct __attribute__((packed)) MgU4 { uint32_t v; };    // four quality values at any byte address
 
 template <bool FWD>
@@ -1484,6 +1485,9 @@ __global__ __launch_bounds__(256) void k_mg_err_prepare(MgArgs a)
 
 #define MG_CALL_CHUNK 256
 #define MG_LEVEL_TILE 512        // calls a wave works through before it moves on
+#ifndef MG_LEVEL_BATCH
+#define MG_LEVEL_BATCH 16        // lanes that wait before the wave runs the take / finish code (1: 191 ms count pass per 1M reads; 8: 147; 16: 141; 32: 146)
+#endif
 
 #ifndef MG_LEVEL_WAVES
 #define MG_LEVEL_WAVES 4         // waves per SIMD the level kernels are compiled for: 128 VGPRs.  Level 1 wants 131 (3 waves:
@@ -1499,7 +1503,6 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
     __syncthreads();
     const bool pen_lds = a.indel_q_thr < 64;
     const int lane = threadIdx.x & 63;
-    const uint64_t lt = (1ull << lane) - 1;
     const int mgl = a.min_gene_len;
     const int lowest_j = mgl - 3 < 3 ? mgl - 3 : 3;
     uint64_t n_in = LEVEL == 0 ? a.n_orfs : (uint64_t)a.n_calls[LEVEL - 1];
@@ -1520,15 +1523,15 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
         uint64_t key = 0;
         uint32_t e0 = 0, e1 = 0;
         bool fwd = false;
-        int64_t off = 0, dir = 1, g0 = 0, g = 0;
-        int n = 0, anchor = 0, avail = 0;
+        int64_t dir = 1, g = 0;
+        int avail = 0;
         uint32_t comp = 0, w = 0;
         const double *wp = a.walk;                      // the call's stream of Frame_Scores, four doubles at a time
         const uint8_t *qp = a.qual;
-        double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        double s0 = 0.0, s1 = 0.0;                      // score[] inside the codon being walked
         uint32_t qw = 0;
         bool walking = false, finishing = false, is_last = false, trunc = false, first_done = false;
-        int tp = 0, jj = 0, br = 0;
+        int tp = 0, br = 0;                             // codon, next branch candidate of it (0..5; 6 none)
         uint32_t pidx = 0, nidx = 0, last_own = MG_NO_SLOT, cnt = 0;
         uint64_t ext_a = 0, ext_b = 0;
         double sum = 0.0, prev = 0.0, best = -DBL_MAX;
@@ -1572,11 +1575,16 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
         };
 
         for (;;) {
-            {   // idle lanes take the next calls of the tile
-                const bool idle = !(walking || finishing);
-                const uint64_t im = __ballot(idle);
+            // The trip of a walking lane is short; taking a new call and finishing one are long, and a wave executes whatever ANY of
+            // its lanes needs.  So those two happen in batches: only when MG_LEVEL_BATCH lanes wait for them (or nobody walks).
+            const uint64_t wm = __ballot(walking);
+            const uint64_t fm = __ballot(finishing && !walking);
+            const bool do_fin = fm && (__popcll(fm) >= MG_LEVEL_BATCH || !wm);
+            const bool idle = !(walking || finishing);
+            const uint64_t im = __ballot(idle);
+            if (next < tile_end && (__popcll(im) >= MG_LEVEL_BATCH || !(wm | fm))) {   // idle lanes take the next calls of the tile
                 const uint64_t left = tile_end - next;
-                const uint32_t rank = __popcll(im & lt);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
                 if (idle && rank < left) {
                     const uint64_t i = next + rank;
                     bool active = true;
@@ -1595,19 +1603,19 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                     if (active && WRITE && accepted_only && !rec.accepted) active = false;
                     if (active) {
                         fwd = rec.frame > 0;
-                        off = (int64_t)a.read_off[rec.read];
-                        n = (int)(a.read_off[rec.read + 1] - a.read_off[rec.read]);
+                        const int64_t off = (int64_t)a.read_off[rec.read];
+                        const int n = (int)(a.read_off[rec.read + 1] - a.read_off[rec.read]);
                         dir = fwd ? -1 : 1; comp = fwd ? 0u : 3u;
-                        anchor = end_point - 1;
+                        const int anchor = end_point - 1;
                         avail = fwd ? anchor + 1 : n - anchor;
-                        g0 = off + anchor; g = g0;
+                        g = off + anchor;
                         if (anchor >= 0 && anchor < n) {
-                            const uint64_t ga = (uint64_t)g0;
+                            const uint64_t ga = (uint64_t)g;
                             wp = a.walk + (uint64_t)((fwd ? 0 : 3) + (int)(ga % 3)) * a.walk_stride + (fwd ? a.total - 1 - ga : ga);
                             qp = fwd ? a.walk_q + (a.total - 1 - ga) : a.qual + ga;
                         }
                         is_last = false; trunc = false; first_done = false; walking = false;
-                        tp = 0; jj = 0; br = 0; last_own = MG_NO_SLOT; cnt = 0;
+                        tp = 0; br = 0; last_own = MG_NO_SLOT; cnt = 0;
                         ext_a = ext_b = fwd ? ~0ull : 0ull;
                         sum = 0.0; prev = 0.0; best = -DBL_MAX;
                         if (anchor >= 0 && anchor < n) {
@@ -1625,59 +1633,56 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                 continue;                               // (the calls just taken were all empty entries)
             }
             {
-            bool want_push = false;
-            MgCall child;
+            bool want_push = false;                     // a branch met in this trip: end point, suffix, error entry, key field
+            int c_end = 0, c_sj = 0;
+            uint32_t c_err = 0, c_field = 0;
+            double c_score = 0.0;
             if (walking) {
-                const int j = 3 * tp + jj;
-                const int k = fwd ? end_point - 2 - j : end_point + 2 + j;
-                const int ph = j & 3;
-                if (br == 0) {
-                    if (jj == 0) is_last = fetch(tp + 1, nidx);
-                    if (ph == 0) {                      // the next four values of the stream (the tables end in 8 spare entries)
-                        const MgD4 d = *(const MgD4 *)(wp + j);
-                        b0 = d.v[0]; b1 = d.v[1]; b2 = d.v[2]; b3 = d.v[3];
-                        if (LEVEL < 2 && !WRITE && a.err_mode == 1) qw = ((const MgU4 *)(qp + j))->v;
-                    }
-                    prev = sum;
-                    sum = prev + (ph == 0 ? b0 : ph == 1 ? b1 : ph == 2 ? b2 : b3);
-                    if (jj == 0 && j >= lowest_j && j + 3 + suffix_j >= mgl) {
+                // one in-frame codon (three buffer positions) per trip: the lanes of a wave stay in the same phase of the codon
+                const int j0 = 3 * tp;
+                if (br == 0) {                          // first visit of the codon
+                    is_last = fetch(tp + 1, nidx);      // is it the last of the region?
+                    const MgD3 d = *(const MgD3 *)(wp + j0);       // (the tables end in 8 spare entries)
+                    if (LEVEL < 2 && !WRITE && a.err_mode == 1) qw = ((const MgU4 *)(qp + j0))->v;
+                    prev = sum;                         // score[j0 - 1]
+                    s0 = prev + d.v[0]; s1 = s0 + d.v[1]; sum = s1 + d.v[2];       // score[j0], [j0 + 1], [j0 + 2]
+                    if (j0 >= lowest_j && j0 + 3 + suffix_j >= mgl) {
+                        const int k = fwd ? end_point - 2 - j0 : end_point + 2 + j0;
                         const int which = s_which[pidx];
                         const double raw = (prev - 0.0) + suffix_score;
-                        if (which >= 0) last_own = emit(raw, j, k, which, 0, 0, 3u);
-                        if (is_last && trunc) { emit(raw, j, k, -1, 1, 1, 2u); first_done = true; }
+                        if (which >= 0) last_own = emit(raw, j0, k, which, 0, 0, 3u);
+                        if (is_last && trunc) { emit(raw, j0, k, -1, 1, 1, 2u); first_done = true; }
                     }
                 }
-                if (LEVEL < 2 && !WRITE && a.err_mode == 1 && LEVEL < a.indel_max && j >= lowest_j) {
-                    const int q = (int)((qw >> (8 * ph)) & 255u);
-                    if (q <= a.indel_q_thr) {
+                if (LEVEL < 2 && !WRITE && a.err_mode == 1 && LEVEL < a.indel_max) {
+                    // Score_Indels at the three positions, in reversed push order: per position insertion, then deletion
+                    while (br < 6) {
+                        const int c = br++, pj = c >> 1, b = c & 1, j = j0 + pj;
+                        const int q = (int)((qw >> (8 * pj)) & 255u);
+                        if (j < lowest_j || q > a.indel_q_thr) { br = 2 * pj + 2; continue; }
                         const double pen = pen_lds ? s_pen[q] : a.pen[q];
-                        while (br < 2) {
-                            const int b = br++;
-                            const double es = ((suffix_score + (b == 0 ? prev : sum)) - 0.0) + pen;
-                            if (es > a.indel_suffix_thr) {
-                                int epos;
-                                if (b == 0) { child.end_point = fwd ? k - (2 - jj) : k + 2 - jj; epos = fwd ? k + 2 : k - 2; }
-                                else { child.end_point = fwd ? k + jj : k - jj; epos = fwd ? k + 3 : k - 1; }
-                                child.suffix_score = es; child.suffix_j = suffix_j + j + 2 - jj;
-                                const uint32_t ce = (uint32_t)(epos + 8) << 2 | (uint32_t)b;
-                                child.e0 = LEVEL == 0 ? ce : e0; child.e1 = LEVEL == 1 ? ce : 0;
-                                child.key = key | (uint64_t)((uint32_t)(2047 - j) << 2 | (b == 0 ? 1u : 0u)) << (26 - 13 * LEVEL);
-                                want_push = true;
-                                break;
-                            }
+                        const double before = pj == 0 ? prev : pj == 1 ? s0 : s1, at = pj == 0 ? s0 : pj == 1 ? s1 : sum;
+                        const double es = ((suffix_score + (b == 0 ? before : at)) - 0.0) + pen;
+                        if (es > a.indel_suffix_thr) {
+                            const int k = fwd ? end_point - 2 - j : end_point + 2 + j;
+                            int epos;
+                            if (b == 0) { c_end = fwd ? k - (2 - pj) : k + 2 - pj; epos = fwd ? k + 2 : k - 2; }
+                            else { c_end = fwd ? k + pj : k - pj; epos = fwd ? k + 3 : k - 1; }
+                            c_score = es; c_sj = suffix_j + j + 2 - pj;
+                            c_err = (uint32_t)(epos + 8) << 2 | (uint32_t)b;
+                            c_field = (uint32_t)(2047 - j) << 2 | (b == 0 ? 1u : 0u);
+                            want_push = true;
+                            break;
                         }
                     }
                 }
                 if (!want_push) {
                     br = 0;
-                    if (++jj == 3) {
-                        jj = 0;
-                        if (is_last) walking = false;
-                        else pidx = nidx;
-                        tp++;
-                    }
+                    if (is_last) walking = false;
+                    else pidx = nidx;
+                    tp++;
                 }
-            } else if (finishing) {
+            } else if (finishing && do_fin) {
                 finishing = false;
                 const int m = 3 * tp;
                 if (LEVEL == 0 && !WRITE) {
@@ -1685,15 +1690,19 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                     if (a.err_mode == 2) {              // the substitution branch (:1771-1806)
                         const int lo = fwd ? end_point - m : end_point, hi = fwd ? end_point : end_point + m;
                         const int eep = fwd ? lo - 3 : hi + 3;
+                        const uint32_t rd = a.orfs[orf].read;
+                        const int64_t off = (int64_t)a.read_off[rd];
+                        const int n = (int)(a.read_off[rd + 1] - a.read_off[rd]);
+                        const int anchor = end_point - 1;
                         if (anchor >= 0 && anchor < n && eep >= 0 && eep - 2 < n) {
                             auto base = [&](int x) { const int64_t y = off + x; return (a.packed[y >> 4] >> (2u * (unsigned)(y & 15))) & 3u; };
                             const uint32_t want = fwd ? 0u : 3u;
                             const int a1 = base(fwd ? lo - 2 : hi) == want, a2 = base(fwd ? lo - 1 : hi - 1) == want;
                             double es = suffix_score + a.pass_stop[a1 * 2 + a2];
                             if (m > 0) es += sum - 0.0;
-                            child.end_point = eep; child.suffix_score = es; child.suffix_j = suffix_j + m;
-                            child.e0 = (uint32_t)((fwd ? lo - 2 : hi + 2) + 8) << 2 | 2u; child.e1 = 0;
-                            child.key = key | (uint64_t)(0u << 2 | 0u) << 26;      // before every position of the call
+                            c_end = eep; c_score = es; c_sj = suffix_j + m;
+                            c_err = (uint32_t)((fwd ? lo - 2 : hi + 2) + 8) << 2 | 2u;
+                            c_field = 0;                    // before every position of the call
                             want_push = true;
                         }
                     }
@@ -1719,13 +1728,21 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                             if (chunk_base + x < a.call_cap) a.calls[LEVEL][chunk_base + x].level = 0;
                         unsigned long long base = 0;
                         if (lane == 0) base = atomicAdd(&a.n_calls[LEVEL], (unsigned long long)MG_CALL_CHUNK);
-                        chunk_base = __shfl(base, 0);
+                        chunk_base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base) |
+                                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32;
                         chunk_used = 0;
                         if (chunk_base + MG_CALL_CHUNK > a.call_cap && lane == 0) atomicOr(a.err_flag, 1u);
                     }
                     if (want_push) {
-                        const uint64_t slot = chunk_base + chunk_used + __popcll(pm & lt);
-                        if (slot < a.call_cap) { child.orf = orf; child.level = LEVEL + 1; a.calls[LEVEL][slot] = child; }
+                        const uint64_t slot = chunk_base + chunk_used + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                        if (slot < a.call_cap) {
+                            MgCall child;
+                            child.suffix_score = c_score; child.end_point = c_end; child.suffix_j = c_sj;
+                            child.key = key | (uint64_t)c_field << (26 - 13 * LEVEL);
+                            child.e0 = LEVEL == 0 ? c_err : e0; child.e1 = LEVEL == 1 ? c_err : 0;
+                            child.orf = orf; child.level = LEVEL + 1;
+                            a.calls[LEVEL][slot] = child;
+                        }
                     }
                     chunk_used += np;
                 }
