@@ -48,13 +48,15 @@ struct gmg_mg_result {
     uint64_t n_reads, n_orfs, n_starts;
 };
 
-struct MgCall {                  // one Score_Orf_Starts call waiting to be walked
+struct MgCall {                  // one Score_Orf_Starts call waiting to be walked (56 bytes)
     double suffix_score;
     uint64_t key;                // order of its starts among the ORF's: the fields of the levels above it
+    uint64_t off;                // its read: first base and length (so that taking a call is ONE load, not a chain of three)
     uint32_t orf;
-    int32_t end_point, suffix_j;
+    int32_t end_point, suffix_j, n;
     uint32_t e0, e1;             // Error_t entries of the path: (pos + 8) << 2 | type
-    uint32_t level;
+    uint32_t level;              // 0: empty entry; else level | forward strand << 8
+    uint32_t pad;
 };
 struct MgOrfAgg { unsigned long long best, ext_a, ext_b; uint32_t cnt, m0; };
 
@@ -1523,8 +1525,8 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
         uint64_t key = 0;
         uint32_t e0 = 0, e1 = 0;
         bool fwd = false;
-        int64_t dir = 1, g = 0;
-        int avail = 0;
+        int64_t dir = 1, g = 0, off = 0;
+        int avail = 0, n = 0;
         uint32_t comp = 0, w = 0;
         const double *wp = a.walk;                      // the call's stream of Frame_Scores, four doubles at a time
         const uint8_t *qp = a.qual;
@@ -1588,23 +1590,25 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                 if (idle && rank < left) {
                     const uint64_t i = next + rank;
                     bool active = true;
-                    gmg_mg_orf rec;
                     suffix_j = 0; suffix_score = 0.0; key = 0; e0 = e1 = 0;
-                    if (LEVEL == 0) { orf = (uint32_t)i; rec = a.orfs[i]; end_point = rec.frame > 0 ? rec.stop_position - 1 : rec.stop_position + 3; }
-                    else {
+                    if (LEVEL == 0) {
+                        const gmg_mg_orf rec = a.orfs[i];
+                        orf = (uint32_t)i; end_point = rec.frame > 0 ? rec.stop_position - 1 : rec.stop_position + 3;
+                        fwd = rec.frame > 0;
+                        if (!a.read_fit[rec.read]) active = false;              // k_mg_err_flat has the read
+                        if (WRITE && accepted_only && !rec.accepted) active = false;
+                        off = (int64_t)a.read_off[rec.read];
+                        n = (int)(a.read_off[rec.read + 1] - a.read_off[rec.read]);
+                    } else {
                         const MgCall c = a.calls[LEVEL - 1][i];
                         if (c.level == 0) active = false;                       // the unused end of a wave's chunk
                         else {
                             orf = c.orf; end_point = c.end_point; suffix_j = c.suffix_j; suffix_score = c.suffix_score; key = c.key; e0 = c.e0; e1 = c.e1;
-                            rec = a.orfs[orf];
+                            off = (int64_t)c.off; n = c.n; fwd = (c.level >> 8) & 1;
+                            if (WRITE && accepted_only && !a.orfs[orf].accepted) active = false;
                         }
                     }
-                    if (active && !a.read_fit[rec.read]) active = false;        // k_mg_err_flat has the read
-                    if (active && WRITE && accepted_only && !rec.accepted) active = false;
                     if (active) {
-                        fwd = rec.frame > 0;
-                        const int64_t off = (int64_t)a.read_off[rec.read];
-                        const int n = (int)(a.read_off[rec.read + 1] - a.read_off[rec.read]);
                         dir = fwd ? -1 : 1; comp = fwd ? 0u : 3u;
                         const int anchor = end_point - 1;
                         avail = fwd ? anchor + 1 : n - anchor;
@@ -1690,9 +1694,6 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                     if (a.err_mode == 2) {              // the substitution branch (:1771-1806)
                         const int lo = fwd ? end_point - m : end_point, hi = fwd ? end_point : end_point + m;
                         const int eep = fwd ? lo - 3 : hi + 3;
-                        const uint32_t rd = a.orfs[orf].read;
-                        const int64_t off = (int64_t)a.read_off[rd];
-                        const int n = (int)(a.read_off[rd + 1] - a.read_off[rd]);
                         const int anchor = end_point - 1;
                         if (anchor >= 0 && anchor < n && eep >= 0 && eep - 2 < n) {
                             auto base = [&](int x) { const int64_t y = off + x; return (a.packed[y >> 4] >> (2u * (unsigned)(y & 15))) & 3u; };
@@ -1740,7 +1741,7 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                             child.suffix_score = c_score; child.end_point = c_end; child.suffix_j = c_sj;
                             child.key = key | (uint64_t)c_field << (26 - 13 * LEVEL);
                             child.e0 = LEVEL == 0 ? c_err : e0; child.e1 = LEVEL == 1 ? c_err : 0;
-                            child.orf = orf; child.level = LEVEL + 1;
+                            child.orf = orf; child.level = (uint32_t)(LEVEL + 1) | (fwd ? 256u : 0u); child.off = (uint64_t)off; child.n = n; child.pad = 0;
                             a.calls[LEVEL][slot] = child;
                         }
                     }
