@@ -119,3 +119,58 @@ def test_error_branch_accepted_only_and_flag_errors(gpu, oracle, nc):
     # the plain mode is untouched by the new fields, and find_orfs follows the flag
     plain = gpu.mg_score_reads(nc, gpu.Icm.indep(gc), reads, **kw)
     assert len(plain[0]) < len(full[0])
+
+
+def test_error_branch_full_size_properties(gpu, oracle, nc):
+    """BASELINE configs[4] shape: 1M reads of ~400 bp (N(400, 60^2) clipped to 100..700), Set_Quality_454 qualities, -i.
+    (1) determinism: two calls give identical bytes although slots inside an ORF's slice are handed out by atomics (the
+    sort by key restores the push order); (2) bookkeeping: accepted ORFs only, slices back to back and exactly
+    sum(n_starts) long, error lists consistent with their length; (3) the per-ORF fallback kernel gives the same bytes on
+    a 20k-read slice; (4) sampled reads equal the oracle, every accepted ORF with its list in push order."""
+    n = 1_000_000
+    lens = np.clip(np.random.default_rng(12).normal(400, 60, n).round(), 100, 700).astype(np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    packed, _ = gpu.synth.packed_reads(1, int(off[-1]), 7)
+    reads = gpu.Reads(packed, off)
+    indep = gpu.Icm.indep(0.5)
+    orfs, starts, first, errs = gpu.mg_score_reads(nc, indep, reads, allow_indels=True, accepted_only=True)
+    orfs2, starts2, first2, errs2 = gpu.mg_score_reads(nc, indep, reads, allow_indels=True, accepted_only=True)
+    assert orfs.tobytes() == orfs2.tobytes() and starts.tobytes() == starts2.tobytes() and errs.tobytes() == errs2.tobytes()
+    assert np.array_equal(first, first2)
+    del orfs2, starts2, errs2
+    assert len(orfs) == first[-1] > n // 10 and np.all(orfs["accepted"] != 0)
+    assert np.array_equal(orfs["start_begin"], np.concatenate([[0], np.cumsum(orfs["n_starts"].astype(np.int64))[:-1]]))
+    assert int(orfs["n_starts"].astype(np.int64).sum()) == len(starts) == len(errs)
+    assert errs["n"].min() >= 0 and errs["n"].max() == 2
+    assert np.all(errs["type"][errs["n"] == 0] == 0) and np.all(errs["pos"][errs["n"] < 2][:, 1] == 0)
+    assert np.all(np.diff(orfs["read"].astype(np.int64)) >= 0)
+
+    m = 20_000                                          # a slice on its own, default kernels and the exact per-ORF fallback
+    sub_packed, _ = gpu.synth.packed_reads(1, int(off[m]), 7)       # same generator, same seed: the first off[m] bases
+    sub = gpu.Reads(sub_packed, off[:m + 1].copy())
+    a = gpu.mg_score_reads(nc, indep, sub, allow_indels=True, accepted_only=True)
+    os.environ["GMG_MG_ERR_FLAT"] = "1"
+    try:
+        b = gpu.mg_score_reads(nc, indep, sub, allow_indels=True, accepted_only=True)
+    finally:
+        del os.environ["GMG_MG_ERR_FLAT"]
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()
+    k = int(first[m])
+    assert a[0].tobytes() == orfs[:k].tobytes() and a[1].tobytes() == starts[:len(a[1])].tobytes()
+
+    prm, ep = oracle.mg_params(), oracle.mg_err_params(allow_indels=True)
+    o_nc, o_indep = oracle.read(os.path.join(DATA, "NC_000915.icm")), oracle.indep(0.5)
+    checked = 0
+    for r in (0, 1, 4242, 31337, 555555, n - 1):
+        seq = gpu.synth.unpack_ascii(packed, int(off[r]), int(off[r + 1] - off[r]))
+        want_orfs, _, scored = oracle.mg_read_errors(o_nc, o_indep, seq, prm, ep)
+        acc = [(o, out, st) for o, (out, st) in zip(want_orfs, scored) if out.accepted]
+        mine = orfs[int(first[r]):int(first[r + 1])]
+        assert len(mine) == len(acc)
+        for g, (o, out, st) in zip(mine, acc):
+            assert (int(g["frame"]), int(g["stop_position"]), int(g["accepted"])) == (int(o[0]), int(o[1]), out.accepted)
+            sl = slice(g["start_begin"], g["start_begin"] + g["n_starts"])
+            assert dev_err_rows(starts[sl], errs[sl]) == err_rows(st)
+            checked += 1
+    assert checked >= 1
