@@ -209,6 +209,17 @@ class Reads:
         _ck(capi.lib().gmg_reads_download(self.h, _ptr(packed), _ptr(off)))
         return packed[:words], off
 
+    def select(self, idx):
+        """gmg_reads_select: a new device batch made of the reads idx (any order, repeats allowed)"""
+        idx = np.ascontiguousarray(idx, np.uint64)
+        sub = Reads.__new__(Reads)
+        sub.h = C.c_void_p()
+        _ck(capi.lib().gmg_reads_select(self.h, _ptr(idx), len(idx), C.byref(sub.h)))
+        n, total = C.c_uint64(), C.c_uint64()
+        _ck(capi.lib().gmg_reads_info(sub.h, C.byref(n), C.byref(total)))
+        sub.n_reads, sub.total_bases, sub.offsets = int(n.value), int(total.value), None
+        return sub
+
     def close(self):
         if self.h:
             capi.lib().gmg_reads_free(self.h)

@@ -50,6 +50,7 @@ PROTOTYPES = {
     "gmg_reads_free": (i32, [vp]),
     "gmg_reads_info": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
     "gmg_reads_download": (i32, [vp, vp, vp]),
+    "gmg_reads_select": (i32, [vp, vp, u64, C.POINTER(vp)]),
     "gmg_segments_upload": (i32, [vp, vp, u64, vp, C.POINTER(u64), C.POINTER(vp)]),
     "gmg_segments_free": (i32, [vp]),
     "gmg_frame_score6": (i32, [vp, vp, vp, vp, vp]),

@@ -308,7 +308,7 @@ static int alloc_packed(gmg_reads *r, const uint32_t *src, hipMemcpyKind kind)
     r->d_packed_alloc = alloc;
     r->d_packed = alloc + GMG_GUARD_WORDS;
     GMG_HIP(hipMemset(alloc, 0, (data_words + 2 * GMG_GUARD_WORDS) * 4));
-    if (data_words) GMG_HIP(hipMemcpy(alloc + GMG_GUARD_WORDS, src, data_words * 4, kind));
+    if (data_words && src) GMG_HIP(hipMemcpy(alloc + GMG_GUARD_WORDS, src, data_words * 4, kind));
     return GMG_OK;
 }
 
@@ -368,6 +368,66 @@ extern "C" int gmg_reads_wrap_device(const uint32_t *d_packed, const uint64_t *d
         return gmg_set_error(GMG_EINVAL, "gmg_reads_wrap_device: base_offsets do not span [0, total_bases]");
     }
     rc = finish_reads(r, h_off.data());
+    if (rc) { gmg_reads_free(r); return rc; }
+    *out = r;
+    return GMG_OK;
+}
+
+// gather kernel of gmg_reads_select: one lane per 16-base word of the new batch
+__global__ __launch_bounds__(256) void k_reads_select(const uint32_t *src, const uint64_t *src_off, const uint64_t *idx, const uint64_t *new_off,
+                                                      uint64_t n, uint64_t total, uint32_t *dst)
+{
+    const uint64_t n_words = (total + 15) / 16;
+    for (uint64_t wd = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wd < n_words; wd += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t g = wd * 16;
+        uint64_t lo = 0, hi = n;                        // the read that holds base g: last r with new_off[r] <= g
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (new_off[mid] <= g) lo = mid; else hi = mid; }
+        uint64_t r = lo;
+        uint32_t out = 0;
+        for (int b = 0; b < 16 && g < total; b++, g++) {
+            while (new_off[r + 1] <= g) r++;            // (empty reads are stepped over)
+            const uint64_t sg = src_off[idx[r]] + (g - new_off[r]);
+            out |= ((src[sg >> 4] >> (2u * (unsigned)(sg & 15))) & 3u) << (2 * b);
+        }
+        dst[wd] = out;
+    }
+}
+
+extern "C" int gmg_reads_select(const gmg_reads *reads, const uint64_t *idx, uint64_t n, gmg_reads **out)
+{
+    int rc = require_init("gmg_reads_select");
+    if (rc) return rc;
+    if (!reads || (!idx && n) || !out || n >= 0xffffffffull) return gmg_set_error(GMG_EINVAL, "gmg_reads_select: bad argument");
+    std::vector<uint64_t> off(reads->n_reads + 1), new_off(n + 1);
+    GMG_HIP(hipMemcpy(off.data(), reads->d_off, off.size() * 8, hipMemcpyDeviceToHost));
+    new_off[0] = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (idx[i] >= reads->n_reads) return gmg_set_error(GMG_ERANGE, "gmg_reads_select: read %llu of %llu", (unsigned long long)idx[i], (unsigned long long)reads->n_reads);
+        new_off[i + 1] = new_off[i] + (off[idx[i] + 1] - off[idx[i]]);
+    }
+    gmg_reads *r = new (std::nothrow) gmg_reads();
+    if (!r) return gmg_set_error(GMG_ENOMEM, "gmg_reads_select: out of host memory");
+    memset(r, 0, sizeof *r);
+    r->n_reads = n;
+    r->total_bases = new_off[n];
+    r->owns_off = 1;
+    rc = alloc_packed(r, nullptr, hipMemcpyDeviceToDevice);     // zeroed words + guards; the gather fills them
+    if (rc) { gmg_reads_free(r); return rc; }
+    uint64_t *d_off = nullptr, *d_idx = nullptr;
+    hipError_t e = hipMalloc((void **)&d_off, (n + 1) * 8);
+    if (e == hipSuccess) { r->d_off = d_off; e = hipMalloc((void **)&d_idx, (n ? n : 1) * 8); }
+    if (e == hipSuccess) e = hipMemcpy(d_off, new_off.data(), (n + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) e = hipMemcpy(d_idx, idx, n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && r->total_bases) {
+        const uint64_t n_words = (r->total_bases + 15) / 16, blocks = (n_words + 255) / 256;
+        hipLaunchKernelGGL(k_reads_select, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, 0, reads->d_packed, reads->d_off, d_idx,
+                           d_off, n, r->total_bases, (uint32_t *)r->d_packed_alloc + GMG_GUARD_WORDS);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(0);
+    }
+    if (d_idx) (void)hipFree(d_idx);
+    if (e != hipSuccess) { gmg_reads_free(r); return gmg_set_error(e == hipErrorOutOfMemory ? GMG_ENOMEM : GMG_EHIP, "gmg_reads_select: %s", hipGetErrorString(e)); }
+    rc = finish_reads(r, new_off.data());
     if (rc) { gmg_reads_free(r); return rc; }
     *out = r;
     return GMG_OK;

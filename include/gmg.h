@@ -118,6 +118,10 @@ int gmg_reads_free(gmg_reads *r);
 int gmg_reads_info(const gmg_reads *r, uint64_t *n_reads, uint64_t *total_bases);
 /* Copies the batch back to HOST buffers: packed2bit[gmg_packed_words(total_bases)], base_offsets[n_reads + 1]. */
 int gmg_reads_download(const gmg_reads *reads, uint32_t *packed2bit, uint64_t *base_offsets);
+/* A new batch made of reads idx[0..n) of `reads` (host indices; any order, repeats allowed), gathered on the device:
+ * the grouping step of glimmer-mg's classification mode, where every ICM scores the reads classified to it with the
+ * null model of their classes (src/Glimmer/glimmer-mg.cc:361-375, 2050-2068) -- one gmg_mg_score_reads call per group. */
+int gmg_reads_select(const gmg_reads *reads, const uint64_t *idx, uint64_t n, gmg_reads **out);
 
 /* ---- segments --------------------------------------------------------------- */
 

@@ -138,6 +138,32 @@ def test_glimmer_mg_with_device_front_half_is_byte_identical(gpu, tmp_path, flag
     assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", golden), "rb").read()
 
 
+def test_reads_select_groups_like_classification_mode(gpu, nc):
+    """gmg_reads_select: the reads of one group gathered on the device (glimmer-mg -c scores every ICM's reads with that ICM
+    and the classes' null model, glimmer-mg.cc:361-375); a group scored alone gives each read's records of the full batch"""
+    rng = np.random.default_rng(5)
+    lens = [0, 17, 300, 1, 512, 499, 0, 76, 1025, 33, 250, 250]
+    seqs = random_reads(rng, lens)
+    reads = gpu.Reads.from_strings(seqs)
+    idx = [8, 2, 2, 0, 11, 5, 6, 4]
+    sub = reads.select(idx)
+    packed, off = sub.download()
+    want = gpu.Reads.from_strings([seqs[i] for i in idx]).download()
+    assert np.array_equal(off, want[1]) and np.array_equal(packed, want[0])
+    assert reads.select([]).n_reads == 0
+    with pytest.raises(gpu.GmgError):
+        reads.select([3, len(seqs)])
+    full = gpu.mg_score_reads(nc, gpu.Icm.indep(0.47), reads, min_gene_len=60)
+    part = gpu.mg_score_reads(nc, gpu.Icm.indep(0.47), sub, min_gene_len=60)
+    for k, i in enumerate(idx):
+        a = full[0][int(full[2][i]):int(full[2][i + 1])]
+        b = part[0][int(part[2][k]):int(part[2][k + 1])]
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert (x["frame"], x["stop_position"], x["n_starts"], x["accepted"]) == (y["frame"], y["stop_position"], y["n_starts"], y["accepted"])
+            assert np.array_equal(full[1][x["start_begin"]:x["start_begin"] + x["n_starts"]], part[1][y["start_begin"]:y["start_begin"] + y["n_starts"]])
+
+
 def test_mg_full_size_properties(gpu, oracle, nc):
     """BASELINE configs[1] shape: 1M x 500 bp (24 GB of Frame_Scores + 8 GB of running sums on the device, 0.8 GB of
     results).  Properties: (1) determinism: two calls give identical bytes; (2) bookkeeping: ORFs are stored read by
