@@ -93,7 +93,7 @@ struct MgArgs {
     uint32_t *orf_cnt;           // [n_orfs + 1] starts per ORF
     const uint64_t *start_off;   // its exclusive scan
     gmg_start *starts;
-    // the error branch (glimmer-mg -i / -s), k_mg_err_starts
+    // the error branch (glimmer-mg -i / -s), k_mg_err_level / k_mg_err_flat
     int err_mode;                // 0 off, 1 indels, 2 substitutions
     int min_indel_orf_len, indel_q_thr, indel_max;
     double indel_suffix_thr;
@@ -101,10 +101,9 @@ struct MgArgs {
     const double *pen;           // [256] Score_Indels' score_penalty by quality value (host libm, like the reference)
     double pass_stop[4];         // Pass_Stop_Penalty by (second base is a/t) * 2 + (third base is a/t)
     gmg_start_errors *errs;
-    uint64_t *keys;              // [n_starts] order of a start inside its ORF's list (k_mg_err_queue), ascending = push order
-    uint8_t *read_fit;           // [n_reads] 1: the per-read kernel (k_mg_err_queue) takes the read, 0: k_mg_err_flat does
-    uint32_t *err_flag;          // set when a write pass could not finish a read (the call then repeats on the exact path)
-    int queue_len;               // bases per read the per-read kernel holds in LDS
+    uint64_t *keys;              // [n_starts] order of a start inside its ORF's list (k_mg_err_level), ascending = push order
+    uint8_t *read_fit;           // [n_reads] 1: the level kernels take the read, 0: k_mg_err_flat does (too long for the order keys)
+    uint32_t *err_flag;          // set when a call array is full (the call then repeats on k_mg_err_flat)
     // level by level (k_mg_err_level): the calls of level 1 and 2 wait in two arrays
     struct MgCall *calls[2];
     unsigned long long *n_calls; // [2] entries used
@@ -703,9 +702,14 @@ __global__ __launch_bounds__(256) void k_mg_starts(MgArgs a)
 // end to the 3' end it branches, at every low-quality base (-i) or once through the previous stop codon (-s),
 // into another Score_Orf_Starts that starts in another reading frame with the score of the suffix kept so far;
 // every call pushes its starts onto ONE list.  Each call sums Frame_Scores sequentially from ITS OWN end point
-// (Cumulative_Frame_Score, :561-604), so no shared running sums: one lane per ORF walks the whole call tree.
+// (Cumulative_Frame_Score, :561-604), so there are no shared running sums as in k_mg_cum.
+// Two implementations, bit-identical (tests/test_gpu_mg_err.py runs both against the oracle and each other):
+// k_mg_err_level (further down; the default) walks the call tree level by level with one lane per call and sorts
+// each ORF's starts into the push order afterwards; k_mg_err_flat (next) lets one lane walk one ORF's whole tree
+// and writes the exact slots -- slower (lopsided trees, every lane on its own rows), but it needs no order keys
+// and no call arrays, so it is the fallback for reads too long for the keys and for a full call array.
 //
-// The lane walks every call from the 3' end to the 5' end (the direction of the sum; the end of the region is
+// A lane walks every call from the 3' end to the 5' end (the direction of the sum; the end of the region is
 // the first in-frame stop codon it meets, which is what the Fwd_Prev_Stops / Rev_Next_Stops tables hold,
 // :675-729) -- the REVERSE of the reference's scan.  So it visits the call tree in exactly reversed order
 // (per position: own start, insertion branch, deletion branch; the substitution branch last) and fills the
@@ -749,179 +753,12 @@ __global__ __launch_bounds__(256) void k_mg_quality(MgArgs a, const uint8_t *use
     }
 }
 
-template <bool WRITE, int LEVEL>
-__device__ void mg_err_walk(const MgArgs &a, const int8_t *s_which, MgErrRun &R, const bool fwd, const int64_t off, const int n,
-                            const int end_point, const double suffix_score, const int suffix_j,
-                            const int e0pos, const int e0type, const int e1pos, const int e1type)
-{
-    const int mgl = a.min_gene_len;
-    const int lowest_j = mgl - 3 < 3 ? mgl - 3 : 3;
-    const int anchor = end_point - 1;                   // read index of buffer position 0 (Reverse_ / Complement_Transfer, :1733,1754)
-    if (anchor < 0 || anchor >= n) {
-        // Fwd_Prev_Stop / Rev_Next_Stop outside the read return their argument (:642-652, 1436-1445): an empty region.
-        // (the substitution branch starts from level 0 only, whose end points lie inside the read)
-        return;
-    }
-    const int avail = fwd ? anchor + 1 : n - anchor;    // bases from the anchor to the end of the read, walking direction
-    const int64_t dir = fwd ? -1 : 1;
-    const uint32_t comp = fwd ? 0u : 3u;
-    const int64_t g0 = off + anchor;
-    const double *row[3];                               // Frame_Scores row of buffer position j: f = 1, 2, 0, ... (:561-604)
-    row[0] = a.fs + (uint64_t)(fwd ? 1 : 4) * a.fs_stride;
-    row[1] = a.fs + (uint64_t)(fwd ? 2 : 5) * a.fs_stride;
-    row[2] = a.fs + (uint64_t)(fwd ? 0 : 3) * a.fs_stride;
-
-    int64_t g = g0;
-    uint32_t w = a.packed[g >> 4];
-    auto next_code = [&]() __attribute__((always_inline)) {
-        const uint32_t c = ((w >> (2u * (unsigned)(g & 15))) & 3u) ^ comp;
-        const int64_t g2 = g + dir;
-        if ((g ^ g2) >> 4) w = a.packed[g2 >> 4];       // word -1 / one past the end: the guard words of gmg_reads
-        g = g2;
-        return c;
-    };
-
-    double sum = 0.0;
-    uint32_t last_own = MG_NO_SLOT;
-    bool first_done = false, trunc = false;
-
-    auto emit = [&](double raw, int j_full, int pos, int which, int truncated, int first) __attribute__((always_inline)) -> uint32_t {
-        const double sc = (j_full > a.ignore_score_len && 0.0 > raw) ? 0.0 : raw;       // Max (0.0, score), :1644-1646
-        if (R.count == 0 || (fwd ? pos < R.ext_pos : pos > R.ext_pos)) { R.ext_pos = pos; R.ext_jmin = R.ext_jmax = j_full; }
-        else if (pos == R.ext_pos) { if (j_full < R.ext_jmin) R.ext_jmin = j_full; if (j_full > R.ext_jmax) R.ext_jmax = j_full; }
-        if (sc > R.best) R.best = sc;
-        R.count++;
-        uint32_t slot = MG_NO_SLOT;
-        if (WRITE) {
-            slot = --R.end;
-            gmg_start st;
-            st.score = sc; st.j = j_full; st.pos = pos; st.which = which; st.truncated = (int16_t)truncated; st.first = (int16_t)first;
-            a.starts[slot] = st;
-            gmg_start_errors er;
-            er.pos[0] = LEVEL > 0 ? e0pos : 0; er.pos[1] = LEVEL > 1 ? e1pos : 0;
-            er.type[0] = (int8_t)(LEVEL > 0 ? e0type : 0); er.type[1] = (int8_t)(LEVEL > 1 ? e1type : 0);
-            er.n = LEVEL; er.reserved = 0;
-            a.errs[slot] = er;
-        }
-        return slot;
-    };
-
-    // the three positions of in-frame codon t; idx = (buff[3t+2], buff[3t+1], buff[3t]) as Codon_t holds them
-    auto codon = [&](const int t, const uint32_t idx, const bool is_last) __attribute__((always_inline)) {
-#pragma unroll 1
-        for (int jj = 0; jj < 3; jj++) {
-            const int j = 3 * t + jj;
-            const int64_t gj = g0 + dir * j;
-            const double prev = sum;
-            sum = prev + row[jj][gj];                   // score[j] = cum_score + Frame_Scores[f][si]
-            if (j < lowest_j) continue;
-            const int k = fwd ? end_point - 2 - j : end_point + 2 + j;       // :1742,1762,1855-1858
-            if (jj == 0 && j + 3 + suffix_j >= mgl) {
-                const int which = s_which[idx];
-                const double raw = (prev - 0.0) + suffix_score;             // next_s + suffix_score, :1826-1834
-                if (which >= 0) last_own = emit(raw, j + 2 + suffix_j, k, which, 0, 0);
-                if (is_last && trunc) { emit(raw, j + 2 + suffix_j, k, -1, 1, 1); first_done = true; }
-            }
-            if constexpr (LEVEL < 2) {
-                if (a.err_mode == 1 && LEVEL < a.indel_max) {
-                    const int q = a.qual[gj];
-                    if (q <= a.indel_q_thr) {           // Score_Indels (:1513-1602); reversed order: insertion, then deletion
-                        const double pen = a.pen[q];
-                        const int sj = suffix_j + j + 2 - jj;
-#pragma unroll 1
-                        for (int br = 0; br < 2; br++) {
-                            const double es = ((suffix_score + (br == 0 ? prev : sum)) - 0.0) + pen;
-                            if (!(es > a.indel_suffix_thr)) continue;
-                            int ep, epos;
-                            if (br == 0) { ep = fwd ? k - (2 - jj) : k + 2 - jj; epos = fwd ? k + 2 : k - 2; }
-                            else { ep = fwd ? k + jj : k - jj; epos = fwd ? k + 3 : k - 1; }
-                            mg_err_walk<WRITE, LEVEL + 1>(a, s_which, R, fwd, off, n, ep, es, sj,
-                                                                          LEVEL == 0 ? epos : e0pos, LEVEL == 0 ? br : e0type,
-                                                                          LEVEL == 1 ? epos : 0, LEVEL == 1 ? br : 0);
-                        }
-                    }
-                }
-            }
-        }
-    };
-
-    uint32_t pidx = 0;
-    bool pending = false;
-    int t = 0;
-    for (;; t++) {
-        bool end = avail - 3 * t < 3;                   // no whole codon left: the virtual stop around the read (:685,708-710)
-        uint32_t idx = 0;
-        if (end) trunc = a.allow_truncated != 0;        // :1741,1761 -- lo < 3 / Sequence_Len - (hi-1) < 3 exactly when no real stop closed the region
-        else {
-            const uint32_t c0 = next_code(), c1 = next_code(), c2 = next_code();
-            idx = c2 << 4 | c1 << 2 | c0;
-            end = (a.fwd_stop >> idx) & 1;              // Must_Be (Fwd_Stop_Pattern) on the buffer's codon, both strands (:689-728)
-        }
-        if (pending) codon(t - 1, pidx, end);
-        if (end) break;
-        pidx = idx;
-        pending = true;
-    }
-    const int m = 3 * t;                                // len = hi - lo
-    if (LEVEL == 0) { R.m0 = m; R.trunc0 = trunc; }
-
-    if constexpr (LEVEL == 0) if (a.err_mode == 2) {    // mutate the previous stop codon (:1771-1806); first in the reference's order
-        const int lo = fwd ? end_point - m : end_point, hi = fwd ? end_point : end_point + m;
-        const int eep = fwd ? lo - 3 : hi + 3;
-        if (eep >= 0 && eep - 2 < n) {
-            auto base = [&](int i) { const int64_t x = off + i; return (a.packed[x >> 4] >> (2u * (unsigned)(x & 15))) & 3u; };
-            const uint32_t want = fwd ? 0u : 3u;        // 'a' forward, 't' reverse (Pass_Stop_Penalty, :961-995)
-            const int a1 = base(fwd ? lo - 2 : hi) == want, a2 = base(fwd ? lo - 1 : hi - 1) == want;
-            double es = suffix_score + a.pass_stop[a1 * 2 + a2];
-            if (m > 0) es += sum - 0.0;
-            mg_err_walk<WRITE, 1>(a, s_which, R, fwd, off, n, eep, es, suffix_j + m, fwd ? lo - 2 : hi + 2, 2, 0, 0);
-        }
-    }
-    if (WRITE && !first_done && last_own != MG_NO_SLOT) a.starts[last_own].first = 1;
-}
-
-template <bool WRITE>
-__global__ __launch_bounds__(256) void k_mg_err_starts(MgArgs a)
-{
-    __shared__ int8_t s_which[64];
-    if (threadIdx.x < 64) s_which[threadIdx.x] = a.which[threadIdx.x];
-    __syncthreads();
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x) {
-        gmg_mg_orf o = a.orfs[i];
-        const bool fwd = o.frame > 0;
-        const int64_t off = (int64_t)a.read_off[o.read];
-        const int n = (int)(a.read_off[o.read + 1] - a.read_off[o.read]);
-        MgErrRun R;
-        R.count = 0; R.end = WRITE ? (uint32_t)a.start_off[i + 1] : 0; R.best = -DBL_MAX; R.ext_pos = 0; R.ext_jmin = R.ext_jmax = 0;
-        R.m0 = 0; R.trunc0 = 0;
-        // Score_Orfs_Errors (:1637-1642): end_point = stop - 1 forward, stop + 3 reverse
-        mg_err_walk<WRITE, 0>(a, s_which, R, fwd, off, n, fwd ? o.stop_position - 1 : o.stop_position + 3, 0.0, 0, 0, 0, 0, 0);
-        if (!WRITE) { a.orf_cnt[i] = R.count; continue; }
-        // Score_Orf_Starts' own bounds (:1730-1757): Find_Orfs also emits ORFs whose stop position is a placeholder
-        // (Do_Rev_Stop_Codon without truncated ORFs, glimmer_base.cc:515-519), for which the scan's lo / hi do not apply
-        if (fwd) { o.hi = o.stop_position - 1; o.lo = o.hi - R.m0; }
-        else { o.lo = o.stop_position + 3; o.hi = o.lo + R.m0; }
-        o.orf_is_truncated = (int16_t)R.trunc0;
-        o.start_begin = (uint32_t)a.start_off[i];
-        o.n_starts = R.count;
-        o.first_j = R.count ? R.ext_jmin : 0;
-        o.best_score = -DBL_MAX;
-        o.accepted = 0;
-        if (R.count > 0 && R.ext_jmax + 1 >= a.min_gene_len) {          // glimmer-mg.cc:1656-1676
-            o.best_score = R.best;
-            if (R.best > a.start_threshold) o.accepted = R.ext_jmin + 1 >= a.min_gene_len ? 1 : 2;
-        }
-        a.orfs[i] = o;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
-// The same walk without nested loops.  In k_mg_err_starts a lane that enters a branch runs the whole inner call
-// while the other 63 lanes of its wave wait at the call site, at every step of every level: the wave's time is
-// the PRODUCT of the levels' lengths, not the longest lane (measured: 0.3 % of the lanes busy).  Here the call
-// tree is walked by ONE loop whose every trip advances every lane by one buffer position of whatever call it is
-// in; a branch pushes the caller's state (two levels at most ever wait: 0 and 1) onto a stack in LDS and a
-// finished call pops it.  Same visiting order, same arithmetic, same slots as mg_err_walk.
+// k_mg_err_flat: one lane per ORF, the whole call tree in the visiting order above, without nested loops.  (With the
+// recursion written as nested calls a lane that enters a branch runs the whole inner call while the other 63 lanes
+// of its wave wait at the call site, at every step of every level.)  ONE loop whose every trip advances every lane
+// by one buffer position of whatever call it is in; a branch pushes the caller's state (two levels at most ever
+// wait: 0 and 1) onto a stack in LDS and a finished call pops it.
 // ---------------------------------------------------------------------------------------------------
 #define MG_ERR_BLOCK 256
 
@@ -1131,26 +968,6 @@ __global__ __launch_bounds__(MG_ERR_BLOCK) void k_mg_err_flat(MgArgs a, const in
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// The error branch, one wave per read (the default).  Two things held the per-ORF walks back: every lane
-// followed its own 3 Frame_Scores rows through HBM (one 64-byte sector per 8-byte value: ~300 GB per pass for
-// 200k reads), and an ORF's call tree is lopsided (33 ORFs per read, ~200 calls, a few of them long).  Here a
-// wave stages its read's six rows, qualities and codes in LDS once and its lanes take CALLS, not ORFs, from a
-// queue in LDS: the ORFs' own calls first, then every branch a walking lane meets is appended and picked up by
-// the next idle lane.  One trip of the loop = one buffer position for every busy lane; queue traffic is
-// wave-synchronous (ballot + rank, no atomics).
-// Calls finish in no particular order, so a start cannot know its slot in the reference's push order.  It
-// carries the order instead: key = (position, kind) of each level of its path, most significant first, each
-// field inverted -- ascending keys are the reference's push order (reverse of the visiting order described at
-// mg_err_walk).  Slots inside the ORF's slice are handed out by an LDS counter; a segmented sort by key
-// (mg_order_starts) puts the slice in order afterwards.  Per-ORF results (count, best score, the j's at the
-// extreme pos) are merged with 64-bit LDS atomics when a call ends.
-// Reads that do not fit (longer than the staged length, more ORFs than the table, a queue overflow) are left to
-// k_mg_err_flat, which writes the exact slots (and keys = slot).
-// ---------------------------------------------------------------------------------------------------
-#define MGQ_CAP 128              // queue entries (ring)
-#define MGQ_ORFS 128             // ORFs of one read
-
 __device__ __forceinline__ uint64_t mg_ord(double x)    // order-preserving map double -> uint64
 {
     const uint64_t u = (uint64_t)__double_as_longlong(x);
@@ -1161,298 +978,27 @@ __device__ __forceinline__ double mg_unord(uint64_t u)
     return __longlong_as_double((long long)((u >> 63) ? (u & 0x7fffffffffffffffull) : ~u));
 }
 
-template <bool WRITE>
-__global__ __launch_bounds__(64) void k_mg_err_queue(MgArgs a, const int accepted_only)
-{
-    extern __shared__ double mgq_smem[];
-    const int LP = a.queue_len;
-    double *s_fs = mgq_smem;                            // [6][LP]
-    double *q_score = s_fs + (size_t)6 * LP;            // the queue, structure of arrays
-    uint64_t *q_key = (uint64_t *)(q_score + MGQ_CAP);
-    uint64_t *o_best = q_key + MGQ_CAP;                 // per ORF of the read
-    uint64_t *o_ext_a = o_best + MGQ_ORFS, *o_ext_b = o_ext_a + MGQ_ORFS;
-    int *q_end = (int *)(o_ext_b + MGQ_ORFS), *q_sj = q_end + MGQ_CAP;
-    uint32_t *q_e0 = (uint32_t *)(q_sj + MGQ_CAP), *q_e1 = q_e0 + MGQ_CAP, *q_meta = q_e1 + MGQ_CAP;
-    uint32_t *o_cnt = q_meta + MGQ_CAP, *o_m0 = o_cnt + MGQ_ORFS;
-    uint8_t *s_qual = (uint8_t *)(o_m0 + MGQ_ORFS), *s_code = s_qual + LP;
-    __shared__ int8_t s_which[64];
-    __shared__ double s_pen[64];                        // score_penalty of the quality values that can branch (<= threshold < 64; else a.pen)
-    const int lane = threadIdx.x;
-    const uint64_t lt = (1ull << lane) - 1;
-    s_which[lane] = a.which[lane];
-    s_pen[lane] = a.err_mode == 1 ? a.pen[lane] : 0.0;
-    const bool pen_lds = a.indel_q_thr < 64;
-    const int mgl = a.min_gene_len;
-    const int lowest_j = mgl - 3 < 3 ? mgl - 3 : 3;
-
-    for (uint64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
-        const uint64_t first_orf = a.read_orf_off[r];
-        const int n_orf = (int)(a.read_orf_off[r + 1] - first_orf);
-        if (n_orf == 0) { if (!WRITE && lane == 0) a.read_fit[r] = 1; continue; }
-        const int64_t off = (int64_t)a.read_off[r];
-        const int n = (int)(a.read_off[r + 1] - a.read_off[r]);
-        if (!WRITE) { if (n > LP || n_orf > MGQ_ORFS) { if (lane == 0) a.read_fit[r] = 0; continue; } }
-        else if (!a.read_fit[r]) continue;
-        if (WRITE && accepted_only) {                   // nothing of a read without an accepted ORF leaves the GPU
-            bool any = false;
-            for (int o = lane; o < n_orf; o += 64) any |= a.orfs[first_orf + o].accepted != 0;
-            if (!__ballot(any)) continue;
-        }
-        __syncthreads();                                // (one wave: orders this read's LDS traffic behind the previous read's)
-        for (int f = 0; f < 6; f++)
-            for (int p = lane; p < n; p += 64) s_fs[(size_t)f * LP + p] = a.fs[(uint64_t)f * a.fs_stride + off + p];
-        for (int p = lane; p < n; p += 64) {
-            const int64_t x = off + p;
-            s_code[p] = (uint8_t)((a.packed[x >> 4] >> (2u * (unsigned)(x & 15))) & 3u);
-            s_qual[p] = a.qual ? a.qual[x] : 255;
-        }
-        uint32_t head = 0, tail = 0;                    // uniform: every lane computes the same values
-        for (int o0 = 0; o0 < n_orf; o0 += 64) {        // the ORFs' own calls (Score_Orfs_Errors, :1637-1642)
-            const int o = o0 + lane;
-            bool want = o < n_orf;
-            gmg_mg_orf rec;
-            if (want) {
-                rec = a.orfs[first_orf + o];
-                const bool fwd = rec.frame > 0;
-                o_cnt[o] = 0; o_m0[o] = 0; o_best[o] = mg_ord(-DBL_MAX);
-                o_ext_a[o] = o_ext_b[o] = fwd ? ~0ull : 0ull;
-                if (WRITE && accepted_only && !rec.accepted) want = false;
-            }
-            const uint64_t m = __ballot(want);
-            if (want) {
-                const uint32_t slot = (tail + __popcll(m & lt)) % MGQ_CAP;
-                q_score[slot] = 0.0; q_key[slot] = 0; q_sj[slot] = 0; q_e0[slot] = 0; q_e1[slot] = 0;
-                q_end[slot] = rec.frame > 0 ? rec.stop_position - 1 : rec.stop_position + 3;
-                q_meta[slot] = (uint32_t)o << 3 | (rec.frame > 0 ? 4u : 0u);            // orf, forward flag, level 0
-            }
-            tail += __popcll(m);
-        }
-        __syncthreads();
-
-        // the call this lane is walking
-        bool active = false, fwd = false, walking = false, is_last = false, trunc = false, first_done = false;
-        int orf = 0, level = 0, end_point = 0, suffix_j = 0, anchor = 0, avail = 0, dir = 1;
-        int tp = 0, jj = 0, br = 0;
-        uint32_t e0 = 0, e1 = 0, pidx = 0, nidx = 0, last_own = MG_NO_SLOT, cnt = 0, comp = 0;
-        uint64_t key = 0, ext_a = 0, ext_b = 0;
-        double suffix_score = 0.0, sum = 0.0, prev = 0.0, best = -DBL_MAX;
-        const double *row0 = s_fs, *row1 = s_fs, *row2 = s_fs;
-        bool overflow = false;
-
-        auto fetch = [&](int t, uint32_t &idx) __attribute__((always_inline)) -> bool {
-            if (avail - 3 * t < 3) { trunc = a.allow_truncated != 0; return true; }
-            const int p0 = anchor + dir * 3 * t;
-            const uint32_t c0 = s_code[p0] ^ comp, c1 = s_code[p0 + dir] ^ comp, c2 = s_code[p0 + 2 * dir] ^ comp;
-            idx = c2 << 4 | c1 << 2 | c0;
-            return (a.fwd_stop >> idx) & 1;
-        };
-        auto emit = [&](double raw, int j_full, int pos, int which, int truncated, int first, uint32_t kind) __attribute__((always_inline)) -> uint32_t {
-            const double sc = (j_full > a.ignore_score_len && 0.0 > raw) ? 0.0 : raw;
-            const uint64_t pa = (uint64_t)(uint32_t)(pos + 16) << 32 | (uint32_t)j_full, pb = (uint64_t)(uint32_t)(pos + 16) << 32 | (0xffffffffu - (uint32_t)j_full);
-            if (fwd) { if (pa < ext_a) ext_a = pa; if (pb < ext_b) ext_b = pb; }
-            else { if (pa > ext_a) ext_a = pa; if (pb > ext_b) ext_b = pb; }
-            if (sc > best) best = sc;
-            uint32_t slot = MG_NO_SLOT;
-            if (WRITE) {
-                slot = (uint32_t)a.start_off[first_orf + orf] + atomicAdd(&o_cnt[orf], 1u);
-                gmg_start s1;
-                s1.score = sc; s1.j = j_full; s1.pos = pos; s1.which = which; s1.truncated = (int16_t)truncated; s1.first = (int16_t)first;
-                a.starts[slot] = s1;
-                gmg_start_errors er;
-                er.pos[0] = level > 0 ? (int)(e0 >> 2) - 8 : 0; er.pos[1] = level > 1 ? (int)(e1 >> 2) - 8 : 0;
-                er.type[0] = (int8_t)(level > 0 ? (e0 & 3) : 0); er.type[1] = (int8_t)(level > 1 ? (e1 & 3) : 0);
-                er.n = (int8_t)level; er.reserved = 0;
-                a.errs[slot] = er;
-                const int j_loc = j_full - 2 - suffix_j;
-                a.keys[slot] = key | (uint64_t)((uint32_t)(2047 - j_loc) << 2 | kind) << (26 - 13 * level);
-            } else cnt++;
-            return slot;
-        };
-
-        for (;;) {
-            // 1. idle lanes take the next calls of the queue
-            {
-                const uint64_t idle = __ballot(!active);
-                const uint32_t availq = tail - head, rank = __popcll(idle & lt);
-                if (!active && rank < availq) {
-                    const uint32_t slot = (head + rank) % MGQ_CAP;
-                    const uint32_t meta = q_meta[slot];
-                    orf = meta >> 3; fwd = (meta >> 2) & 1; level = meta & 3;
-                    end_point = q_end[slot]; suffix_score = q_score[slot]; suffix_j = q_sj[slot];
-                    key = q_key[slot]; e0 = q_e0[slot]; e1 = q_e1[slot];
-                    active = true;
-                    dir = fwd ? -1 : 1; comp = fwd ? 0u : 3u;
-                    row0 = s_fs + (size_t)(fwd ? 1 : 4) * LP; row1 = s_fs + (size_t)(fwd ? 2 : 5) * LP; row2 = s_fs + (size_t)(fwd ? 0 : 3) * LP;
-                    sum = 0.0; prev = 0.0; tp = 0; jj = 0; br = 0; last_own = MG_NO_SLOT; cnt = 0; best = -DBL_MAX;
-                    ext_a = ext_b = fwd ? ~0ull : 0ull;
-                    is_last = false; trunc = false; first_done = false; walking = false;
-                    anchor = end_point - 1;
-                    if (anchor >= 0 && anchor < n) {
-                        avail = fwd ? anchor + 1 : n - anchor;
-                        walking = !fetch(0, pidx);
-                    } else avail = 0;
-                }
-                const uint32_t n_idle = __popcll(idle);
-                head += n_idle < availq ? n_idle : availq;
-            }
-            if (!__ballot(active)) break;               // no call running, none queued
-
-            // 2. one buffer position (or the end of the call) per busy lane
-            bool want_push = false;
-            int c_end = 0, c_sj = 0;
-            uint32_t c_err = 0, c_kind = 0;
-            double c_score = 0.0;
-            int c_j = 0;
-            if (active) {
-                if (walking) {
-                    const int j = 3 * tp + jj;
-                    const int p = anchor + dir * j;
-                    const int k = fwd ? end_point - 2 - j : end_point + 2 + j;
-                    if (br == 0) {
-                        if (jj == 0) is_last = fetch(tp + 1, nidx);
-                        prev = sum;
-                        sum = prev + (jj == 0 ? row0 : jj == 1 ? row1 : row2)[p];
-                        if (jj == 0 && j >= lowest_j && j + 3 + suffix_j >= mgl) {
-                            const int which = s_which[pidx];
-                            const double raw = (prev - 0.0) + suffix_score;
-                            if (which >= 0) last_own = emit(raw, j + 2 + suffix_j, k, which, 0, 0, 3u);
-                            if (is_last && trunc) { emit(raw, j + 2 + suffix_j, k, -1, 1, 1, 2u); first_done = true; }
-                        }
-                    }
-                    if (a.err_mode == 1 && level < 2 && level < a.indel_max && j >= lowest_j) {
-                        const int q = s_qual[p];
-                        if (q <= a.indel_q_thr) {
-                            const double pen = pen_lds ? s_pen[q] : a.pen[q];
-                            while (br < 2) {
-                                const int b = br++;
-                                const double es = ((suffix_score + (b == 0 ? prev : sum)) - 0.0) + pen;
-                                if (es > a.indel_suffix_thr) {
-                                    int epos;
-                                    if (b == 0) { c_end = fwd ? k - (2 - jj) : k + 2 - jj; epos = fwd ? k + 2 : k - 2; }
-                                    else { c_end = fwd ? k + jj : k - jj; epos = fwd ? k + 3 : k - 1; }
-                                    c_score = es; c_sj = suffix_j + j + 2 - jj; c_err = (uint32_t)(epos + 8) << 2 | (uint32_t)b;
-                                    c_kind = b == 0 ? 1u : 0u;              // push order at one position: deletion, insertion, truncated, real
-                                    c_j = j;
-                                    want_push = true;
-                                    break;
-                                }
-                            }
-                        }
-                    }
-                    if (!want_push) {
-                        br = 0;
-                        if (++jj == 3) {
-                            jj = 0;
-                            if (is_last) walking = false;
-                            else pidx = nidx;
-                            tp++;
-                        }
-                    }
-                } else {
-                    const int m = 3 * tp;
-                    bool done = true;
-                    if (br != 3) {
-                        br = 3;
-                        if (level == 0) {
-                            o_m0[orf] = (uint32_t)m << 1 | (trunc ? 1u : 0u);
-                            if (a.err_mode == 2) {      // the substitution branch: first in push order = the highest key field
-                                const int lo = fwd ? end_point - m : end_point, hi = fwd ? end_point : end_point + m;
-                                const int eep = fwd ? lo - 3 : hi + 3;
-                                if (anchor >= 0 && anchor < n && eep >= 0 && eep - 2 < n) {
-                                    const uint32_t want = fwd ? 0u : 3u;
-                                    const int a1 = s_code[fwd ? lo - 2 : hi] == want, a2 = s_code[fwd ? lo - 1 : hi - 1] == want;
-                                    double es = suffix_score + a.pass_stop[a1 * 2 + a2];
-                                    if (m > 0) es += sum - 0.0;
-                                    c_end = eep; c_score = es; c_sj = suffix_j + m;
-                                    c_err = (uint32_t)((fwd ? lo - 2 : hi + 2) + 8) << 2 | 2u;
-                                    c_kind = 0u; c_j = 2047;        // inverted position 0: before every position of the call
-                                    want_push = true;
-                                    done = false;
-                                }
-                            }
-                        }
-                    }
-                    if (done) {                         // the call is finished: its results join the ORF's
-                        if (WRITE) { if (!first_done && last_own != MG_NO_SLOT) a.starts[last_own].first = 1; }
-                        else if (cnt) atomicAdd(&o_cnt[orf], cnt);
-                        if (best > -DBL_MAX) {
-                            atomicMax((unsigned long long *)&o_best[orf], (unsigned long long)mg_ord(best));
-                            if (fwd) { atomicMin((unsigned long long *)&o_ext_a[orf], (unsigned long long)ext_a); atomicMin((unsigned long long *)&o_ext_b[orf], (unsigned long long)ext_b); }
-                            else { atomicMax((unsigned long long *)&o_ext_a[orf], (unsigned long long)ext_a); atomicMax((unsigned long long *)&o_ext_b[orf], (unsigned long long)ext_b); }
-                        }
-                        active = false;
-                    }
-                }
-            }
-
-            // 3. the branches met in this trip join the queue
-            const uint64_t pm = __ballot(want_push);
-            if (pm) {
-                const uint32_t np = __popcll(pm);
-                if (tail + np - head > MGQ_CAP) { overflow = true; break; }
-                if (want_push) {
-                    const uint32_t slot = (tail + __popcll(pm & lt)) % MGQ_CAP;
-                    q_score[slot] = c_score; q_end[slot] = c_end; q_sj[slot] = c_sj;
-                    q_key[slot] = key | (uint64_t)((uint32_t)(2047 - c_j) << 2 | c_kind) << (26 - 13 * level);
-                    q_e0[slot] = level == 0 ? c_err : e0; q_e1[slot] = level == 1 ? c_err : 0;
-                    q_meta[slot] = (uint32_t)orf << 3 | (fwd ? 4u : 0u) | (uint32_t)(level + 1);
-                }
-                tail += np;
-            }
-            __syncthreads();
-        }
-
-        if (overflow) {                                 // too many pending calls: the exact path takes the read
-            if (!WRITE) { if (lane == 0) a.read_fit[r] = 0; }
-            else if (lane == 0) atomicOr(a.err_flag, 1u);
-            continue;
-        }
-        __syncthreads();
-        if (!WRITE && lane == 0) a.read_fit[r] = 1;
-        for (int o = lane; o < n_orf; o += 64) {        // Score_Orfs_Errors' verdict per ORF (:1647-1683)
-            gmg_mg_orf rec = a.orfs[first_orf + o];
-            if (WRITE && accepted_only && !rec.accepted) continue;
-            const bool f = rec.frame > 0;
-            const uint32_t count = o_cnt[o];
-            const int m0 = (int)(o_m0[o] >> 1);
-            if (f) { rec.hi = rec.stop_position - 1; rec.lo = rec.hi - m0; }
-            else { rec.lo = rec.stop_position + 3; rec.hi = rec.lo + m0; }
-            rec.orf_is_truncated = (int16_t)(o_m0[o] & 1);
-            rec.n_starts = count;
-            rec.first_j = 0; rec.best_score = -DBL_MAX; rec.accepted = 0;
-            if (count) {
-                const uint32_t ja = (uint32_t)o_ext_a[o], jb = 0xffffffffu - (uint32_t)o_ext_b[o];
-                const int jmin = (int)(f ? ja : jb), jmax = (int)(f ? jb : ja);
-                rec.first_j = jmin;
-                if (jmax + 1 >= mgl) {
-                    rec.best_score = mg_unord(o_best[o]);
-                    if (rec.best_score > a.start_threshold) rec.accepted = jmin + 1 >= mgl ? 1 : 2;
-                }
-            }
-            if (!WRITE) { a.orf_cnt[first_orf + o] = (accepted_only && !rec.accepted) ? 0u : count; rec.start_begin = 0; }
-            else rec.start_begin = (uint32_t)a.start_off[first_orf + o];
-            a.orfs[first_orf + o] = rec;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // The error branch level by level (the default).  One lane per CALL: level 0 = the ORFs' own calls, and every
-// branch a walk meets is appended to the array of the next level (one atomic per wave), which the next launch
-// walks -- three launches per pass.  A lane does one plain walk of one region: no stack, no queue, lanes of a
-// wave stay in step, and the occupancy of a kernel without LDS hides the latency of the scattered 8-byte reads.
+// branch a walk meets is appended to the array of the next level, which the next launch walks -- three launches
+// per pass.  A lane does one plain walk of one region, a whole in-frame codon per trip: no stack, and the walking
+// lanes of a wave stay in the same phase (a wave executes whatever ANY of its lanes needs -- that, not occupancy
+// or bandwidth, is what the earlier versions paid for; DESIGN.md 4.7 has the numbers).
 // The calls found by the count pass stay in their arrays; the write pass walks them again (only those of the
-// accepted ORFs when that is all the caller wants).  Order: keys + segmented sort as in k_mg_err_queue; per-ORF
-// results through 64-bit atomics on MgOrfAgg.  Reads too long for the key fields (>= 2040 bases) and a full
-// call array are left to k_mg_err_flat.
+// accepted ORFs when that is all the caller wants).  Calls finish in no particular order, so a start cannot know
+// its slot in the reference's push order; it carries the order instead: key = (position, kind) of each level of
+// its path, most significant level first, each field inverted -- ascending keys are the push order (the reverse of
+// the visiting order described above).  Slots inside the ORF's slice are handed out by a counter, and a segmented
+// sort by key puts every slice in order afterwards (mg_run, step 5).  Per-ORF results (count, best score, the j's
+// at the extreme pos) are merged with 64-bit atomics on MgOrfAgg when a call ends.  Reads too long for the key
+// fields (>= 2040 bases) and a full call array are left to k_mg_err_flat.
 // ---------------------------------------------------------------------------------------------------
 // A walk that starts at global base ga reads Frame_Scores[1], [2], [0], [1], ... at ga, ga -/+ 1, ...: three rows, 24 bytes
-// apart in time, 8 useful bytes per 64-byte sector each -- with ~500k lanes walking, no cache keeps a sector until its next
-// use and the level kernels drew ~6 TB/s for 9 useful bytes per step.  Here the table is rewritten once (96 B / base) in
-// walking order: for every class c = ga % 3 one row in which consecutive steps of such a walk are consecutive doubles,
+// apart in time.  The table is rewritten once (96 B / base) in walking order: for every class c = ga % 3 one row in which
+// consecutive steps of such a walk are consecutive doubles,
 //   forward:  walk[c][total-1-g]  = Frame_Scores[((c - g) mod 3 + 1) % 3][g]        (the walk runs down the read: reversed)
 //   reverse:  walk[3+c][g]        = Frame_Scores[3 + ((g - c) mod 3 + 1) % 3][g]
-// so a lane streams 32 bytes per four steps from one address range.
+// so a lane streams the 24 bytes of a codon from one address.
 __global__ __launch_bounds__(256) void k_mg_walk_tables(MgArgs a, double *walk, uint8_t *walk_q)
 {
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (uint64_t)gridDim.x * blockDim.x) {
@@ -2070,7 +1616,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     }
     a.fs = d_frame_scores;
     tm.lap("frame scores");
-    if (err_mode) {                                     // the error branch sums per call (k_mg_err_starts); it needs the qualities
+    if (err_mode) {                                     // the error branch sums per call; it needs the qualities
         MG_TRY(gmg_pool_alloc((void **)&d_pen, sizeof pen_host));
         MG_TRY(hipMemcpyAsync(d_pen, pen_host, sizeof pen_host, hipMemcpyHostToDevice, s));
         a.pen = d_pen;
@@ -2205,43 +1751,32 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     MG_TRY(gmg_pool_alloc((void **)&d_start_off, (no + 1) * 8));
     a.orf_cnt = d_orf_cnt;
     const int err_acc_only = (prm->flags & GMG_MG_ACCEPTED_ONLY) ? 1 : 0;
-    // error branch: 0 = level by level, one lane per call (k_mg_err_level; default), 3 = one wave per read with a call queue in
-    // LDS (k_mg_err_queue), 1 = one lane per ORF with an explicit stack (k_mg_err_flat: exact slots, also the fallback of 0 and 3),
-    // 2 = one lane per ORF, nested calls (the first version).  1-3 stay for A/B runs and as cross-checks in the tests.
-    int err_path = getenv("GMG_MG_ERR_RECURSIVE") ? 2 : getenv("GMG_MG_ERR_FLAT") ? 1 : getenv("GMG_MG_ERR_WAVE") ? 3 : 0;
-    const bool any_unfit = err_path == 3 || reads->max_len >= 2040;
-    if (res->n_orfs && err_mode && (err_path == 0 || err_path == 3)) {
-        // LDS per wave = 50 bytes per staged base + 8.5 KB: the shorter the staged length, the more reads a CU walks at once.
-        // A batch whose reads beyond 512 bases are few (< 2 %) leaves those to the per-ORF kernel.
-        uint64_t longest = reads->max_len < 1024 ? reads->max_len : 1024;
-        if (longest > 512 && reads->n_over_512 * 50 <= reads->n_reads) longest = 512;
-        if (const char *env = getenv("GMG_MG_ERR_STAGE")) longest = (uint64_t)atoi(env) < 16 ? 16 : (uint64_t)atoi(env) > 2040 ? 2040 : (uint64_t)atoi(env);
-        a.queue_len = (int)((longest + 7) & ~7ull);
+    // error branch: 0 = level by level, one lane per call (k_mg_err_level; the default), 1 = one lane per ORF with an explicit stack
+    // (k_mg_err_flat: exact slots; the fallback of 0, and on its own with GMG_MG_ERR_FLAT=1 for A/B runs and cross-checks)
+    int err_path = getenv("GMG_MG_ERR_FLAT") ? 1 : 0;
+    const bool any_unfit = reads->max_len >= 2040;
+    if (res->n_orfs && err_mode && err_path == 0) {
         MG_TRY(gmg_pool_alloc((void **)&d_read_fit, nr ? nr : 1));
         MG_TRY(gmg_pool_alloc((void **)&d_err_flag, 32));           // the flag + the two call counters
         MG_TRY(hipMemsetAsync(d_err_flag, 0, 32, s2));
         a.read_fit = d_read_fit;
         a.err_flag = d_err_flag;
-        if (err_path == 0) {
-            a.n_calls = (unsigned long long *)(d_err_flag + 2);
-            a.call_cap = a.total / 2 > 65536 ? a.total / 2 : 65536;
-            if (const char *env = getenv("GMG_MG_ERR_CALLS")) a.call_cap = (uint64_t)atoll(env);     // (tests: force the fallback)
-            MG_TRY(gmg_pool_alloc((void **)&d_calls[0], a.call_cap * sizeof(MgCall)));
-            MG_TRY(gmg_pool_alloc((void **)&d_calls[1], a.call_cap * sizeof(MgCall)));
-            MG_TRY(gmg_pool_alloc((void **)&d_agg, no * sizeof(MgOrfAgg)));
-            MG_TRY(gmg_pool_alloc((void **)&d_fill, no * 4));
-            a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; a.agg = d_agg; a.fill = d_fill;
-            a.walk_stride = ((a.total + 15) & ~15ull) + 16;
-            MG_TRY(gmg_pool_alloc((void **)&d_walk, (size_t)6 * a.walk_stride * sizeof(double)));
-            if (err_mode == 1) MG_TRY(gmg_pool_alloc((void **)&d_walk_q, a.total + 8));
-            hipLaunchKernelGGL(k_mg_walk_tables, dim3(grid_for(a.total)), dim3(256), 0, s2, a, d_walk, d_walk_q);
-            MG_TRY(hipGetLastError());
-            a.walk = d_walk; a.walk_q = d_walk_q;
-            tm.lap("walk-order tables");
-        }
+        a.n_calls = (unsigned long long *)(d_err_flag + 2);
+        a.call_cap = a.total / 2 > 65536 ? a.total / 2 : 65536;
+        if (const char *env = getenv("GMG_MG_ERR_CALLS")) a.call_cap = (uint64_t)atoll(env);     // (tests: force the fallback)
+        MG_TRY(gmg_pool_alloc((void **)&d_calls[0], a.call_cap * sizeof(MgCall)));
+        MG_TRY(gmg_pool_alloc((void **)&d_calls[1], a.call_cap * sizeof(MgCall)));
+        MG_TRY(gmg_pool_alloc((void **)&d_agg, no * sizeof(MgOrfAgg)));
+        MG_TRY(gmg_pool_alloc((void **)&d_fill, no * 4));
+        a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; a.agg = d_agg; a.fill = d_fill;
+        a.walk_stride = ((a.total + 15) & ~15ull) + 16;
+        MG_TRY(gmg_pool_alloc((void **)&d_walk, (size_t)6 * a.walk_stride * sizeof(double)));
+        if (err_mode == 1) MG_TRY(gmg_pool_alloc((void **)&d_walk_q, a.total + 8));
+        hipLaunchKernelGGL(k_mg_walk_tables, dim3(grid_for(a.total)), dim3(256), 0, s2, a, d_walk, d_walk_q);
+        MG_TRY(hipGetLastError());
+        a.walk = d_walk; a.walk_q = d_walk_q;
+        tm.lap("walk-order tables");
     }
-    const size_t queue_lds = (size_t)50 * a.queue_len + 8 * (2 * MGQ_CAP + 3 * MGQ_ORFS) + 4 * (5 * MGQ_CAP + 2 * MGQ_ORFS);
-    const unsigned queue_grid = (unsigned)(nr < 256 * 16 ? (nr ? nr : 1) : 256 * 16);
     for (int attempt = 0; attempt < 2; attempt++) {
     const dim3 lvl_grid(256 * 16);
     if (no && err_mode && err_path == 0) {
@@ -2251,13 +1786,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         hipLaunchKernelGGL((k_mg_err_level<false, 2>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
         hipLaunchKernelGGL(k_mg_err_verdict, dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only);
         if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 1);
-    } else if (no && err_mode && err_path == 3) {
-        MG_TRY(hipFuncSetAttribute((const void *)k_mg_err_queue<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)queue_lds));
-        MG_TRY(hipFuncSetAttribute((const void *)k_mg_err_queue<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)queue_lds));
-        hipLaunchKernelGGL(k_mg_err_queue<false>, dim3(queue_grid), dim3(64), queue_lds, s2, a, err_acc_only);
-        hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 1);
-    } else if (no && err_mode && err_path == 1) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 0);
-    else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_starts<false>, dim3(grid_for(no)), dim3(256), 0, s2, a);
+    } else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 0);
     else if (no) hipLaunchKernelGGL(k_mg_starts<false>, dim3(grid_for(no)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
     tm.lap("start lists: count");
@@ -2270,7 +1799,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (err_mode) {
         MG_TRY(gmg_pool_alloc((void **)&res->d_errs, (res->n_starts ? res->n_starts : 1) * sizeof(gmg_start_errors)));
         a.errs = res->d_errs;
-        if (err_path == 0 || err_path == 3) {
+        if (err_path == 0) {
             MG_TRY(gmg_pool_alloc((void **)&d_keys, (res->n_starts ? res->n_starts : 1) * 8));
             a.keys = d_keys;
         }
@@ -2285,15 +1814,11 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         hipLaunchKernelGGL((k_mg_err_level<true, 1>), lvl_grid, dim3(256), 0, s, a, err_acc_only);
         hipLaunchKernelGGL((k_mg_err_level<true, 2>), lvl_grid, dim3(256), 0, s, a, err_acc_only);
         if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 1);
-    } else if (no && err_mode && err_path == 3) {
-        hipLaunchKernelGGL(k_mg_err_queue<true>, dim3(queue_grid), dim3(64), queue_lds, s, a, err_acc_only);
-        hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 1);
-    } else if (no && err_mode && err_path == 1) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 0);
-    else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
+    } else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 0);
     else if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
-    if (!(no && err_mode && (err_path == 0 || err_path == 3))) break;
-    uint32_t flag = 0;                                  // a read whose queue held in the count pass overflowed in the write pass?
+    if (!(no && err_mode && err_path == 0)) break;
+    uint32_t flag = 0;                                  // did a call array overflow?
     MG_TRY(hipMemcpyAsync(&flag, d_err_flag, 4, hipMemcpyDeviceToHost, s));
     MG_TRY(hipStreamSynchronize(s));
     tm.lap("start lists: write");

@@ -59,12 +59,12 @@ def test_error_branch_matches_reference_push_order(gpu, oracle, nc, name):
     (dict(allow_subs=True), False),
 ])
 @pytest.mark.parametrize("kw", [dict(), dict(allow_truncated=False, min_gene_len=60), dict(ignore_score_len=150, start_codons=("atg", "rtg"))])
-@pytest.mark.parametrize("path", ["level", "wave", "flat", "recursive", "level-overflow"])
+@pytest.mark.parametrize("path", ["level", "flat", "level-overflow"])
 def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path, monkeypatch):
     """path: level by level with one lane per call and the sort into push order (the default; the 2100-bp read goes to the
-    per-ORF kernel), one wave per read with its call queue (reads beyond 1024 bp go to the per-ORF kernel), the per-ORF kernel
-    alone, the first, recursive version, and the default with call arrays too small (everything repeats on the per-ORF kernel)"""
-    env = {"wave": "GMG_MG_ERR_WAVE", "flat": "GMG_MG_ERR_FLAT", "recursive": "GMG_MG_ERR_RECURSIVE", "level-overflow": "GMG_MG_ERR_CALLS"}
+    per-ORF kernel), the per-ORF kernel alone, and the default with call arrays too small (everything repeats on the per-ORF
+    kernel)"""
+    env = {"flat": "GMG_MG_ERR_FLAT", "level-overflow": "GMG_MG_ERR_CALLS"}
     if path in env:
         monkeypatch.setenv(env[path], "7" if path == "level-overflow" else "1")
     rng = np.random.default_rng(99)
@@ -72,7 +72,7 @@ def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path
     seqs = ["".join("acgt"[c] for c in rng.integers(0, 4, size=n)) for n in lengths]
     seqs.append("acg" * 120)                                            # no stop codon at all
     seqs.append("a" * 40 + "".join("acgt"[c] for c in rng.integers(0, 4, size=200)) + "tttttttt" + "gggg" * 9)   # long runs
-    seqs.append("".join("acgt"[c] for c in rng.integers(0, 4, size=1300)))      # longer than the per-read kernel stages
+    seqs.append("".join("acgt"[c] for c in rng.integers(0, 4, size=1300)))
     seqs.append("".join("acgt"[c] for c in rng.integers(0, 4, size=2100)))      # too long for the order keys
     quals = [np.where(rng.random(len(s)) < 0.12, rng.integers(0, 19, len(s)), rng.integers(19, 41, len(s))).astype(np.int32)
              for s in seqs] if with_q else [None] * len(seqs)
