@@ -317,10 +317,11 @@ typedef struct gmg_mg_orf {
     uint32_t start_begin, n_starts;      /* its start list: starts[start_begin .. +n_starts), in the
                                             order Score_Orf_Starts pushed them, boost applied      */
     int16_t accepted;            /* non-empty, first_j+1 >= Min_Gene_Len, best_score > Start_Threshold
-                                    (glimmer-mg.cc:1656-1676): the ORF goes to Add_Events_*.  Error branch only: 2 =
-                                    best_score passes, but the starts at the extreme pos differ in j and only some
-                                    pass the length test -- first_j is whichever of them the reference's unstable
-                                    sort puts first, so the caller decides after ITS sort (first_j here: the smallest) */
+                                    (glimmer-mg.cc:1656-1676): the ORF goes to Add_Events_*.  Error branch only: paths
+                                    tie on pos with different j, so first_j is whichever entry the reference's unstable
+                                    sort puts first (reported: the smallest).  2 = best_score passes but only some of those
+                                    entries pass the length test, so the caller decides after ITS sort -- a guard: the
+                                    reference's own filter (glimmer-mg.cc:1821) already makes every pushed j pass */
     int16_t orf_is_truncated;
     int32_t reserved;
     double best_score;           /* max over the boosted start scores, -DBL_MAX if none           */
