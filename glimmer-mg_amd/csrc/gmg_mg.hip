@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
         bool fwd = false;
         int64_t dir = 1, g = 0, off = 0;
         int avail = 0, n = 0;
-        uint32_t comp = 0, w = 0;
+        uint32_t comp = 0;
         const double *wp = a.walk;                      // the call's stream of Frame_Scores, four doubles at a time
         const uint8_t *qp = a.qual;
         double s0 = 0.0, s1 = 0.0;                      // score[] inside the codon being walked
@@ -1081,20 +1081,20 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
         bool walking = false, finishing = false, is_last = false, trunc = false, first_done = false;
         int tp = 0, br = 0;                             // codon, next branch candidate of it (0..5; 6 none)
         uint32_t pidx = 0, nidx = 0, last_own = MG_NO_SLOT, cnt = 0;
-        uint64_t ext_a = 0, ext_b = 0;
+        int last_pos = 0, last_j = 0;
         double sum = 0.0, prev = 0.0, best = -DBL_MAX;
 
         auto fetch = [&](int t, uint32_t &idx) __attribute__((always_inline)) -> bool {
             if (avail - 3 * t < 3) { trunc = a.allow_truncated != 0; return true; }
-            uint32_t c[3];
-#pragma unroll
-            for (int x = 0; x < 3; x++) {
-                c[x] = ((w >> (2u * (unsigned)(g & 15))) & 3u) ^ comp;
-                const int64_t g2 = g + dir;
-                if ((g ^ g2) >> 4) w = a.packed[g2 >> 4];
-                g = g2;
-            }
-            idx = c[2] << 4 | c[1] << 2 | c[0];
+            // the three bases of codon t lie in at most two packed words: both are loaded, no branches
+            const int64_t g0c = g, g2c = g + 2 * dir;
+            const uint32_t wa = a.packed[g0c >> 4], wb = a.packed[g2c >> 4];
+            const int64_t g1c = g + dir;
+            const uint32_t c0 = ((wa >> (2u * (unsigned)(g0c & 15))) & 3u) ^ comp;
+            const uint32_t c1 = ((((g1c >> 4) == (g0c >> 4) ? wa : wb) >> (2u * (unsigned)(g1c & 15))) & 3u) ^ comp;
+            const uint32_t c2 = ((wb >> (2u * (unsigned)(g2c & 15))) & 3u) ^ comp;
+            g += 3 * dir;
+            idx = c2 << 4 | c1 << 2 | c0;
             return (a.fwd_stop >> idx) & 1;
         };
         auto emit = [&](double raw, int j_loc, int pos, int which, int truncated, int first, uint32_t kind) __attribute__((always_inline)) -> uint32_t {
@@ -1113,9 +1113,9 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                 a.errs[slot] = er;
                 a.keys[slot] = key | (uint64_t)((uint32_t)(2047 - j_loc) << 2 | kind) << (26 - 13 * LEVEL);
             } else {
-                const uint64_t pa = (uint64_t)(uint32_t)(pos + 16) << 32 | (uint32_t)j_full, pb = (uint64_t)(uint32_t)(pos + 16) << 32 | (0xffffffffu - (uint32_t)j_full);
-                if (fwd) { if (pa < ext_a) ext_a = pa; if (pb < ext_b) ext_b = pb; }
-                else { if (pa > ext_a) ext_a = pa; if (pb > ext_b) ext_b = pb; }
+                // inside one call pos moves with j (forward: pos = end - 2 - j, reverse: end + 2 + j), so the call's entry at the
+                // extreme pos is simply the last one it emits
+                last_pos = pos; last_j = j_full;
                 if (sc > best) best = sc;
                 cnt++;
             }
@@ -1166,12 +1166,8 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                         }
                         is_last = false; trunc = false; first_done = false; walking = false;
                         tp = 0; br = 0; last_own = MG_NO_SLOT; cnt = 0;
-                        ext_a = ext_b = fwd ? ~0ull : 0ull;
                         sum = 0.0; prev = 0.0; best = -DBL_MAX;
-                        if (anchor >= 0 && anchor < n) {
-                            w = a.packed[g >> 4];
-                            walking = !fetch(0, pidx);
-                        }
+                        if (anchor >= 0 && anchor < n) walking = !fetch(0, pidx);
                         finishing = true;               // the end-of-call work is still to do
                     }
                 }
@@ -1205,25 +1201,35 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                     }
                 }
                 if (LEVEL < 2 && !WRITE && a.err_mode == 1 && LEVEL < a.indel_max) {
-                    // Score_Indels at the three positions, in reversed push order: per position insertion, then deletion
-                    while (br < 6) {
-                        const int c = br++, pj = c >> 1, b = c & 1, j = j0 + pj;
+                    // Score_Indels at the three positions, in reversed push order: per position insertion, then deletion -- six
+                    // candidates.  All six are evaluated without branches (most fail on the quality alone, but a wave pays for the
+                    // longest path of any lane: the early-exit loop cost more), then the first one at or after br is taken.
+                    uint32_t pass = 0;
+                    double es6[6];
+#pragma unroll
+                    for (int pj = 0; pj < 3; pj++) {
                         const int q = (int)((qw >> (8 * pj)) & 255u);
-                        if (j < lowest_j || q > a.indel_q_thr) { br = 2 * pj + 2; continue; }
-                        const double pen = pen_lds ? s_pen[q] : a.pen[q];
+                        const bool low = j0 + pj >= lowest_j && q <= a.indel_q_thr;
+                        const double pen = pen_lds ? s_pen[q & 63] : a.pen[q];
                         const double before = pj == 0 ? prev : pj == 1 ? s0 : s1, at = pj == 0 ? s0 : pj == 1 ? s1 : sum;
-                        const double es = ((suffix_score + (b == 0 ? before : at)) - 0.0) + pen;
-                        if (es > a.indel_suffix_thr) {
-                            const int k = fwd ? end_point - 2 - j : end_point + 2 + j;
-                            int epos;
-                            if (b == 0) { c_end = fwd ? k - (2 - pj) : k + 2 - pj; epos = fwd ? k + 2 : k - 2; }
-                            else { c_end = fwd ? k + pj : k - pj; epos = fwd ? k + 3 : k - 1; }
-                            c_score = es; c_sj = suffix_j + j + 2 - pj;
-                            c_err = (uint32_t)(epos + 8) << 2 | (uint32_t)b;
-                            c_field = (uint32_t)(2047 - j) << 2 | (b == 0 ? 1u : 0u);
-                            want_push = true;
-                            break;
-                        }
+                        es6[2 * pj] = ((suffix_score + before) - 0.0) + pen;
+                        es6[2 * pj + 1] = ((suffix_score + at) - 0.0) + pen;
+                        if (low && es6[2 * pj] > a.indel_suffix_thr) pass |= 1u << (2 * pj);
+                        if (low && es6[2 * pj + 1] > a.indel_suffix_thr) pass |= 2u << (2 * pj);
+                    }
+                    pass &= ~((1u << br) - 1u);
+                    if (pass) {
+                        const int c = __ffs((int)pass) - 1, pj = c >> 1, b = c & 1, j = j0 + pj;
+                        br = c + 1;
+                        const int k = fwd ? end_point - 2 - j : end_point + 2 + j;
+                        int epos;
+                        if (b == 0) { c_end = fwd ? k - (2 - pj) : k + 2 - pj; epos = fwd ? k + 2 : k - 2; }
+                        else { c_end = fwd ? k + pj : k - pj; epos = fwd ? k + 3 : k - 1; }
+                        c_score = c == 0 ? es6[0] : c == 1 ? es6[1] : c == 2 ? es6[2] : c == 3 ? es6[3] : c == 4 ? es6[4] : es6[5];
+                        c_sj = suffix_j + j + 2 - pj;
+                        c_err = (uint32_t)(epos + 8) << 2 | (uint32_t)b;
+                        c_field = (uint32_t)(2047 - j) << 2 | (b == 0 ? 1u : 0u);
+                        want_push = true;
                     }
                 }
                 if (!want_push) {
@@ -1259,8 +1265,10 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                     MgOrfAgg *g2 = a.agg + orf;
                     atomicAdd(&g2->cnt, cnt);
                     atomicMax(&g2->best, (unsigned long long)mg_ord(best));
-                    if (fwd) { atomicMin(&g2->ext_a, (unsigned long long)ext_a); atomicMin(&g2->ext_b, (unsigned long long)ext_b); }
-                    else { atomicMax(&g2->ext_a, (unsigned long long)ext_a); atomicMax(&g2->ext_b, (unsigned long long)ext_b); }
+                    const unsigned long long pa = (unsigned long long)(uint32_t)(last_pos + 16) << 32 | (uint32_t)last_j,
+                                             pb = (unsigned long long)(uint32_t)(last_pos + 16) << 32 | (0xffffffffu - (uint32_t)last_j);
+                    if (fwd) { atomicMin(&g2->ext_a, pa); atomicMin(&g2->ext_b, pb); }
+                    else { atomicMax(&g2->ext_a, pa); atomicMax(&g2->ext_b, pb); }
                 }
             }
             if (LEVEL < 2 && !WRITE) {
