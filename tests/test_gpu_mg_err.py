@@ -56,6 +56,8 @@ def test_error_branch_matches_reference_push_order(gpu, oracle, nc, name):
     (dict(allow_indels=True), False),
     (dict(allow_indels=True), True),
     (dict(allow_indels=True, indel_max=1, indel_quality_threshold=21, indel_suffix_score_threshold=-6.0), False),
+    # every base may branch (threshold above all qualities; the penalty table beyond its LDS copy); a tight suffix threshold bounds the tree
+    (dict(allow_indels=True, indel_quality_threshold=70, indel_suffix_score_threshold=-2.5), True),
     (dict(allow_subs=True), False),
 ])
 @pytest.mark.parametrize("kw", [dict(), dict(allow_truncated=False, min_gene_len=60), dict(ignore_score_len=150, start_codons=("atg", "rtg"))])
