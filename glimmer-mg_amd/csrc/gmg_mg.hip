@@ -107,6 +107,7 @@ struct MgArgs {
     // level by level (k_mg_err_level): the calls of level 1 and 2 wait in two arrays
     struct MgCall *calls[2];
     unsigned long long *n_calls; // [2] entries used
+    unsigned long long *tile_ctr;// [6] next tile of calls per (pass, level) (k_mg_err_level)
     uint64_t call_cap;           // entries per array
     struct MgOrfAgg *agg;        // [n_orfs] what the calls of an ORF add up to
     uint32_t *fill;              // [n_orfs] write pass: slots handed out inside the ORF's slice
@@ -1032,7 +1033,9 @@ __global__ __launch_bounds__(256) void k_mg_err_prepare(MgArgs a)
 }
 
 #define MG_CALL_CHUNK 256
-#define MG_LEVEL_TILE 512        // calls a wave works through before it moves on
+// calls a wave works through before it asks for more (count pass per 1M reads: 64: 79 ms, 128: 62, 256: 59, 512: 61, 2048: 71,
+// 8192: 84 -- small tiles keep a wave's lanes on neighbouring reads; the write pass skips most calls and wants fewer atomics: 8 ms at 2048, 12 at 256)
+#define MG_LEVEL_TILE (WRITE ? 2048 : 256)
 #ifndef MG_LEVEL_BATCH
 #define MG_LEVEL_BATCH 16        // lanes that wait before the wave runs the take / finish code (1: 191 ms count pass per 1M reads; 8: 147; 16: 141; 32: 146)
 #endif
@@ -1060,8 +1063,14 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
     // A wave owns MG_LEVEL_TILE consecutive calls at a time and its lanes take them one by one: a lane that has finished its
     // call starts the next one of the tile instead of waiting for the longest call of the wave (calls run from 0 to ~500
     // positions; with one call per lane per round 60 % of the lane-trips were idle).
-    const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t tile = wave_id * MG_LEVEL_TILE; tile < n_in; tile += n_waves * MG_LEVEL_TILE) {
+    // Tiles are handed out by a counter (one atomic per tile): every wave stays busy until the calls run out, whatever its tiles cost.
+    unsigned long long *tile_ctr = a.tile_ctr + (WRITE ? 3 : 0) + LEVEL;
+    for (;;) {
+        unsigned long long t_ = 0;
+        if (lane == 0) t_ = atomicAdd(tile_ctr, 1ull);
+        const uint64_t tile = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t_) |
+                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t_ >> 32)) << 32) * MG_LEVEL_TILE;
+        if (tile >= n_in) break;
         uint64_t next = tile;
         const uint64_t tile_end = tile + MG_LEVEL_TILE < n_in ? tile + MG_LEVEL_TILE : n_in;
         // the call a lane is walking
@@ -1765,11 +1774,12 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     const bool any_unfit = reads->max_len >= 2040;
     if (res->n_orfs && err_mode && err_path == 0) {
         MG_TRY(gmg_pool_alloc((void **)&d_read_fit, nr ? nr : 1));
-        MG_TRY(gmg_pool_alloc((void **)&d_err_flag, 32));           // the flag + the two call counters
-        MG_TRY(hipMemsetAsync(d_err_flag, 0, 32, s2));
+        MG_TRY(gmg_pool_alloc((void **)&d_err_flag, 80));           // the flag + the two call counters + six tile counters
+        MG_TRY(hipMemsetAsync(d_err_flag, 0, 80, s2));
         a.read_fit = d_read_fit;
         a.err_flag = d_err_flag;
         a.n_calls = (unsigned long long *)(d_err_flag + 2);
+        a.tile_ctr = (unsigned long long *)(d_err_flag + 6);
         a.call_cap = a.total / 2 > 65536 ? a.total / 2 : 65536;
         if (const char *env = getenv("GMG_MG_ERR_CALLS")) a.call_cap = (uint64_t)atoll(env);     // (tests: force the fallback)
         MG_TRY(gmg_pool_alloc((void **)&d_calls[0], a.call_cap * sizeof(MgCall)));
