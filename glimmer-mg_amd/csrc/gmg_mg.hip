@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_mg_err_prepare(MgArgs a)
 // 8192: 84 -- small tiles keep a wave's lanes on neighbouring reads; the write pass skips most calls and wants fewer atomics: 8 ms at 2048, 12 at 256)
 #define MG_LEVEL_TILE (WRITE ? 2048 : 256)
 #ifndef MG_LEVEL_BATCH
-#define MG_LEVEL_BATCH 16        // lanes that wait before the wave runs the take / finish code (1: 191 ms count pass per 1M reads; 8: 147; 16: 141; 32: 146)
+#define MG_LEVEL_BATCH 32        // lanes that wait before the wave runs the take / finish code (count pass per 1M reads: 4: 64 ms, 8: 61, 16: 60, 24 - 48: 58)
 #endif
 
 #ifndef MG_LEVEL_WAVES
