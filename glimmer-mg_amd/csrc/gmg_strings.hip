@@ -23,10 +23,49 @@ struct StringSumArgs {
     const uint64_t *read_off;
     uint64_t n_reads, total, tail_start;
     const float *vals;           // [2][total]
+    float *heads;                // [2][n_reads][16]: the first W-1 values of every string (k_string_heads)
     double *sums;                // [n_reads][2]: forward string, reverse complement
 };
 
 struct __attribute__((packed, aligned(4))) StrF4 { float v[4]; };
+
+// The first W-1 positions of every string by the partial-window rule (icm.cc:883-888, 807-842), one lane per
+// (strand, read, position), on the completed tree (shift bytes in LDS; "stop when the context position lies before the
+// string" reads "shift byte < 2 ((W-1) - j)"; crow has the row for inner nodes too).  Its own kernel: inside k_string_sum
+// the dependent global reads of this step stalled every wave for several microseconds and its 5.5 KB of LDS cost a
+// third of the waves per CU (2.7 -> 1.x ms per model for the summing kernel).
+__global__ __launch_bounds__(256) void k_string_heads(StringSumArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_shift[5472];       // completed-tree shifts of sub-model 0, depth 7
+    const int W = a.m.W, D = a.m.D;
+    for (int i = threadIdx.x * 16; i < a.m.cstride && i < 5472; i += 256 * 16) *(uint4 *)(s_shift + i) = *(const uint4 *)(a.m.cshift + i);
+    __syncthreads();
+    const uint32_t ctx_mask = (1u << (2 * W)) - 1u;
+    const uint64_t per_strand = a.n_reads * (uint64_t)(W - 1);
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < 2 * per_strand; idx += (uint64_t)gridDim.x * blockDim.x) {
+        const bool rc = idx >= per_strand;
+        const uint64_t rem = rc ? idx - per_strand : idx;
+        const uint64_t r = rem / (uint32_t)(W - 1);
+        const int j = (int)(rem - r * (uint32_t)(W - 1));
+        const uint64_t off_k = a.read_off[r];
+        const int n_k = (int)(a.read_off[r + 1] - off_k);
+        if (j >= n_k) continue;
+        uint32_t C;                                     // window ending at string position j: char i at bits 2i
+        if (!rc) C = (uint32_t)dev_window_bits(a.packed, (int64_t)off_k + j - (W - 1)) & ctx_mask;
+        else C = (dev_reverse_fields((uint32_t)dev_window_bits(a.packed, (int64_t)off_k + n_k - 1 - j) & ctx_mask, W) ^ ctx_mask);
+        const int thr2 = 2 * ((W - 1) - j);
+        uint32_t tidx = 0, lvl = 0, width = 1, node = 0xffffffffu;
+        for (int l = 0; l < D; l++) {
+            const uint32_t sh = s_shift[lvl + tidx];
+            if (node == 0xffffffffu && (int)sh < thr2) node = lvl + tidx;
+            tidx = (tidx << 2) + ((C >> sh) & 3u);
+            lvl += width;
+            width <<= 2;
+        }
+        if (node == 0xffffffffu) node = lvl + tidx;
+        a.heads[((rc ? a.n_reads : 0) + r) * 16 + j] = a.m.crow[(size_t)node * 4 + ((C >> (2 * (W - 1))) & 3u)];
+    }
+}
 
 // One work-group = one wave = STR_READS consecutive reads of one strand.  Their values are ONE contiguous run of the
 // row, so the wave streams it through LDS in slabs of STR_SLAB floats with fully coalesced 16-byte loads (memory order =
@@ -34,19 +73,19 @@ struct __attribute__((packed, aligned(4))) StrF4 { float v[4]; };
 // read adds the part of its read inside the slab, in string order, carrying its sum from slab to slab.  Forward
 // strings walk the slabs upwards, reverse complements downwards.  Reads of any length work (a long read simply spans
 // several slabs).
+#ifndef STR_READS
 #define STR_READS 16
+#endif
+#ifndef STR_SLAB
 #define STR_SLAB 4096
+#endif
 
 __global__ __launch_bounds__(64) void k_string_sum(StringSumArgs a)
 {
     __shared__ __attribute__((aligned(16))) float s_v[STR_SLAB];
-    __shared__ __attribute__((aligned(16))) uint8_t s_shift[5472];       // completed-tree shifts of sub-model 0, depth 7
-    __shared__ float s_head[STR_READS][16];                             // the first W-1 values of every string of the group
     const uint32_t lane = threadIdx.x;
     const uint64_t groups = (a.n_reads + STR_READS - 1) / STR_READS;
-    const int W = a.m.W, D = a.m.D;
-    for (int i = lane * 16; i < a.m.cstride && i < 5472; i += 64 * 16) *(uint4 *)(s_shift + i) = *(const uint4 *)(a.m.cshift + i);
-    const uint32_t ctx_mask = (1u << (2 * W)) - 1u;
+    const int W = a.m.W;
     for (uint64_t blk = blockIdx.x; blk < 2 * groups; blk += gridDim.x) {
         const bool rc = blk >= groups;                  // reverse complement: string position q <-> read position n-1-q
         const uint64_t r0 = (rc ? blk - groups : blk) * STR_READS;
@@ -58,35 +97,11 @@ __global__ __launch_bounds__(64) void k_string_sum(StringSumArgs a)
         const int n = live ? (int)(a.read_off[r + 1] - off) : 0;
         const DevBuf b = dev_make_buf(a.packed, off, 0, (uint32_t)n, rc ? GMG_REVCOMP : GMG_FORWARD);
         const int head = n < W - 1 ? n : W - 1;
-        // partial windows (icm.cc:883-888, 807-842): the W-1 first positions of the 16 strings, all lanes in parallel,
-        // on the completed tree (shift bytes in LDS; "stop when the context position lies before the string" reads
-        // "shift byte < 2 ((W-1) - j)"; crow has the row for inner nodes too)
-        __syncthreads();
-        for (uint32_t idx = lane; idx < STR_READS * (uint32_t)(W - 1); idx += 64) {
-            const uint32_t k = idx / (uint32_t)(W - 1);
-            const int j = (int)(idx - k * (uint32_t)(W - 1));
-            if (r0 + k >= r1) continue;
-            const uint64_t off_k = a.read_off[r0 + k];
-            const int n_k = (int)(a.read_off[r0 + k + 1] - off_k);
-            if (j >= n_k) continue;
-            uint32_t C;                                 // window ending at string position j: char i at bits 2i
-            if (!rc) C = (uint32_t)dev_window_bits(a.packed, (int64_t)off_k + j - (W - 1)) & ctx_mask;
-            else C = (dev_reverse_fields((uint32_t)dev_window_bits(a.packed, (int64_t)off_k + n_k - 1 - j) & ctx_mask, W) ^ ctx_mask);
-            const int thr2 = 2 * ((W - 1) - j);
-            uint32_t tidx = 0, lvl = 0, width = 1, node = 0xffffffffu;
-            for (int l = 0; l < D; l++) {
-                const uint32_t sh = s_shift[lvl + tidx];
-                if (node == 0xffffffffu && (int)sh < thr2) node = lvl + tidx;
-                tidx = (tidx << 2) + ((C >> sh) & 3u);
-                lvl += width;
-                width <<= 2;
-            }
-            if (node == 0xffffffffu) node = lvl + tidx;
-            s_head[k][j] = a.m.crow[(size_t)node * 4 + ((C >> (2 * (W - 1))) & 3u)];
-        }
-        __syncthreads();
         double sum = 0.0;                               // icm.cc:871
-        if (live) for (int q = 0; q < head; q++) sum += (double)s_head[lane][q];
+        if (live) {                                     // the partial windows first (k_string_heads), in string order
+            const float *hd = a.heads + ((rc ? a.n_reads : 0) + r) * 16;
+            for (int q = 0; q < head; q++) sum += (double)hd[q];
+        }
         int q = head;                                   // next string position of this lane's read
         const float *row = a.vals + (rc ? a.total : 0);
         const uint64_t n_slabs = (g_hi - g_lo + STR_SLAB - 1) / STR_SLAB;
@@ -164,7 +179,7 @@ extern "C" int gmg_score_reads_strings(const gmg_model *const *models, int n_mod
     hipStream_t s = (hipStream_t)stream;
     const uint64_t nr = reads->n_reads;
     if (nr == 0 || n_models == 0) return GMG_OK;
-    float *d_vals = nullptr;
+    float *d_vals = nullptr, *d_heads = nullptr;
     gmg_segments *segs = nullptr;                       // built on demand for models without the fast pass
     int rc = GMG_OK;
     for (int k = 0; k < n_models && rc == GMG_OK; k++) {
@@ -187,6 +202,15 @@ extern "C" int gmg_score_reads_strings(const gmg_model *const *models, int n_mod
             a.tail_start = tail_start;
             a.vals = d_vals;
             a.sums = out;
+            if (!d_heads) {
+                hipError_t eh = gmg_pool_alloc((void **)&d_heads, (size_t)2 * nr * 16 * sizeof(float));
+                if (eh != hipSuccess) { rc = gmg_set_error(GMG_ENOMEM, "gmg_score_reads_strings: %s", hipGetErrorString(eh)); break; }
+            }
+            a.heads = d_heads;
+            {
+                const uint64_t items = 2 * nr * (uint64_t)(m->dev.W - 1), hb = (items + 255) / 256;
+                hipLaunchKernelGGL(k_string_heads, dim3((unsigned)(hb < 256 * 64 ? (hb ? hb : 1) : 256 * 64)), dim3(256), 0, s, a);
+            }
             const uint64_t blocks = 2 * ((nr + STR_READS - 1) / STR_READS);
             hipLaunchKernelGGL(k_string_sum, dim3((unsigned)(blocks < 256 * 256 ? blocks : 256 * 256)), dim3(64), 0, s, a);
             hipError_t e = hipGetLastError();
@@ -212,6 +236,7 @@ extern "C" int gmg_score_reads_strings(const gmg_model *const *models, int n_mod
     }
     hipError_t e = hipStreamSynchronize(s);            // the scratch goes back to the cache: nothing may still use it
     if (d_vals) gmg_pool_release(d_vals);
+    if (d_heads) gmg_pool_release(d_heads);
     if (segs) gmg_segments_free(segs);
     if (rc == GMG_OK && e != hipSuccess) rc = gmg_set_error(GMG_EHIP, "gmg_score_reads_strings: %s", hipGetErrorString(e));
     return rc;
