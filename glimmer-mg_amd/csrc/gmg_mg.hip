@@ -1795,7 +1795,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         a.walk = d_walk; a.walk_q = d_walk_q;
         tm.lap("walk-order tables");
     }
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0; attempt < 3; attempt++) {
     const dim3 lvl_grid(256 * 16);
     if (no && err_mode && err_path == 0) {
         hipLaunchKernelGGL(k_mg_err_prepare, dim3(grid_for(no > nr ? no : nr)), dim3(256), 0, s2, a);
@@ -1810,6 +1810,30 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     tm.lap("start lists: count");
     rc = mg_scan(d_orf_cnt, d_start_off, no, &res->n_starts, s2);
     if (rc) return fail(rc);
+    if (no && err_mode && err_path == 0) {              // did a call array overflow?  (mg_scan has synchronised the stream)
+        uint32_t st[20];
+        MG_TRY(hipMemcpy(st, d_err_flag, 80, hipMemcpyDeviceToHost));
+        if (st[0]) {
+            // once more with arrays of twice what was asked for (level 2 is only partly known when level 1 overflows); if that is
+            // not enough either, or does not fit, everything runs on the per-ORF kernel
+            unsigned long long asked[2];
+            memcpy(asked, st + 2, 16);
+            const uint64_t want = 2 * (asked[0] > asked[1] ? asked[0] : asked[1]) + 65536;
+            gmg_pool_release(d_calls[0]); gmg_pool_release(d_calls[1]);
+            d_calls[0] = d_calls[1] = nullptr;
+            const bool may_grow = attempt == 0 && want <= 8 * a.total + 65536 && (!getenv("GMG_MG_ERR_CALLS") || getenv("GMG_MG_ERR_CALLS_GROW"));
+            bool grown = false;
+            if (may_grow && gmg_pool_alloc((void **)&d_calls[0], want * sizeof(MgCall)) == hipSuccess) {
+                if (gmg_pool_alloc((void **)&d_calls[1], want * sizeof(MgCall)) == hipSuccess) grown = true;
+                else { gmg_pool_release(d_calls[0]); d_calls[0] = nullptr; }
+            }
+            if (grown) { a.call_cap = want; a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; }
+            else err_path = 1;
+            MG_TRY(hipMemsetAsync(d_err_flag, 0, 80, s2));
+            MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
+            continue;
+        }
+    }
     if (res->n_starts >= 0x7fffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
     MG_TRY(gmg_pool_alloc((void **)&res->d_starts, (res->n_starts ? res->n_starts : 1) * sizeof(gmg_start)));
     a.start_off = d_start_off;
@@ -1835,17 +1859,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     } else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 0);
     else if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
-    if (!(no && err_mode && err_path == 0)) break;
-    uint32_t flag = 0;                                  // did a call array overflow?
-    MG_TRY(hipMemcpyAsync(&flag, d_err_flag, 4, hipMemcpyDeviceToHost, s));
-    MG_TRY(hipStreamSynchronize(s));
-    tm.lap("start lists: write");
-    if (!flag) break;
-    gmg_pool_release(res->d_starts); res->d_starts = nullptr;      // (not seen so far) -> everything again on the exact path
-    gmg_pool_release(res->d_errs); res->d_errs = nullptr;
-    gmg_pool_release(d_keys); d_keys = nullptr; a.keys = nullptr;
-    err_path = 1;
-    MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
+    break;
     }
     }
     if (!find_only && (prm->flags & GMG_MG_ACCEPTED_ONLY)) {

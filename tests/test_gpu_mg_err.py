@@ -61,14 +61,16 @@ def test_error_branch_matches_reference_push_order(gpu, oracle, nc, name):
     (dict(allow_subs=True), False),
 ])
 @pytest.mark.parametrize("kw", [dict(), dict(allow_truncated=False, min_gene_len=60), dict(ignore_score_len=150, start_codons=("atg", "rtg"))])
-@pytest.mark.parametrize("path", ["level", "flat", "level-overflow"])
+@pytest.mark.parametrize("path", ["level", "flat", "level-overflow", "level-grow"])
 def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path, monkeypatch):
     """path: level by level with one lane per call and the sort into push order (the default; the 2100-bp read goes to the
-    per-ORF kernel), the per-ORF kernel alone, and the default with call arrays too small (everything repeats on the per-ORF
-    kernel)"""
-    env = {"flat": "GMG_MG_ERR_FLAT", "level-overflow": "GMG_MG_ERR_CALLS"}
+    per-ORF kernel), the per-ORF kernel alone, the default with call arrays too small (everything repeats on the per-ORF
+    kernel), and the same with the arrays allowed to grow (the count pass repeats with larger ones)"""
+    env = {"flat": "GMG_MG_ERR_FLAT", "level-overflow": "GMG_MG_ERR_CALLS", "level-grow": "GMG_MG_ERR_CALLS"}
     if path in env:
-        monkeypatch.setenv(env[path], "7" if path == "level-overflow" else "1")
+        monkeypatch.setenv(env[path], "1" if path == "flat" else "7")
+    if path == "level-grow":
+        monkeypatch.setenv("GMG_MG_ERR_CALLS_GROW", "1")
     rng = np.random.default_rng(99)
     lengths = [0, 1, 5, 14, 15, 16, 17, 18, 33, 74, 75, 76, 99, 150, 231, 300, 301, 302, 400, 523, 700]
     seqs = ["".join("acgt"[c] for c in rng.integers(0, 4, size=n)) for n in lengths]
