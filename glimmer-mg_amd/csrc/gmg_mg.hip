@@ -1633,22 +1633,15 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     }
     a.fs = d_frame_scores;
     tm.lap("frame scores");
-    if (err_mode) {                                     // the error branch sums per call; it needs the qualities
+    if (err_mode) {                                     // the error branch sums per call; it needs the penalties and the qualities
         MG_TRY(gmg_pool_alloc((void **)&d_pen, sizeof pen_host));
-        MG_TRY(hipMemcpyAsync(d_pen, pen_host, sizeof pen_host, hipMemcpyHostToDevice, s));
+        MG_TRY(hipMemcpyAsync(d_pen, pen_host, sizeof pen_host, hipMemcpyHostToDevice, s));    // (pen_host lives until this call returns)
         a.pen = d_pen;
         if (err_mode == 1 && a.total) {
             MG_TRY(gmg_pool_alloc((void **)&d_qual, a.total + 8));     // (+8: the level kernels read four values at a time)
-            if (prm->quality) {
-                MG_TRY(gmg_pool_alloc((void **)&d_user_q, a.total));
-                MG_TRY(hipMemcpyAsync(d_user_q, prm->quality, a.total, hipMemcpyHostToDevice, s));
-            }
-            hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(a.total)), dim3(256), 0, s, a, d_user_q, d_qual);
-            MG_TRY(hipGetLastError());
-            a.qual = d_qual;
+            if (prm->quality) MG_TRY(gmg_pool_alloc((void **)&d_user_q, a.total));
+            a.qual = d_qual;                            // filled below, beside Find_Orfs on the second stream
         }
-        MG_TRY(hipStreamSynchronize(s));                // (pen_host is a stack buffer)
-        tm.lap("quality values");
     }
     // running sums of every reading-frame class (what Cumulative_Frame_Score would give any ORF)
     if (!err_mode) {
@@ -1734,7 +1727,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     hipEvent_t side_done = nullptr;
     int dev_id = 0;
     MG_TRY(hipGetDevice(&dev_id));
-    if (!find_only && !err_mode && !tm.on && !getenv("GMG_MG_ONE_STREAM") && dev_id >= 0 && dev_id < 16) {
+    if (!find_only && !tm.on && !getenv("GMG_MG_ONE_STREAM") && dev_id >= 0 && dev_id < 16) {
         if (!side_of[dev_id]) {
             MG_TRY(hipStreamCreateWithFlags(&side_of[dev_id], hipStreamNonBlocking));
             MG_TRY(hipEventCreateWithFlags(&done_of[dev_id], hipEventDisableTiming));
@@ -1759,8 +1752,18 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     a.n_orfs = no;
     if (nr) hipLaunchKernelGGL(k_mg_find_orfs<true>, dim3(grid_for(nr)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
-
     tm.lap("find orfs");
+    if (err_mode == 1 && a.total && !find_only) {       // Set_Quality_454 / Clean_Quality_454: needs the reads only
+        if (prm->quality) MG_TRY(hipMemcpyAsync(d_user_q, prm->quality, a.total, hipMemcpyHostToDevice, s2));
+        hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(a.total)), dim3(256), 0, s2, a, d_user_q, d_qual);
+        MG_TRY(hipGetLastError());
+        tm.lap("quality values");
+    }
+    if (err_mode && s2 != s) {                          // the error branch needs the six-frame table from here on: one stream again
+        MG_TRY(hipEventRecord(side_done, s2));
+        MG_TRY(hipStreamWaitEvent(s, side_done, 0));
+        s2 = s;
+    }
     // 3. start lists
     if (!find_only) {
     MG_TRY(gmg_pool_alloc((void **)&d_orf_cnt, (no + 1) * 4));
