@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Differential stress run of the error branch: N ragged random reads, several parameter sets, EVERY ORF's start list
-(push order, errors, scores), verdict and bounds against the CPU oracle.  usage: stress_err.py [reads] [seed]"""
+"""Differential stress run of glimmer-mg's front half (default mode and the error branch): N ragged random reads, several parameter sets, EVERY ORF's start list
+(push order, errors, scores), verdict and bounds against the CPU oracle.  usage: stress_mg.py [reads] [seed]"""
 import os
 import sys
 import time
@@ -32,6 +32,8 @@ for i in range(0, n, 7):
 reads = gmg.Reads.from_strings(seqs)
 quals = [np.where(rng.random(len(s)) < 0.1, rng.integers(0, 19, len(s)), rng.integers(19, 41, len(s))).astype(np.int32) for s in seqs]
 cases = [
+    ("default", dict(), dict(), None),
+    ("default2", dict(min_gene_len=45, allow_truncated=False, ignore_score_len=200), dict(), None),
     ("-i", dict(), dict(allow_indels=True), None),
     ("-i -q", dict(min_gene_len=60), dict(allow_indels=True), quals),
     ("-s", dict(allow_truncated=False), dict(allow_subs=True), None),
@@ -41,9 +43,27 @@ gc = 0.46
 indep, o_indep = gmg.Icm.indep(gc), orc.indep(gc)
 for name, kw, ekw, q in cases:
     t0 = time.perf_counter()
-    orfs, starts, off, errs = gmg.mg_score_reads(gene, indep, reads, quality=np.concatenate(q).astype(np.uint8) if q else None, **kw, **ekw)
+    res = gmg.mg_score_reads(gene, indep, reads, quality=np.concatenate(q).astype(np.uint8) if q else None, **kw, **ekw)
     t_dev = time.perf_counter() - t0
     prm, ep = orc.mg_params(**kw), orc.mg_err_params(**ekw)
+    if not ekw:                                         # the default mode: running-sum kernels + start scan, lists in push order
+        orfs, starts, off = res
+        n_orf = n_start = n_acc = 0
+        t0 = time.perf_counter()
+        for r, s in enumerate(seqs):
+            want_orfs, scored = orc.mg_read(o_gene, o_indep, s.encode(), prm)
+            mine = orfs[int(off[r]):int(off[r + 1])]
+            assert np.array_equal(np.stack([mine["frame"], mine["stop_position"], mine["gene_len"], mine["orf_len"]], 1).reshape(-1, 4), want_orfs), (name, r)
+            for o, (out, want) in zip(mine, scored):
+                st = starts[o["start_begin"]:o["start_begin"] + o["n_starts"]]
+                assert [(int(a["j"]), int(a["pos"]), int(a["which"]), int(a["truncated"]), int(a["first"]), float(a["score"])) for a in st] == \
+                       [(w.j, w.pos, w.which, w.truncated, w.first, w.score) for w in want], (name, r)
+                assert (int(o["lo"]), int(o["hi"]), int(o["accepted"]), int(o["first_j"])) == (out.lo, out.hi, out.accepted, out.first_j), (name, r)
+                n_orf += 1; n_start += len(want); n_acc += out.accepted != 0
+        print("%-8s reads %d  ORFs %d  starts %d  accepted %d  device %.1f ms  oracle %.1f s  -- identical" %
+              (name, n, n_orf, n_start, n_acc, t_dev * 1e3, time.perf_counter() - t0))
+        continue
+    orfs, starts, off, errs = res
     n_orf = n_start = n_acc = 0
     t0 = time.perf_counter()
     for r, s in enumerate(seqs):
