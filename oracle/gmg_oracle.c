@@ -10,6 +10,7 @@
 #include "gmg_oracle.h"
 
 #include <ctype.h>
+#include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1157,4 +1158,250 @@ long orc_score_reads_6frame(const orc_model *gene, const orc_model *indep, const
     for (r = 0; r < n_reads; r++)
         orc_score_all_frames(gene, indep, seqs + (size_t)r * L, L, out + (size_t)r * 6 * L);
     return (long)n_reads * L;
+}
+
+/* ------------------------------------------------------------------------ */
+/* training: ICM_Training_t (src/ICM/icm.cc:1010-1455) and its helpers       */
+/* ------------------------------------------------------------------------ */
+
+/* icm.hh:37-43, 62-80 */
+#define ORC_NUM_CHI2 7
+static const float ORC_CHI2_VAL[ORC_NUM_CHI2] = {2.37, 4.11, 6.25, 7.81, 9.35, 11.3, 12.8};
+static const float ORC_CHI2_SIG[ORC_NUM_CHI2] = {0.50, 0.75, 0.90, 0.95, 0.975, 0.99, 0.995};
+static const double ORC_MUT_INFO_BIAS = 0.03;
+static const double ORC_MUT_INFO_EPSILON = 1e-4;
+static const double ORC_PSEUDO_COUNT = 0.001;
+#define ORC_SAMPLE_SIZE_BOUND 400
+
+static int orc_level_first(int level)   /* first node of a level: (4^level - 1) / 3 */
+{
+    int i, pw = 1;
+    for (i = 0; i < level; i++) pw *= ORC_ALPHA;
+    return (pw - 1) / (ORC_ALPHA - 1);
+}
+
+void orc_train_level_counts(const orc_model *m, const char *const *strings, int n_strings, int level,
+                            int32_t *counts)
+{
+    const int W = m->model_len, P = m->periodicity;
+    const int first = orc_level_first(level);
+    const int on_level = orc_level_first(level + 1) - first;
+    int s, i;
+
+    if (level == 0) {
+        /* icm.cc:1373-1390: one pass per sub-model, first window at `offset`, stepping by the periodicity
+         * (Count_Char_Pairs, icm.cc:1841-1870) */
+        int frame;
+        for (frame = 0; frame < P; frame++) {
+            int offset = frame - (W % P);
+            if (offset < 0) offset += P;
+            for (s = 0; s < n_strings; s++) {
+                const char *str = strings[s];
+                int len = (int)strlen(str), start, stop, end;
+                if (offset >= len) continue;      /* the reference would read past the NUL here */
+                str += offset;
+                end = len - offset;
+                for (start = 0, stop = W - 1; stop < end; start += P, stop += P) {
+                    int last = orc_subscript(str[stop]);
+                    for (i = 0; i < W - 1; i++)
+                        counts[((size_t)frame * (W - 1) + i) * 16 + ORC_ALPHA * orc_subscript(str[start + i]) + last]++;
+                }
+            }
+        }
+        return;
+    }
+
+    /* icm.cc:1190-1229 with Get_Training_Node (icm.cc:1233-1256) inlined */
+    for (s = 0; s < n_strings; s++) {
+        const char *str = strings[s];
+        int end = (int)strlen(str), start = 0, stop, frame = W % P;
+        for (stop = W - 1; stop < end; start++, stop++) {
+            const int16_t *mip = m->mip + (size_t)frame * m->num_nodes;
+            int sub = 0, ok = 1;
+            for (i = 0; i < level; i++) {
+                int j = mip[sub];
+                if (j < 0) { ok = 0; break; }
+                sub = sub * ORC_ALPHA + orc_subscript(str[start + j]) + 1;
+            }
+            if (ok) {
+                int last = orc_subscript(str[stop]);
+                int32_t *ct = counts + ((size_t)frame * on_level + (sub - first)) * (W - 1) * 16;
+                for (i = 0; i < W - 1; i++)
+                    ct[i * 16 + ORC_ALPHA * orc_subscript(str[start + i]) + last]++;
+            }
+            if (++frame == P) frame = 0;
+        }
+    }
+}
+
+/* icm.cc:1900-1955 */
+double orc_mutual_info(const int32_t ct[16], int sum)
+{
+    double mut_info = 0.0, left_prob[ORC_ALPHA], right_prob[ORC_ALPHA];
+    int i, j, k;
+    if (sum == 0) return 0.0;
+    for (i = 0; i < ORC_ALPHA; i++) left_prob[i] = right_prob[i] = 0.0;
+    for (i = k = 0; i < ORC_ALPHA; i++)
+        for (j = 0; j < ORC_ALPHA; j++) {
+            left_prob[i] += ct[k];
+            right_prob[j] += ct[k];
+            k++;
+        }
+    for (i = 0; i < ORC_ALPHA; i++) {
+        left_prob[i] /= sum;
+        right_prob[i] /= sum;
+    }
+    for (i = k = 0; i < ORC_ALPHA; i++)
+        for (j = 0; j < ORC_ALPHA; j++) {
+            double prob = (double)ct[k] / sum;
+            if (prob != 0.0 && left_prob[i] != 0.0 && right_prob[j] != 0.0)
+                mut_info += prob * log(prob / (left_prob[i] * right_prob[j]));
+            k++;
+        }
+    return mut_info;
+}
+
+/* icm.cc:1260-1330.  prob / parent are the 4-float rows of the node and of its parent (plain probabilities). */
+static void orc_interpolate_probs(float *prob, const float *parent, const int ct[ORC_ALPHA])
+{
+    double expected, chi2_stat, lambda, total_sum = 0.0;
+    int i;
+    for (i = 0; i < ORC_ALPHA; i++) total_sum += ct[i];
+    for (i = 0; i < ORC_ALPHA; i++)
+        prob[i] = (ct[i] + ORC_PSEUDO_COUNT * parent[i]) / (total_sum + ORC_PSEUDO_COUNT);
+    if (total_sum >= ORC_SAMPLE_SIZE_BOUND) return;
+    chi2_stat = 0.0;
+    for (i = 0; i < ORC_ALPHA; i++) {
+        expected = total_sum * parent[i];
+        if (expected > 0.0) chi2_stat += pow(ct[i] - expected, 2.0) / expected;
+    }
+    for (i = 0; i < ORC_NUM_CHI2 && ORC_CHI2_VAL[i] < chi2_stat; i++)
+        ;
+    if (i == 0)
+        lambda = 0.0;
+    else if (i == ORC_NUM_CHI2)
+        lambda = 1.0;
+    else   /* the table differences are float subtractions, as in the reference */
+        lambda = ORC_CHI2_SIG[i - 1]
+                 + ((chi2_stat - ORC_CHI2_VAL[i - 1]) / (ORC_CHI2_VAL[i] - ORC_CHI2_VAL[i - 1]))
+                       * (ORC_CHI2_SIG[i] - ORC_CHI2_SIG[i - 1]);
+    lambda *= total_sum / ORC_SAMPLE_SIZE_BOUND;
+    if (lambda > 1.0) lambda = 1.0;
+    for (i = 0; i < ORC_ALPHA; i++) {
+        prob[i] *= lambda;
+        prob[i] += (1.0 - lambda) * parent[i];
+    }
+}
+
+/* the max-mutual-information scan shared by the root (icm.cc:1406-1426) and the deeper nodes (icm.cc:1116-1139):
+ * positions to the right win when within MUT_INFO_BIAS.  *used = info of the chosen position (deeper nodes),
+ * *best = the maximum (root). */
+static int orc_best_position(const int32_t *ct, int W, int sum, double *best, double *used)
+{
+    int i, max_pos = 0;
+    double best_info = orc_mutual_info(ct, sum), next_info, used_info;
+    used_info = best_info;
+    for (i = 1; i < W - 1; i++) {
+        next_info = orc_mutual_info(ct + 16 * i, sum);
+        if (next_info >= best_info) {
+            used_info = best_info = next_info;
+            max_pos = i;
+        } else if (next_info >= (best_info / (1.0 + ORC_MUT_INFO_BIAS))) {
+            max_pos = i;
+            used_info = next_info;
+        }
+    }
+    *best = best_info;
+    *used = used_info;
+    return max_pos;
+}
+
+orc_model *orc_train_model(const char *const *strings, int n_strings, int model_len, int model_depth,
+                           int periodicity, float *mut_info)
+{
+    orc_model *m = orc_model_new(model_len, model_depth, periodicity);
+    const int W = model_len, P = periodicity;
+    int frame, level, i, j, k, s;
+    int32_t *counts = NULL;
+    if (!m) return NULL;
+    if (mut_info) memset(mut_info, 0, sizeof(float) * (size_t)P * m->num_nodes);
+
+    if (model_depth == 0) {
+        /* icm.cc:1376-1389: Count_Single_Chars (icm.cc:1874-1896) */
+        for (frame = 0; frame < P; frame++) {
+            int final_char_ct[ORC_ALPHA] = {0}, sum = 0, pos;
+            float *prob = m->prob + 4 * (size_t)frame * m->num_nodes;
+            int offset = frame - (W % P);
+            if (offset < 0) offset += P;
+            for (s = 0; s < n_strings; s++) {
+                int len = (int)strlen(strings[s]);
+                for (pos = offset + W - 1; pos < len; pos += P) final_char_ct[orc_subscript(strings[s][pos])]++;
+            }
+            for (i = 0; i < ORC_ALPHA; i++) sum += final_char_ct[i];
+            for (i = 0; i < ORC_ALPHA; i++)
+                prob[i] = (final_char_ct[i] + (float)(ORC_PSEUDO_COUNT / ORC_ALPHA)) / (sum + ORC_PSEUDO_COUNT);
+            m->mip[(size_t)frame * m->num_nodes] = -1;
+        }
+    } else {
+        /* roots: icm.cc:1391-1432 */
+        counts = (int32_t *)calloc((size_t)P * (W - 1) * 16, sizeof(int32_t));
+        orc_train_level_counts(m, strings, n_strings, 0, counts);
+        for (frame = 0; frame < P; frame++) {
+            const int32_t *ct = counts + (size_t)frame * (W - 1) * 16;
+            int final_char_ct[ORC_ALPHA] = {0}, sum = 0, max_pos;
+            float *prob = m->prob + 4 * (size_t)frame * m->num_nodes;
+            double best, used;
+            for (i = k = 0; i < ORC_ALPHA; i++)
+                for (j = 0; j < ORC_ALPHA; j++) {
+                    sum += ct[k];
+                    final_char_ct[j] += ct[k];
+                    k++;
+                }
+            for (j = 0; j < ORC_ALPHA; j++)   /* float arithmetic throughout, as written in the reference */
+                prob[j] = (final_char_ct[j] + (float)(ORC_PSEUDO_COUNT / ORC_ALPHA)) / (float)(sum + ORC_PSEUDO_COUNT);
+            max_pos = orc_best_position(ct, W, sum, &best, &used);
+            m->mip[(size_t)frame * m->num_nodes] = (int16_t)max_pos;
+            if (mut_info) mut_info[(size_t)frame * m->num_nodes] = (float)best;
+        }
+        free(counts);
+    }
+
+    /* Complete_Tree: icm.cc:1061-1186 */
+    for (level = 1; level <= model_depth; level++) {
+        const int first = orc_level_first(level), on_level = orc_level_first(level + 1) - first;
+        counts = (int32_t *)calloc((size_t)P * on_level * (W - 1) * 16, sizeof(int32_t));
+        orc_train_level_counts(m, strings, n_strings, level, counts);
+        for (frame = 0; frame < P; frame++) {
+            int16_t *mip = m->mip + (size_t)frame * m->num_nodes;
+            float *probs = m->prob + 4 * (size_t)frame * m->num_nodes;
+            int sub;
+            for (sub = first; sub < first + on_level; sub++) {
+                const int32_t *ct = counts + ((size_t)frame * on_level + (sub - first)) * (W - 1) * 16;
+                int final_char_ct[ORC_ALPHA] = {0}, sum = 0, max_pos;
+                double best, used;
+                if (mip[orc_parent(sub)] < 0) {     /* stopped at the parent */
+                    mip[sub] = -2;
+                    continue;
+                }
+                for (i = k = 0; i < ORC_ALPHA; i++)
+                    for (j = 0; j < ORC_ALPHA; j++) {
+                        sum += ct[k];
+                        final_char_ct[j] += ct[k];
+                        k++;
+                    }
+                max_pos = orc_best_position(ct, W, sum, &best, &used);
+                if (best <= ORC_MUT_INFO_EPSILON && sum < ORC_SAMPLE_SIZE_BOUND) max_pos = -1;
+                mip[sub] = (int16_t)max_pos;
+                if (mut_info) mut_info[(size_t)frame * m->num_nodes + sub] = (float)used;
+                orc_interpolate_probs(probs + 4 * sub, probs + 4 * orc_parent(sub), final_char_ct);
+            }
+        }
+        free(counts);
+    }
+
+    /* Take_Logs: icm.cc:1334-1352.  The argument is a float, so the C++ reference resolves  log  to the float
+     * overload: logf, not log. */
+    for (i = 0; i < 4 * P * m->num_nodes; i++)
+        m->prob[i] = (m->prob[i] > 0.0) ? logf(m->prob[i]) : -FLT_MAX;
+    return m;
 }

@@ -14,7 +14,8 @@
  *     values, copied as data to tests/golden/), and
  *   - against golden vectors produced in the build container by the real
  *     reference objects (oracle/_ref, recipe in oracle/Makefile, generator
- *     oracle/gen_golden.py).
+ *     oracle/gen_golden.py); the training side (orc_train_*) against .icm files
+ *     written by the reference's build-icm compiled the same way.
  *
  * Every function cites the reference file:line it restates.  Paths are
  * relative to the reference root.
@@ -156,6 +157,22 @@ void orc_clean_quality_454(const char *seq, int n, int *q, int indel_quality_thr
 int orc_mg_score_orf_errors(const double *frame_scores, const char *seq, int n, const int *fwd_prev, const int *rev_next,
                             const int *quality, int frame, int stop_position, const orc_mg_params *prm,
                             const orc_mg_err_params *ep, orc_start_err *starts, int cap, orc_mg_out *out);
+
+/* ---- training (build-icm): ICM_Training_t, src/ICM/icm.cc:1010-1455, 1841-1955 ------------------------------- */
+/* The 4 x 4 pair counts of one tree level.  level 0: Count_Char_Pairs per sub-model with Train_Model's offsets
+ * (icm.cc:1373-1390, 1841-1870); level >= 1: Count_Char_Pairs_Restricted + Get_Training_Node (icm.cc:1190-1256) on
+ * m->mip of the levels above.  strings are used as given (lower case; every character through orc_subscript).
+ * counts[((f * 4^level + k) * (model_len - 1) + i) * 16 + 4 * code(w[i]) + code(w[model_len-1])], k = node - first
+ * node of the level; the caller zeroes it. */
+void orc_train_level_counts(const orc_model *m, const char *const *strings, int n_strings, int level,
+                            int32_t *counts);
+/* Get_Mutual_Info (icm.cc:1900-1955) for one 4 x 4 table. */
+double orc_mutual_info(const int32_t ct[16], int sum);
+/* Train_Model (icm.cc:1356-1455) + Complete_Tree (icm.cc:1061-1186) + Interpolate_Probs (icm.cc:1260-1330) +
+ * Take_Logs (icm.cc:1334-1352).  mut_info (may be NULL): [periodicity * num_nodes] floats, the value the reference
+ * stores in ICM_Score_Node_t::mut_info (text output only). */
+orc_model *orc_train_model(const char *const *strings, int n_strings, int model_len, int model_depth,
+                           int periodicity, float *mut_info);
 
 /* Fasta_Read (src/Common/fasta.cc:236-286) on a memory buffer.  Starts at *pos; returns 0 at the end of the
  * input, else 1 with the header extent [*hdr_begin, *hdr_end) in buf, the raw sequence characters (every

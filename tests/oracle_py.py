@@ -111,6 +111,11 @@ class Oracle:
         L.orc_fasta_next.argtypes = [C.c_char_p, C.c_long, lp, lp, lp, C.c_char_p, lp]
         L.orc_fasta_all.restype = C.c_long
         L.orc_fasta_all.argtypes = [C.c_char_p, C.c_long, C.c_char_p, lp, lp]
+        L.orc_train_level_counts.argtypes = [MP, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(C.c_int32)]
+        L.orc_mutual_info.restype = C.c_double
+        L.orc_mutual_info.argtypes = [C.POINTER(C.c_int32), C.c_int]
+        L.orc_train_model.restype = MP
+        L.orc_train_model.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
         for f in ("orc_filter", "orc_complement", "orc_subscript"):
             getattr(L, f).argtypes = [C.c_int]
 
@@ -337,6 +342,32 @@ class Oracle:
     def filter_lower(self, seq):
         """tolower(Filter(c)) per character (glimmer3.cc:270-271)"""
         return bytes(ord(chr(self.L.orc_filter(c)).lower()) for c in (seq.encode() if isinstance(seq, str) else seq))
+
+    # ---- training (build-icm)
+    @staticmethod
+    def _strings(strings):
+        return (C.c_char_p * len(strings))(*strings)
+
+    def train_model(self, strings, W=12, D=7, P=3, want_mut_info=False):
+        """strings: list of bytes (lower case).  Returns the model (and the mut_info floats)."""
+        n_nodes = (4 ** (D + 1) - 1) // 3
+        mi = np.zeros(P * n_nodes, np.float32)
+        m = self.L.orc_train_model(self._strings(strings), len(strings), W, D, P,
+                                   mi.ctypes.data_as(C.POINTER(C.c_float)))
+        return (m, mi) if want_mut_info else m
+
+    def train_level_counts(self, m, strings, level):
+        mm = m.contents
+        out = np.zeros((mm.periodicity, 4 ** level, max(mm.model_len - 1, 1), 16), np.int32)
+        self.L.orc_train_level_counts(m, self._strings(strings), len(strings), level,
+                                      out.ctypes.data_as(C.POINTER(C.c_int32)))
+        return out
+
+    def model_tables(self, m):
+        mm = m.contents
+        n = mm.periodicity * mm.num_nodes
+        return (np.ctypeslib.as_array(mm.mip, (n,)).copy().reshape(mm.periodicity, mm.num_nodes),
+                np.ctypeslib.as_array(mm.prob, (4 * n,)).copy().reshape(mm.periodicity, mm.num_nodes, 4))
 
     def score_reads_6frame(self, gene, indep, seqs_bytes, n_reads, L):
         out = np.empty((n_reads, 6, L), np.float64)
