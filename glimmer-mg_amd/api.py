@@ -117,6 +117,16 @@ class Icm:
         _ck(capi.lib().gmg_icm_build_indep(m.h, float(gc_frac), arr, len(stops)))
         return m
 
+    @classmethod
+    def train(cls, strings, model_len=12, model_depth=7, periodicity=3):
+        """ICM_Training_t model(w, d, p); model.Train_Model(strings)  (src/ICM/build-icm.cc:67,120).  strings: lower-case
+        str/bytes in the orientation Train_Model gets them.  The counting runs on the device (gmg_trainer_*)."""
+        raw = [s.encode("latin-1") if isinstance(s, str) else bytes(s) for s in strings]
+        arr = (C.c_char_p * max(len(raw), 1))(*raw)
+        h = C.c_void_p()
+        _ck(capi.lib().gmg_icm_train(arr, len(raw), model_len, model_depth, periodicity, C.byref(h)))
+        return cls(h)
+
     @property
     def params(self):
         w, d, p, n = C.c_int(), C.c_int(), C.c_int(), C.c_int()
@@ -223,6 +233,37 @@ class Reads:
     def close(self):
         if self.h:
             capi.lib().gmg_reads_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Trainer:
+    """gmg_trainer: the pair counts of build-icm's training, one tree level per call (levels in order)."""
+
+    def __init__(self, strings, model_len=12, model_depth=7, periodicity=3):
+        self.strings = strings            # the Reads batch must outlive the trainer
+        self.shape = (model_len, model_depth, periodicity)
+        self.h = C.c_void_p()
+        _ck(capi.lib().gmg_trainer_create(strings.h, model_len, model_depth, periodicity, C.byref(self.h)))
+
+    def level_counts(self, level, mip_prev=None):
+        """-> int32 [periodicity, 4^level, max(model_len - 1, 1), 16]; mip_prev: int16 [periodicity, 4^(level-1)]"""
+        w, _, p = self.shape
+        out = np.zeros((p, 4 ** level, max(w - 1, 1), 16), np.int32)
+        if mip_prev is not None:
+            mip_prev = np.ascontiguousarray(mip_prev, np.int16)
+        _ck(capi.lib().gmg_trainer_level_counts(self.h, level, _ptr(mip_prev) if mip_prev is not None else None,
+                                                _ptr(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            capi.lib().gmg_trainer_free(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

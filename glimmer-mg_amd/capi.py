@@ -83,12 +83,16 @@ PROTOTYPES = {
     "gmg_orfs_upload": (i32, [vp, vp, u64, C.POINTER(u64), C.POINTER(vp)]),
     "gmg_orf_batch_free": (i32, [vp]),
     "gmg_score_orfs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gmg_trainer_create": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
+    "gmg_trainer_level_counts": (i32, [vp, i32, vp, vp]),
+    "gmg_trainer_free": (i32, [vp]),
     "gmg_device_malloc": (i32, [C.POINTER(vp), C.c_size_t]),
     "gmg_device_free": (i32, [vp]),
     "gmg_memcpy_h2d": (i32, [vp, vp, C.c_size_t, vp]),
     "gmg_memcpy_d2h": (i32, [vp, vp, C.c_size_t, vp]),
     # include/gmg_icm.h
     "gmg_icm_new": (i32, [i32, i32, i32, C.POINTER(vp)]),
+    "gmg_icm_train": (i32, [C.POINTER(C.c_char_p), i32, i32, i32, i32, C.POINTER(vp)]),
     "gmg_icm_open": (i32, [C.c_char_p, C.POINTER(vp)]),
     "gmg_icm_build_indep": (i32, [vp, C.c_double, C.POINTER(C.c_char_p), i32]),
     "gmg_icm_write": (i32, [vp, C.c_char_p]),

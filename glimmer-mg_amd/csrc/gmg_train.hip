@@ -1,0 +1,216 @@
+// gmg_train.hip -- the counting side of build-icm on the device.
+//
+// The reference trains an ICM level by level (src/ICM/icm.cc:1356-1455 Train_Model, 1061-1186 Complete_Tree): for
+// every level it walks every window of every training string down the tree built so far (Get_Training_Node,
+// icm.cc:1233-1256) and adds the window's model_len - 1 (context base, predicted base) pairs to the 4 x 4 tables of
+// the node it lands on (Count_Char_Pairs_Restricted, icm.cc:1190-1229; Count_Char_Pairs, icm.cc:1841-1870, for the
+// roots).  That is all the work that grows with the training set; picking the context position from the tables and the
+// chi-squared interpolation are per node and stay host C++ (glimmer-mg_amd/host/icm_train.cc), as libm's log decides
+// ties there.
+//
+// Here: one lane per window.  The node a window reached at level l - 1 is kept in HBM (4 bytes per window), so a level
+// is ONE step of the descent instead of l, a coalesced 4-byte read + write per window, the window's 2-bit codes from
+// the packed stream, and model_len - 1 integer atomics.  Levels whose tables fit 64 KB of LDS (the top three for the
+// default 12 / 7 / 3 shape, where a few hundred counters would take every window's atomics) are counted per
+// workgroup in LDS and flushed once; deeper levels spread over >= 10^4 counters and go to L2 atomics directly.
+//
+//   k_train_level<true/false>   counts of one level (LDS / global atomics)
+//
+// Integer work only: counts are exact, so the tables equal the reference's for any order of the atomics.
+
+#include "gmg_device.h"
+
+#include <new>
+#include <stdio.h>
+#include <vector>
+
+struct gmg_trainer {
+    const gmg_reads *strings;   // borrowed: must outlive the trainer
+    int W, D, P;
+    int next_level;             // levels are taken in order
+    int32_t *d_node;            // [total_bases] node reached by the window starting at that base, -1 = none / stopped
+    int8_t *d_mip_prev;         // [P][4^(level-1)] mut_info_pos of the level above the one being counted
+    int32_t *d_cnt;             // [P][4^level][max(W-1,1)][16] of the level being counted
+    size_t cnt_cap;             // counters allocated at d_cnt
+};
+
+namespace {
+
+struct TrainArgs {
+    const uint32_t *packed;
+    const uint64_t *off;
+    const uint32_t *tile_read;
+    uint64_t total_bases, n_tiles;
+    int W, P, npos;             // npos = max(W - 1, 1)
+    int level, first, on_level; // first node of the level, nodes on it
+    int prev_first, prev_on;    // the level above
+    const int8_t *mip_prev;
+    int32_t *node;
+    int32_t *cnt;
+    uint32_t cnt_len;           // P * on_level * npos * 16
+};
+
+template <bool LDS>
+__global__ __launch_bounds__(256) void k_train_level(TrainArgs a)
+{
+    extern __shared__ int32_t hist[];
+    if (LDS) {
+        for (uint32_t i = threadIdx.x; i < a.cnt_len; i += 256) hist[i] = 0;
+        __syncthreads();
+    }
+    int32_t *const dst = LDS ? hist : a.cnt;
+
+    for (uint64_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        const uint32_t r_lo = a.tile_read[t], r_hi = a.tile_read[t + 1];
+#pragma unroll
+        for (int k = 0; k < GMG_TILE / 256; k++) {
+            const uint64_t g = t * GMG_TILE + (uint64_t)k * 256 + threadIdx.x;
+            if (g >= a.total_bases) break;
+            // string holding base g: the largest r in [r_lo, r_hi] with off[r] <= g (empty strings share offsets)
+            uint32_t lo = r_lo, hi = r_hi;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (a.off[mid] <= g) lo = mid; else hi = mid - 1;
+            }
+            const uint64_t begin = a.off[lo], end = a.off[lo + 1];
+            // frame of the window that starts at offset s of its string: (model_len + s) mod periodicity
+            // (icm.cc:1203-1226; Train_Model's per-frame offsets, icm.cc:1373-1375, say the same for the roots)
+            const int frame = (int)(((uint64_t)a.W + (g - begin)) % (uint64_t)a.P);
+            int node = -1;
+            if (g + (uint64_t)a.W <= end) {                                  // a complete window
+                if (a.level == 0) node = 0;
+                else {
+                    const int prev = a.node[g];
+                    if (prev >= 0) {
+                        const int p = a.mip_prev[frame * a.prev_on + (prev - a.prev_first)];
+                        if (p >= 0) node = 4 * prev + dev_code(a.packed, g + (uint64_t)p) + 1;   // icm.cc:1246-1252
+                    }
+                }
+            }
+            a.node[g] = node;
+            if (node < 0) continue;
+            const uint64_t bits = dev_window_bits(a.packed, (int64_t)g);     // 32 bases from g on
+            const uint32_t last = (uint32_t)(bits >> (2 * (a.W - 1))) & 3u;
+            int32_t *ct = dst + ((size_t)(frame * a.on_level + (node - a.first)) * a.npos) * 16 + last;
+            if (a.W == 1) { atomicAdd(ct, 1); continue; }                    // Count_Single_Chars, icm.cc:1874-1896
+            uint64_t b = bits;
+            for (int i = 0; i < a.W - 1; i++, b >>= 2) atomicAdd(ct + i * 16 + 4 * (int)(b & 3u), 1);   // icm.cc:1214-1219
+        }
+    }
+
+    if (LDS) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < a.cnt_len; i += 256) {
+            const int32_t v = hist[i];
+            if (v) atomicAdd(a.cnt + i, v);
+        }
+    }
+}
+
+int level_first(int level)   // (4^level - 1) / 3
+{
+    int pw = 1;
+    for (int i = 0; i < level; i++) pw *= 4;
+    return (pw - 1) / 3;
+}
+
+}  // namespace
+
+extern "C" int gmg_trainer_create(const gmg_reads *strings, int model_len, int model_depth, int periodicity,
+                                  gmg_trainer **out)
+{
+    if (!strings || !out) return gmg_set_error(GMG_EINVAL, "gmg_trainer_create: NULL argument");
+    if (model_len < 1 || model_len > GMG_MAX_MODEL_LEN || model_depth < 0 || model_depth > 12 || periodicity < 1)
+        return gmg_set_error(GMG_EBADMODEL, "gmg_trainer_create: model_len %d (1..%d), model_depth %d (0..12), "
+                             "periodicity %d (>= 1)", model_len, GMG_MAX_MODEL_LEN, model_depth, periodicity);
+    gmg_trainer *t = new (std::nothrow) gmg_trainer();
+    if (!t) return gmg_set_error(GMG_ENOMEM, "gmg_trainer_create: out of host memory");
+    t->strings = strings;
+    t->W = model_len;
+    t->D = model_depth;
+    t->P = periodicity;
+    t->next_level = 0;
+    t->d_node = nullptr;
+    t->d_mip_prev = nullptr;
+    t->d_cnt = nullptr;
+    const int npos = model_len > 1 ? model_len - 1 : 1;
+    const size_t on_last = (size_t)(level_first(model_depth + 1) - level_first(model_depth));
+    t->cnt_cap = (size_t)periodicity * on_last * npos * 16;
+    const size_t prev_cap = (size_t)periodicity * (model_depth > 0 ? on_last / 4 : 1);
+    hipError_t e = hipMalloc((void **)&t->d_node, (strings->total_bases + 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_mip_prev, prev_cap);
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_cnt, t->cnt_cap * sizeof(int32_t));
+    if (e != hipSuccess) {
+        gmg_trainer_free(t);
+        return gmg_set_error(GMG_ENOMEM, "gmg_trainer_create: device allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = t;
+    return GMG_OK;
+}
+
+extern "C" int gmg_trainer_free(gmg_trainer *t)
+{
+    if (!t) return GMG_OK;
+    if (t->d_node) (void)hipFree(t->d_node);
+    if (t->d_mip_prev) (void)hipFree(t->d_mip_prev);
+    if (t->d_cnt) (void)hipFree(t->d_cnt);
+    delete t;
+    return GMG_OK;
+}
+
+extern "C" int gmg_trainer_level_counts(gmg_trainer *t, int level, const int16_t *mip_prev, int32_t *counts)
+{
+    if (!t || !counts) return gmg_set_error(GMG_EINVAL, "gmg_trainer_level_counts: NULL argument");
+    if (level != t->next_level || level > t->D)
+        return gmg_set_error(GMG_EINVAL, "gmg_trainer_level_counts: level %d asked, level %d is next (levels go in "
+                             "order, 0 .. model_depth = %d)", level, t->next_level, t->D);
+    if (level > 0 && !mip_prev) return gmg_set_error(GMG_EINVAL, "gmg_trainer_level_counts: mip_prev is NULL");
+    const gmg_reads *r = t->strings;
+    TrainArgs a;
+    a.packed = r->d_packed;
+    a.off = r->d_off;
+    a.tile_read = r->d_tile_read;
+    a.total_bases = r->total_bases;
+    a.n_tiles = r->n_tiles;
+    a.W = t->W;
+    a.P = t->P;
+    a.npos = t->W > 1 ? t->W - 1 : 1;
+    a.level = level;
+    a.first = level_first(level);
+    a.on_level = level_first(level + 1) - a.first;
+    a.prev_first = level > 0 ? level_first(level - 1) : 0;
+    a.prev_on = level > 0 ? a.on_level / 4 : 1;
+    a.mip_prev = t->d_mip_prev;
+    a.node = t->d_node;
+    a.cnt = t->d_cnt;
+    const size_t cnt_len = (size_t)t->P * a.on_level * a.npos * 16;
+    a.cnt_len = (uint32_t)cnt_len;
+
+    if (level > 0) {
+        // the level above, narrowed to bytes; a context position outside the window would read another string
+        const size_t n = (size_t)t->P * a.prev_on;
+        std::vector<int8_t> m8(n);
+        for (size_t i = 0; i < n; i++) {
+            if (mip_prev[i] < -2 || mip_prev[i] > t->W - 2)
+                return gmg_set_error(GMG_EBADMODEL, "gmg_trainer_level_counts: mut_info_pos %d outside [-2, %d]",
+                                     (int)mip_prev[i], t->W - 2);
+            m8[i] = (int8_t)mip_prev[i];
+        }
+        GMG_HIP(hipMemcpy(t->d_mip_prev, m8.data(), n, hipMemcpyHostToDevice));
+    }
+    GMG_HIP(hipMemsetAsync(t->d_cnt, 0, cnt_len * sizeof(int32_t), 0));
+    if (a.n_tiles > 0) {
+        const bool lds = cnt_len * sizeof(int32_t) <= 64 * 1024;
+        if (lds) {
+            const unsigned grid = (unsigned)(a.n_tiles < 512 ? a.n_tiles : 512);
+            hipLaunchKernelGGL(k_train_level<true>, dim3(grid), dim3(256), cnt_len * sizeof(int32_t), 0, a);
+        } else {
+            const unsigned grid = (unsigned)(a.n_tiles < 8192 ? a.n_tiles : 8192);
+            hipLaunchKernelGGL(k_train_level<false>, dim3(grid), dim3(256), 0, 0, a);
+        }
+        GMG_HIP(hipGetLastError());
+    }
+    GMG_HIP(hipMemcpy(counts, t->d_cnt, cnt_len * sizeof(int32_t), hipMemcpyDeviceToHost));
+    t->next_level = level + 1;
+    return GMG_OK;
+}

@@ -16,7 +16,7 @@ __attribute__ ((weak)) int  Verbose = 0;
 
 struct gmg_icm
   {
-   ICM_t  model;
+   ICM_Training_t  model;     // an ICM_t with Train_Model; no extra state
    gmg_icm  (int w, int d, int p) : model (w, d, p) {}
   };
 
@@ -27,6 +27,24 @@ extern "C" int  gmg_icm_new  (int w, int d, int p, gmg_icm * * out)
    * out = new (nothrow) gmg_icm (w, d, p);
    if  (* out == NULL)
        return  gmg_set_error (GMG_ENOMEM, "gmg_icm_new: out of memory");
+   return  GMG_OK;
+  }
+
+extern "C" int  gmg_icm_train
+    (const char * const * strings, int n_strings, int w, int d, int p, gmg_icm * * out)
+  {
+   if  (out == NULL || (strings == NULL && n_strings > 0) || n_strings < 0 || w < 1 || d < 0 || d > 12 || p < 1)
+       return  gmg_set_error (GMG_EINVAL, "gmg_icm_train: bad argument");
+   gmg_icm  * h = new (nothrow) gmg_icm (w, d, p);
+   if  (h == NULL)
+       return  gmg_set_error (GMG_ENOMEM, "gmg_icm_train: out of memory");
+   string  err;
+   if  (! h -> model . Try_Train_Model (strings, n_strings, err))
+       {
+        delete  h;
+        return  gmg_set_error (GMG_EHIP, "%s", err . c_str ());
+       }
+   * out = h;
    return  GMG_OK;
   }
 
@@ -99,7 +117,7 @@ extern "C" int  gmg_icm_params
   {
    if  (icm == NULL)
        return  gmg_set_error (GMG_EINVAL, "gmg_icm_params: NULL model");
-   ICM_t  & m = const_cast <ICM_t &> (icm -> model);
+   ICM_t  & m = const_cast <ICM_Training_t &> (icm -> model);
    if  (w)  * w = m . Get_Model_Len ();
    if  (d)  * d = m . Get_Model_Depth ();
    if  (p)  * p = m . Get_Periodicity ();

@@ -1,5 +1,5 @@
-//  icm.hh -- MI355X-native drop-in for the scoring side of the reference's
-//  Interpolated Context Model class.
+//  icm.hh -- MI355X-native drop-in for the reference's Interpolated Context
+//  Model classes (scoring: ICM_t; training: ICM_Training_t).
 //
 //  Same public interface, constants, field names and error behaviour as the
 //  reference's  ICM_t  (src/ICM/icm.hh:26-84,106-180,303), so that code written
@@ -138,6 +138,33 @@ class  ICM_t
    void  Alloc_Tables  (void);
    void  Build_From_Codon_Probs
        (double codon_prob [64], const std::vector <const char *> & stop_codon, const char * who);
+  };
+
+
+//  src/ICM/icm.hh:183-213.  Same constructor and Train_Model as the reference's training class, so that
+//  src/ICM/build-icm.cc recompiles against this header unchanged.  The pair counting of every tree level
+//  (Count_Char_Pairs, Count_Char_Pairs_Restricted, Get_Training_Node; src/ICM/icm.cc:1190-1256,1841-1870) runs on
+//  the device through gmg_trainer_* (include/gmg.h) -- there is no CPU counting path; choosing each node's context
+//  position and the chi-squared interpolation (src/ICM/icm.cc:1061-1186,1260-1352) are per-node host arithmetic as
+//  in the reference (icm_train.cc).  The reference's per-node count tables (ICM_Training_Node_t, 46 MB for the
+//  default shape) are not kept: a level's counts live in HBM while that level is built.
+class  ICM_Training_t  :  public ICM_t
+  {
+  public:
+   ICM_Training_t
+       (int m = DEFAULT_MODEL_LEN,
+        int d = DEFAULT_MODEL_DEPTH,
+        int p = DEFAULT_PERIODICITY);
+   ~ ICM_Training_t
+       ();
+
+   void  Train_Model
+       (const std::vector <char *> & data);
+
+   // ---- additions ---------------------------------------------------------
+   //  Train_Model without the exit: returns false and sets  err  when the device layer fails.
+   bool  Try_Train_Model
+       (const char * const * data, int string_ct, std::string & err);
   };
 
 

@@ -377,6 +377,24 @@ int gmg_fasta_info(const gmg_fasta *index, uint64_t *n_reads, uint64_t *total_ba
 int gmg_fasta_headers(const gmg_fasta *index, uint64_t *hdr_begin, uint64_t *hdr_end);
 int gmg_fasta_free(gmg_fasta *index);
 
+/* ---- build-icm: training counts on the device ---------------------------------------
+ * Replaces the counting of ICM_Training_t: Count_Char_Pairs for the roots (src/ICM/icm.cc:1841-1870, called from
+ * Train_Model, icm.cc:1373-1390), Count_Char_Pairs_Restricted + Get_Training_Node for every deeper level
+ * (icm.cc:1190-1256, called from Complete_Tree, icm.cc:1082-1083) and Count_Single_Chars (icm.cc:1874-1896).
+ * `strings` = the training strings as a gmg_reads batch, in the orientation Train_Model gets them (build-icm -r
+ * reverses them first); it must outlive the trainer.  The tree is built level by level, as in the reference: */
+typedef struct gmg_trainer gmg_trainer;
+int gmg_trainer_create(const gmg_reads *strings, int model_len, int model_depth, int periodicity, gmg_trainer **out);
+/* The 4 x 4 pair tables of tree level `level` (0 = the roots).  Levels are taken in order 0, 1, .. model_depth.
+ * For level >= 1, mip_prev[f * 4^(level-1) + k] = mut_info_pos the caller chose for node k of level - 1 in sub-model f
+ * (< 0: the tree stops there, its windows count no further).  counts (HOST, periodicity * 4^level * npos * 16 int32,
+ * npos = max(model_len - 1, 1)):  counts[((f * 4^level + k) * npos + i) * 16 + 4 * code(w[i]) + code(w[model_len-1])]
+ * = number of complete windows w of sub-model f that reach node k of the level -- the reference's
+ * train[f][first + k].count[i][pair] (src/ICM/icm.hh:88-101).  A window starting at offset s of its string belongs to
+ * sub-model (model_len + s) mod periodicity (icm.cc:1203-1226).  With model_len = 1 only entry [last] of table 0 counts. */
+int gmg_trainer_level_counts(gmg_trainer *t, int level, const int16_t *mip_prev, int32_t *counts);
+int gmg_trainer_free(gmg_trainer *t);
+
 /* ---- device memory helpers (for callers without their own allocator) -------- */
 int gmg_device_malloc(void **d_ptr, size_t bytes);
 int gmg_device_free(void *d_ptr);

@@ -2,7 +2,7 @@
  * gmg_icm.h -- C ABI over the host-side ICM_t (glimmer-mg_amd/host/icm.hh) for
  * FFI users that cannot include the C++ class.  Model I/O and the null-model
  * builder are host code, as in the reference (src/ICM/icm.cc:65-216, 614-803);
- * nothing here scores.  Status codes and gmg_last_error() as in gmg.h; no
+ * nothing here scores (gmg_icm_train counts on the device).  Status codes and gmg_last_error() as in gmg.h; no
  * function exits the process.
  */
 #ifndef GMG_ICM_H
@@ -25,6 +25,10 @@ int gmg_icm_build_indep(gmg_icm *icm, double gc_frac, const char *const *stop_co
 /* ICM_t::Output(fp, binary)                      src/ICM/icm.cc:729-803,961-998 */
 int gmg_icm_write(gmg_icm *icm, const char *path);
 int gmg_icm_free(gmg_icm *icm);
+/* ICM_Training_t(m, d, p) + Train_Model(data)   src/ICM/icm.cc:1010-1042,1356-1455: a model trained on n_strings
+ * NUL-terminated lower-case strings (build-icm's Training_Data).  The counting runs on the device (gmg_trainer_*). */
+int gmg_icm_train(const char *const *strings, int n_strings, int model_len, int model_depth, int periodicity,
+                  gmg_icm **out);
 
 int gmg_icm_params(const gmg_icm *icm, int *model_len, int *model_depth, int *periodicity, int *num_nodes);
 /* copies mip[P*N] and prob4[P*N*4] (the layout gmg_model_upload takes) */
