@@ -85,13 +85,29 @@ extern "C" int gmg_base_code(int ch)
 
 extern "C" uint64_t gmg_packed_words(uint64_t total_bases) { return (total_bases + 15) / 16 + 1; }
 
+// gmg_base_code of every byte value, built on first use
+static const uint8_t *base_code_table(void)
+{
+    static const struct Table {
+        uint8_t code[256];
+        Table() { for (int c = 0; c < 256; c++) code[c] = (uint8_t)gmg_base_code(c); }
+    } table;
+    return table.code;
+}
+
 extern "C" int gmg_pack_bases(const char *ascii, uint64_t n, uint64_t first_base, uint32_t *packed)
 {
     if ((!ascii && n) || !packed) return gmg_set_error(GMG_EINVAL, "gmg_pack_bases: NULL argument");
-    for (uint64_t i = 0; i < n; i++) {
-        uint64_t g = first_base + i;
-        packed[g >> 4] |= (uint32_t)gmg_base_code((unsigned char)ascii[i]) << (2 * (g & 15));
+    const uint8_t *code = base_code_table();
+    const unsigned char *a = (const unsigned char *)ascii;
+    uint64_t i = 0, g = first_base;
+    for (; i < n && (g & 15); i++, g++) packed[g >> 4] |= (uint32_t)code[a[i]] << (2 * (g & 15));   // up to a word boundary
+    for (; i + 16 <= n; i += 16, g += 16) {                                                          // whole words
+        uint32_t w = 0;
+        for (int k = 0; k < 16; k++) w |= (uint32_t)code[a[i + k]] << (2 * k);
+        packed[g >> 4] |= w;
     }
+    for (; i < n; i++, g++) packed[g >> 4] |= (uint32_t)code[a[i]] << (2 * (g & 15));
     return GMG_OK;
 }
 

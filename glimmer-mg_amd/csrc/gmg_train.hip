@@ -10,17 +10,28 @@
 //
 // Here: one lane per window.  The node a window reached at level l - 1 is kept in HBM (4 bytes per window), so a level
 // is ONE step of the descent instead of l, a coalesced 4-byte read + write per window, the window's 2-bit codes from
-// the packed stream, and model_len - 1 integer atomics.  Levels whose tables fit 64 KB of LDS (the top three for the
-// default 12 / 7 / 3 shape, where a few hundred counters would take every window's atomics) are counted per
-// workgroup in LDS and flushed once; deeper levels spread over >= 10^4 counters and go to L2 atomics directly.
+// the packed stream, and model_len - 1 integer increments.  Where the increments go decides the speed:
+//   * levels whose tables fit 64 KB of LDS (the top three for the default 12 / 7 / 3 shape) are counted per workgroup
+//     in LDS and flushed once;
+//   * deeper levels: device-wide atomics from 8 XCDs are served behind the L2s, one memory-side transaction per
+//     increment (27 G increments/s measured, 26 - 38 ms per level for 63 M windows).  So big training sets sort the
+//     windows of the level by table first (hipcub radix sort of (table, window) pairs, <= 17 key bits); a workgroup
+//     then takes 4,096 consecutive windows, which touch a handful of tables, counts them in LDS and adds each
+//     table's 176 counters to HBM once;
+//   * small training sets (below GMG_TRAIN_SORT_MIN bases, default 2^22) keep the direct atomics: the sort's launches
+//     would cost more than they save.
 //
-//   k_train_level<true/false>   counts of one level (LDS / global atomics)
+//   k_train_level<LDS, KEYS>   the descent step + counts of one level (LDS / global atomics) or + the sort keys
+//   k_train_count_sorted       counts from the sorted (table, window) pairs
 //
 // Integer work only: counts are exact, so the tables equal the reference's for any order of the atomics.
 
 #include "gmg_device.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <new>
+#include <stdlib.h>
 #include <stdio.h>
 #include <vector>
 
@@ -32,6 +43,10 @@ struct gmg_trainer {
     int8_t *d_mip_prev;         // [P][4^(level-1)] mut_info_pos of the level above the one being counted
     int32_t *d_cnt;             // [P][4^level][max(W-1,1)][16] of the level being counted
     size_t cnt_cap;             // counters allocated at d_cnt
+    // the sorted path (allocated on first use): (table, window) pairs before / after the sort + hipcub's scratch
+    uint32_t *d_key, *d_key_sorted, *d_win, *d_win_sorted;
+    void *d_sort_tmp;
+    size_t sort_tmp_bytes;
 };
 
 namespace {
@@ -48,9 +63,10 @@ struct TrainArgs {
     int32_t *node;
     int32_t *cnt;
     uint32_t cnt_len;           // P * on_level * npos * 16
+    uint32_t *key, *win;        // KEYS: table of window g (P * on_level = none) and g itself
 };
 
-template <bool LDS>
+template <bool LDS, bool KEYS>
 __global__ __launch_bounds__(256) void k_train_level(TrainArgs a)
 {
     extern __shared__ int32_t hist[];
@@ -88,6 +104,11 @@ __global__ __launch_bounds__(256) void k_train_level(TrainArgs a)
                 }
             }
             a.node[g] = node;
+            if (KEYS) {                                                      // counted after the sort
+                a.key[g] = node < 0 ? (uint32_t)(a.P * a.on_level) : (uint32_t)(frame * a.on_level + (node - a.first));
+                a.win[g] = (uint32_t)g;
+                continue;
+            }
             if (node < 0) continue;
             const uint64_t bits = dev_window_bits(a.packed, (int64_t)g);     // 32 bases from g on
             const uint32_t last = (uint32_t)(bits >> (2 * (a.W - 1))) & 3u;
@@ -105,6 +126,58 @@ __global__ __launch_bounds__(256) void k_train_level(TrainArgs a)
             if (v) atomicAdd(a.cnt + i, v);
         }
     }
+}
+
+// Counts from (table, window) pairs sorted by table.  A workgroup takes SORT_CHUNK consecutive pairs; the tables
+// k0 .. k0 + SORT_TABLES - 1 (k0 = the chunk's first) are counted in LDS, anything beyond goes to HBM directly
+// (only where tables hold a handful of windows each).
+#define SORT_CHUNK 4096
+#define SORT_LDS_INTS (12 * 1024)            // 48 KB
+__global__ __launch_bounds__(256) void k_train_count_sorted(const uint32_t *__restrict__ key, const uint32_t *__restrict__ win,
+                                                            uint64_t n, const uint32_t *__restrict__ packed, int W, int npos,
+                                                            uint32_t n_tables, int32_t *__restrict__ cnt)
+{
+    __shared__ int32_t hist[SORT_LDS_INTS];
+    const uint64_t base = (uint64_t)blockIdx.x * SORT_CHUNK;
+    const uint32_t k0 = key[base];
+    if (k0 >= n_tables) return;                                              // only windows that count nothing from here on
+    const uint32_t tbl = (uint32_t)npos * 16;
+    const uint32_t in_lds = SORT_LDS_INTS / tbl;                             // tables held in LDS
+    const uint32_t used = in_lds * tbl;
+    for (uint32_t i = threadIdx.x; i < used; i += 256) hist[i] = 0;
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < SORT_CHUNK / 256; j++) {
+        const uint64_t e = base + (uint64_t)j * 256 + threadIdx.x;
+        if (e >= n) break;
+        const uint32_t k = key[e];
+        if (k >= n_tables) continue;
+        const uint64_t bits = dev_window_bits(packed, (int64_t)win[e]);
+        const uint32_t last = (uint32_t)(bits >> (2 * (W - 1))) & 3u;
+        const uint32_t rel = k - k0;
+        uint64_t b = bits;
+        if (rel < in_lds) {                                                  // ds_add_u32
+            int32_t *ct = hist + rel * tbl + last;
+            if (W == 1) atomicAdd(ct, 1);
+            else for (int i = 0; i < W - 1; i++, b >>= 2) atomicAdd(ct + i * 16 + 4 * (int)(b & 3u), 1);
+        } else {
+            int32_t *ct = cnt + (size_t)k * tbl + last;
+            if (W == 1) atomicAdd(ct, 1);
+            else for (int i = 0; i < W - 1; i++, b >>= 2) atomicAdd(ct + i * 16 + 4 * (int)(b & 3u), 1);
+        }
+    }
+    __syncthreads();
+    const size_t out0 = (size_t)k0 * tbl, out_end = (size_t)n_tables * tbl;
+    for (uint32_t i = threadIdx.x; i < used && out0 + i < out_end; i += 256) {
+        const int32_t v = hist[i];
+        if (v) atomicAdd(cnt + out0 + i, v);
+    }
+}
+
+size_t sort_min_bases(void)
+{
+    const char *e = getenv("GMG_TRAIN_SORT_MIN");      // read per call: tests switch paths inside one process
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 22;
 }
 
 int level_first(int level)   // (4^level - 1) / 3
@@ -133,13 +206,17 @@ extern "C" int gmg_trainer_create(const gmg_reads *strings, int model_len, int m
     t->d_node = nullptr;
     t->d_mip_prev = nullptr;
     t->d_cnt = nullptr;
+    t->d_key = t->d_key_sorted = t->d_win = t->d_win_sorted = nullptr;
+    t->d_sort_tmp = nullptr;
+    t->sort_tmp_bytes = 0;
     const int npos = model_len > 1 ? model_len - 1 : 1;
     const size_t on_last = (size_t)(level_first(model_depth + 1) - level_first(model_depth));
     t->cnt_cap = (size_t)periodicity * on_last * npos * 16;
     const size_t prev_cap = (size_t)periodicity * (model_depth > 0 ? on_last / 4 : 1);
-    hipError_t e = hipMalloc((void **)&t->d_node, (strings->total_bases + 1) * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&t->d_mip_prev, prev_cap);
-    if (e == hipSuccess) e = hipMalloc((void **)&t->d_cnt, t->cnt_cap * sizeof(int32_t));
+    // from the library's cache of device blocks: a training run per genome asks for the same sizes again and again
+    hipError_t e = gmg_pool_alloc((void **)&t->d_node, (strings->total_bases + 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = gmg_pool_alloc((void **)&t->d_mip_prev, prev_cap);
+    if (e == hipSuccess) e = gmg_pool_alloc((void **)&t->d_cnt, t->cnt_cap * sizeof(int32_t));
     if (e != hipSuccess) {
         gmg_trainer_free(t);
         return gmg_set_error(GMG_ENOMEM, "gmg_trainer_create: device allocation failed: %s", hipGetErrorString(e));
@@ -151,9 +228,15 @@ extern "C" int gmg_trainer_create(const gmg_reads *strings, int model_len, int m
 extern "C" int gmg_trainer_free(gmg_trainer *t)
 {
     if (!t) return GMG_OK;
-    if (t->d_node) (void)hipFree(t->d_node);
-    if (t->d_mip_prev) (void)hipFree(t->d_mip_prev);
-    if (t->d_cnt) (void)hipFree(t->d_cnt);
+    (void)hipDeviceSynchronize();
+    if (t->d_node) gmg_pool_release(t->d_node);
+    if (t->d_mip_prev) gmg_pool_release(t->d_mip_prev);
+    if (t->d_cnt) gmg_pool_release(t->d_cnt);
+    gmg_pool_release(t->d_key);
+    gmg_pool_release(t->d_key_sorted);
+    gmg_pool_release(t->d_win);
+    gmg_pool_release(t->d_win_sorted);
+    gmg_pool_release(t->d_sort_tmp);
     delete t;
     return GMG_OK;
 }
@@ -185,6 +268,7 @@ extern "C" int gmg_trainer_level_counts(gmg_trainer *t, int level, const int16_t
     a.cnt = t->d_cnt;
     const size_t cnt_len = (size_t)t->P * a.on_level * a.npos * 16;
     a.cnt_len = (uint32_t)cnt_len;
+    a.key = a.win = nullptr;
 
     if (level > 0) {
         // the level above, narrowed to bytes; a context position outside the window would read another string
@@ -201,12 +285,48 @@ extern "C" int gmg_trainer_level_counts(gmg_trainer *t, int level, const int16_t
     GMG_HIP(hipMemsetAsync(t->d_cnt, 0, cnt_len * sizeof(int32_t), 0));
     if (a.n_tiles > 0) {
         const bool lds = cnt_len * sizeof(int32_t) <= 64 * 1024;
+        const bool sorted = !lds && a.total_bases >= sort_min_bases() && a.total_bases < 0x7fffffffull;
         if (lds) {
             const unsigned grid = (unsigned)(a.n_tiles < 512 ? a.n_tiles : 512);
-            hipLaunchKernelGGL(k_train_level<true>, dim3(grid), dim3(256), cnt_len * sizeof(int32_t), 0, a);
-        } else {
+            hipLaunchKernelGGL((k_train_level<true, false>), dim3(grid), dim3(256), cnt_len * sizeof(int32_t), 0, a);
+        } else if (!sorted) {
             const unsigned grid = (unsigned)(a.n_tiles < 8192 ? a.n_tiles : 8192);
-            hipLaunchKernelGGL(k_train_level<false>, dim3(grid), dim3(256), 0, 0, a);
+            hipLaunchKernelGGL((k_train_level<false, false>), dim3(grid), dim3(256), 0, 0, a);
+        } else {
+            const uint64_t n = a.total_bases;
+            const uint32_t n_tables = (uint32_t)(t->P * a.on_level);
+            int end_bit = 1;
+            while (end_bit < 32 && (1ull << end_bit) <= n_tables) end_bit++;     // the keys go up to n_tables (= no table)
+            if (!t->d_key) {
+                hipError_t e = gmg_pool_alloc((void **)&t->d_key, n * sizeof(uint32_t));
+                if (e == hipSuccess) e = gmg_pool_alloc((void **)&t->d_key_sorted, n * sizeof(uint32_t));
+                if (e == hipSuccess) e = gmg_pool_alloc((void **)&t->d_win, n * sizeof(uint32_t));
+                if (e == hipSuccess) e = gmg_pool_alloc((void **)&t->d_win_sorted, n * sizeof(uint32_t));
+                if (e != hipSuccess)
+                    return gmg_set_error(GMG_ENOMEM, "gmg_trainer_level_counts: device allocation failed: %s", hipGetErrorString(e));
+            }
+            size_t need = 0;
+            GMG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, t->d_key, t->d_key_sorted, t->d_win, t->d_win_sorted,
+                                                       (int)n, 0, end_bit, (hipStream_t)0));
+            if (need > t->sort_tmp_bytes) {
+                gmg_pool_release(t->d_sort_tmp);
+                t->d_sort_tmp = nullptr;
+                t->sort_tmp_bytes = 0;
+                if (gmg_pool_alloc(&t->d_sort_tmp, need) != hipSuccess)
+                    return gmg_set_error(GMG_ENOMEM, "gmg_trainer_level_counts: device allocation failed (sort scratch)");
+                t->sort_tmp_bytes = need;
+            }
+            a.key = t->d_key;
+            a.win = t->d_win;
+            const unsigned grid = (unsigned)(a.n_tiles < 8192 ? a.n_tiles : 8192);
+            hipLaunchKernelGGL((k_train_level<false, true>), dim3(grid), dim3(256), 0, 0, a);
+            GMG_HIP(hipGetLastError());
+            need = t->sort_tmp_bytes;
+            GMG_HIP(hipcub::DeviceRadixSort::SortPairs(t->d_sort_tmp, need, t->d_key, t->d_key_sorted, t->d_win, t->d_win_sorted,
+                                                       (int)n, 0, end_bit, (hipStream_t)0));
+            const unsigned cgrid = (unsigned)((n + SORT_CHUNK - 1) / SORT_CHUNK);
+            hipLaunchKernelGGL(k_train_count_sorted, dim3(cgrid), dim3(256), 0, 0, t->d_key_sorted, t->d_win_sorted, n,
+                               a.packed, a.W, a.npos, n_tables, t->d_cnt);
         }
         GMG_HIP(hipGetLastError());
     }

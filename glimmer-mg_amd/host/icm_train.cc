@@ -16,6 +16,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <chrono>
 #include <thread>
 
 using namespace std;
@@ -152,11 +154,13 @@ int  First_Node_Of_Level  (int level)
 
 //  body(i) for i in [0, n) on a few host threads; the nodes of one level do not depend on each other
 template <class F>
-void  For_Each_Node  (int n, F body)
+void  For_Each_Node  (int n, F body, int serial_below = 2048)
   {
    unsigned  hw = thread :: hardware_concurrency ();
    int  workers = int (hw == 0 ? 1 : (hw > 16 ? 16 : hw));
-   if  (n < 2048 || workers == 1)
+   if  (workers > n)
+       workers = n;
+   if  (n < serial_below || workers <= 1)
        {
         for  (int i = 0;  i < n;  i ++)
           body (i);
@@ -215,6 +219,19 @@ bool  ICM_Training_t :: Try_Train_Model
 
    Invalidate_Device_Mirror ();
 
+   //  GMG_TRAIN_TIMING=1: wall time of every stage on stderr
+   const bool  timing = (getenv ("GMG_TRAIN_TIMING") != NULL);
+   chrono :: steady_clock :: time_point  t_prev = chrono :: steady_clock :: now ();
+   auto  lap = [&] (const char * what, int level)
+     {
+      if  (! timing)
+          return;
+      chrono :: steady_clock :: time_point  t = chrono :: steady_clock :: now ();
+      fprintf (stderr, "[gmg_train] %-10s level %2d %9.3f ms\n", what, level,
+               chrono :: duration <double, milli> (t - t_prev) . count ());
+      t_prev = t;
+     };
+
    //  the training strings as one packed batch in HBM; characters become codes exactly as Subscript maps them
    vector <uint64_t>  off (string_ct + 1, 0);
    for  (int i = 0;  i < string_ct;  i ++)
@@ -228,12 +245,27 @@ bool  ICM_Training_t :: Try_Train_Model
     if  (gmg_init (env ? atoi (env) : 0) != GMG_OK)
         goto  Fail;
    }
-   for  (int i = 0;  i < string_ct;  i ++)
-     if  (gmg_pack_bases (data [i], off [i + 1] - off [i], off [i], packed . data ()) != GMG_OK)
-         goto  Fail;
+   {
+    //  pieces of 2^20 bases (a multiple of the 16 bases of a packed word, so no two threads share a word)
+    const uint64_t  piece = 1 << 20, total = off [string_ct];
+    const uint64_t  * offp = off . data ();
+    uint32_t  * words = packed . data ();
+    For_Each_Node (int ((total + piece - 1) / piece), [=] (int c)
+      {
+       const uint64_t  lo = piece * c, hi = (lo + piece < total ? lo + piece : total);
+       int  s = int (upper_bound (offp, offp + string_ct + 1, lo) - offp) - 1;    // string holding base lo
+       for  ( ;  s < string_ct && offp [s] < hi;  s ++)
+         {
+          const uint64_t  b = (offp [s] > lo ? offp [s] : lo), e = (offp [s + 1] < hi ? offp [s + 1] : hi);
+          if  (e > b)
+              gmg_pack_bases (data [s] + (b - offp [s]), e - b, b, words);
+         }
+      }, 2);
+   }
    if  (gmg_reads_upload (packed . data (), off . data (), string_ct, & strings) != GMG_OK
           || gmg_trainer_create (strings, model_len, model_depth, periodicity, & trainer) != GMG_OK)
        goto  Fail;
+   lap ("upload", -1);
 
    for  (int level = 0;  level <= model_depth;  level ++)
      {
@@ -253,6 +285,7 @@ bool  ICM_Training_t :: Try_Train_Model
       if  (gmg_trainer_level_counts (trainer, level, level > 0 ? mip_prev . data () : NULL, counts . data ())
              != GMG_OK)
           goto  Fail;
+      lap ("counts", level);
 
       const int32_t  * all = counts . data ();
       ICM_Score_Node_t  * * sc = score;
@@ -305,6 +338,7 @@ bool  ICM_Training_t :: Try_Train_Model
          node . mut_info = float (c . used_info);
          Blend_With_Parent (node . prob, sc [frame] [PARENT (sub)] . prob, c . final_char_ct);
         });
+      lap ("nodes", level);
      }
 
    //  Take_Logs (src/ICM/icm.cc:1334-1352).  The argument is a float, so the reference's  log  is the float
@@ -317,6 +351,7 @@ bool  ICM_Training_t :: Try_Train_Model
           p = (p > 0.0 ? logf (p) : - FLT_MAX);
          }
    ok = true;
+   lap ("logs", -1);
 
   Fail:
    if  (! ok)

@@ -43,7 +43,7 @@ def check_levels(gpu, oracle, strings, W, D, P):
 
 
 @pytest.mark.parametrize("case", [c for c in SHIPPED if not c["text"]], ids=lambda c: c["name"])
-def test_counts_of_every_level_equal_the_oracle(case, gpu, oracle):
+def test_counts_of_every_level_equal_the_oracle(case, gpu, oracle, deep_level_path):
     check_levels(gpu, oracle, training_strings(case, gpu), case["model_len"], case["model_depth"], case["periodicity"])
 
 
@@ -76,6 +76,19 @@ def test_reference_build_icm_cli_on_our_icm_hh(case, tmp_path):
     assert hashlib.sha256(data).hexdigest() == case["sha256"]
 
 
+@pytest.fixture(params=["atomics", "sorted"])
+def deep_level_path(request):
+    """both ways of counting the levels that do not fit LDS: direct device-wide atomics (small training sets) and the
+    sort by table + LDS counting (big ones); GMG_TRAIN_SORT_MIN is the size, in bases, where the library switches"""
+    old = os.environ.get("GMG_TRAIN_SORT_MIN")
+    os.environ["GMG_TRAIN_SORT_MIN"] = "0" if request.param == "sorted" else str(2 ** 40)
+    yield request.param
+    if old is None:
+        del os.environ["GMG_TRAIN_SORT_MIN"]
+    else:
+        os.environ["GMG_TRAIN_SORT_MIN"] = old
+
+
 def random_strings(rng, n, max_len, extra=()):
     lens = [int(x) for x in rng.integers(0, max_len, size=n)] + list(extra)
     return [bytes(rng.choice(np.frombuffer(b"acgt", np.uint8), size=k).tobytes()) for k in lens]
@@ -83,7 +96,7 @@ def random_strings(rng, n, max_len, extra=()):
 
 @pytest.mark.parametrize("shape", [(12, 7, 3), (12, 4, 1), (5, 3, 2), (2, 1, 3), (20, 5, 3), (32, 3, 5), (3, 2, 7)],
                          ids=lambda s: "w%d_d%d_p%d" % s)
-def test_ragged_random_strings_every_shape(shape, gpu, oracle):
+def test_ragged_random_strings_every_shape(shape, gpu, oracle, deep_level_path):
     W, D, P = shape
     rng = np.random.default_rng(100 + W)
     strings = random_strings(rng, 300, 2500, extra=(0, 0, 1, W - 1, W, W + 1, 1023, 1024, 1025, 4096))
@@ -92,7 +105,7 @@ def test_ragged_random_strings_every_shape(shape, gpu, oracle):
     check_levels(gpu, oracle, strings, W, D, P)
 
 
-def test_skewed_strings_stop_the_tree_early(gpu, oracle):
+def test_skewed_strings_stop_the_tree_early(gpu, oracle, deep_level_path):
     """few, very regular strings: most nodes see no windows, the tree stops (mut_info_pos -1 / -2) and the deeper
     levels must count nothing below a stop"""
     strings = [b"acg" * 400, b"a" * 900, b"acgtt" * 300, b"gattaca" * 50]
@@ -148,7 +161,7 @@ def test_no_strings_and_argument_errors(gpu, oracle):
         gpu.Trainer(reads, 12, 2, 0)
 
 
-def test_full_size_training_set_properties(gpu, oracle):
+def test_full_size_training_set_properties(gpu, oracle, deep_level_path):
     """a Phymm-scale genome's worth of genes (4,000 strings, ~4 Mbases): counts are deterministic, every level keeps
     the window bookkeeping (see test_oracle_train.test_level_counts_bookkeeping), the model equals the oracle's"""
     rng = np.random.default_rng(5)
