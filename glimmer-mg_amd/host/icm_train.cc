@@ -18,6 +18,7 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <thread>
 
 using namespace std;
@@ -178,6 +179,60 @@ void  For_Each_Node  (int n, F body, int serial_below = 2048)
      pool [w] . join ();
   }
 
+//  One page-locked host buffer for the count tables, kept for the life of the process: a program that trains many
+//  models (one per genome, src/../scripts/train_all.py style, through gmg_icm_train) pays the page-locking once.
+//  A second training running at the same time gets an ordinary buffer of its own.
+struct  Table_Buffer_t
+  {
+   int32_t  * p;
+   size_t  ints;
+   bool  cached;
+
+   static mutex  & Lock  (void)  { static mutex  m;  return  m; }
+   static int32_t  * & Cached_P  (void)  { static int32_t  * p = NULL;  return  p; }
+   static size_t  & Cached_Ints  (void)  { static size_t  n = 0;  return  n; }
+   static bool  & Cached_Busy  (void)  { static bool  b = false;  return  b; }
+
+   explicit  Table_Buffer_t  (size_t n)  :  p (NULL), ints (n), cached (false)
+     {
+      {
+       lock_guard <mutex>  g (Lock ());
+       if  (! Cached_Busy ())
+           {
+            if  (Cached_Ints () < n)
+                {
+                 if  (Cached_P () != NULL)
+                     {
+                      gmg_host_unregister (Cached_P ());
+                      free (Cached_P ());
+                     }
+                 Cached_P () = (int32_t *) calloc (n, sizeof (int32_t));
+                 Cached_Ints () = (Cached_P () != NULL ? n : 0);
+                 if  (Cached_P () != NULL)
+                     gmg_host_register (Cached_P (), n * sizeof (int32_t));   // a refusal only costs speed
+                }
+            if  (Cached_P () != NULL)
+                {
+                 Cached_Busy () = cached = true;
+                 p = Cached_P ();
+                }
+           }
+      }
+      if  (p == NULL)
+          p = (int32_t *) calloc (n ? n : 1, sizeof (int32_t));
+     }
+   ~ Table_Buffer_t  ()
+     {
+      if  (cached)
+          {
+           lock_guard <mutex>  g (Lock ());
+           Cached_Busy () = false;
+          }
+        else
+          free (p);
+     }
+  };
+
 }  // namespace
 
 
@@ -232,19 +287,24 @@ bool  ICM_Training_t :: Try_Train_Model
       t_prev = t;
      };
 
+   {
+    const char  * env = getenv ("GMG_DEVICE");
+    if  (gmg_init (env ? atoi (env) : 0) != GMG_OK)
+        {
+         err = string ("ICM_Training_t::Train_Model: ") + gmg_last_error ();
+         return  false;
+        }
+   }
+
    //  the training strings as one packed batch in HBM; characters become codes exactly as Subscript maps them
    vector <uint64_t>  off (string_ct + 1, 0);
    for  (int i = 0;  i < string_ct;  i ++)
      off [i + 1] = off [i] + strlen (data [i]);
    vector <uint32_t>  packed (gmg_packed_words (off [string_ct]), 0);
-   vector <int32_t>  counts;
+   Table_Buffer_t  counts (size_t (periodicity) * (First_Node_Of_Level (model_depth + 1) - First_Node_Of_Level (model_depth))
+                             * npos * ALPHA_SQUARED);
    vector <int16_t>  mip_prev;
 
-   {
-    const char  * env = getenv ("GMG_DEVICE");
-    if  (gmg_init (env ? atoi (env) : 0) != GMG_OK)
-        goto  Fail;
-   }
    {
     //  pieces of 2^20 bases (a multiple of the 16 bases of a packed word, so no two threads share a word)
     const uint64_t  piece = 1 << 20, total = off [string_ct];
@@ -267,6 +327,10 @@ bool  ICM_Training_t :: Try_Train_Model
        goto  Fail;
    lap ("upload", -1);
 
+   //  the tables of a level land in a page-locked buffer: the last level's copy back (35 MB for the default shape)
+   //  otherwise runs at pageable-memory speed and costs more than its counting
+   lap ("pin", -1);
+
    for  (int level = 0;  level <= model_depth;  level ++)
      {
       const int  first = First_Node_Of_Level (level);
@@ -281,13 +345,12 @@ bool  ICM_Training_t :: Try_Train_Model
              for  (int k = 0;  k < pon;  k ++)
                mip_prev [size_t (f) * pon + k] = score [f] [pfirst + k] . mut_info_pos;
           }
-      counts . resize (size_t (periodicity) * on_level * npos * ALPHA_SQUARED);
-      if  (gmg_trainer_level_counts (trainer, level, level > 0 ? mip_prev . data () : NULL, counts . data ())
+      if  (gmg_trainer_level_counts (trainer, level, level > 0 ? mip_prev . data () : NULL, counts . p)
              != GMG_OK)
           goto  Fail;
       lap ("counts", level);
 
-      const int32_t  * all = counts . data ();
+      const int32_t  * all = counts . p;
       ICM_Score_Node_t  * * sc = score;
       const int  W = model_len, D = model_depth;
 
