@@ -18,10 +18,11 @@
 //     windows of the level by table first (hipcub radix sort of (table, window) pairs, <= 17 key bits); a workgroup
 //     then takes 4,096 consecutive windows, which touch a handful of tables, counts them in LDS and adds each
 //     table's 176 counters to HBM once;
-//   * small training sets (below GMG_TRAIN_SORT_MIN bases, default 2^22) keep the direct atomics: the sort's launches
-//     would cost more than they save.
+//   * tiny training sets (below GMG_TRAIN_SORT_MIN bases, default 2^16) keep the direct atomics: five more launches
+//     per level would cost more than they save.  (One genome's genes, 1.6 M windows: 0.77 ms per deep level with
+//     direct atomics, 0.14 - 0.26 ms sorted.)
 //
-//   k_train_level<LDS, KEYS>   the descent step + counts of one level (LDS / global atomics) or + the sort keys
+//   k_train_level<LDS, KEYS, NT>   the descent step + counts of one level (LDS / global atomics) or + the sort keys
 //   k_train_count_sorted       counts from the sorted (table, window) pairs
 //
 // Integer work only: counts are exact, so the tables equal the reference's for any order of the atomics.
@@ -66,12 +67,12 @@ struct TrainArgs {
     uint32_t *key, *win;        // KEYS: table of window g (P * on_level = none) and g itself
 };
 
-template <bool LDS, bool KEYS>
-__global__ __launch_bounds__(256) void k_train_level(TrainArgs a)
+template <bool LDS, bool KEYS, int NT>
+__global__ __launch_bounds__(NT) void k_train_level(TrainArgs a)
 {
     extern __shared__ int32_t hist[];
     if (LDS) {
-        for (uint32_t i = threadIdx.x; i < a.cnt_len; i += 256) hist[i] = 0;
+        for (uint32_t i = threadIdx.x; i < a.cnt_len; i += NT) hist[i] = 0;
         __syncthreads();
     }
     int32_t *const dst = LDS ? hist : a.cnt;
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(256) void k_train_level(TrainArgs a)
     for (uint64_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
         const uint32_t r_lo = a.tile_read[t], r_hi = a.tile_read[t + 1];
 #pragma unroll
-        for (int k = 0; k < GMG_TILE / 256; k++) {
-            const uint64_t g = t * GMG_TILE + (uint64_t)k * 256 + threadIdx.x;
+        for (int k = 0; k < GMG_TILE / NT; k++) {
+            const uint64_t g = t * GMG_TILE + (uint64_t)k * NT + threadIdx.x;
             if (g >= a.total_bases) break;
             // string holding base g: the largest r in [r_lo, r_hi] with off[r] <= g (empty strings share offsets)
             uint32_t lo = r_lo, hi = r_hi;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void k_train_level(TrainArgs a)
 
     if (LDS) {
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < a.cnt_len; i += 256) {
+        for (uint32_t i = threadIdx.x; i < a.cnt_len; i += NT) {
             const int32_t v = hist[i];
             if (v) atomicAdd(a.cnt + i, v);
         }
@@ -132,10 +133,11 @@ __global__ __launch_bounds__(256) void k_train_level(TrainArgs a)
 // k0 .. k0 + SORT_TABLES - 1 (k0 = the chunk's first) are counted in LDS, anything beyond goes to HBM directly
 // (only where tables hold a handful of windows each).
 #define SORT_CHUNK 4096
+#define SORT_NT 1024
 #define SORT_LDS_INTS (12 * 1024)            // 48 KB
-__global__ __launch_bounds__(256) void k_train_count_sorted(const uint32_t *__restrict__ key, const uint32_t *__restrict__ win,
-                                                            uint64_t n, const uint32_t *__restrict__ packed, int W, int npos,
-                                                            uint32_t n_tables, int32_t *__restrict__ cnt)
+__global__ __launch_bounds__(SORT_NT) void k_train_count_sorted(const uint32_t *__restrict__ key, const uint32_t *__restrict__ win,
+                                                                uint64_t n, const uint32_t *__restrict__ packed, int W, int npos,
+                                                                uint32_t n_tables, int32_t *__restrict__ cnt)
 {
     __shared__ int32_t hist[SORT_LDS_INTS];
     const uint64_t base = (uint64_t)blockIdx.x * SORT_CHUNK;
@@ -144,31 +146,38 @@ __global__ __launch_bounds__(256) void k_train_count_sorted(const uint32_t *__re
     const uint32_t tbl = (uint32_t)npos * 16;
     const uint32_t in_lds = SORT_LDS_INTS / tbl;                             // tables held in LDS
     const uint32_t used = in_lds * tbl;
-    for (uint32_t i = threadIdx.x; i < used; i += 256) hist[i] = 0;
+    constexpr int PER = SORT_CHUNK / SORT_NT;
+    // all of a lane's pairs and their windows' codes are fetched before the first increment
+    uint32_t k[PER];
+    uint64_t bits[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const uint64_t e = base + (uint64_t)j * SORT_NT + threadIdx.x;
+        k[j] = e < n ? key[e] : n_tables;
+        const uint32_t w = e < n ? win[e] : 0u;
+        bits[j] = dev_window_bits(packed, (int64_t)w);
+    }
+    for (uint32_t i = threadIdx.x; i < used; i += SORT_NT) hist[i] = 0;
     __syncthreads();
-#pragma unroll 4
-    for (int j = 0; j < SORT_CHUNK / 256; j++) {
-        const uint64_t e = base + (uint64_t)j * 256 + threadIdx.x;
-        if (e >= n) break;
-        const uint32_t k = key[e];
-        if (k >= n_tables) continue;
-        const uint64_t bits = dev_window_bits(packed, (int64_t)win[e]);
-        const uint32_t last = (uint32_t)(bits >> (2 * (W - 1))) & 3u;
-        const uint32_t rel = k - k0;
-        uint64_t b = bits;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        if (k[j] >= n_tables) continue;
+        const uint32_t last = (uint32_t)(bits[j] >> (2 * (W - 1))) & 3u;
+        const uint32_t rel = k[j] - k0;
+        uint64_t b = bits[j];
         if (rel < in_lds) {                                                  // ds_add_u32
             int32_t *ct = hist + rel * tbl + last;
             if (W == 1) atomicAdd(ct, 1);
             else for (int i = 0; i < W - 1; i++, b >>= 2) atomicAdd(ct + i * 16 + 4 * (int)(b & 3u), 1);
         } else {
-            int32_t *ct = cnt + (size_t)k * tbl + last;
+            int32_t *ct = cnt + (size_t)k[j] * tbl + last;
             if (W == 1) atomicAdd(ct, 1);
             else for (int i = 0; i < W - 1; i++, b >>= 2) atomicAdd(ct + i * 16 + 4 * (int)(b & 3u), 1);
         }
     }
     __syncthreads();
     const size_t out0 = (size_t)k0 * tbl, out_end = (size_t)n_tables * tbl;
-    for (uint32_t i = threadIdx.x; i < used && out0 + i < out_end; i += 256) {
+    for (uint32_t i = threadIdx.x; i < used && out0 + i < out_end; i += SORT_NT) {
         const int32_t v = hist[i];
         if (v) atomicAdd(cnt + out0 + i, v);
     }
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(256) void k_train_count_sorted(const uint32_t *__re
 size_t sort_min_bases(void)
 {
     const char *e = getenv("GMG_TRAIN_SORT_MIN");      // read per call: tests switch paths inside one process
-    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 22;
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 16;
 }
 
 int level_first(int level)   // (4^level - 1) / 3
@@ -287,11 +296,12 @@ extern "C" int gmg_trainer_level_counts(gmg_trainer *t, int level, const int16_t
         const bool lds = cnt_len * sizeof(int32_t) <= 64 * 1024;
         const bool sorted = !lds && a.total_bases >= sort_min_bases() && a.total_bases < 0x7fffffffull;
         if (lds) {
+            // 1,024 lanes per workgroup: one table copy serves 16 waves (a 34 KB table x 256 lanes left 8 waves per CU)
             const unsigned grid = (unsigned)(a.n_tiles < 512 ? a.n_tiles : 512);
-            hipLaunchKernelGGL((k_train_level<true, false>), dim3(grid), dim3(256), cnt_len * sizeof(int32_t), 0, a);
+            hipLaunchKernelGGL((k_train_level<true, false, 1024>), dim3(grid), dim3(1024), cnt_len * sizeof(int32_t), 0, a);
         } else if (!sorted) {
             const unsigned grid = (unsigned)(a.n_tiles < 8192 ? a.n_tiles : 8192);
-            hipLaunchKernelGGL((k_train_level<false, false>), dim3(grid), dim3(256), 0, 0, a);
+            hipLaunchKernelGGL((k_train_level<false, false, 256>), dim3(grid), dim3(256), 0, 0, a);
         } else {
             const uint64_t n = a.total_bases;
             const uint32_t n_tables = (uint32_t)(t->P * a.on_level);
@@ -319,13 +329,13 @@ extern "C" int gmg_trainer_level_counts(gmg_trainer *t, int level, const int16_t
             a.key = t->d_key;
             a.win = t->d_win;
             const unsigned grid = (unsigned)(a.n_tiles < 8192 ? a.n_tiles : 8192);
-            hipLaunchKernelGGL((k_train_level<false, true>), dim3(grid), dim3(256), 0, 0, a);
+            hipLaunchKernelGGL((k_train_level<false, true, 256>), dim3(grid), dim3(256), 0, 0, a);
             GMG_HIP(hipGetLastError());
             need = t->sort_tmp_bytes;
             GMG_HIP(hipcub::DeviceRadixSort::SortPairs(t->d_sort_tmp, need, t->d_key, t->d_key_sorted, t->d_win, t->d_win_sorted,
                                                        (int)n, 0, end_bit, (hipStream_t)0));
             const unsigned cgrid = (unsigned)((n + SORT_CHUNK - 1) / SORT_CHUNK);
-            hipLaunchKernelGGL(k_train_count_sorted, dim3(cgrid), dim3(256), 0, 0, t->d_key_sorted, t->d_win_sorted, n,
+            hipLaunchKernelGGL(k_train_count_sorted, dim3(cgrid), dim3(SORT_NT), 0, 0, t->d_key_sorted, t->d_win_sorted, n,
                                a.packed, a.W, a.npos, n_tables, t->d_cnt);
         }
         GMG_HIP(hipGetLastError());

@@ -155,7 +155,7 @@ int  First_Node_Of_Level  (int level)
 
 //  body(i) for i in [0, n) on a few host threads; the nodes of one level do not depend on each other
 template <class F>
-void  For_Each_Node  (int n, F body, int serial_below = 2048)
+void  For_Each_Node  (int n, F body, int serial_below = 256)
   {
    unsigned  hw = thread :: hardware_concurrency ();
    int  workers = int (hw == 0 ? 1 : (hw > 16 ? 16 : hw));
@@ -406,13 +406,20 @@ bool  ICM_Training_t :: Try_Train_Model
 
    //  Take_Logs (src/ICM/icm.cc:1334-1352).  The argument is a float, so the reference's  log  is the float
    //  overload.
-   for  (int f = 0;  f < periodicity;  f ++)
-     for  (int i = 0;  i < num_nodes;  i ++)
-       for  (int j = 0;  j < ALPHABET_SIZE;  j ++)
-         {
-          float  & p = score [f] [i] . prob [j];
-          p = (p > 0.0 ? logf (p) : - FLT_MAX);
-         }
+   {
+    ICM_Score_Node_t  * * sc = score;
+    const int  N = num_nodes, slice = 4096, per_frame = (N + slice - 1) / slice;
+    For_Each_Node (periodicity * per_frame, [=] (int idx)
+      {
+       const int  f = idx / per_frame, lo = (idx % per_frame) * slice, hi = (lo + slice < N ? lo + slice : N);
+       for  (int i = lo;  i < hi;  i ++)
+         for  (int j = 0;  j < ALPHABET_SIZE;  j ++)
+           {
+            float  & p = sc [f] [i] . prob [j];
+            p = (p > 0.0 ? logf (p) : - FLT_MAX);
+           }
+      }, 4);
+   }
    ok = true;
    lap ("logs", -1);
 
