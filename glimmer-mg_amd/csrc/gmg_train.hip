@@ -64,7 +64,7 @@ struct TrainArgs {
     int32_t *node;
     int32_t *cnt;
     uint32_t cnt_len;           // P * on_level * npos * 16
-    uint32_t *key, *win;        // KEYS: table of window g (P * on_level = none) and g itself
+    uint32_t *key, *win;        // KEYS: table of window g (P * on_level = none) and its codes (W <= 16) or g itself
 };
 
 template <bool LDS, bool KEYS, int NT>
@@ -107,7 +107,9 @@ __global__ __launch_bounds__(NT) void k_train_level(TrainArgs a)
             a.node[g] = node;
             if (KEYS) {                                                      // counted after the sort
                 a.key[g] = node < 0 ? (uint32_t)(a.P * a.on_level) : (uint32_t)(frame * a.on_level + (node - a.first));
-                a.win[g] = (uint32_t)g;
+                // the pair's value: the window's codes themselves when they fit 32 bits (W <= 16) -- the count kernel then
+                // has nothing to gather (63 M random 12-byte reads per level were its bound) -- else the window's position
+                a.win[g] = a.W <= 16 ? (node < 0 ? 0u : (uint32_t)dev_window_bits(a.packed, (int64_t)g)) : (uint32_t)g;
                 continue;
             }
             if (node < 0) continue;
@@ -144,7 +146,13 @@ __global__ __launch_bounds__(SORT_NT) void k_train_count_sorted(const uint32_t *
     const uint32_t k0 = key[base];
     if (k0 >= n_tables) return;                                              // only windows that count nothing from here on
     const uint32_t tbl = (uint32_t)npos * 16;
-    const uint32_t in_lds = SORT_LDS_INTS / tbl;                             // tables held in LDS
+    // tables held in LDS: as many as fit, but no more than the chunk spans (the pairs are sorted: its last pair names
+    // the last table) -- with 10^3 windows per table that is a handful, and zeroing / flushing 48 KB per 4,096 windows
+    // would cost as much as the counting
+    const uint64_t last_e = (base + SORT_CHUNK < n ? base + SORT_CHUNK : n) - 1;
+    const uint32_t k_last = key[last_e] < n_tables ? key[last_e] : n_tables - 1;
+    const uint32_t fit = SORT_LDS_INTS / tbl, span = k_last - k0 + 1;
+    const uint32_t in_lds = span < fit ? span : fit;
     const uint32_t used = in_lds * tbl;
     constexpr int PER = SORT_CHUNK / SORT_NT;
     // all of a lane's pairs and their windows' codes are fetched before the first increment
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(SORT_NT) void k_train_count_sorted(const uint32_t *
         const uint64_t e = base + (uint64_t)j * SORT_NT + threadIdx.x;
         k[j] = e < n ? key[e] : n_tables;
         const uint32_t w = e < n ? win[e] : 0u;
-        bits[j] = dev_window_bits(packed, (int64_t)w);
+        bits[j] = W <= 16 ? (uint64_t)w : dev_window_bits(packed, (int64_t)w);
     }
     for (uint32_t i = threadIdx.x; i < used; i += SORT_NT) hist[i] = 0;
     __syncthreads();
