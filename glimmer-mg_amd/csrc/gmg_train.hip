@@ -176,7 +176,10 @@ __global__ __launch_bounds__(SORT_NT) void k_train_count_sorted(const uint32_t *
         if (rel < in_lds) {                                                  // ds_add_u32
             int32_t *ct = hist + rel * tbl + last;
             if (W == 1) atomicAdd(ct, 1);
-            else for (int i = 0; i < W - 1; i++, b >>= 2) atomicAdd(ct + i * 16 + 4 * (int)(b & 3u), 1);
+            else   // neighbouring lanes share the table: each starts at its own context position, so that one ds_add
+                   // instruction spreads over the W - 1 sixteen-counter blocks of the table instead of one
+                for (int s = 0, i = (int)(threadIdx.x % (unsigned)(W - 1)); s < W - 1; s++, i = (i + 1 == W - 1 ? 0 : i + 1))
+                    atomicAdd(ct + i * 16 + 4 * (int)((b >> (2 * i)) & 3u), 1);
         } else {
             int32_t *ct = cnt + (size_t)k[j] * tbl + last;
             if (W == 1) atomicAdd(ct, 1);
