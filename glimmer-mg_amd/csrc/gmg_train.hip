@@ -216,6 +216,13 @@ extern "C" int gmg_trainer_create(const gmg_reads *strings, int model_len, int m
     if (model_len < 1 || model_len > GMG_MAX_MODEL_LEN || model_depth < 0 || model_depth > 12 || periodicity < 1)
         return gmg_set_error(GMG_EBADMODEL, "gmg_trainer_create: model_len %d (1..%d), model_depth %d (0..12), "
                              "periodicity %d (>= 1)", model_len, GMG_MAX_MODEL_LEN, model_depth, periodicity);
+    {   // the counters of the deepest level are indexed with 32 bits
+        const double counters = (double)periodicity * (double)(level_first(model_depth + 1) - level_first(model_depth)) *
+                                (model_len > 1 ? model_len - 1 : 1) * 16.0;
+        if (counters >= 2147483648.0)
+            return gmg_set_error(GMG_EBADMODEL, "gmg_trainer_create: %.0f counters on level %d (model_len %d, periodicity %d); "
+                                 "at most 2^31 - 1", counters, model_depth, model_len, periodicity);
+    }
     gmg_trainer *t = new (std::nothrow) gmg_trainer();
     if (!t) return gmg_set_error(GMG_ENOMEM, "gmg_trainer_create: out of host memory");
     t->strings = strings;

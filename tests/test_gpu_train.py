@@ -159,6 +159,8 @@ def test_no_strings_and_argument_errors(gpu, oracle):
         gpu.Trainer(reads, 33, 2, 3)
     with pytest.raises(gpu.GmgError):
         gpu.Trainer(reads, 12, 2, 0)
+    with pytest.raises(gpu.GmgError):            # more counters on the last level than 32 bits index
+        gpu.Trainer(reads, 32, 12, 3)
 
 
 def test_full_size_training_set_properties(gpu, oracle, deep_level_path):
