@@ -1203,6 +1203,8 @@ void orc_train_level_counts(const orc_model *m, const char *const *strings, int 
                 end = len - offset;
                 for (start = 0, stop = W - 1; stop < end; start += P, stop += P) {
                     int last = orc_subscript(str[stop]);
+                    if (W == 1)     /* no context: Count_Single_Chars (icm.cc:1874-1896), kept in table 0 at [last] */
+                        counts[(size_t)frame * 16 + last]++;
                     for (i = 0; i < W - 1; i++)
                         counts[((size_t)frame * (W - 1) + i) * 16 + ORC_ALPHA * orc_subscript(str[start + i]) + last]++;
                 }

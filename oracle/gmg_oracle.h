@@ -163,7 +163,8 @@ int orc_mg_score_orf_errors(const double *frame_scores, const char *seq, int n, 
  * (icm.cc:1373-1390, 1841-1870); level >= 1: Count_Char_Pairs_Restricted + Get_Training_Node (icm.cc:1190-1256) on
  * m->mip of the levels above.  strings are used as given (lower case; every character through orc_subscript).
  * counts[((f * 4^level + k) * (model_len - 1) + i) * 16 + 4 * code(w[i]) + code(w[model_len-1])], k = node - first
- * node of the level; the caller zeroes it. */
+ * node of the level; the caller zeroes it.  model_len = 1: counts[f * 16 + code] of the predicted base alone
+ * (Count_Single_Chars, icm.cc:1874-1896). */
 void orc_train_level_counts(const orc_model *m, const char *const *strings, int n_strings, int level,
                             int32_t *counts);
 /* Get_Mutual_Info (icm.cc:1900-1955) for one 4 x 4 table. */
