@@ -17,7 +17,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -153,31 +156,93 @@ int  First_Node_Of_Level  (int level)
   }
 
 
-//  body(i) for i in [0, n) on a few host threads; the nodes of one level do not depend on each other
-template <class F>
-void  For_Each_Node  (int n, F body, int serial_below = 256)
+//  A few host threads for the length of one training: the nodes of a level do not depend on each other, the pieces of
+//  the packed strings neither.  Run (n, body) calls body (i) for every i in [0, n), handing out  grain  of them at a
+//  time (the tables of a level are unevenly filled), the caller working along; small jobs run on the caller alone.
+class  Host_Workers_t
   {
-   unsigned  hw = thread :: hardware_concurrency ();
-   int  workers = int (hw == 0 ? 1 : (hw > 16 ? 16 : hw));
-   if  (workers > n)
-       workers = n;
-   if  (n < serial_below || workers <= 1)
-       {
-        for  (int i = 0;  i < n;  i ++)
-          body (i);
-        return;
-       }
-   vector <thread>  pool;
-   for  (int w = 0;  w < workers;  w ++)
-     pool . push_back (thread ([=] ()
-       {
-        int  lo = int ((long long) n * w / workers), hi = int ((long long) n * (w + 1) / workers);
-        for  (int i = lo;  i < hi;  i ++)
-          body (i);
-       }));
-   for  (size_t w = 0;  w < pool . size ();  w ++)
-     pool [w] . join ();
-  }
+  private:
+   vector <thread>  threads;
+   mutex  m;
+   condition_variable  wake, all_done;
+   const function <void (int)>  * job;
+   int  job_n, job_grain;
+   atomic <int>  next;
+   int  generation, busy;
+   bool  stop;
+
+   void  Drain  (void)
+     {
+      for  ( ; ; )
+        {
+         int  lo = next . fetch_add (job_grain);
+         if  (lo >= job_n)
+             break;
+         int  hi = (lo + job_grain < job_n ? lo + job_grain : job_n);
+         for  (int i = lo;  i < hi;  i ++)
+           (* job) (i);
+        }
+     }
+   void  Loop  (void)
+     {
+      int  seen = 0;
+      unique_lock <mutex>  lk (m);
+      for  ( ; ; )
+        {
+         wake . wait (lk, [&] { return  stop || generation != seen; });
+         if  (stop)
+             return;
+         seen = generation;
+         lk . unlock ();
+         Drain ();
+         lk . lock ();
+         if  (-- busy == 0)
+             all_done . notify_one ();
+        }
+     }
+
+  public:
+   Host_Workers_t  ()  :  job (NULL), job_n (0), job_grain (1), next (0), generation (0), busy (0), stop (false)
+     {
+      unsigned  hw = thread :: hardware_concurrency ();
+      int  workers = int (hw == 0 ? 1 : (hw > 16 ? 16 : hw));
+      for  (int w = 1;  w < workers;  w ++)
+        threads . push_back (thread (& Host_Workers_t :: Loop, this));
+     }
+   ~ Host_Workers_t  ()
+     {
+      {
+       lock_guard <mutex>  g (m);
+       stop = true;
+      }
+      wake . notify_all ();
+      for  (size_t w = 0;  w < threads . size ();  w ++)
+        threads [w] . join ();
+     }
+   void  Run  (int n, const function <void (int)> & body, int serial_below, int grain)
+     {
+      if  (n < serial_below || threads . empty ())
+          {
+           for  (int i = 0;  i < n;  i ++)
+             body (i);
+           return;
+          }
+      {
+       lock_guard <mutex>  g (m);
+       job = & body;
+       job_n = n;
+       job_grain = (grain > 0 ? grain : 1);
+       next = 0;
+       busy = int (threads . size ());
+       generation ++;
+      }
+      wake . notify_all ();
+      Drain ();
+      unique_lock <mutex>  lk (m);
+      all_done . wait (lk, [&] { return  busy == 0; });
+     }
+  };
+
 
 //  One page-locked host buffer for the count tables, kept for the life of the process: a program that trains many
 //  models (one per genome, src/../scripts/train_all.py style, through gmg_icm_train) pays the page-locking once.
@@ -304,13 +369,14 @@ bool  ICM_Training_t :: Try_Train_Model
    Table_Buffer_t  counts (size_t (periodicity) * (First_Node_Of_Level (model_depth + 1) - First_Node_Of_Level (model_depth))
                              * npos * ALPHA_SQUARED);
    vector <int16_t>  mip_prev;
+   Host_Workers_t  workers;
 
    {
     //  pieces of 2^20 bases (a multiple of the 16 bases of a packed word, so no two threads share a word)
     const uint64_t  piece = 1 << 20, total = off [string_ct];
     const uint64_t  * offp = off . data ();
     uint32_t  * words = packed . data ();
-    For_Each_Node (int ((total + piece - 1) / piece), [=] (int c)
+    workers . Run (int ((total + piece - 1) / piece), [=] (int c)
       {
        const uint64_t  lo = piece * c, hi = (lo + piece < total ? lo + piece : total);
        int  s = int (upper_bound (offp, offp + string_ct + 1, lo) - offp) - 1;    // string holding base lo
@@ -320,7 +386,7 @@ bool  ICM_Training_t :: Try_Train_Model
           if  (e > b)
               gmg_pack_bases (data [s] + (b - offp [s]), e - b, b, words);
          }
-      }, 2);
+      }, 2, 1);
    }
    if  (gmg_reads_upload (packed . data (), off . data (), string_ct, & strings) != GMG_OK
           || gmg_trainer_create (strings, model_len, model_depth, periodicity, & trainer) != GMG_OK)
@@ -354,7 +420,7 @@ bool  ICM_Training_t :: Try_Train_Model
       ICM_Score_Node_t  * * sc = score;
       const int  W = model_len, D = model_depth;
 
-      For_Each_Node (periodicity * on_level, [=] (int idx)
+      workers . Run (periodicity * on_level, [=] (int idx)
         {
          const int  frame = idx / on_level, sub = first + idx % on_level;
          const int32_t  * ct = all + size_t (idx) * npos * ALPHA_SQUARED;
@@ -400,7 +466,7 @@ bool  ICM_Training_t :: Try_Train_Model
          node . mut_info_pos = (short int) c . max_pos;
          node . mut_info = float (c . used_info);
          Blend_With_Parent (node . prob, sc [frame] [PARENT (sub)] . prob, c . final_char_ct);
-        });
+        }, 128, 16);
       lap ("nodes", level);
      }
 
@@ -409,7 +475,7 @@ bool  ICM_Training_t :: Try_Train_Model
    {
     ICM_Score_Node_t  * * sc = score;
     const int  N = num_nodes, slice = 4096, per_frame = (N + slice - 1) / slice;
-    For_Each_Node (periodicity * per_frame, [=] (int idx)
+    workers . Run (periodicity * per_frame, [=] (int idx)
       {
        const int  f = idx / per_frame, lo = (idx % per_frame) * slice, hi = (lo + slice < N ? lo + slice : N);
        for  (int i = lo;  i < hi;  i ++)
@@ -418,7 +484,7 @@ bool  ICM_Training_t :: Try_Train_Model
             float  & p = sc [f] [i] . prob [j];
             p = (p > 0.0 ? logf (p) : - FLT_MAX);
            }
-      }, 4);
+      }, 4, 1);
    }
    ok = true;
    lap ("logs", -1);
