@@ -44,6 +44,20 @@ def test_pack_bases_layout(gmg):
     assert codes == [0, 1, 2, 3] * 4 + [3, 2] + [1, 1, 2, 1]
 
 
+def test_pack_bases_word_at_a_time_equals_base_at_a_time(gmg):
+    """gmg_pack_bases takes whole words where it can; any start offset, any length, every byte value"""
+    rng = np.random.default_rng(3)
+    lib = gmg.capi.lib()
+    for first, n in [(0, 0), (0, 1), (5, 11), (15, 1), (15, 2), (16, 16), (3, 100), (31, 257), (7, 4096)]:
+        raw = rng.integers(1, 256, size=n, dtype=np.uint8).tobytes()
+        words = np.zeros(int(lib.gmg_packed_words(first + n)), np.uint32)
+        assert lib.gmg_pack_bases(raw, n, first, words.ctypes.data) == 0
+        for i, ch in enumerate(raw):
+            g = first + i
+            assert (int(words[g >> 4]) >> (2 * (g & 15))) & 3 == lib.gmg_base_code(ch)
+        assert all(((int(words[g >> 4]) >> (2 * (g & 15))) & 3) == 0 for g in range(first))
+
+
 def test_synthetic_stream_matches_splitmix_reference_values(gmg):
     # SplitMix64 with seed 0: first outputs are well known
     packed, off = gmg.synth.packed_reads(2, 32, 0)
@@ -115,6 +129,9 @@ def test_no_gpu_means_loud_failure_not_fallback(gmg):
         gmg.Reads.from_strings(["acgt"])
     with pytest.raises(gmg.GmgError):
         gmg.Icm.open(os.path.join(DATA, "cluster-4.icm")).device()
+    with pytest.raises(gmg.GmgError) as e:                      # training counts on the device or not at all
+        gmg.Icm.train([b"acgtacgtacgtacgtacgtacgt"], 12, 2, 3)
+    assert "no CPU fallback" in str(e.value)
 
 
 def test_fasta_split_cuts_only_where_a_record_starts(gmg):
