@@ -14,16 +14,17 @@
 //   * levels whose tables fit 64 KB of LDS (the top three for the default 12 / 7 / 3 shape) are counted per workgroup
 //     in LDS and flushed once;
 //   * deeper levels: device-wide atomics from 8 XCDs are served behind the L2s, one memory-side transaction per
-//     increment (27 G increments/s measured, 26 - 38 ms per level for 63 M windows).  So big training sets sort the
-//     windows of the level by table first (hipcub radix sort of (table, window) pairs, <= 17 key bits); a workgroup
-//     then takes 4,096 consecutive windows, which touch a handful of tables, counts them in LDS and adds each
-//     table's 176 counters to HBM once;
+//     increment (27 G increments/s measured, 26 - 38 ms per level for 63 M windows).  So the windows of the level
+//     are sorted by table first (hipcub radix sort of (table, value) pairs, <= 17 key bits; the value is the window's
+//     codes when they fit 32 bits, else its position); a workgroup then takes 4,096 consecutive pairs, which touch
+//     a handful of tables, counts them in LDS and adds each table's 176 counters to HBM once (1.65 ms per level
+//     for 63 M windows: 0.40 step + 0.98 sort + 0.26 count);
 //   * tiny training sets (below GMG_TRAIN_SORT_MIN bases, default 2^16) keep the direct atomics: five more launches
 //     per level would cost more than they save.  (One genome's genes, 1.6 M windows: 0.77 ms per deep level with
 //     direct atomics, 0.14 - 0.26 ms sorted.)
 //
 //   k_train_level<LDS, KEYS, NT>   the descent step + counts of one level (LDS / global atomics) or + the sort keys
-//   k_train_count_sorted       counts from the sorted (table, window) pairs
+//   k_train_count_sorted           counts from the sorted (table, value) pairs
 //
 // Integer work only: counts are exact, so the tables equal the reference's for any order of the atomics.
 
