@@ -140,6 +140,19 @@ def test_trained_tables_bit_identical_to_the_oracle_on_random_strings(gpu, oracl
         assert np.array_equal(prob_g.view(np.uint32), prob_w.view(np.uint32))
 
 
+def test_ambiguity_codes_and_upper_case_count_as_subscript_maps_them(gpu, oracle):
+    """Subscript (Filter (ch)) (src/ICM/icm.cc:2008-2027, src/Common/gene.cc:1139-1175): r -> g, y -> c, ..., anything
+    else -> c; the training counts must see the same codes"""
+    rng = np.random.default_rng(12)
+    alphabet = np.frombuffer(b"acgtacgtacgtnryswmkbdhvxACGTN-", np.uint8)
+    strings = [bytes(rng.choice(alphabet, size=int(k)).tobytes()) for k in rng.integers(0, 1200, size=120)]
+    check_levels(gpu, oracle, strings, 12, 5, 3)
+    want = oracle.train_model(strings, 12, 5, 3)
+    mip_w, prob_w = oracle.model_tables(want)
+    mip_g, prob_g = gpu.Icm.train(strings, 12, 5, 3).tables()
+    assert np.array_equal(mip_g, mip_w) and np.array_equal(prob_g.view(np.uint32), prob_w.view(np.uint32))
+
+
 def test_no_strings_and_argument_errors(gpu, oracle):
     want = oracle.train_model([], 12, 2, 3)
     mip_w, prob_w = oracle.model_tables(want)
