@@ -34,8 +34,37 @@ CASES = [
     ("c4_p4_d2_w3", "seqs.cluster-4.run1.filt.gene.fasta", ["-p", "4", "-d", "2", "-w", "3"], (3, 2, 4), False, True),
     ("c4_d1_w2", "seqs.cluster-4.run1.filt.gene.fasta", ["-d", "1", "-w", "2"], (2, 1, 3), False, True),
     ("c3_w16_d8_r", "seqs.cluster-3.run1.filt.gene.fasta", ["-r", "-w", "16", "-d", "8"], (16, 8, 3), True, False),
+    # our own synthetic file (written below): in-frame stops for -F to skip, upper case, ambiguity codes
+    ("syn_F_r", "train_synth.fa", ["-F", "-r"], (12, 7, 3), True, False),
+    ("syn_d4", "train_synth.fa", ["-d", "4"], (12, 4, 3), False, True),
     ("c4_text_d3_r", "seqs.cluster-4.run1.filt.gene.fasta", ["-r", "-t", "-d", "3"], (12, 3, 3), True, True),
 ]
+
+
+def write_synthetic(path):
+    """240 random strings of 30 - 900 characters: a third-position bias, every fourth string free of in-frame stop codons
+    (so that -F keeps some), some upper case, a few ambiguity codes (build-icm counts them as Subscript (Filter (ch)))"""
+    import numpy as np
+    rng = np.random.default_rng(20260103)
+    acgt = np.frombuffer(b"acgt", np.uint8)
+    with open(path, "wb") as fp:
+        for i in range(240):
+            n = int(rng.integers(30, 900))
+            s = rng.choice(acgt, size=n, p=[0.3, 0.2, 0.2, 0.3])
+            third = np.arange(n) % 3 == 2
+            s[third] = rng.choice(acgt, size=int(third.sum()), p=[0.1, 0.4, 0.4, 0.1])
+            s = bytearray(s.tobytes())
+            if i % 4 == 0:
+                for j in range(0, n - 2, 3):
+                    if bytes(s[j:j + 3]) in (b"taa", b"tag", b"tga"):
+                        s[j] = ord("c")
+            for k in rng.integers(0, n, size=int(rng.integers(0, 4))):
+                s[int(k)] = int(rng.choice(np.frombuffer(b"nryswmkbdhv", np.uint8)))
+            if i % 5 == 0:
+                s = bytearray(bytes(s).upper())
+            fp.write(b">syn%d\n" % i)
+            for k in range(0, n, 60):
+                fp.write(bytes(s[k:k + 60]) + b"\n")
 
 
 def main():
@@ -43,6 +72,7 @@ def main():
     for f in ("seqs.cluster-3.run1.filt.gene.fasta", "seqs.cluster-4.run1.filt.gene.fasta"):
         shutil.copyfile(os.path.join(REF, "sample-run", "glimmer-mg", "results", f), os.path.join(DATA, f))
         os.chmod(os.path.join(DATA, f), 0o644)
+    write_synthetic(os.path.join(DATA, "train_synth.fa"))
     cases = []
     for name, train, opts, shape, rev, whole in CASES:
         out = os.path.join(OUT, name + ".icm")

@@ -20,6 +20,8 @@ def training_strings(case, gmg):
     path = os.path.join(DATA, case["train"]) if case["train"] else REF_BIG
     _, seqs = gmg.read_fasta(path)
     seqs = [s.lower().encode() for s in seqs]
+    if "-F" in case["opts"]:         # Skip_In_Frame_Stop_Strings (build-icm.cc:80-109): default stop codons, before -r
+        seqs = [s for s in seqs if not any(s[j:j + 3] in (b"taa", b"tag", b"tga") for j in range(0, len(s) - 2, 3))]
     return [s[::-1] for s in seqs] if case["reversed"] else seqs
 
 
