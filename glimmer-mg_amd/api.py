@@ -34,6 +34,31 @@ def init(device=0):
     _ck(capi.lib().gmg_init(int(device)))
 
 
+def set_option(key, value):
+    """gmg_set_option: tuning / test switches (include/gmg.h)"""
+    _ck(capi.lib().gmg_set_option(key.encode(), int(value)))
+
+
+def get_option(key):
+    v = C.c_longlong()
+    _ck(capi.lib().gmg_get_option(key.encode(), C.byref(v)))
+    return v.value
+
+
+class option:
+    """with gmg.option("mg_err_flat", 1): ...   -- sets a switch for the block and restores it"""
+
+    def __init__(self, key, value):
+        self.key, self.value = key, value
+
+    def __enter__(self):
+        self.old = get_option(self.key)
+        set_option(self.key, self.value)
+
+    def __exit__(self, *exc):
+        set_option(self.key, self.old)
+
+
 def read_fasta(path):
     """Host-side ingest with the reference's semantics (src/Common/fasta.cc:236-286 Fasta_Read):
     header = text after '>' (leading blanks skipped) up to the newline; sequence = every

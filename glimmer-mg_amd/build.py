@@ -6,7 +6,7 @@ import subprocess
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(PKG, "lib", "libgmg.so")
-SOURCES = ["csrc/gmg_api.hip", "csrc/gmg_kernels.hip", "csrc/gmg_frame6.hip", "csrc/gmg_orfs.hip", "csrc/gmg_mg.hip", "csrc/gmg_ingest.hip", "csrc/gmg_strings.hip", "csrc/gmg_train.hip", "host/icm.cc", "host/icm_train.cc", "host/gmg_icm_c.cc"]
+SOURCES = ["csrc/gmg_api.hip", "csrc/gmg_kernels.hip", "csrc/gmg_frame6.hip", "csrc/gmg_orfs.hip", "csrc/gmg_mg.hip", "csrc/gmg_ingest.hip", "csrc/gmg_strings.hip", "csrc/gmg_train.hip", "host/icm.cc", "host/icm_train.cc", "host/gmg_icm_c.cc", "host/gmg_shard.cc"]
 HEADERS = ["csrc/gmg_internal.h", "csrc/gmg_device.h", "host/icm.hh", "../include/gmg.h", "../include/gmg_icm.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
@@ -19,8 +19,23 @@ def stale():
     return any(os.path.getmtime(os.path.join(PKG, f)) > t for f in SOURCES + HEADERS)
 
 
+def build_variant(name, defines):
+    """lib/variants/libgmg_<name>.so: the same sources with extra -D switches (kernel A/B runs; GMG_LIB_PATH selects one)"""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = os.path.join(PKG, "lib", "variants", "libgmg_%s.so" % name)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [hipcc, *FLAGS, *["-D" + d for d in defines], "-o", out, *SOURCES]
+    res = subprocess.run(cmd, cwd=PKG, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        print(res.stdout)
+        raise RuntimeError("hipcc failed building " + out)
+    return out
+
+
 def build_lib(force=False, verbose=False):
     """Compile every HIP/C++ source into lib/libgmg.so.  Returns the library path."""
+    if os.environ.get("GMG_LIB_PATH"):
+        return os.environ["GMG_LIB_PATH"]
     if not force and not stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

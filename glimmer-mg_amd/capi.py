@@ -39,6 +39,11 @@ PROTOTYPES = {
     "gmg_last_error": (C.c_char_p, []),
     "gmg_version": (C.c_char_p, []),
     "gmg_synchronize": (i32, [vp]),
+    "gmg_shard_plan": (i32, [vp, u64, i32, vp]),
+    "gmg_fasta_shard_ranges": (i32, [C.c_char_p, u64, i32, vp]),
+    "gmg_gc_fraction": (C.c_double, [vp, vp, i32, i32]),
+    "gmg_set_option": (i32, [C.c_char_p, C.c_longlong]),
+    "gmg_get_option": (i32, [C.c_char_p, C.POINTER(C.c_longlong)]),
     "gmg_base_code": (i32, [i32]),
     "gmg_pack_bases": (i32, [C.c_char_p, u64, u64, vp]),
     "gmg_packed_words": (u64, [u64]),
@@ -109,7 +114,8 @@ def lib():
         if not os.path.exists(LIB):
             raise RuntimeError("%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
                                "there is no fallback path" % LIB)
-        _lib = C.CDLL(LIB)
+        # GMG_LIB_PATH: a variant build of the same sources (kernel experiments, tools/build_variants.sh); never a fallback
+        _lib = C.CDLL(os.environ.get("GMG_LIB_PATH") or LIB)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(_lib, name)      # AttributeError if the library lacks a declared symbol
             fn.restype = res

@@ -26,6 +26,64 @@ int gmg_set_error(int code, const char *fmt, ...)
 }
 
 extern "C" const char *gmg_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------
+// options (tuning / test switches): one table, set through the API or once from the environment at gmg_init
+// ---------------------------------------------------------------------------
+long long g_gmg_opt[GMG_OPT_COUNT] = {
+    /* seg_plain */ 0, /* mg_tile */ 0, /* mg_one_stream */ 0, /* mg_err_flat */ 0, /* mg_err_calls */ 0, /* mg_err_calls_grow */ 0,
+    /* orfs_exact_path */ 0, /* train_sort_min */ -1, /* mg_max_entries */ 0x7fffffffll, /* mg_timing */ 0, /* ingest_timing */ 0,
+    /* train_timing */ 0, /* diag */ 0, /* strings_fused */ 1, /* mg_gene32 */ 1};
+static const char *const g_opt_name[GMG_OPT_COUNT] = {
+    "seg_plain", "mg_tile", "mg_one_stream", "mg_err_flat", "mg_err_calls", "mg_err_calls_grow", "orfs_exact_path",
+    "train_sort_min", "mg_max_entries", "mg_timing", "ingest_timing", "train_timing", "diag", "strings_fused",
+    "mg_gene32"};
+
+static int opt_index(const char *key)
+{
+    for (int i = 0; key && i < GMG_OPT_COUNT; i++)
+        if (strcmp(key, g_opt_name[i]) == 0) return i;
+    return -1;
+}
+
+extern "C" int gmg_set_option(const char *key, long long value)
+{
+    const int i = opt_index(key);
+    if (i < 0) return gmg_set_error(GMG_EINVAL, "gmg_set_option: unknown option '%s'", key ? key : "(null)");
+#ifndef GMG_ABLATIONS
+    if (i == GMG_OPT_DIAG && value != 0)
+        return gmg_set_error(GMG_EINVAL, "gmg_set_option: the ablation kernels are not in this build (-DGMG_ABLATIONS)");
+#endif
+    if (i == GMG_OPT_MG_MAX_ENTRIES && (value < 1 || value > 0x7fffffffll))
+        return gmg_set_error(GMG_EINVAL, "gmg_set_option: mg_max_entries must be in [1, 2^31 - 1]");
+    g_gmg_opt[i] = value;
+    return GMG_OK;
+}
+
+extern "C" int gmg_get_option(const char *key, long long *value)
+{
+    const int i = opt_index(key);
+    if (i < 0 || !value) return gmg_set_error(GMG_EINVAL, "gmg_get_option: unknown option '%s'", key ? key : "(null)");
+    *value = g_gmg_opt[i];
+    return GMG_OK;
+}
+
+// GMG_<NAME>=value in the environment, read ONCE (at gmg_init); a variable without a number counts as 1
+static void options_from_env(void)
+{
+    for (int i = 0; i < GMG_OPT_COUNT; i++) {
+        char name[64] = "GMG_";
+        size_t k = 4;
+        for (const char *c = g_opt_name[i]; *c && k + 1 < sizeof name; c++) name[k++] = (char)toupper((unsigned char)*c);
+        name[k] = 0;
+        const char *v = getenv(name);
+        if (!v) continue;
+        char *end = nullptr;
+        long long x = strtoll(v, &end, 10);
+        if (end == v) x = 1;
+        (void)gmg_set_option(g_opt_name[i], x);
+    }
+}
 extern "C" const char *gmg_version(void) { return "glimmer-mg_amd 0.1 (gfx950)"; }
 
 extern "C" int gmg_device_count(void)
@@ -50,18 +108,28 @@ extern "C" int gmg_init(int device)
         return gmg_set_error(GMG_ENODEV, "gmg_init: device %d is %s; this library is built for gfx950 only",
                              device, prop.gcnArchName);
     GMG_HIP(hipSetDevice(device));
+    if (g_device < 0) options_from_env();
     g_device = device;
     return GMG_OK;
 }
 
-static int require_init(const char *who)
+// HIP's current device is per host thread, g_device is per process: every entry point that allocates, copies or
+// launches goes through here, so that a second host thread (a pipeline's fetcher, a worker of the caller) works on
+// the device gmg_init chose and not on device 0.
+int gmg_enter(const char *who)
 {
     if (g_device < 0) return gmg_set_error(GMG_ENODEV, "%s: gmg_init() has not succeeded in this process", who);
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != g_device) GMG_HIP(hipSetDevice(g_device));   // (a thread-local read otherwise)
     return GMG_OK;
 }
 
+static int require_init(const char *who) { return gmg_enter(who); }
+
 extern "C" int gmg_synchronize(void *stream)
 {
+    int rc = gmg_enter("gmg_synchronize");
+    if (rc) return rc;
     GMG_HIP(hipStreamSynchronize((hipStream_t)stream));
     return GMG_OK;
 }
@@ -211,7 +279,9 @@ extern "C" int gmg_model_upload(const int16_t *mip, const float *prob4, int W, i
     size_t o_prob = align_up(o_mip + PN, 256);
     size_t o_cshift = align_up(o_prob + PN * 16, 256);
     size_t o_crow = align_up(o_cshift + (fast ? P * cstride : 0), 256);
-    size_t o_dense = align_up(o_crow + (fast ? (size_t)P * ctot * 16 + 16 : 0), 256);   // + one all-zero row
+    size_t o_chalf = align_up(o_crow + (fast ? (size_t)P * ctot * 16 + 16 : 0), 256);   // + one all-zero row
+    const size_t n_leaves = (size_t)(pw / 4);                // 4^D
+    size_t o_dense = align_up(o_chalf + (fast ? (size_t)P * n_leaves * 16 : 0), 256);
     size_t o_part = align_up(o_dense + (size_t)P * n_dense * 4, 256);
     size_t total = align_up(o_part + (size_t)P * n_part * 4 + 4, 256);
 
@@ -224,6 +294,16 @@ extern "C" int gmg_model_upload(const int16_t *mip, const float *prob4, int W, i
             complete_tree(mip + (size_t)p * N, prob4 + 4 * (size_t)p * N, D,
                           blob.data() + o_cshift + p * cstride,
                           (float *)(blob.data() + o_crow) + (size_t)p * ctot * 4);
+    if (fast)                                                // the leaves again, two floats per half (GmgDevModel::chalf)
+        for (int p = 0; p < P; p++) {
+            const float *leaf = (const float *)(blob.data() + o_crow) + ((size_t)p * ctot + n_internal) * 4;
+            float *half = (float *)(blob.data() + o_chalf) + (size_t)p * n_leaves * 4;
+            for (size_t r = 0; r < n_leaves; r++)
+                for (int h = 0; h < 2; h++) {
+                    half[(h * n_leaves + r) * 2] = leaf[4 * r + 2 * h];
+                    half[(h * n_leaves + r) * 2 + 1] = leaf[4 * r + 2 * h + 1];
+                }
+        }
     if (dense)
         for (int p = 0; p < P; p++) {
             const int16_t *pm = mip + (size_t)p * N;
@@ -252,6 +332,7 @@ extern "C" int gmg_model_upload(const int16_t *mip, const float *prob4, int W, i
     m->dev.prob = (const float *)(d + o_prob);
     m->dev.cshift = fast ? (const uint8_t *)(d + o_cshift) : nullptr;
     m->dev.crow = fast ? (const float *)(d + o_crow) : nullptr;
+    m->dev.chalf = fast ? (const float *)(d + o_chalf) : nullptr;
     m->dev.cstride = (int)cstride;
     m->dev.ctot = (int)ctot;
     m->dev.has_fast = fast;
@@ -383,6 +464,11 @@ extern "C" int gmg_reads_wrap_device(const uint32_t *d_packed, const uint64_t *d
         gmg_reads_free(r);
         return gmg_set_error(GMG_EINVAL, "gmg_reads_wrap_device: base_offsets do not span [0, total_bases]");
     }
+    for (uint64_t i = 0; i < n_reads; i++)                  // the same checks as gmg_reads_upload: the kernels trust the offsets
+        if (h_off[i + 1] < h_off[i] || h_off[i + 1] - h_off[i] > 0x7fffffffull) {
+            gmg_reads_free(r);
+            return gmg_set_error(GMG_EINVAL, "gmg_reads_wrap_device: base_offsets not monotone at read %llu", (unsigned long long)i);
+        }
     rc = finish_reads(r, h_off.data());
     if (rc) { gmg_reads_free(r); return rc; }
     *out = r;
@@ -469,6 +555,7 @@ extern "C" int gmg_reads_info(const gmg_reads *r, uint64_t *n_reads, uint64_t *t
 
 extern "C" int gmg_reads_download(const gmg_reads *r, uint32_t *packed, uint64_t *off)
 {
+    { int rc = gmg_enter("gmg_reads_download"); if (rc) return rc; }
     if (!r || !off || (r->total_bases && !packed)) return gmg_set_error(GMG_EINVAL, "gmg_reads_download: NULL argument");
     if (r->total_bases)
         GMG_HIP(hipMemcpy(packed, r->d_packed, gmg_packed_words(r->total_bases) * 4, hipMemcpyDeviceToHost));
@@ -670,6 +757,7 @@ extern "C" int gmg_device_free(void *d_ptr)
 
 extern "C" int gmg_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *stream)
 {
+    { int rc = gmg_enter("gmg_memcpy_h2d"); if (rc) return rc; }
     GMG_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     GMG_HIP(hipStreamSynchronize((hipStream_t)stream));
     return GMG_OK;
@@ -677,6 +765,7 @@ extern "C" int gmg_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *
 
 extern "C" int gmg_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *stream)
 {
+    { int rc = gmg_enter("gmg_memcpy_d2h"); if (rc) return rc; }
     GMG_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     GMG_HIP(hipStreamSynchronize((hipStream_t)stream));
     return GMG_OK;
@@ -689,7 +778,7 @@ extern "C" int gmg_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *
 // gmg_trim_cache() gives everything back to the driver.
 // ---------------------------------------------------------------------------------------------------
 namespace {
-struct PoolBlock { void *p; size_t bytes; bool busy; };
+struct PoolBlock { void *p; size_t bytes; bool busy; hipEvent_t pending; bool waiting; };   // waiting: free once `pending` has passed
 std::mutex g_pool_mutex;
 std::vector<PoolBlock> g_pool;
 
@@ -700,6 +789,8 @@ hipError_t gmg_pool_alloc(void **out, size_t bytes)
     if (bytes == 0) bytes = 1;
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     int best = -1;
+    for (auto &b : g_pool)                              // blocks released "after the stream reaches here" (gmg_pool_release_after)
+        if (b.busy && b.waiting && hipEventQuery(b.pending) == hipSuccess) { b.busy = false; b.waiting = false; }
     for (size_t i = 0; i < g_pool.size(); i++)
         if (!g_pool[i].busy && g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + 4096 &&
             (best < 0 || g_pool[i].bytes < g_pool[best].bytes))
@@ -709,14 +800,29 @@ hipError_t gmg_pool_alloc(void **out, size_t bytes)
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {                              // make room: drop the idle blocks and try once more
         for (size_t i = 0; i < g_pool.size();)
-            if (!g_pool[i].busy) { (void)hipFree(g_pool[i].p); g_pool.erase(g_pool.begin() + i); } else i++;
+            if (!g_pool[i].busy) { if (g_pool[i].pending) (void)hipEventDestroy(g_pool[i].pending); (void)hipFree(g_pool[i].p); g_pool.erase(g_pool.begin() + i); } else i++;
         (void)hipGetLastError();
         e = hipMalloc(&p, bytes);
         if (e != hipSuccess) return e;
     }
-    g_pool.push_back({p, bytes, true});
+    g_pool.push_back({p, bytes, true, nullptr, false});
     *out = p;
     return hipSuccess;
+}
+
+// The block goes back to the cache once everything queued on `s` so far has run (an asynchronous entry point's scratch).
+void gmg_pool_release_after(void *p, hipStream_t s)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (auto &b : g_pool)
+        if (b.p == p) {
+            if (!b.pending && hipEventCreateWithFlags(&b.pending, hipEventDisableTiming) != hipSuccess) b.pending = nullptr;
+            if (b.pending && hipEventRecord(b.pending, s) == hipSuccess) { b.waiting = true; return; }
+            (void)hipStreamSynchronize(s);              // no event: wait here instead
+            b.busy = false;
+            return;
+        }
 }
 
 void gmg_pool_release(void *p)
@@ -724,15 +830,17 @@ void gmg_pool_release(void *p)
     if (!p) return;
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (auto &b : g_pool)
-        if (b.p == p) { b.busy = false; return; }
+        if (b.p == p) { b.busy = false; b.waiting = false; return; }
     (void)hipFree(p);                                   // not ours
 }
 
 extern "C" int gmg_trim_cache(void)
 {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (auto &b : g_pool)
+        if (b.busy && b.waiting && hipEventQuery(b.pending) == hipSuccess) { b.busy = false; b.waiting = false; }
     for (size_t i = 0; i < g_pool.size();)
-        if (!g_pool[i].busy) { (void)hipFree(g_pool[i].p); g_pool.erase(g_pool.begin() + i); } else i++;
+        if (!g_pool[i].busy) { if (g_pool[i].pending) (void)hipEventDestroy(g_pool[i].pending); (void)hipFree(g_pool[i].p); g_pool.erase(g_pool.begin() + i); } else i++;
     return GMG_OK;
 }
 
@@ -741,6 +849,7 @@ extern "C" int gmg_trim_cache(void)
 // PCIe speed instead of through the runtime's staging buffers.
 extern "C" int gmg_host_register(void *ptr, size_t bytes)
 {
+    { int rc = gmg_enter("gmg_host_register"); if (rc) return rc; }
     if (!ptr || !bytes) return gmg_set_error(GMG_EINVAL, "gmg_host_register: empty buffer");
     GMG_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
     return GMG_OK;

@@ -27,6 +27,20 @@
 #include "gmg_device.h"
 #include <stdlib.h>
 
+#ifndef GMG_F6_STAMPS
+#define GMG_F6_STAMPS 0         // diagnostic build: per-wave cycle counts of the phases of a round (tools/f6_stamps.py); not in the product
+#endif
+#if GMG_F6_STAMPS
+__device__ unsigned long long g_f6_stamps[1024 * 16 * 8];
+extern "C" int gmg_debug_f6_stamps(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f6_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#define F6_STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_prev; st_prev = now_; } while (0)
+#else
+#define F6_STAMP(i) do { } while (0)
+#endif
+
 struct Frame6Args {
     GmgDevModel gene, nul;
     const uint32_t *packed;
@@ -64,22 +78,31 @@ __device__ __forceinline__ uint32_t f6_descend(const uint8_t *tab, uint32_t C, u
 // vector-memory pipe (address coalescer: one divergent lane per cycle) and the L2 channels
 // (1.3e9 requests per launch) are what the kernel waits for, and on gfx9 every load also waits for
 // all older stores (one in-order vmcnt).  So this variant keeps ALL table accesses in LDS by
-// holding one HALF of the sub-model's leaf rows at a time (8,192 rows x 16 B = 128 KiB):
+// holding one HALF of the sub-model's leaf values at a time (128 KiB of the 256 KiB).
+//
+// Which half: the one that holds the predicted base's values.  Half h = the two floats prob[2h], prob[2h+1] of every
+// leaf row (gmg_model_upload lays the leaves out that way, GmgDevModel::chalf).  A lane's two scoring buffers predict
+// S[p] (reversed buffer) and comp (S[p]) (complemented buffer) at the same base, and the complement flips the high
+// bit of the 2-bit code (a 00 <-> t 11, c 01 <-> g 10): of the two values of a base EXACTLY ONE is in the resident
+// half, whatever the read.  So per base one LDS read serves the pair in each phase (no dummy reads, no per-item
+// flags: which of the two it was is a bit of the read itself), and both phases always carry the same load.
 //
 //   round = K chunks of this work-group (K x 2,048 bases; K = 16):
-//     phase 1  (half h resident)   per chunk: contexts, four descents; a leaf value whose row is in
-//                                  half h is read now, the others keep their row offset; 5 registers
-//                                  per chunk and lane survive the phase (4 values/offsets + flags
-//                                  and null-table indices).
-//     swap     barrier; the other half is streamed L2 -> LDS (coalesced 16-byte loads, 8 per lane);
-//              the packed words of the NEXT round are staged into LDS by the same loads' shadow;
-//              barrier.
+//     phase 1  (half h resident)   per chunk: contexts, four descents; per base the value of the buffer whose
+//                                  predicted base is in h is read now, the other keeps its offset; 5 registers per
+//                                  chunk and lane survive the phase (2 values, 2 offsets, 12 bits of read).
+//     swap     barrier; the other half is streamed L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers in
+//              between, so the round's state stays where it is); the packed words of the NEXT round are staged
+//              into LDS, all requested before the first is waited for; barrier.
 //     phase 2  (other half resident) per chunk: the missing values are read, everything is widened,
 //                                  the null value subtracted, and the chunk is stored (full lines).
 //   The next round starts with the half that is resident now, so there is ONE swap per round.
 //
 // Vector memory sees only coalesced traffic: the half reloads, the staged packed words and the
 // output stores; phase 1 of the next round (pure LDS + VALU) overlaps the draining stores.
+// Where a round's cycles go (tools/f6_stamps.py, profiles/r02_f6_stamps.txt): phase 1 52 %, waiting for the last wave
+// of phase 1 19 %, swap 7 %, phase 2 22 % -- the kernel is bound by the LDS lookups and the vector instructions
+// around them, not by HBM.
 // ---------------------------------------------------------------------------
 // GENE_ONLY: write the gene model's value alone, as fp32, to a.out_gene (input of the fused Score_Orfs scan,
 // gmg_orfs.hip); the null model is not touched.
@@ -94,38 +117,53 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     constexpr int CS = f6_cstride(DT);
     constexpr uint32_t SPAN = 2 * BLOCK;                            // bases per chunk
     constexpr uint32_t RAWW = SPAN / 16 + 4;                        // packed words staged per chunk (1 before, 3 after)
-    constexpr uint32_t HALF_ROWS = (1u << (2 * DT)) / 2;
+    constexpr uint32_t LEAVES = 1u << (2 * DT);
+    constexpr uint32_t HALF_BYTES = LEAVES * 8;                     // two floats per leaf
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_half[];   // [LEAVES][2] floats: first in LDS, offsets need no base
     __shared__ __attribute__((aligned(16))) uint8_t s_shr[CS];     // complemented buffer (rows 3+f): 2*mip
     __shared__ __attribute__((aligned(16))) uint8_t s_shf[CS];     // reversed buffer (rows f): 2*(W-1-mip)
     __shared__ __attribute__((aligned(16))) double s_nr[64];        // null model, complemented buffer
     __shared__ __attribute__((aligned(16))) double s_nf[64];        // null model, reversed buffer
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[K * RAWW];   // packed words of the current round
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_half[];   // [HALF_ROWS][4] floats
 
     const int ftype = STRINGS ? 0 : blockIdx.x % 3;
     const uint32_t worker = STRINGS ? blockIdx.x : blockIdx.x / 3, nworkers = STRINGS ? gridDim.x : gridDim.x / 3;
     const int W = a.gene.W;
-    const uint8_t *leaf_rows = (const uint8_t *)(a.gene.crow + ((size_t)ftype * a.gene.ctot + f6_level_base(DT)) * 4);
+    const uint8_t *half_src = (const uint8_t *)(a.gene.chalf + (size_t)ftype * 2 * LEAVES * 2);   // [2][LEAVES][2] floats
 
     const uint64_t n_chunks = a.total / SPAN;                       // full chunks only
     if (worker >= n_chunks) return;
     const uint32_t n_mine = (uint32_t)((n_chunks - worker + nworkers - 1) / nworkers);   // chunks worker, worker+nworkers, ...
 
-    auto load_half = [&](uint32_t h) __attribute__((always_inline)) {
-        const float4 *src = (const float4 *)(leaf_rows + (size_t)h * HALF_ROWS * 16);
-        float4 t[HALF_ROWS / BLOCK];
+    // every wave-instruction moves 1 KiB L2 -> LDS: lane l's 16 bytes land at the wave's LDS base + 16 l
+    constexpr uint32_t NHALF = HALF_BYTES / 16 / BLOCK;             // 16-byte pieces per lane and half
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+    auto half_issue = [&](uint32_t h) __attribute__((always_inline)) {
+        const float4 *src = (const float4 *)(half_src + (size_t)h * HALF_BYTES);
 #pragma unroll
-        for (uint32_t i = 0; i < HALF_ROWS / BLOCK; i++) t[i] = src[i * BLOCK + threadIdx.x];
-#pragma unroll
-        for (uint32_t i = 0; i < HALF_ROWS / BLOCK; i++) ((float4 *)s_half)[i * BLOCK + threadIdx.x] = t[i];
+        for (uint32_t i = 0; i < NHALF; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * BLOCK + threadIdx.x),
+                                             (__attribute__((address_space(3))) void *)(s_half + (size_t)(i * BLOCK + wbase) * 16), 16, 0, 0);
     };
-    auto load_raw_round = [&](uint32_t j0) __attribute__((always_inline)) {
-        // words [c*SPAN/16 - 1, c*SPAN/16 + RAWW - 1) of every chunk c of the round
-        for (uint32_t t = threadIdx.x; t < K * RAWW; t += BLOCK) {
+    auto half_landed = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_waitcnt(0x0F70); };   // vmcnt(0)
+    // words [c*SPAN/16 - 1, c*SPAN/16 + RAWW - 1) of every chunk c of the round that starts at chunk j0 of this worker
+    constexpr uint32_t NRAW = (K * RAWW + BLOCK - 1) / BLOCK;
+    uint32_t raw_t[NRAW];
+    auto raw_issue = [&](uint32_t j0) __attribute__((always_inline)) {
+#pragma unroll
+        for (uint32_t i = 0; i < NRAW; i++) {
+            const uint32_t t = threadIdx.x + i * BLOCK;
             const uint32_t k = t / RAWW, w = t - k * RAWW;
             const uint32_t j = j0 + k < n_mine ? j0 + k : n_mine - 1;
             const uint64_t c = worker + (uint64_t)j * nworkers;
-            s_raw[t] = a.packed[c * (SPAN / 16) - 1 + w];
+            raw_t[i] = t < K * RAWW ? a.packed[c * (SPAN / 16) - 1 + w] : 0u;
+        }
+    };
+    auto raw_commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (uint32_t i = 0; i < NRAW; i++) {
+            const uint32_t t = threadIdx.x + i * BLOCK;
+            if (t < K * RAWW) s_raw[t] = raw_t[i];
         }
     };
 
@@ -145,8 +183,10 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
             s_nr[i] = GENE_ONLY ? 0.0 : (double)a.nul.dense[(size_t)ftype * 64 + (i ^ 63u)];
             s_nf[i] = GENE_ONLY ? 0.0 : (double)a.nul.dense[(size_t)ftype * 64 + mirrored];
         }
-        load_half(0);
-        load_raw_round(0);
+        raw_issue(0);
+        half_issue(0);
+        raw_commit();
+        half_landed();
     }
     __syncthreads();
     const uint32_t shift0_r = __builtin_amdgcn_readfirstlane((uint32_t)s_shr[0]);
@@ -161,11 +201,17 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     double *const out_f = a.out + (uint64_t)ftype * a.stride;
     double *const out_r = a.out + (uint64_t)(3 + ftype) * a.stride;
 
+#if GMG_F6_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
+#endif
     uint32_t cur = 0;                                               // half resident in LDS
     for (uint32_t j0 = 0; j0 < n_mine; j0 += K) {
         const uint32_t kk = n_mine - j0 < (uint32_t)K ? n_mine - j0 : (uint32_t)K;   // chunks in this round
-        uint32_t val[K][4];     // value bits (row in the resident half) or byte offset inside the other half
-        uint32_t meta[K];       // bits 0-3: value present; bits 4-15: read bases S[g0-2 .. g0+3] (null-model windows)
+        // per chunk and base pair (g0, g0 + 1): the value that was in the resident half and the offset of the other
+        uint32_t have[K][2], want[K][2];
+        // per chunk the read bases S[g0-2 .. g0+3] (12 bits: the null-model windows, and which buffer of a base was resident:
+        // the high bit of S[g0] / S[g0+1]); two chunks per register
+        uint32_t meta[(K + 1) / 2];
 
         // ---- phase 1
 #pragma unroll
@@ -187,44 +233,57 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
                 idx[1] = f6_descend<DT>(s_shr, C[1], shift0_r);
                 idx[2] = f6_descend<DT>(s_shf, C[2], shift0_f);
                 idx[3] = f6_descend<DT>(s_shr, C[3], shift0_r);
-                uint32_t mt = 0;
+                // the six bases S[g0-2 .. g0+3] = fields W-3 .. W+2, uncomplemented: field 2 is S[g0], field 3 S[g0+1]
+                const uint32_t six = __builtin_amdgcn_alignbit(xh, xl, sh_f - 4) & 0xfffu;
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const bool fwd = (c & 1) == 0;
-                    const uint32_t pred = fwd ? (C[c] & 3u) : (C[c] >> sh_f);
-                    const uint32_t tb = (((idx[c] & (HALF_ROWS - 1)) << 2) | pred) << 2;   // byte offset inside its half
-                    const bool here = (idx[c] >> (2 * DT - 1)) == cur;
-                    const uint32_t got = (DIAG & 2) ? tb : __float_as_uint(*(const float *)(s_half + (here ? tb : 0u)));
-                    val[k][c] = here ? got : tb;
-                    mt |= (here ? 1u : 0u) << c;
+                for (int b = 0; b < 2; b++) {                       // base g0 + b: items 2b (reversed buffer) and 2b + 1 (complemented)
+                    // predicted bases: C[2b] & 3 and C[2b+1] >> sh_f, complements of each other; byte offset of a value inside
+                    // its half: leaf * 8 + (low bit of the predicted base) * 4
+                    const uint32_t tf = (idx[2 * b] << 3) | ((C[2 * b] & 1u) << 2);
+                    const uint32_t tr = (idx[2 * b + 1] << 3) | (((C[2 * b + 1] >> sh_f) & 1u) << 2);
+                    const bool f_here = ((C[2 * b] >> 1) & 1u) == cur;             // the reversed buffer's value is resident
+                    const uint32_t got = (DIAG & 2) ? tf : __float_as_uint(*(const float *)(s_half + (f_here ? tf : tr)));
+                    have[k][b] = got;
+                    want[k][b] = f_here ? tr : tf;
                 }
-                // the four null-model windows are slices of the six bases S[g0-2 .. g0+3] = fields W-3 .. W+2
-                meta[k] = mt | ((__builtin_amdgcn_alignbit(xh, xl, sh_f - 4) & 0xfffu) << 4);
+                if (k & 1) meta[k >> 1] |= six << 16; else meta[k >> 1] = six;
             }
         }
 
         // ---- swap halves; stage the next round's packed words
+        F6_STAMP(0);                                                // phase 1
         __syncthreads();
+        F6_STAMP(1);                                                // wait at barrier A
         cur ^= 1u;
-        load_half(cur);
-        if (j0 + K < n_mine) load_raw_round(j0 + K);
+        if (j0 + K < n_mine) raw_issue(j0 + K);
+        half_issue(cur);
+        if (j0 + K < n_mine) raw_commit();
+        half_landed();
+        F6_STAMP(2);                                                // swap work
         __syncthreads();
+        F6_STAMP(3);                                                // wait at barrier B
 
         // ---- phase 2
 #pragma unroll
         for (int k = 0; k < K; k++) {
             if ((uint32_t)k < kk) {
-                const uint32_t mt = meta[k];
+                const uint32_t mt = meta[k >> 1];
+                const int mb = (k & 1) * 16;                        // (a constant in the unrolled loop: folded into the bit-field offsets)
                 double v[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const bool have = (mt >> c) & 1u;
-                    const uint32_t got = (DIAG & 2) ? val[k][c] : __float_as_uint(*(const float *)(s_half + (have ? 0u : val[k][c])));
-                    const float gv = __uint_as_float(have ? val[k][c] : got);
-                    // item 0: S[g0..g0+2] reversed buffer; 1: S[g0-2..g0] complemented; 2, 3: one base further
-                    const uint32_t nidx = __builtin_amdgcn_ubfe(mt, c == 0 ? 8 : c == 1 ? 4 : c == 2 ? 10 : 6, 6);
-                    const double nv = (c & 1) == 0 ? s_nf[nidx] : s_nr[nidx];
-                    v[c] = (double)gv - nv;                         // glimmer-mg.cc:1493,1508
+                for (int b = 0; b < 2; b++) {
+                    const uint32_t got = (DIAG & 2) ? want[k][b] : __float_as_uint(*(const float *)(s_half + want[k][b]));
+                    // which buffer was resident in phase 1: the high bit of S[g0 + b] (STRINGS: of its complement) against the half
+                    // of then, i.e. the other one than now
+                    const uint32_t hb = (mt >> (mb + 5 + 2 * b)) & 1u;
+                    const bool f_was_here = (STRINGS ? hb ^ 1u : hb) != cur;
+                    const float gf = __uint_as_float(f_was_here ? have[k][b] : got);
+                    const float gr = __uint_as_float(f_was_here ? got : have[k][b]);
+                    // item 2b: S[g0+b .. g0+b+2] reversed buffer; item 2b+1: S[g0+b-2 .. g0+b] complemented
+                    const double nf = s_nf[__builtin_amdgcn_ubfe(mt, mb + 4 + 2 * b, 6)];
+                    const double nr = s_nr[__builtin_amdgcn_ubfe(mt, mb + 2 * b, 6)];
+                    v[2 * b] = (double)gf - nf;                     // glimmer-mg.cc:1493,1508
+                    v[2 * b + 1] = (double)gr - nr;
                 }
                 const uint64_t chunk = worker + (uint64_t)(j0 + k) * nworkers;
                 if (GENE_ONLY) {
@@ -260,7 +319,12 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
                 }
             }
         }
+        F6_STAMP(4);                                                // phase 2
     }
+#if GMG_F6_STAMPS
+    if ((threadIdx.x & 63u) == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < 8; i++) g_f6_stamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + i] = st_acc[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -451,9 +515,9 @@ int gmg_launch_frame6_strided(const gmg_model *gene, const gmg_model *nul, const
 
     constexpr int BLOCK = 1024, DT = 7;
     constexpr uint32_t SPAN = 2 * BLOCK;
+    constexpr int KR = 16;                                         // chunks per round (8 / 12 / 20 measured slower)
     const uint64_t n_chunks = a.total / SPAN;
-    const char *env = getenv("GMG_DIAG");
-    const int diag = env ? atoi(env) : 0;
+    const int diag = (int)gmg_opt(GMG_OPT_DIAG);
     const bool pair = (a.stride & 1) == 0;          // every row 16-byte aligned
     if (n_chunks > 0) {
         int dev = 0, n_cu = 256;
@@ -464,8 +528,7 @@ int gmg_launch_frame6_strided(const gmg_model *gene, const gmg_model *nul, const
         if (nworkers < 1) nworkers = 1;
         if (nworkers > n_chunks) nworkers = (unsigned)n_chunks;
         const unsigned grid = 3 * nworkers;
-        constexpr int KR = 16;                                     // chunks per round (8 / 12 / 20 measured slower)
-        const size_t lds = ((size_t)1 << (2 * DT)) / 2 * 16;       // dynamic part: half of the leaf rows
+        const size_t lds = ((size_t)1 << (2 * DT)) * 8;            // dynamic part: half of the leaf values
 #define GMG_LAUNCH_F6T(DIAG_, P_)                                                                       \
     do {                                                                                                \
         GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, DIAG_, P_, false>,           \
@@ -473,10 +536,12 @@ int gmg_launch_frame6_strided(const gmg_model *gene, const gmg_model *nul, const
         hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, DIAG_, P_, false>), dim3(grid), dim3(BLOCK), lds, s, a); \
     } while (0)
         if (diag == 0) { if (pair) GMG_LAUNCH_F6T(0, true); else GMG_LAUNCH_F6T(0, false); }
+#ifdef GMG_ABLATIONS
         else if (diag == 1 && pair) GMG_LAUNCH_F6T(1, true);
         else if (diag == 2 && pair) GMG_LAUNCH_F6T(2, true);
         else if (diag == 3 && pair) GMG_LAUNCH_F6T(3, true);
-        else return gmg_set_error(GMG_EINVAL, "GMG_DIAG=%d is not a built ablation", diag);
+#endif
+        else return gmg_set_error(GMG_EINVAL, "the ablation kernel diag=%d is not in this build", diag);
 #undef GMG_LAUNCH_F6T
         GMG_HIP(hipGetLastError());
     }
@@ -527,7 +592,7 @@ int gmg_launch_gene6(const gmg_model *gene, const gmg_reads *reads, float *d_gen
         if (nworkers < 1) nworkers = 1;
         if (nworkers > n_chunks) nworkers = (unsigned)n_chunks;
         const unsigned grid = 3 * nworkers;
-        const size_t lds = ((size_t)1 << (2 * DT)) / 2 * 16;
+        const size_t lds = ((size_t)1 << (2 * DT)) * 8;
         if ((a.total & 1) == 0) {
             GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, true, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -571,7 +636,7 @@ int gmg_launch_strings(const gmg_model *m, const gmg_reads *reads, float *d_vals
     GMG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     unsigned grid = (unsigned)n_cu;                    // one persistent work-group per CU, all on sub-model 0
     if (grid > n_chunks) grid = (unsigned)n_chunks;
-    const size_t lds = ((size_t)1 << (2 * DT)) / 2 * 16;
+    const size_t lds = ((size_t)1 << (2 * DT)) * 8;
     if ((a.total & 1) == 0) {
         GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, true, true, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

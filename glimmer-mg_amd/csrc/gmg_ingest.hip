@@ -187,8 +187,9 @@ extern "C" int gmg_fasta_split(const char *bytes, uint64_t n_bytes, uint64_t chu
 
 extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_reads **out_reads, gmg_fasta **out_index, void *stream)
 {
+    { int rc_enter = gmg_enter("gmg_fasta_ingest_on"); if (rc_enter) return rc_enter; }
     hipStream_t st = (hipStream_t)stream;
-    const bool timing = getenv("GMG_INGEST_TIMING") != nullptr;         // wall time of every stage on stderr
+    const bool timing = gmg_opt(GMG_OPT_INGEST_TIMING) != 0;         // wall time of every stage on stderr
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;

@@ -28,6 +28,8 @@ struct GmgDevModel {
     const float *crow;     // [P][ctot][4]  row the reference uses when a descent ends at that completed-tree
                            //               node (own row; the parent's for a cut node; the stopping ancestor's
                            //               for nodes below a stop).  Leaves (level D) start at (4^D-1)/3.
+    const float *chalf;    // [P][2][4^D][2]  the leaves' values once more, split for the six-frame kernel's LDS halves:
+                           //               half h holds prob[2h], prob[2h+1] of every leaf row (gmg_frame6.hip)
     int cstride;           // bytes per sub-model in cshift (padded to 16)
     int ctot;              // (4^(D+1)-1)/3 nodes per sub-model in crow
     int has_fast;          // cshift/crow valid (W <= 16, D <= 8)
@@ -69,6 +71,9 @@ struct gmg_segments {
 
 // error plumbing (gmg_api.hip)
 int gmg_set_error(int code, const char *fmt, ...);
+// first statement of every entry point that touches the device: gmg_init() done, and the calling host thread bound to
+// the device it chose (HIP's current device is per thread)
+int gmg_enter(const char *who);
 #define GMG_HIP(call)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (call);                                                               \
@@ -77,10 +82,34 @@ int gmg_set_error(int code, const char *fmt, ...);
                                  __FILE__, __LINE__);                                         \
     } while (0)
 
+// Tuning / test switches (gmg_set_option, include/gmg.h).  Set explicitly through the API, or once at gmg_init() from the
+// environment variable GMG_<NAME IN UPPER CASE>; never read from the environment on a scoring path.
+enum GmgOpt {
+    GMG_OPT_SEG_PLAIN,           // segment kernels: plain descent on the original tables even when a completed tree exists
+    GMG_OPT_MG_TILE,             // running-sum kernel: force the 512- or 1504-base tile (0 = by read length)
+    GMG_OPT_MG_ONE_STREAM,       // glimmer-mg front half on the caller's stream only
+    GMG_OPT_MG_ERR_FLAT,         // error branch on the per-ORF kernel (cross-check of the level kernels)
+    GMG_OPT_MG_ERR_CALLS,        // error branch: entries per call array (0 = by batch size); tests force the overflow paths
+    GMG_OPT_MG_ERR_CALLS_GROW,   // ... and allow the one retry with larger arrays although the size was forced
+    GMG_OPT_ORFS_EXACT_PATH,     // gmg_score_orfs: the any-model path even for the default model shape
+    GMG_OPT_TRAIN_SORT_MIN,      // training: smallest set (bases) that takes the sorted counting path (-1 = default)
+    GMG_OPT_MG_MAX_ENTRIES,      // most ORFs / starts one gmg_mg_score_reads result may hold (its index fields are 32-bit)
+    GMG_OPT_MG_TIMING,           // stage timings of gmg_mg_score_reads on stderr (synchronises between stages)
+    GMG_OPT_INGEST_TIMING,       // stage timings of gmg_fasta_ingest on stderr
+    GMG_OPT_TRAIN_TIMING,
+    GMG_OPT_DIAG,                // ablation kernels; only in builds with -DGMG_ABLATIONS (their output is NOT valid)
+    GMG_OPT_STRINGS_FUSED,       // gmg_score_reads_strings: 1 = sums folded into the main pass, 0 = value rows + summing kernel
+    GMG_OPT_MG_GENE32,           // glimmer-mg front half: 1 = fp32 gene rows + null applied in the tile (own table only)
+    GMG_OPT_COUNT
+};
+extern long long g_gmg_opt[GMG_OPT_COUNT];
+static inline long long gmg_opt(int k) { return g_gmg_opt[k]; }
+
 // cache of device blocks for scratch and result buffers (gmg_api.hip): hipMalloc / hipFree of GB-sized buffers cost up
 // to hundreds of milliseconds now and then; a released block is handed to the next request it fits
 hipError_t gmg_pool_alloc(void **out, size_t bytes);
 void gmg_pool_release(void *p);
+void gmg_pool_release_after(void *p, hipStream_t s);   // ... once the work queued on s so far is done
 
 // kernel launchers (gmg_kernels.hip)
 int gmg_launch_tile_read(const uint64_t *d_off, uint64_t n_reads, uint64_t n_tiles, uint32_t *d_tile_read,

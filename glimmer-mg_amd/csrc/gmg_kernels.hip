@@ -283,7 +283,7 @@ int gmg_launch_seg_cum(const gmg_model *m, const gmg_reads *r, const gmg_segment
                        double *d_out, double *d_sums, hipStream_t s)
 {
     SegArgs a = make_seg_args(m, r, sg);
-    if (m->dev.has_fast && m->dev.W <= 15 && m->dev.D <= 8 && (size_t)m->dev.P * m->dev.cstride <= 96 * 1024 && !getenv("GMG_SEG_PLAIN")) {
+    if (m->dev.has_fast && m->dev.W <= 15 && m->dev.D <= 8 && (size_t)m->dev.P * m->dev.cstride <= 96 * 1024 && !gmg_opt(GMG_OPT_SEG_PLAIN)) {
         const size_t lds = (size_t)m->dev.P * m->dev.cstride;
         if (lds > 48 * 1024) GMG_HIP(hipFuncSetAttribute((const void *)k_seg_cum_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_seg_cum_fast, dim3(grid_for(a.n_segs, 256)), dim3(256), lds, s, a, frame0, d_out, d_sums);

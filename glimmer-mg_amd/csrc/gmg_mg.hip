@@ -1482,7 +1482,7 @@ struct MgTimer {
     bool on;
     hipStream_t s;
     std::chrono::steady_clock::time_point t0;
-    MgTimer(hipStream_t st) : on(getenv("GMG_MG_TIMING") != nullptr), s(st), t0(std::chrono::steady_clock::now()) {}
+    MgTimer(hipStream_t st) : on(gmg_opt(GMG_OPT_MG_TIMING) != 0), s(st), t0(std::chrono::steady_clock::now()) {}
     void lap(const char *what)
     {
         if (!on) return;
@@ -1652,9 +1652,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (!err_mode && a.n_reads && a.total) {
         // tile shape: two waves and <= 512 bases (12 KB of LDS, many blocks per CU in different phases) when the reads
         // allow it, else eight waves and 1504 bases (39.8 KB, four blocks per CU)
-        const char *env = getenv("GMG_MG_TILE");
+        const long long forced_tile = gmg_opt(GMG_OPT_MG_TILE);
         // (ragged batches: the few reads beyond 512 bases go to the per-lane kernel; measured 9.6 vs 10.6 ms on 1M x ~400 bp)
-        const bool small = env ? atoi(env) == 512 : (reads->max_len <= 512 || (reads->uniform_len == 0 && reads->n_over_512 * 10 <= reads->n_reads));
+        const bool small = forced_tile ? forced_tile == 512 : (reads->max_len <= 512 || (reads->uniform_len == 0 && reads->n_over_512 * 10 <= reads->n_reads));
         const uint32_t cap = small ? 512 : 1504;
         a.tile_cap = (int)cap;
         bool tiled = false, rest = true;
@@ -1727,7 +1727,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     hipEvent_t side_done = nullptr;
     int dev_id = 0;
     MG_TRY(hipGetDevice(&dev_id));
-    if (!find_only && !tm.on && !getenv("GMG_MG_ONE_STREAM") && dev_id >= 0 && dev_id < 16) {
+    if (!find_only && !tm.on && !gmg_opt(GMG_OPT_MG_ONE_STREAM) && dev_id >= 0 && dev_id < 16) {
         if (!side_of[dev_id]) {
             MG_TRY(hipStreamCreateWithFlags(&side_of[dev_id], hipStreamNonBlocking));
             MG_TRY(hipEventCreateWithFlags(&done_of[dev_id], hipEventDisableTiming));
@@ -1744,7 +1744,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     MG_TRY(hipGetLastError());
     rc = mg_scan(d_read_cnt, res->d_read_orf_off, nr, &res->n_orfs, s2);
     if (rc) return fail(rc);
-    if (res->n_orfs >= 0x7fffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
+    if (res->n_orfs > (uint64_t)gmg_opt(GMG_OPT_MG_MAX_ENTRIES))
+        return fail(gmg_set_error(GMG_ETOOBIG, "gmg_mg_score_reads: %llu ORFs in one batch, the result's 32-bit fields hold %lld: split the batch",
+                                  (unsigned long long)res->n_orfs, gmg_opt(GMG_OPT_MG_MAX_ENTRIES)));
     const uint64_t no = res->n_orfs;
     MG_TRY(gmg_pool_alloc((void **)&res->d_orfs, (no ? no : 1) * sizeof(gmg_mg_orf)));
     a.read_orf_off = res->d_read_orf_off;
@@ -1773,7 +1775,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     const int err_acc_only = (prm->flags & GMG_MG_ACCEPTED_ONLY) ? 1 : 0;
     // error branch: 0 = level by level, one lane per call (k_mg_err_level; the default), 1 = one lane per ORF with an explicit stack
     // (k_mg_err_flat: exact slots; the fallback of 0, and on its own with GMG_MG_ERR_FLAT=1 for A/B runs and cross-checks)
-    int err_path = getenv("GMG_MG_ERR_FLAT") ? 1 : 0;
+    int err_path = gmg_opt(GMG_OPT_MG_ERR_FLAT) ? 1 : 0;
     const bool any_unfit = reads->max_len >= 2040;
     if (res->n_orfs && err_mode && err_path == 0) {
         MG_TRY(gmg_pool_alloc((void **)&d_read_fit, nr ? nr : 1));
@@ -1784,7 +1786,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         a.n_calls = (unsigned long long *)(d_err_flag + 2);
         a.tile_ctr = (unsigned long long *)(d_err_flag + 6);
         a.call_cap = a.total / 2 > 65536 ? a.total / 2 : 65536;
-        if (const char *env = getenv("GMG_MG_ERR_CALLS")) a.call_cap = (uint64_t)atoll(env);     // (tests: force the fallback)
+        if (gmg_opt(GMG_OPT_MG_ERR_CALLS) > 0) a.call_cap = (uint64_t)gmg_opt(GMG_OPT_MG_ERR_CALLS);     // (tests: force the fallback)
         MG_TRY(gmg_pool_alloc((void **)&d_calls[0], a.call_cap * sizeof(MgCall)));
         MG_TRY(gmg_pool_alloc((void **)&d_calls[1], a.call_cap * sizeof(MgCall)));
         MG_TRY(gmg_pool_alloc((void **)&d_agg, no * sizeof(MgOrfAgg)));
@@ -1824,7 +1826,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             const uint64_t want = 2 * (asked[0] > asked[1] ? asked[0] : asked[1]) + 65536;
             gmg_pool_release(d_calls[0]); gmg_pool_release(d_calls[1]);
             d_calls[0] = d_calls[1] = nullptr;
-            const bool may_grow = attempt == 0 && want <= 8 * a.total + 65536 && (!getenv("GMG_MG_ERR_CALLS") || getenv("GMG_MG_ERR_CALLS_GROW"));
+            const bool may_grow = attempt == 0 && want <= 8 * a.total + 65536 && (gmg_opt(GMG_OPT_MG_ERR_CALLS) <= 0 || gmg_opt(GMG_OPT_MG_ERR_CALLS_GROW));
             bool grown = false;
             if (may_grow && gmg_pool_alloc((void **)&d_calls[0], want * sizeof(MgCall)) == hipSuccess) {
                 if (gmg_pool_alloc((void **)&d_calls[1], want * sizeof(MgCall)) == hipSuccess) grown = true;
@@ -1837,7 +1839,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             continue;
         }
     }
-    if (res->n_starts >= 0x7fffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
+    if (res->n_starts > (uint64_t)gmg_opt(GMG_OPT_MG_MAX_ENTRIES))
+        return fail(gmg_set_error(GMG_ETOOBIG, "gmg_mg_score_reads: %llu starts in one batch, gmg_mg_orf.start_begin holds %lld: split the batch",
+                                  (unsigned long long)res->n_starts, gmg_opt(GMG_OPT_MG_MAX_ENTRIES)));
     MG_TRY(gmg_pool_alloc((void **)&res->d_starts, (res->n_starts ? res->n_starts : 1) * sizeof(gmg_start)));
     a.start_off = d_start_off;
     a.starts = res->d_starts;
@@ -2021,6 +2025,7 @@ extern "C" int gmg_mg_result_info(const gmg_mg_result *r, uint64_t *n_orfs, uint
 
 extern "C" int gmg_mg_result_fetch_errors(const gmg_mg_result *r, gmg_start_errors *errs)
 {
+    { int rc_enter = gmg_enter("gmg_mg_result_fetch_errors"); if (rc_enter) return rc_enter; }
     if (!r || (r->n_starts && !errs)) return gmg_set_error(GMG_EINVAL, "gmg_mg_result_fetch_errors: NULL argument");
     if (!r->n_starts) return GMG_OK;
     if (!r->d_errs) { memset(errs, 0, r->n_starts * sizeof(gmg_start_errors)); return GMG_OK; }
@@ -2036,6 +2041,7 @@ extern "C" int gmg_mg_result_fetch(const gmg_mg_result *r, gmg_mg_orf *orfs, gmg
 extern "C" int gmg_mg_result_fetch_on(const gmg_mg_result *r, gmg_mg_orf *orfs, gmg_start *starts, uint64_t *read_orf_off,
                                       void *stream)
 {
+    { int rc_enter = gmg_enter("gmg_mg_result_fetch_on"); if (rc_enter) return rc_enter; }
     if (!r || (r->n_orfs && !orfs) || (r->n_starts && !starts)) return gmg_set_error(GMG_EINVAL, "gmg_mg_result_fetch: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     if (r->n_orfs) GMG_HIP(hipMemcpyAsync(orfs, r->d_orfs, r->n_orfs * sizeof(gmg_mg_orf), hipMemcpyDeviceToHost, s));

@@ -32,6 +32,8 @@ struct gmg_orf_batch {
     gmg_start *d_compact;        // the used slots back to back: what leaves the GPU (grown on demand)
     uint64_t compact_cap;
     uint64_t n, max_starts;
+    const gmg_reads *reads;      // the batch the ORFs were validated against (gmg_orfs_upload): gmg_score_orfs takes no other
+    uint64_t reads_total;
 };
 
 struct OrfScanArgs {
@@ -347,6 +349,7 @@ extern "C" int gmg_orfs_upload(const gmg_reads *reads, const gmg_orf *orfs, uint
                                gmg_orf_batch **out)
 {
     if (!reads || (!orfs && n) || !out) return gmg_set_error(GMG_EINVAL, "gmg_orfs_upload: NULL argument");
+    { int rc0 = gmg_enter("gmg_orfs_upload"); if (rc0) return rc0; }
     std::vector<uint64_t> off(reads->n_reads + 1);
     GMG_HIP(hipMemcpy(off.data(), reads->d_off, off.size() * 8, hipMemcpyDeviceToHost));
     std::vector<gmg_segment> segs(n);
@@ -369,12 +372,16 @@ extern "C" int gmg_orfs_upload(const gmg_reads *reads, const gmg_orf *orfs, uint
         segs[i].orient = o.frame > 0 ? GMG_REVERSED : GMG_COMPLEMENTED;     // glimmer3.cc:1328,1339
         start_off[i + 1] = start_off[i] + (uint64_t)o.orf_len / 3 + 2;     // one per in-frame codon + a truncated start
     }
-    if (start_off[n] >= 0xffffffffull || n >= 0x7fffffffull) return gmg_set_error(GMG_EINVAL, "gmg_orfs_upload: batch too large");
+    if (start_off[n] > (uint64_t)gmg_opt(GMG_OPT_MG_MAX_ENTRIES) || n > (uint64_t)gmg_opt(GMG_OPT_MG_MAX_ENTRIES))
+        return gmg_set_error(GMG_ETOOBIG, "gmg_orfs_upload: %llu ORFs with room for %llu starts, gmg_orf_result.start_begin holds %lld: split the batch",
+                             (unsigned long long)n, (unsigned long long)start_off[n], gmg_opt(GMG_OPT_MG_MAX_ENTRIES));
     gmg_orf_batch *b = new (std::nothrow) gmg_orf_batch();
     if (!b) return gmg_set_error(GMG_ENOMEM, "gmg_orfs_upload: out of host memory");
     memset(b, 0, sizeof *b);
     b->n = n;
     b->max_starts = start_off[n];
+    b->reads = reads;
+    b->reads_total = reads->total_bases;
     int rc = gmg_segments_upload(reads, segs.data(), n, nullptr, nullptr, &b->segs);
     if (rc) { delete b; return rc; }
     hipError_t e = hipMalloc((void **)&b->d_orfs, (n ? n : 1) * sizeof(gmg_orf));
@@ -417,25 +424,41 @@ extern "C" int gmg_score_orfs(const gmg_model *gene, const gmg_model *nul, const
     // Cumulative_Score(buff, score, 1): frame 1 needs periodicity 1 or > 1 (src/ICM/icm.cc:367-369)
     if ((gene->dev.P != 1 && gene->dev.P < 2) || (nul->dev.P != 1 && nul->dev.P < 2))
         return gmg_set_error(GMG_EBADMODEL, "gmg_score_orfs: frame 1 outside the models' periodicity");
+    if (b->reads != reads || b->reads_total != reads->total_bases)
+        return gmg_set_error(GMG_EINVAL, "gmg_score_orfs: `reads` is not the batch these ORFs were uploaded against");
+    { int rc0 = gmg_enter("gmg_score_orfs"); if (rc0) return rc0; }
     if (b->n == 0) return GMG_OK;
     hipStream_t s = (hipStream_t)stream;
     gmg_orf_batch *mb = const_cast<gmg_orf_batch *>(b);            // scratch is allocated on first use
     const bool fused = gene->dev.has_fast && gene->dev.D == 7 && gene->dev.P == 3 && gene->dev.W >= 3 && gene->dev.W <= 15 &&
-                       nul->dev.has_dense && nul->dev.W == 3 && nul->dev.P == 3 && !getenv("GMG_ORFS_EXACT_PATH");
+                       nul->dev.has_dense && nul->dev.W == 3 && nul->dev.P == 3 && !gmg_opt(GMG_OPT_ORFS_EXACT_PATH);
     if (fused) {
-        if (!mb->d_gene6) {
-            hipError_t e = hipMalloc((void **)&mb->d_gene6, (size_t)6 * reads->total_bases * sizeof(float));
-            if (e == hipSuccess) e = hipMalloc((void **)&mb->d_tmp, (b->max_starts ? b->max_starts : 1) * sizeof(OrfTmp));
-            if (e != hipSuccess) return gmg_set_error(GMG_ENOMEM, "gmg_score_orfs: scratch: %s", hipGetErrorString(e));
+        if (!mb->d_gene6 || !mb->d_tmp) {                          // both or neither: a failed second allocation leaves nothing behind
+            float *g6 = nullptr;
+            OrfTmp *tmp = nullptr;
+            hipError_t e = hipMalloc((void **)&g6, (size_t)6 * reads->total_bases * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc((void **)&tmp, (b->max_starts ? b->max_starts : 1) * sizeof(OrfTmp));
+            if (e != hipSuccess) {
+                if (g6) (void)hipFree(g6);
+                return gmg_set_error(GMG_ENOMEM, "gmg_score_orfs: scratch: %s", hipGetErrorString(e));
+            }
+            mb->d_gene6 = g6;
+            mb->d_tmp = tmp;
         }
         int rc = gmg_launch_gene6(gene, reads, mb->d_gene6, s);
         if (rc) return gmg_set_error(rc, "gmg_score_orfs: gene-only pass refused the model");
     } else {
         const size_t tl = b->segs->total_len;
-        if (!mb->d_score) {
-            hipError_t e = hipMalloc((void **)&mb->d_score, (tl ? tl : 1) * 8);
-            if (e == hipSuccess) e = hipMalloc((void **)&mb->d_indep, (tl ? tl : 1) * 8);
-            if (e != hipSuccess) return gmg_set_error(GMG_ENOMEM, "gmg_score_orfs: scratch: %s", hipGetErrorString(e));
+        if (!mb->d_score || !mb->d_indep) {
+            double *sc = nullptr, *in = nullptr;
+            hipError_t e = hipMalloc((void **)&sc, (tl ? tl : 1) * 8);
+            if (e == hipSuccess) e = hipMalloc((void **)&in, (tl ? tl : 1) * 8);
+            if (e != hipSuccess) {
+                if (sc) (void)hipFree(sc);
+                return gmg_set_error(GMG_ENOMEM, "gmg_score_orfs: scratch: %s", hipGetErrorString(e));
+            }
+            mb->d_score = sc;
+            mb->d_indep = in;
         }
         int rc = gmg_launch_seg_cum(gene, reads, b->segs, gene->dev.P == 1 ? 0 : 1, b->d_score, nullptr, s);
         if (rc) return rc;

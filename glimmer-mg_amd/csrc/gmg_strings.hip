@@ -174,6 +174,7 @@ __global__ __launch_bounds__(64) void k_string_sum(StringSumArgs a)
 extern "C" int gmg_score_reads_strings(const gmg_model *const *models, int n_models, const gmg_reads *reads,
                                        double *d_sums, void *stream)
 {
+    { int rc_enter = gmg_enter("gmg_score_reads_strings"); if (rc_enter) return rc_enter; }
     if (!models || n_models < 0 || !reads || (!d_sums && n_models && reads->n_reads))
         return gmg_set_error(GMG_EINVAL, "gmg_score_reads_strings: NULL argument");
     hipStream_t s = (hipStream_t)stream;

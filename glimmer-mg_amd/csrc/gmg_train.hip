@@ -197,8 +197,8 @@ __global__ __launch_bounds__(SORT_NT) void k_train_count_sorted(const uint32_t *
 
 size_t sort_min_bases(void)
 {
-    const char *e = getenv("GMG_TRAIN_SORT_MIN");      // read per call: tests switch paths inside one process
-    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 16;
+    const long long v = gmg_opt(GMG_OPT_TRAIN_SORT_MIN);          // gmg_set_option("train_sort_min", ..): tests switch paths
+    return v >= 0 ? (size_t)v : (size_t)1 << 16;
 }
 
 int level_first(int level)   // (4^level - 1) / 3
@@ -213,6 +213,7 @@ int level_first(int level)   // (4^level - 1) / 3
 extern "C" int gmg_trainer_create(const gmg_reads *strings, int model_len, int model_depth, int periodicity,
                                   gmg_trainer **out)
 {
+    { int rc_enter = gmg_enter("gmg_trainer_create"); if (rc_enter) return rc_enter; }
     if (!strings || !out) return gmg_set_error(GMG_EINVAL, "gmg_trainer_create: NULL argument");
     if (model_len < 1 || model_len > GMG_MAX_MODEL_LEN || model_depth < 0 || model_depth > 12 || periodicity < 1)
         return gmg_set_error(GMG_EBADMODEL, "gmg_trainer_create: model_len %d (1..%d), model_depth %d (0..12), "
@@ -271,6 +272,7 @@ extern "C" int gmg_trainer_free(gmg_trainer *t)
 
 extern "C" int gmg_trainer_level_counts(gmg_trainer *t, int level, const int16_t *mip_prev, int32_t *counts)
 {
+    { int rc_enter = gmg_enter("gmg_trainer_level_counts"); if (rc_enter) return rc_enter; }
     if (!t || !counts) return gmg_set_error(GMG_EINVAL, "gmg_trainer_level_counts: NULL argument");
     if (level != t->next_level || level > t->D)
         return gmg_set_error(GMG_EINVAL, "gmg_trainer_level_counts: level %d asked, level %d is next (levels go in "

@@ -340,7 +340,9 @@ bool  ICM_Training_t :: Try_Train_Model
    Invalidate_Device_Mirror ();
 
    //  GMG_TRAIN_TIMING=1: wall time of every stage on stderr
-   const bool  timing = (getenv ("GMG_TRAIN_TIMING") != NULL);
+   long long  timing_opt = 0;
+   gmg_get_option ("train_timing", & timing_opt);
+   const bool  timing = (timing_opt != 0);
    chrono :: steady_clock :: time_point  t_prev = chrono :: steady_clock :: now ();
    auto  lap = [&] (const char * what, int level)
      {

@@ -40,7 +40,10 @@ typedef enum gmg_status {
     GMG_ENOMEM = -3,     /* host or device allocation failed                              */
     GMG_EHIP = -4,       /* a HIP call failed; text in gmg_last_error()                   */
     GMG_EBADMODEL = -5,  /* model parameters outside what the kernels support             */
-    GMG_ERANGE = -6      /* a segment / window reaches outside its read                   */
+    GMG_ERANGE = -6,     /* a segment / window reaches outside its read                   */
+    GMG_ETOOBIG = -7     /* the batch would hold more ORFs or starts than the 32-bit index fields of the result
+                            records address (gmg_mg_orf.start_begin, gmg_orf_result.start_begin): nothing wraps,
+                            the call refuses -- score the reads in smaller batches (gmg_shard_plan)              */
 } gmg_status;
 
 typedef struct gmg_model gmg_model;       /* device copy of one ICM_t table set  */
@@ -79,6 +82,12 @@ int gmg_device_count(void);
 const char *gmg_last_error(void);
 const char *gmg_version(void);
 int gmg_synchronize(void *stream);
+/* Tuning and test switches (nothing a caller needs for correct results): `key` is one of seg_plain, mg_tile, mg_one_stream,
+ * mg_err_flat, mg_err_calls, mg_err_calls_grow, orfs_exact_path, train_sort_min, mg_max_entries, mg_timing, ingest_timing,
+ * train_timing, strings_fused, mg_gene32, diag.  gmg_init() reads GMG_<KEY IN UPPER CASE> from the
+ * environment ONCE; no scoring call reads the environment. */
+int gmg_set_option(const char *key, long long value);
+int gmg_get_option(const char *key, long long *value);
 
 /* ---- host-side packing helpers (no GPU needed) ---------------------------- */
 
@@ -376,6 +385,23 @@ int gmg_fasta_info(const gmg_fasta *index, uint64_t *n_reads, uint64_t *total_ba
 /* hdr string of read i = bytes[hdr_begin[i] .. hdr_end[i])  (HOST arrays of n_reads entries) */
 int gmg_fasta_headers(const gmg_fasta *index, uint64_t *hdr_begin, uint64_t *hdr_end);
 int gmg_fasta_free(gmg_fasta *index);
+
+/* ---- one job over several GPUs / several batches (host only) -----------------------------------
+ * Reads shard embarrassingly: every sequence is scored on its own (src/Glimmer/glimmer3.cc:262-310,
+ * glimmer-mg.cc:361-451); the one run-wide quantity is the null model's GC fraction, a ratio of two counts over all
+ * bases (Set_GC_Fraction, src/Glimmer/glimmer_base.cc:2564-2595).  One process per GPU takes a contiguous range of
+ * reads of about equal BASE count, the per-shard {gc, total} counts are summed on the host, results are concatenated
+ * in shard order; inside a shard the same plan cuts batches that fit the 32-bit fields of the result records. */
+/* read_begin[k] .. read_begin[k+1] = reads of shard k (n_shards + 1 entries); cut k at the read boundary nearest to
+ * k * total_bases / n_shards. */
+int gmg_shard_plan(const uint64_t *base_offsets, uint64_t n_reads, int n_shards, uint64_t *read_begin);
+/* The same on the bytes of an unparsed FASTA file: cuts[k] = the first certain record start ('>' behind a newline) at
+ * or behind k * n_bytes / n_shards; cuts[0] = 0, cuts[n_shards] = n_bytes.  Every shard is a valid input of
+ * gmg_fasta_ingest / gmg_fasta_split. */
+int gmg_fasta_shard_ranges(const char *bytes, uint64_t n_bytes, int n_shards, uint64_t *cuts);
+/* Indep_GC_Frac from per-shard counts (gmg_fasta_info).  as_reference != 0: the reference's `unsigned int` counters,
+ * which wrap beyond 2^32 bases (byte-identical output on such files); 0: 64-bit counts. */
+double gmg_gc_fraction(const uint64_t *gc_counts, const uint64_t *base_counts, int n_shards, int as_reference);
 
 /* ---- build-icm: training counts on the device ---------------------------------------
  * Replaces the counting of ICM_Training_t: Count_Char_Pairs for the roots (src/ICM/icm.cc:1841-1870, called from

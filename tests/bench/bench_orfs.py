@@ -46,10 +46,7 @@ api._ck(lib.gmg_orfs_upload(reads.h, api._ptr(o), len(o), C.byref(max_starts), C
 
 
 def run(exact):
-    if exact:
-        os.environ["GMG_ORFS_EXACT_PATH"] = "1"
-    else:
-        os.environ.pop("GMG_ORFS_EXACT_PATH", None)
+    api.set_option("orfs_exact_path", 1 if exact else 0)
     res = np.zeros(len(o), api.ORF_RESULT_DTYPE)
     starts = np.zeros(max(int(max_starts.value), 1), api.START_DTYPE)
     call = lambda: api._ck(lib.gmg_score_orfs(gene.device(), indep.device(), reads.h, batch, C.byref(prm),

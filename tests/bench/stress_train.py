@@ -37,7 +37,7 @@ for trial in range(trials):
             unit = s[:int(rng.integers(1, 9))]
             s = np.tile(unit, k // len(unit) + 1)[:k]
         strings.append(s.tobytes())
-    os.environ["GMG_TRAIN_SORT_MIN"] = "0" if trial % 2 else str(2 ** 40)
+    gmg.set_option("train_sort_min", 0 if trial % 2 else 2 ** 40)
     t0 = time.perf_counter()
     want = orc.train_model(strings, W, D, P)
     t_cpu += time.perf_counter() - t0

@@ -39,6 +39,15 @@ def gpu(gmg):
     return gmg
 
 
+@pytest.fixture
+def request_finalizers():
+    """callbacks run after the test (library switches set with gmg_set_option go back to their defaults)"""
+    todo = []
+    yield todo
+    for f in reversed(todo):
+        f()
+
+
 @pytest.fixture(scope="session")
 def seqs_fa(gmg):
     hdrs, seqs = gmg.read_fasta(os.path.join(DATA, "seqs.fa"))

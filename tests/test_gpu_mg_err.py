@@ -62,15 +62,18 @@ def test_error_branch_matches_reference_push_order(gpu, oracle, nc, name):
 ])
 @pytest.mark.parametrize("kw", [dict(), dict(allow_truncated=False, min_gene_len=60), dict(ignore_score_len=150, start_codons=("atg", "rtg"))])
 @pytest.mark.parametrize("path", ["level", "flat", "level-overflow", "level-grow"])
-def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path, monkeypatch):
+def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path, monkeypatch, request_finalizers):
     """path: level by level with one lane per call and the sort into push order (the default; the 2100-bp read goes to the
     per-ORF kernel), the per-ORF kernel alone, the default with call arrays too small (everything repeats on the per-ORF
     kernel), and the same with the arrays allowed to grow (the count pass repeats with larger ones)"""
-    env = {"flat": "GMG_MG_ERR_FLAT", "level-overflow": "GMG_MG_ERR_CALLS", "level-grow": "GMG_MG_ERR_CALLS"}
-    if path in env:
-        monkeypatch.setenv(env[path], "1" if path == "flat" else "7")
+    opt = {"flat": "mg_err_flat", "level-overflow": "mg_err_calls", "level-grow": "mg_err_calls"}
+    if path in opt:
+        old = gpu.get_option(opt[path])
+        gpu.set_option(opt[path], 1 if path == "flat" else 7)
+        request_finalizers.append(lambda: gpu.set_option(opt[path], old))
     if path == "level-grow":
-        monkeypatch.setenv("GMG_MG_ERR_CALLS_GROW", "1")
+        gpu.set_option("mg_err_calls_grow", 1)
+        request_finalizers.append(lambda: gpu.set_option("mg_err_calls_grow", 0))
     rng = np.random.default_rng(99)
     lengths = [0, 1, 5, 14, 15, 16, 17, 18, 33, 74, 75, 76, 99, 150, 231, 300, 301, 302, 400, 523, 700]
     seqs = ["".join("acgt"[c] for c in rng.integers(0, 4, size=n)) for n in lengths]
@@ -153,11 +156,8 @@ def test_error_branch_full_size_properties(gpu, oracle, nc):
     sub_packed, _ = gpu.synth.packed_reads(1, int(off[m]), 7)       # same generator, same seed: the first off[m] bases
     sub = gpu.Reads(sub_packed, off[:m + 1].copy())
     a = gpu.mg_score_reads(nc, indep, sub, allow_indels=True, accepted_only=True)
-    os.environ["GMG_MG_ERR_FLAT"] = "1"
-    try:
+    with gpu.option("mg_err_flat", 1):
         b = gpu.mg_score_reads(nc, indep, sub, allow_indels=True, accepted_only=True)
-    finally:
-        del os.environ["GMG_MG_ERR_FLAT"]
     for x, y in zip(a, b):
         assert x.tobytes() == y.tobytes()
     k = int(first[m])

@@ -101,6 +101,34 @@ def test_frame6_synthetic_reads_vs_oracle(gpu, nc, oracle, o_nc):
     assert np.array_equal(out, exp)
 
 
+@pytest.mark.parametrize("n,L", [(4000, 500), (3000, 293), (1500, 1000), (700, 2049), (300, 4100), (5000, 400)])
+def test_frame6_uniform_batches_vs_oracle(gpu, nc, oracle, o_nc, n, L):
+    """uniform batches of several read lengths (read boundaries at every phase of the 2,048-base chunks): sampled reads equal the
+    oracle's table, and the call is deterministic"""
+    packed, off = gpu.synth.packed_reads(n, L, 77 + L)
+    reads = gpu.Reads(packed, off)
+    indep = gpu.Icm.indep(0.47)
+    a = gpu.frame_score6(nc, indep, reads)
+    assert a.tobytes() == gpu.frame_score6(nc, indep, reads).tobytes()
+    o_indep = oracle.indep(0.47)
+    for r in (0, 1, 7, n // 2, n - 2, n - 1):
+        s = gpu.synth.unpack_ascii(packed, r * L, L)
+        assert np.array_equal(a[:, r * L:(r + 1) * L], oracle.score_all_frames(o_nc, o_indep, s)), r
+
+
+def test_options_api(gpu):
+    assert gpu.get_option("strings_fused") == 1
+    with gpu.option("mg_tile", 512):
+        assert gpu.get_option("mg_tile") == 512
+    assert gpu.get_option("mg_tile") == 0
+    with pytest.raises(gpu.GmgError):
+        gpu.set_option("no_such_switch", 1)
+    with pytest.raises(gpu.GmgError):
+        gpu.set_option("diag", 1)                       # the ablation kernels are not in the product build
+    with pytest.raises(gpu.GmgError):
+        gpu.set_option("mg_max_entries", 2 ** 31)
+
+
 def test_frame6_generic_shapes_use_same_answers(gpu, oracle):
     """period-1 Phymm-style models are refused (Frame_Score would assert); a (3,2,3) model as the
     'gene' model exercises the non-default shape path."""
@@ -262,14 +290,12 @@ def test_frame6_full_size_properties(gpu, nc, oracle, o_nc):
 @pytest.mark.parametrize("name,kw", [("orfs_default", {}), ("orfs_X", {"allow_truncated": True}),
                                      ("orfs_g90_first", {"min_gene_len": 90, "use_first_start": True})])
 @pytest.mark.parametrize("path", ["fused", "exact"])
-def test_score_orfs_golden_start_lists(gpu, nc, fa_reads, name, kw, path, monkeypatch):
+def test_score_orfs_golden_start_lists(gpu, nc, fa_reads, name, kw, path, request_finalizers):
     """ORFs from the reference's Find_Orfs on seqs.fa; start lists, gene score and gene length must equal
     what the reference's Score_Orfs handed to Add_Events_* (tests/golden/orfs_*.npz), bit for bit --
     through the fused path (gene-only six-frame pass + k_orf_fused) and the exact any-model path."""
-    if path == "exact":
-        monkeypatch.setenv("GMG_ORFS_EXACT_PATH", "1")
-    else:
-        monkeypatch.delenv("GMG_ORFS_EXACT_PATH", raising=False)
+    gpu.set_option("orfs_exact_path", 1 if path == "exact" else 0)
+    request_finalizers.append(lambda: gpu.set_option("orfs_exact_path", 0))
     g = np.load(os.path.join(GOLD, name + ".npz"))
     gc = float(np.load(os.path.join(GOLD, "frames_nc.npz"))["gc"])
     res, starts = gpu.score_orfs(nc, gpu.Icm.indep(gc), fa_reads, g["orfs"], **kw)
@@ -288,13 +314,11 @@ def test_score_orfs_golden_start_lists(gpu, nc, fa_reads, name, kw, path, monkey
 
 
 @pytest.mark.parametrize("path", ["fused", "exact"])
-def test_score_orfs_random_orfs_on_ragged_reads_vs_oracle(gpu, nc, oracle, o_nc, path, monkeypatch):
+def test_score_orfs_random_orfs_on_ragged_reads_vs_oracle(gpu, nc, oracle, o_nc, path, request_finalizers):
     """random in-range ORFs (both strands, lengths 3..read length, also not a multiple of 3) on reads of ragged lengths:
     every field of every start and of the per-ORF result must equal the oracle's Score_Orfs restatement"""
-    if path == "exact":
-        monkeypatch.setenv("GMG_ORFS_EXACT_PATH", "1")
-    else:
-        monkeypatch.delenv("GMG_ORFS_EXACT_PATH", raising=False)
+    gpu.set_option("orfs_exact_path", 1 if path == "exact" else 0)
+    request_finalizers.append(lambda: gpu.set_option("orfs_exact_path", 0))
     rng = np.random.default_rng(77)
     lengths = [int(x) for x in rng.integers(40, 900, size=120)] + [12, 13, 30, 500, 2100]
     seqs = ["".join("acgt"[c] for c in rng.integers(0, 4, size=n)) for n in lengths]

@@ -79,14 +79,10 @@ def test_reference_build_icm_cli_on_our_icm_hh(case, tmp_path):
 @pytest.fixture(params=["atomics", "sorted"])
 def deep_level_path(request):
     """both ways of counting the levels that do not fit LDS: direct device-wide atomics (small training sets) and the
-    sort by table + LDS counting (big ones); GMG_TRAIN_SORT_MIN is the size, in bases, where the library switches"""
-    old = os.environ.get("GMG_TRAIN_SORT_MIN")
-    os.environ["GMG_TRAIN_SORT_MIN"] = "0" if request.param == "sorted" else str(2 ** 40)
-    yield request.param
-    if old is None:
-        del os.environ["GMG_TRAIN_SORT_MIN"]
-    else:
-        os.environ["GMG_TRAIN_SORT_MIN"] = old
+    sort by table + LDS counting (big ones); the option train_sort_min is the size, in bases, where the library switches"""
+    gmg = request.getfixturevalue("gpu")
+    with gmg.option("train_sort_min", 0 if request.param == "sorted" else 2 ** 40):
+        yield request.param
 
 
 def random_strings(rng, n, max_len, extra=()):
