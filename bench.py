@@ -8,19 +8,23 @@
 One "step" = one pass of the hot path (gmg_frame_score6, include/gmg.h) over one rank's shard of
 synthetic reads already resident in HBM: 1M x 500 bp per GPU (BASELINE.json configs[1]); with N > 1
 every rank scores its own shard (weak scaling, no collective in the data path -- reads shard
-embarrassingly).  Rank 0 prints ONE JSON line.
+embarrassingly).  `--scaling strong` keeps the job fixed instead: --reads reads in total, cut over
+the ranks by gmg_shard_plan (contiguous ranges of equal base count).  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      dominant kernel (k_frame6) vs the HBM roof: achieved = 48.25 algorithmic bytes per base
-                (0.25 B packed input + 6 x 8 B fp64 Frame_Scores) x bases per launch / mean
-                launch duration measured with HIP events on the launch stream.
+  roofline      dominant kernels (k_frame6t + k_frame6p, one call) vs the HBM roof: achieved = 48.25 algorithmic
+                bytes per base (0.25 B packed input + 6 x 8 B fp64 Frame_Scores) x bases per call /
+                MEDIAN call duration over the timed steps, measured with HIP events on the launch stream.
                 roofline.measured_fill_GBps = what a plain fill of a same-sized buffer reaches on this GPU (a
                 write-only stream's practical ceiling; reported beside, never instead of, the 8 TB/s peak).
-                The same leg is the run's checker: `check` compares the XOR of all 6 x L x sample output doubles on the
-                device with the CPU's.
+  check         the device table against the CPU on the FIRST and the LAST --cpu-reads reads of rank 0's shard: XOR
+                of all output doubles and a position-weighted sum (a permuted or shifted table fails it).  A mismatch
+                nulls `value` and the process exits 1.  With N > 1 rank 0 checks 2,000 + 2,000 reads after the timed region.
   cpu_baseline  the same six-frame loop timed on this box's host cores on a bounded sample of the same
-                reads: the real reference's ICM_t (oracle/_ref/ref_bench, "reference") when that build
-                is present, else the plain-C oracle ("port").  Rank 0, N = 1 only.
+                reads: the real reference's ICM_t (oracle/_ref/ref_bench, "reference") when that build is present,
+                else the plain-C oracle ("port").  `value` is ONE core (the reference is single-threaded);
+                `all_cores` runs one process per host core on disjoint slices (process sharding).  Rank 0, N = 1 only.
+  cli_end_to_end  FASTA file -> .predict, the reference CLI against integration/glimmer-mg_gpu (N = 1, when both are built).
 """
 import argparse
 import json
@@ -36,6 +40,7 @@ ALGO_BYTES_PER_BASE = 0.25 + 6 * 8.0
 HBM_PEAK_GBPS = 8000.0                    # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 SEED = 20260101
 MODEL = os.path.join(ROOT, "tests", "golden", "data", "NC_000915.icm")
+REF_BENCH = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -43,7 +48,7 @@ MODEL = os.path.join(ROOT, "tests", "golden", "data", "NC_000915.icm")
 # ----------------------------------------------------------------------------------------------
 
 def shard_plan(total_reads, world):
-    """contiguous read ranges per rank (strong-scaling helper, also used by the tests)"""
+    """contiguous read ranges per rank for reads of ONE length (the general, base-balanced plan is gmg_shard_plan)"""
     base, extra = divmod(total_reads, world)
     out, lo = [], 0
     for r in range(world):
@@ -81,27 +86,23 @@ def timed_region(step, steps, warmup, sync, dist=None):
     return worst, mine
 
 
-def aggregate(units_per_rank_per_step, world, steps, seconds):
+def aggregate(units_per_step_all_ranks, steps, seconds):
     """whole-job throughput: units all ranks processed in the timed region / max-over-ranks time"""
-    return units_per_rank_per_step * world * steps / seconds
+    return units_per_step_all_ranks * steps / seconds
 
 
 # ----------------------------------------------------------------------------------------------
 # CPU baseline (test infrastructure: oracle/_ref or the oracle port; never the product)
 # ----------------------------------------------------------------------------------------------
 
-def cpu_baseline(n_reads, L, seed, gc, packed):
-    ref = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
-    sample = "first %d of the rank-0 reads (%d x %d bp, same seed)" % (n_reads, n_reads, L)
-    if os.access(ref, os.X_OK):
-        try:
-            res = subprocess.run([ref, MODEL, str(n_reads), str(L), str(seed), repr(float(gc))],
-                                 check=True, stdout=subprocess.PIPE, timeout=600)
-            j = json.loads(res.stdout)
-            return {"value": round(j["mbases_per_s"], 4), "unit": "Mbases/s", "cores": 1, "kind": "reference",
-                    "sample": sample, "seconds": j["seconds"], "xor": j["xor"]}
-        except Exception as e:          # fall through to the port, but say why
-            sys.stderr.write("bench: oracle/_ref/ref_bench failed (%s); timing the oracle port\n" % e)
+def ref_bench(first_read, n_reads, L, seed, gc):
+    res = subprocess.run([REF_BENCH, MODEL, str(n_reads), str(L), str(seed), repr(float(gc)), str(first_read)],
+                         check=True, stdout=subprocess.PIPE, timeout=900)
+    return json.loads(res.stdout)
+
+
+def port_bench(first_read, n_reads, L, seed, gc, packed):
+    """the plain-C oracle on reads [first_read, first_read + n_reads) of the packed stream -> the same fields as ref_bench"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_py
@@ -109,13 +110,69 @@ def cpu_baseline(n_reads, L, seed, gc, packed):
     gmg = _gmg_pkg.load()
     orc = oracle_py.load()
     gene, indep = orc.read(MODEL), orc.indep(gc)
-    ascii_all = gmg.synth.unpack_ascii(packed, 0, n_reads * L)
+    ascii_all = gmg.synth.unpack_ascii(packed, first_read * L, n_reads * L)
     t0 = time.perf_counter()
-    out = orc.score_reads_6frame(gene, indep, ascii_all, n_reads, L)
+    out = orc.score_reads_6frame(gene, indep, ascii_all, n_reads, L)          # [n, 6, L]
     dt = time.perf_counter() - t0
-    x = np.bitwise_xor.reduce(out.view(np.uint64).ravel())
-    return {"value": round(n_reads * L / dt / 1e6, 4), "unit": "Mbases/s", "cores": 1, "kind": "port",
-            "sample": sample, "seconds": dt, "xor": "%016x" % int(x)}
+    bits = np.ascontiguousarray(out.transpose(1, 0, 2)).view(np.uint64).ravel()   # [6][n * L]: the sample's table layout
+    with np.errstate(over="ignore"):
+        mix = int((bits * (2 * np.arange(bits.size, dtype=np.uint64) + 1)).sum(dtype=np.uint64))
+    return {"bases": n_reads * L, "seconds": dt, "mbases_per_s": n_reads * L / dt / 1e6,
+            "xor": "%016x" % int(np.bitwise_xor.reduce(bits)), "mix": "%016x" % mix}
+
+
+def cpu_sample(stream_first_read, local_first_read, n_reads, L, seed, gc, packed):
+    """reads [stream_first_read, +n_reads) of the stream of `seed` = reads [local_first_read, +n_reads) of `packed`
+    -> (result dict, kind)"""
+    if os.access(REF_BENCH, os.X_OK):
+        try:
+            return ref_bench(stream_first_read, n_reads, L, seed, gc), "reference"
+        except Exception as e:          # fall through to the port, but say why
+            sys.stderr.write("bench: oracle/_ref/ref_bench failed (%s); timing the oracle port\n" % e)
+    return port_bench(local_first_read, n_reads, L, seed, gc, packed), "port"
+
+
+def cpu_all_cores(n_reads_each, L, seed, gc):
+    """one ref_bench process per host core, each on its own slice of the stream; wall time of all of them"""
+    cores = len(os.sched_getaffinity(0))
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([REF_BENCH, MODEL, str(n_reads_each), str(L), str(seed), repr(float(gc)), str(c * n_reads_each)],
+                              stdout=subprocess.PIPE) for c in range(cores)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    wall = time.perf_counter() - t0
+    if any(p.returncode != 0 for p in procs):
+        return None
+    secs = [json.loads(o)["seconds"] for o in outs]         # each process times its scoring loop alone (no start-up, no model load)
+    return {"value": round(cores * n_reads_each * L / max(secs) / 1e6, 3), "unit": "Mbases/s", "cores": cores,
+            "sample": "%d concurrent processes x %d reads x %d bp, disjoint slices of the same stream; all bases / the slowest "
+                      "process's scoring time" % (cores, n_reads_each, L),
+            "slowest_scoring_seconds": round(max(secs), 3), "wall_seconds_with_startup": round(wall, 3)}
+
+
+def device_digest(out, total, first_read, n_reads, L):
+    """XOR and position-weighted sum of the sample's slice of the device table, computed on the device"""
+    import torch
+    v = out.view(6, total)[:, first_read * L:(first_read + n_reads) * L].contiguous().view(torch.int64).ravel()
+    w = 2 * torch.arange(v.numel(), dtype=torch.int64, device=v.device) + 1
+    mix = int((v * w).sum().item()) & (2 ** 64 - 1)                       # int64 arithmetic wraps: mod 2^64
+    x = v.cpu().numpy().view("uint64")
+    import numpy as np
+    return "%016x" % int(np.bitwise_xor.reduce(x)), "%016x" % mix
+
+
+def cli_end_to_end(n_reads=20000):
+    exe = os.path.join(ROOT, "integration", "_build", "glimmer-mg_gpu")
+    ref = os.path.join(ROOT, "oracle", "_ref", "glimmer-mg")
+    if not (os.access(exe, os.X_OK) and os.access(ref, os.X_OK)):
+        return None
+    try:
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench", "bench_cli.py"), str(n_reads)],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, BENCH_CLI_SKIP_G3="1"))
+        j = json.loads(res.stdout.decode().strip().splitlines()[-1])
+        return {k: j[k] for k in ("reads", "predict_identical", "reference_cli_s", "reference_cli_mbases_per_s",
+                                  "device_front_half_cli_s", "device_front_half_cli_mbases_per_s")}
+    except Exception as e:
+        return {"error": str(e)[:200]}
 
 
 # ----------------------------------------------------------------------------------------------
@@ -123,11 +180,13 @@ def cpu_baseline(n_reads, L, seed, gc, packed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (weak) / in total (strong)")
     ap.add_argument("--length", type=int, default=500)
-    ap.add_argument("--cpu-reads", type=int, default=20_000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--cpu-reads", type=int, default=20_000, help="reads in each CPU sample (0 = no CPU legs, no check)")
+    ap.add_argument("--no-cli", action="store_true", help="skip the CLI end-to-end leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -153,18 +212,33 @@ def main():
     gmg.build.build_lib()
     gmg.init(local_rank)                      # raises if there is no gfx950 device: no fallback
 
-    n, L = args.reads, args.length
-    seed = SEED + rank                        # every rank has its own shard of the job
-    packed, off = gmg.synth.packed_reads(n, L, seed)
+    L = args.length
+    if args.scaling == "weak":
+        n, seed, first_base = args.reads, SEED + rank, 0        # every rank has its own shard of the job
+        packed, off = gmg.synth.packed_reads(n, L, seed)
+        job_reads = n * world
+    else:                                     # one job of --reads reads, cut by gmg_shard_plan (equal base counts)
+        job_off = np.arange(args.reads + 1, dtype=np.uint64) * np.uint64(L)
+        plan = gmg.shard.shard_plan(job_off, world)
+        lo, hi = int(plan[rank]), int(plan[rank + 1])
+        n, seed, first_base = hi - lo, SEED, lo * L
+        packed, off = gmg.synth.packed_reads_range(first_base, n * L, L, seed)
+        job_reads = args.reads
     total = n * L
-    # null-model GC the way Set_GC_Fraction computes it (glimmer_base.cc:2564-2595): count of g/c over all bases
+    # null-model GC the way Set_GC_Fraction computes it (glimmer_base.cc:2564-2595): count of g/c over all bases of the JOB:
+    # per-shard {gc, total} counts, summed over the ranks (two integers each; shard.allreduce_counts)
     codes = np.unpackbits(packed[:(total + 15) // 16].view(np.uint8), bitorder="little").reshape(-1, 2)
-    gc = float(np.count_nonzero(codes[:total, 0] != codes[:total, 1])) / total     # c=01, g=10 (LSB first)
+    gc_count = int(np.count_nonzero(codes[:total, 0] != codes[:total, 1]))        # c=01, g=10 (LSB first)
     del codes
+    if args.scaling == "strong":
+        gcs, totals = gmg.shard.allreduce_counts(dist if world > 1 else None, gc_count, total)
+        gc = gmg.shard.gc_fraction(gcs, totals, as_reference=False)
+    else:
+        gc = gc_count / max(total, 1)
     gene = gmg.Icm.open(MODEL)
     indep = gmg.Icm.indep(gc)
     reads = gmg.Reads(packed, off)
-    out = torch.empty(6 * total, dtype=torch.float64, device="cuda")
+    out = torch.empty(6 * max(total, 1), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
@@ -178,8 +252,9 @@ def main():
         ev.append((a, b))
 
     seconds, _ = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, dist)
-    timed = ev[args.warmup:]
-    kern_ms = sum(a.elapsed_time(b) for a, b in timed) / max(len(timed), 1)
+    per_call = sorted(a.elapsed_time(b) for a, b in ev[args.warmup:])
+    kern_ms = per_call[len(per_call) // 2] if per_call else 0.0               # MEDIAN of the timed calls
+    kern_min, kern_max = (per_call[0], per_call[-1]) if per_call else (0.0, 0.0)
     if dist is not None:
         t = torch.tensor([kern_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -202,11 +277,10 @@ def main():
         fill_gbps = probe.numel() * 8 / (best * 1e-3) / 1e9
         del probe
 
-    check = None                                      # filled by the cpu_baseline leg below
-
+    ok = True
     if rank == 0:
-        value = aggregate(total, world, args.steps, seconds) / 1e6
-        achieved = ALGO_BYTES_PER_BASE * total / (kern_ms * 1e-3) / 1e9
+        value = aggregate(job_reads * L, args.steps, seconds) / 1e6
+        achieved = ALGO_BYTES_PER_BASE * total / (kern_ms * 1e-3) / 1e9 if kern_ms else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -218,30 +292,51 @@ def main():
             "metric": "Mbases/s scored (6-frame IMM)", "value": round(value, 2), "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(seconds / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d x %d bp synthetic reads per GPU, one 3-periodic ICM (NC_000915.icm), "
-                                   "6-frame per-position scoring, fp64 Frame_Scores" % (n, L),
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d x %d bp synthetic reads %s, one 3-periodic ICM (NC_000915.icm), "
+                                   "6-frame per-position scoring, fp64 Frame_Scores"
+                                   % (args.reads, L, "per GPU" if args.scaling == "weak" else "in total, sharded by gmg_shard_plan"),
                        "reads_per_gpu": n, "read_len": L, "parallelism": "reads sharded, %d rank(s)" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_frame6", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": "k_frame6t + k_frame6p (one gmg_frame_score6 call)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": traffic, "kernel_ms": round(kern_ms, 4),
+                         "traffic": traffic, "kernel_ms": round(kern_ms, 4), "kernel_ms_min_max": [round(kern_min, 4), round(kern_max, 4)],
+                         "statistic": "median of the %d timed calls (HIP events on the launch stream)" % len(per_call),
                          "algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE,
                          "measured_fill_GBps": round(fill_gbps, 1) if fill_gbps else None},
-            "check": check,
+            "timed_region_s": round(seconds, 4),
+            "check": None,
         }
-        if world == 1 and args.cpu_reads > 0:
-            ns = min(args.cpu_reads, n)
-            line["cpu_baseline"] = cpu_baseline(ns, L, seed, gc, packed)
-            # the baseline leg doubles as the checker: XOR of all 6 x L x ns output doubles, device vs CPU
-            host = out.view(6, total)[:, :ns * L].cpu().numpy()
-            x = int(np.bitwise_xor.reduce(host.view(np.uint64).ravel()))
-            same = "%016x" % x == line["cpu_baseline"]["xor"]
-            line["check"] = ("bit-exact vs the CPU %s on %d reads (XOR of all output doubles)" % (line["cpu_baseline"]["kind"], ns)
-                             if same else "MISMATCH vs the CPU %s" % line["cpu_baseline"]["kind"])
+        if args.cpu_reads > 0 and n > 0:
+            ns = min(args.cpu_reads if world == 1 else 2000, n)
+            first_read = first_base // L
+            samples = [("first", 0), ("last", n - ns)] if n > ns else [("all", 0)]
+            verdicts, head = [], None
+            for name, r0 in samples:
+                cpu, kind = cpu_sample(first_read + r0, r0, ns, L, seed, gc, packed)
+                if head is None:
+                    head = (cpu, kind)
+                x, mix = device_digest(out, total, r0, ns, L)
+                same = x == cpu["xor"] and mix == cpu["mix"]
+                ok = ok and same
+                verdicts.append("%s %d reads: %s" % (name, ns, "bit-exact" if same else "MISMATCH (xor %s/%s, mix %s/%s)" % (x, cpu["xor"], mix, cpu["mix"])))
+            line["check"] = "device table vs the CPU %s (XOR and position-weighted sum of all output doubles) -- %s" % (head[1], "; ".join(verdicts))
+            if world == 1:
+                cpu, kind = head
+                line["cpu_baseline"] = {"value": round(cpu["mbases_per_s"], 4), "unit": "Mbases/s", "cores": 1, "kind": kind,
+                                        "sample": "first %d of the rank-0 reads (%d x %d bp, same stream)" % (ns, ns, L),
+                                        "seconds": round(cpu["seconds"], 3)}
+                if kind == "reference":
+                    line["cpu_baseline"]["all_cores"] = cpu_all_cores(max(ns // 2, 1), L, seed, gc)
+        if not ok:
+            line["value"] = None
+        if world == 1 and not args.no_cli and ok:
+            line["cli_end_to_end"] = cli_end_to_end()
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

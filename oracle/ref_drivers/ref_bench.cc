@@ -11,8 +11,10 @@
 // the word is (z >> 2j) & 3 -> "acgt".  Read r is bases [r*L, (r+1)*L) of the stream.  bench.py
 // and the tests generate the same stream with numpy.
 //
-// Prints one JSON line: {"bases":..., "seconds":..., "mbases_per_s":..., "xor":"<hex>", "sum":...}
-// where xor is the XOR of the bit patterns of every output double (order-independent checksum).
+// Prints one JSON line: {"bases":..., "seconds":..., "mbases_per_s":..., "xor":"<hex>", "mix":"<hex>", "sum":...}
+// where xor is the XOR of the bit patterns of every output double (order-independent checksum) and mix the
+// position-sensitive one: sum over the sample's elements of bits * (2 * index + 1) mod 2^64, index = (f * n_reads + r) * L + i
+// (the [6][n_reads * L] layout of the sample) -- a permuted or shifted table does not pass it.
 
 #include "icm.hh"
 #include <string>
@@ -73,7 +75,7 @@ int main(int argc, char **argv)
     vector<vector<double> > fs(6);
     vector<double> g, z;
     string buff;
-    uint64_t x = 0;
+    uint64_t x = 0, mix = 0;
     double sum = 0.0;
 
     double t0 = now_s();
@@ -99,12 +101,13 @@ int main(int argc, char **argv)
                 uint64_t b;
                 memcpy(&b, &fs[f][i], 8);
                 x ^= b;
+                mix += b * (2 * (((uint64_t)f * n_reads + r) * L + i) + 1);
                 sum += fs[f][i];
             }
     }
     double t1 = now_s();
     double bases = double(n_reads) * L;
-    printf("{\"bases\": %.0f, \"seconds\": %.6f, \"mbases_per_s\": %.4f, \"xor\": \"%016llx\", \"sum\": %.17g}\n",
-           bases, t1 - t0, bases / (t1 - t0) / 1e6, (unsigned long long)x, sum);
+    printf("{\"bases\": %.0f, \"seconds\": %.6f, \"mbases_per_s\": %.4f, \"xor\": \"%016llx\", \"mix\": \"%016llx\", \"sum\": %.17g}\n",
+           bases, t1 - t0, bases / (t1 - t0) / 1e6, (unsigned long long)x, (unsigned long long)mix, sum);
     return 0;
 }

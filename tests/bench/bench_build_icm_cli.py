@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """build-icm from the command line: the reference's own binary (oracle/_ref/build-icm, all-reference build) beside the same
-build-icm.cc compiled against our icm.hh (oracle/_ref/build-icm_dropin) on one synthetic training file; the model files
+build-icm.cc compiled against our icm.hh (integration/_build/build-icm_dropin) on one synthetic training file; the model files
 must be byte-identical.  Process start and HIP initialisation are inside the drop-in's time.
 usage: bench_build_icm_cli.py [n_strings] [mean_len] [reps]"""
 import json
@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = os.path.join(ROOT, "oracle", "_ref", "build-icm")
-DROP = os.path.join(ROOT, "oracle", "_ref", "build-icm_dropin")
+DROP = os.path.join(ROOT, "integration", "_build", "build-icm_dropin")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1600
 mean = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3

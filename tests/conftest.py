@@ -39,6 +39,19 @@ def gpu(gmg):
     return gmg
 
 
+def built_binary(*parts):
+    """path of a binary that only the build container can make (it needs /root/reference): integration/_build/* (the drop-in
+    builds, product side) or oracle/_ref/* (the all-reference builds, checker side).  Missing: the test is skipped -- unless
+    GMG_EXPECT_REF=1 says the binaries were pushed with the tree (the round's GPU runs), then it fails."""
+    exe = os.path.join(ROOT, *parts)
+    if not os.access(exe, os.X_OK):
+        msg = "%s not built (needs /root/reference in the build container: make -C oracle ref && make -C integration)" % os.path.join(*parts)
+        if os.environ.get("GMG_EXPECT_REF") == "1":
+            pytest.fail(msg)
+        pytest.skip(msg)
+    return exe
+
+
 @pytest.fixture
 def request_finalizers():
     """callbacks run after the test (library switches set with gmg_set_option go back to their defaults)"""

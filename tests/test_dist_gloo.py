@@ -30,7 +30,7 @@ def step():
 seconds, mine = bench.timed_region(step, 5, 2, lambda: None, dist)
 out = {"rank": rank, "seconds": seconds, "mine": mine, "calls": len(calls),
        "digest": int(np.bitwise_xor.reduce(packed)), "total": int(off[-1]),
-       "value": bench.aggregate(int(off[-1]), world, 5, seconds)}
+       "value": bench.aggregate(int(off[-1]) * world, 5, seconds)}
 print("RESULT " + json.dumps(out), flush=True)
 dist.barrier()
 dist.destroy_process_group()

@@ -1,6 +1,6 @@
 """Drop-in check on the GPU: the reference's own glimmer3 / glimmer-mg sources, compiled unchanged
-against OUR ICM_t (glimmer-mg_amd/host/icm.hh) and linked with libgmg.so (oracle/Makefile target
-`dropin`, built in the build container; the binaries travel in oracle/_ref/), must write .predict files
+against OUR ICM_t (glimmer-mg_amd/host/icm.hh) and linked with libgmg.so (integration/Makefile,
+built in the build container; the binaries travel in integration/_build/), must write .predict files
 byte-identical to the goldens written by the all-reference build.  Every score in these runs comes from
 the HIP layer (one launch per ICM_t call)."""
 import os
@@ -8,7 +8,7 @@ import subprocess
 
 import pytest
 
-from conftest import DATA, GOLD, ROOT
+from conftest import DATA, GOLD, ROOT, built_binary
 
 pytestmark = pytest.mark.gpu
 
@@ -21,9 +21,7 @@ CASES = [
 
 @pytest.mark.parametrize("binary,flags,golden", CASES)
 def test_reference_cli_on_our_icm_is_byte_identical(gpu, tmp_path, binary, flags, golden):
-    exe = os.path.join(ROOT, "oracle", "_ref", binary)
-    if not os.access(exe, os.X_OK):
-        pytest.skip("oracle/_ref/%s not built (needs /root/reference in the build container)" % binary)
+    exe = built_binary("integration", "_build", binary)
     tag = str(tmp_path / "out")
     cmd = [exe, *flags, "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, "seqs.fa"), tag]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
@@ -37,28 +35,24 @@ def test_reference_cli_on_our_icm_is_byte_identical(gpu, tmp_path, binary, flags
 
 @pytest.mark.parametrize("flags,golden", [([], "glimmer3.default.predict"), (["-X"], "glimmer3.X.predict")])
 def test_glimmer3_with_batched_score_orfs_is_byte_identical(gpu, tmp_path, flags, golden):
-    """oracle/_ref/glimmer3_batch: glimmer3's own Find_Orfs / Add_Events / Process_Events / Trace_Back around ONE
-    gmg_score_orfs call that replaces the Score_Orfs inner loops of all 999 reads (oracle/ref_drivers/ref_orfs.cc)."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "glimmer3_batch")
-    if not os.access(exe, os.X_OK):
-        pytest.skip("oracle/_ref/glimmer3_batch not built (needs /root/reference in the build container)")
+    """integration/glimmer3_gpu: glimmer3's own Add_Events / Process_Events / Trace_Back around ONE gmg_fasta_ingest, ONE
+    gmg_find_orfs and ONE gmg_score_orfs call for all 999 reads."""
+    exe = built_binary("integration", "_build", "glimmer3_gpu")
     tag = str(tmp_path / "out")
-    cmd = [exe, "batch", *flags, "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, "seqs.fa"), tag]
+    cmd = [exe, *flags, "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, "seqs.fa"), tag]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", golden), "rb").read()
 
 
-@pytest.mark.parametrize("ref,dev", [("glimmer3", "glimmer3_batch"), ("glimmer-mg", "glimmer-mg_batch")])
+@pytest.mark.parametrize("ref,dev", [("glimmer3", "glimmer3_gpu"), ("glimmer-mg", "glimmer-mg_gpu")])
 def test_long_and_tiny_sequences_through_the_device_front_halves(gpu, tmp_path, ref, dev):
     """one 30 kb sequence, one of 10 bases, one of 5 kb, an empty record: the all-reference CLI and the device front half
     (ingest + Find_Orfs + scoring on the GPU, the reference's events / DP / trace-back on the host) must write the same bytes.
     (The reference's glimmer-mg aborts on an empty record -- assertion in Complement_Transfer, glimmer_base.cc:422 -- so
     that case is left to glimmer3.)"""
     import numpy as np
-    exe_ref, exe_dev = (os.path.join(ROOT, "oracle", "_ref", x) for x in (ref, dev))
-    if not (os.access(exe_ref, os.X_OK) and os.access(exe_dev, os.X_OK)):
-        pytest.skip("oracle/_ref binaries not built (needs /root/reference in the build container)")
+    exe_ref, exe_dev = built_binary("oracle", "_ref", ref), built_binary("integration", "_build", dev)
     rng = np.random.default_rng(8)
     fa = tmp_path / "mixed.fa"
     with open(fa, "w") as f:
@@ -71,7 +65,7 @@ def test_long_and_tiny_sequences_through_the_device_front_halves(gpu, tmp_path, 
                 f.write(s[i:i + 60] + "\n")
     icm = os.path.join(DATA, "NC_000915.icm")
     out = []
-    for exe, extra, tag in ((exe_ref, [], "a"), (exe_dev, ["batch"], "b")):
+    for exe, extra, tag in ((exe_ref, [], "a"), (exe_dev, [], "b")):
         res = subprocess.run([exe, *extra, "-m", icm, str(fa), str(tmp_path / tag)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert res.returncode == 0, res.stderr.decode()[-2000:]
         out.append(open(str(tmp_path / tag) + ".predict", "rb").read())

@@ -3,8 +3,9 @@
     oracle/_ref/ref_mg_orfs, which pulls the reference's glimmer-mg.cc in whole),
   * the oracle on seeded random reads of ragged lengths (edge cases: reads shorter than Min_Gene_Len, no stop at
     all, truncated ORFs off, the Ignore_Score_Len boost, IUPAC start codons, two stop codons),
-  * the reference CLI: oracle/_ref/glimmer-mg_batch = glimmer-mg's own events / DP / trace-back around ONE
-    gmg_mg_score_reads call must write byte-identical .predict files.
+  * the reference CLI: integration/glimmer-mg_gpu = glimmer-mg's own events / DP / trace-back around
+    gmg_mg_score_reads calls must write byte-identical .predict files -- as one process, in several batches, and as one
+    process per shard (forked, the job's GC fraction summed from the shards' counts).
 Integer fields and double scores must be equal bit for bit."""
 import os
 import subprocess
@@ -12,7 +13,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import DATA, GOLD, ROOT
+from conftest import DATA, GOLD, ROOT, built_binary
 from test_oracle_mg import CASES, golden_rows, ignore_score_len, mg_case, sorted_starts
 
 pytestmark = pytest.mark.gpu
@@ -125,17 +126,30 @@ def test_mg_frame_scores_are_handed_back_and_empty_batches_work(gpu, nc, seqs_fa
     (["-i"], "glimmer-mg.indel.predict", "seqs.fa"), (["-s"], "glimmer-mg.sub.predict", "seqs.fa"),
     (["-i", "-q", os.path.join(DATA, "seqs80.qual")], "glimmer-mg.indel_q80.predict", "seqs80.fa")])
 def test_glimmer_mg_with_device_front_half_is_byte_identical(gpu, tmp_path, flags, golden, fasta):
-    """oracle/_ref/glimmer-mg_batch: glimmer-mg's own Add_Events / Process_Events / Trace_Back around ONE
-    gmg_mg_score_reads call that replaces Score_All_Frames, Find_Orfs and Score_Orfs_Errors of all 999 reads
-    (oracle/ref_drivers/ref_mg_orfs.cc)."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "glimmer-mg_batch")
-    if not os.access(exe, os.X_OK):
-        pytest.skip("oracle/_ref/glimmer-mg_batch not built (needs /root/reference in the build container)")
+    """integration/glimmer-mg_gpu: glimmer-mg's own Add_Events / Process_Events / Trace_Back around ONE
+    gmg_mg_score_reads call that replaces Score_All_Frames, Find_Orfs and Score_Orfs_Errors of all 999 reads."""
+    exe = built_binary("integration", "_build", "glimmer-mg_gpu")
     tag = str(tmp_path / "out")
-    cmd = [exe, "batch", *flags, "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, fasta), tag]
+    cmd = [exe, *flags, "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, fasta), tag]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", golden), "rb").read()
+
+
+@pytest.mark.parametrize("how", [["--batch-bytes", "50000"], ["--shards", "2"], ["--shards", "3", "--batch-bytes", "40000"],
+                                 ["--shards", "8", "--gpus", "1"]])
+@pytest.mark.parametrize("flags,golden", [([], "glimmer-mg.default.predict"), (["-i"], "glimmer-mg.indel.predict")])
+def test_glimmer_mg_gpu_in_batches_and_shards_is_byte_identical(gpu, tmp_path, how, flags, golden):
+    """the same file in several batches per process and / or one forked process per shard (all on the one GPU of the box):
+    the null model's GC fraction is the whole file's (summed from the shards' {gc, total}), the parts are concatenated in
+    shard order -- the bytes of the reference's single run."""
+    exe = built_binary("integration", "_build", "glimmer-mg_gpu")
+    tag = str(tmp_path / "out")
+    cmd = [exe, *how, *flags, "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, "seqs.fa"), tag]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", golden), "rb").read()
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
 
 
 def test_reads_select_groups_like_classification_mode(gpu, nc):

@@ -1,6 +1,6 @@
 """build-icm's training through the C ABI: gmg_trainer_* (the pair counts of every tree level, on the
 device), gmg_icm_train (ICM_Training_t::Train_Model on top of them) and the reference's own build-icm.cc recompiled
-against our icm.hh (oracle/_ref/build-icm_dropin, when the build container made it) against
+against our icm.hh (integration/_build/build-icm_dropin, when the build container made it) against
   * the .icm files the REAL reference's build-icm wrote (tests/golden/train/): byte-identical model files,
   * the oracle's counts, level by level, on the golden training sets and on ragged random strings (empty strings,
     strings shorter than the window, every model shape the reference's CLI accepts)."""
@@ -12,12 +12,12 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import DATA, GOLD, ROOT
+from conftest import built_binary, DATA, GOLD, ROOT
 from test_oracle_train import CASES, TRAIN, training_strings
 
 pytestmark = pytest.mark.gpu
 
-DROPIN = os.path.join(ROOT, "oracle", "_ref", "build-icm_dropin")
+DROPIN = os.path.join(ROOT, "integration", "_build", "build-icm_dropin")
 SHIPPED = [c for c in CASES if c["train"]]
 
 
@@ -64,12 +64,12 @@ def test_trained_model_file_is_the_reference_file(case, gpu, tmp_path):
         assert np.isfinite(s).all() and (s < 0).all()
 
 
-@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/build-icm_dropin is made in the build container")
 @pytest.mark.parametrize("case", SHIPPED, ids=lambda c: c["name"])
 def test_reference_build_icm_cli_on_our_icm_hh(case, tmp_path):
     """src/ICM/build-icm.cc, unchanged, compiled against glimmer-mg_amd/host/icm.hh and linked with libgmg.so: same
     options, same bytes out (binary and -t text form, which also prints the mutual information of every node)"""
     out = str(tmp_path / "d.icm")
+    built_binary("integration", "_build", "build-icm_dropin")
     with open(os.path.join(DATA, case["train"]), "rb") as fp:
         subprocess.run([DROPIN, *case["opts"], out], stdin=fp, check=True, timeout=300)
     data = open(out, "rb").read()
