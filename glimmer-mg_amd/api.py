@@ -187,6 +187,27 @@ class Icm:
             pass
 
 
+class NullSet:
+    """gmg_null_set: (3,2,3) null models side by side on the device (glimmer-mg -c: Indep_Model per read)"""
+
+    def __init__(self, icms):
+        self.icms = list(icms)                           # keep the host models (and their device mirrors) alive
+        arr = (C.c_void_p * len(self.icms))(*[m.device() for m in self.icms])
+        self.h = C.c_void_p()
+        _ck(capi.lib().gmg_null_set_upload(arr, len(self.icms), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            capi.lib().gmg_null_set_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def pack_strings(seqs):
     """Filter + lower + 2-bit pack a list of str/bytes sequences -> (packed uint32, offsets uint64)."""
     lens = np.array([len(s) for s in seqs], np.uint64)
@@ -327,17 +348,27 @@ class Segments:
             pass
 
 
-def frame_score6(gene, null, reads, d_out=None, stream=None, row_stride=None):
+def frame_score6(gene, null, reads, d_out=None, stream=None, row_stride=None, read_null=None):
     """Score_All_Frames (glimmer-mg.cc:1468-1510) for every read.  With d_out (a device pointer to
     6*row_stride doubles) the call is asynchronous on `stream` and returns None; otherwise the
     result comes back as a float64 array [6, total_bases].  row_stride (default total_bases) is the
-    distance between the six rows in doubles (gmg_frame_score6_strided)."""
+    distance between the six rows in doubles (gmg_frame_score6_strided).
+    null may be a NullSet with read_null[r] = the null model of read r (gmg_frame_score6_nulls)."""
     stride = reads.total_bases if row_stride is None else int(row_stride)
+
+    def call(ptr):
+        if isinstance(null, NullSet):
+            rn = np.ascontiguousarray(read_null, np.uint32)
+            assert len(rn) == reads.n_reads
+            _ck(capi.lib().gmg_frame_score6_nulls(gene.device(), null.h, _ptr(rn), reads.h, ptr, stride, stream))
+        else:
+            _ck(capi.lib().gmg_frame_score6_strided(gene.device(), null.device(), reads.h, ptr, stride, stream))
+
     if d_out is not None:
-        _ck(capi.lib().gmg_frame_score6_strided(gene.device(), null.device(), reads.h, C.c_void_p(d_out), stride, stream))
+        call(C.c_void_p(d_out))
         return None
     buf = _DeviceBuffer(6 * max(stride, 1) * 8)
-    _ck(capi.lib().gmg_frame_score6_strided(gene.device(), null.device(), reads.h, buf.ptr, stride, stream))
+    call(buf.ptr)
     _ck(capi.lib().gmg_synchronize(stream))
     out = buf.to_host(np.float64, 6 * stride).reshape(6, stride)[:, :reads.total_bases].copy()
     buf.free()
@@ -455,7 +486,8 @@ MG_ACCEPTED_ONLY, MG_ALLOW_INDELS, MG_ALLOW_SUBS = 1, 2, 4
 def mg_score_reads(gene, null, reads, min_gene_len=75, allow_truncated=True, ignore_score_len=2**31 - 1,
                    start_threshold=-6.0, start_codons=("atg", "gtg", "ttg"), stop_codons=("taa", "tag", "tga"),
                    frame_scores=None, accepted_only=False, allow_indels=False, allow_subs=False, quality=None,
-                   min_indel_orf_len=15, indel_quality_threshold=18, indel_max=2, indel_suffix_score_threshold=-12.0):
+                   min_indel_orf_len=15, indel_quality_threshold=18, indel_max=2, indel_suffix_score_threshold=-12.0,
+                   read_null=None, read_ignore_score_len=None):
     """glimmer-mg's front half for a batch of reads (include/gmg.h: gmg_mg_score_reads): Score_All_Frames,
     Find_Orfs, Score_Orf_Starts and the filter of Score_Orfs_Errors.
     -> (orfs[MG_ORF_DTYPE], starts[START_DTYPE], read_orf_off[uint64 n_reads+1]).
@@ -479,8 +511,18 @@ def mg_score_reads(gene, null, reads, min_gene_len=75, allow_truncated=True, ign
         prm.start_codon[i].value = c.encode()
     for i, c in enumerate(stop_codons):
         prm.stop_codon[i].value = c.encode()
+    null_model = null
+    if isinstance(null, NullSet):                       # classification mode: null model (and Ignore_Score_Len) per read
+        read_null = np.ascontiguousarray(read_null, np.uint32)
+        assert len(read_null) == reads.n_reads
+        prm.nulls, prm.read_null = null.h, read_null.ctypes.data
+        if read_ignore_score_len is not None:
+            read_ignore_score_len = np.ascontiguousarray(read_ignore_score_len, np.int32)
+            assert len(read_ignore_score_len) == reads.n_reads
+            prm.read_ignore_score_len = read_ignore_score_len.ctypes.data
+        null_model = null.icms[0]
     res = C.c_void_p()
-    _ck(capi.lib().gmg_mg_score_reads(gene.device(), null.device(), reads.h, C.byref(prm),
+    _ck(capi.lib().gmg_mg_score_reads(gene.device(), null_model.device(), reads.h, C.byref(prm),
                                       frame_scores.ptr if frame_scores is not None else None, C.byref(res), None))
     try:
         n_orfs, n_starts = C.c_uint64(), C.c_uint64()

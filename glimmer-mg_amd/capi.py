@@ -29,7 +29,9 @@ class MgParams(C.Structure):
                 ("stop_codon", (C.c_char * 4) * 8),
                 # the error branch (GMG_MG_ALLOW_INDELS / GMG_MG_ALLOW_SUBS)
                 ("min_indel_orf_len", C.c_int32), ("indel_quality_threshold", C.c_int32), ("indel_max", C.c_int32),
-                ("reserved", C.c_int32), ("indel_suffix_score_threshold", C.c_double), ("quality", C.c_void_p)]
+                ("reserved", C.c_int32), ("indel_suffix_score_threshold", C.c_double), ("quality", C.c_void_p),
+                # classification mode: per-read null model / Ignore_Score_Len
+                ("nulls", C.c_void_p), ("read_null", C.c_void_p), ("read_ignore_score_len", C.c_void_p)]
 
 
 PROTOTYPES = {
@@ -60,6 +62,9 @@ PROTOTYPES = {
     "gmg_segments_free": (i32, [vp]),
     "gmg_frame_score6": (i32, [vp, vp, vp, vp, vp]),
     "gmg_frame_score6_strided": (i32, [vp, vp, vp, vp, u64, vp]),
+    "gmg_null_set_upload": (i32, [vp, i32, C.POINTER(vp)]),
+    "gmg_null_set_free": (i32, [vp]),
+    "gmg_frame_score6_nulls": (i32, [vp, vp, vp, vp, vp, u64, vp]),
     "gmg_segment_frame_score": (i32, [vp, vp, vp, i32, vp, vp]),
     "gmg_segment_cumscore": (i32, [vp, vp, vp, i32, vp, vp]),
     "gmg_score_string": (i32, [vp, vp, vp, i32, vp, vp]),

@@ -362,6 +362,37 @@ extern "C" int gmg_model_info(const gmg_model *m, int *W, int *D, int *P, int *N
     return GMG_OK;
 }
 
+// A set of width-3 null models side by side (glimmer-mg -c: one per GC value the classes of a batch produce)
+extern "C" int gmg_null_set_upload(const gmg_model *const *models, int n, gmg_null_set **out)
+{
+    int rc = require_init("gmg_null_set_upload");
+    if (rc) return rc;
+    if (!models || n < 1 || !out) return gmg_set_error(GMG_EINVAL, "gmg_null_set_upload: bad argument");
+    for (int i = 0; i < n; i++)
+        if (!models[i] || !models[i]->dev.has_dense || models[i]->dev.W != 3 || models[i]->dev.P != 3)
+            return gmg_set_error(GMG_EBADMODEL, "gmg_null_set_upload: model %d is not a (3,2,3) Build_Indep_WO_Stops model", i);
+    gmg_null_set *ns = new (std::nothrow) gmg_null_set();
+    if (!ns) return gmg_set_error(GMG_ENOMEM, "gmg_null_set_upload: out of host memory");
+    ns->d_tab = nullptr;
+    ns->n = n;
+    hipError_t e = hipMalloc((void **)&ns->d_tab, (size_t)n * 252 * sizeof(float));
+    for (int i = 0; i < n && e == hipSuccess; i++) {
+        e = hipMemcpy(ns->d_tab + (size_t)i * 252, models[i]->dev.dense, 192 * sizeof(float), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ns->d_tab + (size_t)i * 252 + 192, models[i]->dev.dense_part, 60 * sizeof(float), hipMemcpyDeviceToDevice);
+    }
+    if (e != hipSuccess) { gmg_null_set_free(ns); return gmg_set_error(GMG_EHIP, "gmg_null_set_upload: %s", hipGetErrorString(e)); }
+    *out = ns;
+    return GMG_OK;
+}
+
+extern "C" int gmg_null_set_free(gmg_null_set *ns)
+{
+    if (!ns) return GMG_OK;
+    if (ns->d_tab) (void)hipFree(ns->d_tab);
+    delete ns;
+    return GMG_OK;
+}
+
 // ---------------------------------------------------------------------------
 // reads
 // ---------------------------------------------------------------------------

@@ -51,7 +51,8 @@ struct Frame6Args {
     uint32_t p_blocks;      // k_frame6p: blocks [0, p_blocks) do partial windows, the rest the tail [first, first+count)
     double *out;            // [6][stride] gene - null (the Frame_Scores table); stride = total for the public entry point
     uint64_t stride;        // distance between the rows of `out` in doubles (>= total)
-    float *out_gene;        // gene-only mode (gmg_launch_gene6): [6][total] gene values as fp32
+    float *out_gene;        // gene-only mode (gmg_launch_gene6): [6][gstride] gene values as fp32
+    uint64_t gstride;       // distance between the rows of out_gene in floats (>= total)
 };
 
 constexpr int f6_cstride(int dt) { return ((((1 << (2 * dt)) - 1) / 3) + 15) & ~15; }
@@ -288,8 +289,8 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
                 const uint64_t chunk = worker + (uint64_t)(j0 + k) * nworkers;
                 if (GENE_ONLY) {
                     // v[c] = gene value exactly (the null tables hold zeros); rows of floats, 8-byte stores
-                    float *gf = a.out_gene + (uint64_t)(STRINGS ? 1 : ftype) * a.total + chunk * SPAN;
-                    float *gr = a.out_gene + (uint64_t)(STRINGS ? 0 : 3 + ftype) * a.total + chunk * SPAN;
+                    float *gf = a.out_gene + (uint64_t)(STRINGS ? 1 : ftype) * a.gstride + chunk * SPAN;
+                    float *gr = a.out_gene + (uint64_t)(STRINGS ? 0 : 3 + ftype) * a.gstride + chunk * SPAN;
                     if (PAIR) {
                         typedef float f2 __attribute__((ext_vector_type(2)));
                         const f2 x0 = {(float)v[0], (float)v[2]}, x1 = {(float)v[1], (float)v[3]};
@@ -350,8 +351,8 @@ __device__ __forceinline__ void f6_generic_range(const Frame6Args &a, uint64_t i
         DevBuf br = dev_make_buf(a.packed, r_off, 0, (uint32_t)L, GMG_COMPLEMENTED);
         for (int f = 0; f < 3; f++) {
             if (a.out_gene) {
-                a.out_gene[(uint64_t)f * a.total + g] = dev_score(a.gene, bf, L - 1 - p, f);
-                a.out_gene[(uint64_t)(3 + f) * a.total + g] = dev_score(a.gene, br, p, f);
+                a.out_gene[(uint64_t)f * a.gstride + g] = dev_score(a.gene, bf, L - 1 - p, f);
+                a.out_gene[(uint64_t)(3 + f) * a.gstride + g] = dev_score(a.gene, br, p, f);
                 continue;
             }
             a.out[(uint64_t)f * a.stride + g] =
@@ -366,7 +367,8 @@ __device__ __forceinline__ void f6_generic_range(const Frame6Args &a, uint64_t i
 // The kernel is a chain of dependent latencies (offsets -> packed words -> D LDS steps -> row gather ->
 // store), so every lane keeps U reads in flight (U x 3 interleaved descents).
 // DT > 0: depth known at compile time.
-template <int DT, int U>
+// GENE: the gene model's value alone, as fp32, into a.out_gene (the complete gene-only table of gmg_launch_gene6_full).
+template <int DT, int U, bool GENE = false>
 __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_shift[];   // [3][cstride] completed-tree shifts
@@ -448,16 +450,20 @@ __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
             for (int f = 0; f < 3; f++) {
                 if (node[u][f] == 0xffffffffu) node[u][f] = lvl + idx[u][f];
                 gv[u][f] = a.gene.crow[((size_t)f * a.gene.ctot + node[u][f]) * 4 + pred];
-                nv[u][f] = ntab[(size_t)f * nstride + nslot];
+                nv[u][f] = GENE ? 0.0f : ntab[(size_t)f * nstride + nslot];
             }
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
             if (live[u])
 #pragma unroll
-                for (int f = 0; f < 3; f++)
-                    __builtin_nontemporal_store((double)gv[u][f] - (double)nv[u][f],
-                                                a.out + (uint64_t)((rev_buf ? 0 : 3) + f) * a.stride + g[u]);
+                for (int f = 0; f < 3; f++) {
+                    if (GENE)
+                        a.out_gene[(uint64_t)((rev_buf ? 0 : 3) + f) * a.gstride + g[u]] = gv[u][f];
+                    else
+                        __builtin_nontemporal_store((double)gv[u][f] - (double)nv[u][f],
+                                                    a.out + (uint64_t)((rev_buf ? 0 : 3) + f) * a.stride + g[u]);
+                }
     }
 }
 
@@ -507,6 +513,7 @@ int gmg_launch_frame6_strided(const gmg_model *gene, const gmg_model *nul, const
     a.out = d_out;
     a.stride = stride;
     a.out_gene = nullptr;
+    a.gstride = 0;
 
     // the specialised path: completed tree of depth 7 (DEFAULT_MODEL_DEPTH) and the width-3 null model
     const bool fast = gene->dev.has_fast && gene->dev.D == 7 && nul->dev.has_dense && nul->dev.W == 3 &&
@@ -565,7 +572,7 @@ int gmg_launch_frame6_strided(const gmg_model *gene, const gmg_model *nul, const
 // complemented (rows 3-5) read.  Bases whose window leaves their read hold a meaningless value
 // (no partial-window pass here): the caller (gmg_score_orfs) never reads them.
 // Returns GMG_EBADMODEL when the model shape has no fast path (the caller then takes its exact path).
-int gmg_launch_gene6(const gmg_model *gene, const gmg_reads *reads, float *d_gene, hipStream_t s)
+static int gene6_impl(const gmg_model *gene, const gmg_reads *reads, float *d_gene, uint64_t gstride, bool full, hipStream_t s)
 {
     if (!(gene->dev.has_fast && gene->dev.D == 7 && gene->dev.W >= 3 && gene->dev.W <= 15 && gene->dev.P >= 3))
         return GMG_EBADMODEL;
@@ -580,7 +587,9 @@ int gmg_launch_gene6(const gmg_model *gene, const gmg_reads *reads, float *d_gen
     a.first = 0;
     a.count = 0;
     a.out = nullptr;
+    a.stride = 0;
     a.out_gene = d_gene;
+    a.gstride = gstride;
     constexpr int BLOCK = 1024, DT = 7, KR = 16;
     constexpr uint32_t SPAN = 2 * BLOCK;
     const uint64_t n_chunks = a.total / SPAN;
@@ -593,7 +602,7 @@ int gmg_launch_gene6(const gmg_model *gene, const gmg_reads *reads, float *d_gen
         if (nworkers > n_chunks) nworkers = (unsigned)n_chunks;
         const unsigned grid = 3 * nworkers;
         const size_t lds = ((size_t)1 << (2 * DT)) * 8;
-        if ((a.total & 1) == 0) {
+        if ((gstride & 1) == 0) {
             GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, true, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, 0, true, true>), dim3(grid), dim3(BLOCK), lds, s, a);
@@ -604,7 +613,32 @@ int gmg_launch_gene6(const gmg_model *gene, const gmg_reads *reads, float *d_gen
         }
         GMG_HIP(hipGetLastError());
     }
-    return launch_generic(a, n_chunks * SPAN, a.total - n_chunks * SPAN, s);
+    if (!full) return launch_generic(a, n_chunks * SPAN, a.total - n_chunks * SPAN, s);
+    // the partial-window heads of every read and the batch tail, as in gmg_launch_frame6_strided
+    if (a.n_reads > 0) {
+        const uint64_t blocks = (a.n_reads + 7) / 8;
+        const unsigned grid = (unsigned)(blocks < 256 * 8 ? blocks : 256 * 8);
+        const size_t lds_p = (size_t)3 * a.gene.cstride;
+        a.first = n_chunks * SPAN;
+        a.count = a.total - n_chunks * SPAN;
+        a.p_blocks = grid;
+        const unsigned tail_blocks = (unsigned)((a.count + 255) / 256);
+        hipLaunchKernelGGL((k_frame6p<7, 4, true>), dim3(grid + tail_blocks), dim3(256), lds_p, s, a);
+        GMG_HIP(hipGetLastError());
+    }
+    return GMG_OK;
+}
+
+int gmg_launch_gene6(const gmg_model *gene, const gmg_reads *reads, float *d_gene, hipStream_t s)
+{
+    return gene6_impl(gene, reads, d_gene, reads->total_bases, false, s);
+}
+
+// The same rows complete: the first W-1 positions of either scoring buffer of every read by the partial-window rule
+// (icm.cc:807-842), rows gstride floats apart.  Frame_Scores = (double) these - (double) the null model's values.
+int gmg_launch_gene6_full(const gmg_model *gene, const gmg_reads *reads, float *d_gene, uint64_t gstride, hipStream_t s)
+{
+    return gene6_impl(gene, reads, d_gene, gstride, true, s);
 }
 
 // Per-base values of the two strings scoreReadsGlim scores with a periodicity-1 ICM (the read, and its reverse
@@ -625,7 +659,9 @@ int gmg_launch_strings(const gmg_model *m, const gmg_reads *reads, float *d_vals
     a.first = 0;
     a.count = 0;
     a.out = nullptr;
+    a.stride = 0;
     a.out_gene = d_vals;
+    a.gstride = reads->total_bases;
     constexpr int BLOCK = 1024, DT = 7, KR = 16;
     constexpr uint32_t SPAN = 2 * BLOCK;
     const uint64_t n_chunks = a.total / SPAN;

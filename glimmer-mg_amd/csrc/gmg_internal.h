@@ -62,6 +62,11 @@ struct gmg_reads {
     uint64_t n_over_512;         // reads longer than 512 bases (tile shape of the mg running-sum kernel)
 };
 
+struct gmg_null_set {
+    float *d_tab;                // [n][252]: [3][64] full windows, then [3][20] partial windows of each model
+    int n;
+};
+
 struct gmg_segments {
     gmg_segment *d_segs;
     uint64_t *d_out_off;         // n + 1, exclusive prefix of len
@@ -99,7 +104,8 @@ enum GmgOpt {
     GMG_OPT_TRAIN_TIMING,
     GMG_OPT_DIAG,                // ablation kernels; only in builds with -DGMG_ABLATIONS (their output is NOT valid)
     GMG_OPT_STRINGS_FUSED,       // gmg_score_reads_strings: 1 = sums folded into the main pass, 0 = value rows + summing kernel
-    GMG_OPT_MG_GENE32,           // glimmer-mg front half: 1 = fp32 gene rows + null applied in the tile (own table only)
+    GMG_OPT_MG_GENE32,           // glimmer-mg front half, the call's own table as fp32 gene rows with the null model applied where the
+                                 // running sums are built: 0 never, 1 with per-read null models (default), 2 always
     GMG_OPT_COUNT
 };
 extern long long g_gmg_opt[GMG_OPT_COUNT];
@@ -119,6 +125,7 @@ int gmg_launch_frame6(const gmg_model *gene, const gmg_model *nul, const gmg_rea
 int gmg_launch_frame6_strided(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, double *d_out,
                               uint64_t stride, hipStream_t s);
 int gmg_launch_gene6(const gmg_model *gene, const gmg_reads *reads, float *d_gene, hipStream_t s);
+int gmg_launch_gene6_full(const gmg_model *gene, const gmg_reads *reads, float *d_gene, uint64_t gstride, hipStream_t s);
 int gmg_launch_strings(const gmg_model *m, const gmg_reads *reads, float *d_vals, uint64_t *tail_start, hipStream_t s);
 int gmg_launch_seg_frame(const gmg_model *m, const gmg_reads *r, const gmg_segments *sg, int frame,
                          double *d_out, hipStream_t s);

@@ -69,10 +69,19 @@ struct MgArgs {
     uint64_t n_reads, total;
     const double *fs;            // Frame_Scores [6][fs_stride]
     uint64_t fs_stride;          // = total for a caller's table; the call's own table pads its rows to 128-byte lines
+    // GENE32 form of the table (the call's own, option mg_gene32): the gene model's values alone as fp32, [6][fs_stride]; the
+    // null model's value is subtracted where the running sums are built -- which is also where a per-read null model costs
+    // nothing (glimmer-mg -c: Update_Meta_Null_ICM, glimmer-mg.cc:2050-2068)
+    const float *gene32;
+    const float *null_tab;       // [n_null][252]: [3][64] full windows of a (3,2,3) null model, idx = sum code(w[k]) << 2k, then
+                                 // [3][20] partial windows: position j < 2 at (4^(j+1)-4)/3
+    const uint32_t *read_null;   // [n_reads] null model of every read, or NULL: model 0 for all
+    const int32_t *read_isl;     // [n_reads] Ignore_Score_Len of every read (Set_Ignore_Score_Len per read, :2067), or NULL
     double *cum;                 // [2][total]: score[j-1] of the ORF for which this base is in frame (k_mg_cum*)
     // tiling of k_mg_cum_tiled: uniform batches take reads_per_tile reads per block; ragged batches the reads
     // that start inside the block's window of tile_window bases
     int uniform_len, reads_per_tile;
+    uint32_t uniform_magic;      // ceil (2^32 / uniform_len): b / uniform_len = __umulhi (b, magic) for b < 2^16
     uint64_t tile_window, n_tiles;
     int lanes_only_unfit;        // k_mg_cum: skip the reads the tiled kernel has done
     const struct MgTile *tiles;  // ragged batches: the non-empty tiles, one entry each (k_mg_tile_table + select)
@@ -268,6 +277,36 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// GENE32: the null model's part of Frame_Scores[(fwd ? 0 : 3) + f][si] of a read of n bases (glimmer-mg.cc:1485-1509):
+// the (3,2,3) model's Frame_Score on the reversed read (fwd) or on the complemented read, at forward coordinate si.
+//   fwd: buffer position j = n-1-si, window B[j-2..j] = S[si+2], S[si+1], S[si]
+//   rev: buffer position j = si,     window B[j-2..j] = comp S[si-2], comp S[si-1], comp S[si]
+// positions j < 2 take the partial-window tables (icm.cc:807-842), as the dense_part tables of gmg_model_upload.
+// c0, c1, c2 = codes of S[si], S[si+1], S[si+2] (fwd) / S[si], S[si-1], S[si-2] (rev); what lies outside the read is not used.
+// ---------------------------------------------------------------------------------------------------
+#define MG_NULL_FLOATS 252       // one null model: [3][64] full windows, then [3][20] partial windows
+// index of the f = 0 entry in that table and the distance to the entries of f = 1, 2 (no branches: the lanes of a wave sit at
+// different distances from their reads' ends)
+template <bool FWD>
+__device__ __forceinline__ uint32_t mg_null_index(int si, int n, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t &stride)
+{
+    const int j = FWD ? n - 1 - si : si;
+    const uint32_t x = FWD ? 0u : 3u;                   // complement
+    const uint32_t b0 = c0 ^ x, b1 = c1 ^ x, b2 = c2 ^ x;          // B[j], B[j-1], B[j-2]
+    const uint32_t full = b2 | b1 << 2 | b0 << 4, p1 = 192u + 4u + (b1 | b0 << 2), p0 = 192u + b0;
+    stride = j >= 2 ? 64u : 20u;
+    return j >= 2 ? full : j == 1 ? p1 : p0;
+}
+
+template <bool FWD>
+__device__ __forceinline__ float mg_null_value(const float *tab, int f, int si, int n, uint32_t c0, uint32_t c1, uint32_t c2)
+{
+    uint32_t stride;
+    const uint32_t i0 = mg_null_index<FWD>(si, n, c0, c1, c2, stride);
+    return tab[i0 + (uint32_t)f * stride];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Cumulative_Frame_Score (glimmer-mg.cc:561-604) for every ORF a read can have, in ONE walk per strand.
 //
 // A forward ORF with bounds (lo, hi) sums Frame_Scores[f][si] for si = hi-1, hi-2, ... with f = 1,2,0,...;
@@ -286,13 +325,13 @@ struct __attribute__((packed, aligned(8))) MgD4 { double v[4]; };
 struct __attribute__((packed, aligned(8))) MgD3 { double v[3]; };
 struct __attribute__((packed)) MgU4 { uint32_t v; };    // four quality values at any byte address
 
-template <bool FWD>
+template <bool FWD, bool GENE32 = false>
 __device__ __forceinline__ void mg_cum_one(const MgArgs &a, uint64_t r)
 {
     const int64_t off = (int64_t)a.read_off[r];
     const int n = (int)((int64_t)a.read_off[r + 1] - off);
     if (n <= 0) return;
-    const double *row0 = a.fs + (FWD ? 0 : 3) * a.fs_stride + off;
+    const double *row0 = GENE32 ? nullptr : a.fs + (FWD ? 0 : 3) * a.fs_stride + off;
     const double *row1 = row0 + a.fs_stride, *row2 = row1 + a.fs_stride;
     double *ctab = a.cum + (FWD ? 0 : a.total) + off;
     const uint64_t stopmask = FWD ? a.fwd_stop : a.rev_stop;
@@ -317,6 +356,23 @@ __device__ __forceinline__ void mg_cum_one(const MgArgs &a, uint64_t r)
         return keep;
     };
 
+    if (GENE32) {                                       // fp32 gene rows - the read's null model, position by position
+        const float *g0 = a.gene32 + (uint64_t)(FWD ? 0 : 3) * a.fs_stride + off, *g1 = g0 + a.fs_stride, *g2 = g1 + a.fs_stride;
+        const uint32_t ni = a.read_null ? a.read_null[r] : 0u;
+        const float *nt = a.null_tab + (size_t)ni * MG_NULL_FLOATS;
+        uint32_t c1 = 0, c2 = 0;
+        for (int t = 0; t < n; t++) {
+            const int si = FWD ? n - 1 - t : t;
+            const uint32_t c0 = (uint32_t)dev_code(a.packed, (uint64_t)(off + si));
+            const double r0 = (double)g0[si] - (double)mg_null_value<FWD>(nt, 0, si, n, c0, c1, c2);
+            const double r1 = (double)g1[si] - (double)mg_null_value<FWD>(nt, 1, si, n, c0, c1, c2);
+            const double r2 = (double)g2[si] - (double)mg_null_value<FWD>(nt, 2, si, n, c0, c1, c2);
+            ctab[si] = step(t < 3, r0, r1, r2);
+            c2 = c1;
+            c1 = c0;
+        }
+        return;
+    }
     int t = 0;
     for (; t + 24 <= n; t += 24) {
 #pragma unroll
@@ -405,7 +461,7 @@ struct MgTileNonEmpty {
     __host__ __device__ bool operator()(const MgTile &t) const { return t.nfit != 0; }
 };
 
-template <int MG_CAP, int BLOCK>
+template <int MG_CAP, int BLOCK, bool GENE32 = false>
 __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
 {
     constexpr int RS = MG_CAP + 8;                                      // row stride: 4 guard entries on both sides, so that
@@ -413,17 +469,26 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
     extern __shared__ __attribute__((aligned(16))) double s_fs[];       // [3][RS]: rows 0,1,2 of one strand, base b at 4 + b
     __shared__ uint16_t s_list[MG_CAP];                                 // tile bases where a running sum starts
     __shared__ uint8_t s_flag[RS + BLOCK];                              // the same as one byte per base (4 + b), ones around the tile
-    __shared__ uint32_t s_packed[MG_CAP / 16 + 3];
+    __shared__ uint32_t s_packed[MG_CAP / 16 + 4];                      // one word in front of the tile's first: base b at bit pair 16 + shift + b
     __shared__ uint32_t s_roff[MG_TILE_READS + 1];                      // read starts relative to the tile
     __shared__ uint32_t s_nlist;
     constexpr int PER = (MG_CAP + BLOCK - 1) / BLOCK;                   // doubles per lane and row
-    constexpr int PW = (MG_CAP / 16 + 3 + BLOCK - 1) / BLOCK;           // packed words per lane
+    constexpr int PW = (MG_CAP / 16 + 4 + BLOCK - 1) / BLOCK;           // packed words per lane
     constexpr int PR = (MG_TILE_READS + 1 + BLOCK - 1) / BLOCK;         // read offsets per lane
 
     struct Tile { uint64_t first, w0; uint32_t nfit, span; };
     const uint64_t n_tiles = a.n_tiles_dev ? (uint64_t)*a.n_tiles_dev : a.n_tiles;
-    double tmp[3][PER];
+    typename std::conditional<GENE32, float, double>::type tmp[3][PER];
     uint32_t tpk[PW], tro[PR];
+    // GENE32: the null models of the tile's first MG_NULL_CACHE reads sit in LDS (1 KB each; one model for the whole batch:
+    // slot 0, loaded once); reads beyond them fetch their values through L1
+    constexpr int NC = GENE32 ? (MG_CAP <= 512 ? 4 : 8) : 1;
+    constexpr int PN = GENE32 ? (NC * MG_NULL_FLOATS + BLOCK - 1) / BLOCK : 1;
+    __shared__ float s_null[GENE32 ? NC * MG_NULL_FLOATS : 1];
+    float tnl[PN];
+    if (GENE32 && !a.read_null) {
+        for (uint32_t i = threadIdx.x; i < MG_NULL_FLOATS; i += BLOCK) s_null[i] = a.null_tab[i];
+    }
     auto meta = [&](uint64_t k, Tile &t) __attribute__((always_inline)) {
         t.nfit = 0; t.span = 0; t.first = 0; t.w0 = 0;
         if (k >= 2 * n_tiles) return;
@@ -444,23 +509,39 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
         const bool fwd = (k & 1) == 0;
 #pragma unroll
         for (int row = 0; row < 3; row++) {
-            const double *src = a.fs + (uint64_t)((fwd ? 0 : 3) + row) * a.fs_stride + t.w0;
+            if (GENE32) {
+                const float *src = a.gene32 + (uint64_t)((fwd ? 0 : 3) + row) * a.fs_stride + t.w0;
 #pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
-                tmp[row][u] = i < t.span ? src[i] : 0.0;
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
+                    tmp[row][u] = i < t.span ? src[i] : 0.0f;
+                }
+            } else {
+                const double *src = a.fs + (uint64_t)((fwd ? 0 : 3) + row) * a.fs_stride + t.w0;
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
+                    tmp[row][u] = i < t.span ? src[i] : 0.0;
+                }
             }
         }
-        const uint32_t n_words = ((uint32_t)(t.w0 & 15) + t.span + 15) / 16;
+        const uint32_t n_words = ((uint32_t)(t.w0 & 15) + t.span + 15) / 16 + 1;       // + the word in front (a guard word of gmg_reads at the batch's start)
 #pragma unroll
         for (int u = 0; u < PW; u++) {
             const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
-            tpk[u] = i < n_words ? a.packed[(t.w0 >> 4) + i] : 0u;
+            tpk[u] = i < n_words ? a.packed[(int64_t)(t.w0 >> 4) - 1 + i] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < PR; u++) {
             const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
             tro[u] = i <= t.nfit ? (uint32_t)(a.read_off[t.first + i] - t.w0) : 0u;
+        }
+        if (GENE32 && a.read_null) {
+#pragma unroll
+            for (int u = 0; u < PN; u++) {
+                const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u, rl = i / MG_NULL_FLOATS;
+                tnl[u] = rl < t.nfit && rl < (uint32_t)NC ? a.null_tab[(size_t)a.read_null[t.first + rl] * MG_NULL_FLOATS + (i - rl * MG_NULL_FLOATS)] : 0.0f;
+            }
         }
     };
 
@@ -474,31 +555,83 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
         const uint64_t w0 = cur.w0;
         __syncthreads();                                // the previous tile has left the LDS
         if (nfit) {
+            if (!GENE32) {
 #pragma unroll
-            for (int row = 0; row < 3; row++)
+                for (int row = 0; row < 3; row++)
 #pragma unroll
-                for (int u = 0; u < PER; u++) {
-                    const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
-                    if (i < span) s_fs[row * RS + 4 + i] = tmp[row][u];
-                }
+                    for (int u = 0; u < PER; u++) {
+                        const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
+                        if (i < span) s_fs[row * RS + 4 + i] = tmp[row][u];
+                    }
+            }
 #pragma unroll
             for (int u = 0; u < PW; u++) {
                 const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
-                if (i < MG_CAP / 16 + 3) s_packed[i] = tpk[u];
+                if (i < MG_CAP / 16 + 4) s_packed[i] = tpk[u];
             }
 #pragma unroll
             for (int u = 0; u < PR; u++) {
                 const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
                 if (i <= nfit) s_roff[i] = tro[u];
             }
+            if (GENE32 && a.read_null) {
+#pragma unroll
+                for (int u = 0; u < PN; u++) {
+                    const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
+                    if (i < (uint32_t)(NC * MG_NULL_FLOATS)) s_null[i] = tnl[u];
+                }
+            }
         }
         if (threadIdx.x == 0) s_nlist = 0;
+        if (GENE32) {
+            // Frame_Scores of the tile = (double) gene value - (double) the read's null-model value, built here from the fp32
+            // rows in registers and the packed bases just staged (the reads' null models come through L1 / L2: 1 KB each)
+            __syncthreads();
+            if (nfit) {
+                const uint32_t shift_g = 16u + (uint32_t)(w0 & 15);
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t b = threadIdx.x + (uint32_t)BLOCK * u;
+                    if (b < span) {
+                        uint32_t rl;                    // the read of base b, relative to the tile's first
+                        if (a.uniform_len > 0) rl = a.uniform_len == 1 ? b : __umulhi(b, a.uniform_magic);      // b / uniform_len (b < 2^16)
+                        else {
+                            uint32_t lo = 0, hi = nfit;
+                            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_roff[mid] <= b) lo = mid; else hi = mid; }
+                            rl = lo;
+                        }
+                        const int rs = a.uniform_len > 0 ? (int)(rl * (uint32_t)a.uniform_len) : (int)s_roff[rl];
+                        const int n = a.uniform_len > 0 ? a.uniform_len : (int)s_roff[rl + 1] - rs;
+                        const int si = (int)b - rs;
+                        // codes of bases b-2 .. b+2 (five 2-bit fields, base b-2 lowest)
+                        const uint32_t x = shift_g + b - 2u;
+                        const uint64_t two = (uint64_t)s_packed[x >> 4] | (uint64_t)s_packed[(x >> 4) + 1] << 32;
+                        const uint32_t five = (uint32_t)(two >> (2u * (x & 15u))) & 0x3ffu;
+                        const uint32_t c0 = (five >> 4) & 3u;
+                        const uint32_t c1 = fwd ? (five >> 6) & 3u : (five >> 2) & 3u;      // S[si+1] / S[si-1]
+                        const uint32_t c2 = fwd ? (five >> 8) & 3u : five & 3u;             // S[si+2] / S[si-2]
+                        uint32_t nstride;
+                        const uint32_t i0 = fwd ? mg_null_index<true>(si, n, c0, c1, c2, nstride) : mg_null_index<false>(si, n, c0, c1, c2, nstride);
+                        const uint32_t slot = a.read_null ? rl : 0u;
+                        if (slot < (uint32_t)NC) {
+                            const float *nt = s_null + slot * MG_NULL_FLOATS + i0;
+#pragma unroll
+                            for (int row = 0; row < 3; row++) s_fs[row * RS + 4 + b] = (double)tmp[row][u] - (double)nt[row * nstride];
+                        } else {                        // (a tile of many short reads)
+                            const float *nt = a.null_tab + (size_t)a.read_null[cur.first + rl] * MG_NULL_FLOATS + i0;
+#pragma unroll
+                            for (int row = 0; row < 3; row++) s_fs[row * RS + 4 + b] = (double)tmp[row][u] - (double)nt[row * nstride];
+                        }
+                    }
+                }
+            }
+        }
         Tile nxt;
         meta(k + gridDim.x, nxt);
         issue(k + gridDim.x, nxt);
         __syncthreads();
         if (nfit) {
-        const uint32_t shift = (uint32_t)(w0 & 15);     // tile base b is bit pair shift + b of s_packed
+        const uint32_t shift = 16u + (uint32_t)(w0 & 15);     // tile base b is bit pair shift + b of s_packed (one word in front)
         auto codon = [&](uint32_t b) __attribute__((always_inline)) {      // tile bases b, b+1, b+2 as Find_Orfs indexes a codon
             const uint32_t x = shift + b;
             const uint64_t two = (uint64_t)s_packed[x >> 4] | (uint64_t)s_packed[(x >> 4) + 1] << 32;
@@ -516,7 +649,7 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
             bool st = true;
             if (b < span) {
                 int rs, n;
-                if (a.uniform_len > 0) { rs = (int)(b / (uint32_t)a.uniform_len) * a.uniform_len; n = a.uniform_len; }
+                if (a.uniform_len > 0) { rs = (int)(a.uniform_len == 1 ? b : __umulhi(b, a.uniform_magic)) * a.uniform_len; n = a.uniform_len; }
                 else {
                     uint32_t lo = 0, hi = nfit;         // last r with s_roff[r] <= b
                     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_roff[mid] <= b) lo = mid; else hi = mid; }
@@ -577,6 +710,7 @@ __global__ __launch_bounds__(256) void k_mg_unfit_list(MgArgs a)
 }
 
 // the per-lane walk: for the listed reads (lanes_only_unfit) or for every read
+template <bool GENE32>
 __global__ __launch_bounds__(256) void k_mg_cum(MgArgs a)
 {
     const uint64_t n = a.lanes_only_unfit ? (uint64_t)*a.unfit_n : a.n_reads;
@@ -584,8 +718,8 @@ __global__ __launch_bounds__(256) void k_mg_cum(MgArgs a)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t e = i < n ? i : i - n;
         const uint64_t r = a.lanes_only_unfit ? a.unfit[e] : e;
-        if (i < n) mg_cum_one<true>(a, r);
-        else mg_cum_one<false>(a, r);
+        if (i < n) mg_cum_one<true, GENE32>(a, r);
+        else mg_cum_one<false, GENE32>(a, r);
     }
 }
 
@@ -609,6 +743,7 @@ __device__ __forceinline__ void mg_starts_one(const MgArgs &a, uint64_t i, const
     const int lo = o.lo, hi = o.hi, m = hi - lo;
     const bool trunc = a.allow_truncated && (fwd ? lo < 3 : n - (hi - 1) < 3);
     const int mgl = a.min_gene_len;
+    const int isl = a.read_isl ? a.read_isl[o.read] : a.ignore_score_len;      // Set_Ignore_Score_Len per read with -c (glimmer-mg.cc:2067)
     int j_lo = mgl - 3 > 1 ? mgl - 3 : 1;              // j >= lowest_j = Min (3, mgl-3), j >= 1 (j-1 is read), j+3 >= mgl
     j_lo = (j_lo + 2) / 3 * 3;
     const int jmax = m >= 1 ? (m - 1) / 3 * 3 : -1;     // highest in-frame position of the buffer
@@ -643,7 +778,7 @@ __device__ __forceinline__ void mg_starts_one(const MgArgs &a, uint64_t i, const
                 if (which >= 0) {
                     if (WRITE) {
                         const double pend = ctab[g0 + dir * j];        // score[j-1] - indep_score[j-1], indep_score == 0
-                        const double sc = (j + 2 > a.ignore_score_len && 0.0 > pend) ? 0.0 : pend;   // Max (0.0, score), :1644-1646
+                        const double sc = (j + 2 > isl && 0.0 > pend) ? 0.0 : pend;   // Max (0.0, score), :1644-1646
                         gmg_start st;
                         st.score = sc; st.j = j + 2; st.pos = fwd ? k_base - j : k_base + j;
                         st.which = which; st.truncated = 0; st.first = 0;
@@ -662,7 +797,7 @@ __device__ __forceinline__ void mg_starts_one(const MgArgs &a, uint64_t i, const
 
     int first_j = 0;
     if (has_trunc) {
-        const double sc = (jmax + 2 > a.ignore_score_len && 0.0 > s_jmax) ? 0.0 : s_jmax;
+        const double sc = (jmax + 2 > isl && 0.0 > s_jmax) ? 0.0 : s_jmax;
         gmg_start st;
         st.score = sc; st.j = jmax + 2; st.pos = fwd ? k_base - jmax : k_base + jmax;
         st.which = -1; st.truncated = 1; st.first = 1;
@@ -834,7 +969,8 @@ __global__ __launch_bounds__(MG_ERR_BLOCK) void k_mg_err_flat(MgArgs a, const in
             walking = true;
         };
         auto emit = [&](double raw, int j_full, int pos, int which, int truncated, int first) __attribute__((always_inline)) -> uint32_t {
-            const double sc = (j_full > a.ignore_score_len && 0.0 > raw) ? 0.0 : raw;
+            const int isl = a.read_isl ? a.read_isl[o.read] : a.ignore_score_len;
+            const double sc = (j_full > isl && 0.0 > raw) ? 0.0 : raw;
             if (R.count == 0 || (fwd ? pos < R.ext_pos : pos > R.ext_pos)) { R.ext_pos = pos; R.ext_jmin = R.ext_jmax = j_full; }
             else if (pos == R.ext_pos) { if (j_full < R.ext_jmin) R.ext_jmin = j_full; if (j_full > R.ext_jmax) R.ext_jmax = j_full; }
             if (sc > R.best) R.best = sc;
@@ -1108,7 +1244,8 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
         };
         auto emit = [&](double raw, int j_loc, int pos, int which, int truncated, int first, uint32_t kind) __attribute__((always_inline)) -> uint32_t {
             const int j_full = j_loc + 2 + suffix_j;
-            const double sc = (j_full > a.ignore_score_len && 0.0 > raw) ? 0.0 : raw;
+            const int isl = a.read_isl ? a.read_isl[a.orfs[orf].read] : a.ignore_score_len;      // (a start is rare: no lane state for it)
+            const double sc = (j_full > isl && 0.0 > raw) ? 0.0 : raw;
             uint32_t slot = MG_NO_SLOT;
             if (WRITE) {
                 slot = (uint32_t)a.start_off[orf] + atomicAdd(&a.fill[orf], 1u);
@@ -1425,9 +1562,85 @@ __global__ __launch_bounds__(256) void k_mg_widen(const uint32_t *in, uint64_t *
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = in[i];
 }
 
+// Frame_Scores with one null model per read from the complete fp32 gene rows: out[row][g] = (double) gene - (double) null
+// (gmg_frame_score6_nulls; the table the error branch walks in classification mode).  One lane per base.
+__global__ __launch_bounds__(256) void k_mg_apply_nulls(MgArgs a, double *out, uint64_t out_stride)
+{
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t r = a.tile_read[g / GMG_TILE];
+        uint64_t r_end = a.read_off[r + 1];
+        while (g >= r_end) { r++; r_end = a.read_off[r + 1]; }
+        const uint64_t off = a.read_off[r];
+        const int n = (int)(r_end - off), si = (int)(g - off);
+        const uint32_t ni = a.read_null ? a.read_null[r] : 0u;
+        const float *nt = a.null_tab + (size_t)ni * MG_NULL_FLOATS;
+        const uint64_t x = dev_window_bits(a.packed, (int64_t)g - 2);          // bases g-2 .. g+2 in the low ten bits
+        const uint32_t five = (uint32_t)x & 0x3ffu, c0 = (five >> 4) & 3u;
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            const float nf = mg_null_value<true>(nt, f, si, n, c0, (five >> 6) & 3u, (five >> 8) & 3u);
+            const float nr = mg_null_value<false>(nt, f, si, n, c0, (five >> 2) & 3u, five & 3u);
+            out[(uint64_t)f * out_stride + g] = (double)a.gene32[(uint64_t)f * a.fs_stride + g] - (double)nf;
+            out[(uint64_t)(3 + f) * out_stride + g] = (double)a.gene32[(uint64_t)(3 + f) * a.fs_stride + g] - (double)nr;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+static unsigned grid_for(uint64_t n);
+
+// the table of gmg_frame_score6 with read r scored against null model d_read_null[r] (device array, or NULL: model 0)
+static int mg_frame6_nulls(const gmg_model *gene, const float *d_null_tab, const uint32_t *d_read_null,
+                           const gmg_reads *reads, double *d_out, uint64_t stride, hipStream_t s)
+{
+    if (reads->total_bases == 0) return GMG_OK;
+    const uint64_t gstride = (reads->total_bases + 15) & ~15ull;
+    float *d_gene32 = nullptr;
+    GMG_HIP(gmg_pool_alloc((void **)&d_gene32, (size_t)6 * gstride * sizeof(float)));
+    int rc = gmg_launch_gene6_full(gene, reads, d_gene32, gstride, s);
+    if (rc) { gmg_pool_release(d_gene32); return gmg_set_error(rc, "per-read null models need a gene model of the default shape (depth 7, window <= 15, periodicity 3)"); }
+    MgArgs a;
+    memset(&a, 0, sizeof a);
+    a.packed = reads->d_packed;
+    a.read_off = reads->d_off;
+    a.tile_read = reads->d_tile_read;
+    a.n_reads = reads->n_reads;
+    a.total = reads->total_bases;
+    a.gene32 = d_gene32;
+    a.fs_stride = gstride;
+    a.null_tab = d_null_tab;
+    a.read_null = d_read_null;
+    hipLaunchKernelGGL(k_mg_apply_nulls, dim3(grid_for(a.total)), dim3(256), 0, s, a, d_out, stride);
+    GMG_HIP(hipGetLastError());
+    gmg_pool_release_after(d_gene32, s);
+    return GMG_OK;
+}
+
+extern "C" int gmg_frame_score6_nulls(const gmg_model *gene, const gmg_null_set *nulls, const uint32_t *read_null,
+                                      const gmg_reads *reads, double *d_out, uint64_t row_stride, void *stream)
+{
+    { int rc_enter = gmg_enter("gmg_frame_score6_nulls"); if (rc_enter) return rc_enter; }
+    if (!gene || !nulls || !reads || (!read_null && reads->n_reads) || (!d_out && reads->total_bases))
+        return gmg_set_error(GMG_EINVAL, "gmg_frame_score6_nulls: NULL argument");
+    if (row_stride < reads->total_bases) return gmg_set_error(GMG_EINVAL, "gmg_frame_score6_nulls: row stride < total_bases");
+    if (gene->dev.P < 3) return gmg_set_error(GMG_EBADMODEL, "gmg_frame_score6_nulls: periodicity must be >= 3");
+    for (uint64_t r = 0; r < reads->n_reads; r++)
+        if (read_null[r] >= (uint32_t)nulls->n)
+            return gmg_set_error(GMG_ERANGE, "gmg_frame_score6_nulls: read %llu names null model %u of %d", (unsigned long long)r, read_null[r], nulls->n);
+    if (reads->total_bases == 0) return GMG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t *d_rn = nullptr;
+    GMG_HIP(gmg_pool_alloc((void **)&d_rn, reads->n_reads * 4));
+    hipError_t e = hipMemcpyAsync(d_rn, read_null, reads->n_reads * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);              // (the caller's array may go away when the call returns)
+    int rc = e == hipSuccess ? mg_frame6_nulls(gene, nulls->d_tab, d_rn, reads, d_out, row_stride, s)
+                             : gmg_set_error(GMG_EHIP, "gmg_frame_score6_nulls: %s", hipGetErrorString(e));
+    gmg_pool_release_after(d_rn, s);
+    return rc;
+}
+
 static unsigned mg_codon_from(const char *s)            // Codon_t::Set_From (gene.cc:133-146)
 {
     unsigned d = 0;
@@ -1503,6 +1716,14 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (!find_only && (gene->dev.P != 3 || nul->dev.P != 3))
         return gmg_set_error(GMG_EBADMODEL, "gmg_mg_score_reads: Score_All_Frames needs models of periodicity 3");
     if (reads->n_reads >= 0x7fffffffull) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large");
+    if (!find_only && prm->nulls) {                     // classification mode: one null model per read
+        if (!prm->read_null && reads->n_reads) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: nulls without read_null");
+        for (uint64_t r = 0; r < reads->n_reads; r++)
+            if (prm->read_null[r] >= (uint32_t)prm->nulls->n)
+                return gmg_set_error(GMG_ERANGE, "gmg_mg_score_reads: read %llu names null model %u of %d", (unsigned long long)r,
+                                     prm->read_null[r], prm->nulls->n);
+    } else if (!find_only && (prm->read_null || prm->read_ignore_score_len))
+        return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: read_null / read_ignore_score_len need a null set (gmg_mg_params.nulls)");
     const int err_mode = (prm->flags & GMG_MG_ALLOW_INDELS) ? 1 : (prm->flags & GMG_MG_ALLOW_SUBS) ? 2 : 0;
     if ((prm->flags & GMG_MG_ALLOW_INDELS) && (prm->flags & GMG_MG_ALLOW_SUBS))     // glimmer-mg.cc:952-955
         return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: cannot use indels and substitutions simultaneously");
@@ -1567,6 +1788,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     memset(res, 0, sizeof *res);
     res->n_reads = reads->n_reads;
     double *d_fs_own = nullptr;
+    float *d_gene32 = nullptr;
+    uint32_t *d_read_null = nullptr;
+    int32_t *d_read_isl = nullptr;
     uint32_t *d_read_cnt = nullptr, *d_orf_cnt = nullptr;
     uint64_t *d_start_off = nullptr;
     double *d_cum = nullptr;
@@ -1586,6 +1810,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     auto fail = [&](int code) {
         (void)hipDeviceSynchronize();                   // nothing (either stream) may still use the blocks that go back to the cache
         if (d_fs_own) gmg_pool_release(d_fs_own);
+        if (d_gene32) gmg_pool_release(d_gene32);
+        if (d_read_null) gmg_pool_release(d_read_null);
+        if (d_read_isl) gmg_pool_release(d_read_isl);
         if (d_read_cnt) gmg_pool_release(d_read_cnt);
         if (d_orf_cnt) gmg_pool_release(d_orf_cnt);
         if (d_start_off) gmg_pool_release(d_start_off);
@@ -1621,17 +1848,54 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     MgTimer tm(s);
     // 1. Frame_Scores
     if (!find_only) {
+    // classification mode: the per-read tables go to the device once per call (4 + 4 bytes per read)
+    // (a (3,2,3) model's partial-window table follows its full-window table in the model blob: gmg_model_upload)
+    const float *d_null_tab = nul->dev.dense;
+    if (prm->nulls) {
+        d_null_tab = prm->nulls->d_tab;
+        if (a.n_reads) {
+            MG_TRY(gmg_pool_alloc((void **)&d_read_null, a.n_reads * 4));
+            MG_TRY(hipMemcpyAsync(d_read_null, prm->read_null, a.n_reads * 4, hipMemcpyHostToDevice, s));
+            if (prm->read_ignore_score_len) {
+                MG_TRY(gmg_pool_alloc((void **)&d_read_isl, a.n_reads * 4));
+                MG_TRY(hipMemcpyAsync(d_read_isl, prm->read_ignore_score_len, a.n_reads * 4, hipMemcpyHostToDevice, s));
+            }
+        }
+        a.read_null = d_read_null;
+        a.read_isl = d_read_isl;
+    }
+    a.null_tab = d_null_tab;
+    // The call's own table in the default mode is the GENE32 form: the gene model's fp32 rows (half the bytes to write, half to
+    // read back), the null model applied where the running sums are built.  A caller's table, the error branch (its walks read
+    // the table in place) and model shapes without the fast path keep the fp64 table of gmg_frame_score6.
+    const bool nul_dense3 = nul->dev.has_dense && nul->dev.W == 3 && nul->dev.P == 3 && nul->dev.dense_part == nul->dev.dense + 192;
+    // Measured (1M x 500 bp, profiles/r02_mg_*): with ONE null model the fp64 table wins (running sums 7.2 ms against 9.1 ms: the
+    // conversion costs more vector work than the halved read saves); with per-read null models GENE32 saves the extra pass over
+    // the table (13.3 ms against 16.6 ms for the table + sums).  Option mg_gene32: 0 never, 1 with per-read nulls (default), 2 always.
+    const long long g32_opt = gmg_opt(GMG_OPT_MG_GENE32);
+    const bool g32 = !d_frame_scores && !err_mode && a.total && (g32_opt == 2 || (g32_opt == 1 && prm->nulls)) && nul_dense3 &&
+                     gene->dev.has_fast && gene->dev.D == 7 && gene->dev.W >= 3 && gene->dev.W <= 15;
+    if (prm->nulls && !nul_dense3) return fail(gmg_set_error(GMG_EBADMODEL, "gmg_mg_score_reads: per-read null models are (3,2,3) models"));
     a.fs_stride = a.total;
-    if (!d_frame_scores && a.total) {
-        a.fs_stride = (a.total + 15) & ~15ull;          // our own table: every row on a 128-byte line
-        MG_TRY(gmg_pool_alloc((void **)&d_fs_own, (size_t)6 * a.fs_stride * sizeof(double)));
-        d_frame_scores = d_fs_own;
-    }
-    if (a.total) {
-        rc = gmg_launch_frame6_strided(gene, nul, reads, d_frame_scores, a.fs_stride, s);
+    if (g32) {
+        a.fs_stride = (a.total + 31) & ~31ull;          // every fp32 row on a 128-byte line
+        MG_TRY(gmg_pool_alloc((void **)&d_gene32, (size_t)6 * a.fs_stride * sizeof(float)));
+        rc = gmg_launch_gene6_full(gene, reads, d_gene32, a.fs_stride, s);
         if (rc) return fail(rc);
+        a.gene32 = d_gene32;
+    } else {
+        if (!d_frame_scores && a.total) {
+            a.fs_stride = (a.total + 15) & ~15ull;      // our own table: every row on a 128-byte line
+            MG_TRY(gmg_pool_alloc((void **)&d_fs_own, (size_t)6 * a.fs_stride * sizeof(double)));
+            d_frame_scores = d_fs_own;
+        }
+        if (a.total) {
+            if (prm->nulls) rc = mg_frame6_nulls(gene, d_null_tab, d_read_null, reads, d_frame_scores, a.fs_stride, s);
+            else rc = gmg_launch_frame6_strided(gene, nul, reads, d_frame_scores, a.fs_stride, s);
+            if (rc) return fail(rc);
+        }
+        a.fs = d_frame_scores;
     }
-    a.fs = d_frame_scores;
     tm.lap("frame scores");
     if (err_mode) {                                     // the error branch sums per call; it needs the penalties and the qualities
         MG_TRY(gmg_pool_alloc((void **)&d_pen, sizeof pen_host));
@@ -1661,6 +1925,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (reads->uniform_len > 0) {                  // every tile takes cap / L whole reads
             if ((uint32_t)reads->uniform_len <= cap) {
                 a.uniform_len = reads->uniform_len;
+                a.uniform_magic = (uint32_t)((0x100000000ull + (uint64_t)reads->uniform_len - 1) / (uint64_t)reads->uniform_len);
                 a.reads_per_tile = cap / reads->uniform_len < MG_TILE_READS ? cap / reads->uniform_len : MG_TILE_READS;
                 a.n_tiles = (a.n_reads + a.reads_per_tile - 1) / a.reads_per_tile;
                 tiled = true; rest = false;
@@ -1693,12 +1958,18 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (tiled && a.n_tiles) {
             const size_t lds = (size_t)3 * (cap + 8) * sizeof(double);
             const unsigned grid = (unsigned)(2 * a.n_tiles < 256 * 1024 ? 2 * a.n_tiles : 256 * 1024);
-            if (small) {
-                hipLaunchKernelGGL((k_mg_cum_tiled<512, 128>), dim3(grid), dim3(128), lds, s, a);     // two waves per tile: 7.1 ms; one: 8.0; four: 9.0
+            if (small) {                                // two waves per tile: 7.1 ms; one: 8.0; four: 9.0
+                if (g32) hipLaunchKernelGGL((k_mg_cum_tiled<512, 128, true>), dim3(grid), dim3(128), lds, s, a);
+                else hipLaunchKernelGGL((k_mg_cum_tiled<512, 128, false>), dim3(grid), dim3(128), lds, s, a);
             } else {
                 // eight waves per tile: 8.8 ms per 400k x 1000 bp; four: 9.7; two: 11.1; twelve: 13.3
-                MG_TRY(hipFuncSetAttribute((const void *)k_mg_cum_tiled<1504, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((k_mg_cum_tiled<1504, 512>), dim3(grid), dim3(512), lds, s, a);
+                if (g32) {
+                    MG_TRY(hipFuncSetAttribute((const void *)k_mg_cum_tiled<1504, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((k_mg_cum_tiled<1504, 512, true>), dim3(grid), dim3(512), lds, s, a);
+                } else {
+                    MG_TRY(hipFuncSetAttribute((const void *)k_mg_cum_tiled<1504, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((k_mg_cum_tiled<1504, 512, false>), dim3(grid), dim3(512), lds, s, a);
+                }
             }
             MG_TRY(hipGetLastError());
         }
@@ -1712,7 +1983,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
                 hipLaunchKernelGGL(k_mg_unfit_list, dim3(grid_for(a.n_reads)), dim3(256), 0, s, a);
                 MG_TRY(hipGetLastError());
             }
-            hipLaunchKernelGGL(k_mg_cum, dim3(grid_for(2 * a.n_reads)), dim3(256), 0, s, a);
+            if (g32) hipLaunchKernelGGL(k_mg_cum<true>, dim3(grid_for(2 * a.n_reads)), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(k_mg_cum<false>, dim3(grid_for(2 * a.n_reads)), dim3(256), 0, s, a);
             MG_TRY(hipGetLastError());
         }
     }
@@ -1978,6 +2250,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     tm.lap("start lists");
 #undef MG_TRY
     if (d_fs_own) gmg_pool_release(d_fs_own);
+    if (d_gene32) gmg_pool_release(d_gene32);
+    if (d_read_null) gmg_pool_release(d_read_null);
+    if (d_read_isl) gmg_pool_release(d_read_isl);
     gmg_pool_release(d_read_cnt);
     if (d_orf_cnt) gmg_pool_release(d_orf_cnt);
     if (d_start_off) gmg_pool_release(d_start_off);

@@ -161,6 +161,17 @@ int gmg_frame_score6(const gmg_model *gene, const gmg_model *null_model, const g
 int gmg_frame_score6_strided(const gmg_model *gene, const gmg_model *null_model, const gmg_reads *reads,
                              double *d_out, uint64_t row_stride, void *stream);
 
+/* Per-read null models: a set of (3,2,3) Build_Indep_WO_Stops models on the device (1 KB each), and the six-frame table
+ * with read r scored against null model read_null[r] (HOST array, n_reads entries) -- what Score_All_Frames gives inside
+ * glimmer-mg's classification loop, where Update_Meta_Null_ICM (glimmer-mg.cc:2050-2068) rebuilds Indep_Model per read.
+ * (Two passes: fp32 gene values, then the null model's part; gmg_mg_score_reads with gmg_mg_params.nulls applies the
+ * null models where it builds its running sums, at no extra pass.) */
+typedef struct gmg_null_set gmg_null_set;
+int gmg_null_set_upload(const gmg_model *const *null_models, int n_models, gmg_null_set **out);
+int gmg_null_set_free(gmg_null_set *nulls);
+int gmg_frame_score6_nulls(const gmg_model *gene, const gmg_null_set *nulls, const uint32_t *read_null,
+                           const gmg_reads *reads, double *d_out, uint64_t row_stride, void *stream);
+
 /* ICM_t::Frame_Score (src/ICM/icm.cc:485-509) on every segment: one fixed
  * sub-model `frame` for all positions, no sum.  d_out[offset(i)+j]. */
 int gmg_segment_frame_score(const gmg_model *m, const gmg_reads *reads, const gmg_segments *segs,
@@ -308,6 +319,13 @@ typedef struct gmg_mg_params {
                                     file (-q), Clean_Quality_454 (glimmer-mg.cc:519-546) is applied on the device;
                                     NULL: Set_Quality_454 (:1865-1906, homopolymer runs).  Indels only: with -s the
                                     reference never loads the values (:384-392)                    */
+    /* classification mode: glimmer-mg rebuilds Indep_Model and Ignore_Score_Len for EVERY read from the GC of its classes
+     * (Update_Meta_Null_ICM, glimmer-mg.cc:2050-2068, inside the ICM-grouped loop :361-451).  One call scores a whole
+     * ICM group: read r takes model read_null[r] of `nulls` (instead of the null_model argument) and
+     * read_ignore_score_len[r] (instead of ignore_score_len above).  All three NULL: one null model for the batch. */
+    const struct gmg_null_set *nulls;
+    const uint32_t *read_null;           /* HOST [n_reads] */
+    const int32_t *read_ignore_score_len;/* HOST [n_reads], or NULL with nulls set: ignore_score_len for every read */
 } gmg_mg_params;
 
 /* the Error_t list (src/Common/gene.hh:138-146) of one start: type 0 insertion, 1 deletion, 2 substitution */
