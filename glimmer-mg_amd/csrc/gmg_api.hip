@@ -326,6 +326,16 @@ extern "C" int gmg_model_upload(const int16_t *mip, const float *prob4, int W, i
     e = hipMemcpy(m->d_blob, blob.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(m->d_blob); delete m; return gmg_set_error(GMG_EHIP, "gmg_model_upload: hipMemcpy: %s", hipGetErrorString(e)); }
     m->blob_bytes = total;
+    m->min_exp = 255;
+    m->odd_values = 0;
+    for (size_t i = 0; i < PN * 4; i++) {
+        uint32_t b;
+        memcpy(&b, &prob4[i], 4);
+        const uint32_t ex = (b >> 23) & 0xffu;
+        if ((b << 1) == 0) continue;                    // +-0: adds nothing
+        if ((b >> 31) == 0 || ex == 0 || ex == 255) m->odd_values = 1;      // positive, denormal, infinity / NaN
+        if ((int)ex < m->min_exp) m->min_exp = (int)ex;
+    }
     unsigned char *d = (unsigned char *)m->d_blob;
     m->dev.W = W; m->dev.D = D; m->dev.P = P; m->dev.N = N;
     m->dev.mip = (const int8_t *)(d + o_mip);

@@ -53,10 +53,85 @@ struct Frame6Args {
     uint64_t stride;        // distance between the rows of `out` in doubles (>= total)
     float *out_gene;        // gene-only mode (gmg_launch_gene6): [6][gstride] gene values as fp32
     uint64_t gstride;       // distance between the rows of out_gene in floats (>= total)
+    // SUM mode (gmg_launch_strings_sum): per read and string the sum of the values whose window lies inside the read
+    double *str_sums;       // [n_reads][2] (forward string, reverse complement), zeroed by the caller: atomically added to
+    uint32_t uniform_len;   // > 0: every read has this length (read lookups by arithmetic)
 };
 
 constexpr int f6_cstride(int dt) { return ((((1 << (2 * dt)) - 1) / 3) + 15) & ~15; }
 constexpr int f6_level_base(int l) { return ((1 << (2 * l)) - 1) / 3; }
+
+// SUM mode of k_frame6t: the four values one lane holds of a chunk -- the read itself (f0, f1) and its reverse complement (r0, r1)
+// at bases g, g + 1 -- into the accumulators of their reads.  All positions are relative to the round's first base; span0 = the
+// wave's first base.  roff: the reads' first bases (ragged batches; rel_a = read of the previous span of this wave, carried from
+// chunk to chunk), or len > 0 for reads of one length (rem0 = the round's first base modulo len).  Reads are at least 86 bases long
+// (the caller checks): a wave's 128 bases touch at most three of them.  Not inlined: sixteen copies of it in the unrolled second
+// phase cost more registers than the call.
+// sum of x over the wave's 64 lanes, valid in lane 63: DPP moves of the two halves + one addition per step (no LDS traffic:
+// the kernel's bottleneck is the LDS, a shuffle through ds_bpermute would add to it).  The order of the additions is whatever
+// the butterfly makes it -- see SUM above for why that is allowed.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double f6_dpp_add(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return x + __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));      // (lanes the mask leaves out add 0)
+}
+__device__ __forceinline__ double f6_wave_sum(double x)
+{
+    x = f6_dpp_add<0xb1>(x);                            // quad_perm [1,0,3,2]
+    x = f6_dpp_add<0x4e>(x);                            // quad_perm [2,3,0,1]
+    x = f6_dpp_add<0x141>(x);                           // row_half_mirror
+    x = f6_dpp_add<0x140>(x);                           // row_mirror: every lane of a row of 16 holds the row's sum
+    x = f6_dpp_add<0x142, 0xa>(x);                      // row_bcast:15 into rows 1 and 3
+    x = f6_dpp_add<0x143, 0xc>(x);                      // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+    return x;
+}
+
+__device__ __noinline__ void f6_sum_chunk(double *sum, const int32_t *roff, uint32_t len, uint32_t len_magic, uint32_t rem0, int32_t wm1,
+                                          uint32_t span0, uint32_t &rel_a, double f0, double r0, double f1, double r1)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    int32_t a0, a1, a2, a3;
+    if (len) {
+        rel_a = __umulhi(span0 + rem0, len_magic);                  // (span0 + rem0) / len, < 2^17
+        a0 = (int32_t)(rel_a * len) - (int32_t)rem0;
+        a1 = a0 + (int32_t)len; a2 = a1 + (int32_t)len; a3 = a2 + (int32_t)len;
+    } else {
+        uint32_t ra = rel_a;
+        while (roff[ra + 1] <= (int32_t)span0) ra++;
+        rel_a = ra;
+        a0 = roff[ra]; a1 = roff[ra + 1]; a2 = roff[ra + 2]; a3 = roff[ra + 3];
+    }
+    if ((int32_t)span0 >= a0 + wm1 && (int32_t)span0 + 128 <= a1 - wm1) {   // every value of the wave belongs to read A and counts
+        const double f = f6_wave_sum(f0 + f1), r = f6_wave_sum(r0 + r1);
+        if (lane == 63) { unsafeAtomicAdd(&sum[2 * rel_a], f); unsafeAtomicAdd(&sum[2 * rel_a + 1], r); }
+        return;
+    }
+    // a read boundary, or a read's first / last W-1 bases, inside the span: what each lane's two bases give to read A and to
+    // read B (the next one), summed over the wave; a third read (reads shorter than 128 bases) takes its values one by one
+    double fa = 0.0, ra_ = 0.0, fb = 0.0, rb = 0.0;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const int32_t g = (int32_t)(span0 + 2 * lane) + b;
+        const uint32_t k = (g >= a1 ? 1u : 0u) + (g >= a2 ? 1u : 0u);
+        const int32_t s0 = k == 0 ? a0 : k == 1 ? a1 : a2, s1 = k == 0 ? a1 : k == 1 ? a2 : a3;
+        // the read itself: window = the W-1 bases in front; reverse complement at forward coordinates: the W-1 bases behind
+        const double vf = g - s0 >= wm1 ? (b ? f1 : f0) : 0.0, vr = s1 - 1 - g >= wm1 ? (b ? r1 : r0) : 0.0;
+        fa += k == 0 ? vf : 0.0; ra_ += k == 0 ? vr : 0.0;
+        fb += k == 1 ? vf : 0.0; rb += k == 1 ? vr : 0.0;
+        if (k == 2) {
+            if (vf != 0.0) unsafeAtomicAdd(&sum[2 * (rel_a + 2)], vf);
+            if (vr != 0.0) unsafeAtomicAdd(&sum[2 * (rel_a + 2) + 1], vr);
+        }
+    }
+    fa = f6_wave_sum(fa); ra_ = f6_wave_sum(ra_); fb = f6_wave_sum(fb); rb = f6_wave_sum(rb);
+    if (lane == 63) {
+        unsafeAtomicAdd(&sum[2 * rel_a], fa); unsafeAtomicAdd(&sum[2 * rel_a + 1], ra_);
+        unsafeAtomicAdd(&sum[2 * rel_a + 2], fb); unsafeAtomicAdd(&sum[2 * rel_a + 3], rb);
+    }
+}
 
 // One descent in the completed tree of depth DT: C holds the window, tab the shift table in LDS.
 // Returns the leaf index (0 .. 4^DT-1).
@@ -112,7 +187,14 @@ __device__ __forceinline__ uint32_t f6_descend(const uint8_t *tab, uint32_t C, u
 // nothing complemented) and its reverse complement (row 1, stored at forward coordinates: window = the complements
 // of the W-1 bases behind p).  Same geometry as the complemented / reversed buffers with the complement swapped;
 // every work-group works on sub-model 0.
-template <int BLOCK, int DT, int K, int DIAG, bool PAIR, bool GENE_ONLY, bool STRINGS = false>
+// SUM (with STRINGS): no per-base values leave the kernel.  Score_String adds its values one after the other (icm.cc:871-900);
+// here a wave adds the 128 values it holds of one string by a shuffle tree, the work-group collects the reads' partial
+// sums of a round in LDS and adds them to a.str_sums once per round.  The order differs from the reference's -- and the
+// result does not, for every read whose sums the caller then accepts (k_string_finish, gmg_strings.hip): all values have
+// one sign and are multiples of 2^(e_min - 150), so while |sum| < 2^(e_min - 150 + 53) every partial sum of every order is
+// exact.  The first W-1 positions of either string (window outside the read) are left out here and added there.
+// A worker's chunks are consecutive in this mode, so that a round is one run of 32,768 bases = a few dozen whole reads.
+template <int BLOCK, int DT, int K, int DIAG, bool PAIR, bool GENE_ONLY, bool STRINGS = false, bool SUM = false>
 __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
 {
     constexpr int CS = f6_cstride(DT);
@@ -126,6 +208,9 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     __shared__ __attribute__((aligned(16))) double s_nr[64];        // null model, complemented buffer
     __shared__ __attribute__((aligned(16))) double s_nf[64];        // null model, reversed buffer
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[K * RAWW];   // packed words of the current round
+    constexpr uint32_t NR_MAX = SUM ? 384 : 1;                      // reads of a round with an accumulator in LDS (more: global atomics)
+    __shared__ double s_sum[SUM ? 2 * NR_MAX : 1];                  // [read of the round][string]
+    __shared__ int32_t s_roff[SUM ? NR_MAX + 4 : 1];                // their first bases relative to the round's first (ragged batches)
 
     const int ftype = STRINGS ? 0 : blockIdx.x % 3;
     const uint32_t worker = STRINGS ? blockIdx.x : blockIdx.x / 3, nworkers = STRINGS ? gridDim.x : gridDim.x / 3;
@@ -133,8 +218,13 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     const uint8_t *half_src = (const uint8_t *)(a.gene.chalf + (size_t)ftype * 2 * LEAVES * 2);   // [2][LEAVES][2] floats
 
     const uint64_t n_chunks = a.total / SPAN;                       // full chunks only
-    if (worker >= n_chunks) return;
-    const uint32_t n_mine = (uint32_t)((n_chunks - worker + nworkers - 1) / nworkers);   // chunks worker, worker+nworkers, ...
+    // chunk j of this worker: worker + j * nworkers (neighbouring work-groups write neighbouring chunks), or, SUM mode, a
+    // consecutive range of the batch
+    const uint64_t per_worker = SUM ? (n_chunks + nworkers - 1) / nworkers : 0;
+    const uint64_t chunk0 = SUM ? (uint64_t)worker * per_worker : worker, chunk_step = SUM ? 1 : nworkers;
+    if (chunk0 >= n_chunks) return;
+    const uint32_t n_mine = SUM ? (uint32_t)(n_chunks - chunk0 < per_worker ? n_chunks - chunk0 : per_worker)
+                                : (uint32_t)((n_chunks - worker + nworkers - 1) / nworkers);
 
     // every wave-instruction moves 1 KiB L2 -> LDS: lane l's 16 bytes land at the wave's LDS base + 16 l
     constexpr uint32_t NHALF = HALF_BYTES / 16 / BLOCK;             // 16-byte pieces per lane and half
@@ -156,7 +246,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
             const uint32_t t = threadIdx.x + i * BLOCK;
             const uint32_t k = t / RAWW, w = t - k * RAWW;
             const uint32_t j = j0 + k < n_mine ? j0 + k : n_mine - 1;
-            const uint64_t c = worker + (uint64_t)j * nworkers;
+            const uint64_t c = chunk0 + (uint64_t)j * chunk_step;
             raw_t[i] = t < K * RAWW ? a.packed[c * (SPAN / 16) - 1 + w] : 0u;
         }
     };
@@ -201,6 +291,40 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     const uint32_t wsh = 2u * (first_rel & 15u);
     double *const out_f = a.out + (uint64_t)ftype * a.stride;
     double *const out_r = a.out + (uint64_t)(3 + ftype) * a.stride;
+
+    // ---- SUM mode: the reads of the round (kk * SPAN consecutive bases) and their accumulators
+    uint64_t round_r0 = 0;                                          // read that holds the round's first base
+    uint32_t round_rem0 = 0, sum_rel = 0;                           // uniform batches: that base's position in its read; ragged: see f6_sum_chunk
+    const uint32_t L_u = a.uniform_len;
+    const uint32_t L_magic = L_u > 1 ? (uint32_t)((0x100000000ull + L_u - 1) / L_u) : 0u;
+    auto round_setup = [&](uint32_t j0) __attribute__((always_inline)) {       // all lanes; before the barrier that opens phase 2
+        const uint64_t round_g0 = (chunk0 + j0) * SPAN;
+        if (L_u) {
+            round_r0 = round_g0 / L_u;
+            round_rem0 = (uint32_t)(round_g0 - round_r0 * L_u);
+        } else {
+            uint64_t r = a.tile_read[round_g0 / GMG_TILE];          // read holding base round_g0 (a multiple of 1,024)
+            while (a.off[r + 1] <= round_g0) r++;
+            round_r0 = r;
+            for (uint32_t i = threadIdx.x; i < NR_MAX + 4; i += BLOCK) {
+                const uint64_t rr = r + i < a.n_reads ? r + i : a.n_reads;
+                const int64_t rel = (int64_t)a.off[rr] - (int64_t)round_g0;
+                s_roff[i] = rel > 0x3fffffff ? 0x3fffffff : (int32_t)rel;
+            }
+        }
+        sum_rel = 0;
+        for (uint32_t i = threadIdx.x; i < 2 * NR_MAX; i += BLOCK) s_sum[i] = 0.0;
+    };
+    auto sum_chunk = [&](uint32_t k, const double *v) __attribute__((always_inline)) {
+        f6_sum_chunk(s_sum, s_roff, L_u, L_magic, round_rem0, W - 1, k * SPAN + (threadIdx.x & ~63u) * 2u, sum_rel, v[1], v[0], v[3], v[2]);
+    };
+    // the round's sums to the batch's (one wave-instruction per 32 reads: consecutive addresses)
+    auto round_flush = [&]() __attribute__((always_inline)) {
+        for (uint32_t i = threadIdx.x; i < 2 * NR_MAX; i += BLOCK) {
+            const double x = s_sum[i];
+            if (x != 0.0) unsafeAtomicAdd(&a.str_sums[2 * round_r0 + i], x);
+        }
+    };
 
 #if GMG_F6_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
@@ -259,6 +383,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
         if (j0 + K < n_mine) raw_issue(j0 + K);
         half_issue(cur);
         if (j0 + K < n_mine) raw_commit();
+        if (SUM) round_setup(j0);
         half_landed();
         F6_STAMP(2);                                                // swap work
         __syncthreads();
@@ -281,13 +406,20 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
                     const float gf = __uint_as_float(f_was_here ? have[k][b] : got);
                     const float gr = __uint_as_float(f_was_here ? got : have[k][b]);
                     // item 2b: S[g0+b .. g0+b+2] reversed buffer; item 2b+1: S[g0+b-2 .. g0+b] complemented
-                    const double nf = s_nf[__builtin_amdgcn_ubfe(mt, mb + 4 + 2 * b, 6)];
-                    const double nr = s_nr[__builtin_amdgcn_ubfe(mt, mb + 2 * b, 6)];
-                    v[2 * b] = (double)gf - nf;                     // glimmer-mg.cc:1493,1508
-                    v[2 * b + 1] = (double)gr - nr;
+                    if (GENE_ONLY) {                                // the gene model's value alone: no null-model lookups
+                        v[2 * b] = (double)gf;
+                        v[2 * b + 1] = (double)gr;
+                    } else {
+                        const double nf = s_nf[__builtin_amdgcn_ubfe(mt, mb + 4 + 2 * b, 6)];
+                        const double nr = s_nr[__builtin_amdgcn_ubfe(mt, mb + 2 * b, 6)];
+                        v[2 * b] = (double)gf - nf;                 // glimmer-mg.cc:1493,1508
+                        v[2 * b + 1] = (double)gr - nr;
+                    }
                 }
-                const uint64_t chunk = worker + (uint64_t)(j0 + k) * nworkers;
-                if (GENE_ONLY) {
+                const uint64_t chunk = chunk0 + (uint64_t)(j0 + k) * chunk_step;
+                if (SUM) {
+                    sum_chunk((uint32_t)k, v);
+                } else if (GENE_ONLY) {
                     // v[c] = gene value exactly (the null tables hold zeros); rows of floats, 8-byte stores
                     float *gf = a.out_gene + (uint64_t)(STRINGS ? 1 : ftype) * a.gstride + chunk * SPAN;
                     float *gr = a.out_gene + (uint64_t)(STRINGS ? 0 : 3 + ftype) * a.gstride + chunk * SPAN;
@@ -319,6 +451,10 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
                     }
                 }
             }
+        }
+        if (SUM) {                                                  // (the next write to s_sum is behind two more barriers)
+            __syncthreads();
+            round_flush();
         }
         F6_STAMP(4);                                                // phase 2
     }
@@ -514,6 +650,10 @@ int gmg_launch_frame6_strided(const gmg_model *gene, const gmg_model *nul, const
     a.stride = stride;
     a.out_gene = nullptr;
     a.gstride = 0;
+    a.str_sums = nullptr;
+    a.uniform_len = 0;
+    a.str_sums = nullptr;
+    a.uniform_len = 0;
 
     // the specialised path: completed tree of depth 7 (DEFAULT_MODEL_DEPTH) and the width-3 null model
     const bool fast = gene->dev.has_fast && gene->dev.D == 7 && nul->dev.has_dense && nul->dev.W == 3 &&
@@ -590,6 +730,8 @@ static int gene6_impl(const gmg_model *gene, const gmg_reads *reads, float *d_ge
     a.stride = 0;
     a.out_gene = d_gene;
     a.gstride = gstride;
+    a.str_sums = nullptr;
+    a.uniform_len = 0;
     constexpr int BLOCK = 1024, DT = 7, KR = 16;
     constexpr uint32_t SPAN = 2 * BLOCK;
     const uint64_t n_chunks = a.total / SPAN;
@@ -662,6 +804,8 @@ int gmg_launch_strings(const gmg_model *m, const gmg_reads *reads, float *d_vals
     a.stride = 0;
     a.out_gene = d_vals;
     a.gstride = reads->total_bases;
+    a.str_sums = nullptr;
+    a.uniform_len = 0;
     constexpr int BLOCK = 1024, DT = 7, KR = 16;
     constexpr uint32_t SPAN = 2 * BLOCK;
     const uint64_t n_chunks = a.total / SPAN;
@@ -682,6 +826,47 @@ int gmg_launch_strings(const gmg_model *m, const gmg_reads *reads, float *d_vals
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, 0, false, true, true>), dim3(grid), dim3(BLOCK), lds, s, a);
     }
+    GMG_HIP(hipGetLastError());
+    return GMG_OK;
+}
+
+// The same pass with the values summed per read and string instead of stored (k_frame6t<.., SUM>): d_sums[n_reads][2] must be
+// zero; on return (stream-ordered) it holds, per read and string, the sum of the values at the positions whose window lies
+// inside the read and whose base is in front of *tail_start.  The caller (gmg_strings.hip) adds the first W-1 positions,
+// decides per read whether the order of the additions could have mattered, and recomputes the reads where it could.
+int gmg_launch_strings_sum(const gmg_model *m, const gmg_reads *reads, double *d_sums, uint64_t *tail_start, hipStream_t s)
+{
+    if (!(m->dev.has_fast && m->dev.D == 7 && m->dev.W >= 3 && m->dev.W <= 15 && m->dev.P == 1)) return GMG_EBADMODEL;
+    Frame6Args a;
+    a.gene = m->dev;
+    a.nul = m->dev;                                    // not used in gene-only mode
+    a.packed = reads->d_packed;
+    a.off = reads->d_off;
+    a.tile_read = reads->d_tile_read;
+    a.total = reads->total_bases;
+    a.n_reads = reads->n_reads;
+    a.first = 0;
+    a.count = 0;
+    a.out = nullptr;
+    a.stride = 0;
+    a.out_gene = nullptr;
+    a.gstride = 0;
+    a.str_sums = d_sums;
+    a.uniform_len = reads->uniform_len > 0 ? (uint32_t)reads->uniform_len : 0u;
+    constexpr int BLOCK = 1024, DT = 7, KR = 16;
+    constexpr uint32_t SPAN = 2 * BLOCK;
+    const uint64_t n_chunks = a.total / SPAN;
+    *tail_start = n_chunks * SPAN;
+    if (n_chunks == 0) return GMG_OK;
+    int dev = 0, n_cu = 256;
+    GMG_HIP(hipGetDevice(&dev));
+    GMG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    unsigned grid = (unsigned)n_cu;                    // one persistent work-group per CU, all on sub-model 0
+    if (grid > n_chunks) grid = (unsigned)n_chunks;
+    const size_t lds = ((size_t)1 << (2 * DT)) * 8;
+    GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, true, true, true, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, 0, true, true, true, true>), dim3(grid), dim3(BLOCK), lds, s, a);
     GMG_HIP(hipGetLastError());
     return GMG_OK;
 }

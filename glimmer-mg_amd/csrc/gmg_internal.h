@@ -42,6 +42,9 @@ struct GmgDevModel {
 };
 
 struct gmg_model {
+    // what the values of the model allow (gmg_strings.hip: sums in any order): the smallest exponent field among the non-zero
+    // probabilities' logarithms (1 .. 254; 255: all zero), and whether any value is positive, a NaN or denormal
+    int min_exp, odd_values;
     GmgDevModel dev;
     void *d_blob;          // single allocation backing every table
     size_t blob_bytes;
@@ -127,6 +130,7 @@ int gmg_launch_frame6_strided(const gmg_model *gene, const gmg_model *nul, const
 int gmg_launch_gene6(const gmg_model *gene, const gmg_reads *reads, float *d_gene, hipStream_t s);
 int gmg_launch_gene6_full(const gmg_model *gene, const gmg_reads *reads, float *d_gene, uint64_t gstride, hipStream_t s);
 int gmg_launch_strings(const gmg_model *m, const gmg_reads *reads, float *d_vals, uint64_t *tail_start, hipStream_t s);
+int gmg_launch_strings_sum(const gmg_model *m, const gmg_reads *reads, double *d_sums, uint64_t *tail_start, hipStream_t s);
 int gmg_launch_seg_frame(const gmg_model *m, const gmg_reads *r, const gmg_segments *sg, int frame,
                          double *d_out, hipStream_t s);
 int gmg_launch_seg_cum(const gmg_model *m, const gmg_reads *r, const gmg_segments *sg, int frame0,

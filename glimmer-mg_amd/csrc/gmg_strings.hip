@@ -2,14 +2,23 @@
 // simple-score (scripts/scoreReadsGlim.pl:450,482: every read and its reverse complement against every genome's ICM;
 // ICM_t::Score_String, src/ICM/icm.cc:864-903, frame 0, periodicity-1 models).  BASELINE configs[3].
 //
-// Per model two passes:
-//   k_frame6t<STRINGS> (gmg_frame6.hip)  per-base values of both strings for the whole batch, fp32 rows [2][total], at the
-//                                        six-frame kernel's rate (LDS table swapping, no read boundaries)
-//   k_string_sum                         one lane per (read, strand): the first W-1 positions of the string by the
-//                                        partial-window rule (plain descent on the original tables, icm.cc:807-842), the rest
-//                                        from the rows (streamed through LDS in contiguous slabs); ONE running sum of doubles
-//                                        in string order -- the reference's sequence of additions, so the sums are
-//                                        bit-identical.
+// Per model (option strings_fused, the default):
+//   k_frame6t<STRINGS, SUM> (gmg_frame6.hip)  the six-frame kernel's main pass on both strings, the values added per read
+//                                        inside the kernel (wave shuffle tree -> LDS accumulators per round -> one atomic add
+//                                        per read and round): nothing per base leaves the chip (0.25 B/base in, 16 B/read out)
+//   k_string_heads                       the first W-1 positions of every string by the partial-window rule (icm.cc:807-842)
+//   k_string_finish                      per (read, string): main sum + heads, and the proof that the ORDER of the additions
+//                                        could not matter: every value of the model is <= 0 and a multiple of 2^(e_min - 150),
+//                                        so while |sum| < 2^(e_min - 150 + 51) every partial sum of every order is an exact
+//                                        double -- the result IS the reference's sequential sum (icm.cc:871-900).  Reads that
+//                                        fail the test (or touch the last, partial chunk of the batch) are listed ...
+//   k_string_exact                       ... and recomputed one lane per string in the reference's order (plain descent).
+//   Models with a positive, denormal or non-finite value, or values so small that ordinary reads would fail the test, take
+//   the two-pass form below from the start.
+// Two-pass form (strings_fused = 0; 4 GB of fp32 values out and back per model and 1M x 500 bp):
+//   k_frame6t<STRINGS>                   per-base values of both strings, fp32 rows [2][total]
+//   k_string_sum                         one lane per (read, strand): heads first, then the rows streamed through LDS in
+//                                        contiguous slabs; ONE running sum of doubles in string order.
 // Models the fast pass does not cover (periodicity 3, other depths) go through k_seg_cum (exact, any shape).
 
 #include "gmg_device.h"
@@ -171,6 +180,65 @@ __global__ __launch_bounds__(64) void k_string_sum(StringSumArgs a)
     }
 }
 
+// Fused form: main sums (k_frame6t<.., SUM>) + heads -> final sums, or onto the list of strings to recompute
+struct StringFinishArgs {
+    StringSumArgs s;
+    int min_exp;                 // smallest exponent field among the model's non-zero values
+    uint32_t *n_redo;            // strings to recompute ...
+    uint32_t *redo;              // ... 2 * read + string
+};
+
+__global__ __launch_bounds__(256) void k_string_finish(StringFinishArgs a)
+{
+    const int W = a.s.m.W;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * a.s.n_reads; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i >> 1;
+        const bool rc = i & 1;
+        const uint64_t off = a.s.read_off[r];
+        const int n = (int)(a.s.read_off[r + 1] - off);
+        double sum = a.s.sums[i];                        // the positions with a full window, added in no particular order
+        const int head = n < W - 1 ? n : W - 1;
+        const float *hd = a.s.heads + ((rc ? a.s.n_reads : 0) + r) * 16;
+        for (int q = 0; q < head; q++) sum += (double)hd[q];
+        // every partial sum of every order has |x| <= |sum| (one sign) and is a multiple of 2^(min_exp - 150): exact doubles
+        // while ilogb |sum| + 2 - (min_exp - 150) <= 53 (one bit of margin for a sum that was itself rounded)
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(sum);
+        const int e = (int)((bits >> 52) & 0x7ffull) - 1023;
+        const bool exact = sum == 0.0 || e + 2 - (a.min_exp - 150) <= 53;
+        const bool complete = off + (uint64_t)n <= a.s.tail_start;       // no base in the batch's last, partial chunk
+        if (exact && complete) a.s.sums[i] = sum;
+        else a.redo[atomicAdd(a.n_redo, 1u)] = (uint32_t)i;
+    }
+}
+
+// the listed strings once more, the reference's way: plain descent, additions in string order.  One wave per string: 64
+// positions' values at a time (the descents are chains of dependent loads: one lane alone would take a millisecond per
+// read), then lane 0 adds them in order.
+__global__ __launch_bounds__(64) void k_string_exact(StringFinishArgs a)
+{
+    __shared__ float s_v[64];
+    const uint32_t n_redo = *a.n_redo;
+    for (uint32_t k = blockIdx.x; k < n_redo; k += gridDim.x) {
+        const uint32_t i = a.redo[k];
+        const uint64_t r = i >> 1;
+        const uint64_t off = a.s.read_off[r];
+        const int n = (int)(a.s.read_off[r + 1] - off);
+        const DevBuf b = dev_make_buf(a.s.packed, off, 0, (uint32_t)n, (i & 1) ? GMG_REVCOMP : GMG_FORWARD);
+        double sum = 0.0;
+        for (int q0 = 0; q0 < n; q0 += 64) {
+            const int q = q0 + (int)threadIdx.x;
+            __syncthreads();
+            s_v[threadIdx.x] = q < n ? dev_score(a.s.m, b, q, 0) : 0.0f;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int cnt = n - q0 < 64 ? n - q0 : 64;
+                for (int e = 0; e < cnt; e++) sum += (double)s_v[e];
+            }
+        }
+        if (threadIdx.x == 0) a.s.sums[i] = sum;
+    }
+}
+
 extern "C" int gmg_score_reads_strings(const gmg_model *const *models, int n_models, const gmg_reads *reads,
                                        double *d_sums, void *stream)
 {
@@ -181,6 +249,7 @@ extern "C" int gmg_score_reads_strings(const gmg_model *const *models, int n_mod
     const uint64_t nr = reads->n_reads;
     if (nr == 0 || n_models == 0) return GMG_OK;
     float *d_vals = nullptr, *d_heads = nullptr;
+    uint32_t *d_redo = nullptr;                         // [1 + 2 nr]: counter, list
     gmg_segments *segs = nullptr;                       // built on demand for models without the fast pass
     int rc = GMG_OK;
     for (int k = 0; k < n_models && rc == GMG_OK; k++) {
@@ -188,6 +257,42 @@ extern "C" int gmg_score_reads_strings(const gmg_model *const *models, int n_mod
         if (!m) { rc = gmg_set_error(GMG_EINVAL, "gmg_score_reads_strings: model %d is NULL", k); break; }
         double *out = d_sums + (size_t)k * nr * 2;
         uint64_t tail_start = 0;
+        // the fused form: values that are all <= 0 and not too small (ordinary reads then pass k_string_finish's test)
+        // ... and reads of at least 86 bases: at most 384 of them then overlap a round of 32,768 bases (the accumulators in LDS) and
+        // at most three a wave's 128 bases
+        if (gmg_opt(GMG_OPT_STRINGS_FUSED) && !m->odd_values && m->min_exp >= 109 && reads->total_bases && reads->min_len >= 86) {
+            hipError_t e = hipMemsetAsync(out, 0, nr * 2 * sizeof(double), s);
+            if (e != hipSuccess) { rc = gmg_set_error(GMG_EHIP, "gmg_score_reads_strings: %s", hipGetErrorString(e)); break; }
+            const int fused = gmg_launch_strings_sum(m, reads, out, &tail_start, s);
+            if (fused == GMG_OK) {
+                if (!d_heads) e = gmg_pool_alloc((void **)&d_heads, (size_t)2 * nr * 16 * sizeof(float));
+                if (e == hipSuccess && !d_redo) e = gmg_pool_alloc((void **)&d_redo, (1 + 2 * nr) * sizeof(uint32_t));
+                if (e == hipSuccess) e = hipMemsetAsync(d_redo, 0, 4, s);
+                if (e != hipSuccess) { rc = gmg_set_error(GMG_ENOMEM, "gmg_score_reads_strings: %s", hipGetErrorString(e)); break; }
+                StringFinishArgs f;
+                f.s.m = m->dev;
+                f.s.packed = reads->d_packed;
+                f.s.read_off = reads->d_off;
+                f.s.n_reads = nr;
+                f.s.total = reads->total_bases;
+                f.s.tail_start = tail_start;
+                f.s.vals = nullptr;
+                f.s.heads = d_heads;
+                f.s.sums = out;
+                f.min_exp = m->min_exp;
+                f.n_redo = d_redo;
+                f.redo = d_redo + 1;
+                const uint64_t items = 2 * nr * (uint64_t)(m->dev.W - 1), hb = (items + 255) / 256;
+                hipLaunchKernelGGL(k_string_heads, dim3((unsigned)(hb < 256 * 64 ? (hb ? hb : 1) : 256 * 64)), dim3(256), 0, s, f.s);
+                const uint64_t fb = (2 * nr + 255) / 256;
+                hipLaunchKernelGGL(k_string_finish, dim3((unsigned)(fb < 256 * 32 ? fb : 256 * 32)), dim3(256), 0, s, f);
+                hipLaunchKernelGGL(k_string_exact, dim3(256 * 4), dim3(64), 0, s, f);
+                e = hipGetLastError();
+                if (e != hipSuccess) rc = gmg_set_error(GMG_EHIP, "gmg_score_reads_strings: %s", hipGetErrorString(e));
+                continue;
+            }
+            if (fused != GMG_EBADMODEL) { rc = fused; break; }
+        }
         if (!d_vals && reads->total_bases) {
             hipError_t e = gmg_pool_alloc((void **)&d_vals, (size_t)2 * reads->total_bases * sizeof(float));
             if (e != hipSuccess) { rc = gmg_set_error(GMG_ENOMEM, "gmg_score_reads_strings: %s", hipGetErrorString(e)); break; }
@@ -238,6 +343,7 @@ extern "C" int gmg_score_reads_strings(const gmg_model *const *models, int n_mod
     hipError_t e = hipStreamSynchronize(s);            // the scratch goes back to the cache: nothing may still use it
     if (d_vals) gmg_pool_release(d_vals);
     if (d_heads) gmg_pool_release(d_heads);
+    if (d_redo) gmg_pool_release(d_redo);
     if (segs) gmg_segments_free(segs);
     if (rc == GMG_OK && e != hipSuccess) rc = gmg_set_error(GMG_EHIP, "gmg_score_reads_strings: %s", hipGetErrorString(e));
     return rc;

@@ -77,3 +77,80 @@ def test_strings_edge_batches(gpu, oracle):
     for r, s in enumerate(seqs):
         assert got[0, r, 0] == got[1, r, 0] == oracle.score_string(om, s, 0)
         assert got[0, r, 1] == got[1, r, 1] == oracle.score_string(om, revcomp(s), 0)
+
+
+def test_fused_sums_equal_the_two_pass_sums_and_the_oracle_on_ragged_long_reads(gpu, oracle):
+    """reads of 86 .. 1,400 bases (the fused form: sums inside the main pass, order of the additions proven irrelevant per
+    read) against the two-pass form (one running sum per string in string order) and the oracle; read boundaries fall at
+    every phase of the kernel's 128-base spans and 32,768-base rounds"""
+    rng = np.random.default_rng(77)
+    lengths = [86, 87, 127, 128, 129, 255, 256, 257, 1400, 2048, 2049, 4097] + [int(x) for x in rng.integers(86, 1400, size=700)]
+    seqs = ["".join("acgt"[c] for c in rng.integers(0, 4, size=n)) for n in lengths]
+    reads = gpu.Reads.from_strings(seqs)
+    names = ["cluster-0.icm", "cluster-3.icm", "cluster-5.icm"]
+    models = [gpu.Icm.open(os.path.join(DATA, n)) for n in names]
+    with gpu.option("strings_fused", 1):
+        fused = gpu.score_reads_strings(models, reads)
+    with gpu.option("strings_fused", 0):
+        two_pass = gpu.score_reads_strings(models, reads)
+    assert fused.tobytes() == two_pass.tobytes()
+    for k, name in enumerate(names):
+        m = oracle.read(os.path.join(DATA, name))
+        for r in list(range(12)) + [int(x) for x in rng.integers(0, len(seqs), 40)]:
+            assert fused[k, r, 0] == oracle.score_string(m, seqs[r], 0), (name, r)
+            assert fused[k, r, 1] == oracle.score_string(m, revcomp(seqs[r]), 0), (name, r)
+
+
+def test_fused_form_refuses_models_whose_values_could_make_the_order_matter(gpu, oracle, tmp_path):
+    """a model with a probability so close to 1 that its logarithm is tiny (and one with a zero probability: -FLT_MAX):
+    the first takes the two-pass form from the start, reads that meet the second are recomputed in string order --
+    either way the sums are the oracle's"""
+    src = os.path.join(DATA, "cluster-2.icm")
+    raw = bytearray(open(src, "rb").read())
+    rec0 = 150 + 24                                     # first record: int32 id, 4 floats, int16 mip
+    tiny = np.frombuffer(raw, "<f4", 4, rec0 + 4).copy()
+    tiny[1] = np.float32(-3.0e-7)                       # exponent field 105: below what the fused form takes
+    raw[rec0 + 4:rec0 + 20] = tiny.tobytes()
+    p1 = tmp_path / "tiny.icm"
+    p1.write_bytes(bytes(raw))
+    raw2 = bytearray(open(src, "rb").read())
+    zero = np.frombuffer(raw2, "<f4", 4, rec0 + 4).copy()
+    zero[2] = np.float32(-3.4028234663852886e38)        # log of a zero probability (icm.cc:1345-1349)
+    raw2[rec0 + 4:rec0 + 20] = zero.tobytes()
+    p2 = tmp_path / "zero.icm"
+    p2.write_bytes(bytes(raw2))
+    rng = np.random.default_rng(5)
+    seqs = ["".join("acgt"[c] for c in rng.integers(0, 4, size=int(n))) for n in rng.integers(100, 600, size=300)]
+    reads = gpu.Reads.from_strings(seqs)
+    for path in (p1, p2):
+        got = gpu.score_reads_strings([gpu.Icm.open(str(path))], reads)[0]
+        m = oracle.read(str(path))
+        for r, s_ in enumerate(seqs):
+            assert got[r, 0] == oracle.score_string(m, s_, 0) and got[r, 1] == oracle.score_string(m, revcomp(s_), 0), (path.name, r)
+
+
+def test_configs3_shape_ten_million_reads_64_models_in_pieces(gpu, oracle):
+    """BASELINE configs[3]: 10M reads x 64 Phymm ICMs.  Ten pieces of 1M x 500 bp, 64 models per call (the six sample-run
+    ICMs in turn): determinism (first piece twice), model repeats agree, sampled (read, model) pairs of every piece --
+    incl. the last read of the job -- equal the oracle."""
+    n_piece, L, pieces = 1_000_000, 500, 10
+    paths = [os.path.join(DATA, "cluster-%d.icm" % (i % 6)) for i in range(64)]
+    models = [gpu.Icm.open(p) for p in paths[:6]]
+    models64 = [models[i % 6] for i in range(64)]
+    o_models = [oracle.read(p) for p in paths[:6]]
+    rng = np.random.default_rng(9)
+    for pc in range(pieces):
+        packed, off = gpu.synth.packed_reads_range(pc * n_piece * L, n_piece * L, L, 41)
+        reads = gpu.Reads(packed, off)
+        got = gpu.score_reads_strings(models64, reads)
+        assert got.shape == (64, n_piece, 2)
+        if pc == 0:
+            assert got.tobytes() == gpu.score_reads_strings(models64, reads).tobytes()
+        for k in range(6, 64):
+            assert np.array_equal(got[k], got[k % 6])
+        for r in [0, n_piece - 1] + [int(x) for x in rng.integers(0, n_piece, 3)]:
+            s_ = gpu.synth.unpack_ascii(packed, r * L, L).decode()
+            k = int(rng.integers(0, 6))
+            assert got[k, r, 0] == oracle.score_string(o_models[k], s_, 0)
+            assert got[k, r, 1] == oracle.score_string(o_models[k], revcomp(s_), 0)
+        del reads, got
