@@ -605,6 +605,136 @@ extern "C" int gmg_reads_download(const gmg_reads *r, uint32_t *packed, uint64_t
 }
 
 // ---------------------------------------------------------------------------
+// one string at a time (the ICM_t methods): persistent staging, no allocation per call
+// ---------------------------------------------------------------------------
+struct gmg_single {
+    gmg_reads reads;
+    gmg_segments segs;
+    uint64_t cap_bases;          // capacity of everything below
+    unsigned char *h_in;         // page-locked: [packed words + guard][off[2]][segment][out_off[2]]
+    unsigned char *d_in;         // the same block on the device, behind GMG_GUARD_WORDS zero words
+    double *h_out, *d_out;       // results (page-locked / device), cap_bases + 16 doubles
+    uint32_t *d_tile_read;       // zeros: every tile lies in read 0
+    bool in_flight;              // a staged copy may still read h_in
+};
+
+static void single_release(gmg_single *st)
+{
+    if (st->h_in) (void)hipHostFree(st->h_in);
+    if (st->d_in) (void)hipFree(st->d_in);
+    if (st->h_out) (void)hipHostFree(st->h_out);
+    if (st->d_out) (void)hipFree(st->d_out);
+    if (st->d_tile_read) (void)hipFree(st->d_tile_read);
+    st->h_in = st->d_in = nullptr;
+    st->h_out = st->d_out = nullptr;
+    st->d_tile_read = nullptr;
+    st->cap_bases = 0;
+}
+
+static size_t single_words(uint64_t bases) { return (size_t)((bases + 15) / 16 + GMG_GUARD_WORDS); }   // data + trailing guard
+
+static int single_reserve(gmg_single *st, uint64_t n)
+{
+    if (n <= st->cap_bases && st->h_in) return GMG_OK;
+    single_release(st);
+    uint64_t cap = 4096;
+    while (cap < n) cap *= 2;
+    const size_t in_bytes = single_words(cap) * 4 + 16 + sizeof(gmg_segment) + 16;
+    hipError_t e = hipHostMalloc((void **)&st->h_in, in_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&st->d_in, GMG_GUARD_WORDS * 4 + in_bytes);
+    if (e == hipSuccess) e = hipMemset(st->d_in, 0, GMG_GUARD_WORDS * 4 + in_bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&st->h_out, (cap + 16) * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&st->d_out, (cap + 16) * sizeof(double));
+    const size_t tiles = (size_t)(cap / GMG_TILE + 2);
+    if (e == hipSuccess) e = hipMalloc((void **)&st->d_tile_read, tiles * 4);
+    if (e == hipSuccess) e = hipMemset(st->d_tile_read, 0, tiles * 4);
+    if (e != hipSuccess) { single_release(st); return gmg_set_error(GMG_ENOMEM, "gmg_single: %s", hipGetErrorString(e)); }
+    st->cap_bases = cap;
+    return GMG_OK;
+}
+
+extern "C" int gmg_single_create(gmg_single **out)
+{
+    int rc = require_init("gmg_single_create");
+    if (rc) return rc;
+    if (!out) return gmg_set_error(GMG_EINVAL, "gmg_single_create: NULL argument");
+    gmg_single *st = new (std::nothrow) gmg_single();
+    if (!st) return gmg_set_error(GMG_ENOMEM, "gmg_single_create: out of host memory");
+    memset(st, 0, sizeof *st);
+    *out = st;
+    return GMG_OK;
+}
+
+extern "C" int gmg_single_free(gmg_single *st)
+{
+    if (!st) return GMG_OK;
+    single_release(st);
+    delete st;
+    return GMG_OK;
+}
+
+extern "C" int gmg_single_stage(gmg_single *st, const char *ascii, uint64_t n, int orient, const gmg_reads **reads,
+                                const gmg_segments **segs, double **d_out)
+{
+    int rc = require_init("gmg_single_stage");
+    if (rc) return rc;
+    if (!st || (!ascii && n) || !reads || !segs || !d_out || orient < 0 || orient > GMG_REVCOMP || n > 0x7fffffffull)
+        return gmg_set_error(GMG_EINVAL, "gmg_single_stage: bad argument");
+    if (st->in_flight) GMG_HIP(hipStreamSynchronize(0));            // (a stage without a fetch: the last copy may still read h_in)
+    if ((rc = single_reserve(st, n)) != GMG_OK) return rc;
+    // host block: the packed words with the zero guard behind them, then the read's offsets, its segment, the output offsets
+    const size_t words = single_words(n);
+    uint32_t *h_packed = (uint32_t *)st->h_in;
+    memset(h_packed, 0, words * 4);
+    if (n && (rc = gmg_pack_bases(ascii, n, 0, h_packed)) != GMG_OK) return rc;
+    unsigned char *h_tail = st->h_in + single_words(st->cap_bases) * 4;
+    uint64_t off[2] = {0, n};
+    gmg_segment sg = {0, 0, (uint32_t)n, (uint32_t)orient};
+    memcpy(h_tail, off, 16);
+    memcpy(h_tail + 16, &sg, sizeof sg);
+    memcpy(h_tail + 16 + sizeof sg, off, 16);
+    unsigned char *d_packed = st->d_in + GMG_GUARD_WORDS * 4, *d_tail = d_packed + single_words(st->cap_bases) * 4;
+    GMG_HIP(hipMemcpyAsync(d_packed, h_packed, words * 4, hipMemcpyHostToDevice, 0));
+    GMG_HIP(hipMemcpyAsync(d_tail, h_tail, 16 + sizeof sg + 16, hipMemcpyHostToDevice, 0));
+    gmg_reads &r = st->reads;
+    memset(&r, 0, sizeof r);
+    r.d_packed = (const uint32_t *)d_packed;
+    r.d_off = (const uint64_t *)d_tail;
+    r.d_tile_read = st->d_tile_read;
+    r.n_reads = 1;
+    r.total_bases = n;
+    r.n_tiles = (n + GMG_TILE - 1) / GMG_TILE;
+    r.n_words = words;
+    r.d_packed_alloc = st->d_in;
+    r.uniform_len = n > 0 && n < (1u << 30) ? (int)n : 0;
+    r.max_len = r.min_len = n;
+    r.n_over_512 = n > 512;
+    gmg_segments &g = st->segs;
+    g.d_segs = (gmg_segment *)(d_tail + 16);
+    g.d_out_off = (uint64_t *)(d_tail + 16 + sizeof sg);
+    g.n = 1;
+    g.total_len = n;
+    st->in_flight = true;
+    *reads = &r;
+    *segs = &g;
+    *d_out = st->d_out;
+    return GMG_OK;
+}
+
+extern "C" int gmg_single_fetch(gmg_single *st, double *dst, size_t n)
+{
+    int rc = require_init("gmg_single_fetch");
+    if (rc) return rc;
+    if (!st || (!dst && n) || n > st->cap_bases + 16) return gmg_set_error(GMG_EINVAL, "gmg_single_fetch: bad argument");
+    if (n == 0) return GMG_OK;
+    GMG_HIP(hipMemcpyAsync(st->h_out, st->d_out, n * sizeof(double), hipMemcpyDeviceToHost, 0));
+    GMG_HIP(hipStreamSynchronize(0));
+    st->in_flight = false;
+    memcpy(dst, st->h_out, n * sizeof(double));
+    return GMG_OK;
+}
+
+// ---------------------------------------------------------------------------
 // segments
 // ---------------------------------------------------------------------------
 

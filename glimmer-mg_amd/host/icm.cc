@@ -46,35 +46,30 @@ void  Ensure_Device  (void)
    ready = true;
   }
 
-//  One string as a one-read batch in HBM, plus a device output buffer.
+//  One string as a one-read batch in HBM, plus a device output buffer: the calling thread's gmg_single (persistent
+//  page-locked staging and device buffers: a call is one copy in, one launch, one copy out; nothing is allocated)
 struct  One_Read_t
   {
-   gmg_reads  * reads;
-   gmg_segments  * segs;
-   void  * d_out;
+   const gmg_reads  * reads;
+   const gmg_segments  * segs;
+   double  * d_out;
+   gmg_single  * stage;
 
    One_Read_t  (const char * s, int n, gmg_orient orient, size_t out_doubles)
-     : reads (NULL), segs (NULL), d_out (NULL)
+     : reads (NULL), segs (NULL), d_out (NULL), stage (NULL)
      {
       Ensure_Device ();
-      vector <uint32_t>  packed (gmg_packed_words (n), 0);
-      uint64_t  off [2] = {0, (uint64_t) n};
-      gmg_segment  sg = {0, 0, (uint32_t) n, (uint32_t) orient};
-      if  (gmg_pack_bases (s, n, 0, packed . data ()) != GMG_OK
-             || gmg_reads_upload (packed . data (), off, 1, & reads) != GMG_OK
-             || gmg_segments_upload (reads, & sg, 1, NULL, NULL, & segs) != GMG_OK
-             || gmg_device_malloc (& d_out, sizeof (double) * (out_doubles ? out_doubles : 1)) != GMG_OK)
+      static thread_local gmg_single  * mine = NULL;     // lives as long as the thread
+      if  (mine == NULL && gmg_single_create (& mine) != GMG_OK)
+          Device_Fatal ("gmg_single_create");
+      stage = mine;
+      (void) out_doubles;                                //  (the staging has room for n + 16)
+      if  (gmg_single_stage (stage, s, (uint64_t) n, (int) orient, & reads, & segs, & d_out) != GMG_OK)
           Device_Fatal ("ICM_t device staging");
-     }
-   ~ One_Read_t  ()
-     {
-      gmg_device_free (d_out);
-      gmg_segments_free (segs);
-      gmg_reads_free (reads);
      }
    void  Fetch  (double * dst, size_t n)
      {
-      if  (n > 0 && gmg_memcpy_d2h (dst, d_out, n * sizeof (double), NULL) != GMG_OK)
+      if  (n > 0 && gmg_single_fetch (stage, dst, n) != GMG_OK)
           Device_Fatal ("ICM_t result copy");
      }
   };

@@ -132,6 +132,20 @@ int gmg_reads_download(const gmg_reads *reads, uint32_t *packed2bit, uint64_t *b
  * null model of their classes (src/Glimmer/glimmer-mg.cc:361-375, 2050-2068) -- one gmg_mg_score_reads call per group. */
 int gmg_reads_select(const gmg_reads *reads, const uint64_t *idx, uint64_t n, gmg_reads **out);
 
+/* ---- one string at a time ------------------------------------------------------
+ * The ICM_t methods take ONE string per call (src/ICM/icm.hh:131-180).  A gmg_single keeps what such a call needs --
+ * page-locked host staging, the packed read, its one segment and a result buffer on the device -- from call to call, so
+ * that a call is one copy in, one launch and one copy out (no allocation).  One per host thread; glimmer-mg_amd/host/icm.cc
+ * holds one per thread.  gmg_single_stage: the string `ascii` of n characters as a one-read batch with the whole read as
+ * its segment in orientation `orient`; *reads / *segs are valid until the next stage call; *d_out has room for n + 16
+ * doubles.  gmg_single_fetch copies n_doubles of it back (after the stream's work). */
+typedef struct gmg_single gmg_single;
+int gmg_single_create(gmg_single **out);
+int gmg_single_stage(gmg_single *st, const char *ascii, uint64_t n, int orient, const gmg_reads **reads,
+                     const gmg_segments **segs, double **d_out);
+int gmg_single_fetch(gmg_single *st, double *dst, size_t n_doubles);
+int gmg_single_free(gmg_single *st);
+
 /* ---- segments --------------------------------------------------------------- */
 
 /* Validates every segment against the read lengths (GMG_ERANGE otherwise).
