@@ -132,9 +132,30 @@ def cpu_sample(stream_first_read, local_first_read, n_reads, L, seed, gc, packed
     return port_bench(local_first_read, n_reads, L, seed, gc, packed), "port"
 
 
+def host_cores():
+    """the cores this process may really use: affinity mask, cut by the cgroup CPU quota (a 1-GPU box's share of its host);
+    GMG_BENCH_CORES overrides"""
+    if os.environ.get("GMG_BENCH_CORES"):
+        return max(1, int(os.environ["GMG_BENCH_CORES"]))
+    n = len(os.sched_getaffinity(0))
+    try:                                                    # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        try:                                                # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return min(n, 64)                                       # (more processes than that only measure the scheduler)
+
+
 def cpu_all_cores(n_reads_each, L, seed, gc):
     """one ref_bench process per host core, each on its own slice of the stream; wall time of all of them"""
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     t0 = time.perf_counter()
     procs = [subprocess.Popen([REF_BENCH, MODEL, str(n_reads_each), str(L), str(seed), repr(float(gc)), str(c * n_reads_each)],
                               stdout=subprocess.PIPE) for c in range(cores)]

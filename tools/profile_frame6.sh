@@ -7,9 +7,10 @@ TAG=${1:-run}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-BENCH="python3 bench.py --steps 5 --warmup 2 --cpu-reads 0 $*"
-# the kernel trace runs the DEFAULT bench command (steps 20, warmup 5), so that its averages are the ones bench.py reports
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --cpu-reads 0 $* > "$OUT/trace.log" 2>&1
+BENCH="python3 bench.py --steps 5 --warmup 2 --cpu-reads 0 --no-cli $*"
+# the kernel trace runs the DEFAULT bench command's timed region (steps 100, warmup 10; no CPU legs), so that its averages are the
+# ones bench.py reports
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --cpu-reads 0 --no-cli $* > "$OUT/trace.log" 2>&1
 i=1
 for set in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
@@ -18,7 +19,7 @@ for set in \
   "FETCH_SIZE" \
   "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
   "TCC_REQ_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_EA0_RDREQ_sum"; do
-  rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc$i" -- $BENCH > "$OUT/pmc$i.log" 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc$i" -- $BENCH > "$OUT/pmc$i.log" 2>&1
   i=$((i+1))
 done
 python3 tools/summarize_pmc.py "$OUT" > "$OUT/summary.txt" 2>&1
