@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of gmg_frame_score6 between builds of the library in ONE process on ONE GPU (boxes differ by several per cent):
-    python tools/f6_ab.py libA.so libB.so ...     -> median / min ms per call of each, calls interleaved"""
+    python tools/f6_ab.py libA.so libB.so ...     -> median / min ms per call of each, calls interleaved
+a library may be given as  path:key=value[,key=value]  (gmg_set_option after gmg_init; use copies of one file for A/B of a switch)"""
 import ctypes as C
 import os
 import sys
@@ -29,10 +30,15 @@ def ck(lib, rc):
 
 
 class Build:
-    def __init__(self, path):
-        self.name = os.path.basename(path)
+    def __init__(self, spec):
+        path, _, opts = spec.partition(":")
+        self.name = os.path.basename(spec)
         lib = self.lib = C.CDLL(path)
         ck(lib, lib.gmg_init(0))
+        for kv in filter(None, opts.split(",")):
+            key, val = kv.split("=")
+            lib.gmg_set_option.argtypes = [C.c_char_p, C.c_longlong]
+            ck(lib, lib.gmg_set_option(key.encode(), int(val)))
         gene, indep = vp(), vp()
         ck(lib, lib.gmg_icm_open(MODEL, C.byref(gene)))
         ck(lib, lib.gmg_icm_new(3, 2, 3, C.byref(indep)))
