@@ -33,11 +33,11 @@ extern "C" const char *gmg_last_error(void) { return g_err; }
 long long g_gmg_opt[GMG_OPT_COUNT] = {
     /* seg_plain */ 0, /* mg_tile */ 0, /* mg_one_stream */ 0, /* mg_err_flat */ 0, /* mg_err_calls */ 0, /* mg_err_calls_grow */ 0,
     /* orfs_exact_path */ 0, /* train_sort_min */ -1, /* mg_max_entries */ 0x7fffffffll, /* mg_timing */ 0, /* ingest_timing */ 0,
-    /* train_timing */ 0, /* diag */ 0, /* strings_fused */ 1, /* mg_gene32 */ 1};
+    /* train_timing */ 0, /* diag */ 0, /* strings_fused */ 1, /* mg_gene32 */ 1, /* mg_fused */ 1};
 static const char *const g_opt_name[GMG_OPT_COUNT] = {
     "seg_plain", "mg_tile", "mg_one_stream", "mg_err_flat", "mg_err_calls", "mg_err_calls_grow", "orfs_exact_path",
     "train_sort_min", "mg_max_entries", "mg_timing", "ingest_timing", "train_timing", "diag", "strings_fused",
-    "mg_gene32"};
+    "mg_gene32", "mg_fused"};
 
 static int opt_index(const char *key)
 {
@@ -327,6 +327,7 @@ extern "C" int gmg_model_upload(const int16_t *mip, const float *prob4, int W, i
     if (e != hipSuccess) { (void)hipFree(m->d_blob); delete m; return gmg_set_error(GMG_EHIP, "gmg_model_upload: hipMemcpy: %s", hipGetErrorString(e)); }
     m->blob_bytes = total;
     m->min_exp = 255;
+    m->max_exp = 0;
     m->odd_values = 0;
     for (size_t i = 0; i < PN * 4; i++) {
         uint32_t b;
@@ -335,6 +336,7 @@ extern "C" int gmg_model_upload(const int16_t *mip, const float *prob4, int W, i
         if ((b << 1) == 0) continue;                    // +-0: adds nothing
         if ((b >> 31) == 0 || ex == 0 || ex == 255) m->odd_values = 1;      // positive, denormal, infinity / NaN
         if ((int)ex < m->min_exp) m->min_exp = (int)ex;
+        if ((int)ex > m->max_exp) m->max_exp = (int)ex;
     }
     unsigned char *d = (unsigned char *)m->d_blob;
     m->dev.W = W; m->dev.D = D; m->dev.P = P; m->dev.N = N;
@@ -385,6 +387,12 @@ extern "C" int gmg_null_set_upload(const gmg_model *const *models, int n, gmg_nu
     if (!ns) return gmg_set_error(GMG_ENOMEM, "gmg_null_set_upload: out of host memory");
     ns->d_tab = nullptr;
     ns->n = n;
+    ns->min_exp = 255; ns->max_exp = 0; ns->odd_values = 0;
+    for (int i = 0; i < n; i++) {
+        if (models[i]->min_exp < ns->min_exp) ns->min_exp = models[i]->min_exp;
+        if (models[i]->max_exp > ns->max_exp) ns->max_exp = models[i]->max_exp;
+        ns->odd_values |= models[i]->odd_values;
+    }
     hipError_t e = hipMalloc((void **)&ns->d_tab, (size_t)n * 252 * sizeof(float));
     for (int i = 0; i < n && e == hipSuccess; i++) {
         e = hipMemcpy(ns->d_tab + (size_t)i * 252, models[i]->dev.dense, 192 * sizeof(float), hipMemcpyDeviceToDevice);

@@ -43,8 +43,9 @@ struct GmgDevModel {
 
 struct gmg_model {
     // what the values of the model allow (gmg_strings.hip: sums in any order): the smallest exponent field among the non-zero
-    // probabilities' logarithms (1 .. 254; 255: all zero), and whether any value is positive, a NaN or denormal
-    int min_exp, odd_values;
+    // probabilities' logarithms (1 .. 254; 255: all zero), the largest (0: all zero), and whether any value is positive, a NaN
+    // or denormal
+    int min_exp, max_exp, odd_values;
     GmgDevModel dev;
     void *d_blob;          // single allocation backing every table
     size_t blob_bytes;
@@ -68,6 +69,7 @@ struct gmg_reads {
 struct gmg_null_set {
     float *d_tab;                // [n][252]: [3][64] full windows, then [3][20] partial windows of each model
     int n;
+    int min_exp, max_exp, odd_values;    // over all of its models, as in gmg_model
 };
 
 struct gmg_segments {
@@ -109,6 +111,8 @@ enum GmgOpt {
     GMG_OPT_STRINGS_FUSED,       // gmg_score_reads_strings: 1 = sums folded into the main pass, 0 = value rows + summing kernel
     GMG_OPT_MG_GENE32,           // glimmer-mg front half, the call's own table as fp32 gene rows with the null model applied where the
                                  // running sums are built: 0 never, 1 with per-read null models (default), 2 always
+    GMG_OPT_MG_FUSED,            // glimmer-mg front half, default mode: 1 = running sums as a parallel scan + start lists in one kernel
+                                 // when the models' values allow it (k_mg_tile_starts), 0 = always the sequential walks
     GMG_OPT_COUNT
 };
 extern long long g_gmg_opt[GMG_OPT_COUNT];

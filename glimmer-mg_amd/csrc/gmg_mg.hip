@@ -479,7 +479,7 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
     struct Tile { uint64_t first, w0; uint32_t nfit, span; };
     const uint64_t n_tiles = a.n_tiles_dev ? (uint64_t)*a.n_tiles_dev : a.n_tiles;
     typename std::conditional<GENE32, float, double>::type tmp[3][PER];
-    uint32_t tpk[PW], tro[PR];
+    uint32_t tpk[PW], tro[PR];                          // (raw: arithmetic on a loaded value where it is issued would wait for every load before it)
     // GENE32: the null models of the tile's first MG_NULL_CACHE reads sit in LDS (1 KB each; one model for the whole batch:
     // slot 0, loaded once); reads beyond them fetch their values through L1
     constexpr int NC = GENE32 ? (MG_CAP <= 512 ? 4 : 8) : 1;
@@ -499,8 +499,8 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
         }
         mg_tile_reads(a, k >> 1, t.first, t.nfit, MG_CAP);
         if (t.nfit == 0) return;
-        t.w0 = a.read_off[t.first];
-        t.span = (uint32_t)(a.read_off[t.first + t.nfit] - t.w0);
+        t.w0 = t.first * (uint64_t)a.uniform_len;       // (uniform batches only come here: no load, nothing to wait for)
+        t.span = t.nfit * (uint32_t)a.uniform_len;
     };
     // every global load of a tile is issued here, one tile ahead: they are in flight while the block works on the
     // tile before
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
 #pragma unroll
         for (int u = 0; u < PR; u++) {
             const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
-            tro[u] = i <= t.nfit ? (uint32_t)(a.read_off[t.first + i] - t.w0) : 0u;
+            tro[u] = i <= t.nfit ? ((const uint32_t *)(a.read_off + t.first + i))[0] : 0u;        // (the low word is all that is needed)
         }
         if (GENE32 && a.read_null) {
 #pragma unroll
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
 #pragma unroll
             for (int u = 0; u < PR; u++) {
                 const uint32_t i = threadIdx.x + (uint32_t)BLOCK * u;
-                if (i <= nfit) s_roff[i] = tro[u];
+                if (i <= nfit) s_roff[i] = tro[u] - (uint32_t)w0;
             }
             if (GENE32 && a.read_null) {
 #pragma unroll
@@ -829,6 +829,513 @@ __global__ __launch_bounds__(256) void k_mg_starts(MgArgs a)
     __syncthreads();
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x) {
         mg_starts_one<WRITE>(a, i, s_which);
+    }
+}
+
+__device__ __forceinline__ uint64_t mg_ord(double x)    // order-preserving map double -> uint64
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double mg_unord(uint64_t u)
+{
+    return __longlong_as_double((long long)((u >> 63) ? (u & 0x7fffffffffffffffull) : ~u));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_mg_tile_starts: steps 3 and 4 (the running sums and the start lists of the default mode) in ONE kernel per
+// tile and strand, the sums as a parallel scan.  The running sums never reach HBM.
+//
+// Why the order of the additions may change.  Every Frame_Scores entry is (double) g - (double) n with g, n
+// floats of the two models; all non-zero floats of both models are multiples of 2^(e_min - 150), and every sum
+// of up to R of the differences is below 2^(ceil log2 R + e_max - 125) in magnitude (e_min / e_max: smallest /
+// largest exponent field, gmg_model).  While ceil log2 R + e_max - e_min <= 28 all of these are exact doubles: the
+// reference's sequential score[j] = score[j-1] + Frame_Scores[f][si] (glimmer-mg.cc:561-604) never rounds, and any
+// other order of the same additions gives the same bits.  mg_run checks that with R = the longest read + 2 and
+// falls back to the sequential walks (k_mg_cum_tiled / k_mg_cum + k_mg_starts) otherwise; a real model's values span
+// about ten binades (NC_000915.icm: 0.16 .. 97).
+//
+// Walk coordinate u of a tile: u = b on the reverse strand, span-1-b on the forward strand (b = base in the tile),
+// so every walk of k_mg_cum_tiled goes up in u, in steps of 3.  T[u] = the three entries the walk consumes at u.
+// The three classes u % 3 are three independent segmented sums over the tile; a segment starts where
+// k_mg_cum_tiled would start a lane (behind an in-class stop codon, real or virtual; read boundaries are such
+// places), and the exclusive sum at u is score[j-1] of the ORF whose region holds u, j = u - (start of the
+// segment).
+//   stage 0  the staged tile goes to LDS: T (one double per base, formed from the three rows while they are
+//            in registers), the packed bases, the read offsets
+//   stage 1  one byte per base: segment start?  codon inside the read?  which start codon (Codon_t::Can_Be)?
+//            one lane per ORF of the tile: its record's local index, region length and truncation flag go to
+//            the LDS slot of the base where its region starts
+//   stage 2  the scan.  Lane (class c, part p) owns MT_EL consecutive elements of class c; sum, number of start
+//            codons so far and the segment's first u travel together: sequential inside the lane, then a segmented
+//            scan over the lanes' totals with DPP moves (no LDS), then over the waves of the work-group.  Every start
+//            codon inside an ORF's region at j >= lowest j is a start: its u goes into a queue.
+//   stage 3  one lane per queued start: slot in the ORF's slice = n - 1 - (start codons before it in the region,
+//            from the scan) -- the reference's push order, k_mg_starts -- score with the Ignore_Score_Len rule,
+//            best score per ORF by LDS atomics
+//   stage 4  one lane per ORF: the truncated start (glimmer-mg.cc:1741,1761), first_j, best score, verdict
+// Reads no tile takes go to k_mg_cum + k_mg_starts_unfit as before.
+// ---------------------------------------------------------------------------------------------------
+#ifndef GMG_MT_STAMPS
+#define GMG_MT_STAMPS 0          // diagnostic build: cycles per stage of k_mg_tile_starts, summed over all waves (tools/mt_stamps.py); not in the product
+#endif
+#if GMG_MT_STAMPS
+__device__ unsigned long long g_mt_stamps[8];
+extern "C" int gmg_debug_mt_stamps(unsigned long long *out, int reset)
+{
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return hipMemcpyToSymbol(HIP_SYMBOL(g_mt_stamps), z, sizeof z) == hipSuccess ? 0 : -1; }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mt_stamps), 64) == hipSuccess ? 0 : -1;
+}
+#define MT_STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_prev; st_prev = now_; } while (0)
+#else
+#define MT_STAMP(i) do { } while (0)
+#endif
+
+#ifndef MT_MIN_WAVES
+#define MT_MIN_WAVES 1           // waves per SIMD the register allocation aims at
+#endif
+#define MT_EL 9                  // chain elements per lane
+#define MT_CL 21                 // lanes per class
+#define MT_W (3 * MT_CL * MT_EL) // bases per wave: 567
+#define MT_ORFS 64               // ORFs per pass of stages 3 and 4
+#define MT_REAL (1u << 24)       // scan word: start codons so far (bits 0-11), u of the segment start (12-23), "holds one" (24),
+#define MT_BLK (1u << 25)        // "nothing flows in from the left" (25: a segment start, or the first lane of a class)
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void mt_scan_step(double &s, uint32_t &p)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(s);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    const uint32_t ps = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, CTRL, ROW_MASK, 0xf, false);
+    const double ss = __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));   // (0.0, 0) where the pattern has no source
+    const bool blk = (p & MT_BLK) != 0;
+    s = blk ? s : ss + s;
+    p = blk ? p : ps + p;
+}
+
+struct MtTile { uint64_t w0; uint32_t first, nfit, span, o0, o1; };     // reads [first, first + nfit), bases [w0, w0 + span), ORFs [o0, o1)
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs a)
+{
+    constexpr int BLOCK = 64 * NW, CAP = MT_W * NW;
+    constexpr int NPK = CAP / 16 + 4;                                   // packed words staged (one in front)
+    constexpr int PW = (NPK + BLOCK - 1) / BLOCK, PR = (MG_TILE_READS + 1 + BLOCK - 1) / BLOCK;
+    __shared__ __attribute__((aligned(16))) double s_val[CAP];          // T in walk order, then the running sums
+    __shared__ uint16_t s_oinfo[CAP];                                   // at a region's first u: the ORF's index in the tile + 1
+    __shared__ uint32_t s_ch[CAP];                                      // start codons before u in its segment | the segment's first u << 12
+    __shared__ uint16_t s_q[CAP];                                       // the starts found
+    __shared__ uint8_t s_flag[CAP];                                     // bit 0 segment start, bit 1 codon inside the read, bits 2.. which + 1
+    __shared__ uint32_t s_packed[NPK];
+    __shared__ uint32_t s_roff[MG_TILE_READS + 1];
+    __shared__ int32_t s_isl[MG_TILE_READS];
+    __shared__ int8_t s_which[64];
+    __shared__ unsigned long long s_obest[MT_ORFS];
+    __shared__ uint32_t s_oso[MT_ORFS], s_ont[MT_ORFS], s_ofj[MT_ORFS];
+    __shared__ double s_wsum[NW][3];
+    __shared__ uint32_t s_wp[NW][3];
+    __shared__ uint32_t s_nq;
+
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n_tiles = a.n_tiles_dev ? (uint64_t)*a.n_tiles_dev : a.n_tiles;
+    if (tid < 64) s_which[tid] = a.which[tid];
+    const int mgl = a.min_gene_len;
+    int j_lo = mgl - 3 > 1 ? mgl - 3 : 1;               // as in mg_starts_one
+    j_lo = (j_lo + 2) / 3 * 3;
+
+    // A tile's loads are issued in three steps, one iteration apart, and nothing is computed from a loaded value in the step
+    // that loads it (the wait would be for every load issued before it, with the latency in the open):
+    //   meta_a  which reads (ragged batches: the tile's entry is loaded; uniform batches: arithmetic)
+    //   meta_b  the ORFs of those reads (two offsets)
+    //   issue   the three rows, the packed bases, the read offsets, the lane's ORF record
+    // The two meta steps read at wave-uniform addresses.  As scalar loads they would share the LDS counter (every wait for an LDS
+    // read would wait for them), as uniform vector loads the compiler moves each result to a scalar register at once (a wait for
+    // the load where it is issued).  So they are vector loads indexed with a zero the compiler cannot see through: the results
+    // stay in vector registers, behind the tile's other loads in the queue, and become scalars where the tile is worked on.
+    uint32_t vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    auto meta_a = [&](uint64_t k, MtTile &t) __attribute__((always_inline)) {
+        t.nfit = 0; t.span = 0; t.first = 0; t.w0 = 0; t.o0 = 0; t.o1 = 0;
+        if (k >= 2 * n_tiles) return;
+        if (a.tiles) {                                  // ragged batch: precomputed, non-empty
+            const MgTile *e = a.tiles + (k >> 1) + vzero;
+            t.first = e->first; t.nfit = e->nfit; t.w0 = e->w0; t.span = e->span;
+        } else {                                        // uniform batch: reads_per_tile whole reads (mg_tile_reads)
+            const uint64_t f = (k >> 1) * (uint64_t)a.reads_per_tile;
+            const uint64_t end = f + (uint64_t)a.reads_per_tile < a.n_reads ? f + (uint64_t)a.reads_per_tile : a.n_reads;
+            t.first = (uint32_t)f;
+            t.nfit = f < end ? (uint32_t)(end - f) : 0u;
+            t.w0 = f * (uint64_t)a.uniform_len;
+            t.span = t.nfit * (uint32_t)a.uniform_len;
+        }
+    };
+    auto meta_b = [&](MtTile &t) __attribute__((always_inline)) {
+        const uint32_t *roo = (const uint32_t *)(a.read_orf_off + vzero);      // (low words: a batch has less than 2^31 ORFs)
+        t.o0 = roo[2 * (uint64_t)t.first];
+        t.o1 = roo[2 * ((uint64_t)t.first + t.nfit)];
+    };
+    // every global load of a tile is issued one tile ahead
+    double tmp[3][MT_EL];
+    // (no arithmetic on a loaded value in there: it would wait for every load issued before it)
+    // (and no load wider than what is used: a register half nobody reads is handed out again, and the write to it waits for the load)
+    uint32_t tpk[PW], tro[PR];
+    int32_t tis[PR];
+    uint32_t po_read = 0, po_s0 = 0, po_s1 = 0;         // the lane's first ORF of the tile: read, frame / lo / hi, slice of the start array (low words)
+    int32_t po_frame = 0, po_lo = 0, po_hi = 0;
+    auto issue = [&](uint64_t k, const MtTile &t) __attribute__((always_inline)) {
+        if (t.nfit == 0) return;
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                   // (index arithmetic is redone where it is used: kept across the stages it costs more registers than instructions)
+        const bool fwd = (k & 1) == 0;
+        const int64_t D = fwd ? -1 : 1;
+        const double *r0 = a.fs + (uint64_t)(fwd ? 0 : 3) * a.fs_stride, *r1 = r0 + a.fs_stride, *r2 = r1 + a.fs_stride;
+#pragma unroll
+        for (int i = 0; i < MT_EL; i++) {
+            const uint32_t b = tid + (uint32_t)BLOCK * i;
+            const int64_t g = (int64_t)t.w0 + b, g2 = g + D, g0 = g + 2 * D;
+            const bool in = b < t.span;
+            tmp[1][i] = in ? r1[g] : 0.0;
+            tmp[2][i] = in && g2 >= 0 && g2 < (int64_t)a.total ? r2[g2] : 0.0;
+            tmp[0][i] = in && g0 >= 0 && g0 < (int64_t)a.total ? r0[g0] : 0.0;
+        }
+        const uint32_t n_words = ((uint32_t)(t.w0 & 15) + t.span + 15) / 16 + 1;
+#pragma unroll
+        for (int u = 0; u < PW; u++) {
+            const uint32_t i = tid + (uint32_t)BLOCK * u;
+            tpk[u] = i < n_words ? a.packed[(int64_t)(t.w0 >> 4) - 1 + i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < PR; u++) {
+            const uint32_t i = tid + (uint32_t)BLOCK * u;
+            tro[u] = i <= t.nfit ? ((const uint32_t *)(a.read_off + t.first + i))[0] : 0u;        // (the low word is all that is needed)
+            tis[u] = a.read_isl && i < t.nfit ? a.read_isl[t.first + i] : a.ignore_score_len;
+        }
+        if (tid < t.o1 - t.o0) {
+            const gmg_mg_orf *o = a.orfs + t.o0 + tid;
+            po_read = o->read; po_frame = o->frame; po_lo = o->lo; po_hi = o->hi;
+            po_s0 = ((const uint32_t *)(a.start_off + t.o0 + tid))[0];
+            po_s1 = ((const uint32_t *)(a.start_off + t.o0 + tid + 1))[0];
+        }
+    };
+
+    uint64_t k = blockIdx.x;
+    MtTile cur, nxt, nx2;
+    meta_a(k, cur);
+    meta_a(k + gridDim.x, nxt);
+    meta_a(k + 2 * (uint64_t)gridDim.x, nx2);
+    meta_b(cur);
+    meta_b(nxt);
+    issue(k, cur);
+#if GMG_MT_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
+#endif
+    for (; k < 2 * n_tiles; k += gridDim.x) {           // (tile, strand)
+        const bool fwd = (k & 1) == 0;
+        // (wave-uniform all of them; the loads they come from are older than the tile's rows, so this waits for nothing new)
+        const uint32_t nfit = __builtin_amdgcn_readfirstlane(cur.nfit), span = __builtin_amdgcn_readfirstlane(cur.span);
+        const uint32_t first = __builtin_amdgcn_readfirstlane(cur.first), o0 = __builtin_amdgcn_readfirstlane(cur.o0);
+        const uint32_t n_orf = __builtin_amdgcn_readfirstlane(cur.o1) - o0;
+        const uint32_t w0_lo = __builtin_amdgcn_readfirstlane((uint32_t)cur.w0);
+        __syncthreads();                                // the previous tile has left the LDS
+        MT_STAMP(6);
+        // ---- stage 0
+        if (nfit) {
+            uint32_t tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+#pragma unroll
+            for (int i = 0; i < MT_EL; i++) {
+                const uint32_t b = tid + (uint32_t)BLOCK * i;
+                if (b < span) s_val[fwd ? span - 1 - b : b] = (tmp[1][i] + tmp[2][i]) + tmp[0][i];
+                if (b < CAP) s_oinfo[b] = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < PW; u++) {
+                const uint32_t i = tid + (uint32_t)BLOCK * u;
+                if (i < NPK) s_packed[i] = tpk[u];
+            }
+#pragma unroll
+            for (int u = 0; u < PR; u++) {
+                const uint32_t i = tid + (uint32_t)BLOCK * u;
+                if (i <= nfit) s_roff[i] = tro[u] - w0_lo;
+                if (i < nfit) s_isl[i] = tis[u];
+            }
+            if (tid == 0) s_nq = 0;
+        }
+        // the lane's first ORF of this tile stays in registers through the stages; the loads of the next tile overwrite po_*
+        const uint32_t mo_read = po_read, mo_so = po_s0, mo_nt = po_s1 - po_s0;
+        const int32_t mo_frame = po_frame, mo_lo = po_lo, mo_hi = po_hi;
+        __syncthreads();
+        MT_STAMP(0);                                    // stage 0 (waits for the tile's loads)
+        // read of tile base b: index in the tile, first base, length
+        auto read_of = [&](uint32_t b, uint32_t &rl, int &rs, int &n) __attribute__((always_inline)) {
+            if (a.uniform_len > 0) {
+                rl = a.uniform_len == 1 ? b : __umulhi(b, a.uniform_magic);
+                rs = (int)(rl * (uint32_t)a.uniform_len);
+                n = a.uniform_len;
+            } else {
+                uint32_t lo = 0, hi = nfit;             // last r with s_roff[r] <= b
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_roff[mid] <= b) lo = mid; else hi = mid; }
+                rl = lo;
+                rs = (int)s_roff[lo];
+                n = (int)s_roff[lo + 1] - rs;
+            }
+        };
+        // ORF e of the tile (e = tid: from the registers)
+        auto orf_of = [&](uint32_t e, uint32_t &rd, int32_t &frame, int32_t &lo, int32_t &hi, uint32_t &so, uint32_t &nt) __attribute__((always_inline)) {
+            if (e == tid) { rd = mo_read; frame = mo_frame; lo = mo_lo; hi = mo_hi; so = mo_so; nt = mo_nt; return; }
+            const gmg_mg_orf *o = a.orfs + o0 + e;
+            rd = o->read; frame = o->frame; lo = o->lo; hi = o->hi;
+            const uint64_t s0 = a.start_off[o0 + e];
+            so = (uint32_t)s0;
+            nt = (uint32_t)(a.start_off[o0 + e + 1] - s0);
+        };
+        // geometry of an ORF of this strand: truncated?  region length, u of the region's first base
+        auto orf_geo = [&](uint32_t rd, int32_t lo, int32_t hi, bool &trunc, int &m, uint32_t &uh) __attribute__((always_inline)) {
+            const uint32_t rl = (uint32_t)(rd - first);
+            const int rs = a.uniform_len > 0 ? (int)(rl * (uint32_t)a.uniform_len) : (int)s_roff[rl];
+            const int n = a.uniform_len > 0 ? a.uniform_len : (int)s_roff[rl + 1] - rs;
+            m = hi - lo;
+            trunc = a.allow_truncated && (fwd ? lo < 3 : n - (hi - 1) < 3);
+            const uint32_t bh = (uint32_t)(rs + (fwd ? hi - 1 : lo - 1));
+            uh = fwd ? span - 1 - bh : bh;
+        };
+
+        // ---- stage 1: flags (lane-contiguous: MT_EL consecutive bases per lane, one 64-bit window of the packed bases)
+        if (nfit) {
+            uint32_t tid1 = threadIdx.x;
+            asm volatile("" : "+v"(tid1));
+            const uint32_t b0 = tid1 * MT_EL;
+            if (b0 < CAP) {
+                uint32_t rl = 0; int rs = 0, n = 0;
+                if (b0 < span) read_of(b0, rl, rs, n);
+                const uint32_t x = 16u + (w0_lo & 15u) + b0 - 3u;                  // bit pair of base b0 - 3 (one word in front)
+                const uint32_t xi = (x >> 4) < (uint32_t)(NPK - 1) ? (x >> 4) : (uint32_t)(NPK - 2);
+                const uint64_t win = ((uint64_t)s_packed[xi] | (uint64_t)s_packed[xi + 1] << 32) >> (2u * (x & 15u));   // base b0 - 3 + i at bits 2i
+#pragma unroll
+                for (int i = 0; i < MT_EL; i++) {
+                    const uint32_t b = b0 + i;
+                    uint32_t f = 1;
+                    if (b < span) {
+                        while ((int)b >= rs + n) { rl++; rs = (int)s_roff[rl]; n = (int)s_roff[rl + 1] - rs; }   // (s_roff[nfit] = span > b)
+                        const int si = (int)b - rs;
+                        const uint32_t c7 = (uint32_t)(win >> (2 * i)) & 0x3fffu;      // bases b-3 .. b+3, b-3 lowest
+                        auto code = [&](int kk) { return (c7 >> (2 * (kk + 3))) & 3u; };
+                        bool st, geo;
+                        uint32_t sidx;
+                        if (fwd) {
+                            st = si + 3 >= n || ((a.fwd_stop >> (code(1) << 4 | code(2) << 2 | code(3))) & 1ull);
+                            geo = si >= 2;
+                            sidx = code(-2) << 4 | code(-1) << 2 | code(0);
+                        } else {
+                            st = si < 3 || ((a.rev_stop >> (code(-3) << 4 | code(-2) << 2 | code(-1))) & 1ull);
+                            geo = si + 2 <= n - 1;
+                            sidx = (code(2) << 4 | code(1) << 2 | code(0)) ^ 63u;
+                        }
+                        f = (st ? 1u : 0u) | (geo ? 2u : 0u) | (uint32_t)(s_which[sidx] + 1) << 2;
+                    }
+                    if (b < CAP) s_flag[b < span ? (fwd ? span - 1 - b : b) : b] = (uint8_t)f;
+                }
+            }
+            for (uint32_t e = tid; e < n_orf; e += BLOCK) {
+                uint32_t rd, so, nt, uh; int32_t frame, lo, hi; bool trunc; int m;
+                orf_of(e, rd, frame, lo, hi, so, nt);
+                if ((frame > 0) != fwd) continue;
+                orf_geo(rd, lo, hi, trunc, m, uh);
+                if (m > 0) s_oinfo[uh] = (uint16_t)(e + 1);
+            }
+        }
+        __syncthreads();
+        MT_STAMP(2);                                    // stage 1
+        // ---- stage 2: the scan
+        if (nfit) {
+            uint32_t tid2 = threadIdx.x;
+            asm volatile("" : "+v"(tid2));
+            const uint32_t wv = tid2 >> 6, l = tid2 & 63u;
+            const uint32_t c = l >= 2 * MT_CL ? 2u : l >= MT_CL ? 1u : 0u;
+            const bool idle = l == 63;
+            const uint32_t jl = idle ? MT_CL - 1 : l - MT_CL * c;          // (the idle lane repeats its neighbour's work and drops it)
+            const uint32_t ub = MT_W * wv + 3 * MT_EL * jl + c;
+            double es[MT_EL];
+            uint32_t ep[MT_EL];
+            double acc = 0.0;
+            uint32_t p = 0;
+#pragma unroll
+            for (int i = 0; i < MT_EL; i++) {
+                const uint32_t u = ub + 3 * i;
+                const uint32_t f = s_flag[u];
+                const double T = s_val[u];
+                if (f & 1u) { acc = 0.0; p = (u << 12) | MT_REAL | MT_BLK; }
+                es[i] = acc;
+                ep[i] = p | (f << 26);                  // (the flag byte's bits 1.. ride along in bits 27..31: codon inside, which + 1)
+                acc += T;
+                p += ((f >> 1) & 1u) & ((f >> 2) != 0 ? 1u : 0u);
+            }
+            // the totals of the lanes before this one in its class: shift by one lane, then an inclusive segmented scan
+            double xs;
+            uint32_t xp;
+            {
+                const unsigned long long bb = (unsigned long long)__double_as_longlong(acc);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)bb, 0x138, 0xf, 0xf, false);      // wave_shr:1
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(bb >> 32), 0x138, 0xf, 0xf, false);
+                xp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x138, 0xf, 0xf, false);
+                xs = __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
+                if (jl == 0) { xs = 0.0; xp = MT_BLK; }
+            }
+            mt_scan_step<0x111, 0xf>(xs, xp);           // row_shr:1
+            mt_scan_step<0x112, 0xf>(xs, xp);           // row_shr:2
+            mt_scan_step<0x114, 0xf>(xs, xp);           // row_shr:4
+            mt_scan_step<0x118, 0xf>(xs, xp);           // row_shr:8
+            mt_scan_step<0x142, 0xa>(xs, xp);           // row_bcast:15 into rows 1 and 3
+            mt_scan_step<0x143, 0xc>(xs, xp);           // row_bcast:31 into rows 2 and 3
+            if (NW > 1) {
+                // what the waves before this one leave open in each class
+                if (!idle && jl == MT_CL - 1) {
+                    const bool blk = (p & MT_BLK) != 0;
+                    s_wsum[wv][c] = blk ? acc : xs + acc;
+                    s_wp[wv][c] = blk ? p : xp + p;
+                }
+                __syncthreads();
+                if (!(xp & MT_REAL)) {
+                    double ws = 0.0;
+                    uint32_t wp = 0;
+                    for (uint32_t w2 = 0; w2 < wv; w2++) {
+                        const double s2 = s_wsum[w2][c];
+                        const uint32_t p2 = s_wp[w2][c];
+                        const bool blk = (p2 & MT_REAL) != 0;            // (a wave's first lanes block without a segment start)
+                        ws = blk ? s2 : ws + s2;
+                        wp = blk ? p2 : wp + (p2 & 0xfffu);
+                    }
+                    xs = ws + xs;
+                    xp = (wp & ~MT_BLK) + (xp & 0xfffu);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MT_EL; i++) {
+                const uint32_t u = ub + 3 * i;
+                const bool own = (ep[i] & MT_REAL) != 0;                   // the segment starts inside this lane's elements
+                const double cum = own ? es[i] : xs + es[i];
+                const uint32_t pp = own ? ep[i] : xp + (ep[i] & 0xfffu);
+                const uint32_t ch = pp & 0xffffffu;
+                const uint32_t f1 = ep[i] >> 27;                           // bit 0: codon inside the read, bits 1..: which + 1
+                if (!idle) {
+                    s_val[u] = cum;
+                    s_ch[u] = ch;
+                    if ((f1 & 1u) && (f1 >> 1)) {
+                        const uint32_t hd = ch >> 12;
+                        if (s_oinfo[hd] != 0 && (int)(u - hd) >= j_lo) s_q[atomicAdd(&s_nq, 1u)] = (uint16_t)u;
+                    }
+                }
+            }
+        }
+        // the next tile's loads: behind the scan (the stage with the most registers alive), in flight through stages 3, 4 and
+        // whatever the other waves of the CU are doing
+        MT_STAMP(3);                                    // stage 2
+        MtTile nx3;
+        meta_a(k + 3 * (uint64_t)gridDim.x, nx3);
+        meta_b(nx2);
+        issue(k + gridDim.x, nxt);
+        __syncthreads();
+        MT_STAMP(1);                                    // the next tile's loads issued
+#ifdef GMG_MT_LOADS_ONLY                                // diagnostic build: the load pattern alone (results invalid)
+        if (s_val[tid] != 1.2345e300) { cur = nxt; nxt = nx2; nx2 = nx3; continue; }
+#endif
+        // ---- stages 3 and 4, MT_ORFS ORFs of the tile at a time
+        for (uint32_t e0 = 0; e0 < (nfit ? n_orf : 0u); e0 += MT_ORFS) {
+            for (uint32_t i = tid; i < MT_ORFS; i += BLOCK) {
+                const uint32_t e = e0 + i;
+                s_obest[i] = 0;
+                s_ofj[i] = 0;
+                if (e < n_orf) {
+                    uint32_t rd, so, nt; int32_t frame, lo, hi;
+                    orf_of(e, rd, frame, lo, hi, so, nt);
+                    s_oso[i] = so;
+                    s_ont[i] = nt;
+                }
+            }
+            __syncthreads();
+            const uint32_t nq = s_nq;
+            for (uint32_t qi = tid; qi < nq; qi += BLOCK) {
+                const uint32_t u = s_q[qi];
+                const uint32_t ch = s_ch[u], hd = ch >> 12;
+                const uint32_t info = s_oinfo[hd];
+                const uint32_t e = info - 1u;
+                if (e < e0 || e >= e0 + MT_ORFS) continue;
+                const int j = (int)(u - hd);
+                const uint32_t t = (ch & 0xfffu) - (s_ch[hd + (uint32_t)j_lo] & 0xfffu);    // start codons of the region at lower j >= lowest j
+                const uint32_t nt = s_ont[e - e0];
+                if (t >= nt) continue;                  // (cannot happen: the count pass found the same start codons; never write outside the slice)
+                const uint32_t slot = nt - 1u - t;
+                const uint32_t b = fwd ? span - 1 - u : u;
+                uint32_t rl; int rs, n;
+                read_of(b, rl, rs, n);
+                const int si = (int)b - rs;
+                const double pend = s_val[u];
+                const double sc = (j + 2 > s_isl[rl] && 0.0 > pend) ? 0.0 : pend;          // glimmer-mg.cc:1644-1646
+                gmg_start st;
+                st.score = sc; st.j = j + 2; st.pos = fwd ? si - 1 : si + 3;
+                st.which = (int32_t)(s_flag[u] >> 2) - 1; st.truncated = 0; st.first = slot == 0 ? 1 : 0;
+                a.starts[(uint64_t)s_oso[e - e0] + slot] = st;
+                atomicMax(&s_obest[e - e0], (unsigned long long)mg_ord(sc));
+                if (slot == 0) s_ofj[e - e0] = (uint32_t)(j + 2);
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < MT_ORFS && e0 + i < n_orf; i += BLOCK) {
+                const uint32_t e = e0 + i;
+                uint32_t rd, so, nt, uh; int32_t frame, lo, hi; bool trunc; int m;
+                orf_of(e, rd, frame, lo, hi, so, nt);
+                if ((frame > 0) != fwd) continue;
+                orf_geo(rd, lo, hi, trunc, m, uh);
+                double best = s_obest[i] ? mg_unord(s_obest[i]) : -DBL_MAX;
+                int first_j = (int)s_ofj[i];
+                const int jmax = m >= 1 ? (m - 1) / 3 * 3 : -1;
+                if (trunc && jmax >= j_lo && nt > 0) {  // the truncated start: slot 0
+                    const uint32_t uj = uh + (uint32_t)jmax;
+                    const uint32_t b = fwd ? span - 1 - uj : uj;
+                    const uint32_t rl = (uint32_t)(rd - first);
+                    const int rs = a.uniform_len > 0 ? (int)(rl * (uint32_t)a.uniform_len) : (int)s_roff[rl];
+                    const int si = (int)b - rs;
+                    const double pend = s_val[uj];
+                    const double sc = (jmax + 2 > s_isl[rl] && 0.0 > pend) ? 0.0 : pend;
+                    gmg_start st;
+                    st.score = sc; st.j = jmax + 2; st.pos = fwd ? si - 1 : si + 3;
+                    st.which = -1; st.truncated = 1; st.first = 1;
+                    a.starts[so] = st;
+                    if (sc > best) best = sc;
+                    first_j = jmax + 2;
+                }
+                gmg_mg_orf *o = a.orfs + o0 + e;
+                o->orf_is_truncated = trunc;
+                o->start_begin = so;
+                o->n_starts = nt;
+                o->first_j = nt ? first_j : 0;
+                const bool ok = nt > 0 && first_j + 1 >= mgl;               // glimmer-mg.cc:1656-1676
+                o->best_score = ok ? best : -DBL_MAX;
+                o->accepted = ok && best > a.start_threshold;
+            }
+            if (e0 + MT_ORFS < n_orf) __syncthreads();
+        }
+        MT_STAMP(4);                                    // stages 3 and 4
+        cur = nxt;
+        nxt = nx2;
+        nx2 = nx3;
+    }
+#if GMG_MT_STAMPS
+    if ((tid & 63u) == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&g_mt_stamps[i], st_acc[i]);
+#endif
+}
+
+// the ORFs of the reads no tile took (k_mg_unfit_list; their running sums come from k_mg_cum): one lane per read
+__global__ __launch_bounds__(256) void k_mg_starts_unfit(MgArgs a)
+{
+    __shared__ int8_t s_which[64];
+    if (threadIdx.x < 64) s_which[threadIdx.x] = a.which[threadIdx.x];
+    __syncthreads();
+    const uint64_t n = *a.unfit_n;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = a.unfit[e];
+        for (uint64_t i = a.read_orf_off[r]; i < a.read_orf_off[r + 1]; i++) mg_starts_one<true>(a, i, s_which);
     }
 }
 
@@ -1103,16 +1610,6 @@ __global__ __launch_bounds__(MG_ERR_BLOCK) void k_mg_err_flat(MgArgs a, const in
         } else o.start_begin = (uint32_t)a.start_off[i];
         a.orfs[i] = o;
     }
-}
-
-__device__ __forceinline__ uint64_t mg_ord(double x)    // order-preserving map double -> uint64
-{
-    const uint64_t u = (uint64_t)__double_as_longlong(x);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double mg_unord(uint64_t u)
-{
-    return __longlong_as_double((long long)((u >> 63) ? (u & 0x7fffffffffffffffull) : ~u));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1794,6 +2291,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     uint32_t *d_read_cnt = nullptr, *d_orf_cnt = nullptr;
     uint64_t *d_start_off = nullptr;
     double *d_cum = nullptr;
+    int fused_nw = 0;                                   // waves per tile of k_mg_tile_starts, 0: the sequential kernels
+    bool fused_rest = false;
     MgTile *d_tiles = nullptr, *d_all = nullptr;
     uint32_t *d_unfit = nullptr;
     uint32_t *d_ntiles = nullptr;
@@ -1908,18 +2407,30 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         }
     }
     // running sums of every reading-frame class (what Cumulative_Frame_Score would give any ORF)
-    if (!err_mode) {
-    MG_TRY(gmg_pool_alloc((void **)&d_cum, (size_t)2 * (a.total ? a.total : 1) * sizeof(double)));
-    a.cum = d_cum;
-    tm.lap("alloc running sums");
+    // The fused kernel (k_mg_tile_starts: sums as a parallel scan + start lists) when every sum of the batch is exact in any
+    // order -- see there; R = the longest read + 2 terms.  Not with the GENE32 table (per-read null models) yet.
+    {
+        const int n_min = prm->nulls ? prm->nulls->min_exp : nul->min_exp, n_max = prm->nulls ? prm->nulls->max_exp : nul->max_exp;
+        const int n_odd = prm->nulls ? prm->nulls->odd_values : nul->odd_values;
+        const int mn = gene->min_exp < n_min ? gene->min_exp : n_min, mx = gene->max_exp > n_max ? gene->max_exp : n_max;
+        int clog = 0;
+        while ((1ull << clog) < reads->max_len + 2) clog++;
+        const bool exact = !gene->odd_values && !n_odd && (mx < mn || clog + mx - mn <= 28);
+        const long long forced_tile = gmg_opt(GMG_OPT_MG_TILE);
+        if (!err_mode && !g32 && exact && gmg_opt(GMG_OPT_MG_FUSED) && a.n_reads && a.total) {
+            if (forced_tile == 1 || forced_tile == 2 || forced_tile == 4) fused_nw = (int)forced_tile;
+            else if (reads->uniform_len > 0) fused_nw = reads->uniform_len <= MT_W ? 1 : reads->uniform_len <= 2 * MT_W ? 2 : reads->uniform_len <= 4 * MT_W ? 4 : 0;
+            else fused_nw = (reads->max_len <= MT_W || reads->n_over_512 * 10 <= reads->n_reads) ? 1 : reads->max_len <= 2 * MT_W ? 2 : 4;
+            if (reads->uniform_len > (int)(MT_W * fused_nw)) fused_nw = 0;
+        }
     }
     if (!err_mode && a.n_reads && a.total) {
-        // tile shape: two waves and <= 512 bases (12 KB of LDS, many blocks per CU in different phases) when the reads
-        // allow it, else eight waves and 1504 bases (39.8 KB, four blocks per CU)
+        // tile shape of the sequential kernel: two waves and <= 512 bases (12 KB of LDS, many blocks per CU in different phases)
+        // when the reads allow it, else eight waves and 1504 bases (39.8 KB, four blocks per CU); the fused kernel: 567 bases per wave
         const long long forced_tile = gmg_opt(GMG_OPT_MG_TILE);
         // (ragged batches: the few reads beyond 512 bases go to the per-lane kernel; measured 9.6 vs 10.6 ms on 1M x ~400 bp)
         const bool small = forced_tile ? forced_tile == 512 : (reads->max_len <= 512 || (reads->uniform_len == 0 && reads->n_over_512 * 10 <= reads->n_reads));
-        const uint32_t cap = small ? 512 : 1504;
+        const uint32_t cap = fused_nw ? (uint32_t)(MT_W * fused_nw) : small ? 512 : 1504;
         a.tile_cap = (int)cap;
         bool tiled = false, rest = true;
         if (reads->uniform_len > 0) {                  // every tile takes cap / L whole reads
@@ -1955,6 +2466,26 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             a.n_tiles_dev = d_n;
             a.n_tiles = n_windows;                          // upper bound, for the grid
         }
+        if (fused_nw && !tiled) fused_nw = 0;
+        fused_rest = rest;
+        if (!fused_nw || rest) {
+            MG_TRY(gmg_pool_alloc((void **)&d_cum, (size_t)2 * a.total * sizeof(double)));
+            a.cum = d_cum;
+        }
+        if (fused_nw) {
+            // the kernel itself goes behind the ORF scan and the count pass (it writes the start lists); the reads no tile takes are
+            // listed now
+            if (rest) {
+                a.lanes_only_unfit = 1;
+                MG_TRY(gmg_pool_alloc((void **)&d_unfit, (a.n_reads + 1) * 4));
+                a.unfit = d_unfit + 1;
+                a.unfit_n = d_unfit;
+                MG_TRY(hipMemsetAsync(d_unfit, 0, 4, s));
+                hipLaunchKernelGGL(k_mg_unfit_list, dim3(grid_for(a.n_reads)), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(k_mg_cum<false>, dim3(grid_for(2 * a.n_reads)), dim3(256), 0, s, a);
+                MG_TRY(hipGetLastError());
+            }
+        } else {
         if (tiled && a.n_tiles) {
             const size_t lds = (size_t)3 * (cap + 8) * sizeof(double);
             const unsigned grid = (unsigned)(2 * a.n_tiles < 256 * 1024 ? 2 * a.n_tiles : 256 * 1024);
@@ -1986,6 +2517,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             if (g32) hipLaunchKernelGGL(k_mg_cum<true>, dim3(grid_for(2 * a.n_reads)), dim3(256), 0, s, a);
             else hipLaunchKernelGGL(k_mg_cum<false>, dim3(grid_for(2 * a.n_reads)), dim3(256), 0, s, a);
             MG_TRY(hipGetLastError());
+        }
         }
     }
     tm.lap("running sums");
@@ -2136,7 +2668,13 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         hipLaunchKernelGGL((k_mg_err_level<true, 2>), lvl_grid, dim3(256), 0, s, a, err_acc_only);
         if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 1);
     } else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 0);
-    else if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
+    else if (no && fused_nw) {
+        const unsigned grid = (unsigned)(2 * a.n_tiles < 64 * 1024 ? 2 * a.n_tiles : 64 * 1024);
+        if (fused_nw == 1) hipLaunchKernelGGL(k_mg_tile_starts<1>, dim3(grid), dim3(64), 0, s, a);
+        else if (fused_nw == 2) hipLaunchKernelGGL(k_mg_tile_starts<2>, dim3(grid), dim3(128), 0, s, a);
+        else hipLaunchKernelGGL(k_mg_tile_starts<4>, dim3(grid), dim3(256), 0, s, a);
+        if (fused_rest) hipLaunchKernelGGL(k_mg_starts_unfit, dim3(grid_for(a.n_reads / 16 + 1)), dim3(256), 0, s, a);
+    } else if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
     break;
     }

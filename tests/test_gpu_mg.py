@@ -296,3 +296,57 @@ def test_empty_reads_inside_a_batch_are_harmless(gpu, oracle, nc):
     assert np.all(s[[0, 2, 3, 6, 8]] == 0.0) and np.array_equal(s[[1, 4, 5, 7]], gpu.score_reads_strings([m], dense)[0])
     f_orfs, f_first = gpu.find_orfs(reads, min_gene_len=60, allow_truncated=True)
     assert np.array_equal(f_orfs["stop_position"], orfs["stop_position"]) and np.array_equal(f_first, first)
+
+
+@pytest.mark.parametrize("shape,kw", [
+    ("uniform 500", dict()),
+    ("uniform 500", dict(allow_truncated=False, min_gene_len=90, ignore_score_len=150)),
+    ("uniform 100", dict(min_gene_len=30)),
+    ("uniform 9", dict(min_gene_len=4, start_threshold=-1e300)),
+    ("uniform 567", dict()),
+    ("uniform 568", dict(min_gene_len=4, ignore_score_len=10)),
+    ("uniform 1134", dict()),
+    ("uniform 2268", dict(min_gene_len=30, start_codons=("atg", "rtg", "ttg", "ctg"), stop_codons=("taa", "tag"))),
+    ("uniform 2269", dict()),
+    ("ragged 400", dict()),
+    ("ragged 400", dict(min_gene_len=4, ignore_score_len=10, start_threshold=-1e300)),
+    ("ragged 900", dict()),
+    ("ragged 30", dict(min_gene_len=4)),
+    ("codons", dict(min_gene_len=4)),
+])
+def test_mg_fused_kernel_equals_the_sequential_kernels(gpu, nc, shape, kw):
+    """k_mg_tile_starts (running sums as a parallel scan + start lists, option mg_fused = 1, the default when the models'
+    values make every sum exact) against k_mg_cum_tiled / k_mg_cum + k_mg_starts (sequential sums in the reference's
+    order): every byte of the ORF records and of the start lists, for every tile shape (mg_tile = 1, 2, 4 waves)"""
+    kind, _, arg = shape.partition(" ")
+    rng = np.random.default_rng(len(shape) * 1000 + len(kw))
+    if kind == "uniform":
+        L = int(arg)
+        n = max(40, min(4000, 400_000 // L))
+        packed, off = gpu.synth.packed_reads(n, L, 100 + L)
+        reads = gpu.Reads(packed, off)
+    elif kind == "ragged":
+        mean = int(arg)
+        lens = np.clip(rng.normal(mean, mean * 0.3, 1500).round(), 0, 2600).astype(np.int64)
+        lens[::97] = 0
+        lens[5::131] = 2500                                             # beyond every tile: the per-lane kernels
+        reads = gpu.Reads.from_strings(random_reads(rng, lens))
+    else:                                                               # nothing but start codons / stops back to back / no stop at all
+        seqs = ["atg" * 170, "ttg" * 60 + "c", "cat" * 150 + "aa", "taa" * 100 + "a", "acg" * 200, "atgtaa" * 80,
+                "g" + "ttacat" * 90, "atg" * 400, "cat" * 700] + random_reads(rng, [600, 3, 2, 1])
+        reads = gpu.Reads.from_strings(seqs)
+    stops = kw.get("stop_codons", ("taa", "tag", "tga"))
+    indep = gpu.Icm.indep(0.45, stops)
+    with gpu.option("mg_fused", 0):
+        want = gpu.mg_score_reads(nc, indep, reads, **kw)
+    assert len(want[0]) > 0
+    for tile in (0, 1, 2, 4):
+        if kind == "uniform" and tile and int(arg) > 567 * tile:
+            continue
+        print("mg_tile", tile, flush=True)
+        with gpu.option("mg_tile", tile):
+            got = gpu.mg_score_reads(nc, indep, reads, **kw)
+        assert np.array_equal(got[2], want[2])
+        for c in want[0].dtype.names:
+            assert np.array_equal(got[0][c], want[0][c]), (shape, tile, c)
+        assert got[1].tobytes() == want[1].tobytes(), (shape, tile)
