@@ -99,6 +99,7 @@ struct MgArgs {
     const uint64_t *read_orf_off;
     gmg_mg_orf *orfs;
     uint64_t n_orfs;
+    int count_starts;            // k_mg_find_orfs<write> also counts every ORF's starts (default mode, lowest j within 64 codons): no k_mg_starts<count>
     uint32_t *orf_cnt;           // [n_orfs + 1] starts per ORF
     const uint64_t *start_off;   // its exclusive scan
     gmg_start *starts;
@@ -160,6 +161,12 @@ struct BaseStream {
 struct MgClass {
     int first_fwd_start, last_rev_start, prev_fwd_stop, prev_rev_stop;
     int fwd_last;                // Save_Prev_Stops' last_stops for the forward scan (glimmer-mg.cc:685-699)
+    // the number of starts Score_Orf_Starts will push for the ORF that is open in this class (count_starts), counted while the
+    // scan passes them.  Forward: position j is counted from the ORF's stop codon, which comes later -- the start codons of the
+    // last k0 = 1 + lowest_j / 3 codons wait in a bit mask, older ones are counted.  Reverse: j is counted from the previous
+    // stop: start codons from a threshold position on.
+    unsigned long long fwd_recent;
+    int fwd_older, rev_cnt, rev_from;
 };
 
 template <bool WRITE>
@@ -171,9 +178,14 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
         const int mgl = a.min_gene_len;
         const bool trunc = a.allow_truncated != 0;
         uint32_t cnt = 0;
-        gmg_mg_orf *out = WRITE ? a.orfs + a.read_orf_off[r] : nullptr;
+        const uint64_t orf0 = WRITE ? a.read_orf_off[r] : 0;
+        gmg_mg_orf *out = WRITE ? a.orfs + orf0 : nullptr;
+        const bool counting = WRITE && a.count_starts;
+        int j_lo = mgl - 3 > 1 ? mgl - 3 : 1;           // lowest j of a start, as in mg_starts_one
+        j_lo = (j_lo + 2) / 3 * 3;
+        const int k0 = 1 + j_lo / 3;                    // (<= 64 when count_starts is set)
 
-        auto emit = [&](int stop_position, int frame, int gene_len, int orf_len, int lo, int hi) __attribute__((always_inline)) {
+        auto emit = [&](int stop_position, int frame, int gene_len, int orf_len, int lo, int hi, int n_real) __attribute__((always_inline)) {
             if (gene_len >= mgl || (a.err_mode && orf_len >= a.min_indel_orf_len)) {   // glimmer_base.cc:494,528,806
                 if (WRITE) {
                     gmg_mg_orf o;
@@ -182,6 +194,12 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
                     o.first_j = 0; o.start_begin = 0; o.n_starts = 0; o.accepted = 0; o.orf_is_truncated = 0;
                     o.reserved = 0; o.best_score = -DBL_MAX;
                     out[cnt] = o;
+                    if (counting) {                     // + the truncated start (mg_starts_one: has_trunc)
+                        const int m = hi - lo;
+                        const bool tr = trunc && (frame > 0 ? lo < 3 : n - (hi - 1) < 3);
+                        const int jmax = m >= 1 ? (m - 1) / 3 * 3 : -1;
+                        a.orf_cnt[orf0 + cnt] = (uint32_t)((m > 0 ? n_real : 0) + (tr && jmax >= j_lo ? 1 : 0));
+                    }
                 }
                 cnt++;
             }
@@ -199,9 +217,11 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
                 gene_len = (i - S.first_fwd_start) - 1;
                 orf_len = i - S.prev_fwd_stop - 4;
             }
-            emit(i - 1, 1 + (cls + 1) % 3, gene_len, orf_len, S.fwd_last + 1, i - 2);
+            emit(i - 1, 1 + (cls + 1) % 3, gene_len, orf_len, S.fwd_last + 1, i - 2, S.fwd_older);
             S.first_fwd_start = INT_MAX;
             S.prev_fwd_stop = i - 1;
+            S.fwd_older = 0;
+            S.fwd_recent = 0;
         };
         // Do_Rev_Stop_Codon (glimmer_base.cc:506-537) + Handle_First_Reverse_Stop (:989-1015)
         auto rev_stop = [&](int i, MgClass &S, int cls) __attribute__((always_inline)) {
@@ -217,9 +237,11 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
                 orf_stop = S.prev_rev_stop;
                 gene_len = S.last_rev_start - orf_stop;
             }
-            emit(orf_stop, -1 - (cls + 1) % 3, gene_len, i - orf_stop - 4, orf_stop + 3, i - 1);
+            emit(orf_stop, -1 - (cls + 1) % 3, gene_len, i - orf_stop - 4, orf_stop + 3, i - 1, S.rev_cnt);
             S.last_rev_start = 0;
             S.prev_rev_stop = i - 1;
+            S.rev_cnt = 0;
+            S.rev_from = (i - 1) + 4 + j_lo;            // j = i - 4 - orf_stop >= lowest j
         };
 
         if (n >= mgl) {                                 // glimmer_base.cc:676-677
@@ -228,6 +250,9 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
             for (int c = 0; c < 3; c++) {
                 cs[c].first_fwd_start = INT_MAX;
                 cs[c].last_rev_start = cs[c].prev_fwd_stop = cs[c].prev_rev_stop = 0;
+                cs[c].fwd_recent = 0;
+                cs[c].fwd_older = cs[c].rev_cnt = 0;
+                cs[c].rev_from = (c == 0 ? -1 : c == 1 ? 0 : -2) + 4 + j_lo;      // the virtual stop in front of the read (Handle_First_Reverse_Stop)
             }
             cs[0].fwd_last = 0; cs[1].fwd_last = 1; cs[2].fwd_last = -1;
             BaseStream<1> bs;
@@ -241,6 +266,11 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
                         idx6 = ((idx6 << 2) | (uint32_t)bs.next()) & 63u;
                         if (i >= 2) {                   // a Codon_t with an empty position matches nothing (gene.cc:56,85)
                             const uint64_t bit = 1ull << idx6;
+                            if (counting) {             // the codon that is now k0 codons back leaves the mask (a stop codon is no start codon)
+                                cs[c].fwd_older += (int)((cs[c].fwd_recent >> (k0 - 1)) & 1ull);
+                                cs[c].fwd_recent = (cs[c].fwd_recent << 1) | ((a.fwd_start & bit) ? 1ull : 0ull);
+                                if ((a.rev_start & bit) && i >= cs[c].rev_from) cs[c].rev_cnt++;
+                            }
                             if ((a.fwd_start & bit) && cs[c].first_fwd_start == INT_MAX) cs[c].first_fwd_start = i - 1;
                             if (a.rev_start & bit) cs[c].last_rev_start = i - 1;
                             if (a.fwd_stop & bit) { fwd_stop(i, cs[c], c); cs[c].fwd_last = i; }
@@ -262,11 +292,17 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
                 int hi;
                 if (e >= n) hi = e + 1;
                 else { const int rc = (n - 1 - e) % 3; hi = (rc == 0 ? n - 1 : rc == 1 ? n - 2 : n) + 1; }
-                emit(orf_stop, -1 - (fr + 1) % 3, gene_len, orf_len, orf_stop + 3, hi);
+                emit(orf_stop, -1 - (fr + 1) % 3, gene_len, orf_len, orf_stop + 3, hi, S.rev_cnt);
             }
             if (trunc)                                  // glimmer_base.cc:765-776: 3 bp past the end count as stops
                 for (int i = n; i < n + 3; i++) {
                     const int c = i % 3;
+                    if (counting) {                     // (the virtual stop takes a place in the mask like a real one; static
+                                                        // indices, or the class states would live in scratch memory)
+                        if (c == 0) { cs[0].fwd_older += (int)((cs[0].fwd_recent >> (k0 - 1)) & 1ull); cs[0].fwd_recent <<= 1; }
+                        else if (c == 1) { cs[1].fwd_older += (int)((cs[1].fwd_recent >> (k0 - 1)) & 1ull); cs[1].fwd_recent <<= 1; }
+                        else { cs[2].fwd_older += (int)((cs[2].fwd_recent >> (k0 - 1)) & 1ull); cs[2].fwd_recent <<= 1; }
+                    }
                     if (c == 0) fwd_stop(i, cs[0], 0);
                     else if (c == 1) fwd_stop(i, cs[1], 1);
                     else fwd_stop(i, cs[2], 2);
@@ -2556,6 +2592,15 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     a.read_orf_off = res->d_read_orf_off;
     a.orfs = res->d_orfs;
     a.n_orfs = no;
+    {   // default mode: the write pass of the ORF scan counts every ORF's starts as it goes (lowest j within the 64 codons its mask holds)
+        const int j_lo = ((a.min_gene_len - 3 > 1 ? a.min_gene_len - 3 : 1) + 2) / 3 * 3;
+        a.count_starts = !find_only && !err_mode && 1 + j_lo / 3 <= 64;
+        if (!find_only) {
+            MG_TRY(gmg_pool_alloc((void **)&d_orf_cnt, (no + 1) * 4));
+            MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
+            a.orf_cnt = d_orf_cnt;
+        }
+    }
     if (nr) hipLaunchKernelGGL(k_mg_find_orfs<true>, dim3(grid_for(nr)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
     tm.lap("find orfs");
@@ -2572,10 +2617,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     }
     // 3. start lists
     if (!find_only) {
-    MG_TRY(gmg_pool_alloc((void **)&d_orf_cnt, (no + 1) * 4));
-    MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
     MG_TRY(gmg_pool_alloc((void **)&d_start_off, (no + 1) * 8));
-    a.orf_cnt = d_orf_cnt;
     const int err_acc_only = (prm->flags & GMG_MG_ACCEPTED_ONLY) ? 1 : 0;
     // error branch: 0 = level by level, one lane per call (k_mg_err_level; the default), 1 = one lane per ORF with an explicit stack
     // (k_mg_err_flat: exact slots; the fallback of 0, and on its own with GMG_MG_ERR_FLAT=1 for A/B runs and cross-checks)
@@ -2614,7 +2656,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         hipLaunchKernelGGL(k_mg_err_verdict, dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only);
         if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 1);
     } else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 0);
-    else if (no) hipLaunchKernelGGL(k_mg_starts<false>, dim3(grid_for(no)), dim3(256), 0, s2, a);
+    else if (no && !a.count_starts) hipLaunchKernelGGL(k_mg_starts<false>, dim3(grid_for(no)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
     tm.lap("start lists: count");
     rc = mg_scan(d_orf_cnt, d_start_off, no, &res->n_starts, s2);

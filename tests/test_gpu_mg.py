@@ -137,7 +137,7 @@ def test_glimmer_mg_with_device_front_half_is_byte_identical(gpu, tmp_path, flag
 
 
 @pytest.mark.parametrize("how", [["--batch-bytes", "50000"], ["--shards", "2"], ["--shards", "3", "--batch-bytes", "40000"],
-                                 ["--shards", "8", "--gpus", "1"]])
+                                 ["--shards", "4", "--gpus", "1"]])    # (at most 6 processes may hold the GPU of a test box: 4 + this one)
 @pytest.mark.parametrize("flags,golden", [([], "glimmer-mg.default.predict"), (["-i"], "glimmer-mg.indel.predict")])
 def test_glimmer_mg_gpu_in_batches_and_shards_is_byte_identical(gpu, tmp_path, how, flags, golden):
     """the same file in several batches per process and / or one forked process per shard (all on the one GPU of the box):
@@ -311,6 +311,9 @@ def test_empty_reads_inside_a_batch_are_harmless(gpu, oracle, nc):
     ("ragged 400", dict()),
     ("ragged 400", dict(min_gene_len=4, ignore_score_len=10, start_threshold=-1e300)),
     ("ragged 900", dict()),
+    ("ragged 900", dict(min_gene_len=198)),                            # lowest j = 195: the last shape whose starts the ORF scan counts itself
+    ("ragged 900", dict(min_gene_len=199, allow_truncated=False)),     # ... and the first that needs the count pass
+    ("uniform 500", dict(min_gene_len=300)),
     ("ragged 30", dict(min_gene_len=4)),
     ("codons", dict(min_gene_len=4)),
 ])
