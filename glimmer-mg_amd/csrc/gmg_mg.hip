@@ -92,6 +92,7 @@ struct MgArgs {
     int tile_cap;                // bases per tile of the tiled kernel
     // codon tests as 64-bit sets over idx6 = code(oldest) << 4 | code << 2 | code(newest)
     uint64_t fwd_start, rev_start, fwd_stop, rev_stop;
+    uint64_t fwd_stop_nat, rev_stop_nat;     // the stop sets over v = code(first base) | code << 2 | code(last) << 4 (k_mg_tile_starts)
     int8_t which[64];            // index of the first matching start codon, -1 for none (Codon_t::Can_Be)
     int min_gene_len, allow_truncated, ignore_score_len;
     double start_threshold;
@@ -952,30 +953,50 @@ __device__ __forceinline__ void mt_scan_step(double &s, uint32_t &p)
 
 struct MtTile { uint64_t w0; uint32_t first, nfit, span, o0, o1; };     // reads [first, first + nfit), bases [w0, w0 + span), ORFs [o0, o1)
 
-template <int NW>
+// G32: the table is the GENE32 form (fp32 rows of the gene model's values alone, a.gene32): half the bytes to read.  T is formed
+// from the widened floats, and stage 1, which has the bases of every position in a register anyway, subtracts the three null-model
+// values of T from a 3 x 64 table in LDS (one null model for the batch).  A buffer's first two positions take the partial-window
+// tables (icm.cc:807-842): the last two bases of a read on the forward strand, its first two on the reverse strand.
+template <int NW, bool G32>
 __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs a)
 {
     constexpr int BLOCK = 64 * NW, CAP = MT_W * NW;
-    constexpr int NPK = CAP / 16 + 4;                                   // packed words staged (one in front)
+    constexpr int NPK = CAP / 16 + 7;                                   // packed words staged (two in front, the windows of stage 2 behind)
     constexpr int PW = (NPK + BLOCK - 1) / BLOCK, PR = (MG_TILE_READS + 1 + BLOCK - 1) / BLOCK;
     __shared__ __attribute__((aligned(16))) double s_val[CAP];          // T in walk order, then the running sums
     __shared__ uint16_t s_oinfo[CAP];                                   // at a region's first u: the ORF's index in the tile + 1
     __shared__ uint32_t s_ch[CAP];                                      // start codons before u in its segment | the segment's first u << 12
-    __shared__ uint16_t s_q[CAP];                                       // the starts found
-    __shared__ uint8_t s_flag[CAP];                                     // bit 0 segment start, bit 1 codon inside the read, bits 2.. which + 1
+    __shared__ uint16_t s_q[CAP];                                       // the starts found: u | (which + 1) << 12
     __shared__ uint32_t s_packed[NPK];
     __shared__ uint32_t s_roff[MG_TILE_READS + 1];
     __shared__ int32_t s_isl[MG_TILE_READS];
-    __shared__ int8_t s_which[64];
+    __shared__ uint8_t s_whf[64], s_whr[64];                             // which + 1 of the codon field C (see stage 2), forward / reverse strand
     __shared__ unsigned long long s_obest[MT_ORFS];
     __shared__ uint32_t s_oso[MT_ORFS], s_ont[MT_ORFS], s_ofj[MT_ORFS];
     __shared__ double s_wsum[NW][3];
     __shared__ uint32_t s_wp[NW][3];
     __shared__ uint32_t s_nq;
+    // G32: the null model's full-window values indexed with the read's own bases as they sit in the packed word -- s_nullf[f][v],
+    // v = S[x] | S[x+1] << 2 | S[x+2] << 4 (forward strand: window of position x of the reversed read), s_nullr[f][v],
+    // v = S[x-2] | S[x-1] << 2 | S[x] << 4 (complemented read) -- and the partial-window tables as they are
+    __shared__ float s_nullf[G32 ? 192 : 1], s_nullr[G32 ? 192 : 1], s_nullp[G32 ? 60 : 1];
 
     const uint32_t tid = threadIdx.x;
+    if (G32) {
+        for (uint32_t i = tid; i < 192; i += BLOCK) {
+            const uint32_t f = i >> 6, v = i & 63u;
+            s_nullf[i] = a.null_tab[f * 64 + ((v & 3u) << 4 | (v & 12u) | v >> 4)];    // window w[k]: B[j-2], B[j-1], B[j] = S[x+2], S[x+1], S[x]
+            s_nullr[i] = a.null_tab[f * 64 + (v ^ 63u)];                               // ... = comp S[x-2], comp S[x-1], comp S[x]
+        }
+        for (uint32_t i = tid; i < 60; i += BLOCK) s_nullp[i] = a.null_tab[192 + i];
+    }
     const uint64_t n_tiles = a.n_tiles_dev ? (uint64_t)*a.n_tiles_dev : a.n_tiles;
-    if (tid < 64) s_which[tid] = a.which[tid];
+    if (tid < 64) {
+        // forward: the codon (b-2, b-1, b) as Codon_t holds it = the field with its pairs reversed; reverse: the complement of
+        // (b+2, b+1, b) = the field itself, complemented
+        s_whf[tid] = (uint8_t)(a.which[(tid & 3u) << 4 | (tid & 12u) | tid >> 4] + 1);
+        s_whr[tid] = (uint8_t)(a.which[tid ^ 63u] + 1);
+    }
     const int mgl = a.min_gene_len;
     int j_lo = mgl - 3 > 1 ? mgl - 3 : 1;               // as in mg_starts_one
     j_lo = (j_lo + 2) / 3 * 3;
@@ -1012,7 +1033,7 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
         t.o1 = roo[2 * ((uint64_t)t.first + t.nfit)];
     };
     // every global load of a tile is issued one tile ahead
-    double tmp[3][MT_EL];
+    typename std::conditional<G32, float, double>::type tmp[3][MT_EL];
     // (no arithmetic on a loaded value in there: it would wait for every load issued before it)
     // (and no load wider than what is used: a register half nobody reads is handed out again, and the write to it waits for the load)
     uint32_t tpk[PW], tro[PR];
@@ -1020,38 +1041,53 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
     uint32_t po_read = 0, po_s0 = 0, po_s1 = 0;         // the lane's first ORF of the tile: read, frame / lo / hi, slice of the start array (low words)
     int32_t po_frame = 0, po_lo = 0, po_hi = 0;
     auto issue = [&](uint64_t k, const MtTile &t) __attribute__((always_inline)) {
-        if (t.nfit == 0) return;
+        // (the tile's geometry is wave-uniform and has arrived an iteration ago: as scalars the rows' addresses are a scalar
+        // base + a 32-bit lane offset)
+        const uint32_t nfit = __builtin_amdgcn_readfirstlane(t.nfit);
+        if (nfit == 0) return;
+        const uint32_t span = __builtin_amdgcn_readfirstlane(t.span), first = __builtin_amdgcn_readfirstlane(t.first);
+        const uint32_t o0 = __builtin_amdgcn_readfirstlane(t.o0), n_orf = __builtin_amdgcn_readfirstlane(t.o1) - o0;
+        const uint64_t w0 = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t.w0 >> 32)) << 32 | __builtin_amdgcn_readfirstlane((uint32_t)t.w0);
         uint32_t tid = threadIdx.x;
         asm volatile("" : "+v"(tid));                   // (index arithmetic is redone where it is used: kept across the stages it costs more registers than instructions)
         const bool fwd = (k & 1) == 0;
-        const int64_t D = fwd ? -1 : 1;
-        const double *r0 = a.fs + (uint64_t)(fwd ? 0 : 3) * a.fs_stride, *r1 = r0 + a.fs_stride, *r2 = r1 + a.fs_stride;
+        typedef typename std::conditional<G32, float, double>::type row_t;
+        const row_t *r0 = (G32 ? (const row_t *)a.gene32 : (const row_t *)a.fs) + (uint64_t)(fwd ? 0 : 3) * a.fs_stride;
+        // T[b] = row 1 at b, row 2 at b -/+ 1, row 0 at b -/+ 2 (forward / reverse).  The neighbours of the batch's very first and
+        // last bases are clamped into the table: what T holds beyond its read is never used
+        const row_t *p1 = r0 + a.fs_stride + w0, *p2 = r0 + 2 * a.fs_stride + w0 - 2, *p0 = r0 + w0 - 2;       // (p2, p0: offset + 2 >= 0)
+        const uint32_t lo_lim = w0 >= 2 ? 0u : 2u - (uint32_t)w0;
+        const uint64_t left = a.total - w0;             // bases from the tile's first to the table's end (>= span)
+        const uint32_t hi_lim = left + 1 < 0x7fffffffull ? (uint32_t)left + 1 : 0x7fffffffu;       // offset + 2 of the table's last entry
 #pragma unroll
         for (int i = 0; i < MT_EL; i++) {
             const uint32_t b = tid + (uint32_t)BLOCK * i;
-            const int64_t g = (int64_t)t.w0 + b, g2 = g + D, g0 = g + 2 * D;
-            const bool in = b < t.span;
-            tmp[1][i] = in ? r1[g] : 0.0;
-            tmp[2][i] = in && g2 >= 0 && g2 < (int64_t)a.total ? r2[g2] : 0.0;
-            tmp[0][i] = in && g0 >= 0 && g0 < (int64_t)a.total ? r0[g0] : 0.0;
+            if (b < span) {
+                uint32_t x2 = fwd ? b + 1 : b + 3, x0 = fwd ? b : b + 4;       // b -/+ 1 and b -/+ 2, + 2
+                x2 = x2 < lo_lim ? lo_lim : x2 > hi_lim ? hi_lim : x2;
+                x0 = x0 < lo_lim ? lo_lim : x0 > hi_lim ? hi_lim : x0;
+                tmp[1][i] = p1[b];
+                tmp[2][i] = p2[x2];
+                tmp[0][i] = p0[x0];
+            } else
+                tmp[0][i] = tmp[1][i] = tmp[2][i] = (row_t)0;
         }
-        const uint32_t n_words = ((uint32_t)(t.w0 & 15) + t.span + 15) / 16 + 1;
 #pragma unroll
-        for (int u = 0; u < PW; u++) {
+        for (int u = 0; u < PW; u++) {                  // (packed reads have hundreds of guard words on both sides)
             const uint32_t i = tid + (uint32_t)BLOCK * u;
-            tpk[u] = i < n_words ? a.packed[(int64_t)(t.w0 >> 4) - 1 + i] : 0u;
+            tpk[u] = i < NPK ? (a.packed + ((int64_t)(w0 >> 4) - 2))[i] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < PR; u++) {
             const uint32_t i = tid + (uint32_t)BLOCK * u;
-            tro[u] = i <= t.nfit ? ((const uint32_t *)(a.read_off + t.first + i))[0] : 0u;        // (the low word is all that is needed)
-            tis[u] = a.read_isl && i < t.nfit ? a.read_isl[t.first + i] : a.ignore_score_len;
+            tro[u] = i <= nfit ? ((const uint32_t *)(a.read_off + first))[2 * i] : 0u;        // (the low word is all that is needed)
+            tis[u] = a.read_isl && i < nfit ? (a.read_isl + first)[i] : a.ignore_score_len;
         }
-        if (tid < t.o1 - t.o0) {
-            const gmg_mg_orf *o = a.orfs + t.o0 + tid;
+        if (tid < n_orf) {
+            const gmg_mg_orf *o = a.orfs + o0 + tid;
             po_read = o->read; po_frame = o->frame; po_lo = o->lo; po_hi = o->hi;
-            po_s0 = ((const uint32_t *)(a.start_off + t.o0 + tid))[0];
-            po_s1 = ((const uint32_t *)(a.start_off + t.o0 + tid + 1))[0];
+            po_s0 = ((const uint32_t *)(a.start_off + o0))[2 * tid];
+            po_s1 = ((const uint32_t *)(a.start_off + o0))[2 * tid + 2];
         }
     };
 
@@ -1082,7 +1118,7 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
 #pragma unroll
             for (int i = 0; i < MT_EL; i++) {
                 const uint32_t b = tid + (uint32_t)BLOCK * i;
-                if (b < span) s_val[fwd ? span - 1 - b : b] = (tmp[1][i] + tmp[2][i]) + tmp[0][i];
+                if (b < span) s_val[fwd ? span - 1 - b : b] = ((double)tmp[1][i] + (double)tmp[2][i]) + (double)tmp[0][i];
                 if (b < CAP) s_oinfo[b] = 0;
             }
 #pragma unroll
@@ -1137,42 +1173,8 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
             uh = fwd ? span - 1 - bh : bh;
         };
 
-        // ---- stage 1: flags (lane-contiguous: MT_EL consecutive bases per lane, one 64-bit window of the packed bases)
+        // ---- stage 1: one lane per ORF of the tile: where its region starts
         if (nfit) {
-            uint32_t tid1 = threadIdx.x;
-            asm volatile("" : "+v"(tid1));
-            const uint32_t b0 = tid1 * MT_EL;
-            if (b0 < CAP) {
-                uint32_t rl = 0; int rs = 0, n = 0;
-                if (b0 < span) read_of(b0, rl, rs, n);
-                const uint32_t x = 16u + (w0_lo & 15u) + b0 - 3u;                  // bit pair of base b0 - 3 (one word in front)
-                const uint32_t xi = (x >> 4) < (uint32_t)(NPK - 1) ? (x >> 4) : (uint32_t)(NPK - 2);
-                const uint64_t win = ((uint64_t)s_packed[xi] | (uint64_t)s_packed[xi + 1] << 32) >> (2u * (x & 15u));   // base b0 - 3 + i at bits 2i
-#pragma unroll
-                for (int i = 0; i < MT_EL; i++) {
-                    const uint32_t b = b0 + i;
-                    uint32_t f = 1;
-                    if (b < span) {
-                        while ((int)b >= rs + n) { rl++; rs = (int)s_roff[rl]; n = (int)s_roff[rl + 1] - rs; }   // (s_roff[nfit] = span > b)
-                        const int si = (int)b - rs;
-                        const uint32_t c7 = (uint32_t)(win >> (2 * i)) & 0x3fffu;      // bases b-3 .. b+3, b-3 lowest
-                        auto code = [&](int kk) { return (c7 >> (2 * (kk + 3))) & 3u; };
-                        bool st, geo;
-                        uint32_t sidx;
-                        if (fwd) {
-                            st = si + 3 >= n || ((a.fwd_stop >> (code(1) << 4 | code(2) << 2 | code(3))) & 1ull);
-                            geo = si >= 2;
-                            sidx = code(-2) << 4 | code(-1) << 2 | code(0);
-                        } else {
-                            st = si < 3 || ((a.rev_stop >> (code(-3) << 4 | code(-2) << 2 | code(-1))) & 1ull);
-                            geo = si + 2 <= n - 1;
-                            sidx = (code(2) << 4 | code(1) << 2 | code(0)) ^ 63u;
-                        }
-                        f = (st ? 1u : 0u) | (geo ? 2u : 0u) | (uint32_t)(s_which[sidx] + 1) << 2;
-                    }
-                    if (b < CAP) s_flag[b < span ? (fwd ? span - 1 - b : b) : b] = (uint8_t)f;
-                }
-            }
             for (uint32_t e = tid; e < n_orf; e += BLOCK) {
                 uint32_t rd, so, nt, uh; int32_t frame, lo, hi; bool trunc; int m;
                 orf_of(e, rd, frame, lo, hi, so, nt);
@@ -1181,9 +1183,15 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                 if (m > 0) s_oinfo[uh] = (uint16_t)(e + 1);
             }
         }
-        __syncthreads();
         MT_STAMP(2);                                    // stage 1
-        // ---- stage 2: the scan
+        // ---- stage 2: the scan.  Lane (class c, part jl) owns elements u = ub + 3 i, i < MT_EL: every third base of 27
+        // consecutive ones.  The ten codons of its class that surround them come out of ONE 64-bit window of the packed bases as
+        // 6-bit fields C[k] = S[x] | S[x+1] << 2 | S[x+2] << 4, x = sb + 3 k; the stop-codon sets and the start-codon table are
+        // indexed that way (MgArgs::*_nat, s_whf / s_whr).
+        //   reverse strand (u = b):         element i is base sb + 3 + 3 i; a segment starts behind the stop codon C[i]
+        //                                   (bases b-3 .. b-1), the start codon at it is C[i+1] (bases b .. b+2)
+        //   forward strand (u = span-1-b):  element i is base sb + 26 - 3 i; a segment starts below the stop codon C[9-i]
+        //                                   (bases b+1 .. b+3), the start codon at it is C[8-i] (bases b-2 .. b)
         if (nfit) {
             uint32_t tid2 = threadIdx.x;
             asm volatile("" : "+v"(tid2));
@@ -1193,20 +1201,78 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
             const uint32_t jl = idle ? MT_CL - 1 : l - MT_CL * c;          // (the idle lane repeats its neighbour's work and drops it)
             const uint32_t ub = MT_W * wv + 3 * MT_EL * jl + c;
             double es[MT_EL];
-            uint32_t ep[MT_EL];
+            uint32_t ep[MT_EL];                         // scan word | start codon here << 26 | (which + 1) << 27
             double acc = 0.0;
             uint32_t p = 0;
+            auto local = [&](auto FWD_) __attribute__((always_inline)) {
+                constexpr bool FWD = decltype(FWD_)::value;
+                const int b0 = FWD ? (int)span - 1 - (int)ub : (int)ub;            // base of element 0 (beyond the tile's reads: padding)
+                int sb = FWD ? b0 - 26 : b0 - 3;
+                if (sb < -26) sb = -26;                                            // (a lane of padding only: any window will do)
+                const uint32_t X = 2u * (uint32_t)(32 + (int)(w0_lo & 15u) + sb);  // two words in front of the tile's first
+                const uint32_t *pw = s_packed + (X >> 5);
+                const uint32_t q0 = pw[0], q1 = pw[1], q2 = pw[2];
+                const uint32_t wlo = __builtin_amdgcn_alignbit(q1, q0, X & 31u), whi = __builtin_amdgcn_alignbit(q2, q1, X & 31u);
+                const uint64_t win = (uint64_t)whi << 32 | wlo;                    // base sb + t at bits 2t
+                uint32_t rl = 0; int rs = 0, n = 0;
+                if ((uint32_t)b0 < span) read_of((uint32_t)b0, rl, rs, n);
+                const uint64_t stops = FWD ? a.fwd_stop_nat : a.rev_stop_nat;
+                const uint8_t *wht = FWD ? s_whf : s_whr;
 #pragma unroll
-            for (int i = 0; i < MT_EL; i++) {
-                const uint32_t u = ub + 3 * i;
-                const uint32_t f = s_flag[u];
-                const double T = s_val[u];
-                if (f & 1u) { acc = 0.0; p = (u << 12) | MT_REAL | MT_BLK; }
-                es[i] = acc;
-                ep[i] = p | (f << 26);                  // (the flag byte's bits 1.. ride along in bits 27..31: codon inside, which + 1)
-                acc += T;
-                p += ((f >> 1) & 1u) & ((f >> 2) != 0 ? 1u : 0u);
-            }
+                for (int i = 0; i < MT_EL; i++) {
+                    const uint32_t u = ub + 3 * i;
+                    const int b = FWD ? b0 - 3 * i : b0 + 3 * i;
+                    const bool valid = (uint32_t)b < span;
+                    if (valid) {
+                        if (FWD) while (b < rs) { rl--; rs = (int)s_roff[rl]; n = (int)s_roff[rl + 1] - rs; }
+                        else while (b >= rs + n) { rl++; rs = (int)s_roff[rl]; n = (int)s_roff[rl + 1] - rs; }
+                    }
+                    const int si = b - rs;
+                    const uint32_t cs = (uint32_t)(win >> (6 * (FWD ? 9 - i : i))) & 63u;
+                    const uint32_t cw = (uint32_t)(win >> (6 * (FWD ? 8 - i : i + 1))) & 63u;
+                    const bool st = !valid || (FWD ? si + 3 >= n : si < 3) || ((stops >> cs) & 1ull);
+                    const bool geo = FWD ? si >= 2 : si + 2 <= n - 1;
+                    const uint32_t wh = wht[cw];
+                    const uint32_t cand = valid && geo && wh != 0 ? 1u : 0u;
+                    double T = s_val[u];
+                    if (G32 && valid) {
+                        // T holds the gene model's three values; the null model's: sub-model 1 at x = b, 2 at x = b -/+ 1, 0 at
+                        // x = b -/+ 2 (forward / reverse), buffer position j = n-1-x / x
+                        const int bitb = FWD ? 52 - 6 * i : 6 * i + 6;             // bit position of S[b] in the window
+                        double nsum;
+                        if (FWD ? si + 2 >= n : si < 2) {                          // one of them is a partial window
+                            nsum = 0.0;
+#pragma unroll
+                            for (int t = 0; t < 3; t++) {
+                                const int fr = t == 0 ? 1 : t == 1 ? 2 : 0;
+                                const int xs = FWD ? si - t : si + t;              // the term's base in its read
+                                const int j = FWD ? n - 1 - xs : xs;
+                                if (xs < 0 || xs >= n) continue;                   // (beyond the read: T is never used then)
+                                const int bx = bitb + (FWD ? -2 * t : 2 * t);      // bit position of S[x]
+                                const uint32_t c0 = (uint32_t)(win >> bx) & 3u;
+                                const uint32_t c1 = (uint32_t)(win >> (FWD ? bx + 2 : bx - 2)) & 3u;
+                                const uint32_t b0c = FWD ? c0 : c0 ^ 3u, b1c = FWD ? c1 : c1 ^ 3u;
+                                float nv;
+                                if (j >= 2) nv = FWD ? s_nullf[fr * 64 + ((uint32_t)(win >> bx) & 63u)] : s_nullr[fr * 64 + ((uint32_t)(win >> (bx - 4)) & 63u)];
+                                else nv = s_nullp[fr * 20 + (j == 1 ? 4u + (b1c | b0c << 2) : b0c)];
+                                nsum += (double)nv;
+                            }
+                        } else if (FWD)
+                            nsum = ((double)s_nullf[64 + ((uint32_t)(win >> bitb) & 63u)] + (double)s_nullf[128 + ((uint32_t)(win >> (bitb - 2)) & 63u)]) +
+                                   (double)s_nullf[(uint32_t)(win >> (bitb - 4)) & 63u];
+                        else
+                            nsum = ((double)s_nullr[64 + ((uint32_t)(win >> (bitb - 4)) & 63u)] + (double)s_nullr[128 + ((uint32_t)(win >> (bitb - 2)) & 63u)]) +
+                                   (double)s_nullr[(uint32_t)(win >> bitb) & 63u];
+                        T -= nsum;
+                    }
+                    if (st) { acc = 0.0; p = (u << 12) | MT_REAL | MT_BLK; }
+                    es[i] = acc;
+                    ep[i] = p | cand << 26 | wh << 27;
+                    acc += T;
+                    p += cand;
+                }
+            };
+            if (fwd) local(std::integral_constant<bool, true>()); else local(std::integral_constant<bool, false>());
             // the totals of the lanes before this one in its class: shift by one lane, then an inclusive segmented scan
             double xs;
             uint32_t xp;
@@ -1231,7 +1297,9 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                     s_wsum[wv][c] = blk ? acc : xs + acc;
                     s_wp[wv][c] = blk ? p : xp + p;
                 }
-                __syncthreads();
+            }
+            __syncthreads();                            // (the ORFs' region starts are in place too)
+            if (NW > 1) {
                 if (!(xp & MT_REAL)) {
                     double ws = 0.0;
                     uint32_t wp = 0;
@@ -1253,13 +1321,12 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                 const double cum = own ? es[i] : xs + es[i];
                 const uint32_t pp = own ? ep[i] : xp + (ep[i] & 0xfffu);
                 const uint32_t ch = pp & 0xffffffu;
-                const uint32_t f1 = ep[i] >> 27;                           // bit 0: codon inside the read, bits 1..: which + 1
                 if (!idle) {
                     s_val[u] = cum;
                     s_ch[u] = ch;
-                    if ((f1 & 1u) && (f1 >> 1)) {
+                    if ((ep[i] >> 26) & 1u) {           // a start codon inside the read: a start if an ORF's region holds it at j >= lowest j
                         const uint32_t hd = ch >> 12;
-                        if (s_oinfo[hd] != 0 && (int)(u - hd) >= j_lo) s_q[atomicAdd(&s_nq, 1u)] = (uint16_t)u;
+                        if (s_oinfo[hd] != 0 && (int)(u - hd) >= j_lo) s_q[atomicAdd(&s_nq, 1u)] = (uint16_t)(u | (ep[i] >> 27) << 12);
                     }
                 }
             }
@@ -1270,7 +1337,9 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
         MtTile nx3;
         meta_a(k + 3 * (uint64_t)gridDim.x, nx3);
         meta_b(nx2);
+#ifndef MT_ISSUE_LATE
         issue(k + gridDim.x, nxt);
+#endif
         __syncthreads();
         MT_STAMP(1);                                    // the next tile's loads issued
 #ifdef GMG_MT_LOADS_ONLY                                // diagnostic build: the load pattern alone (results invalid)
@@ -1292,7 +1361,7 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
             __syncthreads();
             const uint32_t nq = s_nq;
             for (uint32_t qi = tid; qi < nq; qi += BLOCK) {
-                const uint32_t u = s_q[qi];
+                const uint32_t qe = s_q[qi], u = qe & 0xfffu;
                 const uint32_t ch = s_ch[u], hd = ch >> 12;
                 const uint32_t info = s_oinfo[hd];
                 const uint32_t e = info - 1u;
@@ -1310,7 +1379,7 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                 const double sc = (j + 2 > s_isl[rl] && 0.0 > pend) ? 0.0 : pend;          // glimmer-mg.cc:1644-1646
                 gmg_start st;
                 st.score = sc; st.j = j + 2; st.pos = fwd ? si - 1 : si + 3;
-                st.which = (int32_t)(s_flag[u] >> 2) - 1; st.truncated = 0; st.first = slot == 0 ? 1 : 0;
+                st.which = (int32_t)(qe >> 12) - 1; st.truncated = 0; st.first = slot == 0 ? 1 : 0;
                 a.starts[(uint64_t)s_oso[e - e0] + slot] = st;
                 atomicMax(&s_obest[e - e0], (unsigned long long)mg_ord(sc));
                 if (slot == 0) s_ofj[e - e0] = (uint32_t)(j + 2);
@@ -1352,6 +1421,9 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
             if (e0 + MT_ORFS < n_orf) __syncthreads();
         }
         MT_STAMP(4);                                    // stages 3 and 4
+#ifdef MT_ISSUE_LATE
+        issue(k + gridDim.x, nxt);
+#endif
         cur = nxt;
         nxt = nx2;
         nx2 = nx3;
@@ -2314,6 +2386,11 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             if (must_be(f_stop, prm->n_stop_codons)) a.fwd_stop |= 1ull << idx;
             if (must_be(r_stop, prm->n_stop_codons)) a.rev_stop |= 1ull << idx;
         }
+        for (unsigned v = 0; v < 64; v++) {
+            const unsigned idx = (v & 3u) << 4 | (v & 12u) | v >> 4;
+            if ((a.fwd_stop >> idx) & 1ull) a.fwd_stop_nat |= 1ull << v;
+            if ((a.rev_stop >> idx) & 1ull) a.rev_stop_nat |= 1ull << v;
+        }
     }
 
     gmg_mg_result *res = new (std::nothrow) gmg_mg_result();
@@ -2407,9 +2484,30 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     // Measured (1M x 500 bp, profiles/r02_mg_*): with ONE null model the fp64 table wins (running sums 7.2 ms against 9.1 ms: the
     // conversion costs more vector work than the halved read saves); with per-read null models GENE32 saves the extra pass over
     // the table (13.3 ms against 16.6 ms for the table + sums).  Option mg_gene32: 0 never, 1 with per-read nulls (default), 2 always.
+    // The fused kernel (k_mg_tile_starts: sums as a parallel scan + start lists) when every sum of the batch is exact in any
+    // order -- see there; R = the longest read + 2 terms.  Not with per-read null models on the GENE32 table yet.
+    {
+        const int n_min = prm->nulls ? prm->nulls->min_exp : nul->min_exp, n_max = prm->nulls ? prm->nulls->max_exp : nul->max_exp;
+        const int n_odd = prm->nulls ? prm->nulls->odd_values : nul->odd_values;
+        const int mn = gene->min_exp < n_min ? gene->min_exp : n_min, mx = gene->max_exp > n_max ? gene->max_exp : n_max;
+        int clog = 0;
+        while ((1ull << clog) < reads->max_len + 2) clog++;
+        const bool exact = !gene->odd_values && !n_odd && (mx < mn || clog + mx - mn <= 28);
+        const long long forced_tile = gmg_opt(GMG_OPT_MG_TILE);
+        if (!err_mode && exact && gmg_opt(GMG_OPT_MG_FUSED) && a.n_reads && a.total) {
+            if (forced_tile == 1 || forced_tile == 2 || forced_tile == 4) fused_nw = (int)forced_tile;
+            else if (reads->uniform_len > 0) fused_nw = reads->uniform_len <= MT_W ? 1 : reads->uniform_len <= 2 * MT_W ? 2 : reads->uniform_len <= 4 * MT_W ? 4 : 0;
+            else fused_nw = (reads->max_len <= MT_W || reads->n_over_512 * 10 <= reads->n_reads) ? 1 : reads->max_len <= 2 * MT_W ? 2 : 4;
+            if (reads->uniform_len > (int)(MT_W * fused_nw)) fused_nw = 0;
+        }
+    }
+    // (the fused kernel reads whichever table there is.  Measured, 1M x 500 bp, one null model: the fp64 table 4.9 + 6.2 ms, the
+    // GENE32 form 3.9 + 7.5 ms -- the kernel is bound by its vector instructions, not by the table's bytes, and the null-model
+    // lookups add a quarter to them; profiles/r02_mg_pmc_*.txt)
     const long long g32_opt = gmg_opt(GMG_OPT_MG_GENE32);
     const bool g32 = !d_frame_scores && !err_mode && a.total && (g32_opt == 2 || (g32_opt == 1 && prm->nulls)) && nul_dense3 &&
                      gene->dev.has_fast && gene->dev.D == 7 && gene->dev.W >= 3 && gene->dev.W <= 15;
+    if (g32 && prm->nulls) fused_nw = 0;
     if (prm->nulls && !nul_dense3) return fail(gmg_set_error(GMG_EBADMODEL, "gmg_mg_score_reads: per-read null models are (3,2,3) models"));
     a.fs_stride = a.total;
     if (g32) {
@@ -2443,23 +2541,6 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         }
     }
     // running sums of every reading-frame class (what Cumulative_Frame_Score would give any ORF)
-    // The fused kernel (k_mg_tile_starts: sums as a parallel scan + start lists) when every sum of the batch is exact in any
-    // order -- see there; R = the longest read + 2 terms.  Not with the GENE32 table (per-read null models) yet.
-    {
-        const int n_min = prm->nulls ? prm->nulls->min_exp : nul->min_exp, n_max = prm->nulls ? prm->nulls->max_exp : nul->max_exp;
-        const int n_odd = prm->nulls ? prm->nulls->odd_values : nul->odd_values;
-        const int mn = gene->min_exp < n_min ? gene->min_exp : n_min, mx = gene->max_exp > n_max ? gene->max_exp : n_max;
-        int clog = 0;
-        while ((1ull << clog) < reads->max_len + 2) clog++;
-        const bool exact = !gene->odd_values && !n_odd && (mx < mn || clog + mx - mn <= 28);
-        const long long forced_tile = gmg_opt(GMG_OPT_MG_TILE);
-        if (!err_mode && !g32 && exact && gmg_opt(GMG_OPT_MG_FUSED) && a.n_reads && a.total) {
-            if (forced_tile == 1 || forced_tile == 2 || forced_tile == 4) fused_nw = (int)forced_tile;
-            else if (reads->uniform_len > 0) fused_nw = reads->uniform_len <= MT_W ? 1 : reads->uniform_len <= 2 * MT_W ? 2 : reads->uniform_len <= 4 * MT_W ? 4 : 0;
-            else fused_nw = (reads->max_len <= MT_W || reads->n_over_512 * 10 <= reads->n_reads) ? 1 : reads->max_len <= 2 * MT_W ? 2 : 4;
-            if (reads->uniform_len > (int)(MT_W * fused_nw)) fused_nw = 0;
-        }
-    }
     if (!err_mode && a.n_reads && a.total) {
         // tile shape of the sequential kernel: two waves and <= 512 bases (12 KB of LDS, many blocks per CU in different phases)
         // when the reads allow it, else eight waves and 1504 bases (39.8 KB, four blocks per CU); the fused kernel: 567 bases per wave
@@ -2518,7 +2599,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
                 a.unfit_n = d_unfit;
                 MG_TRY(hipMemsetAsync(d_unfit, 0, 4, s));
                 hipLaunchKernelGGL(k_mg_unfit_list, dim3(grid_for(a.n_reads)), dim3(256), 0, s, a);
-                hipLaunchKernelGGL(k_mg_cum<false>, dim3(grid_for(2 * a.n_reads)), dim3(256), 0, s, a);
+                if (g32) hipLaunchKernelGGL(k_mg_cum<true>, dim3(grid_for(2 * a.n_reads)), dim3(256), 0, s, a);
+                else hipLaunchKernelGGL(k_mg_cum<false>, dim3(grid_for(2 * a.n_reads)), dim3(256), 0, s, a);
                 MG_TRY(hipGetLastError());
             }
         } else {
@@ -2712,9 +2794,15 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     } else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 0);
     else if (no && fused_nw) {
         const unsigned grid = (unsigned)(2 * a.n_tiles < 64 * 1024 ? 2 * a.n_tiles : 64 * 1024);
-        if (fused_nw == 1) hipLaunchKernelGGL(k_mg_tile_starts<1>, dim3(grid), dim3(64), 0, s, a);
-        else if (fused_nw == 2) hipLaunchKernelGGL(k_mg_tile_starts<2>, dim3(grid), dim3(128), 0, s, a);
-        else hipLaunchKernelGGL(k_mg_tile_starts<4>, dim3(grid), dim3(256), 0, s, a);
+        if (a.gene32) {
+            if (fused_nw == 1) hipLaunchKernelGGL((k_mg_tile_starts<1, true>), dim3(grid), dim3(64), 0, s, a);
+            else if (fused_nw == 2) hipLaunchKernelGGL((k_mg_tile_starts<2, true>), dim3(grid), dim3(128), 0, s, a);
+            else hipLaunchKernelGGL((k_mg_tile_starts<4, true>), dim3(grid), dim3(256), 0, s, a);
+        } else {
+            if (fused_nw == 1) hipLaunchKernelGGL((k_mg_tile_starts<1, false>), dim3(grid), dim3(64), 0, s, a);
+            else if (fused_nw == 2) hipLaunchKernelGGL((k_mg_tile_starts<2, false>), dim3(grid), dim3(128), 0, s, a);
+            else hipLaunchKernelGGL((k_mg_tile_starts<4, false>), dim3(grid), dim3(256), 0, s, a);
+        }
         if (fused_rest) hipLaunchKernelGGL(k_mg_starts_unfit, dim3(grid_for(a.n_reads / 16 + 1)), dim3(256), 0, s, a);
     } else if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());

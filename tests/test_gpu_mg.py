@@ -320,7 +320,8 @@ def test_empty_reads_inside_a_batch_are_harmless(gpu, oracle, nc):
 def test_mg_fused_kernel_equals_the_sequential_kernels(gpu, nc, shape, kw):
     """k_mg_tile_starts (running sums as a parallel scan + start lists, option mg_fused = 1, the default when the models'
     values make every sum exact) against k_mg_cum_tiled / k_mg_cum + k_mg_starts (sequential sums in the reference's
-    order): every byte of the ORF records and of the start lists, for every tile shape (mg_tile = 1, 2, 4 waves)"""
+    order): every byte of the ORF records and of the start lists, for every tile shape (mg_tile = 1, 2, 4 waves) and both
+    forms of the table it reads"""
     kind, _, arg = shape.partition(" ")
     rng = np.random.default_rng(len(shape) * 1000 + len(kw))
     if kind == "uniform":
@@ -346,10 +347,10 @@ def test_mg_fused_kernel_equals_the_sequential_kernels(gpu, nc, shape, kw):
     for tile in (0, 1, 2, 4):
         if kind == "uniform" and tile and int(arg) > 567 * tile:
             continue
-        print("mg_tile", tile, flush=True)
-        with gpu.option("mg_tile", tile):
-            got = gpu.mg_score_reads(nc, indep, reads, **kw)
-        assert np.array_equal(got[2], want[2])
-        for c in want[0].dtype.names:
-            assert np.array_equal(got[0][c], want[0][c]), (shape, tile, c)
-        assert got[1].tobytes() == want[1].tobytes(), (shape, tile)
+        for g32 in (1, 0):                                              # the call's own table as fp32 gene rows (the default) / as doubles
+            with gpu.option("mg_tile", tile), gpu.option("mg_gene32", g32):
+                got = gpu.mg_score_reads(nc, indep, reads, **kw)
+            assert np.array_equal(got[2], want[2])
+            for c in want[0].dtype.names:
+                assert np.array_equal(got[0][c], want[0][c]), (shape, tile, g32, c)
+            assert got[1].tobytes() == want[1].tobytes(), (shape, tile, g32)
