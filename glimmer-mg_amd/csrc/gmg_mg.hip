@@ -1059,18 +1059,26 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
         const uint32_t lo_lim = w0 >= 2 ? 0u : 2u - (uint32_t)w0;
         const uint64_t left = a.total - w0;             // bases from the tile's first to the table's end (>= span)
         const uint32_t hi_lim = left + 1 < 0x7fffffffull ? (uint32_t)left + 1 : 0x7fffffffu;       // offset + 2 of the table's last entry
+        const uint32_t d2 = fwd ? 1u : 3u, d0 = fwd ? 0u : 4u;                 // b -/+ 1 and b -/+ 2, + 2
+        if (lo_lim == 0 && hi_lim >= span + 3) {        // (every tile but the batch's first and last)
 #pragma unroll
-        for (int i = 0; i < MT_EL; i++) {
-            const uint32_t b = tid + (uint32_t)BLOCK * i;
-            if (b < span) {
-                uint32_t x2 = fwd ? b + 1 : b + 3, x0 = fwd ? b : b + 4;       // b -/+ 1 and b -/+ 2, + 2
-                x2 = x2 < lo_lim ? lo_lim : x2 > hi_lim ? hi_lim : x2;
-                x0 = x0 < lo_lim ? lo_lim : x0 > hi_lim ? hi_lim : x0;
-                tmp[1][i] = p1[b];
-                tmp[2][i] = p2[x2];
-                tmp[0][i] = p0[x0];
-            } else
-                tmp[0][i] = tmp[1][i] = tmp[2][i] = (row_t)0;
+            for (int i = 0; i < MT_EL; i++) {
+                const uint32_t b = tid + (uint32_t)BLOCK * i;
+                if (b < span) { tmp[1][i] = p1[b]; tmp[2][i] = p2[b + d2]; tmp[0][i] = p0[b + d0]; }      // (what a lane beyond the span holds is not used)
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT_EL; i++) {
+                const uint32_t b = tid + (uint32_t)BLOCK * i;
+                if (b < span) {
+                    uint32_t x2 = b + d2, x0 = b + d0;
+                    x2 = x2 < lo_lim ? lo_lim : x2 > hi_lim ? hi_lim : x2;
+                    x0 = x0 < lo_lim ? lo_lim : x0 > hi_lim ? hi_lim : x0;
+                    tmp[1][i] = p1[b];
+                    tmp[2][i] = p2[x2];
+                    tmp[0][i] = p0[x0];
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < PW; u++) {                  // (packed reads have hundreds of guard words on both sides)
@@ -2644,18 +2652,20 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     //    stream beside the six-frame and running-sum kernels (light kernels without LDS, they fit next to the main pass's
     //    work-groups) and join the caller's stream before the start lists are written.
     static thread_local hipStream_t side_of[16] = {};   // one per device this host thread has used
-    static thread_local hipEvent_t done_of[16] = {};
+    static thread_local hipEvent_t done_of[16] = {}, cum_of[16] = {};
     hipStream_t s2 = s;
-    hipEvent_t side_done = nullptr;
+    hipEvent_t side_done = nullptr, cum_done = nullptr;
     int dev_id = 0;
     MG_TRY(hipGetDevice(&dev_id));
     if (!find_only && !tm.on && !gmg_opt(GMG_OPT_MG_ONE_STREAM) && dev_id >= 0 && dev_id < 16) {
         if (!side_of[dev_id]) {
             MG_TRY(hipStreamCreateWithFlags(&side_of[dev_id], hipStreamNonBlocking));
             MG_TRY(hipEventCreateWithFlags(&done_of[dev_id], hipEventDisableTiming));
+            MG_TRY(hipEventCreateWithFlags(&cum_of[dev_id], hipEventDisableTiming));
         }
         s2 = side_of[dev_id];
         side_done = done_of[dev_id];
+        cum_done = cum_of[dev_id];
     }
     const uint64_t nr = a.n_reads;
     MG_TRY(gmg_pool_alloc((void **)&d_read_cnt, (nr + 1) * 4));
@@ -2794,6 +2804,15 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     } else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 0);
     else if (no && fused_nw) {
         const unsigned grid = (unsigned)(2 * a.n_tiles < 64 * 1024 ? 2 * a.n_tiles : 64 * 1024);
+        // the few reads no tile takes (one lane per read, long loops): beside the tile kernel on the side stream, behind their
+        // running sums (k_mg_cum, queued on the caller's stream long ago)
+        const bool unfit_aside = fused_rest && s2 != s;
+        if (unfit_aside) {
+            MG_TRY(hipEventRecord(cum_done, s));
+            MG_TRY(hipStreamWaitEvent(s2, cum_done, 0));
+            hipLaunchKernelGGL(k_mg_starts_unfit, dim3(grid_for(a.n_reads / 16 + 1)), dim3(256), 0, s2, a);
+            MG_TRY(hipEventRecord(side_done, s2));
+        }
         if (a.gene32) {
             if (fused_nw == 1) hipLaunchKernelGGL((k_mg_tile_starts<1, true>), dim3(grid), dim3(64), 0, s, a);
             else if (fused_nw == 2) hipLaunchKernelGGL((k_mg_tile_starts<2, true>), dim3(grid), dim3(128), 0, s, a);
@@ -2803,7 +2822,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             else if (fused_nw == 2) hipLaunchKernelGGL((k_mg_tile_starts<2, false>), dim3(grid), dim3(128), 0, s, a);
             else hipLaunchKernelGGL((k_mg_tile_starts<4, false>), dim3(grid), dim3(256), 0, s, a);
         }
-        if (fused_rest) hipLaunchKernelGGL(k_mg_starts_unfit, dim3(grid_for(a.n_reads / 16 + 1)), dim3(256), 0, s, a);
+        if (unfit_aside) MG_TRY(hipStreamWaitEvent(s, side_done, 0));
+        else if (fused_rest) hipLaunchKernelGGL(k_mg_starts_unfit, dim3(grid_for(a.n_reads / 16 + 1)), dim3(256), 0, s, a);
     } else if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
     MG_TRY(hipGetLastError());
     break;
