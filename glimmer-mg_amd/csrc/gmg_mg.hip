@@ -81,6 +81,7 @@ struct MgArgs {
     // tiling of k_mg_cum_tiled: uniform batches take reads_per_tile reads per block; ragged batches the reads
     // that start inside the block's window of tile_window bases
     int uniform_len, reads_per_tile;
+    int tile_reads_max;          // most reads a tile takes: MG_TILE_READS, or MT_NC when the fused kernel holds a null model per read in LDS
     uint32_t uniform_magic;      // ceil (2^32 / uniform_len): b / uniform_len = __umulhi (b, magic) for b < 2^16
     uint64_t tile_window, n_tiles;
     int lanes_only_unfit;        // k_mg_cum: skip the reads the tiled kernel has done
@@ -475,7 +476,7 @@ __device__ __forceinline__ void mg_tile_reads(const MgArgs &a, uint64_t k, uint6
     nfit = 0;
     if (first >= a.n_reads) return;
     const uint64_t w0 = a.read_off[first];
-    while (first + nfit < end && nfit < MG_TILE_READS && a.read_off[first + nfit + 1] - w0 <= cap) nfit++;
+    while (first + nfit < end && nfit < (uint32_t)a.tile_reads_max && a.read_off[first + nfit + 1] - w0 <= cap) nfit++;
 }
 
 // ragged batches: the tile of every window, computed once (the tiled kernel then needs ONE load per tile instead of a
@@ -935,6 +936,7 @@ extern "C" int gmg_debug_mt_stamps(unsigned long long *out, int reset)
 #define MT_CL 21                 // lanes per class
 #define MT_W (3 * MT_CL * MT_EL) // bases per wave: 567
 #define MT_ORFS 64               // ORFs per pass of stages 3 and 4
+#define MT_NC 6                  // per-read null models of a tile held in LDS = reads per tile in that mode
 #define MT_REAL (1u << 24)       // scan word: start codons so far (bits 0-11), u of the segment start (12-23), "holds one" (24),
 #define MT_BLK (1u << 25)        // "nothing flows in from the left" (25: a segment start, or the first lane of a class)
 
@@ -979,17 +981,23 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
     // G32: the null model's full-window values indexed with the read's own bases as they sit in the packed word -- s_nullf[f][v],
     // v = S[x] | S[x+1] << 2 | S[x+2] << 4 (forward strand: window of position x of the reversed read), s_nullr[f][v],
     // v = S[x-2] | S[x-1] << 2 | S[x] << 4 (complemented read) -- and the partial-window tables as they are
-    __shared__ float s_nullf[G32 ? 192 : 1], s_nullr[G32 ? 192 : 1], s_nullp[G32 ? 60 : 1];
+    // ([0] forward, [1] reverse, each followed by the partial-window tables).  With a null model per read (a.read_null) the tables of
+    // the tile's reads (MT_NC at most in this mode) are fetched with the tile, in the order of the strand it works on.
+    __shared__ float s_null1[G32 ? 2 : 1][G32 ? MG_NULL_FLOATS : 1], s_nullm[G32 ? MT_NC : 1][G32 ? MG_NULL_FLOATS : 1];
+    __shared__ uint32_t s_rnull[G32 ? MG_TILE_READS : 1];
 
     const uint32_t tid = threadIdx.x;
-    if (G32) {
-        for (uint32_t i = tid; i < 192; i += BLOCK) {
-            const uint32_t f = i >> 6, v = i & 63u;
-            s_nullf[i] = a.null_tab[f * 64 + ((v & 3u) << 4 | (v & 12u) | v >> 4)];    // window w[k]: B[j-2], B[j-1], B[j] = S[x+2], S[x+1], S[x]
-            s_nullr[i] = a.null_tab[f * 64 + (v ^ 63u)];                               // ... = comp S[x-2], comp S[x-1], comp S[x]
+    // entry e of a table in the strand's order <- entry of the (3,2,3) model's table as gmg_null_set / gmg_model_upload lay it out
+    auto null_src = [](uint32_t e, bool fwd_order) __attribute__((always_inline)) {
+        const uint32_t v = e & 63u;
+        return e >= 192u ? e : (e & ~63u) + (fwd_order ? (v & 3u) << 4 | (v & 12u) | v >> 4      // window w[k]: B[j-2], B[j-1], B[j] = S[x+2], S[x+1], S[x]
+                                                       : v ^ 63u);                               // ... = comp S[x-2], comp S[x-1], comp S[x]
+    };
+    if (G32 && !a.read_null)
+        for (uint32_t i = tid; i < MG_NULL_FLOATS; i += BLOCK) {
+            s_null1[0][i] = a.null_tab[null_src(i, true)];
+            s_null1[1][i] = a.null_tab[null_src(i, false)];
         }
-        for (uint32_t i = tid; i < 60; i += BLOCK) s_nullp[i] = a.null_tab[192 + i];
-    }
     const uint64_t n_tiles = a.n_tiles_dev ? (uint64_t)*a.n_tiles_dev : a.n_tiles;
     if (tid < 64) {
         // forward: the codon (b-2, b-1, b) as Codon_t holds it = the field with its pairs reversed; reverse: the complement of
@@ -1036,7 +1044,7 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
     typename std::conditional<G32, float, double>::type tmp[3][MT_EL];
     // (no arithmetic on a loaded value in there: it would wait for every load issued before it)
     // (and no load wider than what is used: a register half nobody reads is handed out again, and the write to it waits for the load)
-    uint32_t tpk[PW], tro[PR];
+    uint32_t tpk[PW], tro[PR], trn[PR];
     int32_t tis[PR];
     uint32_t po_read = 0, po_s0 = 0, po_s1 = 0;         // the lane's first ORF of the tile: read, frame / lo / hi, slice of the start array (low words)
     int32_t po_frame = 0, po_lo = 0, po_hi = 0;
@@ -1090,6 +1098,7 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
             const uint32_t i = tid + (uint32_t)BLOCK * u;
             tro[u] = i <= nfit ? ((const uint32_t *)(a.read_off + first))[2 * i] : 0u;        // (the low word is all that is needed)
             tis[u] = a.read_isl && i < nfit ? (a.read_isl + first)[i] : a.ignore_score_len;
+            trn[u] = G32 && a.read_null && i < nfit ? (a.read_null + first)[i] : 0u;
         }
         if (tid < n_orf) {
             const gmg_mg_orf *o = a.orfs + o0 + tid;
@@ -1139,6 +1148,7 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                 const uint32_t i = tid + (uint32_t)BLOCK * u;
                 if (i <= nfit) s_roff[i] = tro[u] - w0_lo;
                 if (i < nfit) s_isl[i] = tis[u];
+                if (G32 && i < nfit) s_rnull[i] = trn[u];
             }
             if (tid == 0) s_nq = 0;
         }
@@ -1190,7 +1200,15 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                 orf_geo(rd, lo, hi, trunc, m, uh);
                 if (m > 0) s_oinfo[uh] = (uint16_t)(e + 1);
             }
+            if (G32 && a.read_null) {
+                const uint32_t nc = nfit < MT_NC ? nfit : MT_NC;
+                for (uint32_t i = tid; i < nc * MG_NULL_FLOATS; i += BLOCK) {
+                    const uint32_t rl = i / MG_NULL_FLOATS, e = i - rl * MG_NULL_FLOATS;
+                    s_nullm[rl][e] = a.null_tab[(size_t)s_rnull[rl] * MG_NULL_FLOATS + null_src(e, fwd)];
+                }
+            }
         }
+        if (G32) __syncthreads();
         MT_STAMP(2);                                    // stage 1
         // ---- stage 2: the scan.  Lane (class c, part jl) owns elements u = ub + 3 i, i < MT_EL: every third base of 27
         // consecutive ones.  The ten codons of its class that surround them come out of ONE 64-bit window of the packed bases as
@@ -1247,6 +1265,11 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                         // T holds the gene model's three values; the null model's: sub-model 1 at x = b, 2 at x = b -/+ 1, 0 at
                         // x = b -/+ 2 (forward / reverse), buffer position j = n-1-x / x
                         const int bitb = FWD ? 52 - 6 * i : 6 * i + 6;             // bit position of S[b] in the window
+                        // entry `off` of the read's table in this strand's order
+                        auto nullv = [&](uint32_t off, uint32_t) __attribute__((always_inline)) {
+                            if (!a.read_null) return s_null1[FWD ? 0 : 1][off];
+                            return s_nullm[rl < MT_NC ? rl : 0u][off];               // (mg_run lets a tile take MT_NC reads at most then)
+                        };
                         double nsum;
                         if (FWD ? si + 2 >= n : si < 2) {                          // one of them is a partial window
                             nsum = 0.0;
@@ -1261,16 +1284,16 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                                 const uint32_t c1 = (uint32_t)(win >> (FWD ? bx + 2 : bx - 2)) & 3u;
                                 const uint32_t b0c = FWD ? c0 : c0 ^ 3u, b1c = FWD ? c1 : c1 ^ 3u;
                                 float nv;
-                                if (j >= 2) nv = FWD ? s_nullf[fr * 64 + ((uint32_t)(win >> bx) & 63u)] : s_nullr[fr * 64 + ((uint32_t)(win >> (bx - 4)) & 63u)];
-                                else nv = s_nullp[fr * 20 + (j == 1 ? 4u + (b1c | b0c << 2) : b0c)];
+                                const uint32_t v = (uint32_t)(win >> (FWD ? bx : bx - 4)) & 63u;
+                                if (j >= 2) nv = nullv(fr * 64 + v, v);
+                                else nv = nullv(192u + fr * 20 + (j == 1 ? 4u + (b1c | b0c << 2) : b0c), 0);
                                 nsum += (double)nv;
                             }
-                        } else if (FWD)
-                            nsum = ((double)s_nullf[64 + ((uint32_t)(win >> bitb) & 63u)] + (double)s_nullf[128 + ((uint32_t)(win >> (bitb - 2)) & 63u)]) +
-                                   (double)s_nullf[(uint32_t)(win >> (bitb - 4)) & 63u];
-                        else
-                            nsum = ((double)s_nullr[64 + ((uint32_t)(win >> (bitb - 4)) & 63u)] + (double)s_nullr[128 + ((uint32_t)(win >> (bitb - 2)) & 63u)]) +
-                                   (double)s_nullr[(uint32_t)(win >> bitb) & 63u];
+                        } else {
+                            const uint32_t v1 = (uint32_t)(win >> (FWD ? bitb : bitb - 4)) & 63u, v2 = (uint32_t)(win >> (bitb - 2)) & 63u;
+                            const uint32_t v0 = (uint32_t)(win >> (FWD ? bitb - 4 : bitb)) & 63u;
+                            nsum = ((double)nullv(64 + v1, v1) + (double)nullv(128 + v2, v2)) + (double)nullv(v0, v0);
+                        }
                         T -= nsum;
                     }
                     if (st) { acc = 0.0; p = (u << 12) | MT_REAL | MT_BLK; }
@@ -2493,7 +2516,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     // conversion costs more vector work than the halved read saves); with per-read null models GENE32 saves the extra pass over
     // the table (13.3 ms against 16.6 ms for the table + sums).  Option mg_gene32: 0 never, 1 with per-read nulls (default), 2 always.
     // The fused kernel (k_mg_tile_starts: sums as a parallel scan + start lists) when every sum of the batch is exact in any
-    // order -- see there; R = the longest read + 2 terms.  Not with per-read null models on the GENE32 table yet.
+    // order -- see there; R = the longest read + 2 terms.
     {
         const int n_min = prm->nulls ? prm->nulls->min_exp : nul->min_exp, n_max = prm->nulls ? prm->nulls->max_exp : nul->max_exp;
         const int n_odd = prm->nulls ? prm->nulls->odd_values : nul->odd_values;
@@ -2515,7 +2538,6 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     const long long g32_opt = gmg_opt(GMG_OPT_MG_GENE32);
     const bool g32 = !d_frame_scores && !err_mode && a.total && (g32_opt == 2 || (g32_opt == 1 && prm->nulls)) && nul_dense3 &&
                      gene->dev.has_fast && gene->dev.D == 7 && gene->dev.W >= 3 && gene->dev.W <= 15;
-    if (g32 && prm->nulls) fused_nw = 0;
     if (prm->nulls && !nul_dense3) return fail(gmg_set_error(GMG_EBADMODEL, "gmg_mg_score_reads: per-read null models are (3,2,3) models"));
     a.fs_stride = a.total;
     if (g32) {
@@ -2557,12 +2579,13 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         const bool small = forced_tile ? forced_tile == 512 : (reads->max_len <= 512 || (reads->uniform_len == 0 && reads->n_over_512 * 10 <= reads->n_reads));
         const uint32_t cap = fused_nw ? (uint32_t)(MT_W * fused_nw) : small ? 512 : 1504;
         a.tile_cap = (int)cap;
+        a.tile_reads_max = fused_nw && g32 && prm->nulls ? MT_NC : MG_TILE_READS;
         bool tiled = false, rest = true;
         if (reads->uniform_len > 0) {                  // every tile takes cap / L whole reads
             if ((uint32_t)reads->uniform_len <= cap) {
                 a.uniform_len = reads->uniform_len;
                 a.uniform_magic = (uint32_t)((0x100000000ull + (uint64_t)reads->uniform_len - 1) / (uint64_t)reads->uniform_len);
-                a.reads_per_tile = cap / reads->uniform_len < MG_TILE_READS ? cap / reads->uniform_len : MG_TILE_READS;
+                a.reads_per_tile = (int)(cap / reads->uniform_len) < a.tile_reads_max ? cap / reads->uniform_len : a.tile_reads_max;
                 a.n_tiles = (a.n_reads + a.reads_per_tile - 1) / a.reads_per_tile;
                 tiled = true; rest = false;
             }
@@ -2571,7 +2594,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             a.tile_window = cap - longest;
             const uint64_t n_windows = a.total / a.tile_window + 1;
             tiled = true;
-            rest = reads->max_len > longest || reads->min_len * MG_TILE_READS < a.tile_window;
+            rest = reads->max_len > longest || reads->min_len * (uint64_t)a.tile_reads_max < a.tile_window;
             if (n_windows >= 0x7fffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
             uint32_t *d_n = nullptr;
             size_t sel_bytes = 0;

@@ -43,8 +43,14 @@ for i, c in enumerate(("atg", "gtg", "ttg")):
     prm.start_codon[i].value = c.encode()
 for i, c in enumerate(("taa", "tag", "tga")):
     prm.stop_codon[i].value = c.encode()
+n_nulls = int(os.environ.get("BENCH_NULLS", "0"))      # glimmer-mg -c: a null model per read, BENCH_NULLS GC values
+if n_nulls:
+    null_set = gmg.NullSet([gmg.Icm.indep(float(gc)) for gc in np.linspace(0.3, 0.7, n_nulls)])
+    read_null = np.random.default_rng(3).integers(0, n_nulls, n_reads).astype(np.uint32)
+    prm.nulls, prm.read_null = null_set.h, read_null.ctypes.data
+    indep = null_set.icms[0]
 fs = api._DeviceBuffer(6 * reads.total_bases * 8)      # the Frame_Scores table stays on the device
-fs_ptr = None if os.environ.get("BENCH_OWN_TABLE") else fs.ptr    # (or let the call use its own, row-padded table)
+fs_ptr = None if os.environ.get("BENCH_OWN_TABLE") or n_nulls else fs.ptr    # (or let the call use its own, row-padded table)
 
 
 def run():

@@ -56,9 +56,10 @@ def test_frame6_nulls_ragged_reads_120_gcs_vs_oracle(gpu, nc, oracle):
     assert np.array_equal(same, gpu.frame_score6(nc, gpu.Icm.indep(float(gcs[57])), reads))
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("gene32", [2, 0])
 @pytest.mark.parametrize("uniform", [False, True])
-def test_mg_per_read_null_and_ignore_score_len_vs_oracle(gpu, nc, oracle, gene32, uniform):
+def test_mg_per_read_null_and_ignore_score_len_vs_oracle(gpu, nc, oracle, gene32, uniform, fused):
     """every read against its own Indep_Model and its own Ignore_Score_Len, one call: ORFs, start lists (scores bit for bit),
     best score and the accepted flag equal the oracle's, read by read"""
     rng = np.random.default_rng(5 + uniform)
@@ -70,7 +71,7 @@ def test_mg_per_read_null_and_ignore_score_len_vs_oracle(gpu, nc, oracle, gene32
     reads = gpu.Reads.from_strings(seqs)
     ns = gpu.NullSet([gpu.Icm.indep(float(gc)) for gc in gcs])
     kw = dict(min_gene_len=60)
-    with gpu.option("mg_gene32", gene32):
+    with gpu.option("mg_gene32", gene32), gpu.option("mg_fused", fused):     # (fused: the tile's reads' tables in LDS; else the sequential kernels)
         orfs, starts, first = gpu.mg_score_reads(nc, ns, reads, read_null=read_null, read_ignore_score_len=read_isl, **kw)
     o_nc = oracle.read(os.path.join(DATA, "NC_000915.icm"))
     o_nulls = [oracle.indep(float(gc)) for gc in gcs]
