@@ -268,10 +268,11 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
                         idx6 = ((idx6 << 2) | (uint32_t)bs.next()) & 63u;
                         if (i >= 2) {                   // a Codon_t with an empty position matches nothing (gene.cc:56,85)
                             const uint64_t bit = 1ull << idx6;
-                            if (counting) {             // the codon that is now k0 codons back leaves the mask (a stop codon is no start codon)
+                            if (counting) {             // the codon that is now k0 codons back leaves the mask.  (The stop codon that ends a
+                                                        // region is no start, even when the start set holds it: "-A nnn")
                                 cs[c].fwd_older += (int)((cs[c].fwd_recent >> (k0 - 1)) & 1ull);
-                                cs[c].fwd_recent = (cs[c].fwd_recent << 1) | ((a.fwd_start & bit) ? 1ull : 0ull);
-                                if ((a.rev_start & bit) && i >= cs[c].rev_from) cs[c].rev_cnt++;
+                                cs[c].fwd_recent = (cs[c].fwd_recent << 1) | ((a.fwd_start & ~a.fwd_stop & bit) ? 1ull : 0ull);
+                                if ((a.rev_start & ~a.rev_stop & bit) && i >= cs[c].rev_from) cs[c].rev_cnt++;
                             }
                             if ((a.fwd_start & bit) && cs[c].first_fwd_start == INT_MAX) cs[c].first_fwd_start = i - 1;
                             if (a.rev_start & bit) cs[c].last_rev_start = i - 1;
@@ -1259,7 +1260,8 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                     const bool st = !valid || (FWD ? si + 3 >= n : si < 3) || ((stops >> cs) & 1ull);
                     const bool geo = FWD ? si >= 2 : si + 2 <= n - 1;
                     const uint32_t wh = wht[cw];
-                    const uint32_t cand = valid && geo && wh != 0 ? 1u : 0u;
+                    // (a codon may be in the start set AND in the stop set -- "-A nnn": the stop codon that ends a region is no start)
+                    const uint32_t cand = valid && geo && wh != 0 && !((stops >> cw) & 1ull) ? 1u : 0u;
                     double T = s_val[u];
                     if (G32 && valid) {
                         // T holds the gene model's three values; the null model's: sub-model 1 at x = b, 2 at x = b -/+ 1, 0 at

@@ -316,6 +316,7 @@ def test_empty_reads_inside_a_batch_are_harmless(gpu, oracle, nc):
     ("uniform 500", dict(min_gene_len=300)),
     ("ragged 30", dict(min_gene_len=4)),
     ("codons", dict(min_gene_len=4)),
+    ("ragged 400", dict(min_gene_len=4, start_codons=("nnn",), stop_codons=("taa", "tag", "tga", "tta"))),   # start set and stop set overlap
 ])
 def test_mg_fused_kernel_equals_the_sequential_kernels(gpu, nc, shape, kw):
     """k_mg_tile_starts (running sums as a parallel scan + start lists, option mg_fused = 1, the default when the models'
