@@ -113,6 +113,8 @@ enum GmgOpt {
                                  // running sums are built: 0 never, 1 with per-read null models (default), 2 always
     GMG_OPT_MG_FUSED,            // glimmer-mg front half, default mode: 1 = running sums as a parallel scan + start lists in one kernel
                                  // when the models' values allow it (k_mg_tile_starts), 0 = always the sequential walks
+    GMG_OPT_MG_ERR_SKIP,         // glimmer-mg's error branch: 1 = scores as differences of running sums, walks visit their events only (when the
+                                 // models' values allow it), 0 = every walk adds up its own sum codon by codon
     GMG_OPT_COUNT
 };
 extern long long g_gmg_opt[GMG_OPT_COUNT];

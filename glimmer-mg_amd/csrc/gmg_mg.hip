@@ -123,7 +123,11 @@ struct MgArgs {
     uint64_t call_cap;           // entries per array
     struct MgOrfAgg *agg;        // [n_orfs] what the calls of an ORF add up to
     uint32_t *fill;              // [n_orfs] write pass: slots handed out inside the ORF's slice
-    const double *walk;          // [6][walk_stride] Frame_Scores in walking order (k_mg_walk_tables)
+    const double *walk;          // [6][walk_stride] Frame_Scores in walking order (k_mg_walk_tables), or, pfx: their running sums
+                                 // inside every read (k_mg_walk_prefix)
+    int pfx;                     // the level kernels take score[j] as a difference of two running sums and skip the codons nothing happens at
+    const uint8_t *run_q, *run_n;// [2][walk_stride] by strand and walk index: codons from here on at which nothing can happen (k_mg_run_tables),
+                                 // with / without the low-quality bases as events
     const uint8_t *walk_q;       // [total + 8] the qualities, last base first (forward walks; reverse walks read a.qual)
     uint64_t walk_stride;
 };
@@ -1793,6 +1797,123 @@ __global__ __launch_bounds__(256) void k_mg_walk_tables(MgArgs a, double *walk, 
     }
 }
 
+// The same rows as RUNNING SUMS inside every read (inclusive, in walking order): when every sum of the batch is exact in any order (see
+// k_mg_tile_starts), score[j] of a call that starts at walk index w is I[w + j] - I[w - 1] -- the reference's sequential sum, bit for
+// bit -- so a walk needs no sum of its own and may jump over the codons at which nothing happens (k_mg_run_tables).
+// One wave per (read, strand): 64 walk steps at a time, the three class rows scanned with DPP moves, carries in scalar registers.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double mg_dpp_add(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return x + __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));      // (lanes without a source add 0)
+}
+__device__ __forceinline__ double mg_wave_scan(double x)               // inclusive sum over the lanes of a wave
+{
+    x = mg_dpp_add<0x111, 0xf>(x);                      // row_shr:1
+    x = mg_dpp_add<0x112, 0xf>(x);                      // row_shr:2
+    x = mg_dpp_add<0x114, 0xf>(x);                      // row_shr:4
+    x = mg_dpp_add<0x118, 0xf>(x);                      // row_shr:8
+    x = mg_dpp_add<0x142, 0xa>(x);                      // row_bcast:15 into rows 1 and 3
+    x = mg_dpp_add<0x143, 0xc>(x);                      // row_bcast:31 into rows 2 and 3
+    return x;
+}
+__global__ __launch_bounds__(256) void k_mg_walk_prefix(MgArgs a, double *walk, uint8_t *walk_q)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t it = wave; it < 2 * a.n_reads; it += n_waves) {
+        const uint64_t r = it >> 1;
+        const bool fwd = (it & 1) == 0;
+        const uint64_t off = a.read_off[r];
+        const uint32_t n = (uint32_t)(a.read_off[r + 1] - off);
+        double carry[3] = {0.0, 0.0, 0.0};
+        for (uint32_t t0 = 0; t0 < n; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            const bool in = t < n;
+            const uint64_t g = in ? (fwd ? off + n - 1 - t : off + t) : off;      // base of walk step t
+            double v[3];
+#pragma unroll
+            for (int f = 0; f < 3; f++) v[f] = in ? a.fs[(uint64_t)((fwd ? 0 : 3) + f) * a.fs_stride + g] : 0.0;
+            const int m = (int)(g % 3);
+            const uint64_t w = fwd ? a.total - 1 - g : g;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int row = ((fwd ? c - m + 3 : m - c + 3) % 3 + 1) % 3;          // as k_mg_walk_tables
+                const double x = row == 0 ? v[0] : row == 1 ? v[1] : v[2];
+                const double sc = mg_wave_scan(x) + carry[c];
+                if (in) walk[(uint64_t)((fwd ? 0 : 3) + c) * a.walk_stride + w] = sc;
+                const unsigned long long top = (unsigned long long)__double_as_longlong(sc);
+                carry[c] = __longlong_as_double((long long)((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(top >> 32), 63) << 32 |
+                                                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)top, 63)));
+            }
+            if (walk_q && fwd && in) walk_q[w] = a.qual[g];
+        }
+    }
+}
+
+// run[strand][w] = the number of consecutive codons of a walk, from the one that starts at walk index w, at which nothing can
+// happen: no start codon, no base of low quality (run_q only), and the codon after it is there and is no stop codon -- so it is not
+// the last of its region either.  One wave per (read, strand), 64 walk steps at a time from the read's last to its first: the "nothing
+// happens" bits of a chunk as a 64-bit mask, the length of the run of set bits i, i + 3, i + 6, ... by doubling (runs of >= 2, 4, 8, 16
+// as masks), what a run that reaches the chunk's end finds behind it carried from the chunk before.
+__device__ __forceinline__ uint32_t mg_run_len(uint64_t b, uint32_t lane, const uint32_t carry[3])
+{
+    const uint64_t a2 = b & (b >> 3), a4 = a2 & (a2 >> 6), a8 = a4 & (a4 >> 12), a16 = a8 & (a8 >> 24);
+    uint32_t len = 0, pos = lane;
+    if ((a16 >> pos) & 1ull) { len += 16; pos += 48; }
+    if (pos < 64 && ((a8 >> pos) & 1ull)) { len += 8; pos += 24; }
+    if (pos < 64 && ((a4 >> pos) & 1ull)) { len += 4; pos += 12; }
+    if (pos < 64 && ((a2 >> pos) & 1ull)) { len += 2; pos += 6; }
+    if (pos < 64 && ((b >> pos) & 1ull)) { len += 1; pos += 3; }
+    if (pos >= 64) len += pos == 64 ? carry[0] : pos == 65 ? carry[1] : carry[2];
+    return len < 254u ? len : 254u;
+}
+__global__ __launch_bounds__(256) void k_mg_run_tables(MgArgs a, uint8_t *run_q, uint8_t *run_n)
+{
+    __shared__ int8_t s_which[64];
+    if (threadIdx.x < 64) s_which[threadIdx.x] = a.which[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t it = wave; it < 2 * a.n_reads; it += n_waves) {
+        const uint64_t r = it >> 1;
+        const bool fwd = (it & 1) == 0;
+        const int64_t off = (int64_t)a.read_off[r];
+        const int n = (int)((int64_t)a.read_off[r + 1] - off);
+        if (n <= 0) continue;
+        const uint64_t w_first = fwd ? a.total - 1 - (uint64_t)(off + n - 1) : (uint64_t)off;     // walk index of walk step 0
+        const uint8_t *qp = a.err_mode == 1 ? (fwd ? a.walk_q + w_first : a.qual + off) : nullptr;  // quality of walk step t: qp[t]
+        uint8_t *oq = run_q + (fwd ? 0 : a.walk_stride) + w_first, *on = run_n + (fwd ? 0 : a.walk_stride) + w_first;
+        uint32_t cq[3] = {0, 0, 0}, cn[3] = {0, 0, 0};
+        for (int t0 = (n - 1) / 64 * 64; t0 >= 0; t0 -= 64) {
+            const int t = t0 + (int)lane;
+            bool bn = false, bq = false;
+            if (t + 5 <= n - 1) {                       // (the codon after this one is there)
+                // the six bases of walk steps t .. t + 5: forward strand bases g, g-1, .., g-5, reverse strand g, g+1, .., g+5 complemented
+                const int64_t g = fwd ? off + n - 1 - t : off + t, gs = fwd ? g - 5 : g;
+                const uint32_t w0 = a.packed[gs >> 4], w1 = a.packed[(gs >> 4) + 1];
+                const uint32_t six = (uint32_t)(((uint64_t)w1 << 32 | w0) >> (2u * (unsigned)(gs & 15))) & 0xfffu;
+                const uint32_t lo6 = six & 63u, hi6 = six >> 6;
+                // codon index as the walks form it: code(step) | code(step + 1) << 2 | code(step + 2) << 4
+                const uint32_t idx = fwd ? (hi6 & 3u) << 4 | (hi6 & 12u) | hi6 >> 4 : lo6 ^ 63u;
+                const uint32_t nidx = fwd ? (lo6 & 3u) << 4 | (lo6 & 12u) | lo6 >> 4 : hi6 ^ 63u;
+                bn = s_which[idx] < 0 && !((a.fwd_stop >> nidx) & 1ull);
+                bq = bn && !(qp && (qp[t] <= a.indel_q_thr || qp[t + 1] <= a.indel_q_thr || qp[t + 2] <= a.indel_q_thr));
+            }
+            const uint64_t mn = __ballot(bn), mq = __ballot(bq);
+            const uint32_t vn = mg_run_len(mn, lane, cn), vq = mg_run_len(mq, lane, cq);
+            if (t < n) { on[t] = (uint8_t)vn; oq[t] = (uint8_t)vq; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                cn[k] = (uint32_t)__builtin_amdgcn_readlane((int)vn, k);
+                cq[k] = (uint32_t)__builtin_amdgcn_readlane((int)vq, k);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_mg_err_prepare(MgArgs a)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -1819,7 +1940,10 @@ __global__ __launch_bounds__(256) void k_mg_err_prepare(MgArgs a)
                                  // 214 ms per 1M reads instead of 190); asking for 5 / 6 / 8 waves spills inside the walk: 457 / 688 / 1202 ms
 #endif
 
-template <bool WRITE, int LEVEL>
+// PFX: a.walk holds the running sums of k_mg_walk_prefix: score[j] = I[w + j] - I[w - 1] instead of a sum of its own, and a walk
+// jumps over the codons at which nothing can happen (a.run_q / a.run_n) -- it visits its start codons, its low-quality bases and its
+// last codon only.
+template <bool WRITE, int LEVEL, bool PFX>
 __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, const int accepted_only)
 {
     __shared__ int8_t s_which[64];
@@ -1859,6 +1983,8 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
         uint32_t comp = 0;
         const double *wp = a.walk;                      // the call's stream of Frame_Scores, four doubles at a time
         const uint8_t *qp = a.qual;
+        const uint8_t *rp = a.run_n;                    // PFX: the call's stream of run lengths
+        double p0 = 0.0;                                // PFX: the running sum in front of the call's first position
         double s0 = 0.0, s1 = 0.0;                      // score[] inside the codon being walked
         uint32_t qw = 0;
         bool walking = false, finishing = false, is_last = false, trunc = false, first_done = false;
@@ -1945,8 +2071,14 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                         g = off + anchor;
                         if (anchor >= 0 && anchor < n) {
                             const uint64_t ga = (uint64_t)g;
-                            wp = a.walk + (uint64_t)((fwd ? 0 : 3) + (int)(ga % 3)) * a.walk_stride + (fwd ? a.total - 1 - ga : ga);
-                            qp = fwd ? a.walk_q + (a.total - 1 - ga) : a.qual + ga;
+                            const uint64_t w = fwd ? a.total - 1 - ga : ga;
+                            wp = a.walk + (uint64_t)((fwd ? 0 : 3) + (int)(ga % 3)) * a.walk_stride + w;
+                            qp = fwd ? a.walk_q + w : a.qual + ga;
+                            if (PFX) {
+                                const bool with_q = LEVEL < 2 && !WRITE && a.err_mode == 1 && LEVEL < a.indel_max;     // (branches can start here)
+                                rp = (with_q ? a.run_q : a.run_n) + (fwd ? 0 : a.walk_stride) + w;
+                                p0 = (fwd ? anchor == n - 1 : anchor == 0) ? 0.0 : wp[-1];         // (the sums restart with every read)
+                            }
                         }
                         is_last = false; trunc = false; first_done = false; walking = false;
                         tp = 0; br = 0; last_own = MG_NO_SLOT; cnt = 0;
@@ -1969,13 +2101,27 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
             double c_score = 0.0;
             if (walking) {
                 // one in-frame codon (three buffer positions) per trip: the lanes of a wave stay in the same phase of the codon
+                if (PFX && br == 0) {
+                    const uint32_t skip = rp[3 * tp];   // codons from this one on at which nothing happens: on to the one behind them
+                    if (skip) {
+                        tp += (int)skip;
+                        g += 3 * (int64_t)(skip - 1) * dir;
+                        fetch(tp, pidx);                // (it is there and is no stop codon: the codon before it was not the last)
+                    }
+                }
                 const int j0 = 3 * tp;
                 if (br == 0) {                          // first visit of the codon
                     is_last = fetch(tp + 1, nidx);      // is it the last of the region?
-                    const MgD3 d = *(const MgD3 *)(wp + j0);       // (the tables end in 8 spare entries)
                     if (LEVEL < 2 && !WRITE && a.err_mode == 1) qw = ((const MgU4 *)(qp + j0))->v;
-                    prev = sum;                         // score[j0 - 1]
-                    s0 = prev + d.v[0]; s1 = s0 + d.v[1]; sum = s1 + d.v[2];       // score[j0], [j0 + 1], [j0 + 2]
+                    if (PFX) {
+                        const MgD4 d = *(const MgD4 *)(wp + j0 - 1);               // (8 spare entries on both sides of the tables)
+                        prev = j0 ? d.v[0] - p0 : 0.0;  // score[j0 - 1]
+                        s0 = d.v[1] - p0; s1 = d.v[2] - p0; sum = d.v[3] - p0;     // score[j0], [j0 + 1], [j0 + 2]
+                    } else {
+                        const MgD3 d = *(const MgD3 *)(wp + j0);   // (the tables end in 8 spare entries)
+                        prev = sum;                     // score[j0 - 1]
+                        s0 = prev + d.v[0]; s1 = s0 + d.v[1]; sum = s1 + d.v[2];   // score[j0], [j0 + 1], [j0 + 2]
+                    }
                     if (j0 >= lowest_j && j0 + 3 + suffix_j >= mgl) {
                         const int k = fwd ? end_point - 2 - j0 : end_point + 2 + j0;
                         const int which = s_which[pidx];
@@ -2438,6 +2584,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     uint64_t *d_start_off = nullptr;
     double *d_cum = nullptr;
     int fused_nw = 0;                                   // waves per tile of k_mg_tile_starts, 0: the sequential kernels
+    bool err_exact = false;                             // the batch's sums are exact in any order: the error branch may take differences of running sums
+    uint8_t *d_run = nullptr;
     bool fused_rest = false;
     MgTile *d_tiles = nullptr, *d_all = nullptr;
     uint32_t *d_unfit = nullptr;
@@ -2479,6 +2627,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (d_agg) gmg_pool_release(d_agg);
         if (d_walk) gmg_pool_release(d_walk);
         if (d_walk_q) gmg_pool_release(d_walk_q);
+        if (d_run) gmg_pool_release(d_run);
         gmg_mg_result_free(res);
         return code;
     };
@@ -2526,6 +2675,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         int clog = 0;
         while ((1ull << clog) < reads->max_len + 2) clog++;
         const bool exact = !gene->odd_values && !n_odd && (mx < mn || clog + mx - mn <= 28);
+        err_exact = exact;
         const long long forced_tile = gmg_opt(GMG_OPT_MG_TILE);
         if (!err_mode && exact && gmg_opt(GMG_OPT_MG_FUSED) && a.n_reads && a.total) {
             if (forced_tile == 1 || forced_tile == 2 || forced_tile == 4) fused_nw = (int)forced_tile;
@@ -2756,20 +2906,31 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         MG_TRY(gmg_pool_alloc((void **)&d_fill, no * 4));
         a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; a.agg = d_agg; a.fill = d_fill;
         a.walk_stride = ((a.total + 15) & ~15ull) + 16;
-        MG_TRY(gmg_pool_alloc((void **)&d_walk, (size_t)6 * a.walk_stride * sizeof(double)));
+        MG_TRY(gmg_pool_alloc((void **)&d_walk, ((size_t)6 * a.walk_stride + 8) * sizeof(double)));
         if (err_mode == 1) MG_TRY(gmg_pool_alloc((void **)&d_walk_q, a.total + 8));
-        hipLaunchKernelGGL(k_mg_walk_tables, dim3(grid_for(a.total)), dim3(256), 0, s2, a, d_walk, d_walk_q);
+        a.walk_q = d_walk_q;
+        a.pfx = err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) ? 1 : 0;
+        if (a.pfx) {                                    // running sums + run lengths: the walks visit their events only
+            MG_TRY(gmg_pool_alloc((void **)&d_run, (size_t)4 * a.walk_stride));
+            hipLaunchKernelGGL(k_mg_walk_prefix, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s2, a, d_walk + 8, d_walk_q);
+            a.run_q = d_run; a.run_n = d_run + 2 * a.walk_stride;
+            hipLaunchKernelGGL(k_mg_run_tables, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s2, a, d_run, d_run + 2 * a.walk_stride);
+        } else
+            hipLaunchKernelGGL(k_mg_walk_tables, dim3(grid_for(a.total)), dim3(256), 0, s2, a, d_walk + 8, d_walk_q);
         MG_TRY(hipGetLastError());
-        a.walk = d_walk; a.walk_q = d_walk_q;
+        a.walk = d_walk + 8;                            // (8 spare entries in front: a call at the table's first entry looks one back)
         tm.lap("walk-order tables");
     }
     for (int attempt = 0; attempt < 3; attempt++) {
     const dim3 lvl_grid(256 * 16);
     if (no && err_mode && err_path == 0) {
         hipLaunchKernelGGL(k_mg_err_prepare, dim3(grid_for(no > nr ? no : nr)), dim3(256), 0, s2, a);
-        hipLaunchKernelGGL((k_mg_err_level<false, 0>), dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only);
-        hipLaunchKernelGGL((k_mg_err_level<false, 1>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
-        hipLaunchKernelGGL((k_mg_err_level<false, 2>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
+        if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<false, 0, true>), dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only);
+        else hipLaunchKernelGGL((k_mg_err_level<false, 0, false>), dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only);
+        if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<false, 1, true>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
+        else hipLaunchKernelGGL((k_mg_err_level<false, 1, false>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
+        if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<false, 2, true>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
+        else hipLaunchKernelGGL((k_mg_err_level<false, 2, false>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
         hipLaunchKernelGGL(k_mg_err_verdict, dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only);
         if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 1);
     } else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 0);
@@ -2822,9 +2983,12 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     }
     if (no && err_mode && err_path == 0) {
         hipLaunchKernelGGL(k_mg_err_begin, dim3(grid_for(no)), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((k_mg_err_level<true, 0>), dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
-        hipLaunchKernelGGL((k_mg_err_level<true, 1>), lvl_grid, dim3(256), 0, s, a, err_acc_only);
-        hipLaunchKernelGGL((k_mg_err_level<true, 2>), lvl_grid, dim3(256), 0, s, a, err_acc_only);
+        if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<true, 0, true>), dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
+        else hipLaunchKernelGGL((k_mg_err_level<true, 0, false>), dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
+        if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<true, 1, true>), lvl_grid, dim3(256), 0, s, a, err_acc_only);
+        else hipLaunchKernelGGL((k_mg_err_level<true, 1, false>), lvl_grid, dim3(256), 0, s, a, err_acc_only);
+        if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<true, 2, true>), lvl_grid, dim3(256), 0, s, a, err_acc_only);
+        else hipLaunchKernelGGL((k_mg_err_level<true, 2, false>), lvl_grid, dim3(256), 0, s, a, err_acc_only);
         if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 1);
     } else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 0);
     else if (no && fused_nw) {
@@ -2987,6 +3151,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (d_agg) gmg_pool_release(d_agg);
     if (d_walk) gmg_pool_release(d_walk);
     if (d_walk_q) gmg_pool_release(d_walk_q);
+    if (d_run) gmg_pool_release(d_run);
     tm.lap("free scratch");
     *out = res;
     return GMG_OK;
