@@ -1985,6 +1985,7 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
         const uint8_t *qp = a.qual;
         const uint8_t *rp = a.run_n;                    // PFX: the call's stream of run lengths
         double p0 = 0.0;                                // PFX: the running sum in front of the call's first position
+        uint32_t nskip = 0;                             // PFX: the run length at the codon the next trip starts with
         double s0 = 0.0, s1 = 0.0;                      // score[] inside the codon being walked
         uint32_t qw = 0;
         bool walking = false, finishing = false, is_last = false, trunc = false, first_done = false;
@@ -2084,6 +2085,7 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                         tp = 0; br = 0; last_own = MG_NO_SLOT; cnt = 0;
                         sum = 0.0; prev = 0.0; best = -DBL_MAX;
                         if (anchor >= 0 && anchor < n) walking = !fetch(0, pidx);
+                        if (PFX && walking) nskip = rp[0];
                         finishing = true;               // the end-of-call work is still to do
                     }
                 }
@@ -2102,7 +2104,7 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
             if (walking) {
                 // one in-frame codon (three buffer positions) per trip: the lanes of a wave stay in the same phase of the codon
                 if (PFX && br == 0) {
-                    const uint32_t skip = rp[3 * tp];   // codons from this one on at which nothing happens: on to the one behind them
+                    const uint32_t skip = nskip;        // codons from this one on at which nothing happens: on to the one behind them
                     if (skip) {
                         tp += (int)skip;
                         g += 3 * (int64_t)(skip - 1) * dir;
@@ -2167,6 +2169,7 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                     if (is_last) walking = false;
                     else pidx = nidx;
                     tp++;
+                    if (PFX && !is_last) nskip = rp[3 * tp];        // (requested a trip ahead of its use)
                 }
             } else if (finishing && do_fin) {
                 finishing = false;
