@@ -2103,23 +2103,34 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
             double c_score = 0.0;
             if (walking) {
                 // one in-frame codon (three buffer positions) per trip: the lanes of a wave stay in the same phase of the codon
-                if (PFX && br == 0) {
-                    const uint32_t skip = nskip;        // codons from this one on at which nothing happens: on to the one behind them
-                    if (skip) {
-                        tp += (int)skip;
-                        g += 3 * (int64_t)(skip - 1) * dir;
-                        fetch(tp, pidx);                // (it is there and is no stop codon: the codon before it was not the last)
-                    }
-                }
+                if (PFX && br == 0) tp += (int)nskip;  // codons from the one due on at which nothing happens: on to the one behind them
                 const int j0 = 3 * tp;
                 if (br == 0) {                          // first visit of the codon
-                    is_last = fetch(tp + 1, nidx);      // is it the last of the region?
-                    if (LEVEL < 2 && !WRITE && a.err_mode == 1) qw = ((const MgU4 *)(qp + j0))->v;
                     if (PFX) {
+                        // the codon the trip works on (it is there and is no stop codon: the codon before it was not the last) and the one
+                        // behind it: everything the trip reads is requested before any of it is used -- ONE memory latency per trip behind
+                        // the run length, which was requested a trip ago
+                        const int64_t ga_ = g + (3 * (int64_t)nskip - 3) * dir, gb_ = ga_ + 3 * dir;
+                        const uint32_t wa0 = a.packed[ga_ >> 4], wa1 = a.packed[(ga_ + 2 * dir) >> 4];
+                        const uint32_t wb0 = a.packed[gb_ >> 4], wb1 = a.packed[(gb_ + 2 * dir) >> 4];      // (guard words around the batch)
                         const MgD4 d = *(const MgD4 *)(wp + j0 - 1);               // (8 spare entries on both sides of the tables)
+                        if (LEVEL < 2 && !WRITE && a.err_mode == 1) qw = ((const MgU4 *)(qp + j0))->v;
+                        auto codon = [&](int64_t gx, uint32_t w0, uint32_t w1) __attribute__((always_inline)) {
+                            const int64_t g1 = gx + dir, g2 = gx + 2 * dir;
+                            const uint32_t c0 = ((w0 >> (2u * (unsigned)(gx & 15))) & 3u) ^ comp;
+                            const uint32_t c1 = ((((g1 >> 4) == (gx >> 4) ? w0 : w1) >> (2u * (unsigned)(g1 & 15))) & 3u) ^ comp;
+                            const uint32_t c2 = ((w1 >> (2u * (unsigned)(g2 & 15))) & 3u) ^ comp;
+                            return c2 << 4 | c1 << 2 | c0;
+                        };
+                        pidx = codon(ga_, wa0, wa1);
+                        if (avail - 3 * (tp + 1) < 3) { trunc = a.allow_truncated != 0; is_last = true; }
+                        else { nidx = codon(gb_, wb0, wb1); is_last = (a.fwd_stop >> nidx) & 1; }
+                        g = gb_ + 3 * dir;
                         prev = j0 ? d.v[0] - p0 : 0.0;  // score[j0 - 1]
                         s0 = d.v[1] - p0; s1 = d.v[2] - p0; sum = d.v[3] - p0;     // score[j0], [j0 + 1], [j0 + 2]
                     } else {
+                        is_last = fetch(tp + 1, nidx);  // is it the last of the region?
+                        if (LEVEL < 2 && !WRITE && a.err_mode == 1) qw = ((const MgU4 *)(qp + j0))->v;
                         const MgD3 d = *(const MgD3 *)(wp + j0);   // (the tables end in 8 spare entries)
                         prev = sum;                     // score[j0 - 1]
                         s0 = prev + d.v[0]; s1 = s0 + d.v[1]; sum = s1 + d.v[2];   // score[j0], [j0 + 1], [j0 + 2]
