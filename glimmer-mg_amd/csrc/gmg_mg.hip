@@ -1073,11 +1073,12 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
         const uint64_t left = a.total - w0;             // bases from the tile's first to the table's end (>= span)
         const uint32_t hi_lim = left + 1 < 0x7fffffffull ? (uint32_t)left + 1 : 0x7fffffffu;       // offset + 2 of the table's last entry
         const uint32_t d2 = fwd ? 1u : 3u, d0 = fwd ? 0u : 4u;                 // b -/+ 1 and b -/+ 2, + 2
-        if (lo_lim == 0 && hi_lim >= span + 3) {        // (every tile but the batch's first and last)
+        if (lo_lim == 0 && hi_lim >= (uint32_t)(MT_EL * BLOCK) + 3u) {         // (every tile but the batch's first and last few)
+            // no test against the span: a lane beyond it reads the next tile's entries (they are on their way anyway) and nobody uses them
 #pragma unroll
             for (int i = 0; i < MT_EL; i++) {
                 const uint32_t b = tid + (uint32_t)BLOCK * i;
-                if (b < span) { tmp[1][i] = p1[b]; tmp[2][i] = p2[b + d2]; tmp[0][i] = p0[b + d0]; }      // (what a lane beyond the span holds is not used)
+                tmp[1][i] = p1[b]; tmp[2][i] = p2[b + d2]; tmp[0][i] = p0[b + d0];
             }
         } else {
 #pragma unroll
@@ -1140,8 +1141,11 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
 #pragma unroll
             for (int i = 0; i < MT_EL; i++) {
                 const uint32_t b = tid + (uint32_t)BLOCK * i;
-                if (b < span) s_val[fwd ? span - 1 - b : b] = ((double)tmp[1][i] + (double)tmp[2][i]) + (double)tmp[0][i];
-                if (b < CAP) s_oinfo[b] = 0;
+                // (beyond the span T goes to its own padding slot: no branch)
+                if (i < MT_EL - 1 || b < CAP) {
+                    s_val[b < span ? (fwd ? span - 1 - b : b) : b] = ((double)tmp[1][i] + (double)tmp[2][i]) + (double)tmp[0][i];
+                    s_oinfo[b] = 0;
+                }
             }
 #pragma unroll
             for (int u = 0; u < PW; u++) {
