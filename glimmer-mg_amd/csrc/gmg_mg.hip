@@ -2691,7 +2691,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         const int n_odd = prm->nulls ? prm->nulls->odd_values : nul->odd_values;
         const int mn = gene->min_exp < n_min ? gene->min_exp : n_min, mx = gene->max_exp > n_max ? gene->max_exp : n_max;
         int clog = 0;
-        while ((1ull << clog) < reads->max_len + 2) clog++;
+        const uint64_t longest_read = reads->max_len ? reads->max_len : reads->total_bases;   // (no lengths on the host: the batch's size is a bound)
+        while ((1ull << clog) < longest_read + 2) clog++;
         const bool exact = !gene->odd_values && !n_odd && (mx < mn || clog + mx - mn <= 28);
         err_exact = exact;
         const long long forced_tile = gmg_opt(GMG_OPT_MG_TILE);
