@@ -355,3 +355,49 @@ def test_mg_fused_kernel_equals_the_sequential_kernels(gpu, nc, shape, kw):
             for c in want[0].dtype.names:
                 assert np.array_equal(got[0][c], want[0][c]), (shape, tile, g32, c)
             assert got[1].tobytes() == want[1].tobytes(), (shape, tile, g32)
+
+
+@pytest.mark.parametrize("doctor", ["tiny", "zero"])
+def test_mg_models_whose_sums_could_round_take_the_sequential_kernels(gpu, oracle, tmp_path, doctor):
+    """the fused kernel and the event-only walks of the error branch change the ORDER of the additions, which is harmless only
+    while every sum is exact; a gene model with a value of 3e-33 (exponent spread beyond the bound) or the logarithm of a zero
+    probability (-FLT_MAX, icm.cc:1345-1349) must run the reference's order -- either way the starts are the oracle's, bit for bit"""
+    src = os.path.join(DATA, "NC_000915.icm")
+    raw = bytearray(open(src, "rb").read())
+    _, prob = oracle.tables(oracle.read(src))
+    at = bytes(raw).find(prob[0, 0].astype("<f4").tobytes())             # the root of sub-model 0: its four values
+    assert at > 0
+    vals = prob[0, 0].astype("<f4").copy()
+    vals[1] = np.float32(-3.0e-33) if doctor == "tiny" else np.float32(-3.4028234663852886e38)
+    raw[at:at + 16] = vals.tobytes()
+    path = tmp_path / (doctor + ".icm")
+    path.write_bytes(bytes(raw))
+    rng = np.random.default_rng(9)
+    seqs = random_reads(rng, list(rng.integers(30, 700, size=120)) + [500] * 30)
+    reads = gpu.Reads.from_strings(seqs)
+    gene, o_gene = gpu.Icm.open(str(path)), oracle.read(str(path))
+    indep, o_indep = gpu.Icm.indep(0.5), oracle.indep(0.5)
+    kw = dict(min_gene_len=30)
+    orfs, starts, off = gpu.mg_score_reads(gene, indep, reads, **kw)
+    prm = oracle.mg_params(**kw)
+    n_starts = 0
+    for r, seq in enumerate(seqs):
+        _, scored = oracle.mg_read(o_gene, o_indep, seq.encode(), prm)
+        mine = orfs[int(off[r]):int(off[r + 1])]
+        for o, (out, want) in zip(mine, scored):
+            st = starts[o["start_begin"]:o["start_begin"] + o["n_starts"]]
+            assert [(s["j"], s["pos"], s["which"], s["score"]) for s in st] == [(w.j, w.pos, w.which, w.score) for w in want], (doctor, r)
+            assert o["best_score"] == out.best_score
+            n_starts += len(want)
+    assert n_starts > 100
+    # the error branch on the same model: every start list against the oracle's recursion
+    e_orfs, e_starts, e_off, e_errs = gpu.mg_score_reads(gene, indep, reads, allow_indels=True, **kw)
+    ep = oracle.mg_err_params(allow_indels=True)
+    from test_gpu_mg_err import dev_err_rows, err_rows
+    for r in range(0, len(seqs), 5):
+        _, _, scored = oracle.mg_read_errors(o_gene, o_indep, seqs[r].encode(), prm, ep)
+        mine = e_orfs[int(e_off[r]):int(e_off[r + 1])]
+        assert len(mine) == len(scored)
+        for o, (out, want) in zip(mine, scored):
+            sl = slice(o["start_begin"], o["start_begin"] + o["n_starts"])
+            assert dev_err_rows(e_starts[sl], e_errs[sl]) == err_rows(want), (doctor, "-i", r)
