@@ -115,6 +115,8 @@ enum GmgOpt {
                                  // when the models' values allow it (k_mg_tile_starts), 0 = always the sequential walks
     GMG_OPT_MG_ERR_SKIP,         // glimmer-mg's error branch: 1 = scores as differences of running sums, walks visit their events only (when the
                                  // models' values allow it), 0 = every walk adds up its own sum codon by codon
+    GMG_OPT_MG_ORFS_EVENTS,      // glimmer-mg front half, default mode: 1 = the ORF scan's write pass queues the codons that are in a start or
+                                 // stop set and runs the reference's steps over the queue (k_mg_find_orfs_ev), 0 = at every position
     GMG_OPT_COUNT
 };
 extern long long g_gmg_opt[GMG_OPT_COUNT];

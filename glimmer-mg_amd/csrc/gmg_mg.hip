@@ -320,6 +320,172 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_mg_find_orfs_ev: the write pass of Find_Orfs in two phases per 64 positions.  In k_mg_find_orfs a wave pays at every position
+// for the stop-codon code of whichever lane met one (88 vector instructions per position and wave; one codon in five is a start or
+// a stop codon of either strand).  Here phase A only LOOKS -- four set bits per codon from a 64-entry table, the codons that
+// have any queued in LDS (one column per lane) -- and phase B runs the reference's per-codon steps over the queue, every lane busy
+// with an event of its own.  The class of an event is data there: its state is picked from the three classes' registers and put back.
+// The start count of k_mg_find_orfs (count_starts) catches up with the codons between two events of a class in one step.
+// Same records, same order; default mode only (mg_run), the count pass stays k_mg_find_orfs<false>.
+// ---------------------------------------------------------------------------------------------------
+#define MG_EV_CH 64
+__global__ __launch_bounds__(128) void k_mg_find_orfs_ev(MgArgs a)
+{
+    __shared__ uint16_t s_q[MG_EV_CH][128];             // events of the chunk: position in the chunk | set bits << 8
+    __shared__ uint8_t s_evt[64];                       // by codon index: bit 0 forward start, 1 reverse start, 2 forward stop, 3 reverse stop
+    if (threadIdx.x < 64) {
+        const uint64_t bit = 1ull << threadIdx.x;
+        s_evt[threadIdx.x] = (uint8_t)(((a.fwd_start & bit) ? 1 : 0) | ((a.rev_start & bit) ? 2 : 0) | ((a.fwd_stop & bit) ? 4 : 0) | ((a.rev_stop & bit) ? 8 : 0));
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x;
+    const int mgl = a.min_gene_len;
+    const bool trunc = a.allow_truncated != 0;
+    const bool counting = a.count_starts != 0;
+    int j_lo = mgl - 3 > 1 ? mgl - 3 : 1;
+    j_lo = (j_lo + 2) / 3 * 3;
+    const int k0 = 1 + j_lo / 3;                        // (<= 64: mg_run)
+    const unsigned long long k0_mask = k0 >= 64 ? ~0ull : (1ull << k0) - 1ull;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t off = a.read_off[r];
+        const int n = (int)(a.read_off[r + 1] - off);
+        uint32_t cnt = 0;
+        const uint64_t orf0 = a.read_orf_off[r];
+        gmg_mg_orf *out = a.orfs + orf0;
+        if (n < mgl) continue;                          // glimmer_base.cc:676-677
+
+        auto emit = [&](int stop_position, int frame, int gene_len, int orf_len, int lo, int hi, int n_real) __attribute__((always_inline)) {
+            if (gene_len >= mgl) {                      // glimmer_base.cc:494,528,806 (default mode)
+                gmg_mg_orf o;
+                o.read = (uint32_t)r; o.frame = frame; o.stop_position = stop_position;
+                o.orf_len = orf_len; o.gene_len = gene_len; o.lo = lo; o.hi = hi;
+                o.first_j = 0; o.start_begin = 0; o.n_starts = 0; o.accepted = 0; o.orf_is_truncated = 0;
+                o.reserved = 0; o.best_score = -DBL_MAX;
+                out[cnt] = o;
+                if (counting) {
+                    const int m = hi - lo;
+                    const bool tr = trunc && (frame > 0 ? lo < 3 : n - (hi - 1) < 3);
+                    const int jmax = m >= 1 ? (m - 1) / 3 * 3 : -1;
+                    a.orf_cnt[orf0 + cnt] = (uint32_t)((m > 0 ? n_real : 0) + (tr && jmax >= j_lo ? 1 : 0));
+                }
+                cnt++;
+            }
+        };
+        auto fwd_stop = [&](int i, MgClass &S, int cls) __attribute__((always_inline)) {
+            int gene_len, orf_len;
+            if (S.prev_fwd_stop == 0) {
+                const int pos = i - 1;
+                orf_len = pos - 1;
+                orf_len -= orf_len % 3;
+                gene_len = S.first_fwd_start == INT_MAX ? 0 : pos - S.first_fwd_start;
+                if (trunc && gene_len < mgl) gene_len = orf_len;
+            } else {
+                gene_len = (i - S.first_fwd_start) - 1;
+                orf_len = i - S.prev_fwd_stop - 4;
+            }
+            emit(i - 1, 1 + (cls + 1) % 3, gene_len, orf_len, S.fwd_last + 1, i - 2, S.fwd_older);
+            S.first_fwd_start = INT_MAX;
+            S.prev_fwd_stop = i - 1;
+            S.fwd_older = 0;
+            S.fwd_recent = 0;
+        };
+        auto rev_stop = [&](int i, MgClass &S, int cls) __attribute__((always_inline)) {
+            int gene_len, orf_stop = 0;
+            if (S.prev_rev_stop == 0) {
+                if (!trunc) gene_len = 0;
+                else {
+                    orf_stop = (i - 1) % 3;
+                    if (orf_stop > 0) orf_stop -= 3;
+                    gene_len = S.last_rev_start - orf_stop;
+                }
+            } else {
+                orf_stop = S.prev_rev_stop;
+                gene_len = S.last_rev_start - orf_stop;
+            }
+            emit(orf_stop, -1 - (cls + 1) % 3, gene_len, i - orf_stop - 4, orf_stop + 3, i - 1, S.rev_cnt);
+            S.last_rev_start = 0;
+            S.prev_rev_stop = i - 1;
+            S.rev_cnt = 0;
+            S.rev_from = (i - 1) + 4 + j_lo;
+        };
+        // the forward start count of class S catches up to position i (the codons of the class since its last event hold no start)
+        auto advance = [&](MgClass &S, int &last_i, int i, unsigned long long flag) __attribute__((always_inline)) {
+            const int shift = (i - last_i) / 3;
+            if (shift >= k0) { S.fwd_older += __popcll(S.fwd_recent); S.fwd_recent = 0; }
+            else { S.fwd_older += __popcll(S.fwd_recent >> (k0 - shift)); S.fwd_recent = (S.fwd_recent << shift) & k0_mask; }
+            S.fwd_recent |= flag;
+            last_i = i;
+        };
+
+        MgClass cs[3];
+        int last_i[3] = {0, 1, -1};                     // one codon in front of the class's first (positions 3, 4, 2)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            cs[c].first_fwd_start = INT_MAX;
+            cs[c].last_rev_start = cs[c].prev_fwd_stop = cs[c].prev_rev_stop = 0;
+            cs[c].fwd_recent = 0;
+            cs[c].fwd_older = cs[c].rev_cnt = 0;
+            cs[c].rev_from = (c == 0 ? -1 : c == 1 ? 0 : -2) + 4 + j_lo;
+        }
+        cs[0].fwd_last = 0; cs[1].fwd_last = 1; cs[2].fwd_last = -1;
+        BaseStream<1> bs;
+        bs.init(a.packed, off);
+        uint32_t idx6 = 0;
+        for (int chunk0 = 0; chunk0 < n; chunk0 += MG_EV_CH) {
+            // ---- phase A: look
+            const int kn = n - chunk0 < MG_EV_CH ? n - chunk0 : MG_EV_CH;
+            uint32_t nq = 0;
+            for (int k = 0; k < kn; k++) {
+                idx6 = ((idx6 << 2) | (uint32_t)bs.next()) & 63u;
+                const uint32_t bits = s_evt[idx6];
+                s_q[nq][lane] = (uint16_t)((uint32_t)k | bits << 8);       // (overwritten by the next codon when this one has none)
+                nq += bits != 0 && chunk0 + k >= 2 ? 1u : 0u;                 // a Codon_t with an empty position matches nothing (gene.cc:56,85)
+            }
+            // ---- phase B: the reference's steps at the queued codons
+            for (uint32_t e = 0; e < nq; e++) {
+                const uint32_t ev = s_q[e][lane];
+                const int i = chunk0 + (int)(ev & 255u);
+                const uint32_t bits = ev >> 8;
+                const int c = (int)((uint32_t)i % 3u);
+                MgClass S = c == 0 ? cs[0] : c == 1 ? cs[1] : cs[2];
+                int li = c == 0 ? last_i[0] : c == 1 ? last_i[1] : last_i[2];
+                if (counting) {                         // (the stop codon that ends a region is no start, even when the start set holds it)
+                    advance(S, li, i, (bits & 5u) == 1u ? 1ull : 0ull);
+                    if ((bits & 10u) == 2u && i >= S.rev_from) S.rev_cnt++;
+                }
+                if ((bits & 1u) && S.first_fwd_start == INT_MAX) S.first_fwd_start = i - 1;
+                if (bits & 2u) S.last_rev_start = i - 1;
+                if (bits & 4u) { fwd_stop(i, S, c); S.fwd_last = i; }
+                if (bits & 8u) rev_stop(i, S, c);
+                if (c == 0) { cs[0] = S; last_i[0] = li; } else if (c == 1) { cs[1] = S; last_i[1] = li; } else { cs[2] = S; last_i[2] = li; }
+            }
+        }
+        // Finish_Orfs (glimmer_base.cc:783-817) + Handle_Last_Reverse_Stop, linear (:1053-1066)
+#pragma unroll
+        for (int fr = 0; fr < 3; fr++) {
+            const MgClass &S = cs[fr];
+            const int orf_stop = S.prev_rev_stop == 0 ? (fr == 0 ? -1 : fr == 1 ? 0 : -2) : S.prev_rev_stop;
+            int orf_len = n - orf_stop - 2;
+            orf_len -= orf_len % 3;
+            int gene_len = S.last_rev_start == 0 ? 0 : S.last_rev_start - orf_stop;
+            if (trunc && gene_len < mgl) gene_len = orf_len;
+            const int e = orf_stop + 2;
+            int hi;
+            if (e >= n) hi = e + 1;
+            else { const int rc = (n - 1 - e) % 3; hi = (rc == 0 ? n - 1 : rc == 1 ? n - 2 : n) + 1; }
+            emit(orf_stop, -1 - (fr + 1) % 3, gene_len, orf_len, orf_stop + 3, hi, S.rev_cnt);
+        }
+        if (trunc)                                      // glimmer_base.cc:765-776: 3 bp past the end count as stops
+            for (int i = n; i < n + 3; i++) {
+                const int c = i % 3;
+                if (c == 0) { if (counting) advance(cs[0], last_i[0], i, 0ull); fwd_stop(i, cs[0], 0); }
+                else if (c == 1) { if (counting) advance(cs[1], last_i[1], i, 0ull); fwd_stop(i, cs[1], 1); }
+                else { if (counting) advance(cs[2], last_i[2], i, 0ull); fwd_stop(i, cs[2], 2); }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // GENE32: the null model's part of Frame_Scores[(fwd ? 0 : 3) + f][si] of a read of n bases (glimmer-mg.cc:1485-1509):
 // the (3,2,3) model's Frame_Score on the reversed read (fwd) or on the complemented read, at forward coordinate si.
 //   fwd: buffer position j = n-1-si, window B[j-2..j] = S[si+2], S[si+1], S[si]
@@ -2887,7 +3053,10 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             a.orf_cnt = d_orf_cnt;
         }
     }
-    if (nr) hipLaunchKernelGGL(k_mg_find_orfs<true>, dim3(grid_for(nr)), dim3(256), 0, s2, a);
+    if (nr && !err_mode && gmg_opt(GMG_OPT_MG_ORFS_EVENTS)) {
+        const uint64_t blocks = (nr + 127) / 128;
+        hipLaunchKernelGGL(k_mg_find_orfs_ev, dim3((unsigned)(blocks < 256 * 64 ? blocks : 256 * 64)), dim3(128), 0, s2, a);
+    } else if (nr) hipLaunchKernelGGL(k_mg_find_orfs<true>, dim3(grid_for(nr)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
     tm.lap("find orfs");
     if (err_mode == 1 && a.total && !find_only) {       // Set_Quality_454 / Clean_Quality_454: needs the reads only

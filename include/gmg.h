@@ -84,7 +84,7 @@ const char *gmg_version(void);
 int gmg_synchronize(void *stream);
 /* Tuning and test switches (nothing a caller needs for correct results): `key` is one of seg_plain, mg_tile, mg_one_stream,
  * mg_err_flat, mg_err_calls, mg_err_calls_grow, orfs_exact_path, train_sort_min, mg_max_entries, mg_timing, ingest_timing,
- * train_timing, strings_fused, mg_gene32, mg_fused, mg_err_skip, diag.  gmg_init() reads GMG_<KEY IN UPPER CASE> from the
+ * train_timing, strings_fused, mg_gene32, mg_fused, mg_err_skip, mg_orfs_events, diag.  gmg_init() reads GMG_<KEY IN UPPER CASE> from the
  * environment ONCE; no scoring call reads the environment. */
 int gmg_set_option(const char *key, long long value);
 int gmg_get_option(const char *key, long long *value);

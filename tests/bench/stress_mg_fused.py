@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Differential stress run of k_mg_tile_starts (glimmer-mg's front half, default mode: running sums as a parallel scan fused with
-the start lists) against the sequential kernels (mg_fused = 0: the reference's order of additions): random batch shapes, codon
+the start lists; the ORF scan's write pass over queued events) against the round-1 kernels (mg_fused = 0, mg_orfs_events = 0: the
+reference's order of additions, every position visited): random batch shapes, codon
 sets, Min_Gene_Len, truncation, Ignore_Score_Len, thresholds, one null model or one per read, both table forms, every tile size.
 Every byte of the ORF records and start lists must agree.  usage: stress_mg_fused.py [configurations] [seed]"""
 import os
@@ -56,7 +57,7 @@ for cfg in range(n_cfg):
             kw["read_ignore_score_len"] = rng.choice([2 ** 31 - 1, 60, 200], reads.n_reads).astype(np.int32)
     else:
         nul = gmg.Icm.indep(float(rng.uniform(0.3, 0.7)), kw["stop_codons"]) if len(kw["stop_codons"][0]) == 3 else nulls[5]
-    with gmg.option("mg_fused", 0), gmg.option("mg_gene32", int(rng.integers(0, 3))):
+    with gmg.option("mg_fused", 0), gmg.option("mg_orfs_events", 0), gmg.option("mg_gene32", int(rng.integers(0, 3))):
         want = gmg.mg_score_reads(gene, nul, reads, **kw)
     for tile in (0, 1, 2, 4):
         for g32 in (1, 0, 2):
