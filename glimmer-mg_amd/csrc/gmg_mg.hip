@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
 // have any queued in LDS (one column per lane) -- and phase B runs the reference's per-codon steps over the queue, every lane busy
 // with an event of its own.  The class of an event is data there: its state is picked from the three classes' registers and put back.
 // The start count of k_mg_find_orfs (count_starts) catches up with the codons between two events of a class in one step.
-// Same records, same order; default mode only (mg_run), the count pass stays k_mg_find_orfs<false>.
+// Same records, same order; the count pass stays k_mg_find_orfs<false> (30 registers: it runs beside the six-frame kernel).
 // ---------------------------------------------------------------------------------------------------
 #define MG_EV_CH 64
 __global__ __launch_bounds__(128) void k_mg_find_orfs_ev(MgArgs a)
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(128) void k_mg_find_orfs_ev(MgArgs a)
         if (n < mgl) continue;                          // glimmer_base.cc:676-677
 
         auto emit = [&](int stop_position, int frame, int gene_len, int orf_len, int lo, int hi, int n_real) __attribute__((always_inline)) {
-            if (gene_len >= mgl) {                      // glimmer_base.cc:494,528,806 (default mode)
+            if (gene_len >= mgl || (a.err_mode && orf_len >= a.min_indel_orf_len)) {   // glimmer_base.cc:494,528,806
                 gmg_mg_orf o;
                 o.read = (uint32_t)r; o.frame = frame; o.stop_position = stop_position;
                 o.orf_len = orf_len; o.gene_len = gene_len; o.lo = lo; o.hi = hi;
@@ -3053,7 +3053,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             a.orf_cnt = d_orf_cnt;
         }
     }
-    if (nr && !err_mode && gmg_opt(GMG_OPT_MG_ORFS_EVENTS)) {
+    if (nr && gmg_opt(GMG_OPT_MG_ORFS_EVENTS)) {
         const uint64_t blocks = (nr + 127) / 128;
         hipLaunchKernelGGL(k_mg_find_orfs_ev, dim3((unsigned)(blocks < 256 * 64 ? blocks : 256 * 64)), dim3(128), 0, s2, a);
     } else if (nr) hipLaunchKernelGGL(k_mg_find_orfs<true>, dim3(grid_for(nr)), dim3(256), 0, s2, a);
