@@ -87,8 +87,8 @@ __device__ __forceinline__ double f6_row_sum(double x)
     x = f6_dpp_add<0x140>(x);                           // row_mirror
     return x;
 }
-__device__ __noinline__ void f6_sum_chunk(double *sum, const int32_t *roff, uint32_t len, uint32_t len_magic, uint32_t rem0, int32_t wm1,
-                                          uint32_t span0, uint32_t &rel_a, double f0, double r0, double f1, double r1)
+__device__ __noinline__ void f6_sum_chunk_slow(double *sum, const int32_t *roff, uint32_t len, uint32_t len_magic, uint32_t rem0, int32_t wm1,
+                                               uint32_t span0, uint32_t &rel_a, double f0, double r0, double f1, double r1)
 {
     const uint32_t lane = threadIdx.x & 63u;
     int32_t a0, a1, a2, a3;
@@ -131,6 +131,24 @@ __device__ __noinline__ void f6_sum_chunk(double *sum, const int32_t *roff, uint
         unsafeAtomicAdd(&sum[2 * rel_a], fa); unsafeAtomicAdd(&sum[2 * rel_a + 1], ra_);
         unsafeAtomicAdd(&sum[2 * rel_a + 2], fb); unsafeAtomicAdd(&sum[2 * rel_a + 3], rb);
     }
+}
+
+// Reads of one length: the common case -- the wave's 128 bases inside one read, away from its first / last W-1 -- stays in line
+// (a wave-uniform test and two row sums); everything else goes through the call.
+__device__ __forceinline__ void f6_sum_chunk(double *sum, const int32_t *roff, uint32_t len, uint32_t len_magic, uint32_t rem0, int32_t wm1,
+                                             uint32_t span0, uint32_t &rel_a, double f0, double r0, double f1, double r1)
+{
+    if (len) {
+        const uint32_t ra = __umulhi(span0 + rem0, len_magic);
+        const int32_t a0 = (int32_t)(ra * len) - (int32_t)rem0, a1 = a0 + (int32_t)len;
+        if ((int32_t)span0 >= a0 + wm1 && (int32_t)span0 + 128 <= a1 - wm1) {
+            rel_a = ra;
+            const double f = f6_row_sum(f0 + f1), r = f6_row_sum(r0 + r1);
+            if ((threadIdx.x & 15u) == 15u) { unsafeAtomicAdd(&sum[2 * ra], f); unsafeAtomicAdd(&sum[2 * ra + 1], r); }
+            return;
+        }
+    }
+    f6_sum_chunk_slow(sum, roff, len, len_magic, rem0, wm1, span0, rel_a, f0, r0, f1, r1);
 }
 
 // One descent in the completed tree of depth DT: C holds the window, tab the shift table in LDS.
