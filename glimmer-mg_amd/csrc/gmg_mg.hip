@@ -1,18 +1,18 @@
 // gmg_mg.hip -- glimmer-mg's front half on gfx950: from packed reads to the start lists that
 // Score_Orfs_Errors (src/Glimmer/glimmer-mg.cc:1605-1689) hands to Add_Events_*.  Linear sequences, no ignore
-// regions.  Steps 3 and 4 below are the default mode (Allow_Indels = Allow_Subs = false, glimmer-mg.cc:100-102);
-// with -i / -s they are replaced by the error branch further down (k_mg_err_*: Score_Indels and the recursive
-// Score_Orf_Starts, one lane per call, level by level).
+// regions.  Step 3 below is the default mode (Allow_Indels = Allow_Subs = false, glimmer-mg.cc:100-102);
+// with -i / -s it is replaced by the error branch further down (k_mg_err_*: Score_Indels and the recursive
+// Score_Orf_Starts, one lane per call, level by level; scores as differences of running sums when those are exact).
 //
 //   1. gmg_launch_frame6        Score_All_Frames (glimmer-mg.cc:1468-1510): Frame_Scores[6][total] in HBM
-//   2. k_mg_find_orfs<count>    Find_Orfs (glimmer_base.cc:638-779), one lane per read: ORFs per read
-//      exclusive scan, k_mg_find_orfs<write>: the Orf_t records + lo / hi of Score_Orf_Starts
-//   3. k_mg_cum                 Cumulative_Frame_Score (glimmer-mg.cc:561-604) for EVERY possible ORF at once:
-//      one lane per (read, strand) walks the read once with three running sums (one per reading-frame
-//      class), each reset at the in-class stop codons, and stores the sum at every in-frame position.
-//   4. k_mg_starts<count>       one lane per ORF: number of entries Score_Orf_Starts will push
-//      exclusive scan, k_mg_starts<write>: the start list in push order (scores = one read of the running
-//      sums per start codon), boost, first_j, best score, threshold.
+//   2. k_mg_find_orfs<count>    Find_Orfs (glimmer_base.cc:638-779), one lane per read: ORFs per read (beside step 1 on a second stream)
+//      exclusive scan, k_mg_find_orfs_ev: the Orf_t records + lo / hi of Score_Orf_Starts + the number of starts each will push
+//   3. k_mg_tile_starts         Cumulative_Frame_Score (glimmer-mg.cc:561-604) for EVERY possible ORF as three segmented parallel
+//      scans per tile and strand, and Score_Orf_Starts on top of them: the start lists in push order (scores = the scan's value at
+//      every start codon), boost, first_j, best score, threshold.  Needs sums that are exact in any order (checked per batch from
+//      the models' exponent range); otherwise, and as the cross-check of the tests, the round-1 kernels:
+//      k_mg_cum_tiled / k_mg_cum   one lane per stop-to-stop region (per (read, strand)): sequential sums, reset at the in-class stops
+//      k_mg_starts<count / write>  one lane per ORF: its starts from the stored sums
 // Integer / byte work except the one running sum; no table of Save_Prev_Stops (glimmer-mg.cc:675-729) is
 // materialised -- the ORF scan already knows the previous / next in-frame stop of every ORF it emits:
 //   forward ORF ended by the stop whose last base is i (class c = i % 3):
