@@ -1450,20 +1450,18 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                         if (FWD ? si + 2 >= n : si < 2) {                          // one of them is a partial window
                             nsum = 0.0;
 #pragma unroll
-                            for (int t = 0; t < 3; t++) {
+                            for (int t = 0; t < 3; t++) {                          // (no branches in here: selects)
                                 const int fr = t == 0 ? 1 : t == 1 ? 2 : 0;
                                 const int xs = FWD ? si - t : si + t;              // the term's base in its read
                                 const int j = FWD ? n - 1 - xs : xs;
-                                if (xs < 0 || xs >= n) continue;                   // (beyond the read: T is never used then)
                                 const int bx = bitb + (FWD ? -2 * t : 2 * t);      // bit position of S[x]
                                 const uint32_t c0 = (uint32_t)(win >> bx) & 3u;
                                 const uint32_t c1 = (uint32_t)(win >> (FWD ? bx + 2 : bx - 2)) & 3u;
                                 const uint32_t b0c = FWD ? c0 : c0 ^ 3u, b1c = FWD ? c1 : c1 ^ 3u;
-                                float nv;
                                 const uint32_t v = (uint32_t)(win >> (FWD ? bx : bx - 4)) & 63u;
-                                if (j >= 2) nv = nullv(fr * 64 + v, v);
-                                else nv = nullv(192u + fr * 20 + (j == 1 ? 4u + (b1c | b0c << 2) : b0c), 0);
-                                nsum += (double)nv;
+                                const uint32_t off = j >= 2 ? fr * 64 + v : 192u + fr * 20 + (j == 1 ? 4u + (b1c | b0c << 2) : b0c);
+                                const float nv = nullv(off, v);
+                                nsum += xs >= 0 && xs < n ? (double)nv : 0.0;      // (beyond the read: T is never used then)
                             }
                         } else {
                             const uint32_t v1 = (uint32_t)(win >> (FWD ? bitb : bitb - 4)) & 63u, v2 = (uint32_t)(win >> (bitb - 2)) & 63u;
