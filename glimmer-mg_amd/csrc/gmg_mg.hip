@@ -1124,7 +1124,8 @@ __device__ __forceinline__ void mt_scan_step(double &s, uint32_t &p)
     p = blk ? p : ps + p;
 }
 
-struct MtTile { uint64_t w0; uint32_t first, nfit, span, o0, o1; };     // reads [first, first + nfit), bases [w0, w0 + span), ORFs [o0, o1)
+struct MtTile { uint64_t w0; uint32_t first, nfit, span, o0, o1, rn0; };    // reads [first, first + nfit), bases [w0, w0 + span), ORFs [o0, o1);
+                                                                             // rn0: the null model of the tile's first read (GENE32, one per read)
 
 // G32: the table is the GENE32 form (fp32 rows of the gene model's values alone, a.gene32): half the bytes to read.  T is formed
 // from the widened floats, and stage 1, which has the bases of every position in a register anyway, subtracts the three null-model
@@ -1192,7 +1193,7 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
     uint32_t vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     auto meta_a = [&](uint64_t k, MtTile &t) __attribute__((always_inline)) {
-        t.nfit = 0; t.span = 0; t.first = 0; t.w0 = 0; t.o0 = 0; t.o1 = 0;
+        t.nfit = 0; t.span = 0; t.first = 0; t.w0 = 0; t.o0 = 0; t.o1 = 0; t.rn0 = 0;
         if (k >= 2 * n_tiles) return;
         if (a.tiles) {                                  // ragged batch: precomputed, non-empty
             const MgTile *e = a.tiles + (k >> 1) + vzero;
@@ -1210,12 +1211,15 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
         const uint32_t *roo = (const uint32_t *)(a.read_orf_off + vzero);      // (low words: a batch has less than 2^31 ORFs)
         t.o0 = roo[2 * (uint64_t)t.first];
         t.o1 = roo[2 * ((uint64_t)t.first + t.nfit)];
+        if (G32 && a.read_null) t.rn0 = (a.read_null + vzero)[t.first];
     };
     // every global load of a tile is issued one tile ahead
     typename std::conditional<G32, float, double>::type tmp[3][MT_EL];
     // (no arithmetic on a loaded value in there: it would wait for every load issued before it)
     // (and no load wider than what is used: a register half nobody reads is handed out again, and the write to it waits for the load)
     uint32_t tpk[PW], tro[PR], trn[PR];
+    constexpr int PN1 = (MG_NULL_FLOATS + BLOCK - 1) / BLOCK;
+    float tn1[G32 ? PN1 : 1];                           // GENE32, a null model per read: the table of the tile's first read, in the strand's order
     int32_t tis[PR];
     uint32_t po_read = 0, po_s0 = 0, po_s1 = 0;         // the lane's first ORF of the tile: read, frame / lo / hi, slice of the start array (low words)
     int32_t po_frame = 0, po_lo = 0, po_hi = 0;
@@ -1272,6 +1276,14 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
             tis[u] = a.read_isl && i < nfit ? (a.read_isl + first)[i] : a.ignore_score_len;
             trn[u] = G32 && a.read_null && i < nfit ? (a.read_null + first)[i] : 0u;
         }
+        if (G32 && a.read_null) {                       // (its index came with the tile's geometry: no wait here)
+            const float *nt = a.null_tab + (size_t)__builtin_amdgcn_readfirstlane(t.rn0) * MG_NULL_FLOATS;
+#pragma unroll
+            for (int u = 0; u < PN1; u++) {
+                const uint32_t e = tid + (uint32_t)BLOCK * u;
+                tn1[u] = nt[null_src(e < MG_NULL_FLOATS ? e : 0u, fwd)];
+            }
+        }
         if (tid < n_orf) {
             const gmg_mg_orf *o = a.orfs + o0 + tid;
             po_read = o->read; po_frame = o->frame; po_lo = o->lo; po_hi = o->hi;
@@ -1325,6 +1337,13 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                 if (i < nfit) s_isl[i] = tis[u];
                 if (G32 && i < nfit) s_rnull[i] = trn[u];
             }
+            if (G32 && a.read_null) {
+#pragma unroll
+                for (int u = 0; u < PN1; u++) {
+                    const uint32_t e = tid + (uint32_t)BLOCK * u;
+                    if (e < MG_NULL_FLOATS) s_nullm[0][e] = tn1[u];
+                }
+            }
             if (tid == 0) s_nq = 0;
         }
         // the lane's first ORF of this tile stays in registers through the stages; the loads of the next tile overwrite po_*
@@ -1377,7 +1396,7 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
             }
             if (G32 && a.read_null) {
                 const uint32_t nc = nfit < MT_NC ? nfit : MT_NC;
-                for (uint32_t i = tid; i < nc * MG_NULL_FLOATS; i += BLOCK) {
+                for (uint32_t i = MG_NULL_FLOATS + tid; i < nc * MG_NULL_FLOATS; i += BLOCK) {       // (the first read's came with the tile)
                     const uint32_t rl = i / MG_NULL_FLOATS, e = i - rl * MG_NULL_FLOATS;
                     s_nullm[rl][e] = a.null_tab[(size_t)s_rnull[rl] * MG_NULL_FLOATS + null_src(e, fwd)];
                 }
