@@ -1103,7 +1103,7 @@ extern "C" int gmg_debug_mt_stamps(unsigned long long *out, int reset)
 #ifndef MT_MIN_WAVES
 #define MT_MIN_WAVES 1           // waves per SIMD the register allocation aims at
 #endif
-#define MT_EL 9                  // chain elements per lane
+#define MT_EL 9                  // chain elements per lane (the kernel's EL: 9, or 8 when 504 bases per wave hold the batch's reads as well)
 #define MT_CL 21                 // lanes per class
 #define MT_W (3 * MT_CL * MT_EL) // bases per wave: 567
 #define MT_ORFS 64               // ORFs per pass of stages 3 and 4
@@ -1131,10 +1131,12 @@ struct MtTile { uint64_t w0; uint32_t first, nfit, span, o0, o1, rn0; };    // r
 // from the widened floats, and stage 1, which has the bases of every position in a register anyway, subtracts the three null-model
 // values of T from a 3 x 64 table in LDS (one null model for the batch).  A buffer's first two positions take the partial-window
 // tables (icm.cc:807-842): the last two bases of a read on the forward strand, its first two on the reverse strand.
-template <int NW, bool G32>
-__global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs a)
+// EL: elements per lane: 9 (567 bases per wave), or 8 (504) when that holds the batch's reads -- 500-bp reads: a ninth less of every loop
+// (nine elements: three waves per SIMD asked for -- 168 registers, three of them spilled, against 173 and two waves)
+template <int NW, bool G32, int EL>
+__global__ __launch_bounds__(64 * NW, EL == 9 ? 3 : MT_MIN_WAVES) void k_mg_tile_starts(MgArgs a)
 {
-    constexpr int BLOCK = 64 * NW, CAP = MT_W * NW;
+    constexpr int BLOCK = 64 * NW, WV = 3 * MT_CL * EL, CAP = WV * NW;
     constexpr int NPK = CAP / 16 + 7;                                   // packed words staged (two in front, the windows of stage 2 behind)
     constexpr int PW = (NPK + BLOCK - 1) / BLOCK, PR = (MG_TILE_READS + 1 + BLOCK - 1) / BLOCK;
     __shared__ __attribute__((aligned(16))) double s_val[CAP];          // T in walk order, then the running sums
@@ -1214,7 +1216,7 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
         if (G32 && a.read_null) t.rn0 = (a.read_null + vzero)[t.first];
     };
     // every global load of a tile is issued one tile ahead
-    typename std::conditional<G32, float, double>::type tmp[3][MT_EL];
+    typename std::conditional<G32, float, double>::type tmp[3][EL];
     // (no arithmetic on a loaded value in there: it would wait for every load issued before it)
     // (and no load wider than what is used: a register half nobody reads is handed out again, and the write to it waits for the load)
     uint32_t tpk[PW], tro[PR], trn[PR];
@@ -1243,16 +1245,16 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
         const uint64_t left = a.total - w0;             // bases from the tile's first to the table's end (>= span)
         const uint32_t hi_lim = left + 1 < 0x7fffffffull ? (uint32_t)left + 1 : 0x7fffffffu;       // offset + 2 of the table's last entry
         const uint32_t d2 = fwd ? 1u : 3u, d0 = fwd ? 0u : 4u;                 // b -/+ 1 and b -/+ 2, + 2
-        if (lo_lim == 0 && hi_lim >= (uint32_t)(MT_EL * BLOCK) + 3u) {         // (every tile but the batch's first and last few)
+        if (lo_lim == 0 && hi_lim >= (uint32_t)(EL * BLOCK) + 3u) {         // (every tile but the batch's first and last few)
             // no test against the span: a lane beyond it reads the next tile's entries (they are on their way anyway) and nobody uses them
 #pragma unroll
-            for (int i = 0; i < MT_EL; i++) {
+            for (int i = 0; i < EL; i++) {
                 const uint32_t b = tid + (uint32_t)BLOCK * i;
                 tmp[1][i] = p1[b]; tmp[2][i] = p2[b + d2]; tmp[0][i] = p0[b + d0];
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < MT_EL; i++) {
+            for (int i = 0; i < EL; i++) {
                 const uint32_t b = tid + (uint32_t)BLOCK * i;
                 if (b < span) {
                     uint32_t x2 = b + d2, x0 = b + d0;
@@ -1317,10 +1319,10 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
             uint32_t tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
 #pragma unroll
-            for (int i = 0; i < MT_EL; i++) {
+            for (int i = 0; i < EL; i++) {
                 const uint32_t b = tid + (uint32_t)BLOCK * i;
                 // (beyond the span T goes to its own padding slot: no branch)
-                if (i < MT_EL - 1 || b < CAP) {
+                if (i < EL - 1 || b < CAP) {
                     s_val[b < span ? (fwd ? span - 1 - b : b) : b] = ((double)tmp[1][i] + (double)tmp[2][i]) + (double)tmp[0][i];
                     s_oinfo[b] = 0;
                 }
@@ -1404,14 +1406,14 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
         }
         if (G32) __syncthreads();
         MT_STAMP(2);                                    // stage 1
-        // ---- stage 2: the scan.  Lane (class c, part jl) owns elements u = ub + 3 i, i < MT_EL: every third base of 27
+        // ---- stage 2: the scan.  Lane (class c, part jl) owns elements u = ub + 3 i, i < EL: every third base of 27
         // consecutive ones.  The ten codons of its class that surround them come out of ONE 64-bit window of the packed bases as
         // 6-bit fields C[k] = S[x] | S[x+1] << 2 | S[x+2] << 4, x = sb + 3 k; the stop-codon sets and the start-codon table are
         // indexed that way (MgArgs::*_nat, s_whf / s_whr).
         //   reverse strand (u = b):         element i is base sb + 3 + 3 i; a segment starts behind the stop codon C[i]
         //                                   (bases b-3 .. b-1), the start codon at it is C[i+1] (bases b .. b+2)
-        //   forward strand (u = span-1-b):  element i is base sb + 26 - 3 i; a segment starts below the stop codon C[9-i]
-        //                                   (bases b+1 .. b+3), the start codon at it is C[8-i] (bases b-2 .. b)
+        //   forward strand (u = span-1-b):  element i is base sb + FW0 - 3 i (FW0 = 3 (EL-1) + 2); a segment starts below the stop
+        //                                   codon C[EL-i] (bases b+1 .. b+3), the start codon at it is C[EL-1-i] (bases b-2 .. b)
         if (nfit) {
             uint32_t tid2 = threadIdx.x;
             asm volatile("" : "+v"(tid2));
@@ -1419,16 +1421,17 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
             const uint32_t c = l >= 2 * MT_CL ? 2u : l >= MT_CL ? 1u : 0u;
             const bool idle = l == 63;
             const uint32_t jl = idle ? MT_CL - 1 : l - MT_CL * c;          // (the idle lane repeats its neighbour's work and drops it)
-            const uint32_t ub = MT_W * wv + 3 * MT_EL * jl + c;
-            double es[MT_EL];
-            uint32_t ep[MT_EL];                         // scan word | start codon here << 26 | (which + 1) << 27
+            const uint32_t ub = WV * wv + 3 * EL * jl + c;
+            double es[EL];
+            uint32_t ep[EL];                         // scan word | start codon here << 26 | (which + 1) << 27
             double acc = 0.0;
             uint32_t p = 0;
             auto local = [&](auto FWD_) __attribute__((always_inline)) {
                 constexpr bool FWD = decltype(FWD_)::value;
                 const int b0 = FWD ? (int)span - 1 - (int)ub : (int)ub;            // base of element 0 (beyond the tile's reads: padding)
-                int sb = FWD ? b0 - 26 : b0 - 3;
-                if (sb < -26) sb = -26;                                            // (a lane of padding only: any window will do)
+                constexpr int FW0 = 3 * (EL - 1) + 2;                             // forward strand: element 0 sits FW0 bases behind the window's first
+                int sb = FWD ? b0 - FW0 : b0 - 3;
+                if (sb < -FW0) sb = -FW0;                                            // (a lane of padding only: any window will do)
                 const uint32_t X = 2u * (uint32_t)(32 + (int)(w0_lo & 15u) + sb);  // two words in front of the tile's first
                 const uint32_t *pw = s_packed + (X >> 5);
                 const uint32_t q0 = pw[0], q1 = pw[1], q2 = pw[2];
@@ -1439,7 +1442,7 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                 const uint64_t stops = FWD ? a.fwd_stop_nat : a.rev_stop_nat;
                 const uint8_t *wht = FWD ? s_whf : s_whr;
 #pragma unroll
-                for (int i = 0; i < MT_EL; i++) {
+                for (int i = 0; i < EL; i++) {
                     const uint32_t u = ub + 3 * i;
                     const int b = FWD ? b0 - 3 * i : b0 + 3 * i;
                     const bool valid = (uint32_t)b < span;
@@ -1448,8 +1451,8 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                         else while (b >= rs + n) { rl++; rs = (int)s_roff[rl]; n = (int)s_roff[rl + 1] - rs; }
                     }
                     const int si = b - rs;
-                    const uint32_t cs = (uint32_t)(win >> (6 * (FWD ? 9 - i : i))) & 63u;
-                    const uint32_t cw = (uint32_t)(win >> (6 * (FWD ? 8 - i : i + 1))) & 63u;
+                    const uint32_t cs = (uint32_t)(win >> (6 * (FWD ? EL - i : i))) & 63u;
+                    const uint32_t cw = (uint32_t)(win >> (6 * (FWD ? EL - 1 - i : i + 1))) & 63u;
                     const bool st = !valid || (FWD ? si + 3 >= n : si < 3) || ((stops >> cs) & 1ull);
                     const bool geo = FWD ? si >= 2 : si + 2 <= n - 1;
                     const uint32_t wh = wht[cw];
@@ -1459,7 +1462,7 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                     if (G32 && valid) {
                         // T holds the gene model's three values; the null model's: sub-model 1 at x = b, 2 at x = b -/+ 1, 0 at
                         // x = b -/+ 2 (forward / reverse), buffer position j = n-1-x / x
-                        const int bitb = FWD ? 52 - 6 * i : 6 * i + 6;             // bit position of S[b] in the window
+                        const int bitb = FWD ? 2 * FW0 - 6 * i : 6 * i + 6;             // bit position of S[b] in the window
                         // entry `off` of the read's table in this strand's order
                         auto nullv = [&](uint32_t off, uint32_t) __attribute__((always_inline)) {
                             if (!a.read_null) return s_null1[FWD ? 0 : 1][off];
@@ -1539,7 +1542,7 @@ __global__ __launch_bounds__(64 * NW, MT_MIN_WAVES) void k_mg_tile_starts(MgArgs
                 }
             }
 #pragma unroll
-            for (int i = 0; i < MT_EL; i++) {
+            for (int i = 0; i < EL; i++) {
                 const uint32_t u = ub + 3 * i;
                 const bool own = (ep[i] & MT_REAL) != 0;                   // the segment starts inside this lane's elements
                 const double cum = own ? es[i] : xs + es[i];
@@ -2784,7 +2787,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     uint32_t *d_read_cnt = nullptr, *d_orf_cnt = nullptr;
     uint64_t *d_start_off = nullptr;
     double *d_cum = nullptr;
-    int fused_nw = 0;                                   // waves per tile of k_mg_tile_starts, 0: the sequential kernels
+    int fused_nw = 0, fused_el = 9;                     // waves per tile of k_mg_tile_starts (0: the sequential kernels), elements per lane
     bool err_exact = false;                             // the batch's sums are exact in any order: the error branch may take differences of running sums
     uint8_t *d_run = nullptr;
     bool fused_rest = false;
@@ -2884,6 +2887,11 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             else if (reads->uniform_len > 0) fused_nw = reads->uniform_len <= MT_W ? 1 : reads->uniform_len <= 2 * MT_W ? 2 : reads->uniform_len <= 4 * MT_W ? 4 : 0;
             else fused_nw = (reads->max_len <= MT_W || reads->n_over_512 * 10 <= reads->n_reads) ? 1 : reads->max_len <= 2 * MT_W ? 2 : 4;
             if (reads->uniform_len > (int)(MT_W * fused_nw)) fused_nw = 0;
+            // eight elements per lane (504 bases per wave) when the reads of a uniform batch fill such tiles as well as the larger ones
+            if (fused_nw && reads->uniform_len > 0) {
+                const int l = reads->uniform_len, c8 = 504 * fused_nw, c9 = (int)MT_W * fused_nw;
+                if (l <= c8 && (c8 / l) * 9 >= (c9 / l) * 8) fused_el = 8;
+            }
         }
     }
     // (the fused kernel reads whichever table there is.  Measured, 1M x 500 bp, one null model: the fp64 table 4.9 + 6.2 ms, the
@@ -2931,7 +2939,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         const long long forced_tile = gmg_opt(GMG_OPT_MG_TILE);
         // (ragged batches: the few reads beyond 512 bases go to the per-lane kernel; measured 9.6 vs 10.6 ms on 1M x ~400 bp)
         const bool small = forced_tile ? forced_tile == 512 : (reads->max_len <= 512 || (reads->uniform_len == 0 && reads->n_over_512 * 10 <= reads->n_reads));
-        const uint32_t cap = fused_nw ? (uint32_t)(MT_W * fused_nw) : small ? 512 : 1504;
+        const uint32_t cap = fused_nw ? (uint32_t)(3 * MT_CL * fused_el * fused_nw) : small ? 512 : 1504;
         a.tile_cap = (int)cap;
         a.tile_reads_max = fused_nw && g32 && prm->nulls ? MT_NC : MG_TILE_READS;
         bool tiled = false, rest = true;
@@ -3207,15 +3215,15 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             hipLaunchKernelGGL(k_mg_starts_unfit, dim3(grid_for(a.n_reads / 16 + 1)), dim3(256), 0, s2, a);
             MG_TRY(hipEventRecord(side_done, s2));
         }
+#define MG_LAUNCH_TILE(NW_, G_, EL_) hipLaunchKernelGGL((k_mg_tile_starts<NW_, G_, EL_>), dim3(grid), dim3(64 * NW_), 0, s, a)
+#define MG_LAUNCH_TILE_EL(NW_, G_) do { if (fused_el == 8) MG_LAUNCH_TILE(NW_, G_, 8); else MG_LAUNCH_TILE(NW_, G_, 9); } while (0)
         if (a.gene32) {
-            if (fused_nw == 1) hipLaunchKernelGGL((k_mg_tile_starts<1, true>), dim3(grid), dim3(64), 0, s, a);
-            else if (fused_nw == 2) hipLaunchKernelGGL((k_mg_tile_starts<2, true>), dim3(grid), dim3(128), 0, s, a);
-            else hipLaunchKernelGGL((k_mg_tile_starts<4, true>), dim3(grid), dim3(256), 0, s, a);
+            if (fused_nw == 1) MG_LAUNCH_TILE_EL(1, true); else if (fused_nw == 2) MG_LAUNCH_TILE_EL(2, true); else MG_LAUNCH_TILE_EL(4, true);
         } else {
-            if (fused_nw == 1) hipLaunchKernelGGL((k_mg_tile_starts<1, false>), dim3(grid), dim3(64), 0, s, a);
-            else if (fused_nw == 2) hipLaunchKernelGGL((k_mg_tile_starts<2, false>), dim3(grid), dim3(128), 0, s, a);
-            else hipLaunchKernelGGL((k_mg_tile_starts<4, false>), dim3(grid), dim3(256), 0, s, a);
+            if (fused_nw == 1) MG_LAUNCH_TILE_EL(1, false); else if (fused_nw == 2) MG_LAUNCH_TILE_EL(2, false); else MG_LAUNCH_TILE_EL(4, false);
         }
+#undef MG_LAUNCH_TILE_EL
+#undef MG_LAUNCH_TILE
         if (unfit_aside) MG_TRY(hipStreamWaitEvent(s, side_done, 0));
         else if (fused_rest) hipLaunchKernelGGL(k_mg_starts_unfit, dim3(grid_for(a.n_reads / 16 + 1)), dim3(256), 0, s, a);
     } else if (no) hipLaunchKernelGGL(k_mg_starts<true>, dim3(grid_for(no)), dim3(256), 0, s, a);
