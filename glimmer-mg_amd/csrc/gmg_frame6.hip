@@ -135,9 +135,48 @@ __device__ __noinline__ void f6_sum_chunk_slow(double *sum, const int32_t *roff,
 
 // Reads of one length: the common case -- the wave's 128 bases inside one read, away from its first / last W-1 -- stays in line
 // (a wave-uniform test and two row sums); everything else goes through the call.
+#ifndef GMG_F6_SUM_UNI
+#define GMG_F6_SUM_UNI 1
+#endif
+// inclusive sums over the lanes 0 .. i of a row of 16
+__device__ __forceinline__ double f6_row_scan(double x)
+{
+    x = f6_dpp_add<0x111>(x);                           // row_shr:1 (lanes without a source add 0)
+    x = f6_dpp_add<0x112>(x);
+    x = f6_dpp_add<0x114>(x);
+    x = f6_dpp_add<0x118>(x);
+    return x;
+}
 __device__ __forceinline__ void f6_sum_chunk(double *sum, const int32_t *roff, uint32_t len, uint32_t len_magic, uint32_t rem0, int32_t wm1,
                                              uint32_t span0, uint32_t &rel_a, double f0, double r0, double f1, double r1)
 {
+    if (GMG_F6_SUM_UNI && len >= 192) {
+        // Reads of one length, long enough that a wave's 128 bases touch two of them at most: ONE path for every span, no call.
+        // The values that do not count (a string's first W-1 positions) become 0, a row's lanes take running sums, and the row's
+        // last lane adds the row's sum to the read of its last base; in the one row that holds the end of read A and the start of
+        // read B the lane with A's last base moves A's share over: + share to A, - share to B (sums of at most 32 values: exact
+        // under the caller's condition on the model's exponents, whatever the reads' totals come to).
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t ra = __umulhi(span0 + rem0, len_magic);
+        rel_a = ra;
+        const int32_t a1 = (int32_t)((ra + 1) * len) - (int32_t)rem0;          // first base of read B = A + 1
+        const int32_t d0 = (int32_t)(span0 + 2 * lane) - a1, d1 = d0 + 1;      // < 0: read A
+        const int32_t e0 = d0 < 0 ? d0 + (int32_t)len : d0, e1 = d1 < 0 ? d1 + (int32_t)len : d1;     // position in its read
+        const int32_t hi = (int32_t)len - 1 - wm1;
+        const double vf1 = e1 >= wm1 ? f1 : 0.0, vr1 = e1 <= hi ? r1 : 0.0;
+        const double xf = (e0 >= wm1 ? f0 : 0.0) + vf1, xr = (e0 <= hi ? r0 : 0.0) + vr1;
+        const double sf = f6_row_scan(xf), sr = f6_row_scan(xr);
+        if ((lane & 15u) == 15u) {
+            const uint32_t t = ra + (d1 >= 0 ? 1u : 0u);
+            unsafeAtomicAdd(&sum[2 * t], sf); unsafeAtomicAdd(&sum[2 * t + 1], sr);
+        }
+        if (d0 < 0 && d1 >= -1 && d1 + 2 * (15 - (int32_t)(lane & 15u)) >= 0) {  // A's last base here, and bases of B further on in the row
+            const double af = sf - (d1 >= 0 ? vf1 : 0.0), ar = sr - (d1 >= 0 ? vr1 : 0.0);
+            unsafeAtomicAdd(&sum[2 * ra], af); unsafeAtomicAdd(&sum[2 * ra + 1], ar);
+            unsafeAtomicAdd(&sum[2 * ra + 2], -af); unsafeAtomicAdd(&sum[2 * ra + 3], -ar);
+        }
+        return;
+    }
     if (len) {
         const uint32_t ra = __umulhi(span0 + rem0, len_magic);
         const int32_t a0 = (int32_t)(ra * len) - (int32_t)rem0, a1 = a0 + (int32_t)len;

@@ -101,6 +101,29 @@ def test_fused_sums_equal_the_two_pass_sums_and_the_oracle_on_ragged_long_reads(
             assert fused[k, r, 1] == oracle.score_string(m, revcomp(seqs[r]), 0), (name, r)
 
 
+def test_fused_sums_of_uniform_batches_equal_the_two_pass_sums_for_every_read(gpu, oracle):
+    """batches of ONE read length (the kernel then finds the reads by arithmetic; from 192 bases on every 128-base span takes the
+    single path with row scans and the share of the read that ends inside a row moved over): lengths around that switch, the span,
+    the chunk and the round sizes, every read against the two-pass form, some against the oracle"""
+    rng = np.random.default_rng(78)
+    names = ["cluster-1.icm", "cluster-4.icm"]
+    models = [gpu.Icm.open(os.path.join(DATA, n)) for n in names]
+    om = oracle.read(os.path.join(DATA, names[0]))
+    for L in (86, 127, 128, 129, 191, 192, 193, 199, 200, 255, 256, 257, 333, 500, 501, 1000, 1023, 1024, 1025, 2047, 2048, 2049, 4099):
+        n = max(70, 140_000 // L)
+        codes = rng.integers(0, 4, size=(n, L))
+        seqs = ["".join("acgt"[c] for c in row) for row in codes]
+        reads = gpu.Reads.from_strings(seqs)
+        with gpu.option("strings_fused", 1):
+            fused = gpu.score_reads_strings(models, reads)
+        with gpu.option("strings_fused", 0):
+            two_pass = gpu.score_reads_strings(models, reads)
+        assert fused.tobytes() == two_pass.tobytes(), L
+        for r in (0, 1, n // 2, n - 1):
+            assert fused[0, r, 0] == oracle.score_string(om, seqs[r], 0), (L, r)
+            assert fused[0, r, 1] == oracle.score_string(om, revcomp(seqs[r]), 0), (L, r)
+
+
 def test_fused_form_refuses_models_whose_values_could_make_the_order_matter(gpu, oracle, tmp_path):
     """a model with a probability so close to 1 that its logarithm is tiny (and one with a zero probability: -FLT_MAX):
     the first takes the two-pass form from the start, reads that meet the second are recomputed in string order --
