@@ -1708,7 +1708,7 @@ struct MgErrRun {                // what one ORF's walk accumulates
 };
 
 // Set_Quality_454 (glimmer-mg.cc:1865-1906) / Clean_Quality_454 (:519-546): one lane per base
-__global__ __launch_bounds__(256) void k_mg_quality(MgArgs a, const uint8_t *user, uint8_t *out)
+__global__ __launch_bounds__(256) void k_mg_quality(MgArgs a, const uint8_t *user, uint8_t *out, uint8_t *walk_q)
 {
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = mg_lower_bound(a, g + 1) - 1;                 // the read that holds base g
@@ -1728,6 +1728,7 @@ __global__ __launch_bounds__(256) void k_mg_quality(MgArgs a, const uint8_t *use
             q = run < 6 ? 31 - 5 * run : 6;
         }
         out[g] = (uint8_t)(q > 255 ? 255 : q);
+        if (walk_q) walk_q[a.total - 1 - g] = (uint8_t)(q > 255 ? 255 : q);     // last base first: what a forward walk reads
     }
 }
 
@@ -1968,7 +1969,7 @@ __global__ __launch_bounds__(MG_ERR_BLOCK) void k_mg_err_flat(MgArgs a, const in
 //   forward:  walk[c][total-1-g]  = Frame_Scores[((c - g) mod 3 + 1) % 3][g]        (the walk runs down the read: reversed)
 //   reverse:  walk[3+c][g]        = Frame_Scores[3 + ((g - c) mod 3 + 1) % 3][g]
 // so a lane streams the 24 bytes of a codon from one address.
-__global__ __launch_bounds__(256) void k_mg_walk_tables(MgArgs a, double *walk, uint8_t *walk_q)
+__global__ __launch_bounds__(256) void k_mg_walk_tables(MgArgs a, double *walk)
 {
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (uint64_t)gridDim.x * blockDim.x) {
         double v[6];
@@ -1983,7 +1984,6 @@ __global__ __launch_bounds__(256) void k_mg_walk_tables(MgArgs a, double *walk, 
             walk[(uint64_t)c * a.walk_stride + rg] = rf == 0 ? v[0] : rf == 1 ? v[1] : v[2];
             walk[(uint64_t)(3 + c) * a.walk_stride + g] = rr == 0 ? v[3] : rr == 1 ? v[4] : v[5];
         }
-        if (walk_q) walk_q[rg] = a.qual[g];
     }
 }
 
@@ -2009,7 +2009,7 @@ __device__ __forceinline__ double mg_wave_scan(double x)               // inclus
     x = mg_dpp_add<0x143, 0xc>(x);                      // row_bcast:31 into rows 2 and 3
     return x;
 }
-__global__ __launch_bounds__(256) void k_mg_walk_prefix(MgArgs a, double *walk, uint8_t *walk_q)
+__global__ __launch_bounds__(256) void k_mg_walk_prefix(MgArgs a, double *walk)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -2038,7 +2038,6 @@ __global__ __launch_bounds__(256) void k_mg_walk_prefix(MgArgs a, double *walk, 
                 carry[c] = __longlong_as_double((long long)((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(top >> 32), 63) << 32 |
                                                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)top, 63)));
             }
-            if (walk_q && fwd && in) walk_q[w] = a.qual[g];
         }
     }
 }
@@ -3086,9 +3085,31 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     tm.lap("find orfs");
     if (err_mode == 1 && a.total && !find_only) {       // Set_Quality_454 / Clean_Quality_454: needs the reads only
         if (prm->quality) MG_TRY(hipMemcpyAsync(d_user_q, prm->quality, a.total, hipMemcpyHostToDevice, s2));
-        hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(a.total)), dim3(256), 0, s2, a, d_user_q, d_qual);
+        MG_TRY(gmg_pool_alloc((void **)&d_walk_q, a.total + 8));
+        hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(a.total)), dim3(256), 0, s2, a, d_user_q, d_qual, d_walk_q);
         MG_TRY(hipGetLastError());
+        a.walk_q = d_walk_q;
         tm.lap("quality values");
+    }
+    // error branch, level by level: 0 (k_mg_err_level; the default), 1 = one lane per ORF with an explicit stack
+    // (k_mg_err_flat: exact slots; the fallback of 0, and on its own with GMG_MG_ERR_FLAT=1 for A/B runs and cross-checks)
+    int err_path = gmg_opt(GMG_OPT_MG_ERR_FLAT) ? 1 : 0;
+    if (!find_only && res->n_orfs && err_mode && err_path == 0) {
+        // the walk-order tables: the rows (running sums) need the six-frame table and go behind it on the caller's stream; the run
+        // lengths need the reads and the qualities only and stay on the second stream, beside the six-frame kernel and the rows
+        a.walk_stride = ((a.total + 15) & ~15ull) + 16;
+        MG_TRY(gmg_pool_alloc((void **)&d_walk, ((size_t)6 * a.walk_stride + 8) * sizeof(double)));
+        a.pfx = err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) ? 1 : 0;
+        if (a.pfx) {                                    // running sums + run lengths: the walks visit their events only
+            MG_TRY(gmg_pool_alloc((void **)&d_run, (size_t)4 * a.walk_stride));
+            hipLaunchKernelGGL(k_mg_walk_prefix, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s, a, d_walk + 8);
+            a.run_q = d_run; a.run_n = d_run + 2 * a.walk_stride;
+            hipLaunchKernelGGL(k_mg_run_tables, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s2, a, d_run, d_run + 2 * a.walk_stride);
+        } else
+            hipLaunchKernelGGL(k_mg_walk_tables, dim3(grid_for(a.total)), dim3(256), 0, s, a, d_walk + 8);
+        MG_TRY(hipGetLastError());
+        a.walk = d_walk + 8;                            // (8 spare entries in front: a call at the table's first entry looks one back)
+        tm.lap("walk-order tables");
     }
     if (err_mode && s2 != s) {                          // the error branch needs the six-frame table from here on: one stream again
         MG_TRY(hipEventRecord(side_done, s2));
@@ -3099,9 +3120,6 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (!find_only) {
     MG_TRY(gmg_pool_alloc((void **)&d_start_off, (no + 1) * 8));
     const int err_acc_only = (prm->flags & GMG_MG_ACCEPTED_ONLY) ? 1 : 0;
-    // error branch: 0 = level by level, one lane per call (k_mg_err_level; the default), 1 = one lane per ORF with an explicit stack
-    // (k_mg_err_flat: exact slots; the fallback of 0, and on its own with GMG_MG_ERR_FLAT=1 for A/B runs and cross-checks)
-    int err_path = gmg_opt(GMG_OPT_MG_ERR_FLAT) ? 1 : 0;
     const bool any_unfit = reads->max_len >= 2040;
     if (res->n_orfs && err_mode && err_path == 0) {
         MG_TRY(gmg_pool_alloc((void **)&d_read_fit, nr ? nr : 1));
@@ -3118,21 +3136,6 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         MG_TRY(gmg_pool_alloc((void **)&d_agg, no * sizeof(MgOrfAgg)));
         MG_TRY(gmg_pool_alloc((void **)&d_fill, no * 4));
         a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; a.agg = d_agg; a.fill = d_fill;
-        a.walk_stride = ((a.total + 15) & ~15ull) + 16;
-        MG_TRY(gmg_pool_alloc((void **)&d_walk, ((size_t)6 * a.walk_stride + 8) * sizeof(double)));
-        if (err_mode == 1) MG_TRY(gmg_pool_alloc((void **)&d_walk_q, a.total + 8));
-        a.walk_q = d_walk_q;
-        a.pfx = err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) ? 1 : 0;
-        if (a.pfx) {                                    // running sums + run lengths: the walks visit their events only
-            MG_TRY(gmg_pool_alloc((void **)&d_run, (size_t)4 * a.walk_stride));
-            hipLaunchKernelGGL(k_mg_walk_prefix, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s2, a, d_walk + 8, d_walk_q);
-            a.run_q = d_run; a.run_n = d_run + 2 * a.walk_stride;
-            hipLaunchKernelGGL(k_mg_run_tables, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s2, a, d_run, d_run + 2 * a.walk_stride);
-        } else
-            hipLaunchKernelGGL(k_mg_walk_tables, dim3(grid_for(a.total)), dim3(256), 0, s2, a, d_walk + 8, d_walk_q);
-        MG_TRY(hipGetLastError());
-        a.walk = d_walk + 8;                            // (8 spare entries in front: a call at the table's first entry looks one back)
-        tm.lap("walk-order tables");
     }
     for (int attempt = 0; attempt < 3; attempt++) {
     const dim3 lvl_grid(256 * 16);
