@@ -2501,15 +2501,28 @@ __global__ __launch_bounds__(256) void k_mg_permute_starts(const uint32_t *idx, 
     }
 }
 
+// (the accepted ORFs are one in a hundred in the error branch: a wave looks at 64 ORFs at a time, and all its lanes copy the list of each
+// accepted one together -- one lane per ORF copying its list entry by entry took 2.5 ms per 1M reads, five times this)
 __global__ __launch_bounds__(256) void k_mg_keep_gather_errs(const gmg_mg_orf *orfs, const gmg_start_errors *errs, const uint64_t *keys,
                                                              uint64_t n, const uint64_t *new_start, gmg_start_errors *out, uint64_t *keys_out)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const gmg_mg_orf o = orfs[i];
-        if (!o.accepted) continue;
-        for (uint32_t t = 0; t < o.n_starts; t++) out[new_start[i] + t] = errs[o.start_begin + t];
-        if (keys)
-            for (uint32_t t = 0; t < o.n_starts; t++) keys_out[new_start[i] + t] = keys[o.start_begin + t];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t base = wave * 64; base < n; base += n_waves * 64) {
+        const uint64_t i = base + lane;
+        uint32_t b = 0, cnt = 0;
+        uint64_t dst = 0;
+        bool acc = false;
+        if (i < n && orfs[i].accepted) { acc = true; b = orfs[i].start_begin; cnt = orfs[i].n_starts; dst = new_start[i]; }
+        for (uint64_t m = __ballot(acc); m; m &= m - 1) {
+            const int src = __ffsll((long long)m) - 1;
+            const uint32_t b_ = (uint32_t)__shfl((int)b, src), cnt_ = (uint32_t)__shfl((int)cnt, src);
+            const uint64_t dst_ = (uint64_t)(uint32_t)__shfl((int)(uint32_t)dst, src) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(dst >> 32), src) << 32;
+            for (uint32_t t = lane; t < cnt_; t += 64) {
+                out[dst_ + t] = errs[b_ + t];
+                if (keys) keys_out[dst_ + t] = keys[b_ + t];
+            }
+        }
     }
 }
 
@@ -2527,14 +2540,25 @@ __global__ __launch_bounds__(256) void k_mg_keep_gather(const gmg_mg_orf *orfs, 
                                                         const uint64_t *new_orf, const uint64_t *new_start,
                                                         gmg_mg_orf *out_orfs, gmg_start *out_starts)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        gmg_mg_orf o = orfs[i];
-        if (!o.accepted) continue;
-        const gmg_start *src = starts + o.start_begin;
-        gmg_start *dst = out_starts + new_start[i];
-        for (uint32_t t = 0; t < o.n_starts; t++) dst[t] = src[t];
-        o.start_begin = (uint32_t)new_start[i];
-        out_orfs[new_orf[i]] = o;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t base = wave * 64; base < n; base += n_waves * 64) {
+        const uint64_t i = base + lane;
+        uint32_t b = 0, cnt = 0;
+        uint64_t dst = 0;
+        bool acc = false;
+        if (i < n && orfs[i].accepted) {
+            gmg_mg_orf o = orfs[i];
+            acc = true; b = o.start_begin; cnt = o.n_starts; dst = new_start[i];
+            o.start_begin = (uint32_t)dst;
+            out_orfs[new_orf[i]] = o;
+        }
+        for (uint64_t m = __ballot(acc); m; m &= m - 1) {
+            const int src = __ffsll((long long)m) - 1;
+            const uint32_t b_ = (uint32_t)__shfl((int)b, src), cnt_ = (uint32_t)__shfl((int)cnt, src);
+            const uint64_t dst_ = (uint64_t)(uint32_t)__shfl((int)(uint32_t)dst, src) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(dst >> 32), src) << 32;
+            for (uint32_t t = lane; t < cnt_; t += 64) out_starts[dst_ + t] = starts[b_ + t];
+        }
     }
 }
 
@@ -3037,8 +3061,10 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     //    work-groups) and join the caller's stream before the start lists are written.
     static thread_local hipStream_t side_of[16] = {};   // one per device this host thread has used
     static thread_local hipEvent_t done_of[16] = {}, cum_of[16] = {};
-    hipStream_t s2 = s;
-    hipEvent_t side_done = nullptr, cum_done = nullptr;
+    static thread_local hipStream_t side2_of[16] = {};  // error branch: the qualities and the run lengths beside the ORF scan and the six-frame table
+    static thread_local hipEvent_t done2_of[16] = {};
+    hipStream_t s2 = s, s3 = s;
+    hipEvent_t side_done = nullptr, cum_done = nullptr, side2_done = nullptr;
     int dev_id = 0;
     MG_TRY(hipGetDevice(&dev_id));
     if (!find_only && !tm.on && !gmg_opt(GMG_OPT_MG_ONE_STREAM) && dev_id >= 0 && dev_id < 16) {
@@ -3050,6 +3076,15 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         s2 = side_of[dev_id];
         side_done = done_of[dev_id];
         cum_done = cum_of[dev_id];
+        s3 = s2;
+        if (err_mode) {
+            if (!side2_of[dev_id]) {
+                MG_TRY(hipStreamCreateWithFlags(&side2_of[dev_id], hipStreamNonBlocking));
+                MG_TRY(hipEventCreateWithFlags(&done2_of[dev_id], hipEventDisableTiming));
+            }
+            s3 = side2_of[dev_id];
+            side2_done = done2_of[dev_id];
+        }
     }
     const uint64_t nr = a.n_reads;
     MG_TRY(gmg_pool_alloc((void **)&d_read_cnt, (nr + 1) * 4));
@@ -3084,9 +3119,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     MG_TRY(hipGetLastError());
     tm.lap("find orfs");
     if (err_mode == 1 && a.total && !find_only) {       // Set_Quality_454 / Clean_Quality_454: needs the reads only
-        if (prm->quality) MG_TRY(hipMemcpyAsync(d_user_q, prm->quality, a.total, hipMemcpyHostToDevice, s2));
+        if (prm->quality) MG_TRY(hipMemcpyAsync(d_user_q, prm->quality, a.total, hipMemcpyHostToDevice, s3));
         MG_TRY(gmg_pool_alloc((void **)&d_walk_q, a.total + 8));
-        hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(a.total)), dim3(256), 0, s2, a, d_user_q, d_qual, d_walk_q);
+        hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(a.total)), dim3(256), 0, s3, a, d_user_q, d_qual, d_walk_q);
         MG_TRY(hipGetLastError());
         a.walk_q = d_walk_q;
         tm.lap("quality values");
@@ -3096,7 +3131,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     int err_path = gmg_opt(GMG_OPT_MG_ERR_FLAT) ? 1 : 0;
     if (!find_only && res->n_orfs && err_mode && err_path == 0) {
         // the walk-order tables: the rows (running sums) need the six-frame table and go behind it on the caller's stream; the run
-        // lengths need the reads and the qualities only and stay on the second stream, beside the six-frame kernel and the rows
+        // lengths need the reads and the qualities only and follow the quality kernel on a stream of their own, beside the ORF scan
+        // (second stream), the six-frame kernel and the rows
         a.walk_stride = ((a.total + 15) & ~15ull) + 16;
         MG_TRY(gmg_pool_alloc((void **)&d_walk, ((size_t)6 * a.walk_stride + 8) * sizeof(double)));
         a.pfx = err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) ? 1 : 0;
@@ -3104,7 +3140,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             MG_TRY(gmg_pool_alloc((void **)&d_run, (size_t)4 * a.walk_stride));
             hipLaunchKernelGGL(k_mg_walk_prefix, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s, a, d_walk + 8);
             a.run_q = d_run; a.run_n = d_run + 2 * a.walk_stride;
-            hipLaunchKernelGGL(k_mg_run_tables, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s2, a, d_run, d_run + 2 * a.walk_stride);
+            hipLaunchKernelGGL(k_mg_run_tables, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s3, a, d_run, d_run + 2 * a.walk_stride);
         } else
             hipLaunchKernelGGL(k_mg_walk_tables, dim3(grid_for(a.total)), dim3(256), 0, s, a, d_walk + 8);
         MG_TRY(hipGetLastError());
@@ -3114,6 +3150,10 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (err_mode && s2 != s) {                          // the error branch needs the six-frame table from here on: one stream again
         MG_TRY(hipEventRecord(side_done, s2));
         MG_TRY(hipStreamWaitEvent(s, side_done, 0));
+        if (s3 != s2) {
+            MG_TRY(hipEventRecord(side2_done, s3));
+            MG_TRY(hipStreamWaitEvent(s, side2_done, 0));
+        }
         s2 = s;
     }
     // 3. start lists
