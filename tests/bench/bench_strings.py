@@ -25,8 +25,15 @@ L = 500
 gmg.init(0)
 data = os.path.join(ROOT, "tests", "golden", "data")
 models = [gmg.Icm.open(os.path.join(data, "cluster-%d.icm" % (i % 6))) for i in range(n_models)]
-packed, off = gmg.synth.packed_reads(n_reads, L, 7)
+ragged = len(sys.argv) > 3 and sys.argv[3] == "ragged"
+if ragged:                                              # 454-like lengths ~ N(400, 60^2), clipped (as tests/bench/bench_mg.py)
+    lens = np.clip(np.random.default_rng(12).normal(400, 60, n_reads).round(), 100, 700).astype(np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    packed, _ = gmg.synth.packed_reads(1, int(off[-1]), 7)
+else:
+    packed, off = gmg.synth.packed_reads(n_reads, L, 7)
 reads = gmg.Reads(packed, off)
+total_bases = int(off[-1])
 lib = capi.lib()
 arr = (C.c_void_p * n_models)(*[m.device() for m in models])
 out = api._DeviceBuffer(n_models * n_reads * 2 * 8)
@@ -44,12 +51,12 @@ for _ in range(3):
     times.append(time.perf_counter() - t0)
 dt = sorted(times)[1]
 res = {"reads": n_reads, "models": n_models, "ms": dt * 1e3, "ms_per_model": dt * 1e3 / n_models,
-       "string_scores_per_s": 2 * n_reads * n_models / dt, "gbase_model_strand_per_s": 2 * n_reads * L * n_models / dt / 1e9}
+       "string_scores_per_s": 2 * n_reads * n_models / dt, "gbase_model_strand_per_s": 2 * total_bases * n_models / dt / 1e9, "ragged": ragged}
 
 # the exact segment kernel, one model, both strands
 rows = np.zeros((2 * n_reads, 4), np.uint32)
 rows[:, 0] = np.repeat(np.arange(n_reads, dtype=np.uint32), 2)
-rows[:, 2] = L
+rows[:, 2] = np.repeat(np.diff(off).astype(np.uint32), 2)
 rows[0::2, 3] = gmg.FORWARD
 rows[1::2, 3] = gmg.REVCOMP
 segs = gmg.Segments(reads, rows)
@@ -61,7 +68,7 @@ api._ck(lib.gmg_score_string(models[0].device(), reads.h, segs.h, 0, buf.ptr, No
 api._ck(lib.gmg_synchronize(None))
 t_seg = time.perf_counter() - t0
 res["segment_kernel_ms_per_model"] = t_seg * 1e3
-res["segment_kernel_gbase_model_strand_per_s"] = 2 * n_reads * L / t_seg / 1e9
+res["segment_kernel_gbase_model_strand_per_s"] = 2 * total_bases / t_seg / 1e9
 fast = out.to_host(np.float64, 2 * n_reads)
 assert np.array_equal(fast, buf.to_host(np.float64, 2 * n_reads)), "batched and segment paths differ"
 
@@ -71,7 +78,7 @@ om = orc.read(os.path.join(data, "cluster-0.icm"))
 sample = 2000
 t0 = time.perf_counter()
 for r in range(sample):
-    s = gmg.synth.unpack_ascii(packed, r * L, L)
+    s = gmg.synth.unpack_ascii(packed, int(off[r]), int(off[r + 1] - off[r]))
     orc.score_string(om, s, 0)
     orc.score_string(om, s[::-1].translate(bytes.maketrans(b"acgt", b"tgca")), 0)
 res["cpu_port_gbase_model_strand_per_s"] = 2 * sample * L / (time.perf_counter() - t0) / 1e9
