@@ -910,7 +910,7 @@ int gmg_launch_strings_sum(const gmg_model *m, const gmg_reads *reads, double *d
     a.gstride = 0;
     a.str_sums = d_sums;
     a.uniform_len = reads->uniform_len > 0 ? (uint32_t)reads->uniform_len : 0u;
-    constexpr int BLOCK = 1024, DT = 7, KR = 16;
+    constexpr int BLOCK = 1024, DT = 7, KR = 14;      // chunks per round: 10 .. 14 take 1.77 - 1.80 ms per model, 16 (128 registers) 1.91, 8 1.84, 24 2.01
     constexpr uint32_t SPAN = 2 * BLOCK;
     const uint64_t n_chunks = a.total / SPAN;
     *tail_start = n_chunks * SPAN;
