@@ -110,7 +110,7 @@ enum GmgOpt {
     GMG_OPT_DIAG,                // ablation kernels; only in builds with -DGMG_ABLATIONS (their output is NOT valid)
     GMG_OPT_STRINGS_FUSED,       // gmg_score_reads_strings: 1 = sums folded into the main pass, 0 = value rows + summing kernel
     GMG_OPT_MG_GENE32,           // glimmer-mg front half, the call's own table as fp32 gene rows with the null model applied where the
-                                 // running sums are built: 0 never, 1 with per-read null models and on ragged batches (default), 2 always
+                                 // running sums are built: 0 never, 1 with per-read null models and with tiles of two waves or more (default), 2 always
     GMG_OPT_MG_FUSED,            // glimmer-mg front half, default mode: 1 = running sums as a parallel scan + start lists in one kernel
                                  // when the models' values allow it (k_mg_tile_starts), 0 = always the sequential walks
     GMG_OPT_MG_ERR_SKIP,         // glimmer-mg's error branch: 1 = scores as differences of running sums, walks visit their events only (when the

@@ -2892,7 +2892,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     const bool nul_dense3 = nul->dev.has_dense && nul->dev.W == 3 && nul->dev.P == 3 && nul->dev.dense_part == nul->dev.dense + 192;
     // Measured (1M x 500 bp, profiles/r02_mg_*): with ONE null model the fp64 table wins (running sums 7.2 ms against 9.1 ms: the
     // conversion costs more vector work than the halved read saves); with per-read null models GENE32 saves the extra pass over
-    // the table (13.3 ms against 16.6 ms for the table + sums).  Option mg_gene32: 0 never, 1 with per-read nulls and on ragged batches (default), 2 always.
+    // the table (13.3 ms against 16.6 ms for the table + sums).  Option mg_gene32: 0 never, 1 with per-read nulls and with tiles of two waves or more (default), 2 always.
     // The fused kernel (k_mg_tile_starts: sums as a parallel scan + start lists) when every sum of the batch is exact in any
     // order -- see there; R = the longest read + 2 terms.
     {
@@ -2912,12 +2912,14 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             if (reads->uniform_len > (int)(MT_W * fused_nw)) fused_nw = 0;
             // Measured (1M reads, tests/bench/bench_mg.py with GMG_MG_TILE; profiles/r02_mg_tile_width.txt): ragged reads fill four-wave tiles
             // better than one-wave ones (~400 bp: 70 % of 567 bases, 88 % of 2,268) -- 12.5 -> 11.7 ms with one null model, 13.7 -> 10.95 ms with
-            // a null model per read (one LDS table per read and tile: fewer, fuller tiles); two reads of a uniform batch per tile with a null
-            // model per read: 12.3 -> 11.1 ms.  (A tile takes whole reads, at most tile_reads_max of them.)
+            // a null model per read (one LDS table per read and tile: fewer, fuller tiles); two-wave tiles for uniform batches (two 500-bp reads
+            // per tile): 12.3 -> 11.1 ms with a null model per read, 11.1 -> 10.9 ms with one (fp64 table), 11.5 -> 10.2 ms with the GENE32
+            // table, which is why the call's own table takes that form whenever the tiles have two waves or more.
+            // (A tile takes whole reads, at most tile_reads_max of them.)
             if (!(forced_tile == 1 || forced_tile == 2 || forced_tile == 4) && fused_nw) {
                 const uint64_t mean = a.total / a.n_reads, per_tile = prm->nulls ? MT_NC : MG_TILE_READS;
                 if (reads->uniform_len == 0 && mean * per_tile * 5 >= (uint64_t)4 * MT_W * 4) fused_nw = 4;
-                else if (reads->uniform_len > 0 && prm->nulls && fused_nw == 1 && (uint64_t)reads->uniform_len * per_tile >= (uint64_t)2 * MT_W) fused_nw = 2;
+                else if (reads->uniform_len > 0 && fused_nw == 1 && (uint64_t)reads->uniform_len * per_tile >= (uint64_t)2 * MT_W) fused_nw = 2;
             }
             // eight elements per lane (504 bases per wave) when the reads of a uniform batch fill such tiles as well as the larger ones
             if (fused_nw && reads->uniform_len > 0) {
@@ -2930,9 +2932,10 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     // GENE32 form 3.9 + 7.5 ms -- the kernel is bound by its vector instructions, not by the table's bytes, and the null-model
     // lookups add a quarter to them; profiles/r02_mg_pmc_*.txt)
     const long long g32_opt = gmg_opt(GMG_OPT_MG_GENE32);
-    // (with four-wave tiles -- ragged batches -- the GENE32 form wins with one null model as well: 10.6 -> 10.0 ms per 1M x ~400 bp)
+    // (with tiles of two waves or more the GENE32 form wins with one null model as well: ragged 10.6 -> 10.0 ms per 1M x ~400 bp,
+    // 500-bp reads 10.9 -> 10.2 ms)
     const bool g32 = !d_frame_scores && !err_mode && a.total &&
-                     (g32_opt == 2 || (g32_opt == 1 && (prm->nulls || (reads->uniform_len == 0 && fused_nw == 4)))) && nul_dense3 &&
+                     (g32_opt == 2 || (g32_opt == 1 && (prm->nulls || fused_nw >= 2))) && nul_dense3 &&
                      gene->dev.has_fast && gene->dev.D == 7 && gene->dev.W >= 3 && gene->dev.W <= 15;
     if (prm->nulls && !nul_dense3) return fail(gmg_set_error(GMG_EBADMODEL, "gmg_mg_score_reads: per-read null models are (3,2,3) models"));
     a.fs_stride = a.total;
