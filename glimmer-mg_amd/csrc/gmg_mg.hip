@@ -1707,28 +1707,42 @@ struct MgErrRun {                // what one ORF's walk accumulates
     int m0, trunc0;              // the ORF's own call: region length and orf_is_truncated
 };
 
-// Set_Quality_454 (glimmer-mg.cc:1865-1906) / Clean_Quality_454 (:519-546): one lane per base
+// Set_Quality_454 (glimmer-mg.cc:1865-1906) / Clean_Quality_454 (:519-546).  One wave per read, 64 bases at a time: "this base equals
+// the one before it" as a 64-bit mask, the length of the homopolymer run that ends at a base = the distance to the last clear bit at or
+// below its own (a run that reaches the chunk's first base goes on with what the chunk before ended with) -- no search for the read of a
+// base, no loop back over the run (one lane per base: 2.3 ms per 1M reads).
 __global__ __launch_bounds__(256) void k_mg_quality(MgArgs a, const uint8_t *user, uint8_t *out, uint8_t *walk_q)
 {
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = mg_lower_bound(a, g + 1) - 1;                 // the read that holds base g
-        const uint64_t b = a.read_off[r], e = a.read_off[r + 1];
-        auto code = [&](uint64_t x) { return (a.packed[x >> 4] >> (2u * (unsigned)(x & 15))) & 3u; };
-        const uint32_t c = code(g);
-        const bool inside = g + 1 < e && code(g + 1) == c;              // not the last base of its homopolymer run
-        int q;
-        if (user) {
-            q = user[g];
-            if (q <= 0) q = 1;
-            if (inside && q < a.indel_q_thr + 1) q = a.indel_q_thr + 1;
-        } else if (inside) q = 31;
-        else {
-            int run = 1;
-            while (run < 6 && g >= b + run && code(g - run) == c) run++;
-            q = run < 6 ? 31 - 5 * run : 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < a.n_reads; r += n_waves) {
+        const uint64_t b = a.read_off[r];
+        const uint32_t n = (uint32_t)(a.read_off[r + 1] - b);
+        uint32_t carry = 0;                             // the run that ends at the last base of the chunk before (<= 6)
+        for (uint32_t t0 = 0; t0 < n; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            const bool in = t < n;
+            const uint64_t g = b + (in ? t : 0);
+            const uint64_t x = dev_window_bits(a.packed, (int64_t)g - 1);         // bases g - 1, g, g + 1 in the low six bits
+            const uint32_t cp = (uint32_t)x & 3u, c = (uint32_t)(x >> 2) & 3u, cn = (uint32_t)(x >> 4) & 3u;
+            const uint64_t eq = __ballot(in && t > 0 && c == cp);
+            const uint64_t below = ~eq & ((2ull << lane) - 1ull);                 // the clear bits at or below this lane
+            uint32_t run = below ? lane - (63u - (uint32_t)__clzll((long long)below)) + 1u : lane + 1u + carry;
+            if (run > 6u) run = 6u;
+            const bool inside = in && t + 1 < n && cn == c;                       // not the last base of its homopolymer run
+            int q;
+            if (user) {
+                q = user[g];
+                if (q <= 0) q = 1;
+                if (inside && q < a.indel_q_thr + 1) q = a.indel_q_thr + 1;
+            } else if (inside) q = 31;
+            else q = run < 6u ? 31 - 5 * (int)run : 6;
+            if (in) {
+                out[g] = (uint8_t)(q > 255 ? 255 : q);
+                if (walk_q) walk_q[a.total - 1 - g] = (uint8_t)(q > 255 ? 255 : q);     // last base first: what a forward walk reads
+            }
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)run, 63);
         }
-        out[g] = (uint8_t)(q > 255 ? 255 : q);
-        if (walk_q) walk_q[a.total - 1 - g] = (uint8_t)(q > 255 ? 255 : q);     // last base first: what a forward walk reads
     }
 }
 
@@ -3135,7 +3149,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (err_mode == 1 && a.total && !find_only) {       // Set_Quality_454 / Clean_Quality_454: needs the reads only
         if (prm->quality) MG_TRY(hipMemcpyAsync(d_user_q, prm->quality, a.total, hipMemcpyHostToDevice, s3));
         MG_TRY(gmg_pool_alloc((void **)&d_walk_q, a.total + 8));
-        hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(a.total)), dim3(256), 0, s3, a, d_user_q, d_qual, d_walk_q);
+        hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(nr * 64)), dim3(256), 0, s3, a, d_user_q, d_qual, d_walk_q);
         MG_TRY(hipGetLastError());
         a.walk_q = d_walk_q;
         tm.lap("quality values");
