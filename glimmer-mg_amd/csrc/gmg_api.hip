@@ -32,7 +32,7 @@ extern "C" const char *gmg_last_error(void) { return g_err; }
 // ---------------------------------------------------------------------------
 long long g_gmg_opt[GMG_OPT_COUNT] = {
     /* seg_plain */ 0, /* mg_tile */ 0, /* mg_one_stream */ 0, /* mg_err_flat */ 0, /* mg_err_calls */ 0, /* mg_err_calls_grow */ 0,
-    /* orfs_exact_path */ 0, /* train_sort_min */ -1, /* mg_max_entries */ 0x7fffffffll, /* mg_timing */ 0, /* ingest_timing */ 0,
+    /* orfs_exact_path */ 0, /* train_sort_min */ -1, /* mg_max_entries */ 0x7ffffffell, /* mg_timing */ 0, /* ingest_timing */ 0,
     /* train_timing */ 0, /* diag */ 0, /* strings_fused */ 1, /* mg_gene32 */ 1, /* mg_fused */ 1, /* mg_err_skip */ 1, /* mg_orfs_events */ 1};
 static const char *const g_opt_name[GMG_OPT_COUNT] = {
     "seg_plain", "mg_tile", "mg_one_stream", "mg_err_flat", "mg_err_calls", "mg_err_calls_grow", "orfs_exact_path",
@@ -54,8 +54,8 @@ extern "C" int gmg_set_option(const char *key, long long value)
     if (i == GMG_OPT_DIAG && value != 0)
         return gmg_set_error(GMG_EINVAL, "gmg_set_option: the ablation kernels are not in this build (-DGMG_ABLATIONS)");
 #endif
-    if (i == GMG_OPT_MG_MAX_ENTRIES && (value < 1 || value > 0x7fffffffll))
-        return gmg_set_error(GMG_EINVAL, "gmg_set_option: mg_max_entries must be in [1, 2^31 - 1]");
+    if (i == GMG_OPT_MG_MAX_ENTRIES && (value < 1 || value > 0x7ffffffell))     // n + 1 entries must fit the int of the hipcub calls
+        return gmg_set_error(GMG_EINVAL, "gmg_set_option: mg_max_entries must be in [1, 2^31 - 2]");
     g_gmg_opt[i] = value;
     return GMG_OK;
 }

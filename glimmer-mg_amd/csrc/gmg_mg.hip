@@ -2734,6 +2734,7 @@ struct MgTimer {
 static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, const gmg_mg_params *prm,
                   double *d_frame_scores, gmg_mg_result **out, void *stream, const bool find_only)
 {
+    { int rc_enter = gmg_enter(find_only ? "gmg_find_orfs" : "gmg_mg_score_reads"); if (rc_enter) return rc_enter; }
     if ((!find_only && (!gene || !nul)) || !reads || !prm || !out) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: NULL argument");
     if (prm->n_start_codons < 0 || prm->n_start_codons > 8 || prm->n_stop_codons < 0 || prm->n_stop_codons > 8 ||
         prm->min_gene_len < 4)

@@ -260,7 +260,13 @@ extern "C" int gmg_score_reads_strings(const gmg_model *const *models, int n_mod
         // the fused form: values that are all <= 0 and not too small (ordinary reads then pass k_string_finish's test)
         // ... and reads of at least 86 bases: at most 384 of them then overlap a round of 32,768 bases (the accumulators in LDS) and
         // at most three a wave's 128 bases
-        if (gmg_opt(GMG_OPT_STRINGS_FUSED) && !m->odd_values && m->min_exp >= 109 && reads->total_bases && reads->min_len >= 86) {
+        // ... and a bounded exponent range: the uniform-length path moves the share of the read that ends inside a row of 16 lanes
+        // (<= 32 values) through the NEXT read's accumulator (+ row sum, - share; f6_sum_chunk).  That is exact only while such a
+        // share cannot push the neighbour's partial sums past 53 bits: 32 values < 2^(max_exp - 121), the read's own sum passes
+        // k_string_finish's test below 2^(min_exp - 99), so max_exp - min_exp <= 23 keeps every transient an exact double.  A model
+        // with a zero probability (-FLT_MAX, exponent field 254; icm.cc:1345-1349) therefore takes the two-pass form.
+        if (gmg_opt(GMG_OPT_STRINGS_FUSED) && !m->odd_values && m->min_exp >= 109 && m->max_exp - m->min_exp <= 23 &&
+            reads->total_bases && reads->min_len >= 86) {
             hipError_t e = hipMemsetAsync(out, 0, nr * 2 * sizeof(double), s);
             if (e != hipSuccess) { rc = gmg_set_error(GMG_EHIP, "gmg_score_reads_strings: %s", hipGetErrorString(e)); break; }
             const int fused = gmg_launch_strings_sum(m, reads, out, &tail_start, s);

@@ -31,6 +31,7 @@
 #include "gmg.h"
 
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -310,6 +311,7 @@ int main(int argc, char **argv)
             down[k] = pd[1];
         }
         int rc = EXIT_SUCCESS;
+        signal(SIGPIPE, SIG_IGN);                       // a child that died must not take the parent with it: the write fails instead
         if (!GC_Frac_Set) {                             // two integers up per child, one double down
             vector<uint64_t> gc(n_shards), total(n_shards);
             for (int k = 0; k < n_shards; k++) {
@@ -326,7 +328,14 @@ int main(int argc, char **argv)
             waitpid(pid[k], &status, 0);
             if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) { fprintf(stderr, "glimmer-mg_gpu: shard %d failed\n", k); rc = EXIT_FAILURE; }
         }
-        if (rc != EXIT_SUCCESS) return rc;
+        if (rc != EXIT_SUCCESS) {                       // every child has been waited for: no part file survives a failed run
+            for (int k = 0; k < n_shards; k++) {
+                char part[32];
+                snprintf(part, sizeof part, ".part%d", k);
+                unlink((out + part).c_str());
+            }
+            return rc;
+        }
         FILE *fo = File_Open(out, "w", __FILE__, __LINE__);      // the parts in shard order = the reads in file order
         vector<char> buf(1 << 20);
         for (int k = 0; k < n_shards; k++) {
