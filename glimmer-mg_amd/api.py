@@ -483,6 +483,68 @@ START_ERRORS_DTYPE = np.dtype([("pos", "<i4", (2,)), ("type", "i1", (2,)), ("n",
 MG_ACCEPTED_ONLY, MG_ALLOW_INDELS, MG_ALLOW_SUBS = 1, 2, 4
 
 
+class Classes:
+    """gmg_classes: glimmer-mg -c bookkeeping (Parse_Classes, Read_Meta_ICMs / _GC / _Stops; host only)"""
+
+    def __init__(self, class_text, icm_dir):
+        if isinstance(class_text, str):
+            class_text = class_text.encode()
+        self.h = C.c_void_p()
+        _ck(capi.lib().gmg_classes_load(class_text, len(class_text), icm_dir.encode(), C.byref(self.h)))
+        n, k, c, miss = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        _ck(capi.lib().gmg_classes_info(self.h, C.byref(n), C.byref(k), C.byref(c), C.byref(miss)))
+        self.n_reads, self.n_icms, self.n_classes, self.n_missing_gc = n.value, k.value, c.value, miss.value
+
+    def icm_file(self, k):
+        p = capi.lib().gmg_classes_icm_file(self.h, k)
+        if p is None:
+            _ck(-1)
+        return p.decode()
+
+    def plan(self, headers):
+        """headers: the header LINES of one chunk -> (order, icm_begin, gc, transl): gmg_classes_plan"""
+        hb = [h.encode() if isinstance(h, str) else h for h in headers]
+        n = len(hb)
+        arr = (C.c_char_p * max(n, 1))(*hb)
+        lens = np.array([len(h) for h in hb], np.uint32)
+        order = np.zeros(max(n, 1), np.uint64)
+        icm_begin = np.zeros(self.n_icms + 1, np.uint64)
+        gc = np.zeros(max(n, 1), np.float64)
+        transl = np.zeros(max(n, 1), np.int32)
+        k = C.c_uint64()
+        _ck(capi.lib().gmg_classes_plan(self.h, arr, _ptr(lens), n, _ptr(order), _ptr(icm_begin), _ptr(gc), _ptr(transl), C.byref(k)))
+        return order[:k.value], icm_begin, gc[:k.value], transl[:k.value]
+
+    def close(self):
+        if self.h:
+            capi.lib().gmg_classes_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def stop_codons_by_code(code):
+    """gmg_stop_codons_by_code: Set_Stop_Codons_By_Code (gene.cc:1560-1624) -> tuple of codons"""
+    buf = ((C.c_char * 4) * 8)()
+    n = C.c_int()
+    _ck(capi.lib().gmg_stop_codons_by_code(int(code), buf, C.byref(n)))
+    return tuple(buf[i].value.decode() for i in range(n.value))
+
+
+def ignore_score_len(gc, stops=DEFAULT_STOPS):
+    """gmg_ignore_score_len: Set_Ignore_Score_Len (glimmer_base.cc:2597-2633)"""
+    buf = ((C.c_char * 4) * 8)()
+    for i, c in enumerate(stops):
+        buf[i].value = c.encode()
+    out = C.c_int32()
+    _ck(capi.lib().gmg_ignore_score_len(float(gc), buf, len(stops), C.byref(out)))
+    return out.value
+
+
 def mg_score_reads(gene, null, reads, min_gene_len=75, allow_truncated=True, ignore_score_len=2**31 - 1,
                    start_threshold=-6.0, start_codons=("atg", "gtg", "ttg"), stop_codons=("taa", "tag", "tga"),
                    frame_scores=None, accepted_only=False, allow_indels=False, allow_subs=False, quality=None,

@@ -6,7 +6,7 @@ import subprocess
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(PKG, "lib", "libgmg.so")
-SOURCES = ["csrc/gmg_api.hip", "csrc/gmg_kernels.hip", "csrc/gmg_frame6.hip", "csrc/gmg_orfs.hip", "csrc/gmg_mg.hip", "csrc/gmg_ingest.hip", "csrc/gmg_strings.hip", "csrc/gmg_train.hip", "host/icm.cc", "host/icm_train.cc", "host/gmg_icm_c.cc", "host/gmg_shard.cc"]
+SOURCES = ["csrc/gmg_api.hip", "csrc/gmg_kernels.hip", "csrc/gmg_frame6.hip", "csrc/gmg_orfs.hip", "csrc/gmg_mg.hip", "csrc/gmg_ingest.hip", "csrc/gmg_strings.hip", "csrc/gmg_train.hip", "host/icm.cc", "host/icm_train.cc", "host/gmg_icm_c.cc", "host/gmg_shard.cc", "host/gmg_classes.cc"]
 HEADERS = ["csrc/gmg_internal.h", "csrc/gmg_device.h", "host/icm.hh", "../include/gmg.h", "../include/gmg_icm.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
@@ -48,7 +48,42 @@ def build_lib(force=False, verbose=False):
             if not force and not stale():
                 return LIB
             tmp = "%s.tmp.%d" % (LIB, os.getpid())
-            cmd = [hipcc, *FLAGS, "-o", tmp, *SOURCES]
+            # one object per source, only the stale ones, a few at a time (the box has 8 - 16 cores); then one link
+            objdir = os.path.join(PKG, "lib", "obj")
+            os.makedirs(objdir, exist_ok=True)
+            newest_header = max(os.path.getmtime(os.path.join(PKG, h)) for h in HEADERS)
+            objs, jobs = [], []
+            for src in SOURCES:
+                obj = os.path.join(objdir, os.path.basename(src) + ".o")
+                objs.append(obj)
+                if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(os.path.join(PKG, src)), newest_header):
+                    jobs.append((src, [hipcc, *[f for f in FLAGS if f != "-shared"], "-c", "-o", obj, src]))
+            running = []
+            failed = []
+
+            def reap(block):
+                for item in list(running):
+                    src, proc = item
+                    if block or proc.poll() is not None:
+                        out = proc.communicate()[0]
+                        running.remove(item)
+                        if verbose or proc.returncode != 0:
+                            print(out)
+                        if proc.returncode != 0:
+                            failed.append(src)
+                        if block:
+                            return
+
+            width = max(1, min(6, (os.cpu_count() or 2) - 1))
+            for src, cmd in jobs:
+                while len(running) >= width:
+                    reap(True)
+                running.append((src, subprocess.Popen(cmd, cwd=PKG, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+            while running:
+                reap(True)
+            if failed:
+                raise RuntimeError("hipcc failed compiling " + ", ".join(failed))
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
             res = subprocess.run(cmd, cwd=PKG, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             if verbose or res.returncode != 0:
                 print(" ".join(cmd))
@@ -56,7 +91,7 @@ def build_lib(force=False, verbose=False):
             if res.returncode != 0:
                 if os.path.exists(tmp):
                     os.remove(tmp)
-                raise RuntimeError("hipcc failed building libgmg.so")
+                raise RuntimeError("hipcc failed linking libgmg.so")
             os.replace(tmp, LIB)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

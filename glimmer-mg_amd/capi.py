@@ -97,6 +97,13 @@ PROTOTYPES = {
     "gmg_orfs_upload": (i32, [vp, vp, u64, C.POINTER(u64), C.POINTER(vp)]),
     "gmg_orf_batch_free": (i32, [vp]),
     "gmg_score_orfs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gmg_classes_load": (i32, [C.c_char_p, u64, C.c_char_p, C.POINTER(vp)]),
+    "gmg_classes_free": (i32, [vp]),
+    "gmg_classes_info": (i32, [vp, C.POINTER(u64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(u64)]),
+    "gmg_classes_icm_file": (C.c_char_p, [vp, C.c_uint32]),
+    "gmg_classes_plan": (i32, [vp, vp, vp, u64, vp, vp, vp, vp, C.POINTER(u64)]),
+    "gmg_stop_codons_by_code": (i32, [i32, vp, C.POINTER(i32)]),
+    "gmg_ignore_score_len": (i32, [C.c_double, vp, i32, C.POINTER(C.c_int32)]),
     "gmg_trainer_create": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
     "gmg_trainer_level_counts": (i32, [vp, i32, vp, vp]),
     "gmg_trainer_free": (i32, [vp]),

@@ -435,6 +435,39 @@ int gmg_fasta_shard_ranges(const char *bytes, uint64_t n_bytes, int n_shards, ui
  * which wrap beyond 2^32 bases (byte-identical output on such files); 0: 64-bit counts. */
 double gmg_gc_fraction(const uint64_t *gc_counts, const uint64_t *base_counts, int n_shards, int as_reference);
 
+/* ---- glimmer-mg's classification mode, -c (host only) --------------------------------------------
+ * With -c every read is scored by the gene ICM its Phymm classes name, against a null model and with stop codons that
+ * are rebuilt per read, and the reads are visited -- and <tag>.predict is written -- ICM by ICM in the iteration order of
+ * the reference's hash tables, not in file order.  gmg_classes_* reproduce that bookkeeping; the scoring of one ICM's
+ * reads is then ONE gmg_mg_score_reads call (gmg_reads_select, gmg_null_set_upload, gmg_mg_params.read_null /
+ * read_ignore_score_len) per stop-codon set.  INTEGRATION.md shows the loop; integration/glimmer-mg_gpu.cc runs it. */
+typedef struct gmg_classes gmg_classes;
+/* Parse_Classes (src/Glimmer/glimmer-mg.cc:726-758) on the text of a classification file ("<read> <class> <class> ..."
+ * per line, class = <strain>|<NC>), then Read_Meta_ICMs (:998-1027) with Classes_ICM_File (:473-515; looks for the
+ * double ICMs under icm_dir with stat), Read_Meta_GC (:1389-1420: <icm_dir>/<strain>/<NC>.gc.txt, 0.5 when missing) and
+ * Read_Meta_Stops (:1211-1250: transl_table of <NC>.gbk, 11 when missing).  icm_dir is the reference's ICM_dir (:147). */
+int gmg_classes_load(const char *class_text, uint64_t n_bytes, const char *icm_dir, gmg_classes **out);
+int gmg_classes_free(gmg_classes *c);
+/* classified reads, distinct ICM files, distinct classes, classes without a .gc.txt (any pointer may be NULL) */
+int gmg_classes_info(const gmg_classes *c, uint64_t *n_reads, uint32_t *n_icms, uint32_t *n_classes, uint64_t *n_missing_gc);
+/* ICM file k (0 .. n_icms-1) in the order the reference's loop over ICM_Sequences loads them (glimmer-mg.cc:361-364) */
+const char *gmg_classes_icm_file(const gmg_classes *c, uint32_t k);
+/* The plan of ONE chunk of the input (the reference reads Chunk_Sequences = 500000 reads at a time, glimmer-mg.cc:128,
+ * 326-356): hdr[i] / hdr_len[i] = header line of read i of the chunk (its first white-space-delimited token is the key;
+ * when two reads share a key the later one is taken, as Read_Indexes does).  order[k], k < *n_order <= n: chunk index of
+ * the k-th read the reference processes and prints; order[icm_begin[f] .. icm_begin[f+1]) are the reads of ICM file f
+ * (icm_begin: n_icms + 1 entries).  Reads without a line in the class file are never processed (:369-371).  Per
+ * processed read, parallel to order (either may be NULL): gc[k] = Indep_GC_Frac of Update_Meta_Null_ICM (:2050-2064: the
+ * float GCs of its classes summed in double, divided by their float count), transl[k] = Genbank_Xlate_Code of
+ * Update_Meta_Stop (:2196: the table of its FIRST class). */
+int gmg_classes_plan(const gmg_classes *c, const char *const *hdr, const uint32_t *hdr_len, uint64_t n,
+                     uint64_t *order, uint64_t *icm_begin, double *gc, int32_t *transl, uint64_t *n_order);
+/* Set_Stop_Codons_By_Code (src/Common/gene.cc:1560-1624): the stop codons of a GenBank translation table, in the
+ * reference's order (Build_Indep_WO_Stops depends on it); GMG_EINVAL for a table the reference does not know. */
+int gmg_stop_codons_by_code(int code, char stop_codon[8][4], int *n_stop_codons);
+/* Set_Ignore_Score_Len (src/Glimmer/glimmer_base.cc:2597-2633) */
+int gmg_ignore_score_len(double gc_frac, const char (*stop_codon)[4], int n_stop_codons, int32_t *out);
+
 /* ---- build-icm: training counts on the device ---------------------------------------
  * Replaces the counting of ICM_Training_t: Count_Char_Pairs for the roots (src/ICM/icm.cc:1841-1870, called from
  * Train_Model, icm.cc:1373-1390), Count_Char_Pairs_Restricted + Get_Training_Node for every deeper level

@@ -54,7 +54,7 @@ def parse_dump(text, icm_dir, list_reads):
             reads.append(f[1]); gc.append(float.fromhex(f[3])); isl.append(int(f[4])); transl.append(int(f[5]))
             nstops.append(n_st); stops.append(",".join(f[7:7 + n_st]))
             name = f[7 + n_st]
-            name = os.path.relpath(name, icm_dir) if name.startswith(icm_dir) else os.path.basename(name)
+            name = name[len(icm_dir):] if name.startswith(icm_dir) else os.path.basename(name)
             icm_idx.append(names.setdefault(name, len(names)))
             orf_off.append(orf_off[-1])
         elif f[0] == "O":
@@ -93,14 +93,16 @@ def main():
         os.makedirs(os.path.join(GOLD, "predict"), exist_ok=True)
         for name, flags, cls, chunk, list_reads in CASES:
             cls_path = mixed if cls == "mixed.class.txt" else os.path.join(DATA, cls)
-            env = dict(os.environ, GMG_REF_ICM_DIR=icm_dir)
+            # the iteration order of ICM_Sequences depends on the hash of the whole file NAME, ICM_dir included: the goldens
+            # are made with the relative name ".genomeData" (cwd = the directory that holds it), which every test can repeat
+            env = dict(os.environ, GMG_REF_ICM_DIR=".genomeData")
             if chunk:
                 env["GMG_REF_CHUNK"] = str(chunk)
             tag = os.path.join(tmp, name)
-            out = subprocess.run([exe, *flags, "-c", cls_path, os.path.join(DATA, "seqs.fa"), tag], check=True, env=env,
+            out = subprocess.run([exe, *flags, "-c", cls_path, os.path.join(DATA, "seqs.fa"), tag], check=True, env=env, cwd=tmp,
                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
             shutil.copy(tag + ".predict", os.path.join(GOLD, "predict", "classes.%s.predict" % name))
-            d = parse_dump(out, icm_dir + os.sep, list_reads)
+            d = parse_dump(out, ".genomeData" + os.sep, list_reads)
             np.savez_compressed(os.path.join(GOLD, "classes_%s.npz" % name), flags=" ".join(os.path.basename(x) for x in flags),
                                 class_file=cls, chunk=chunk or 0, **d)
             print("%-14s %4d reads, %3d ICM files, %3d distinct GCs, %d stop sets, %6d ORFs, %5d accepted, %7d starts" % (

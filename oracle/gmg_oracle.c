@@ -1407,3 +1407,392 @@ orc_model *orc_train_model(const char *const *strings, int n_strings, int model_
         m->prob[i] = (m->prob[i] > 0.0) ? logf(m->prob[i]) : -FLT_MAX;
     return m;
 }
+
+/* ==== glimmer-mg -c: classification bookkeeping ==========================================================
+ * Which ICM file scores which read, in which order, with which null-model GC and stop codons
+ * (src/Glimmer/glimmer-mg.cc:326-375, 473-515, 726-758, 998-1027, 1211-1250, 1389-1420, 2050-2068, 2185-2219).
+ *
+ * The order comes from the iteration order of two __gnu_cxx::hash_map<string, ...> (glimmer-mg.hh:22-49 picks
+ * <ext/hash_map>).  That container is not part of the reference tree: it is libstdc++'s SGI hash table
+ * (GCC 11: /usr/include/c++/11/backward/hashtable.h, hash_fun.h; unchanged since GCC 3.1), whose published algorithm is
+ * restated here:
+ *   hash of a string        h = 5 h + c over its characters, unsigned long                (hash_fun.h __stl_hash_string)
+ *   bucket counts           the next of 29 fixed primes >= the request; hash_map() asks for 100 -> 193
+ *   operator[] / insert     resize (elements + 1) FIRST -- when that exceeds the bucket count every node moves to
+ *                           the HEAD of its new bucket, old buckets in ascending order, chains front to back --, then
+ *                           the key is looked up in bucket h % n and, if new, linked in at the HEAD of that bucket
+ *   iteration               buckets in ascending order, each chain front to back
+ * ========================================================================================================= */
+
+static const unsigned long orc_sgi_primes[29] = {
+    5ul, 53ul, 97ul, 193ul, 389ul, 769ul, 1543ul, 3079ul, 6151ul, 12289ul, 24593ul, 49157ul, 98317ul, 196613ul, 393241ul,
+    786433ul, 1572869ul, 3145739ul, 6291469ul, 12582917ul, 25165843ul, 50331653ul, 100663319ul, 201326611ul, 402653189ul,
+    805306457ul, 1610612741ul, 3221225473ul, 4294967291ul};
+
+typedef struct orc_sgi_node { struct orc_sgi_node *next; char *key; void *val; } orc_sgi_node;
+typedef struct orc_sgi_table { orc_sgi_node **bucket; unsigned long n_buckets, n_elements; } orc_sgi_table;
+
+static unsigned long orc_sgi_next_prime(unsigned long n)
+{
+    int i;
+    for (i = 0; i < 29; i++)
+        if (orc_sgi_primes[i] >= n) return orc_sgi_primes[i];
+    return orc_sgi_primes[28];
+}
+
+static unsigned long orc_sgi_hash(const char *s)
+{
+    unsigned long h = 0;
+    for (; *s; ++s) h = 5 * h + (unsigned long)(long)*s;      /* `char` is signed on this platform, as in the reference's build */
+    return h;
+}
+
+static void orc_sgi_init(orc_sgi_table *t)
+{
+    t->n_buckets = orc_sgi_next_prime(100);
+    t->bucket = (orc_sgi_node **)calloc(t->n_buckets, sizeof(orc_sgi_node *));
+    t->n_elements = 0;
+}
+
+static void orc_sgi_resize(orc_sgi_table *t, unsigned long hint)
+{
+    unsigned long n, b;
+    orc_sgi_node **nb;
+    if (hint <= t->n_buckets) return;
+    n = orc_sgi_next_prime(hint);
+    if (n <= t->n_buckets) return;
+    nb = (orc_sgi_node **)calloc(n, sizeof(orc_sgi_node *));
+    for (b = 0; b < t->n_buckets; b++) {
+        orc_sgi_node *first = t->bucket[b];
+        while (first) {
+            const unsigned long k = orc_sgi_hash(first->key) % n;
+            t->bucket[b] = first->next;
+            first->next = nb[k];
+            nb[k] = first;
+            first = t->bucket[b];
+        }
+    }
+    free(t->bucket);
+    t->bucket = nb;
+    t->n_buckets = n;
+}
+
+static orc_sgi_node *orc_sgi_find(const orc_sgi_table *t, const char *key)
+{
+    orc_sgi_node *c = t->bucket[orc_sgi_hash(key) % t->n_buckets];
+    for (; c; c = c->next)
+        if (strcmp(c->key, key) == 0) return c;
+    return NULL;
+}
+
+/* hash_map::operator[]: find_or_insert of (key, empty value) */
+static orc_sgi_node *orc_sgi_index(orc_sgi_table *t, const char *key)
+{
+    unsigned long k;
+    orc_sgi_node *c;
+    orc_sgi_resize(t, t->n_elements + 1);
+    k = orc_sgi_hash(key) % t->n_buckets;
+    for (c = t->bucket[k]; c; c = c->next)
+        if (strcmp(c->key, key) == 0) return c;
+    c = (orc_sgi_node *)calloc(1, sizeof *c);
+    c->key = strdup(key);
+    c->next = t->bucket[k];
+    t->bucket[k] = c;
+    t->n_elements++;
+    return c;
+}
+
+static void orc_sgi_free(orc_sgi_table *t, void (*free_val)(void *))
+{
+    unsigned long b;
+    for (b = 0; b < t->n_buckets; b++) {
+        orc_sgi_node *c = t->bucket[b];
+        while (c) {
+            orc_sgi_node *nx = c->next;
+            if (free_val && c->val) free_val(c->val);
+            free(c->key);
+            free(c);
+            c = nx;
+        }
+    }
+    free(t->bucket);
+}
+
+typedef struct orc_strlist { char **s; long n, cap; } orc_strlist;
+static void orc_strlist_push(orc_strlist *l, const char *s)
+{
+    if (l->n == l->cap) {
+        l->cap = l->cap ? 2 * l->cap : 4;
+        l->s = (char **)realloc(l->s, (size_t)l->cap * sizeof(char *));
+    }
+    l->s[l->n++] = strdup(s);
+}
+static void orc_strlist_free(void *p)
+{
+    orc_strlist *l = (orc_strlist *)p;
+    long i;
+    for (i = 0; i < l->n; i++) free(l->s[i]);
+    free(l->s);
+    free(l);
+}
+
+struct orc_classes {
+    char *icm_dir;
+    orc_sgi_table classifications;      /* header prefix -> orc_strlist of classes          (glimmer-mg.cc:163-164) */
+    orc_sgi_table icm_sequences;        /* ICM file -> orc_strlist of header prefixes       (:205-206) */
+    orc_sgi_table gc;                   /* class -> float *                                 (:196-197) */
+    orc_sgi_table transl;               /* class -> int *                                   (:199-200) */
+};
+
+/* split (s, '|') (src/Common/kelley.cc:10-26): fields 0 and 1 */
+static int orc_strain_nc(const char *cls, char *strain, char *nc, size_t cap)
+{
+    const char *bar = strchr(cls, '|'), *bar2;
+    size_t n;
+    if (!bar) return -1;
+    n = (size_t)(bar - cls);
+    if (n >= cap) return -1;
+    memcpy(strain, cls, n);
+    strain[n] = 0;
+    bar2 = strchr(bar + 1, '|');
+    n = bar2 ? (size_t)(bar2 - bar - 1) : strlen(bar + 1);
+    if (n >= cap) return -1;
+    memcpy(nc, bar + 1, n);
+    nc[n] = 0;
+    return 0;
+}
+
+#include <sys/stat.h>
+
+/* Classes_ICM_File (glimmer-mg.cc:473-515) */
+static char *orc_classes_icm_name(const orc_classes *c, const orc_strlist *cl)
+{
+    char s1[512], n1[512], s2[512], n2[512];
+    const size_t cap = strlen(c->icm_dir) + 2200;
+    char *out = (char *)malloc(cap);
+    long i;
+    if (cl->n >= 2) {
+        for (i = 1; i < cl->n; i++) {
+            const int first_smaller = strcmp(cl->s[0], cl->s[i]) < 0;   /* string::compare: bytes as unsigned char, like strcmp */
+            const char *a = first_smaller ? cl->s[0] : cl->s[i], *b = first_smaller ? cl->s[i] : cl->s[0];
+            struct stat st;
+            if (orc_strain_nc(a, s1, n1, sizeof s1) || orc_strain_nc(b, s2, n2, sizeof s2)) { free(out); return NULL; }
+            snprintf(out, cap, "%s/%s/%s_2/%s/%s.gicm", c->icm_dir, s1, n1, s2, n2);
+            if (stat(out, &st) == 0) return out;
+        }
+    }
+    if (orc_strain_nc(cl->s[0], s1, n1, sizeof s1)) { free(out); return NULL; }
+    snprintf(out, cap, "%s/%s/%s.gicm", c->icm_dir, s1, n1);
+    return out;
+}
+
+void orc_classes_free(orc_classes *c)
+{
+    if (!c) return;
+    orc_sgi_free(&c->classifications, orc_strlist_free);
+    orc_sgi_free(&c->icm_sequences, orc_strlist_free);
+    orc_sgi_free(&c->gc, free);
+    orc_sgi_free(&c->transl, free);
+    free(c->icm_dir);
+    free(c);
+}
+
+orc_classes *orc_classes_load(const char *text, long n, const char *icm_dir)
+{
+    orc_classes *c = (orc_classes *)calloc(1, sizeof *c);
+    long pos = 0;
+    unsigned long b;
+    c->icm_dir = strdup(icm_dir);
+    orc_sgi_init(&c->classifications);
+    orc_sgi_init(&c->icm_sequences);
+    orc_sgi_init(&c->gc);
+    orc_sgi_init(&c->transl);
+    /* Parse_Classes (:726-758): getline, split on white space (kelley.cc:34-53), classifications[a[0]] = a[1..] */
+    while (pos < n) {
+        long end = pos, i;
+        orc_strlist *v = (orc_strlist *)calloc(1, sizeof *v);
+        char *key = NULL;
+        while (end < n && text[end] != '\n') end++;
+        i = pos;
+        while (i < end) {
+            long b0;
+            while (i < end && (text[i] == ' ' || text[i] == '\t' || text[i] == '\r')) i++;
+            b0 = i;
+            while (i < end && !(text[i] == ' ' || text[i] == '\t' || text[i] == '\r')) i++;
+            if (i > b0) {
+                char *tok = (char *)malloc((size_t)(i - b0) + 1);
+                memcpy(tok, text + b0, (size_t)(i - b0));
+                tok[i - b0] = 0;
+                if (!key) key = tok;
+                else { orc_strlist_push(v, tok); free(tok); }
+            }
+        }
+        pos = end + 1;
+        if (!key || v->n == 0) {        /* undefined behaviour in the reference (a[0] of an empty vector, Seq_Classes[0]) */
+            free(key);
+            orc_strlist_free(v);
+            orc_classes_free(c);
+            return NULL;
+        }
+        {
+            orc_sgi_node *nd = orc_sgi_index(&c->classifications, key);
+            if (nd->val) orc_strlist_free(nd->val);     /* a later line for the same read replaces the earlier one */
+            nd->val = v;
+        }
+        free(key);
+    }
+    /* Read_Meta_ICMs (:998-1027), Read_Meta_GC (:1389-1420), Read_Meta_Stops (:1211-1250): the classifications in the
+     * table's own order */
+    for (b = 0; b < c->classifications.n_buckets; b++) {
+        orc_sgi_node *ci;
+        for (ci = c->classifications.bucket[b]; ci; ci = ci->next) {
+            const orc_strlist *cl = (const orc_strlist *)ci->val;
+            char *icm_file = orc_classes_icm_name(c, cl);
+            char strain[512], nc[512], path[4096], line[4096];
+            orc_sgi_node *isi;
+            long i;
+            if (!icm_file) { orc_classes_free(c); return NULL; }
+            isi = orc_sgi_find(&c->icm_sequences, icm_file);
+            if (!isi) {
+                isi = orc_sgi_index(&c->icm_sequences, icm_file);
+                isi->val = calloc(1, sizeof(orc_strlist));
+            }
+            orc_strlist_push((orc_strlist *)isi->val, ci->key);
+            free(icm_file);
+            for (i = 0; i < cl->n; i++) {
+                FILE *fp;
+                float *g;
+                if (orc_sgi_find(&c->gc, cl->s[i])) continue;
+                if (orc_strain_nc(cl->s[i], strain, nc, sizeof strain)) { orc_classes_free(c); return NULL; }
+                snprintf(path, sizeof path, "%s/%s/%s.gc.txt", c->icm_dir, strain, nc);
+                g = (float *)malloc(sizeof(float));
+                fp = fopen(path, "r");
+                if (fp) {
+                    line[0] = 0;
+                    if (!fgets(line, sizeof line, fp)) line[0] = 0;
+                    *g = (float)strtod(line, NULL);     /* Sequence_GC holds floats */
+                    fclose(fp);
+                } else
+                    *g = 0.5f;                          /* "WARNING: GC classification file unavailable" */
+                orc_sgi_index(&c->gc, cl->s[i])->val = g;
+            }
+            if (!orc_sgi_find(&c->transl, cl->s[0])) {
+                FILE *fp;
+                int *code = (int *)malloc(sizeof(int));
+                *code = 11;
+                orc_strain_nc(cl->s[0], strain, nc, sizeof strain);
+                snprintf(path, sizeof path, "%s/%s/%s.gbk", c->icm_dir, strain, nc);
+                fp = fopen(path, "r");
+                if (fp) {
+                    while (fgets(line, sizeof line, fp)) {
+                        const char *tt = strstr(line, "transl_table=");
+                        if (tt) { *code = (int)strtol(tt + 13, NULL, 10); break; }
+                    }
+                    fclose(fp);
+                }
+                orc_sgi_index(&c->transl, cl->s[0])->val = code;
+            }
+        }
+    }
+    return c;
+}
+
+int orc_classes_n_icms(const orc_classes *c) { return (int)c->icm_sequences.n_elements; }
+
+/* ICM file k in the iteration order of ICM_Sequences (the loop of glimmer-mg.cc:361) */
+const char *orc_classes_icm_file(const orc_classes *c, int k)
+{
+    unsigned long b;
+    for (b = 0; b < c->icm_sequences.n_buckets; b++) {
+        const orc_sgi_node *nd;
+        for (nd = c->icm_sequences.bucket[b]; nd; nd = nd->next)
+            if (k-- == 0) return nd->key;
+    }
+    return NULL;
+}
+
+/* One chunk of the main loop (glimmer-mg.cc:326-375): Read_Indexes[prefix] = index for every read of the chunk, then ICM by
+ * ICM, read by read.  hdr: NUL-terminated header lines.  Returns the number of reads processed. */
+long orc_classes_plan(const orc_classes *c, const char *const *hdr, long n, long *order, long *icm_begin, double *gc,
+                      int *transl)
+{
+    orc_sgi_table read_index;
+    long i, k = 0, f = 0;
+    unsigned long b;
+    orc_sgi_init(&read_index);
+    for (i = 0; i < n; i++) {
+        const char *h = hdr[i];
+        char *key;
+        size_t b0 = 0, e;
+        while (h[b0] == ' ' || h[b0] == '\t' || h[b0] == '\n' || h[b0] == '\r') b0++;
+        e = b0;
+        while (h[e] && !(h[e] == ' ' || h[e] == '\t' || h[e] == '\n' || h[e] == '\r')) e++;
+        if (e == b0) continue;                          /* split (hdr)[0] of an empty vector: undefined in the reference */
+        key = (char *)malloc(e - b0 + 1);
+        memcpy(key, h + b0, e - b0);
+        key[e - b0] = 0;
+        orc_sgi_index(&read_index, key)->val = (void *)(size_t)(i + 1);     /* a later read of the same key wins */
+        free(key);
+    }
+    for (b = 0; b < c->icm_sequences.n_buckets; b++) {
+        const orc_sgi_node *nd;
+        for (nd = c->icm_sequences.bucket[b]; nd; nd = nd->next) {
+            const orc_strlist *reads = (const orc_strlist *)nd->val;
+            long r;
+            icm_begin[f++] = k;
+            for (r = 0; r < reads->n; r++) {
+                const orc_sgi_node *ri = orc_sgi_find(&read_index, reads->s[r]);
+                const orc_strlist *cl;
+                if (!ri) continue;
+                order[k] = (long)(size_t)ri->val - 1;
+                cl = (const orc_strlist *)orc_sgi_find(&c->classifications, reads->s[r])->val;
+                if (gc) {               /* Update_Meta_Null_ICM (:2058-2064) */
+                    const float num_classes = (float)cl->n;
+                    double g = 0.0;
+                    unsigned int s;
+                    for (s = 0; s < num_classes; s++) g += *(const float *)orc_sgi_find(&c->gc, cl->s[s])->val;
+                    g /= num_classes;
+                    gc[k] = g;
+                }
+                if (transl) transl[k] = *(const int *)orc_sgi_find(&c->transl, cl->s[0])->val;   /* Update_Meta_Stop (:2196) */
+                k++;
+            }
+        }
+    }
+    icm_begin[f] = k;
+    orc_sgi_free(&read_index, NULL);
+    return k;
+}
+
+/* Set_Stop_Codons_By_Code (src/Common/gene.cc:1560-1624); returns the number of codons, 0 for an unknown table */
+int orc_stop_codons_by_code(int code, const char *out[8])
+{
+    int n = 0;
+    switch (code) {
+    case 1: case 11: case 12: out[n++] = "taa"; out[n++] = "tag"; out[n++] = "tga"; break;
+    case 2: out[n++] = "taa"; out[n++] = "tag"; out[n++] = "aga"; out[n++] = "agg"; break;
+    case 3: case 4: case 5: case 9: case 10: case 13: case 21: out[n++] = "taa"; out[n++] = "tag"; break;
+    case 6: out[n++] = "tga"; break;
+    case 14: out[n++] = "tag"; break;
+    case 15: case 16: out[n++] = "taa"; out[n++] = "tga"; break;
+    case 22: out[n++] = "taa"; out[n++] = "tga"; out[n++] = "tca"; break;
+    case 23: out[n++] = "taa"; out[n++] = "tag"; out[n++] = "tga"; out[n++] = "tta"; break;
+    default: break;
+    }
+    return n;
+}
+
+/* Set_Ignore_Score_Len (src/Glimmer/glimmer_base.cc:2597-2633) */
+int orc_ignore_score_len(double gc_frac, const char *const *stop_codon, int n_stops)
+{
+    double poisson_lambda = 0.0;
+    int i, j;
+    for (i = 0; i < n_stops; i++) {
+        double x = 1.0;
+        for (j = 0; j < 3; j++)
+            if (stop_codon[i][j] == 'c' || stop_codon[i][j] == 'g') x *= gc_frac / 2.0;
+            else x *= (1.0 - gc_frac) / 2.0;
+        poisson_lambda += x;
+    }
+    return (int)(long)floor(3.0 * log(2.0 * 1000000 * poisson_lambda) / poisson_lambda);
+}

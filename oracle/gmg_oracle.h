@@ -175,6 +175,24 @@ double orc_mutual_info(const int32_t ct[16], int sum);
 orc_model *orc_train_model(const char *const *strings, int n_strings, int model_len, int model_depth,
                            int periodicity, float *mut_info);
 
+/* ---- glimmer-mg -c: which ICM file scores which read, in which order, with which null-model GC and stop codons ----
+ * Parse_Classes (src/Glimmer/glimmer-mg.cc:726-758), Read_Meta_ICMs :998-1027 with Classes_ICM_File :473-515 (stat on the
+ * double-ICM paths under icm_dir), Read_Meta_GC :1389-1420, Read_Meta_Stops :1211-1250.  The visiting order is the
+ * iteration order of libstdc++'s SGI hash table (<ext/hash_map>, not part of the reference tree): restated in gmg_oracle.c.
+ * NULL for a file the reference would crash on (a line without read or class, a class without '|'). */
+typedef struct orc_classes orc_classes;
+orc_classes *orc_classes_load(const char *text, long n, const char *icm_dir);
+void orc_classes_free(orc_classes *c);
+int orc_classes_n_icms(const orc_classes *c);
+const char *orc_classes_icm_file(const orc_classes *c, int k);    /* in the order of the loop of glimmer-mg.cc:361 */
+/* One chunk of the main loop (glimmer-mg.cc:326-375): hdr = header lines of the chunk's reads; order[k] = chunk index of the
+ * k-th processed read, icm_begin[n_icms + 1], gc[k] = Indep_GC_Frac (Update_Meta_Null_ICM :2050-2064), transl[k] =
+ * Genbank_Xlate_Code (Update_Meta_Stop :2196).  Returns the number of processed reads. */
+long orc_classes_plan(const orc_classes *c, const char *const *hdr, long n, long *order, long *icm_begin, double *gc,
+                      int *transl);
+int orc_stop_codons_by_code(int code, const char *out[8]);                        /* src/Common/gene.cc:1560-1624 */
+int orc_ignore_score_len(double gc_frac, const char *const *stop_codon, int n_stops);   /* glimmer_base.cc:2597-2633 */
+
 /* Fasta_Read (src/Common/fasta.cc:236-286) on a memory buffer.  Starts at *pos; returns 0 at the end of the
  * input, else 1 with the header extent [*hdr_begin, *hdr_end) in buf, the raw sequence characters (every
  * non-isspace byte up to the next '>') in seq[0 .. *seq_len) (seq needs room for n - *pos bytes), *pos advanced. */

@@ -118,6 +118,45 @@ class Oracle:
         L.orc_train_model.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
         for f in ("orc_filter", "orc_complement", "orc_subscript"):
             getattr(L, f).argtypes = [C.c_int]
+        L.orc_classes_load.restype = C.c_void_p
+        L.orc_classes_load.argtypes = [C.c_char_p, C.c_long, C.c_char_p]
+        L.orc_classes_free.argtypes = [C.c_void_p]
+        L.orc_classes_n_icms.argtypes = [C.c_void_p]
+        L.orc_classes_icm_file.restype = C.c_char_p
+        L.orc_classes_icm_file.argtypes = [C.c_void_p, C.c_int]
+        L.orc_classes_plan.restype = C.c_long
+        L.orc_classes_plan.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_long, lp, lp, dp, ip]
+        L.orc_stop_codons_by_code.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+        L.orc_ignore_score_len.argtypes = [C.c_double, C.POINTER(C.c_char_p), C.c_int]
+
+    # ---- glimmer-mg -c bookkeeping
+    def classes_load(self, text, icm_dir):
+        if isinstance(text, str):
+            text = text.encode()
+        return self.L.orc_classes_load(text, len(text), icm_dir.encode())       # None where the reference would crash
+
+    def classes_icm_files(self, c):
+        return [self.L.orc_classes_icm_file(c, k).decode() for k in range(self.L.orc_classes_n_icms(c))]
+
+    def classes_plan(self, c, headers):
+        n = len(headers)
+        arr = (C.c_char_p * max(n, 1))(*[h.encode() for h in headers])
+        order = np.zeros(max(n, 1), np.int64)
+        icm_begin = np.zeros(self.L.orc_classes_n_icms(c) + 1, np.int64)
+        gc = np.zeros(max(n, 1), np.float64)
+        transl = np.zeros(max(n, 1), np.int32)
+        k = self.L.orc_classes_plan(c, arr, n, order.ctypes.data_as(C.POINTER(C.c_long)), icm_begin.ctypes.data_as(C.POINTER(C.c_long)),
+                                    gc.ctypes.data_as(dp), transl.ctypes.data_as(C.POINTER(C.c_int)))
+        return order[:k], icm_begin, gc[:k], transl[:k]
+
+    def stop_codons_by_code(self, code):
+        out = (C.c_char_p * 8)()
+        n = self.L.orc_stop_codons_by_code(int(code), out)
+        return tuple(out[i].decode() for i in range(n))
+
+    def ignore_score_len(self, gc, stops=("taa", "tag", "tga")):
+        arr = (C.c_char_p * len(stops))(*[s.encode() for s in stops])
+        return self.L.orc_ignore_score_len(float(gc), arr, len(stops))
 
     # ---- models
     def read(self, path):
