@@ -196,6 +196,19 @@ class NullSet:
         self.h = C.c_void_p()
         _ck(capi.lib().gmg_null_set_upload(arr, len(self.icms), C.byref(self.h)))
 
+    @classmethod
+    def build(cls, gcs, stops=DEFAULT_STOPS):
+        """gmg_null_set_build: Build_Indep_WO_Stops (gc, stops) for every GC value, one upload"""
+        self = cls.__new__(cls)
+        gcs = np.ascontiguousarray(gcs, np.float64)
+        buf = ((C.c_char * 4) * 8)()
+        for i, c in enumerate(stops):
+            buf[i].value = c.encode()
+        self.icms = [Icm.indep(float(gcs[0]), stops)]    # (mg_score_reads wants a model object for the unused null argument)
+        self.h = C.c_void_p()
+        _ck(capi.lib().gmg_null_set_build(_ptr(gcs), len(gcs), buf, len(stops), C.byref(self.h)))
+        return self
+
     def close(self):
         if self.h:
             capi.lib().gmg_null_set_free(self.h)

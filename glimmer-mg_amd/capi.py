@@ -67,6 +67,8 @@ PROTOTYPES = {
     "gmg_frame_score6": (i32, [vp, vp, vp, vp, vp]),
     "gmg_frame_score6_strided": (i32, [vp, vp, vp, vp, u64, vp]),
     "gmg_null_set_upload": (i32, [vp, i32, C.POINTER(vp)]),
+    "gmg_null_set_from_tables": (i32, [vp, vp, i32, C.POINTER(vp)]),
+    "gmg_null_set_build": (i32, [vp, i32, vp, i32, C.POINTER(vp)]),
     "gmg_null_set_free": (i32, [vp]),
     "gmg_frame_score6_nulls": (i32, [vp, vp, vp, vp, vp, u64, vp]),
     "gmg_segment_frame_score": (i32, [vp, vp, vp, i32, vp, vp]),

@@ -403,6 +403,52 @@ extern "C" int gmg_null_set_upload(const gmg_model *const *models, int n, gmg_nu
     return GMG_OK;
 }
 
+// The same set straight from HOST tables: n models of shape (3,2,3), mip[i][3][21], prob4[i][3][21][4] as Build_Indep_WO_Stops
+// fills them (icm.cc:65-216).  The direct-lookup tables of all models are made on the host and go up in one copy -- a batch of
+// glimmer-mg's classification mode can need one null model per read (the mean GC of a read's classes takes many values).
+extern "C" int gmg_null_set_from_tables(const int16_t *mip, const float *prob4, int n, gmg_null_set **out)
+{
+    int rc = require_init("gmg_null_set_from_tables");
+    if (rc) return rc;
+    if (!mip || !prob4 || n < 1 || !out) return gmg_set_error(GMG_EINVAL, "gmg_null_set_from_tables: bad argument");
+    for (size_t i = 0; i < (size_t)n * 63; i++)
+        if (mip[i] < -2 || mip[i] > 2)
+            return gmg_set_error(GMG_EBADMODEL, "gmg_null_set_from_tables: mut_info_pos %d in model %zu outside [-2,2]", (int)mip[i], i / 63);
+    gmg_null_set *ns = new (std::nothrow) gmg_null_set();
+    if (!ns) return gmg_set_error(GMG_ENOMEM, "gmg_null_set_from_tables: out of host memory");
+    ns->d_tab = nullptr;
+    ns->n = n;
+    ns->min_exp = 255; ns->max_exp = 0; ns->odd_values = 0;
+    std::vector<float> tab((size_t)n * 252);
+    for (int i = 0; i < n; i++)
+        for (int p = 0; p < 3; p++) {
+            const int16_t *pm = mip + ((size_t)i * 3 + p) * 21;
+            const float *pp = prob4 + ((size_t)i * 3 + p) * 21 * 4;
+            float *full = tab.data() + (size_t)i * 252 + p * 64, *part = tab.data() + (size_t)i * 252 + 192 + p * 20;
+            for (uint32_t idx = 0; idx < 64; idx++) full[idx] = dense_entry(pm, pp, 3, 2, idx);
+            size_t o = 0;
+            for (int j = 0; j < 2; j++) {
+                const uint32_t cnt = 1u << (2 * (j + 1));
+                for (uint32_t idx = 0; idx < cnt; idx++) part[o + idx] = dense_part_entry(pm, pp, 3, 2, j, idx);
+                o += cnt;
+            }
+            for (int k = 0; k < 21 * 4; k++) {          // the exponent range of the values, as gmg_model_upload records it
+                uint32_t b;
+                memcpy(&b, pp + k, 4);
+                const uint32_t ex = (b >> 23) & 255u;
+                if ((b << 1) == 0) continue;
+                if ((b >> 31) == 0 || ex == 0 || ex == 255) ns->odd_values = 1;
+                if ((int)ex < ns->min_exp) ns->min_exp = (int)ex;
+                if ((int)ex > ns->max_exp) ns->max_exp = (int)ex;
+            }
+        }
+    hipError_t e = hipMalloc((void **)&ns->d_tab, tab.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(ns->d_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { gmg_null_set_free(ns); return gmg_set_error(GMG_EHIP, "gmg_null_set_from_tables: %s", hipGetErrorString(e)); }
+    *out = ns;
+    return GMG_OK;
+}
+
 extern "C" int gmg_null_set_free(gmg_null_set *ns)
 {
     if (!ns) return GMG_OK;

@@ -15,6 +15,7 @@
 // insertion at the head of a bucket, rehashing that reverses chains): it is reproduced here by USING that container --
 // <ext/hash_map> is part of the toolchain the reference itself needs -- not by imitating it.
 
+#include "icm.hh"
 #include "../../include/gmg.h"
 
 #define _GLIBCXX_PERMIT_BACKWARD_HASH 1
@@ -26,6 +27,7 @@
 #include <string.h>
 #include <string>
 #include <sys/stat.h>
+#include <thread>
 #include <vector>
 
 extern int gmg_set_error(int code, const char *fmt, ...);
@@ -281,4 +283,36 @@ extern "C" int gmg_ignore_score_len(double gc_frac, const char (*stop_codon)[4],
     if (poisson_lambda == 0.0) return gmg_set_error(GMG_EINVAL, "gmg_ignore_score_len: the stop codons have probability 0");
     *out = (int32_t)(long int)floor(3.0 * log(2.0 * 1000000 * poisson_lambda) / poisson_lambda);
     return GMG_OK;
+}
+
+// The null models of one ICM group: Indep_Model . Build_Indep_WO_Stops (gc, Stop_Codon) (glimmer-mg.cc:2066; icm.cc:65-216) for
+// every GC value of the list, with the host ICM_t of this library (its libm, like the reference's), on a few host threads,
+// and up to the device as one gmg_null_set.
+extern "C" int gmg_null_set_build(const double *gc_frac, int n, const char (*stop_codon)[4], int n_stop_codons, gmg_null_set **out)
+{
+    if (!gc_frac || n < 1 || !stop_codon || n_stop_codons < 1 || n_stop_codons > 8 || !out)
+        return gmg_set_error(GMG_EINVAL, "gmg_null_set_build: bad argument");
+    std::vector<const char *> stops;
+    for (int i = 0; i < n_stop_codons; i++) {
+        if (strlen(stop_codon[i]) != 3) return gmg_set_error(GMG_EINVAL, "gmg_null_set_build: stop codon %d is not 3 letters", i);
+        stops.push_back(stop_codon[i]);
+    }
+    std::vector<int16_t> mip((size_t)n * 63);
+    std::vector<float> prob((size_t)n * 63 * 4);
+    const int n_threads = n < 256 ? 1 : n < 4096 ? 4 : 16;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; t++)
+        pool.push_back(std::thread([&, t]() {
+            ICM_t m(3, 2, 3);
+            std::vector<short> mp;
+            std::vector<float> pp;
+            for (int i = (int)((long long)n * t / n_threads); i < (int)((long long)n * (t + 1) / n_threads); i++) {
+                m.Build_Indep_WO_Stops(gc_frac[i], stops);
+                m.Export_Tables(mp, pp);
+                memcpy(mip.data() + (size_t)i * 63, mp.data(), 63 * sizeof(int16_t));
+                memcpy(prob.data() + (size_t)i * 252, pp.data(), 252 * sizeof(float));
+            }
+        }));
+    for (size_t t = 0; t < pool.size(); t++) pool[t].join();
+    return gmg_null_set_from_tables(mip.data(), prob.data(), n, out);
 }

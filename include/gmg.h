@@ -182,6 +182,12 @@ int gmg_frame_score6_strided(const gmg_model *gene, const gmg_model *null_model,
  * null models where it builds its running sums, at no extra pass.) */
 typedef struct gmg_null_set gmg_null_set;
 int gmg_null_set_upload(const gmg_model *const *null_models, int n_models, gmg_null_set **out);
+/* The same set from HOST tables: mip[n][3][21], prob4[n][3][21][4] as Build_Indep_WO_Stops fills (3,2,3) models; one copy. */
+int gmg_null_set_from_tables(const int16_t *mip, const float *prob4, int n_models, gmg_null_set **out);
+/* ... or from the GC values themselves: model i = Build_Indep_WO_Stops (gc_frac[i], stop_codon) (src/ICM/icm.cc:65-216,
+ * the library's host ICM_t) -- what Update_Meta_Null_ICM (glimmer-mg.cc:2050-2068) builds per read. */
+int gmg_null_set_build(const double *gc_frac, int n_models, const char (*stop_codon)[4], int n_stop_codons,
+                       gmg_null_set **out);
 int gmg_null_set_free(gmg_null_set *nulls);
 int gmg_frame_score6_nulls(const gmg_model *gene, const gmg_null_set *nulls, const uint32_t *read_null,
                            const gmg_reads *reads, double *d_out, uint64_t row_stride, void *stream);

@@ -7,10 +7,18 @@
 //                                                                                             glimmer_base.cc:2564-2595)
 //     Score_All_Frames + Find_Orfs + Score_Orfs_Errors          -> gmg_mg_score_reads        (glimmer-mg.cc:1468-1510,
 //                                                                                             1605-1861; glimmer_base.cc:638-817)
-// Only the user-ICM mode (-m <icm>, no -c classifications) is driven; -i / -s / -q are.
+// Both modes are driven: -m <icm> (one gene ICM, one null model) and -c <class file> (classification mode: the ICM, the null
+// model and the stop codons follow every read's Phymm classes, reads are visited ICM by ICM -- glimmer-mg.cc:361-451 --;
+// the bookkeeping is the library's gmg_classes_*, one gmg_mg_score_reads call per ICM group and stop-codon set), each with
+// -i / -s / -q.
 //
-//     glimmer-mg_gpu [--shards N] [--gpus G] [--batch-bytes B] <glimmer-mg options> <fasta> <tag>
+//     glimmer-mg_gpu [--shards N] [--gpus G] [--batch-bytes B] [--icm-dir DIR] [--chunk-reads N]
+//                    <glimmer-mg options> <fasta> <tag>
 //
+// --icm-dir DIR   (-c) the Phymm .genomeData directory: the reference compiles it in as ICM_dir (glimmer-mg.cc:147,
+//              patched by install_glimmer.py:121); default: $GMG_ICM_DIR.  The visiting order depends on the hash of the whole
+//              file name, so the same string gives the same <tag>.predict as the reference built with it.
+// --chunk-reads N (-c) Chunk_Sequences (glimmer-mg.cc:128; default 500000): every chunk of N reads is visited ICM by ICM.
 // --shards N   the file is cut into N byte ranges at record starts (gmg_fasta_shard_ranges); N child processes are
 //              forked BEFORE anything touches a GPU, child k binds to device k mod G, ingests and scores its range and
 //              writes <tag>.predict.part<k>.  The one run-wide quantity, the null model's GC fraction
@@ -66,9 +74,16 @@ static void setup_options(int argc, char **argv)
     Parse_Command_Line(argc, argv);
     Set_Start_And_Stop_Codons();
     if (Feature_File != NULL) Parse_Features(Feature_File);
-    if (!User_ICM || !classifications.empty() || Detail_Log) {
-        fprintf(stderr, "glimmer-mg_gpu: only -m <icm> without -c / detail log is driven here\n");
+    if ((!User_ICM && classifications.empty()) || Detail_Log) {
+        fprintf(stderr, "glimmer-mg_gpu: need -m <icm> or -c <class file>; the detail log is not driven here\n");
         exit(2);
+    }
+    if (!classifications.empty()) {                     // glimmer-mg.cc:268-279: the per-class feature models (host side, the reference's)
+        if (!User_Length) Read_Meta_Lengths();
+        if (!User_Start) Read_Meta_Starts();
+        if (!User_Adj) { Read_Meta_AdjOr(); Read_Meta_AdjDist(); }
+        if (!User_Stop) Read_Meta_Stops();
+        if (!User_RBS) Read_Meta_RBS();                 // :313-316
     }
 }
 
@@ -83,9 +98,105 @@ static void setup_models(void)
     Gene_ICM.Read(ICM_File_Name);
 }
 
+// what one gmg_mg_score_reads call gives back, on the host
+struct Scored {
+    vector<gmg_mg_orf> orfs;
+    vector<gmg_start> starts;
+    vector<gmg_start_errors> errs;
+    vector<uint64_t> read_orf_off;
+};
+
+static void score_batch(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, uint64_t n_reads,
+                        const gmg_mg_params &prm, bool error_mode, Scored &sc)
+{
+    gmg_mg_result *res = NULL;
+    if (gmg_mg_score_reads(gene, nul, reads, &prm, NULL, &res, NULL) != GMG_OK) die_gmg("gmg_mg_score_reads");
+    uint64_t n_orfs = 0, n_starts = 0;
+    gmg_mg_result_info(res, &n_orfs, &n_starts);
+    sc.orfs.resize(n_orfs ? n_orfs : 1);
+    sc.starts.resize(n_starts ? n_starts : 1);
+    sc.read_orf_off.resize(n_reads + 1);
+    sc.errs.resize(error_mode ? (n_starts ? n_starts : 1) : 0);
+    if (gmg_mg_result_fetch(res, sc.orfs.data(), sc.starts.data(), sc.read_orf_off.data()) != GMG_OK) die_gmg("gmg_mg_result_fetch");
+    if (error_mode && gmg_mg_result_fetch_errors(res, sc.errs.data()) != GMG_OK) die_gmg("gmg_mg_result_fetch_errors");
+    gmg_mg_result_free(res);
+}
+
+// read i of a downloaded batch as glimmer-mg.cc:376-382 prepares it: the filtered lower-case sequence (back from the device)
+static void load_sequence(const vector<uint32_t> &packed, const vector<uint64_t> &off, uint64_t i)
+{
+    Sequence.resize(off[i + 1] - off[i]);
+    for (uint64_t k = 0; k < Sequence.size(); k++) {
+        const uint64_t g = off[i] + k;
+        Sequence[k] = "acgt"[(packed[g >> 4] >> (2 * (g & 15))) & 3];
+    }
+    Sequence_Len = Sequence.length();
+}
+
+// the reference's back half for the read in Fasta_Header / Sequence (glimmer-mg.cc:417-448): the accepted ORFs of read r of
+// the scored batch go to Add_Events_* as Score_Orfs_Errors hands them over (:1656-1683), then the DP and the trace-back
+static void back_half(FILE *predict_fp, const Scored &sc, uint64_t r, bool error_mode)
+{
+    Initialize_Terminal_Events(First_Event, Final_Event, Best_Event, Last_Event);
+    Meta_PWM_Save.resize(2 * Sequence_Len);                                // glimmer-mg.cc:1622-1627
+    for (unsigned int si = 0; si < 2 * Sequence_Len; si++) Meta_PWM_Save[si] = pair<double, int>(0.0, 999);
+    int id = 0;
+    for (uint64_t o = sc.read_orf_off[r]; o < sc.read_orf_off[r + 1]; o++) {
+        const gmg_mg_orf &g = sc.orfs[o];
+        if (!g.accepted) continue;
+        Orf_t orf;
+        orf.Set_Stop_Position(g.stop_position);
+        orf.Set_Frame(g.frame);
+        orf.Set_Gene_Len(g.gene_len);
+        orf.Set_Orf_Len(g.orf_len);
+        vector<Start_t> sl(g.n_starts);
+        for (uint32_t s = 0; s < g.n_starts; s++) {
+            const gmg_start &t = sc.starts[g.start_begin + s];
+            sl[s].j = t.j; sl[s].pos = t.pos; sl[s].score = t.score; sl[s].rate = 0.0; sl[s].which = t.which;
+            sl[s].truncated = t.truncated; sl[s].first = t.first;
+            if (error_mode) {
+                const gmg_start_errors &e = sc.errs[g.start_begin + s];
+                for (int k = 0; k < e.n; k++) sl[s].errors.push_back(Error_t(e.pos[k], e.type[k]));
+            }
+        }
+        std::sort(sl.begin(), sl.end(), Start_Cmp);                        // glimmer-mg.cc:1659: same algorithm on the same push order
+        if (g.accepted == 2) {                                             // ties on pos: first_j is the sort's to decide (:1661-1666)
+            const int first_j = g.frame > 0 ? sl.front().j : sl.back().j;
+            if (first_j + 1 < Min_Gene_Len) continue;
+        }
+        if (g.frame > 0) Add_Events_Fwd(orf, sl, id);
+        else Add_Events_Rev(orf, sl, id);
+    }
+    Process_Events();
+    Set_Final_Event(Final_Event, Best_Event, Sequence_Len);
+    Trace_Back(predict_fp, Final_Event);
+    Clear_Events();
+}
+
+static void fill_params(gmg_mg_params &prm, bool error_mode)
+{
+    memset(&prm, 0, sizeof prm);
+    prm.min_gene_len = Min_Gene_Len;
+    prm.allow_truncated = Allow_Truncated_Orfs;
+    prm.ignore_score_len = Ignore_Score_Len;
+    prm.start_threshold = Start_Threshold;
+    prm.flags = GMG_MG_ACCEPTED_ONLY;                   // only what Add_Events_* will see comes back
+    if (error_mode) {                                   // -i / -s: Score_Indels / the substitution branch run on the device too
+        prm.flags |= Allow_Indels ? GMG_MG_ALLOW_INDELS : GMG_MG_ALLOW_SUBS;
+        prm.min_indel_orf_len = Min_Indel_ORF_Len;
+        prm.indel_quality_threshold = Indel_Quality_Threshold;
+        prm.indel_max = Indel_Max;
+        prm.indel_suffix_score_threshold = Indel_Suffix_Score_Threshold;
+    }
+    prm.n_start_codons = Start_Codon.size();
+    prm.n_stop_codons = Stop_Codon.size();
+    for (size_t s = 0; s < Start_Codon.size() && s < 8; s++) memcpy(prm.start_codon[s], Start_Codon[s], 3);
+    for (size_t s = 0; s < Stop_Codon.size() && s < 8; s++) memcpy(prm.stop_codon[s], Stop_Codon[s], 3);
+}
+
 struct Piece {
     gmg_reads *reads;
-    uint64_t byte0, n_reads, total_bases;
+    uint64_t byte0, n_bytes, n_reads, total_bases;
     vector<uint64_t> hdr_begin, hdr_end;                // header extents, relative to the piece's first byte
 };
 
@@ -137,23 +248,7 @@ static int run_shard(const char *bytes, uint64_t b0, uint64_t b1, int device, ui
     setup_models();
 
     gmg_mg_params prm;
-    memset(&prm, 0, sizeof prm);
-    prm.min_gene_len = Min_Gene_Len;
-    prm.allow_truncated = Allow_Truncated_Orfs;
-    prm.ignore_score_len = Ignore_Score_Len;
-    prm.start_threshold = Start_Threshold;
-    prm.flags = GMG_MG_ACCEPTED_ONLY;                   // only what Add_Events_* will see comes back
-    if (error_mode) {                                   // -i / -s: Score_Indels / the substitution branch run on the device too
-        prm.flags |= Allow_Indels ? GMG_MG_ALLOW_INDELS : GMG_MG_ALLOW_SUBS;
-        prm.min_indel_orf_len = Min_Indel_ORF_Len;
-        prm.indel_quality_threshold = Indel_Quality_Threshold;
-        prm.indel_max = Indel_Max;
-        prm.indel_suffix_score_threshold = Indel_Suffix_Score_Threshold;
-    }
-    prm.n_start_codons = Start_Codon.size();
-    prm.n_stop_codons = Stop_Codon.size();
-    for (size_t s = 0; s < Start_Codon.size() && s < 8; s++) memcpy(prm.start_codon[s], Start_Codon[s], 3);
-    for (size_t s = 0; s < Stop_Codon.size() && s < 8; s++) memcpy(prm.stop_codon[s], Stop_Codon[s], 3);
+    fill_params(prm, error_mode);
     FILE *quality_fp = NULL;                            // -q: the values are read in file order, piece by piece
     if (Allow_Indels && Quality_File_Name != NULL) quality_fp = File_Open(Quality_File_Name, "r", __FILE__, __LINE__);
 
@@ -181,67 +276,18 @@ static int run_shard(const char *bytes, uint64_t b0, uint64_t b1, int device, ui
             }
             prm.quality = qual_all.data();
         }
-        gmg_mg_result *res = NULL;
-        if (gmg_mg_score_reads(Gene_ICM.Device_Model(), Indep_Model.Device_Model(), pc.reads, &prm, NULL, &res, NULL) != GMG_OK)
-            die_gmg("gmg_mg_score_reads");
-        uint64_t n_orfs = 0, n_starts = 0;
-        gmg_mg_result_info(res, &n_orfs, &n_starts);
-        vector<gmg_mg_orf> orfs(n_orfs ? n_orfs : 1);
-        vector<gmg_start> starts(n_starts ? n_starts : 1);
-        vector<uint64_t> read_orf_off(pc.n_reads + 1);
-        vector<gmg_start_errors> errs(error_mode ? (n_starts ? n_starts : 1) : 0);
-        if (gmg_mg_result_fetch(res, orfs.data(), starts.data(), read_orf_off.data()) != GMG_OK) die_gmg("gmg_mg_result_fetch");
-        if (error_mode && gmg_mg_result_fetch_errors(res, errs.data()) != GMG_OK) die_gmg("gmg_mg_result_fetch_errors");
-        gmg_mg_result_free(res);
+        Scored sc;
+        score_batch(Gene_ICM.Device_Model(), Indep_Model.Device_Model(), pc.reads, pc.n_reads, prm, error_mode, sc);
         gmg_reads_free(pc.reads);
         pc.reads = NULL;
 
         string hdr;
         for (int i = 0; i < n_seq; i++) {
-            // what glimmer-mg.cc:376-382 prepares per read: header, filtered lower-case sequence (back from the device)
             hdr.assign(bytes + pc.byte0 + pc.hdr_begin[i], pc.hdr_end[i] - pc.hdr_begin[i]);
             Fasta_Header = hdr.c_str();
-            Sequence.resize(off[i + 1] - off[i]);
-            for (uint64_t k = 0; k < Sequence.size(); k++) {
-                const uint64_t g = off[i] + k;
-                Sequence[k] = "acgt"[(packed[g >> 4] >> (2 * (g & 15))) & 3];
-            }
-            Sequence_Len = Sequence.length();
+            load_sequence(packed, off, i);
             fprintf(predict_fp, ">%s\n", Fasta_Header);
-            Initialize_Terminal_Events(First_Event, Final_Event, Best_Event, Last_Event);
-            Meta_PWM_Save.resize(2 * Sequence_Len);                        // glimmer-mg.cc:1622-1627
-            for (unsigned int si = 0; si < 2 * Sequence_Len; si++) Meta_PWM_Save[si] = pair<double, int>(0.0, 999);
-            int id = 0;
-            for (uint64_t o = read_orf_off[i]; o < read_orf_off[i + 1]; o++) {
-                const gmg_mg_orf &g = orfs[o];
-                if (!g.accepted) continue;
-                Orf_t orf;
-                orf.Set_Stop_Position(g.stop_position);
-                orf.Set_Frame(g.frame);
-                orf.Set_Gene_Len(g.gene_len);
-                orf.Set_Orf_Len(g.orf_len);
-                vector<Start_t> sl(g.n_starts);
-                for (uint32_t s = 0; s < g.n_starts; s++) {
-                    const gmg_start &t = starts[g.start_begin + s];
-                    sl[s].j = t.j; sl[s].pos = t.pos; sl[s].score = t.score; sl[s].rate = 0.0; sl[s].which = t.which;
-                    sl[s].truncated = t.truncated; sl[s].first = t.first;
-                    if (error_mode) {
-                        const gmg_start_errors &e = errs[g.start_begin + s];
-                        for (int k = 0; k < e.n; k++) sl[s].errors.push_back(Error_t(e.pos[k], e.type[k]));
-                    }
-                }
-                std::sort(sl.begin(), sl.end(), Start_Cmp);                // glimmer-mg.cc:1659: same algorithm on the same push order
-                if (g.accepted == 2) {                                     // ties on pos: first_j is the sort's to decide (:1661-1666)
-                    const int first_j = g.frame > 0 ? sl.front().j : sl.back().j;
-                    if (first_j + 1 < Min_Gene_Len) continue;
-                }
-                if (g.frame > 0) Add_Events_Fwd(orf, sl, id);
-                else Add_Events_Rev(orf, sl, id);
-            }
-            Process_Events();
-            Set_Final_Event(Final_Event, Best_Event, Sequence_Len);
-            Trace_Back(predict_fp, Final_Event);
-            Clear_Events();
+            back_half(predict_fp, sc, i, error_mode);
         }
     }
     fclose(predict_fp);
@@ -249,10 +295,289 @@ static int run_shard(const char *bytes, uint64_t b0, uint64_t b1, int device, ui
     return EXIT_SUCCESS;
 }
 
+// ---- classification mode (-c) -------------------------------------------------------------------------------------------
+// glimmer-mg.cc:326-451: the input is read in chunks of Chunk_Sequences reads; per chunk every ICM file is loaded in turn and
+// scores the reads classified to it, each against the null model and the stop codons of ITS classes.  Here, per chunk:
+// gmg_classes_plan gives the visiting order and every read's GC / translation table; the reads of an ICM group that share a
+// stop-codon set are gathered on the device (gmg_reads_select) and scored by ONE gmg_mg_score_reads call with a null model per
+// distinct GC (gmg_null_set_build, gmg_mg_params.read_null / read_ignore_score_len); the back half then runs read by read in
+// the reference's order with the reference's own Update_Meta_* in between.  With -m AND -c (glimmer-mg.py's --long-orfs path)
+// there is one group -- every read, in file order, under the user's ICM and the file's GC -- and only the stop codons vary.
+
+static uint64_t next_record_start(const char *bytes, uint64_t from, uint64_t n_bytes)
+{
+    // the first '>' at or behind `from` that directly follows a newline: always a record start (Fasta_Read, fasta.cc:236-286)
+    for (uint64_t q = from ? from : 1; q < n_bytes; q++) {
+        const char *hit = (const char *)memchr(bytes + q, '>', n_bytes - q);
+        if (hit == NULL) break;
+        q = (uint64_t)(hit - bytes);
+        if (bytes[q - 1] == '\n') return q;
+    }
+    return n_bytes;
+}
+
+// bytes [pos, *end) hold exactly `chunk_reads` reads (or all that are left): found by ingesting a guess and cutting at the
+// header of read number chunk_reads
+static void ingest_chunk(const char *bytes, uint64_t pos, uint64_t n_bytes, uint64_t chunk_reads, uint64_t guess_bytes, Piece &pc,
+                         uint64_t &gc_out)
+{
+    uint64_t want = guess_bytes;
+    for (;;) {
+        uint64_t end = pos + want >= n_bytes ? n_bytes : next_record_start(bytes, pos + want, n_bytes);
+        if (end - pos >= 0x7fffffffull) {
+            fprintf(stderr, "glimmer-mg_gpu: a chunk of %llu reads exceeds 2 GiB of input; use a smaller --chunk-reads\n",
+                    (unsigned long long)chunk_reads);
+            exit(EXIT_FAILURE);
+        }
+        gmg_fasta *index = NULL;
+        pc.byte0 = pos;
+        if (gmg_fasta_ingest(bytes + pos, end - pos, &pc.reads, &index) != GMG_OK) die_gmg("gmg_fasta_ingest");
+        gmg_fasta_info(index, &pc.n_reads, &pc.total_bases, &gc_out);
+        pc.hdr_begin.resize(pc.n_reads);
+        pc.hdr_end.resize(pc.n_reads);
+        if (pc.n_reads) gmg_fasta_headers(index, pc.hdr_begin.data(), pc.hdr_end.data());
+        gmg_fasta_free(index);
+        if (pc.n_reads == chunk_reads || (pc.n_reads < chunk_reads && end == n_bytes)) { pc.n_bytes = end - pos; return; }
+        if (pc.n_reads > chunk_reads) want = pc.hdr_begin[chunk_reads] - 1;    // the '>' of the first read that is one too many
+        else want *= 2;
+        gmg_reads_free(pc.reads);
+        pc.reads = NULL;
+        if (pc.n_reads > chunk_reads) {                 // exact now: [pos, pos + want) ends right in front of that '>'
+            gmg_fasta *ix = NULL;
+            if (gmg_fasta_ingest(bytes + pos, want, &pc.reads, &ix) != GMG_OK) die_gmg("gmg_fasta_ingest");
+            gmg_fasta_info(ix, &pc.n_reads, &pc.total_bases, &gc_out);
+            pc.hdr_begin.resize(pc.n_reads);
+            pc.hdr_end.resize(pc.n_reads);
+            if (pc.n_reads) gmg_fasta_headers(ix, pc.hdr_begin.data(), pc.hdr_end.data());
+            gmg_fasta_free(ix);
+            pc.n_bytes = want;
+            return;
+        }
+    }
+}
+
+struct SubBatch {                                       // the reads of one ICM group that share a stop-codon set
+    int code;                                           // translation table (0: the user's -z / -Z set)
+    vector<uint64_t> member;                            // positions in the group's read list
+    Scored sc;
+};
+
+static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t batch_bytes, const char *class_file,
+                       const string &icm_dir, const string &out_name)
+{
+    if (gmg_init(device) != GMG_OK) die_gmg("gmg_init");
+    const bool error_mode = Allow_Indels || Allow_Subs;
+    const uint64_t chunk_reads = (uint64_t)Chunk_Sequences;
+
+    // the class file once more, for the library's bookkeeping (the reference's own Parse_Classes filled `classifications`,
+    // which its Update_Meta_* functions read)
+    gmg_classes *cls = NULL;
+    {
+        FILE *fp = File_Open(class_file, "r", __FILE__, __LINE__);
+        string text;
+        char buf[1 << 16];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, got);
+        fclose(fp);
+        if (gmg_classes_load(text.data(), text.size(), icm_dir.c_str(), &cls) != GMG_OK) die_gmg("gmg_classes_load");
+    }
+    uint32_t n_icms = 0;
+    uint64_t missing_gc = 0;
+    gmg_classes_info(cls, NULL, &n_icms, NULL, &missing_gc);
+    if (missing_gc) fprintf(stderr, "WARNING: GC classification file unavailable for %llu classes (0.5 taken)\n", (unsigned long long)missing_gc);
+
+    // every chunk onto the device (0.25 B/base stays resident); with -m the null model needs the whole file's GC first
+    vector<Piece> chunks;
+    uint64_t gc = 0, total = 0;
+    for (uint64_t pos = 0; pos < n_bytes;) {
+        Piece pc;
+        uint64_t g = 0;
+        ingest_chunk(bytes, pos, n_bytes, chunk_reads, batch_bytes, pc, g);
+        gc += g;
+        total += pc.total_bases;
+        pos += pc.n_bytes;
+        if (pc.n_reads == 0) { gmg_reads_free(pc.reads); continue; }
+        chunks.push_back(pc);
+    }
+    if (User_ICM) {                                     // glimmer-mg.cc:283-296
+        if (!GC_Frac_Set) { Indep_GC_Frac = gmg_gc_fraction(&gc, &total, 1, 1); GC_Frac_Set = true; }
+        setup_models();
+    } else if (User_RBS) {                              // :305-312 (-b without -m needs Indep_GC_Frac as well)
+        if (!GC_Frac_Set) { Indep_GC_Frac = gmg_gc_fraction(&gc, &total, 1, 1); GC_Frac_Set = true; }
+        LogOdds_PWM = Ribosome_PWM;
+        LogOdds_PWM.Make_Log_Odds_WRT_GC(Indep_GC_Frac);
+    }
+    const double file_gc = Indep_GC_Frac;
+
+    FILE *quality_fp = NULL;
+    if (Allow_Indels && Quality_File_Name != NULL) quality_fp = File_Open(Quality_File_Name, "r", __FILE__, __LINE__);
+    FILE *predict_fp = File_Open(out_name, "w", __FILE__, __LINE__);
+    vector<const char *> user_stops(Stop_Codon);         // -z / -Z: one set for every read
+
+    for (size_t c = 0; c < chunks.size(); c++) {
+        Piece &pc = chunks[c];
+        const uint64_t n = pc.n_reads;
+        vector<uint64_t> off(n + 1);
+        vector<uint32_t> packed(gmg_packed_words(pc.total_bases) + 1, 0);
+        if (gmg_reads_download(pc.reads, packed.data(), off.data()) != GMG_OK) die_gmg("gmg_reads_download");
+        vector<uint8_t> qual_all;                       // -q: the chunk's Phred values, reads back to back
+        if (quality_fp) {
+            qual_all.reserve(pc.total_bases);
+            vector<int> q;
+            string header;
+            for (uint64_t i = 0; i < n; i++) {
+                Fasta_Qual_Vec_Read(quality_fp, q, header);
+                if (q.size() != off[i + 1] - off[i]) {
+                    fprintf(stderr, "ERROR:  %s sequence length does not match quality values length\n", header.c_str());
+                    return EXIT_FAILURE;
+                }
+                for (size_t k = 0; k < q.size(); k++) qual_all.push_back(q[k] > 255 ? 255 : q[k] < 0 ? 0 : q[k]);
+            }
+        }
+        // the plan of the chunk
+        vector<const char *> hdr(n);
+        vector<uint32_t> hdr_len(n);
+        for (uint64_t i = 0; i < n; i++) { hdr[i] = bytes + pc.byte0 + pc.hdr_begin[i]; hdr_len[i] = (uint32_t)(pc.hdr_end[i] - pc.hdr_begin[i]); }
+        vector<uint64_t> order(n ? n : 1), icm_begin(n_icms + 1);
+        vector<double> read_gc(n ? n : 1);
+        vector<int32_t> read_tt(n ? n : 1);
+        uint64_t n_order = 0;
+        if (gmg_classes_plan(cls, hdr.data(), hdr_len.data(), n, order.data(), icm_begin.data(), read_gc.data(), read_tt.data(), &n_order) != GMG_OK)
+            die_gmg("gmg_classes_plan");
+        uint32_t n_groups = n_icms;
+        if (User_ICM) {                                 // one group: every read in file order; classes give the stop codons only
+            vector<int32_t> tt_of(n, -1);
+            for (uint64_t k = 0; k < n_order; k++) tt_of[order[k]] = read_tt[k];
+            for (uint64_t i = 0; i < n; i++) {
+                if (tt_of[i] < 0) {                     // the reference indexes the empty class list of such a read (glimmer-mg.cc:2196)
+                    fprintf(stderr, "glimmer-mg_gpu: read %.*s has no line in the classification file (-m with -c needs one for every read)\n",
+                            (int)hdr_len[i], hdr[i]);
+                    return EXIT_FAILURE;
+                }
+                order[i] = i;
+                read_tt[i] = tt_of[i];
+                read_gc[i] = file_gc;
+            }
+            n_groups = 1;
+            icm_begin.assign(2, 0);
+            icm_begin[1] = n;
+        }
+
+        for (uint32_t f = 0; f < n_groups; f++) {
+            const uint64_t g0 = icm_begin[f], g1 = icm_begin[f + 1];
+            if (!User_ICM) {
+                // the reference loads every ICM of the class file for every chunk, used or not (glimmer-mg.cc:364); an unused one is
+                // not read here
+                if (g1 == g0) continue;
+                Gene_ICM.Read((char *)gmg_classes_icm_file(cls, f));
+            }
+            // sub-batches by stop-codon set, reads in group order
+            vector<SubBatch> sub;
+            vector<pair<uint32_t, uint64_t> > where(g1 - g0);          // group position -> (sub-batch, index in it)
+            for (uint64_t k = g0; k < g1; k++) {
+                const int code = User_Stop ? 0 : read_tt[k];
+                size_t b = 0;
+                while (b < sub.size() && sub[b].code != code) b++;
+                if (b == sub.size()) { sub.push_back(SubBatch()); sub[b].code = code; }
+                where[k - g0] = make_pair((uint32_t)b, (uint64_t)sub[b].member.size());
+                sub[b].member.push_back(k);
+            }
+            for (size_t b = 0; b < sub.size(); b++) {
+                SubBatch &sb = sub[b];
+                const uint64_t m = sb.member.size();
+                char stops[8][4];
+                int n_stops = 0;
+                memset(stops, 0, sizeof stops);
+                if (User_Stop) {
+                    n_stops = (int)user_stops.size();
+                    for (int t = 0; t < n_stops && t < 8; t++) memcpy(stops[t], user_stops[t], 3);
+                } else if (gmg_stop_codons_by_code(sb.code, stops, &n_stops) != GMG_OK) {
+                    fprintf(stderr, "%s\n", gmg_last_error());       // Set_Stop_Codons_By_Code's message (gene.cc:1618)
+                    return EXIT_FAILURE;
+                }
+                // a null model per distinct GC, Ignore_Score_Len per read (Update_Meta_Null_ICM, glimmer-mg.cc:2050-2068)
+                vector<double> gcs;
+                vector<uint32_t> read_null(m);
+                vector<int32_t> read_isl(m);
+                vector<uint64_t> idx(m);
+                std::map<uint64_t, uint32_t> seen;
+                for (uint64_t r = 0; r < m; r++) {
+                    const uint64_t k = sb.member[r];
+                    idx[r] = order[k];
+                    uint64_t bits;
+                    memcpy(&bits, &read_gc[k], 8);
+                    std::map<uint64_t, uint32_t>::iterator it = seen.find(bits);
+                    if (it == seen.end()) { it = seen.insert(make_pair(bits, (uint32_t)gcs.size())).first; gcs.push_back(read_gc[k]); }
+                    read_null[r] = it->second;
+                    if (gmg_ignore_score_len(read_gc[k], stops, n_stops, &read_isl[r]) != GMG_OK) die_gmg("gmg_ignore_score_len");
+                }
+                gmg_null_set *nulls = NULL;
+                if (gmg_null_set_build(gcs.data(), (int)gcs.size(), stops, n_stops, &nulls) != GMG_OK) die_gmg("gmg_null_set_build");
+                gmg_reads *batch = NULL;
+                if (gmg_reads_select(pc.reads, idx.data(), m, &batch) != GMG_OK) die_gmg("gmg_reads_select");
+                gmg_mg_params prm;
+                fill_params(prm, error_mode);
+                prm.n_stop_codons = n_stops;
+                memcpy(prm.stop_codon, stops, sizeof stops);
+                prm.nulls = nulls;
+                prm.read_null = read_null.data();
+                prm.read_ignore_score_len = read_isl.data();
+                vector<uint8_t> qual;
+                if (quality_fp) {
+                    for (uint64_t r = 0; r < m; r++) qual.insert(qual.end(), qual_all.begin() + off[idx[r]], qual_all.begin() + off[idx[r] + 1]);
+                    prm.quality = qual.data();
+                }
+                ICM_t any_null(3, 2, 3);                // the null_model argument is not read when params.nulls is set, but must be a model
+                {
+                    vector<const char *> sv;
+                    for (int t = 0; t < n_stops; t++) sv.push_back(stops[t]);
+                    any_null.Build_Indep_WO_Stops(gcs[0], sv);
+                }
+                score_batch(Gene_ICM.Device_Model(), any_null.Device_Model(), batch, m, prm, error_mode, sb.sc);
+                gmg_reads_free(batch);
+                gmg_null_set_free(nulls);
+            }
+            // the back half, read by read in the reference's order (glimmer-mg.cc:367-450)
+            string hs;
+            for (uint64_t k = g0; k < g1; k++) {
+                const uint64_t i = order[k];
+                hs.assign(hdr[i], hdr_len[i]);
+                Fasta_Header = hs.c_str();
+                load_sequence(packed, off, i);
+                fprintf(predict_fp, ">%s\n", Fasta_Header);
+                if (!User_RBS) Update_Meta_RBS();
+                if (!User_Length) Update_Meta_Length();
+                if (!User_Start) Update_Meta_Start();
+                if (!User_Adj) Update_Meta_Adj();
+                if (!User_Stop) Update_Meta_Stop();
+                const SubBatch &sb = sub[where[k - g0].first];
+                if (!User_ICM) {                        // what Update_Meta_Null_ICM leaves in the globals the back half reads
+                    Indep_GC_Frac = read_gc[k];
+                    int32_t isl = 0;
+                    char st[8][4];
+                    int ns = 0;
+                    memset(st, 0, sizeof st);
+                    for (size_t t = 0; t < Stop_Codon.size() && t < 8; t++, ns++) memcpy(st[t], Stop_Codon[t], 3);
+                    gmg_ignore_score_len(read_gc[k], st, ns, &isl);
+                    Ignore_Score_Len = isl;
+                }
+                back_half(predict_fp, sb.sc, where[k - g0].second, error_mode);
+            }
+        }
+        gmg_reads_free(pc.reads);
+        pc.reads = NULL;
+    }
+    fclose(predict_fp);
+    if (quality_fp) fclose(quality_fp);
+    gmg_classes_free(cls);
+    return EXIT_SUCCESS;
+}
+
 int main(int argc, char **argv)
 {
     int n_shards = 1, n_gpus = 1;
     uint64_t batch_bytes = DEFAULT_BATCH_BYTES;
+    string icm_dir = getenv("GMG_ICM_DIR") ? getenv("GMG_ICM_DIR") : "";
     if (const char *e = getenv("GMG_GPUS")) n_gpus = atoi(e);
     // our own options come first; the rest is glimmer-mg's command line, untouched
     vector<char *> rest(1, argv[0]);
@@ -261,6 +586,8 @@ int main(int argc, char **argv)
         if (strcmp(argv[a], "--shards") == 0) n_shards = atoi(argv[a + 1]);
         else if (strcmp(argv[a], "--gpus") == 0) n_gpus = atoi(argv[a + 1]);
         else if (strcmp(argv[a], "--batch-bytes") == 0) batch_bytes = strtoull(argv[a + 1], NULL, 10);
+        else if (strcmp(argv[a], "--icm-dir") == 0) icm_dir = argv[a + 1];
+        else if (strcmp(argv[a], "--chunk-reads") == 0) Chunk_Sequences = atoi(argv[a + 1]);
         else break;
     }
     for (; a < argc; a++) rest.push_back(argv[a]);
@@ -268,7 +595,28 @@ int main(int argc, char **argv)
         fprintf(stderr, "usage: glimmer-mg_gpu [--shards N] [--gpus G] [--batch-bytes B < 2^31] <glimmer-mg options> <fasta> <tag>\n");
         return 2;
     }
+    if (Chunk_Sequences < 1) { fprintf(stderr, "glimmer-mg_gpu: --chunk-reads must be positive\n"); return 2; }
+    // -c <file> / -c<file> / --class <file> / --class=<file> (getopt_long, glimmer-mg.cc:777-801): the library parses the file too
+    const char *class_file = NULL;
+    for (size_t k = 1; k < rest.size(); k++) {
+        const char *w = rest[k];
+        if (strcmp(w, "--") == 0) break;
+        if (strncmp(w, "--class=", 8) == 0) class_file = w + 8;
+        else if (strcmp(w, "--class") == 0 && k + 1 < rest.size()) class_file = rest[++k];
+        else if (w[0] == '-' && w[1] != '-' && w[1] != 0) {
+            for (const char *o = w + 1; *o; o++) {
+                if (strchr("bcfgmoPquzZ", *o) == NULL) continue;        // a flag without an argument: the next letter
+                const char *val = o[1] ? o + 1 : (k + 1 < rest.size() ? rest[++k] : NULL);
+                if (*o == 'c') class_file = val;
+                break;
+            }
+        }
+    }
     try {
+        if (class_file != NULL) {
+            if (icm_dir.empty()) { fprintf(stderr, "glimmer-mg_gpu: -c needs --icm-dir DIR (or GMG_ICM_DIR): the Phymm .genomeData directory\n"); return 2; }
+            ICM_dir = icm_dir;                          // glimmer-mg.cc:147: what the reference's Read_Meta_* open
+        }
         setup_options((int)rest.size(), rest.data());
         if (n_shards > 1 && Quality_File_Name != NULL) {
             fprintf(stderr, "glimmer-mg_gpu: -q with --shards > 1 is not supported (the quality file is read in order)\n");
@@ -283,6 +631,10 @@ int main(int argc, char **argv)
         if (bytes == MAP_FAILED) { perror("mmap"); return EXIT_FAILURE; }
         const string out = string(Output_Tag) + ".predict";
         const int env_dev = getenv("GMG_DEVICE") ? atoi(getenv("GMG_DEVICE")) : 0;
+        if (!classifications.empty()) {
+            if (n_shards > 1) { fprintf(stderr, "glimmer-mg_gpu: -c with --shards > 1 is not supported yet\n"); return 2; }
+            return run_classes(bytes, n_bytes, env_dev, batch_bytes, class_file, icm_dir, out);
+        }
         if (n_shards == 1) return run_shard(bytes, 0, n_bytes, env_dev, batch_bytes, -1, -1, out);
 
         vector<uint64_t> cuts(n_shards + 1);

@@ -1,0 +1,182 @@
+"""glimmer-mg's classification mode (-c, SURVEY 8(f) #3: the ICM-grouped loop, glimmer-mg.cc:361-451) end to end on the device:
+
+  * integration/glimmer-mg_gpu -c writes <tag>.predict byte for byte as the REAL reference did (tests/golden/predict/classes.*:
+    the reference's own main() over the synthetic .genomeData tree, six option sets incl. -i, -s, chunks of 250 reads, and
+    -m together with -c);
+  * the product's loop in Python -- gmg_classes_plan -> per ICM group and stop-codon set ONE gmg_mg_score_reads with a null
+    model per distinct GC (gmg_null_set_build) and Ignore_Score_Len per read -- gives, for every processed read in the
+    reference's order, the ORFs of the reference's Find_Orfs and, for every ORF the reference handed to Add_Events_*, its start
+    list in the order Score_Orf_Starts pushed it (scores bit for bit, Error_t lists with -i / -s);
+  * the same loop against the oracle (its own plan, its own scoring) for EVERY ORF of every read."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLD, built_binary
+
+sys.path.insert(0, GOLD)
+import make_genome_data  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def genome_data(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("genomeData"))
+    mixed = make_genome_data.write_class_variants(d)
+    make_genome_data.build(os.path.join(d, ".genomeData"), [os.path.join(DATA, "seqs.class.txt"), mixed])
+    return d
+
+
+@pytest.fixture(autouse=True)
+def in_genome_data_dir(genome_data, monkeypatch):
+    monkeypatch.chdir(genome_data)                      # ICM_dir = ".genomeData", as the goldens were made (the order depends on the name)
+
+
+CLI_CASES = [
+    ("default", [], "seqs.class.txt", None), ("indel", ["-i"], "seqs.class.txt", None), ("g90", ["-g", "90"], "seqs.class.txt", None),
+    ("mixed_chunks", [], "mixed.class.txt", 250), ("mixed_sub", ["-s"], "mixed.class.txt", None),
+    ("user_icm", ["-m", os.path.join(DATA, "NC_000915.icm")], "seqs.class.txt", None),
+]
+
+
+@pytest.mark.parametrize("name,flags,cls,chunk", CLI_CASES)
+def test_glimmer_mg_gpu_classification_mode_is_byte_identical(gpu, tmp_path, name, flags, cls, chunk):
+    exe = built_binary("integration", "_build", "glimmer-mg_gpu")
+    tag = str(tmp_path / "out")
+    own = ["--icm-dir", ".genomeData"] + (["--chunk-reads", str(chunk)] if chunk else [])
+    cmd = [exe, *own, *flags, "-c", os.path.join(DATA, cls), os.path.join(DATA, "seqs.fa"), tag]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", "classes.%s.predict" % name), "rb").read()
+
+
+def chunks(n, size):
+    return [(b, min(n, b + size)) for b in range(0, n, size)] if size else [(0, n)]
+
+
+def score_groups(gpu, cls, hdrs, seqs, chunk, models, **kw):
+    """the product's -c loop: yields, per processed read in the reference's order,
+    (chunk-global read index, gc, stops, isl, orfs, starts, errs-or-None) -- one gmg_mg_score_reads per (ICM, stop set)"""
+    err = bool(kw.get("allow_indels") or kw.get("allow_subs"))
+    for b, e in chunks(len(hdrs), chunk):
+        reads = gpu.Reads.from_strings(seqs[b:e])
+        order, icm_begin, gc, transl = cls.plan(hdrs[b:e])
+        for f in range(cls.n_icms):
+            g0, g1 = int(icm_begin[f]), int(icm_begin[f + 1])
+            if g0 == g1:
+                continue
+            path = os.path.realpath(cls.icm_file(f))
+            if path not in models:
+                models[path] = gpu.Icm.open(path)
+            per_read = {}
+            for code in sorted(set(transl[g0:g1].tolist())):
+                ks = [k for k in range(g0, g1) if transl[k] == code]
+                stops = gpu.api.stop_codons_by_code(code)
+                ugc, inv = np.unique(gc[ks], return_inverse=True)
+                isl = np.array([gpu.api.ignore_score_len(gc[k], stops) for k in ks], np.int32)
+                batch = reads.select([int(order[k]) for k in ks])
+                res = gpu.mg_score_reads(models[path], gpu.NullSet.build(ugc, stops), batch, read_null=inv.astype(np.uint32),
+                                         read_ignore_score_len=isl, stop_codons=stops, **kw)
+                for r, k in enumerate(ks):
+                    o = res[0][int(res[2][r]):int(res[2][r + 1])]
+                    per_read[k] = (b + int(order[k]), float(gc[k]), stops, int(isl[r]), o, res[1], res[3] if err else None)
+            for k in range(g0, g1):
+                yield per_read[k]
+
+
+@pytest.mark.parametrize("name", ["default", "indel", "g90", "mixed_chunks", "mixed_sub"])
+def test_grouped_scoring_equals_the_reference_read_by_read(gpu, seqs_fa, genome_data, name):
+    g = np.load(os.path.join(GOLD, "classes_%s.npz" % name))
+    flags = str(g["flags"]).split()
+    kw = dict(allow_indels="-i" in flags, allow_subs="-s" in flags)
+    if "-g" in flags:
+        kw["min_gene_len"] = int(flags[flags.index("-g") + 1])
+    hdrs, seqs = seqs_fa
+    cls = gpu.api.Classes(open(os.path.join(DATA, str(g["class_file"]))).read(), ".genomeData")
+    acc_of = {}
+    for a, r in enumerate(g["acc_read"]):
+        acc_of.setdefault(int(r), []).append(a)
+    n_lists = n_starts = 0
+    k = -1
+    for k, (ri, gc, stops, isl, orfs, starts, errs) in enumerate(score_groups(gpu, cls, hdrs, seqs, int(g["chunk"]), {}, **kw)):
+        assert hdrs[ri].split()[0] == str(g["reads"][k])
+        assert (gc, ",".join(stops), isl) == (float(g["gc"][k]), str(g["stops"][k]), int(g["isl"][k]))
+        want = g["orfs"][int(g["orf_off"][k]):int(g["orf_off"][k + 1])]
+        got = np.stack([orfs["frame"], orfs["stop_position"], orfs["gene_len"], orfs["orf_len"]], 1).reshape(-1, 4)
+        assert np.array_equal(got, want), (name, k)                           # Find_Orfs with this read's stop codons
+        if k >= int(g["list_reads"]):
+            continue
+        mine = [o for o in orfs if o["accepted"]]
+        assert [(int(o["frame"]), int(o["stop_position"]), int(o["n_starts"])) for o in mine] == \
+               [tuple(int(x) for x in g["acc"][a]) for a in acc_of.get(k, [])], (name, k)
+        for o, a in zip(mine, acc_of.get(k, [])):
+            sl = slice(int(o["start_begin"]), int(o["start_begin"]) + int(o["n_starts"]))
+            gl = slice(int(g["st_off"][a]), int(g["st_off"][a + 1]))
+            st = starts[sl]
+            assert np.array_equal(st["j"], g["st_j"][gl]) and np.array_equal(st["pos"], g["st_pos"][gl])
+            assert np.array_equal(st["score"], g["st_score"][gl])                  # doubles, bit for bit
+            assert np.array_equal(st["which"], g["st_which"][gl]) and np.array_equal(st["truncated"], g["st_trunc"][gl])
+            assert np.array_equal(st["first"], g["st_first"][gl])
+            if errs is not None:
+                e = errs[sl]
+                assert np.array_equal(e["n"], g["st_nerr"][gl])
+                for c in range(2):
+                    used = g["st_nerr"][gl] > c
+                    assert np.array_equal(e["pos"][:, c][used], g["st_epos"][gl][:, c][used])
+                    assert np.array_equal(e["type"][:, c][used], g["st_etype"][gl][:, c][used])
+            n_lists += 1
+            n_starts += gl.stop - gl.start
+    assert k + 1 == len(g["reads"]) and n_lists == len(g["acc"]) and n_starts == len(g["st_j"])
+
+
+def test_grouped_scoring_equals_the_oracle_for_every_orf(gpu, oracle, seqs_fa, genome_data):
+    """the oracle end to end: its own plan (orc_classes_*), its own null model per read, its own Score_Orf_Starts -- against the
+    product's grouped calls, every ORF of every processed read of mixed.class.txt in chunks of 300"""
+    hdrs, seqs = seqs_fa
+    text = open(os.path.join(DATA, "mixed.class.txt")).read()
+    cls = gpu.api.Classes(text, ".genomeData")
+    oc = oracle.classes_load(text, ".genomeData")
+    o_files = oracle.classes_icm_files(oc)
+    want_order = []
+    for b, e in chunks(len(hdrs), 300):
+        order, icm_begin, gc, transl = oracle.classes_plan(oc, hdrs[b:e])
+        for f in range(len(o_files)):
+            for k in range(int(icm_begin[f]), int(icm_begin[f + 1])):
+                want_order.append((b + int(order[k]), float(gc[k]), int(transl[k]), os.path.realpath(o_files[f])))
+    o_models, n_orfs, n_starts, n_acc = {}, 0, 0, 0
+    got = list(score_groups(gpu, cls, hdrs, seqs, 300, {}))
+    assert len(got) == len(want_order) > 800
+    for (ri, gc, stops, isl, orfs, starts, _), (w_ri, w_gc, w_tt, w_path) in zip(got, want_order):
+        assert (ri, gc) == (w_ri, w_gc) and stops == oracle.stop_codons_by_code(w_tt)
+        assert isl == oracle.ignore_score_len(w_gc, stops)
+        if w_path not in o_models:
+            o_models[w_path] = oracle.read(w_path)
+        prm = oracle.mg_params(ignore_score_len=isl, stop_codons=stops)
+        want_orfs, scored = oracle.mg_read(o_models[w_path], oracle.indep(w_gc, stops), seqs[ri].encode(), prm)
+        assert np.array_equal(np.stack([orfs["frame"], orfs["stop_position"], orfs["gene_len"], orfs["orf_len"]], 1).reshape(-1, 4), want_orfs)
+        for o, (out, want) in zip(orfs, scored):
+            st = starts[o["start_begin"]:o["start_begin"] + o["n_starts"]]
+            assert [(s["j"], s["pos"], s["which"], s["truncated"], s["first"], s["score"]) for s in st] == \
+                   [(w.j, w.pos, w.which, w.truncated, w.first, w.score) for w in want]
+            assert (o["first_j"], bool(o["accepted"]), o["best_score"]) == (out.first_j, bool(out.accepted), out.best_score)
+            n_starts += len(want)
+            n_acc += int(out.accepted)
+        n_orfs += len(orfs)
+    assert n_orfs > 5000 and n_starts > 10000 and n_acc > 500
+    oracle.L.orc_classes_free(oc)
+
+
+def test_null_set_build_equals_uploaded_models(gpu, seqs_fa):
+    """gmg_null_set_build (tables made on the host, one copy) = gmg_null_set_upload of the same models one by one"""
+    nc = gpu.Icm.open(os.path.join(DATA, "NC_000915.icm"))
+    reads = gpu.Reads.from_strings(seqs_fa[1][:64])
+    gcs = np.linspace(0.21, 0.79, 300)
+    rn = (np.arange(64) * 7 % 300).astype(np.uint32)
+    for stops in (("taa", "tag", "tga"), ("taa", "tag"), ("tga",)):
+        a = gpu.frame_score6(nc, gpu.NullSet.build(gcs, stops), reads, read_null=rn)
+        b = gpu.frame_score6(nc, gpu.NullSet([gpu.Icm.indep(float(x), stops) for x in gcs]), reads, read_null=rn)
+        assert a.tobytes() == b.tobytes()

@@ -152,6 +152,45 @@ def test_fused_form_refuses_models_whose_values_could_make_the_order_matter(gpu,
             assert got[r, 0] == oracle.score_string(m, s_, 0) and got[r, 1] == oracle.score_string(m, revcomp(s_), 0), (path.name, r)
 
 
+def test_zero_probability_leaves_on_uniform_batches(gpu, oracle, tmp_path):
+    """-FLT_MAX (the logarithm of a zero probability, icm.cc:1345-1349) in LEAF rows, batches of ONE read length >= 192: the
+    uniform path of the fused form moves the share of a read that ends inside a row of 16 lanes through the next read's
+    accumulator, which a value of that size would swamp -- such a model (exponent range > 23) must take the two-pass form.
+    Every read against the oracle, and the fused switch changes nothing."""
+    src = os.path.join(DATA, "cluster-2.icm")
+    raw = bytearray(open(src, "rb").read())
+    n_rec = (len(raw) - 174 - 4) // 22
+    rng = np.random.default_rng(44)
+    hit = 0
+    for r in rng.permutation(n_rec)[:3000]:
+        off = 174 + 22 * int(r)
+        (nid,) = np.frombuffer(raw, "<i4", 1, off)
+        if nid >= 5461:                                 # a leaf of the depth-7 tree
+            v = np.frombuffer(raw, "<f4", 4, off + 4).copy()
+            v[int(rng.integers(0, 4))] = np.float32(-3.4028234663852886e38)
+            raw[off + 4:off + 20] = v.tobytes()
+            hit += 1
+    assert hit > 1000
+    path = tmp_path / "zero_leaves.icm"
+    path.write_bytes(bytes(raw))
+    m, om = gpu.Icm.open(str(path)), oracle.read(str(path))
+    for L in (192, 250, 500):
+        codes = rng.integers(0, 4, size=(400, L))
+        seqs = ["".join("acgt"[c] for c in row) for row in codes]
+        reads = gpu.Reads.from_strings(seqs)
+        with gpu.option("strings_fused", 1):
+            a = gpu.score_reads_strings([m], reads)[0]
+        with gpu.option("strings_fused", 0):
+            b = gpu.score_reads_strings([m], reads)[0]
+        assert a.tobytes() == b.tobytes()
+        n_huge = 0
+        for r, s_ in enumerate(seqs):
+            want = (oracle.score_string(om, s_, 0), oracle.score_string(om, revcomp(s_), 0))
+            assert (a[r, 0], a[r, 1]) == want, (L, r)
+            n_huge += int(want[0] < -1e38) + int(want[1] < -1e38)
+        assert n_huge > 20                              # reads that met a zero probability, and their neighbours, are all right
+
+
 def test_configs3_shape_ten_million_reads_64_models_in_pieces(gpu, oracle):
     """BASELINE configs[3]: 10M reads x 64 Phymm ICMs.  Ten pieces of 1M x 500 bp, 64 models per call (the six sample-run
     ICMs in turn): determinism (first piece twice), model repeats agree, sampled (read, model) pairs of every piece --
