@@ -562,7 +562,7 @@ def mg_score_reads(gene, null, reads, min_gene_len=75, allow_truncated=True, ign
                    start_threshold=-6.0, start_codons=("atg", "gtg", "ttg"), stop_codons=("taa", "tag", "tga"),
                    frame_scores=None, accepted_only=False, allow_indels=False, allow_subs=False, quality=None,
                    min_indel_orf_len=15, indel_quality_threshold=18, indel_max=2, indel_suffix_score_threshold=-12.0,
-                   read_null=None, read_ignore_score_len=None):
+                   read_null=None, read_ignore_score_len=None, groups=None):
     """glimmer-mg's front half for a batch of reads (include/gmg.h: gmg_mg_score_reads): Score_All_Frames,
     Find_Orfs, Score_Orf_Starts and the filter of Score_Orfs_Errors.
     -> (orfs[MG_ORF_DTYPE], starts[START_DTYPE], read_orf_off[uint64 n_reads+1]).
@@ -597,8 +597,12 @@ def mg_score_reads(gene, null, reads, min_gene_len=75, allow_truncated=True, ign
             prm.read_ignore_score_len = read_ignore_score_len.ctypes.data
         null_model = null.icms[0]
     res = C.c_void_p()
-    _ck(capi.lib().gmg_mg_score_reads(gene.device(), null_model.device(), reads.h, C.byref(prm),
-                                      frame_scores.ptr if frame_scores is not None else None, C.byref(res), None))
+    if groups is not None:                              # gmg_mg_score_groups: [(Icm, read_begin, read_end), ...], `gene` is not used
+        arr = (capi.MgGroup * max(len(groups), 1))(*[capi.MgGroup(m.device(), int(b), int(e)) for m, b, e in groups])
+        _ck(capi.lib().gmg_mg_score_groups(arr, len(groups), null_model.device(), reads.h, C.byref(prm), C.byref(res), None))
+    else:
+        _ck(capi.lib().gmg_mg_score_reads(gene.device(), null_model.device(), reads.h, C.byref(prm),
+                                          frame_scores.ptr if frame_scores is not None else None, C.byref(res), None))
     try:
         n_orfs, n_starts = C.c_uint64(), C.c_uint64()
         _ck(capi.lib().gmg_mg_result_info(res, C.byref(n_orfs), C.byref(n_starts)))

@@ -16,6 +16,10 @@ class Segment(C.Structure):
     _fields_ = [("read", C.c_uint32), ("lo", C.c_uint32), ("len", C.c_uint32), ("orient", C.c_uint32)]
 
 
+class MgGroup(C.Structure):
+    _fields_ = [("gene", C.c_void_p), ("read_begin", C.c_uint64), ("read_end", C.c_uint64)]
+
+
 class OrfParams(C.Structure):
     _fields_ = [("min_gene_len", C.c_int32), ("allow_truncated", C.c_int32), ("use_first_start", C.c_int32),
                 ("ignore_score_len", C.c_int32), ("start_threshold", C.c_double), ("n_start_codons", C.c_int32),
@@ -78,6 +82,7 @@ PROTOTYPES = {
     "gmg_all_frame_score": (i32, [vp, vp, vp, vp, vp, vp, vp]),
     "gmg_window_distrib": (i32, [vp, vp, vp, u64, vp, vp, vp]),
     "gmg_mg_score_reads": (i32, [vp, vp, vp, vp, vp, C.POINTER(vp), vp]),
+    "gmg_mg_score_groups": (i32, [vp, i32, vp, vp, vp, C.POINTER(vp), vp]),
     "gmg_find_orfs": (i32, [vp, vp, C.POINTER(vp), vp]),
     "gmg_mg_result_info": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
     "gmg_mg_result_fetch": (i32, [vp, vp, vp, vp]),

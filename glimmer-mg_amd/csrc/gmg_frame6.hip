@@ -26,6 +26,7 @@
 
 #include "gmg_device.h"
 #include <stdlib.h>
+#include <vector>
 
 #ifndef GMG_F6_STAMPS
 #define GMG_F6_STAMPS 0         // diagnostic build: per-wave cycle counts of the phases of a round (tools/f6_stamps.py); not in the product
@@ -56,7 +57,15 @@ struct Frame6Args {
     // SUM mode (gmg_launch_strings_sum): per read and string the sum of the values whose window lies inside the read
     double *str_sums;       // [n_reads][2] (forward string, reverse complement), zeroed by the caller: atomically added to
     uint32_t uniform_len;   // > 0: every read has this length (read lookups by arithmetic)
+    // MULTI mode (gmg_launch_gene6_groups; glimmer-mg -c: consecutive groups of reads, each under its own gene ICM)
+    const struct F6Round *rounds = nullptr;     // k_frame6t: runs of <= K whole chunks that lie inside ONE group
+    const GmgDevModel *gmodels = nullptr;       // [n_groups] the groups' models (all of one window width)
+    const struct F6Range *ranges = nullptr;     // the bases no round covers: group edges inside a chunk, the batch tail
+    const uint64_t *group_read = nullptr;       // [n_groups + 1] first read of every group (k_frame6p)
+    uint32_t n_rounds = 0, n_ranges = 0, n_groups = 0;
 };
+struct F6Round { uint32_t chunk0; uint16_t n, group; };
+struct F6Range { uint64_t first; uint32_t count, group; };
 
 constexpr int f6_cstride(int dt) { return ((((1 << (2 * dt)) - 1) / 3) + 15) & ~15; }
 constexpr int f6_level_base(int l) { return ((1 << (2 * l)) - 1) / 3; }
@@ -251,7 +260,12 @@ __device__ __forceinline__ uint32_t f6_descend(const uint8_t *tab, uint32_t C, u
 // one sign and are multiples of 2^(e_min - 150), so while |sum| < 2^(e_min - 150 + 53) every partial sum of every order is
 // exact.  The first W-1 positions of either string (window outside the read) are left out here and added there.
 // A worker's chunks are consecutive in this mode, so that a round is one run of 32,768 bases = a few dozen whole reads.
-template <int BLOCK, int DT, int K, int DIAG, bool PAIR, bool GENE_ONLY, bool STRINGS = false, bool SUM = false>
+// MULTI (with GENE_ONLY): the batch is a sequence of read groups, each scored by its own gene model (glimmer-mg's classification
+// mode loads one ICM per group of reads, glimmer-mg.cc:361-366).  The work is a list of rounds -- runs of at most K whole chunks
+// that lie inside ONE group -- cut into consecutive shares, one per work-group; when a work-group's next round belongs to another
+// group than its last it swaps the WHOLE model (both shift tables and the resident half: ~140 KiB from L2, once per group and
+// work-group, against 128 KiB per round anyway).  One launch for any number of groups.
+template <int BLOCK, int DT, int K, int DIAG, bool PAIR, bool GENE_ONLY, bool STRINGS = false, bool SUM = false, bool MULTI = false>
 __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
 {
     constexpr int CS = f6_cstride(DT);
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
 
     const int ftype = STRINGS ? 0 : blockIdx.x % 3;
     const uint32_t worker = STRINGS ? blockIdx.x : blockIdx.x / 3, nworkers = STRINGS ? gridDim.x : gridDim.x / 3;
-    const int W = a.gene.W;
+    const int W = a.gene.W;                                         // (MULTI: every group's model has this width)
     const uint8_t *half_src = (const uint8_t *)(a.gene.chalf + (size_t)ftype * 2 * LEAVES * 2);   // [2][LEAVES][2] floats
 
     const uint64_t n_chunks = a.total / SPAN;                       // full chunks only
@@ -279,9 +293,12 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     // consecutive range of the batch
     const uint64_t per_worker = SUM ? (n_chunks + nworkers - 1) / nworkers : 0;
     const uint64_t chunk0 = SUM ? (uint64_t)worker * per_worker : worker, chunk_step = SUM ? 1 : nworkers;
-    if (chunk0 >= n_chunks) return;
-    const uint32_t n_mine = SUM ? (uint32_t)(n_chunks - chunk0 < per_worker ? n_chunks - chunk0 : per_worker)
-                                : (uint32_t)((n_chunks - worker + nworkers - 1) / nworkers);
+    // MULTI: rounds [r_first, r_first + n_mine / K) of the list
+    const uint32_t r_first = MULTI ? (uint32_t)((uint64_t)a.n_rounds * worker / nworkers) : 0u;
+    if (MULTI ? (uint32_t)((uint64_t)a.n_rounds * (worker + 1) / nworkers) == r_first : chunk0 >= n_chunks) return;
+    const uint32_t n_mine = MULTI ? ((uint32_t)((uint64_t)a.n_rounds * (worker + 1) / nworkers) - r_first) * (uint32_t)K
+                            : SUM ? (uint32_t)(n_chunks - chunk0 < per_worker ? n_chunks - chunk0 : per_worker)
+                                  : (uint32_t)((n_chunks - worker + nworkers - 1) / nworkers);
 
     // every wave-instruction moves 1 KiB L2 -> LDS: lane l's 16 bytes land at the wave's LDS base + 16 l
     constexpr uint32_t NHALF = HALF_BYTES / 16 / BLOCK;             // 16-byte pieces per lane and half
@@ -298,12 +315,14 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     constexpr uint32_t NRAW = (K * RAWW + BLOCK - 1) / BLOCK;
     uint32_t raw_t[NRAW];
     auto raw_issue = [&](uint32_t j0) __attribute__((always_inline)) {
+        F6Round nd = {0, 1, 0};
+        if (MULTI) nd = a.rounds[r_first + j0 / K];
 #pragma unroll
         for (uint32_t i = 0; i < NRAW; i++) {
             const uint32_t t = threadIdx.x + i * BLOCK;
             const uint32_t k = t / RAWW, w = t - k * RAWW;
             const uint32_t j = j0 + k < n_mine ? j0 + k : n_mine - 1;
-            const uint64_t c = chunk0 + (uint64_t)j * chunk_step;
+            const uint64_t c = MULTI ? (uint64_t)nd.chunk0 + (k < nd.n ? k : nd.n - 1u) : chunk0 + (uint64_t)j * chunk_step;
             raw_t[i] = t < K * RAWW ? a.packed[c * (SPAN / 16) - 1 + w] : 0u;
         }
     };
@@ -318,7 +337,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     // ---- fill LDS
     {
         const uint8_t *sh_src = a.gene.cshift + (size_t)ftype * a.gene.cstride;
-        for (int i = threadIdx.x; i < CS; i += BLOCK) {
+        for (int i = threadIdx.x; i < CS && !MULTI; i += BLOCK) {   // (MULTI: with the first round's model, below)
             const uint8_t sh = sh_src[i];
             s_shr[i] = sh;
             s_shf[i] = (uint8_t)(2 * (W - 1) - sh);
@@ -332,13 +351,14 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
             s_nf[i] = GENE_ONLY ? 0.0 : (double)a.nul.dense[(size_t)ftype * 64 + mirrored];
         }
         raw_issue(0);
-        half_issue(0);
+        if (!MULTI) half_issue(0);
         raw_commit();
         half_landed();
     }
     __syncthreads();
-    const uint32_t shift0_r = __builtin_amdgcn_readfirstlane((uint32_t)s_shr[0]);
-    const uint32_t shift0_f = __builtin_amdgcn_readfirstlane((uint32_t)s_shf[0]);
+    uint32_t shift0_r = MULTI ? 0u : __builtin_amdgcn_readfirstlane((uint32_t)s_shr[0]);
+    uint32_t shift0_f = MULTI ? 0u : __builtin_amdgcn_readfirstlane((uint32_t)s_shf[0]);
+    uint32_t cur_group = 0xffffffffu;                               // MULTI: the group whose model is in LDS
 
     const uint32_t ctx_mask = (1u << (2 * W)) - 1u;                 // W <= 15
     const uint32_t sh_f = 2u * (uint32_t)(W - 1);                   // bit offset of S[p] in the window word
@@ -388,7 +408,30 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
 #endif
     uint32_t cur = 0;                                               // half resident in LDS
     for (uint32_t j0 = 0; j0 < n_mine; j0 += K) {
-        const uint32_t kk = n_mine - j0 < (uint32_t)K ? n_mine - j0 : (uint32_t)K;   // chunks in this round
+        uint32_t kk = n_mine - j0 < (uint32_t)K ? n_mine - j0 : (uint32_t)K;   // chunks in this round
+        uint64_t round_chunk0 = 0;
+        if (MULTI) {
+            const F6Round rd = a.rounds[r_first + j0 / K];
+            kk = rd.n;
+            round_chunk0 = rd.chunk0;
+            if (rd.group != cur_group) {                            // another group: its model instead of the one in LDS
+                cur_group = rd.group;
+                __syncthreads();                                    // every wave has left the previous round's second phase
+                const GmgDevModel &gm = a.gmodels[rd.group];
+                const uint8_t *sh_src = gm.cshift + (size_t)ftype * gm.cstride;
+                for (int i = threadIdx.x; i < CS; i += BLOCK) {
+                    const uint8_t sh = sh_src[i];
+                    s_shr[i] = sh;
+                    s_shf[i] = (uint8_t)(2 * (W - 1) - sh);
+                }
+                half_src = (const uint8_t *)(gm.chalf + (size_t)ftype * 2 * LEAVES * 2);
+                half_issue(cur);
+                half_landed();
+                __syncthreads();
+                shift0_r = __builtin_amdgcn_readfirstlane((uint32_t)s_shr[0]);
+                shift0_f = __builtin_amdgcn_readfirstlane((uint32_t)s_shf[0]);
+            }
+        }
         // per chunk and base pair (g0, g0 + 1): the value that was in the resident half and the offset of the other
         uint32_t have[K][2], want[K][2];
         // per chunk the read bases S[g0-2 .. g0+3] (12 bits: the null-model windows, and which buffer of a base was resident:
@@ -473,7 +516,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
                         v[2 * b + 1] = (double)gr - nr;
                     }
                 }
-                const uint64_t chunk = chunk0 + (uint64_t)(j0 + k) * chunk_step;
+                const uint64_t chunk = MULTI ? round_chunk0 + (uint64_t)k : chunk0 + (uint64_t)(j0 + k) * chunk_step;
                 if (SUM) {
                     sum_chunk((uint32_t)k, v);
                 } else if (GENE_ONLY) {
@@ -530,10 +573,11 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
 // ---------------------------------------------------------------------------
 
 // Exact plain descent on the original tables for both models: bases [a.first, a.first + a.count), lane i0 of every n_lanes.
-__device__ __forceinline__ void f6_generic_range(const Frame6Args &a, uint64_t i0, uint64_t n_lanes)
+__device__ __forceinline__ void f6_generic_range(const Frame6Args &a, const GmgDevModel &gene, uint64_t first, uint64_t count,
+                                                 uint64_t i0, uint64_t n_lanes)
 {
-    for (uint64_t i = i0; i < a.count; i += n_lanes) {
-        const uint64_t g = a.first + i;
+    for (uint64_t i = i0; i < count; i += n_lanes) {
+        const uint64_t g = first + i;
         uint64_t r = a.tile_read[g / GMG_TILE];
         uint64_t r_end = a.off[r + 1];
         while (g >= r_end) { r++; r_end = a.off[r + 1]; }
@@ -544,16 +588,20 @@ __device__ __forceinline__ void f6_generic_range(const Frame6Args &a, uint64_t i
         DevBuf br = dev_make_buf(a.packed, r_off, 0, (uint32_t)L, GMG_COMPLEMENTED);
         for (int f = 0; f < 3; f++) {
             if (a.out_gene) {
-                a.out_gene[(uint64_t)f * a.gstride + g] = dev_score(a.gene, bf, L - 1 - p, f);
-                a.out_gene[(uint64_t)(3 + f) * a.gstride + g] = dev_score(a.gene, br, p, f);
+                a.out_gene[(uint64_t)f * a.gstride + g] = dev_score(gene, bf, L - 1 - p, f);
+                a.out_gene[(uint64_t)(3 + f) * a.gstride + g] = dev_score(gene, br, p, f);
                 continue;
             }
             a.out[(uint64_t)f * a.stride + g] =
-                (double)dev_score(a.gene, bf, L - 1 - p, f) - (double)dev_score(a.nul, bf, L - 1 - p, f);
+                (double)dev_score(gene, bf, L - 1 - p, f) - (double)dev_score(a.nul, bf, L - 1 - p, f);
             a.out[(uint64_t)(3 + f) * a.stride + g] =
-                (double)dev_score(a.gene, br, p, f) - (double)dev_score(a.nul, br, p, f);
+                (double)dev_score(gene, br, p, f) - (double)dev_score(a.nul, br, p, f);
         }
     }
+}
+__device__ __forceinline__ void f6_generic_range(const Frame6Args &a, uint64_t i0, uint64_t n_lanes)
+{
+    f6_generic_range(a, a.gene, a.first, a.count, i0, n_lanes);
 }
 
 // 32 lanes per read (z = lane & 31 < 2(W-1) <= 28 active): no division, read offsets broadcast.
@@ -561,20 +609,35 @@ __device__ __forceinline__ void f6_generic_range(const Frame6Args &a, uint64_t i
 // store), so every lane keeps U reads in flight (U x 3 interleaved descents).
 // DT > 0: depth known at compile time.
 // GENE: the gene model's value alone, as fp32, into a.out_gene (the complete gene-only table of gmg_launch_gene6_full).
-template <int DT, int U, bool GENE = false>
+// MULTI (with GENE): groups of reads under their own models (see k_frame6t<.., MULTI>): block b takes the reads
+// [n_reads b / p_blocks, n_reads (b + 1) / p_blocks) -- a consecutive share, so it meets one group, seldom two -- and loads the
+// shift tables of the group it is in; the blocks behind p_blocks score the ranges no round of the main pass covers (eight blocks
+// per range) with the exact any-shape code.
+template <int DT, int U, bool GENE = false, bool MULTI = false>
 __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_shift[];   // [3][cstride] completed-tree shifts
     if (blockIdx.x >= a.p_blocks) {
+        if (MULTI) {
+            const uint32_t bi = blockIdx.x - a.p_blocks;
+            if (bi / 8 >= a.n_ranges) return;
+            const F6Range rg = a.ranges[bi / 8];
+            f6_generic_range(a, a.gmodels[rg.group], rg.first, rg.count, (uint64_t)(bi % 8) * blockDim.x + threadIdx.x, (uint64_t)8 * blockDim.x);
+            return;
+        }
         // the last < 2,048 bases of the batch (the main pass does whole chunks), in the same launch.  The partial-window
         // positions in there are written by both kinds of blocks, with identical bits.
         f6_generic_range(a, (uint64_t)(blockIdx.x - a.p_blocks) * blockDim.x + threadIdx.x, (uint64_t)(gridDim.x - a.p_blocks) * blockDim.x);
         return;
     }
     const int cstride = a.gene.cstride;
-    for (int i = threadIdx.x * 16; i < 3 * cstride; i += 256 * 16)
-        *(uint4 *)(s_shift + i) = *(const uint4 *)(a.gene.cshift + i);
-    __syncthreads();
+    const float *crow = a.gene.crow;
+    int ctot = a.gene.ctot;
+    if (!MULTI) {
+        for (int i = threadIdx.x * 16; i < 3 * cstride; i += 256 * 16)
+            *(uint4 *)(s_shift + i) = *(const uint4 *)(a.gene.cshift + i);
+        __syncthreads();
+    }
 
     const int W = a.gene.W, D = DT > 0 ? DT : a.gene.D, Wn = a.nul.W;
     const uint32_t Z = 2u * (uint32_t)(W - 1);
@@ -591,15 +654,37 @@ __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
     const float *ntab = (j >= Wn - 1) ? a.nul.dense : a.nul.dense_part;
     const int nstride = (j >= Wn - 1) ? n_dense : n_part;
 
-    for (uint64_t r0 = (uint64_t)blockIdx.x * (256 / 32) + (threadIdx.x >> 5); r0 < a.n_reads; r0 += U * reads_per_pass) {
+    // the reads of this block: every reads_per_pass-th one from the block's own on, or (MULTI) its share group by group
+    const uint64_t share_lo = MULTI ? a.n_reads * blockIdx.x / a.p_blocks : 0, share_hi = MULTI ? a.n_reads * (blockIdx.x + 1) / a.p_blocks : a.n_reads;
+    uint32_t grp = 0;
+    if (MULTI) {
+        uint32_t lo = 0, hi = a.n_groups;                           // the group that holds read share_lo
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.group_read[mid] <= share_lo) lo = mid; else hi = mid; }
+        grp = lo;
+    }
+    for (uint64_t part_lo = share_lo; part_lo < share_hi;) {
+    uint64_t part_hi = share_hi;
+    if (MULTI) {
+        while (a.group_read[grp + 1] <= part_lo) grp++;
+        if (a.group_read[grp + 1] < part_hi) part_hi = a.group_read[grp + 1];
+        const GmgDevModel &gm = a.gmodels[grp];
+        __syncthreads();                                            // (the previous part's lookups are done)
+        for (int i = threadIdx.x * 16; i < 3 * cstride; i += 256 * 16)
+            *(uint4 *)(s_shift + i) = *(const uint4 *)(gm.cshift + i);
+        __syncthreads();
+        crow = gm.crow;
+        ctot = gm.ctot;
+    }
+    const uint64_t r_step = MULTI ? 256 / 32 : reads_per_pass;
+    for (uint64_t r0 = (MULTI ? part_lo : (uint64_t)blockIdx.x * (256 / 32)) + (threadIdx.x >> 5); r0 < part_hi; r0 += U * r_step) {
         bool live[U];
         uint64_t g[U];
         uint32_t C[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint64_t r = r0 + u * reads_per_pass;
-            const bool in = r < a.n_reads;
-            const uint64_t rq = in ? r : a.n_reads - 1;
+            const uint64_t r = r0 + u * r_step;
+            const bool in = r < part_hi;
+            const uint64_t rq = in ? r : part_hi - 1;
             const uint64_t r_off = a.off[rq];
             const int L = (int)(a.off[rq + 1] - r_off);
             live[u] = in && z < Z && j < L;                         // idle lanes; reads shorter than W-1
@@ -642,7 +727,7 @@ __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
 #pragma unroll
             for (int f = 0; f < 3; f++) {
                 if (node[u][f] == 0xffffffffu) node[u][f] = lvl + idx[u][f];
-                gv[u][f] = a.gene.crow[((size_t)f * a.gene.ctot + node[u][f]) * 4 + pred];
+                gv[u][f] = crow[((size_t)f * ctot + node[u][f]) * 4 + pred];
                 nv[u][f] = GENE ? 0.0f : ntab[(size_t)f * nstride + nslot];
             }
         }
@@ -657,6 +742,8 @@ __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
                         __builtin_nontemporal_store((double)gv[u][f] - (double)nv[u][f],
                                                     a.out + (uint64_t)((rev_buf ? 0 : 3) + f) * a.stride + g[u]);
                 }
+    }
+    part_lo = part_hi;
     }
 }
 
@@ -838,6 +925,164 @@ int gmg_launch_gene6(const gmg_model *gene, const gmg_reads *reads, float *d_gen
 int gmg_launch_gene6_full(const gmg_model *gene, const gmg_reads *reads, float *d_gene, uint64_t gstride, hipStream_t s)
 {
     return gene6_impl(gene, reads, d_gene, gstride, true, s);
+}
+
+__global__ void k_f6_gather_u64(const uint64_t *src, const uint64_t *idx, uint32_t n, uint64_t *dst)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+// The gene-only table of a batch whose reads come in consecutive groups, every group under its own gene model -- what
+// glimmer-mg's classification mode scores ICM by ICM (glimmer-mg.cc:361-451) in ONE pass over the batch: the main pass takes a
+// list of rounds (runs of <= 16 whole chunks inside one group) and swaps the model in LDS when a work-group crosses into another
+// group, the partial-window pass takes its reads group by group, and the bases no round covers (the chunks that hold a group
+// boundary, the batch tail) go to the exact any-shape code, all in two launches.  Models without the fast path (or of different
+// window widths) make the whole batch take the any-shape kernel, group by group: same values.
+int gmg_launch_gene6_groups(const gmg_model *const *models, const uint64_t *group_read, int n_groups, const gmg_reads *reads,
+                            float *d_gene, uint64_t gstride, hipStream_t s)
+{
+    if (!models || !group_read || n_groups < 1 || n_groups > 65535 || group_read[0] != 0 || group_read[n_groups] != reads->n_reads)
+        return gmg_set_error(GMG_EINVAL, "gmg_launch_gene6_groups: bad group list");
+    for (int g = 0; g < n_groups; g++)
+        if (!models[g] || group_read[g + 1] < group_read[g] || models[g]->dev.P < 3)
+            return gmg_set_error(GMG_EINVAL, "gmg_launch_gene6_groups: group %d has no periodicity-3 model or an inverted read range", g);
+    if (reads->total_bases == 0) return GMG_OK;
+    constexpr int BLOCK = 1024, DT = 7, KR = 16;
+    constexpr uint32_t SPAN = 2 * BLOCK;
+
+    // the groups' first bases
+    std::vector<uint64_t> base(n_groups + 1);
+    {
+        uint64_t *d_idx = nullptr, *d_val = nullptr;
+        GMG_HIP(gmg_pool_alloc((void **)&d_idx, (size_t)(n_groups + 1) * 8));
+        GMG_HIP(gmg_pool_alloc((void **)&d_val, (size_t)(n_groups + 1) * 8));
+        hipError_t e = hipMemcpyAsync(d_idx, group_read, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_f6_gather_u64, dim3((n_groups + 256) / 256), dim3(256), 0, s, reads->d_off, d_idx, (uint32_t)(n_groups + 1), d_val);
+            e = hipMemcpyAsync(base.data(), d_val, (size_t)(n_groups + 1) * 8, hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        gmg_pool_release(d_idx);
+        gmg_pool_release(d_val);
+        if (e != hipSuccess) return gmg_set_error(GMG_EHIP, "gmg_launch_gene6_groups: %s", hipGetErrorString(e));
+    }
+
+    Frame6Args a;
+    a.gene = models[0]->dev;
+    a.nul = models[0]->dev;                            // not used in gene-only mode
+    a.packed = reads->d_packed;
+    a.off = reads->d_off;
+    a.tile_read = reads->d_tile_read;
+    a.total = reads->total_bases;
+    a.n_reads = reads->n_reads;
+    a.first = 0;
+    a.count = 0;
+    a.p_blocks = 0;
+    a.out = nullptr;
+    a.stride = 0;
+    a.out_gene = d_gene;
+    a.gstride = gstride;
+    a.str_sums = nullptr;
+    a.uniform_len = 0;
+
+    bool fast = true;
+    for (int g = 0; g < n_groups && fast; g++) {
+        const GmgDevModel &m = models[g]->dev;
+        fast = m.has_fast && m.D == 7 && m.W >= 3 && m.W <= 15 && m.W == models[0]->dev.W && m.cstride == models[0]->dev.cstride;
+    }
+    if (!fast) {                                       // any shapes: the exact kernel, group by group
+        for (int g = 0; g < n_groups; g++) {
+            a.gene = models[g]->dev;
+            const int rc = launch_generic(a, base[g], base[g + 1] - base[g], s);
+            if (rc) return rc;
+        }
+        return GMG_OK;
+    }
+
+    // rounds: whole chunks of the global 2,048-base grid that lie inside one group; ranges: everything else
+    std::vector<F6Round> rounds;
+    std::vector<F6Range> ranges;
+    std::vector<GmgDevModel> gm(n_groups);
+    auto add_range = [&](uint64_t first, uint64_t end, int g) {
+        for (; first < end; first += 4 * SPAN) {        // pieces of at most four chunks: eight blocks each
+            const uint64_t n = end - first < 4 * SPAN ? end - first : 4 * SPAN;
+            ranges.push_back(F6Range{first, (uint32_t)n, (uint32_t)g});
+        }
+    };
+    for (int g = 0; g < n_groups; g++) {
+        gm[g] = models[g]->dev;
+        const uint64_t b0 = base[g], b1 = base[g + 1];
+        if (b1 == b0) continue;
+        const uint64_t c0 = (b0 + SPAN - 1) / SPAN, c1 = b1 / SPAN;     // whole chunks [c0, c1)
+        if (c1 <= c0) { add_range(b0, b1, g); continue; }
+        if (c1 > 0xffffffffull) return gmg_set_error(GMG_ETOOBIG, "gmg_launch_gene6_groups: batch too large");
+        add_range(b0, c0 * SPAN, g);
+        for (uint64_t c = c0; c < c1; c += KR)
+            rounds.push_back(F6Round{(uint32_t)c, (uint16_t)(c1 - c < KR ? c1 - c : KR), (uint16_t)g});
+        add_range(c1 * SPAN, b1, g);
+    }
+    F6Round *d_rounds = nullptr;
+    F6Range *d_ranges = nullptr;
+    GmgDevModel *d_gm = nullptr;
+    uint64_t *d_gread = nullptr;
+    hipError_t e = gmg_pool_alloc((void **)&d_rounds, (rounds.size() + 1) * sizeof(F6Round));
+    if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_ranges, (ranges.size() + 1) * sizeof(F6Range));
+    if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_gm, gm.size() * sizeof(GmgDevModel));
+    if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_gread, (size_t)(n_groups + 1) * 8);
+    if (e == hipSuccess && !rounds.empty()) e = hipMemcpyAsync(d_rounds, rounds.data(), rounds.size() * sizeof(F6Round), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && !ranges.empty()) e = hipMemcpyAsync(d_ranges, ranges.data(), ranges.size() * sizeof(F6Range), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_gm, gm.data(), gm.size() * sizeof(GmgDevModel), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_gread, group_read, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);               // (the host vectors go away with this call)
+    auto done = [&](int rc) {
+        gmg_pool_release_after(d_rounds, s);
+        gmg_pool_release_after(d_ranges, s);
+        gmg_pool_release_after(d_gm, s);
+        gmg_pool_release_after(d_gread, s);
+        return rc;
+    };
+    if (e != hipSuccess) return done(gmg_set_error(GMG_EHIP, "gmg_launch_gene6_groups: %s", hipGetErrorString(e)));
+    a.rounds = d_rounds;
+    a.n_rounds = (uint32_t)rounds.size();
+    a.ranges = d_ranges;
+    a.n_ranges = (uint32_t)ranges.size();
+    a.gmodels = d_gm;
+    a.group_read = d_gread;
+    a.n_groups = (uint32_t)n_groups;
+
+    if (!rounds.empty()) {
+        int dev = 0, n_cu = 256;
+        GMG_HIP(hipGetDevice(&dev));
+        GMG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        unsigned nworkers = (unsigned)(n_cu / 3);
+        if (nworkers < 1) nworkers = 1;
+        if (nworkers > rounds.size()) nworkers = (unsigned)rounds.size();
+        const unsigned grid = 3 * nworkers;
+        const size_t lds = ((size_t)1 << (2 * DT)) * 8;
+        if ((gstride & 1) == 0) {
+            GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, true, true, false, false, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, 0, true, true, false, false, true>), dim3(grid), dim3(BLOCK), lds, s, a);
+        } else {
+            GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, false, true, false, false, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, 0, false, true, false, false, true>), dim3(grid), dim3(BLOCK), lds, s, a);
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return done(gmg_set_error(GMG_EHIP, "gmg_launch_gene6_groups: %s", hipGetErrorString(e)));
+    }
+    // the partial-window heads of every read, group by group, and the ranges outside the rounds
+    {
+        const uint64_t blocks = (a.n_reads + 7) / 8;
+        const unsigned grid = (unsigned)(blocks < 256 * 8 ? blocks : 256 * 8);
+        const size_t lds_p = (size_t)3 * a.gene.cstride;
+        a.p_blocks = grid;
+        hipLaunchKernelGGL((k_frame6p<7, 4, true, true>), dim3(grid + 8 * (unsigned)ranges.size()), dim3(256), lds_p, s, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return done(gmg_set_error(GMG_EHIP, "gmg_launch_gene6_groups: %s", hipGetErrorString(e)));
+    }
+    return done(GMG_OK);
 }
 
 // Per-base values of the two strings scoreReadsGlim scores with a periodicity-1 ICM (the read, and its reverse

@@ -137,6 +137,10 @@ int gmg_launch_frame6_strided(const gmg_model *gene, const gmg_model *nul, const
                               uint64_t stride, hipStream_t s);
 int gmg_launch_gene6(const gmg_model *gene, const gmg_reads *reads, float *d_gene, hipStream_t s);
 int gmg_launch_gene6_full(const gmg_model *gene, const gmg_reads *reads, float *d_gene, uint64_t gstride, hipStream_t s);
+// the same table for a batch made of consecutive GROUPS of reads, group g = reads [group_read[g], group_read[g+1]) (HOST array,
+// n_groups + 1 entries, group_read[n_groups] = n_reads) scored by models[g]: one launch of the main pass for all groups
+int gmg_launch_gene6_groups(const gmg_model *const *models, const uint64_t *group_read, int n_groups, const gmg_reads *reads,
+                            float *d_gene, uint64_t gstride, hipStream_t s);
 int gmg_launch_strings(const gmg_model *m, const gmg_reads *reads, float *d_vals, uint64_t *tail_start, hipStream_t s);
 int gmg_launch_strings_sum(const gmg_model *m, const gmg_reads *reads, double *d_sums, uint64_t *tail_start, hipStream_t s);
 int gmg_launch_seg_frame(const gmg_model *m, const gmg_reads *r, const gmg_segments *sg, int frame,

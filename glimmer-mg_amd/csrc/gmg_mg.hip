@@ -2616,15 +2616,30 @@ __global__ __launch_bounds__(256) void k_mg_apply_nulls(MgArgs a, double *out, u
 // ---------------------------------------------------------------------------------------------------
 static unsigned grid_for(uint64_t n);
 
+// gmg_mg_score_groups: consecutive groups of reads, each under its own gene model (NULL / 0: one model for the batch)
+struct MgGroups {
+    std::vector<const gmg_model *> models;
+    std::vector<uint64_t> read_begin;                   // n + 1 entries
+    int n = 0;
+};
+
+// the gene model's fp32 rows, complete (gmg_launch_gene6_full), for one model or for groups of reads under their own models
+static int mg_gene6_full(const gmg_model *gene, const MgGroups *groups, const gmg_reads *reads, float *d_gene32, uint64_t gstride, hipStream_t s)
+{
+    if (groups && groups->n > 0)
+        return gmg_launch_gene6_groups(groups->models.data(), groups->read_begin.data(), groups->n, reads, d_gene32, gstride, s);
+    return gmg_launch_gene6_full(gene, reads, d_gene32, gstride, s);
+}
+
 // the table of gmg_frame_score6 with read r scored against null model d_read_null[r] (device array, or NULL: model 0)
 static int mg_frame6_nulls(const gmg_model *gene, const float *d_null_tab, const uint32_t *d_read_null,
-                           const gmg_reads *reads, double *d_out, uint64_t stride, hipStream_t s)
+                           const gmg_reads *reads, double *d_out, uint64_t stride, hipStream_t s, const MgGroups *groups = nullptr)
 {
     if (reads->total_bases == 0) return GMG_OK;
     const uint64_t gstride = (reads->total_bases + 15) & ~15ull;
     float *d_gene32 = nullptr;
     GMG_HIP(gmg_pool_alloc((void **)&d_gene32, (size_t)6 * gstride * sizeof(float)));
-    int rc = gmg_launch_gene6_full(gene, reads, d_gene32, gstride, s);
+    int rc = mg_gene6_full(gene, groups, reads, d_gene32, gstride, s);
     if (rc) { gmg_pool_release(d_gene32); return gmg_set_error(rc, "per-read null models need a gene model of the default shape (depth 7, window <= 15, periodicity 3)"); }
     MgArgs a;
     memset(&a, 0, sizeof a);
@@ -2732,7 +2747,7 @@ struct MgTimer {
 };
 
 static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, const gmg_mg_params *prm,
-                  double *d_frame_scores, gmg_mg_result **out, void *stream, const bool find_only)
+                  double *d_frame_scores, gmg_mg_result **out, void *stream, const bool find_only, const MgGroups *groups = nullptr)
 {
     { int rc_enter = gmg_enter(find_only ? "gmg_find_orfs" : "gmg_mg_score_reads"); if (rc_enter) return rc_enter; }
     if ((!find_only && (!gene || !nul)) || !reads || !prm || !out) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: NULL argument");
@@ -2913,11 +2928,18 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     {
         const int n_min = prm->nulls ? prm->nulls->min_exp : nul->min_exp, n_max = prm->nulls ? prm->nulls->max_exp : nul->max_exp;
         const int n_odd = prm->nulls ? prm->nulls->odd_values : nul->odd_values;
-        const int mn = gene->min_exp < n_min ? gene->min_exp : n_min, mx = gene->max_exp > n_max ? gene->max_exp : n_max;
+        int g_min = gene->min_exp, g_max = gene->max_exp, g_odd = gene->odd_values;
+        for (int k = 0; groups && k < groups->n; k++) {   // every group's model
+            const gmg_model *m = groups->models[k];
+            if (m->min_exp < g_min) g_min = m->min_exp;
+            if (m->max_exp > g_max) g_max = m->max_exp;
+            g_odd |= m->odd_values;
+        }
+        const int mn = g_min < n_min ? g_min : n_min, mx = g_max > n_max ? g_max : n_max;
         int clog = 0;
         const uint64_t longest_read = reads->max_len ? reads->max_len : reads->total_bases;   // (no lengths on the host: the batch's size is a bound)
         while ((1ull << clog) < longest_read + 2) clog++;
-        const bool exact = !gene->odd_values && !n_odd && (mx < mn || clog + mx - mn <= 28);
+        const bool exact = !g_odd && !n_odd && (mx < mn || clog + mx - mn <= 28);
         err_exact = exact;
         const long long forced_tile = gmg_opt(GMG_OPT_MG_TILE);
         if (!err_mode && exact && gmg_opt(GMG_OPT_MG_FUSED) && a.n_reads && a.total) {
@@ -2949,15 +2971,21 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     const long long g32_opt = gmg_opt(GMG_OPT_MG_GENE32);
     // (with tiles of two waves or more the GENE32 form wins with one null model as well: ragged 10.6 -> 10.0 ms per 1M x ~400 bp,
     // 500-bp reads 10.9 -> 10.2 ms)
+    bool all_fast = gene->dev.has_fast && gene->dev.D == 7 && gene->dev.W >= 3 && gene->dev.W <= 15;
+    for (int k = 0; groups && k < groups->n; k++) {
+        const GmgDevModel &m = groups->models[k]->dev;
+        all_fast = all_fast && m.has_fast && m.D == 7 && m.W == gene->dev.W;
+    }
+    // (groups of any-shape models: their gene rows come from the exact kernel, group by group -- still the GENE32 form)
     const bool g32 = !d_frame_scores && !err_mode && a.total &&
                      (g32_opt == 2 || (g32_opt == 1 && (prm->nulls || fused_nw >= 2))) && nul_dense3 &&
-                     gene->dev.has_fast && gene->dev.D == 7 && gene->dev.W >= 3 && gene->dev.W <= 15;
+                     (all_fast || (groups && groups->n > 0));
     if (prm->nulls && !nul_dense3) return fail(gmg_set_error(GMG_EBADMODEL, "gmg_mg_score_reads: per-read null models are (3,2,3) models"));
     a.fs_stride = a.total;
     if (g32) {
         a.fs_stride = (a.total + 31) & ~31ull;          // every fp32 row on a 128-byte line
         MG_TRY(gmg_pool_alloc((void **)&d_gene32, (size_t)6 * a.fs_stride * sizeof(float)));
-        rc = gmg_launch_gene6_full(gene, reads, d_gene32, a.fs_stride, s);
+        rc = mg_gene6_full(gene, groups, reads, d_gene32, a.fs_stride, s);
         if (rc) return fail(rc);
         a.gene32 = d_gene32;
     } else {
@@ -2967,7 +2995,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             d_frame_scores = d_fs_own;
         }
         if (a.total) {
-            if (prm->nulls) rc = mg_frame6_nulls(gene, d_null_tab, d_read_null, reads, d_frame_scores, a.fs_stride, s);
+            if (prm->nulls) rc = mg_frame6_nulls(gene, d_null_tab, d_read_null, reads, d_frame_scores, a.fs_stride, s, groups);
             else rc = gmg_launch_frame6_strided(gene, nul, reads, d_frame_scores, a.fs_stride, s);
             if (rc) return fail(rc);
         }
@@ -3450,6 +3478,31 @@ extern "C" int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *nul, c
                                   const gmg_mg_params *prm, double *d_frame_scores, gmg_mg_result **out, void *stream)
 {
     return mg_run(gene, nul, reads, prm, d_frame_scores, out, stream, false);
+}
+
+// glimmer-mg's classification mode: one call for a batch whose reads come in consecutive groups, every group under its own gene
+// ICM (the loop over ICM_Sequences, glimmer-mg.cc:361-451), the null model and Ignore_Score_Len per read as in gmg_mg_score_reads
+extern "C" int gmg_mg_score_groups(const gmg_mg_group *groups, int n_groups, const gmg_model *nul, const gmg_reads *reads,
+                                   const gmg_mg_params *prm, gmg_mg_result **out, void *stream)
+{
+    if (!groups || n_groups < 1 || !reads || !prm) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_groups: NULL argument");
+    if (n_groups > 65535) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_groups: at most 65,535 groups per call");
+    if (!prm->nulls) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_groups: needs the per-read null models (gmg_mg_params.nulls / read_null)");
+    MgGroups g;
+    g.n = n_groups;
+    uint64_t next = 0;
+    for (int k = 0; k < n_groups; k++) {
+        if (!groups[k].gene || groups[k].read_begin != next || groups[k].read_end < groups[k].read_begin)
+            return gmg_set_error(GMG_EINVAL, "gmg_mg_score_groups: group %d has no model, or the groups are not consecutive read ranges from 0", k);
+        if (groups[k].gene->dev.P != 3) return gmg_set_error(GMG_EBADMODEL, "gmg_mg_score_groups: Score_All_Frames needs models of periodicity 3");
+        g.models.push_back(groups[k].gene);
+        g.read_begin.push_back(next);
+        next = groups[k].read_end;
+    }
+    if (next != reads->n_reads) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_groups: the groups end at read %llu of %llu",
+                                                     (unsigned long long)next, (unsigned long long)reads->n_reads);
+    g.read_begin.push_back(next);
+    return mg_run(groups[0].gene, nul, reads, prm, nullptr, out, stream, false, &g);
 }
 
 extern "C" int gmg_find_orfs(const gmg_reads *reads, const gmg_mg_params *prm, gmg_mg_result **out, void *stream)

@@ -382,6 +382,20 @@ typedef struct gmg_mg_result gmg_mg_result;
 int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *null_model, const gmg_reads *reads,
                        const gmg_mg_params *params, double *d_frame_scores, gmg_mg_result **out,
                        void *stream);
+/* The same for a batch whose reads come in consecutive GROUPS, every group under its own gene ICM: one chunk of glimmer-mg's
+ * classification mode (the loop over ICM_Sequences, src/Glimmer/glimmer-mg.cc:361-451: Gene_ICM.Read per group, then every read
+ * of the group against the null model and Ignore_Score_Len of ITS classes, Update_Meta_Null_ICM :2050-2068) in ONE call: the
+ * reads gathered in visiting order (gmg_reads_select on the order of gmg_classes_plan), groups[k] = reads [read_begin, read_end)
+ * of that batch (consecutive, from 0 to n_reads), params->nulls / read_null / read_ignore_score_len per read (required; one
+ * stop-codon set per call).  The six-frame pass swaps the group's tables in LDS as it crosses from group to group -- one launch
+ * whatever the number of groups; everything behind it never sees a gene model.  Results as gmg_mg_score_reads', reads in batch
+ * order. */
+typedef struct gmg_mg_group {
+    const gmg_model *gene;
+    uint64_t read_begin, read_end;
+} gmg_mg_group;
+int gmg_mg_score_groups(const gmg_mg_group *groups, int n_groups, const gmg_model *null_model, const gmg_reads *reads,
+                        const gmg_mg_params *params, gmg_mg_result **out, void *stream);
 /* Find_Orfs alone (src/Glimmer/glimmer_base.cc:638-779; linear sequences, no ignore regions) for every read of the
  * batch -- the ORF list glimmer3's Score_Orfs / gmg_score_orfs and glimmer-mg's Score_Orfs_Errors start from.  Uses
  * min_gene_len, allow_truncated and the codon lists of `params`; the result holds the Orf_t fields (and lo / hi), no

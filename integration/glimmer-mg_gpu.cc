@@ -106,11 +106,18 @@ struct Scored {
     vector<uint64_t> read_orf_off;
 };
 
+static void fetch_result(gmg_mg_result *res, uint64_t n_reads, bool error_mode, Scored &sc);
+
 static void score_batch(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, uint64_t n_reads,
                         const gmg_mg_params &prm, bool error_mode, Scored &sc)
 {
     gmg_mg_result *res = NULL;
     if (gmg_mg_score_reads(gene, nul, reads, &prm, NULL, &res, NULL) != GMG_OK) die_gmg("gmg_mg_score_reads");
+    fetch_result(res, n_reads, error_mode, sc);
+}
+
+static void fetch_result(gmg_mg_result *res, uint64_t n_reads, bool error_mode, Scored &sc)
+{
     uint64_t n_orfs = 0, n_starts = 0;
     gmg_mg_result_info(res, &n_orfs, &n_starts);
     sc.orfs.resize(n_orfs ? n_orfs : 1);
@@ -298,10 +305,11 @@ static int run_shard(const char *bytes, uint64_t b0, uint64_t b1, int device, ui
 // ---- classification mode (-c) -------------------------------------------------------------------------------------------
 // glimmer-mg.cc:326-451: the input is read in chunks of Chunk_Sequences reads; per chunk every ICM file is loaded in turn and
 // scores the reads classified to it, each against the null model and the stop codons of ITS classes.  Here, per chunk:
-// gmg_classes_plan gives the visiting order and every read's GC / translation table; the reads of an ICM group that share a
-// stop-codon set are gathered on the device (gmg_reads_select) and scored by ONE gmg_mg_score_reads call with a null model per
-// distinct GC (gmg_null_set_build, gmg_mg_params.read_null / read_ignore_score_len); the back half then runs read by read in
-// the reference's order with the reference's own Update_Meta_* in between.  With -m AND -c (glimmer-mg.py's --long-orfs path)
+// gmg_classes_plan gives the visiting order and every read's GC / translation table; the reads that share a stop-codon set are
+// gathered on the device in visiting order (gmg_reads_select) and scored by ONE gmg_mg_score_groups call -- every ICM group a
+// consecutive range of that batch under its own gene model, a null model per distinct GC (gmg_null_set_build,
+// gmg_mg_params.read_null / read_ignore_score_len); the back half then runs read by read in the reference's order with the
+// reference's own Update_Meta_* in between.  With -m AND -c (glimmer-mg.py's --long-orfs path)
 // there is one group -- every read, in file order, under the user's ICM and the file's GC -- and only the stop codons vary.
 
 static uint64_t next_record_start(const char *bytes, uint64_t from, uint64_t n_bytes)
@@ -413,6 +421,7 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
     if (Allow_Indels && Quality_File_Name != NULL) quality_fp = File_Open(Quality_File_Name, "r", __FILE__, __LINE__);
     FILE *predict_fp = File_Open(out_name, "w", __FILE__, __LINE__);
     vector<const char *> user_stops(Stop_Codon);         // -z / -Z: one set for every read
+    std::map<string, ICM_t *> icm_cache;                // gene ICMs by file name, read once
 
     for (size_t c = 0; c < chunks.size(); c++) {
         Piece &pc = chunks[c];
@@ -463,106 +472,127 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
             icm_begin[1] = n;
         }
 
+        const uint64_t n_proc = icm_begin[n_groups];
+        // the gene ICMs of the groups that have reads in this chunk (the reference reads every ICM of the class file for every
+        // chunk, used or not, and again for the next chunk, glimmer-mg.cc:364; here a file is read once)
+        vector<const gmg_model *> group_model(n_groups, (const gmg_model *)NULL);
         for (uint32_t f = 0; f < n_groups; f++) {
-            const uint64_t g0 = icm_begin[f], g1 = icm_begin[f + 1];
-            if (!User_ICM) {
-                // the reference loads every ICM of the class file for every chunk, used or not (glimmer-mg.cc:364); an unused one is
-                // not read here
-                if (g1 == g0) continue;
-                Gene_ICM.Read((char *)gmg_classes_icm_file(cls, f));
+            if (icm_begin[f + 1] == icm_begin[f]) continue;
+            if (User_ICM) { group_model[f] = Gene_ICM.Device_Model(); continue; }
+            const string name = gmg_classes_icm_file(cls, f);
+            std::map<string, ICM_t *>::iterator it = icm_cache.find(name);
+            if (it == icm_cache.end()) {
+                ICM_t *m = new ICM_t();
+                m->Read((char *)name.c_str());
+                it = icm_cache.insert(make_pair(name, m)).first;
             }
-            // sub-batches by stop-codon set, reads in group order
-            vector<SubBatch> sub;
-            vector<pair<uint32_t, uint64_t> > where(g1 - g0);          // group position -> (sub-batch, index in it)
-            for (uint64_t k = g0; k < g1; k++) {
-                const int code = User_Stop ? 0 : read_tt[k];
-                size_t b = 0;
-                while (b < sub.size() && sub[b].code != code) b++;
-                if (b == sub.size()) { sub.push_back(SubBatch()); sub[b].code = code; }
-                where[k - g0] = make_pair((uint32_t)b, (uint64_t)sub[b].member.size());
-                sub[b].member.push_back(k);
+            group_model[f] = it->second->Device_Model();
+        }
+        // one gmg_mg_score_groups call per stop-codon set: its reads in visiting order, its ICM groups as consecutive ranges
+        vector<SubBatch> sub;
+        vector<pair<uint32_t, uint64_t> > where(n_proc);                // visiting position -> (sub-batch, index in it)
+        for (uint64_t k = 0; k < n_proc; k++) {
+            const int code = User_Stop ? 0 : read_tt[k];
+            size_t b = 0;
+            while (b < sub.size() && sub[b].code != code) b++;
+            if (b == sub.size()) { sub.push_back(SubBatch()); sub[b].code = code; }
+            where[k] = make_pair((uint32_t)b, (uint64_t)sub[b].member.size());
+            sub[b].member.push_back(k);
+        }
+        for (size_t b = 0; b < sub.size(); b++) {
+            SubBatch &sb = sub[b];
+            const uint64_t m = sb.member.size();
+            char stops[8][4];
+            int n_stops = 0;
+            memset(stops, 0, sizeof stops);
+            if (User_Stop) {
+                n_stops = (int)user_stops.size();
+                for (int t = 0; t < n_stops && t < 8; t++) memcpy(stops[t], user_stops[t], 3);
+            } else if (gmg_stop_codons_by_code(sb.code, stops, &n_stops) != GMG_OK) {
+                fprintf(stderr, "%s\n", gmg_last_error());           // Set_Stop_Codons_By_Code's message (gene.cc:1618)
+                return EXIT_FAILURE;
             }
-            for (size_t b = 0; b < sub.size(); b++) {
-                SubBatch &sb = sub[b];
-                const uint64_t m = sb.member.size();
-                char stops[8][4];
-                int n_stops = 0;
-                memset(stops, 0, sizeof stops);
-                if (User_Stop) {
-                    n_stops = (int)user_stops.size();
-                    for (int t = 0; t < n_stops && t < 8; t++) memcpy(stops[t], user_stops[t], 3);
-                } else if (gmg_stop_codons_by_code(sb.code, stops, &n_stops) != GMG_OK) {
-                    fprintf(stderr, "%s\n", gmg_last_error());       // Set_Stop_Codons_By_Code's message (gene.cc:1618)
-                    return EXIT_FAILURE;
+            // a null model per distinct GC, Ignore_Score_Len per read (Update_Meta_Null_ICM, glimmer-mg.cc:2050-2068)
+            vector<double> gcs;
+            vector<uint32_t> read_null(m);
+            vector<int32_t> read_isl(m);
+            vector<uint64_t> idx(m);
+            vector<gmg_mg_group> groups;
+            std::map<uint64_t, uint32_t> seen;
+            uint32_t f = 0, f_last = 0xffffffffu;
+            for (uint64_t r = 0; r < m; r++) {
+                const uint64_t k = sb.member[r];
+                while (icm_begin[f + 1] <= k) f++;                  // the ICM group of visiting position k
+                if (f != f_last) {
+                    gmg_mg_group g;
+                    g.gene = group_model[f];
+                    g.read_begin = r;
+                    g.read_end = r;
+                    groups.push_back(g);
+                    f_last = f;
                 }
-                // a null model per distinct GC, Ignore_Score_Len per read (Update_Meta_Null_ICM, glimmer-mg.cc:2050-2068)
-                vector<double> gcs;
-                vector<uint32_t> read_null(m);
-                vector<int32_t> read_isl(m);
-                vector<uint64_t> idx(m);
-                std::map<uint64_t, uint32_t> seen;
-                for (uint64_t r = 0; r < m; r++) {
-                    const uint64_t k = sb.member[r];
-                    idx[r] = order[k];
-                    uint64_t bits;
-                    memcpy(&bits, &read_gc[k], 8);
-                    std::map<uint64_t, uint32_t>::iterator it = seen.find(bits);
-                    if (it == seen.end()) { it = seen.insert(make_pair(bits, (uint32_t)gcs.size())).first; gcs.push_back(read_gc[k]); }
-                    read_null[r] = it->second;
-                    if (gmg_ignore_score_len(read_gc[k], stops, n_stops, &read_isl[r]) != GMG_OK) die_gmg("gmg_ignore_score_len");
-                }
-                gmg_null_set *nulls = NULL;
-                if (gmg_null_set_build(gcs.data(), (int)gcs.size(), stops, n_stops, &nulls) != GMG_OK) die_gmg("gmg_null_set_build");
-                gmg_reads *batch = NULL;
-                if (gmg_reads_select(pc.reads, idx.data(), m, &batch) != GMG_OK) die_gmg("gmg_reads_select");
-                gmg_mg_params prm;
-                fill_params(prm, error_mode);
-                prm.n_stop_codons = n_stops;
-                memcpy(prm.stop_codon, stops, sizeof stops);
-                prm.nulls = nulls;
-                prm.read_null = read_null.data();
-                prm.read_ignore_score_len = read_isl.data();
-                vector<uint8_t> qual;
-                if (quality_fp) {
-                    for (uint64_t r = 0; r < m; r++) qual.insert(qual.end(), qual_all.begin() + off[idx[r]], qual_all.begin() + off[idx[r] + 1]);
-                    prm.quality = qual.data();
-                }
-                ICM_t any_null(3, 2, 3);                // the null_model argument is not read when params.nulls is set, but must be a model
-                {
-                    vector<const char *> sv;
-                    for (int t = 0; t < n_stops; t++) sv.push_back(stops[t]);
-                    any_null.Build_Indep_WO_Stops(gcs[0], sv);
-                }
-                score_batch(Gene_ICM.Device_Model(), any_null.Device_Model(), batch, m, prm, error_mode, sb.sc);
-                gmg_reads_free(batch);
-                gmg_null_set_free(nulls);
+                groups.back().read_end = r + 1;
+                idx[r] = order[k];
+                uint64_t bits;
+                memcpy(&bits, &read_gc[k], 8);
+                std::map<uint64_t, uint32_t>::iterator it = seen.find(bits);
+                if (it == seen.end()) { it = seen.insert(make_pair(bits, (uint32_t)gcs.size())).first; gcs.push_back(read_gc[k]); }
+                read_null[r] = it->second;
+                if (gmg_ignore_score_len(read_gc[k], stops, n_stops, &read_isl[r]) != GMG_OK) die_gmg("gmg_ignore_score_len");
             }
-            // the back half, read by read in the reference's order (glimmer-mg.cc:367-450)
-            string hs;
-            for (uint64_t k = g0; k < g1; k++) {
-                const uint64_t i = order[k];
-                hs.assign(hdr[i], hdr_len[i]);
-                Fasta_Header = hs.c_str();
-                load_sequence(packed, off, i);
-                fprintf(predict_fp, ">%s\n", Fasta_Header);
-                if (!User_RBS) Update_Meta_RBS();
-                if (!User_Length) Update_Meta_Length();
-                if (!User_Start) Update_Meta_Start();
-                if (!User_Adj) Update_Meta_Adj();
-                if (!User_Stop) Update_Meta_Stop();
-                const SubBatch &sb = sub[where[k - g0].first];
-                if (!User_ICM) {                        // what Update_Meta_Null_ICM leaves in the globals the back half reads
-                    Indep_GC_Frac = read_gc[k];
-                    int32_t isl = 0;
-                    char st[8][4];
-                    int ns = 0;
-                    memset(st, 0, sizeof st);
-                    for (size_t t = 0; t < Stop_Codon.size() && t < 8; t++, ns++) memcpy(st[t], Stop_Codon[t], 3);
-                    gmg_ignore_score_len(read_gc[k], st, ns, &isl);
-                    Ignore_Score_Len = isl;
-                }
-                back_half(predict_fp, sb.sc, where[k - g0].second, error_mode);
+            gmg_null_set *nulls = NULL;
+            if (gmg_null_set_build(gcs.data(), (int)gcs.size(), stops, n_stops, &nulls) != GMG_OK) die_gmg("gmg_null_set_build");
+            gmg_reads *batch = NULL;
+            if (gmg_reads_select(pc.reads, idx.data(), m, &batch) != GMG_OK) die_gmg("gmg_reads_select");
+            gmg_mg_params prm;
+            fill_params(prm, error_mode);
+            prm.n_stop_codons = n_stops;
+            memcpy(prm.stop_codon, stops, sizeof stops);
+            prm.nulls = nulls;
+            prm.read_null = read_null.data();
+            prm.read_ignore_score_len = read_isl.data();
+            vector<uint8_t> qual;
+            if (quality_fp) {
+                for (uint64_t r = 0; r < m; r++) qual.insert(qual.end(), qual_all.begin() + off[idx[r]], qual_all.begin() + off[idx[r] + 1]);
+                prm.quality = qual.data();
             }
+            ICM_t any_null(3, 2, 3);                    // the null_model argument is not read when params.nulls is set, but must be a model
+            {
+                vector<const char *> sv;
+                for (int t = 0; t < n_stops; t++) sv.push_back(stops[t]);
+                any_null.Build_Indep_WO_Stops(gcs[0], sv);
+            }
+            gmg_mg_result *res = NULL;
+            if (gmg_mg_score_groups(groups.data(), (int)groups.size(), any_null.Device_Model(), batch, &prm, &res, NULL) != GMG_OK)
+                die_gmg("gmg_mg_score_groups");
+            fetch_result(res, m, error_mode, sb.sc);
+            gmg_reads_free(batch);
+            gmg_null_set_free(nulls);
+        }
+        // the back half, read by read in the reference's order (glimmer-mg.cc:367-450)
+        string hs;
+        for (uint64_t k = 0; k < n_proc; k++) {
+            const uint64_t i = order[k];
+            hs.assign(hdr[i], hdr_len[i]);
+            Fasta_Header = hs.c_str();
+            load_sequence(packed, off, i);
+            fprintf(predict_fp, ">%s\n", Fasta_Header);
+            if (!User_RBS) Update_Meta_RBS();
+            if (!User_Length) Update_Meta_Length();
+            if (!User_Start) Update_Meta_Start();
+            if (!User_Adj) Update_Meta_Adj();
+            if (!User_Stop) Update_Meta_Stop();
+            if (!User_ICM) {                            // what Update_Meta_Null_ICM leaves in the globals the back half reads
+                Indep_GC_Frac = read_gc[k];
+                int32_t isl = 0;
+                char st[8][4];
+                int ns = 0;
+                memset(st, 0, sizeof st);
+                for (size_t t = 0; t < Stop_Codon.size() && t < 8; t++, ns++) memcpy(st[t], Stop_Codon[t], 3);
+                gmg_ignore_score_len(read_gc[k], st, ns, &isl);
+                Ignore_Score_Len = isl;
+            }
+            back_half(predict_fp, sub[where[k].first].sc, where[k].second, error_mode);
         }
         gmg_reads_free(pc.reads);
         pc.reads = NULL;

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""glimmer-mg's classification mode on the device (the ICM-grouped loop, glimmer-mg.cc:361-451): 1 M x 500 bp
+synthetic reads over G ICM groups (default 64) and N null models (default 100 GC values), reads resident in HBM.
+Timed: (a) ONE gmg_mg_score_reads over all reads with one ICM and a null model per read (the single-ICM time);
+(b) the grouped job: the reads gathered in group order (gmg_reads_select) and scored group by group with each group's own ICM
+handle -- one gmg_mg_score_reads per group, or gmg_mg_score_groups when the library has it (BENCH_GROUPS_API=1).
+Prints one JSON line."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import _gmg_pkg  # noqa: E402
+
+gmg = _gmg_pkg.load()
+api, capi = gmg.api, gmg.capi
+n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+n_groups = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+n_nulls = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+L = 500
+gmg.init(0)
+lib = capi.lib()
+DATA = os.path.join(ROOT, "tests", "golden", "data")
+files = ["NC_000915.icm", "seqs.cluster-0.run1.filt.gicm", "seqs.cluster-2.run1.filt.gicm", "seqs.cluster-4.run1.filt.gicm",
+         "seqs.cluster-5.run1.filt.gicm"]
+models = [gmg.Icm.open(os.path.join(DATA, files[g % len(files)])) for g in range(n_groups)]     # one handle (one table) per group
+packed, off = gmg.synth.packed_reads(n_reads, L, 7)
+reads = gmg.Reads(packed, off)
+rng = np.random.default_rng(3)
+group = rng.integers(0, n_groups, n_reads)
+order = np.argsort(group, kind="stable").astype(np.uint64)
+begin = np.searchsorted(group[order.astype(np.int64)], np.arange(n_groups + 1)).astype(np.uint64)
+nulls = gmg.NullSet.build(np.linspace(0.3, 0.7, n_nulls))
+read_null = rng.integers(0, n_nulls, n_reads).astype(np.uint32)
+read_isl = np.full(n_reads, 2**31 - 1, np.int32)
+
+
+def params(rn, isl):
+    prm = capi.MgParams(75, 1, 2**31 - 1, 3, 3, 1, -6.0)            # GMG_MG_ACCEPTED_ONLY, as the driver asks
+    for i, c in enumerate(("atg", "gtg", "ttg")):
+        prm.start_codon[i].value = c.encode()
+    for i, c in enumerate(("taa", "tag", "tga")):
+        prm.stop_codon[i].value = c.encode()
+    prm.nulls, prm.read_null, prm.read_ignore_score_len = nulls.h, rn.ctypes.data, isl.ctypes.data
+    return prm
+
+
+def score(model, batch, prm):
+    res = C.c_void_p()
+    api._ck(lib.gmg_mg_score_reads(model.device(), nulls.icms[0].device(), batch.h, C.byref(prm), None, C.byref(res), None))
+    n_orfs, n_starts = C.c_uint64(), C.c_uint64()
+    api._ck(lib.gmg_mg_result_info(res, C.byref(n_orfs), C.byref(n_starts)))
+    lib.gmg_mg_result_free(res)
+    return n_orfs.value, n_starts.value
+
+
+def single():
+    return score(models[0], reads, params(read_null, read_isl))
+
+
+def grouped():
+    tot = [0, 0]
+    rn = read_null[order.astype(np.int64)]
+    for g in range(n_groups):
+        b, e = int(begin[g]), int(begin[g + 1])
+        if b == e:
+            continue
+        batch = reads.select(order[b:e])
+        a = score(models[g], batch, params(np.ascontiguousarray(rn[b:e]), np.ascontiguousarray(read_isl[b:e])))
+        tot[0] += a[0]
+        tot[1] += a[1]
+        batch.close()
+    return tuple(tot)
+
+
+def grouped_one_call():
+    # gmg_mg_score_groups: the reads gathered in visiting order once, every group a consecutive range under its own model
+    batch = reads.select(order)
+    rn = np.ascontiguousarray(read_null[order.astype(np.int64)])
+    prm = params(rn, read_isl)
+    arr = (capi.MgGroup * n_groups)(*[capi.MgGroup(models[g].device(), int(begin[g]), int(begin[g + 1])) for g in range(n_groups)])
+    res = C.c_void_p()
+    api._ck(lib.gmg_mg_score_groups(arr, n_groups, nulls.icms[0].device(), batch.h, C.byref(prm), C.byref(res), None))
+    n_orfs, n_starts = C.c_uint64(), C.c_uint64()
+    api._ck(lib.gmg_mg_result_info(res, C.byref(n_orfs), C.byref(n_starts)))
+    lib.gmg_mg_result_free(res)
+    batch.close()
+    return n_orfs.value, n_starts.value
+
+
+def timed(fn):
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return sorted(ts)[len(ts) // 2], [round(t, 2) for t in ts], r
+
+
+t_single, all_single, r1 = timed(single)
+t_grouped, all_grouped, r2 = timed(grouped) if os.environ.get("BENCH_PER_GROUP_CALLS", "1") == "1" else (float("nan"), [], (0, 0))
+t_one, all_one, r3 = timed(grouped_one_call)
+print(json.dumps({"reads": n_reads, "read_len": L, "groups": n_groups, "null_models": n_nulls, "single_icm_ms": round(t_single, 3),
+                  "score_groups_ms": round(t_one, 3), "ratio": round(t_one / t_single, 3),
+                  "one_call_per_group_ms": round(t_grouped, 3), "single_all": all_single, "score_groups_all": all_one,
+                  "one_call_per_group_all": all_grouped, "accepted_orfs_single": r1[0], "accepted_orfs_groups": r3[0],
+                  "accepted_orfs_per_group_calls": r2[0]}))

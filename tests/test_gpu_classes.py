@@ -58,38 +58,51 @@ def chunks(n, size):
     return [(b, min(n, b + size)) for b in range(0, n, size)] if size else [(0, n)]
 
 
-def score_groups(gpu, cls, hdrs, seqs, chunk, models, **kw):
+def score_groups(gpu, cls, hdrs, seqs, chunk, models, grouped=True, **kw):
     """the product's -c loop: yields, per processed read in the reference's order,
-    (chunk-global read index, gc, stops, isl, orfs, starts, errs-or-None) -- one gmg_mg_score_reads per (ICM, stop set)"""
+    (chunk-global read index, gc, stops, isl, orfs, starts, errs-or-None).  grouped: ONE gmg_mg_score_groups call per chunk and
+    stop-codon set (every ICM group a consecutive range of the gathered batch); else one gmg_mg_score_reads per (ICM, stop set)"""
     err = bool(kw.get("allow_indels") or kw.get("allow_subs"))
     for b, e in chunks(len(hdrs), chunk):
         reads = gpu.Reads.from_strings(seqs[b:e])
         order, icm_begin, gc, transl = cls.plan(hdrs[b:e])
-        for f in range(cls.n_icms):
-            g0, g1 = int(icm_begin[f]), int(icm_begin[f + 1])
-            if g0 == g1:
-                continue
+        group_of = np.searchsorted(icm_begin, np.arange(len(order)), side="right") - 1
+        for f in set(group_of.tolist()):
             path = os.path.realpath(cls.icm_file(f))
             if path not in models:
                 models[path] = gpu.Icm.open(path)
-            per_read = {}
-            for code in sorted(set(transl[g0:g1].tolist())):
-                ks = [k for k in range(g0, g1) if transl[k] == code]
-                stops = gpu.api.stop_codons_by_code(code)
+        per_read = {}
+        for code in sorted(set(transl.tolist())):
+            stops = gpu.api.stop_codons_by_code(code)
+            jobs = []                                   # [(positions k, groups or model)]
+            ks_all = [k for k in range(len(order)) if transl[k] == code]
+            if grouped:
+                groups, r = [], 0
+                for f in sorted(set(group_of[ks_all].tolist())):
+                    n = int(np.sum(group_of[ks_all] == f))
+                    groups.append((models[os.path.realpath(cls.icm_file(f))], r, r + n))
+                    r += n
+                jobs.append((ks_all, groups))
+            else:
+                for f in sorted(set(group_of[ks_all].tolist())):
+                    jobs.append(([k for k in ks_all if group_of[k] == f], models[os.path.realpath(cls.icm_file(f))]))
+            for ks, what in jobs:
                 ugc, inv = np.unique(gc[ks], return_inverse=True)
                 isl = np.array([gpu.api.ignore_score_len(gc[k], stops) for k in ks], np.int32)
                 batch = reads.select([int(order[k]) for k in ks])
-                res = gpu.mg_score_reads(models[path], gpu.NullSet.build(ugc, stops), batch, read_null=inv.astype(np.uint32),
-                                         read_ignore_score_len=isl, stop_codons=stops, **kw)
+                extra = dict(groups=what) if grouped else {}
+                res = gpu.mg_score_reads(None if grouped else what, gpu.NullSet.build(ugc, stops), batch, read_null=inv.astype(np.uint32),
+                                         read_ignore_score_len=isl, stop_codons=stops, **extra, **kw)
                 for r, k in enumerate(ks):
                     o = res[0][int(res[2][r]):int(res[2][r + 1])]
                     per_read[k] = (b + int(order[k]), float(gc[k]), stops, int(isl[r]), o, res[1], res[3] if err else None)
-            for k in range(g0, g1):
-                yield per_read[k]
+        for k in range(len(order)):
+            yield per_read[k]
 
 
+@pytest.mark.parametrize("grouped", [True, False])
 @pytest.mark.parametrize("name", ["default", "indel", "g90", "mixed_chunks", "mixed_sub"])
-def test_grouped_scoring_equals_the_reference_read_by_read(gpu, seqs_fa, genome_data, name):
+def test_grouped_scoring_equals_the_reference_read_by_read(gpu, seqs_fa, genome_data, name, grouped):
     g = np.load(os.path.join(GOLD, "classes_%s.npz" % name))
     flags = str(g["flags"]).split()
     kw = dict(allow_indels="-i" in flags, allow_subs="-s" in flags)
@@ -102,7 +115,7 @@ def test_grouped_scoring_equals_the_reference_read_by_read(gpu, seqs_fa, genome_
         acc_of.setdefault(int(r), []).append(a)
     n_lists = n_starts = 0
     k = -1
-    for k, (ri, gc, stops, isl, orfs, starts, errs) in enumerate(score_groups(gpu, cls, hdrs, seqs, int(g["chunk"]), {}, **kw)):
+    for k, (ri, gc, stops, isl, orfs, starts, errs) in enumerate(score_groups(gpu, cls, hdrs, seqs, int(g["chunk"]), {}, grouped=grouped, **kw)):
         assert hdrs[ri].split()[0] == str(g["reads"][k])
         assert (gc, ",".join(stops), isl) == (float(g["gc"][k]), str(g["stops"][k]), int(g["isl"][k]))
         want = g["orfs"][int(g["orf_off"][k]):int(g["orf_off"][k + 1])]
@@ -180,3 +193,88 @@ def test_null_set_build_equals_uploaded_models(gpu, seqs_fa):
         a = gpu.frame_score6(nc, gpu.NullSet.build(gcs, stops), reads, read_null=rn)
         b = gpu.frame_score6(nc, gpu.NullSet([gpu.Icm.indep(float(x), stops) for x in gcs]), reads, read_null=rn)
         assert a.tobytes() == b.tobytes()
+
+
+def ragged(rng, lengths):
+    return ["".join("acgt"[c] for c in rng.integers(0, 4, size=n)) for n in lengths]
+
+
+GICMS = ["NC_000915.icm", "seqs.cluster-0.run1.filt.gicm", "seqs.cluster-2.run1.filt.gicm", "seqs.cluster-4.run1.filt.gicm",
+         "seqs.cluster-5.run1.filt.gicm"]
+
+
+@pytest.mark.parametrize("shape", ["uniform500", "ragged", "tiny_groups", "long_reads", "one_group", "other_depth"])
+@pytest.mark.parametrize("mode", ["default", "indel", "fp64_table"])
+def test_score_groups_equals_one_call_per_group(gpu, shape, mode):
+    """gmg_mg_score_groups (ONE six-frame launch that swaps the groups' tables in LDS) = gmg_mg_score_reads group by group,
+    bytes of every record and start: group edges inside chunks, groups smaller than a chunk, empty groups, reads longer than a
+    chunk, a model of another depth among the groups (the any-shape kernel), the error branch and the fp64 table form"""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32((shape + mode).encode()))
+    if shape == "uniform500":
+        lens, cuts = [500] * 6000, [0, 1, 700, 701, 2500, 2500, 4097, 6000]
+    elif shape == "ragged":
+        lens = [int(x) for x in rng.integers(0, 900, 5000)]
+        cuts = [0, 900, 1800, 1803, 1803, 3333, 5000]
+    elif shape == "tiny_groups":
+        lens = [int(x) for x in rng.integers(30, 400, 600)]
+        cuts = list(range(0, 600, 3)) + [600]
+    elif shape == "long_reads":
+        lens = [int(x) for x in rng.integers(1500, 9000, 300)]
+        cuts = [0, 50, 51, 200, 300]
+    elif shape == "one_group":
+        lens, cuts = [int(x) for x in rng.integers(100, 700, 3000)], [0, 3000]
+    else:
+        lens, cuts = [int(x) for x in rng.integers(100, 700, 3000)], [0, 1000, 2000, 3000]
+    if mode == "indel":
+        lens, cuts = lens[:len(lens) // 6], [c // 6 for c in cuts]
+    seqs = ragged(rng, lens)
+    reads = gpu.Reads.from_strings(seqs)
+    files = list(GICMS)
+    if shape == "other_depth":
+        files = ["NC_000915.icm", os.path.join("..", "train", "syn_d4.icm"), "seqs.cluster-5.run1.filt.gicm"]
+    models = [gpu.Icm.open(os.path.join(DATA, f)) for f in files]
+    groups = [(models[g % len(models)], cuts[g], cuts[g + 1]) for g in range(len(cuts) - 1)]
+    gcs = np.linspace(0.3, 0.7, 37)
+    nulls = gpu.NullSet.build(gcs)
+    read_null = rng.integers(0, len(gcs), len(seqs)).astype(np.uint32)
+    read_isl = rng.choice([2 ** 31 - 1, 200, 90], len(seqs)).astype(np.int32)
+    kw = dict(min_gene_len=60, allow_indels=mode == "indel")
+    with gpu.option("mg_gene32", 0 if mode == "fp64_table" else 1):
+        whole = gpu.mg_score_reads(None, nulls, reads, read_null=read_null, read_ignore_score_len=read_isl, groups=groups, **kw)
+        n_orfs = n_starts = 0
+        for m, b, e in groups:
+            if b == e:
+                continue
+            part = gpu.mg_score_reads(m, nulls, reads.select(np.arange(b, e, dtype=np.uint64)), read_null=read_null[b:e],
+                                      read_ignore_score_len=read_isl[b:e], **kw)
+            o0, o1 = int(whole[2][b]), int(whole[2][e])
+            mine = whole[0][o0:o1].copy()
+            assert len(mine) == len(part[0])
+            if len(mine) == 0:
+                continue
+            s0 = int(mine["start_begin"][0])
+            s1 = int(mine["start_begin"][-1]) + int(mine["n_starts"][-1])
+            mine["read"] -= b                            # the two fields that count from the batch's start
+            mine["start_begin"] -= s0
+            assert mine.tobytes() == part[0].tobytes(), (shape, b, e)
+            assert whole[1][s0:s1].tobytes() == part[1].tobytes(), (shape, b, e)
+            if mode == "indel":
+                assert whole[3][s0:s1].tobytes() == part[3].tobytes()
+            n_orfs += len(mine)
+            n_starts += s1 - s0
+    assert n_orfs == len(whole[0]) and n_starts == len(whole[1]) and n_starts > 100
+
+
+def test_score_groups_refuses_bad_group_lists(gpu):
+    rng = np.random.default_rng(1)
+    reads = gpu.Reads.from_strings(ragged(rng, [300] * 10))
+    m = gpu.Icm.open(os.path.join(DATA, "NC_000915.icm"))
+    nulls = gpu.NullSet.build([0.5])
+    rn = np.zeros(10, np.uint32)
+    for bad in ([(m, 0, 5)], [(m, 0, 5), (m, 6, 10)], [(m, 1, 10)], [(m, 0, 11)], [],
+                [(m, 0, 5), (gpu.Icm.open(os.path.join(DATA, "cluster-4.icm")), 5, 10)]):      # ... a periodicity-1 model
+        with pytest.raises(gpu.GmgError):
+            gpu.mg_score_reads(None, nulls, reads, read_null=rn, groups=bad)
+    with pytest.raises(gpu.GmgError):                   # groups need the per-read null models
+        gpu.mg_score_reads(None, gpu.Icm.indep(0.5), reads, groups=[(m, 0, 10)])
