@@ -18,7 +18,8 @@
 struct OrfTmp { double s; int32_t which, pad; };   // one in-frame position of the ascending pass
 
 struct gmg_orf_batch {
-    float *d_gene6;              // fused path: per-base gene values, [6][total_bases] (allocated on first use)
+    double *d_walk;              // events path: running sums in walking order, [2][total_bases] (allocated on first use)
+    float *d_gene6;              // fused / events path: per-base gene values, [6][total_bases] (allocated on first use)
     OrfTmp *d_tmp;               // fused path: one slot per in-frame position, same offsets as the start lists
     gmg_orf *d_orfs;
     gmg_segments *segs;          // the ORF buffers as segments (REVERSED / COMPLEMENTED)
@@ -246,6 +247,279 @@ __global__ __launch_bounds__(256) void k_orf_fused(OrfFusedArgs fa)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Events path (round 3; default model shapes whose sums are exact in any order -- the test of gmg_mg.hip's fused kernel).
+//
+// score[j-1] - indep_score[j-1] of an ORF is a sum over its buffer positions 0 .. j-1 (glimmer3.cc:1346-1347, 1369).  Every term
+// is (double) a float of the gene table - (double) a float of the null table, all multiples of 2^(e_min - 150); while
+// ceil(log2 R) + e_max - e_min <= 28 (R = longest read + 2) every partial sum in every order is an exact double, so the
+// reference's two sequential sums and their difference are exact too and ANY way of adding the same terms gives the same bits.
+// Then an ORF need not be walked base by base:
+//   * from buffer position HEAD = 12 on (>= W-1) a position's window lies inside the ORF and its value is the whole-read value of
+//     the six-frame pass -- row (1 + j) % 3 of the strand's three rows.  All ORFs of one reading-frame class use the same row at
+//     the same base, so ONE running sum per strand and class over the read serves them all: k_orf_walk_sums writes, per base p
+//     and strand, Q[p] = the sum of the class of p over the bases the walk has passed before p (one double per base and strand:
+//     a base is an in-frame position of exactly one class), and sum_{k = HEAD}^{j-1} = Q[p_j] - Q[p_HEAD];
+//   * the first HEAD positions (partial windows: the ORF's own start) are HEAD descents per ORF;
+//   * the scan over the in-frame codons (glimmer3.cc:1355-1421) is integer work on the packed bases; a start codon -- an EVENT --
+//     costs one 8-byte read of Q.
+// k_orf_fused (one lane per ORF, ~290 positions of dependent double additions behind a gather each) stays as the path for models
+// that fail the test; both give the reference's start lists (tests/test_gpu_parity.py, tests/bench/bench_orfs.py compares bytes).
+// ---------------------------------------------------------------------------
+struct OrfWalkArgs {
+    const uint32_t *packed;
+    const uint64_t *read_off;
+    uint64_t n_reads, total;
+    const float *gene6;          // [6][total]: rows 0-2 reversed buffer (forward ORFs), rows 3-5 complemented buffer
+    const float *null_dense;     // [3][64] full-window values of the (3,2,3) null model
+    double *q;                   // [2][total]: forward-strand sums, reverse-strand sums
+};
+
+constexpr int OW_U = 4;          // trips of 64 walk steps whose loads are in flight together
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double ow_dpp_add(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return x + __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));      // (lanes without a source add 0)
+}
+__device__ __forceinline__ double ow_wave_scan(double x)           // inclusive sum over the lanes of a wave
+{
+    x = ow_dpp_add<0x111, 0xf>(x);                      // row_shr:1
+    x = ow_dpp_add<0x112, 0xf>(x);
+    x = ow_dpp_add<0x114, 0xf>(x);
+    x = ow_dpp_add<0x118, 0xf>(x);
+    x = ow_dpp_add<0x142, 0xa>(x);                      // row_bcast:15 into rows 1 and 3
+    x = ow_dpp_add<0x143, 0xc>(x);                      // row_bcast:31 into rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ double ow_last_lane(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return __longlong_as_double((long long)((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63) << 32 |
+                                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63)));
+}
+
+// One wave per (read, strand), 64 consecutive walk steps at a time, one per lane -- every load and store of a wave covers 64
+// consecutive bases (the first version gave a lane 8 consecutive steps: 2.8 ms per 200 k reads, an eighth of every line used per
+// instruction) --, the three class sums scanned over the wave with DPP moves, carries in scalar registers.
+//   forward ORFs (frame > 0) walk DOWN the read: step t <-> base p = L-1-t; at base p' an ORF whose in-frame positions are
+//     p == c - 1 (mod 3) takes row f = (c - p') mod 3 of rows 0-2 and the null value of window (S[p'+2], S[p'+1], S[p']);
+//   reverse ORFs walk UP: step t <-> p = t; an ORF with in-frame positions p == c (mod 3) takes row f = (1 + p' - c) mod 3 of rows
+//     3-5 and the null value of (comp S[p'-2], comp S[p'-1], comp S[p']).
+// Q[p] = the class-of-p sum over the steps before p's.  Windows that leave the read see the neighbouring read's bases (or the
+// guard words): such terms are in both Q values an ORF subtracts, or in neither.
+__global__ __launch_bounds__(256) void k_orf_walk_sums(OrfWalkArgs a)
+{
+    __shared__ double s_null[3 * 64];
+    for (int i = threadIdx.x; i < 3 * 64; i += 256) s_null[i] = (double)a.null_dense[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t it = wave; it < 2 * a.n_reads; it += n_waves) {
+        const uint64_t r = it >> 1;
+        const bool fwd = (it & 1) == 0;
+        const uint64_t off = a.read_off[r];
+        const uint32_t n = (uint32_t)(a.read_off[r + 1] - off);
+        const float *rows = a.gene6 + (fwd ? 0 : 3) * a.total;
+        double *q = a.q + (fwd ? 0 : a.total);
+        double carry[3] = {0.0, 0.0, 0.0};
+        // OW_U trips of 64 steps per iteration, all of their loads requested before the first scan (one trip at a time left the
+        // wave waiting for memory eight times per 500-bp read: 1.36 ms per 200 k reads)
+        for (uint32_t t0 = 0; t0 < n; t0 += 64 * OW_U) {
+            float v[OW_U][3];
+            uint32_t w3[OW_U];
+#pragma unroll
+            for (int u = 0; u < OW_U; u++) {
+                const uint32_t t = t0 + 64 * u + lane;
+                const bool in = t < n;
+                const uint64_t g = off + (in ? (fwd ? n - 1 - t : t) : 0);
+#pragma unroll
+                for (int f = 0; f < 3; f++) v[u][f] = in ? rows[(uint64_t)f * a.total + g] : 0.0f;
+                w3[u] = (uint32_t)dev_window_bits(a.packed, (int64_t)g - 2) & 0xfffu;      // bases g-2 .. g+3 at fields 0 .. 5
+            }
+#pragma unroll
+            for (int u = 0; u < OW_U; u++) {
+                const uint32_t t = t0 + 64 * u + lane;
+                if (t0 + 64 * u >= n) break;                        // (wave-uniform)
+                const bool in = t < n;
+                const uint32_t p = in ? (fwd ? n - 1 - t : t) : 0;  // position in the read
+                // the three chars of the null window, oldest buffer char in the low bits
+                const uint32_t n6 = fwd ? (((w3[u] >> 8) & 3u) | (((w3[u] >> 6) & 3u) << 2) | (((w3[u] >> 4) & 3u) << 4)) : ((w3[u] & 63u) ^ 63u);
+                const uint32_t pm = p % 3u;
+                const uint32_t c_mine = fwd ? (p + 1u) % 3u : pm;
+                const double d0 = (double)v[u][0] - s_null[n6], d1 = (double)v[u][1] - s_null[64 + n6], d2 = (double)v[u][2] - s_null[128 + n6];
+                double mine = 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const uint32_t f = fwd ? (uint32_t)(c + 3 - (int)pm) % 3u : (uint32_t)(1 + (int)pm + 3 - c) % 3u;
+                    const double x = in ? (f == 0 ? d0 : f == 1 ? d1 : d2) : 0.0;
+                    const double inc = ow_wave_scan(x);
+                    if (c_mine == (uint32_t)c) mine = carry[c] + (inc - x);     // exclusive: the steps before this one
+                    carry[c] += ow_last_lane(inc);
+                }
+                if (in) q[off + p] = mine;
+            }
+        }
+    }
+}
+
+struct OrfEventArgs {
+    OrfScanArgs sc;
+    GmgDevModel gene, nul;
+    const float *gene6;
+    const double *q;
+    uint64_t total;
+};
+
+// One lane per ORF: the HEAD positions by descent, then the codons from the 5' end down to the stop as the reference visits them
+// (glimmer3.cc:1355-1421), pure bit work on the packed bases; only a start codon touches memory (Q, and the start it pushes).
+__global__ __launch_bounds__(256) void k_orf_events(OrfEventArgs fa)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
+    const OrfScanArgs &a = fa.sc;
+    const int cstride = fa.gene.cstride;
+    uint8_t *s_shift = s_lds;                                       // [3][cstride]
+    float *s_dense = (float *)(s_lds + 3 * cstride);                // [3][64]
+    float *s_part = s_dense + 3 * 64;                               // [3][20]
+    __shared__ int8_t s_which[64];                                  // start pattern index of a codon (buff[j+2], buff[j+1], buff[j]), -1: none
+    for (int i = threadIdx.x * 16; i < 3 * cstride; i += 256 * 16) *(uint4 *)(s_shift + i) = *(const uint4 *)(fa.gene.cshift + i);
+    for (int i = threadIdx.x; i < 3 * 64; i += 256) s_dense[i] = fa.nul.dense[i];
+    for (int i = threadIdx.x; i < 3 * 20; i += 256) s_part[i] = fa.nul.dense_part[i];
+    if (threadIdx.x < 64) {                                         // Codon_t::Can_Be (gene.cc:39-66) for every definite codon
+        const uint32_t c = threadIdx.x, m = (1u << ((c >> 4) & 3u)) << 8 | (1u << ((c >> 2) & 3u)) << 4 | (1u << (c & 3u));
+        int which = -1;
+        for (int p = a.n_pat - 1; p >= 0; p--) {
+            const uint32_t x = m & a.pat[p];
+            if ((x & 0xf00u) && (x & 0xf0u) && (x & 0x0fu)) which = p;
+        }
+        s_which[c] = (int8_t)which;
+    }
+    __syncthreads();
+
+    const int W = fa.gene.W, D = fa.gene.D;
+    const int HEAD = (W - 1 + 2) / 3 * 3;                           // the smallest multiple of 3 >= W - 1 (12 for W = 12): <= 15
+    const uint32_t sh_top = 2u * (uint32_t)(W - 1);
+    const uint32_t ctot = (uint32_t)fa.gene.ctot;
+
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const gmg_orf orf = a.orfs[i];
+        const uint64_t r_off = a.read_off[orf.read];
+        const int L = (int)(a.read_off[orf.read + 1] - r_off);
+        const int len = orf.orf_len;
+        const bool fwd = orf.frame > 0;
+        int lo, hi, k0;
+        bool trunc;
+        if (fwd) { hi = orf.stop_position - 1; lo = hi - len; trunc = lo < 3 && a.allow_truncated; k0 = orf.stop_position - len - 2; }
+        else { lo = orf.stop_position + 2; hi = lo + len; trunc = L - hi < 3 && a.allow_truncated; k0 = orf.stop_position + len + 4; }
+        const int lowest_j = a.min_gene_len - 3 < 3 ? a.min_gene_len - 3 : 3;
+        int j_lo = lowest_j > 1 ? lowest_j : 1;
+        if (j_lo + 3 < a.min_gene_len) j_lo = a.min_gene_len - 3;
+        j_lo = (j_lo + 2) / 3 * 3;
+        const uint32_t comp = fwd ? 0u : 3u;
+        const int64_t g_b0 = (int64_t)r_off + (fwd ? hi - 1 : lo);  // base of buffer position 0; position j at g_b0 -/+ j
+        const int64_t dirg = fwd ? -1 : 1;
+
+        // ---- the head: score[j-1] - indep[j-1] for j = 3, 6, .. HEAD, by the partial-window rule (icm.cc:807-842)
+        double dh[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};             // dh[j / 3] (dh[0] unused: j >= 1)
+        {
+            double gsum = 0.0, nsum = 0.0;
+            uint32_t C = 0, n6 = 0;
+            int f = 1;
+            const int head = len < HEAD ? len : HEAD;
+            for (int j = 0; j < head; j++) {
+                const int64_t g = g_b0 + dirg * j;
+                const uint32_t code = (uint32_t)dev_code(a.packed, (uint64_t)g) ^ comp;
+                C = (C >> 2) | (code << sh_top);
+                n6 = (n6 >> 2) | (code << 4);
+                const uint8_t *tab = s_shift + f * cstride;
+                const int thr2 = 2 * ((W - 1) - j);
+                uint32_t idx = 0, lvl = 0, width = 1, node = 0xffffffffu;
+                for (int l = 0; l < D; l++) {
+                    const uint32_t sh = tab[lvl + idx];
+                    if (node == 0xffffffffu && (int)sh < thr2) node = lvl + idx;
+                    idx = (idx << 2) + ((C >> sh) & 3u);
+                    lvl += width;
+                    width <<= 2;
+                }
+                if (node == 0xffffffffu) node = lvl + idx;
+                const float gv = fa.gene.crow[((size_t)f * ctot + node) * 4 + code];
+                float nv;
+                if (j >= 2) nv = s_dense[f * 64 + n6];
+                else if (j == 1) nv = s_part[f * 20 + 4 + (n6 >> 2)];
+                else nv = s_part[f * 20 + code];
+                gsum += (double)gv;
+                nsum += (double)nv;
+                if (j % 3 == 2) dh[(j + 1) / 3] = gsum - nsum;      // = score[j] - indep[j]: the value position j + 1 asks for
+                f = f == 2 ? 0 : f + 1;
+            }
+        }
+        const double q_head = len > HEAD ? fa.q[(fwd ? 0 : fa.total) + (uint64_t)(g_b0 + dirg * HEAD)] : 0.0;
+
+        // ---- the scan, from the 5' end (j = len - 1) down; only in-frame positions j >= j_lo can carry a start
+        gmg_start *out = a.starts + a.start_off[i];
+        uint32_t n_starts = 0;
+        int first_pos = 0, best_pos = 0, first_j = 0, best_j = 0;
+        bool first_trunc = false, best_trunc = false;
+        double first_score = -DBL_MAX, best_score = -DBL_MAX;
+        int j = len - 1;
+        if (j >= j_lo) {
+            int64_t g = g_b0 + dirg * j;                            // walks towards g_b0
+            uint32_t w = a.packed[g >> 4];
+            auto next_code = [&]() __attribute__((always_inline)) {
+                const uint32_t c = ((w >> (2u * (unsigned)(g & 15))) & 3u) ^ comp;
+                const int64_t g2 = g - dirg;
+                if ((g ^ g2) >> 4) w = a.packed[g2 >> 4];
+                g = g2;
+                return c;
+            };
+            uint32_t n6 = 0, have = 0;                              // the last three chars shifted in (newest = lowest j in bits 0-1)
+            for (; j % 3 != 0; j--) { n6 = ((n6 << 2) | next_code()) & 63u; have++; }     // the incomplete codon at the 5' end
+            for (; j >= j_lo; j -= 3) {
+                n6 = ((n6 << 2) | next_code()) & 63u;               // buff[j]: the codon (buff[j+2], buff[j+1], buff[j]) is complete if have >= 2
+                const int which = have >= 2 ? (int)s_which[n6] : -1;
+                have = 2;
+                if (which >= 0 || (first_pos == 0 && trunc)) {
+                    const int k = fwd ? k0 + (len - 1 - j) : k0 - (len - 1 - j);
+                    double next_s;
+                    if (j <= HEAD) next_s = dh[j / 3];
+                    else next_s = dh[HEAD / 3] + (fa.q[(fwd ? 0 : fa.total) + (uint64_t)(g_b0 + dirg * j)] - q_head);
+                    const double pushed = (j + 2 > a.ignore_score_len && next_s < 0.0) ? 0.0 : next_s;
+                    gmg_start st;
+                    st.score = pushed; st.j = j + 2; st.pos = k; st.first = (first_pos == 0);
+                    if (which >= 0 && first_pos == 0 && trunc) {
+                        st.which = -1; st.truncated = 1;
+                        out[n_starts++] = st;
+                        st.first = 0;
+                    }
+                    st.which = which; st.truncated = (which < 0);
+                    out[n_starts++] = st;
+                    if (first_pos == 0) { first_score = next_s; first_pos = k; first_j = j + 2; first_trunc = (first_pos == 0 && trunc); }
+                    if (next_s > best_score) { best_score = next_s; best_pos = k; best_j = j + 2; best_trunc = st.truncated; }
+                }
+                if (j - 3 >= j_lo) { n6 = ((n6 << 2) | next_code()) & 63u; n6 = ((n6 << 2) | next_code()) & 63u; }    // buff[j-1], buff[j-2]
+            }
+        }
+        if (a.use_first_start) { best_score = first_score; best_pos = first_pos; best_j = first_j; best_trunc = first_trunc; }
+        (void)best_trunc;
+        gmg_orf_result res;
+        res.start_begin = (uint32_t)a.start_off[i];
+        res.first_j = first_j; res.best_j = best_j; res.best_pos = best_pos;
+        res.best_score = best_score;
+        res.orf_is_truncated = trunc;
+        if (first_j + 1 < a.min_gene_len) { res.n_starts = 0; res.is_tentative_gene = 0; res.gene_score = 0.0; }
+        else {
+            res.n_starts = n_starts;
+            res.is_tentative_gene = best_score > a.start_threshold;
+            res.gene_score = 100.0 * best_score / (best_j - 2);
+        }
+        a.results[i] = res;
+        a.nst[i] = res.n_starts;
+    }
+}
+
 // exact any-shape path: cumulative scores in scratch (k_seg_cum), then one lane per ORF scans them
 __global__ __launch_bounds__(256) void k_orf_scan(OrfScanArgs a)
 {
@@ -405,7 +679,7 @@ extern "C" int gmg_orf_batch_free(gmg_orf_batch *b)
 {
     if (!b) return GMG_OK;
     if (b->segs) gmg_segments_free(b->segs);
-    void *ptrs[] = {b->d_orfs, b->d_start_off, b->d_score, b->d_indep, b->d_results, b->d_starts, b->d_gene6, b->d_tmp,
+    void *ptrs[] = {b->d_orfs, b->d_start_off, b->d_score, b->d_indep, b->d_results, b->d_starts, b->d_gene6, b->d_tmp, b->d_walk,
                     b->d_nst, b->d_coff, b->d_scan_tmp, b->d_compact};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -430,16 +704,52 @@ extern "C" int gmg_score_orfs(const gmg_model *gene, const gmg_model *nul, const
     if (b->n == 0) return GMG_OK;
     hipStream_t s = (hipStream_t)stream;
     gmg_orf_batch *mb = const_cast<gmg_orf_batch *>(b);            // scratch is allocated on first use
+    // option orfs_exact_path: 0 = the fastest path the models allow, 1 = the any-shape path, 2 = k_orf_fused even where the events path could run
     const bool fused = gene->dev.has_fast && gene->dev.D == 7 && gene->dev.P == 3 && gene->dev.W >= 3 && gene->dev.W <= 15 &&
-                       nul->dev.has_dense && nul->dev.W == 3 && nul->dev.P == 3 && !gmg_opt(GMG_OPT_ORFS_EXACT_PATH);
-    if (fused) {
+                       nul->dev.has_dense && nul->dev.W == 3 && nul->dev.P == 3 && gmg_opt(GMG_OPT_ORFS_EXACT_PATH) != 1;
+    // the events path: every sum of the batch exact in any order (the test of gmg_mg.hip's fused kernel; R = longest read + 2)
+    bool events = false;
+    if (fused && gmg_opt(GMG_OPT_ORFS_EXACT_PATH) == 0) {
+        const int mn = gene->min_exp < nul->min_exp ? gene->min_exp : nul->min_exp, mx = gene->max_exp > nul->max_exp ? gene->max_exp : nul->max_exp;
+        const uint64_t longest = reads->max_len ? reads->max_len : reads->total_bases;
+        int clog = 0;
+        while ((1ull << clog) < longest + 2) clog++;
+        events = !gene->odd_values && !nul->odd_values && (mx < mn || clog + mx - mn <= 28) && nul->dev.dense_part == nul->dev.dense + 192;
+    }
+    if (events) {
+        if (!mb->d_gene6 || !mb->d_walk) {
+            float *g6 = mb->d_gene6;
+            double *wk = nullptr;
+            hipError_t e = g6 ? hipSuccess : hipMalloc((void **)&g6, (size_t)6 * reads->total_bases * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc((void **)&wk, (size_t)2 * reads->total_bases * sizeof(double));
+            if (e != hipSuccess) {
+                if (g6 && !mb->d_gene6) (void)hipFree(g6);
+                return gmg_set_error(GMG_ENOMEM, "gmg_score_orfs: scratch: %s", hipGetErrorString(e));
+            }
+            mb->d_gene6 = g6;
+            mb->d_walk = wk;
+        }
+        int rc = gmg_launch_gene6(gene, reads, mb->d_gene6, s);
+        if (rc) return gmg_set_error(rc, "gmg_score_orfs: gene-only pass refused the model");
+        OrfWalkArgs wa;
+        wa.packed = reads->d_packed;
+        wa.read_off = reads->d_off;
+        wa.n_reads = reads->n_reads;
+        wa.total = reads->total_bases;
+        wa.gene6 = mb->d_gene6;
+        wa.null_dense = nul->dev.dense;
+        wa.q = mb->d_walk;
+        const uint64_t waves = 2 * reads->n_reads, wblocks = (waves + 3) / 4;
+        hipLaunchKernelGGL(k_orf_walk_sums, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
+        GMG_HIP(hipGetLastError());
+    } else if (fused) {
         if (!mb->d_gene6 || !mb->d_tmp) {                          // both or neither: a failed second allocation leaves nothing behind
-            float *g6 = nullptr;
+            float *g6 = mb->d_gene6;
             OrfTmp *tmp = nullptr;
-            hipError_t e = hipMalloc((void **)&g6, (size_t)6 * reads->total_bases * sizeof(float));
+            hipError_t e = g6 ? hipSuccess : hipMalloc((void **)&g6, (size_t)6 * reads->total_bases * sizeof(float));
             if (e == hipSuccess) e = hipMalloc((void **)&tmp, (b->max_starts ? b->max_starts : 1) * sizeof(OrfTmp));
             if (e != hipSuccess) {
-                if (g6) (void)hipFree(g6);
+                if (g6 && !mb->d_gene6) (void)hipFree(g6);
                 return gmg_set_error(GMG_ENOMEM, "gmg_score_orfs: scratch: %s", hipGetErrorString(e));
             }
             mb->d_gene6 = g6;
@@ -492,7 +802,17 @@ extern "C" int gmg_score_orfs(const gmg_model *gene, const gmg_model *nul, const
     }
     const uint64_t blocks = (b->n + 255) / 256;
     const unsigned grid = (unsigned)(blocks < 256 * 16 ? blocks : 256 * 16);
-    if (fused) {
+    if (events) {
+        OrfEventArgs ea;
+        ea.sc = a;
+        ea.gene = gene->dev;
+        ea.nul = nul->dev;
+        ea.gene6 = b->d_gene6;
+        ea.q = b->d_walk;
+        ea.total = reads->total_bases;
+        const size_t lds = (size_t)3 * gene->dev.cstride + (3 * 64 + 3 * 20) * sizeof(float);
+        hipLaunchKernelGGL(k_orf_events, dim3(grid), dim3(256), lds, s, ea);
+    } else if (fused) {
         OrfFusedArgs fa;
         fa.sc = a;
         fa.gene = gene->dev;

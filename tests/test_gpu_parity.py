@@ -288,14 +288,18 @@ def test_frame6_full_size_properties(gpu, nc, oracle, o_nc):
 
 # ---------------------------------------------------------------- a12: Score_Orfs inner loop
 
+ORF_PATHS = {"events": 0, "exact": 1, "fused": 2}        # option orfs_exact_path (gmg_orfs.hip)
+
+
 @pytest.mark.parametrize("name,kw", [("orfs_default", {}), ("orfs_X", {"allow_truncated": True}),
                                      ("orfs_g90_first", {"min_gene_len": 90, "use_first_start": True})])
-@pytest.mark.parametrize("path", ["fused", "exact"])
+@pytest.mark.parametrize("path", sorted(ORF_PATHS))
 def test_score_orfs_golden_start_lists(gpu, nc, fa_reads, name, kw, path, request_finalizers):
     """ORFs from the reference's Find_Orfs on seqs.fa; start lists, gene score and gene length must equal
     what the reference's Score_Orfs handed to Add_Events_* (tests/golden/orfs_*.npz), bit for bit --
-    through the fused path (gene-only six-frame pass + k_orf_fused) and the exact any-model path."""
-    gpu.set_option("orfs_exact_path", 1 if path == "exact" else 0)
+    through the events path (running sums per strand and class, an ORF visits its start codons only), the fused path
+    (gene-only six-frame pass + k_orf_fused: one lane walks the ORF) and the exact any-model path."""
+    gpu.set_option("orfs_exact_path", ORF_PATHS[path])
     request_finalizers.append(lambda: gpu.set_option("orfs_exact_path", 0))
     g = np.load(os.path.join(GOLD, name + ".npz"))
     gc = float(np.load(os.path.join(GOLD, "frames_nc.npz"))["gc"])
@@ -314,11 +318,11 @@ def test_score_orfs_golden_start_lists(gpu, nc, fa_reads, name, kw, path, reques
         assert np.array_equal(got, g["start_int"][b:b + cnt])
 
 
-@pytest.mark.parametrize("path", ["fused", "exact"])
+@pytest.mark.parametrize("path", sorted(ORF_PATHS))
 def test_score_orfs_random_orfs_on_ragged_reads_vs_oracle(gpu, nc, oracle, o_nc, path, request_finalizers):
     """random in-range ORFs (both strands, lengths 3..read length, also not a multiple of 3) on reads of ragged lengths:
     every field of every start and of the per-ORF result must equal the oracle's Score_Orfs restatement"""
-    gpu.set_option("orfs_exact_path", 1 if path == "exact" else 0)
+    gpu.set_option("orfs_exact_path", ORF_PATHS[path])
     request_finalizers.append(lambda: gpu.set_option("orfs_exact_path", 0))
     rng = np.random.default_rng(77)
     lengths = [int(x) for x in rng.integers(40, 900, size=120)] + [12, 13, 30, 500, 2100]
@@ -363,3 +367,60 @@ def test_score_orfs_rejects_wrapping_orfs(gpu, nc, fa_reads):
         gpu.score_orfs(nc, gpu.Icm.indep(0.5), fa_reads, np.array([[0, 1, 30, 90]]))     # lo < 0: circular wrap
     with pytest.raises(gpu.GmgError):
         gpu.score_orfs(nc, gpu.Icm.indep(0.5), fa_reads, np.array([[0, -1, 450, 90]]))   # hi > L
+
+
+def test_score_orfs_full_size_properties(gpu, nc, oracle, o_nc, request_finalizers):
+    """BASELINE configs[1] shape on the glimmer3 side: 1 M x 500 bp, every ORF Find_Orfs gives (gmg_find_orfs, ~5 M of them)
+    through gmg_orfs_upload + gmg_score_orfs on the events path.  Properties: (1) determinism: two calls, the same bytes;
+    (2) bookkeeping: start lists back to back in ORF order; (3) the three device paths agree on a 40,000-read slice; (4) sampled
+    ORFs equal the oracle's Score_Orfs; (5) a batch beyond the 32-bit index fields is refused with GMG_ETOOBIG, not wrapped."""
+    n, L = 1_000_000, 500
+    packed, off = gpu.synth.packed_reads(n, L, 11)
+    reads = gpu.Reads(packed, off)
+    found, first = gpu.find_orfs(reads, min_gene_len=90)
+    assert len(found) > 3 * n
+    rows = np.stack([found["read"].astype(np.int64), found["frame"], found["stop_position"], found["orf_len"]], 1)
+    indep = gpu.Icm.indep(0.5)
+    kw = dict(min_gene_len=90)
+    res, starts = gpu.score_orfs(nc, indep, reads, rows, **kw)
+    res2, starts2 = gpu.score_orfs(nc, indep, reads, rows, **kw)
+    total = int(res["start_begin"][-1]) + int(res["n_starts"][-1])
+    assert res.tobytes() == res2.tobytes() and starts[:total].tobytes() == starts2[:total].tobytes()
+    del res2, starts2
+    assert int(res["n_starts"].sum(dtype=np.uint64)) == total > n
+    assert np.array_equal(res["start_begin"], np.concatenate([[0], np.cumsum(res["n_starts"], dtype=np.uint64)[:-1]]).astype(np.uint32))
+    # (3) a slice through all three paths
+    m = 40_000
+    sl_reads = gpu.Reads(*gpu.synth.packed_reads(m, L, 11))
+    sl_rows = rows[:int(first[m])]
+    got = {}
+    for name, opt in ORF_PATHS.items():
+        gpu.set_option("orfs_exact_path", opt)
+        request_finalizers.append(lambda: gpu.set_option("orfs_exact_path", 0))
+        r_, s_ = gpu.score_orfs(nc, indep, sl_reads, sl_rows, **kw)
+        got[name] = (r_.tobytes(), s_[:int(r_["start_begin"][-1]) + int(r_["n_starts"][-1])].tobytes())
+    gpu.set_option("orfs_exact_path", 0)
+    assert got["events"] == got["fused"] == got["exact"]
+    assert got["events"][0] == res[:len(sl_rows)].tobytes()                 # ... and the slice of the big batch
+    # (4) the oracle on sampled ORFs
+    o_indep = oracle.indep(0.5)
+    prm = oracle.orf_params(**kw)
+    rng = np.random.default_rng(5)
+    for i in [0, 1, len(rows) - 1] + [int(x) for x in rng.integers(0, len(rows), 300)]:
+        r, frame, stop, ln = (int(x) for x in rows[i])
+        seq = gpu.synth.unpack_ascii(packed, r * L, L)
+        cnt, out, want = oracle.score_orf(o_nc, o_indep, seq, frame, stop, ln, prm)
+        g_ = res[i]
+        assert (g_["first_j"], g_["best_j"], g_["best_pos"], g_["best_score"]) == (out.first_j, out.best_j, out.best_pos, out.best_score)
+        if cnt < 0:
+            assert g_["n_starts"] == 0
+            continue
+        st = starts[g_["start_begin"]:g_["start_begin"] + g_["n_starts"]]
+        assert [(s["j"], s["pos"], s["which"], s["truncated"], s["first"], s["score"]) for s in st] == \
+               [(w.j, w.pos, w.which, w.truncated, w.first, w.score) for w in want]
+    # (5) the guard: with the limit lowered the same upload is refused, never wrapped
+    gpu.set_option("mg_max_entries", 1_000_000)
+    request_finalizers.append(lambda: gpu.set_option("mg_max_entries", 0x7ffffffe))
+    with pytest.raises(gpu.GmgError) as e:
+        gpu.score_orfs(nc, indep, reads, rows, **kw)
+    assert e.value.code == -7                                                 # GMG_ETOOBIG
