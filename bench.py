@@ -11,6 +11,10 @@ every rank scores its own shard (weak scaling, no collective in the data path --
 embarrassingly).  `--scaling strong` keeps the job fixed instead: --reads reads in total, cut over
 the ranks by gmg_shard_plan (contiguous ranges of equal base count).  Rank 0 prints ONE JSON line.
 
+`--data genome`: SURVEY.md 8(d)'s second input distribution -- the same job shape with every read cut uniformly from
+tests/golden/data/NC_000915.fna (the reference's sample genome), either strand; same JSON contract, same head + tail check
+("data" says which).  The default (what the driver runs) is the synthetic stream.
+
 Extra objects on that line:
   roofline      dominant kernels (k_frame6t + k_frame6p, one call) vs the HBM roof: achieved = 48.25 algorithmic
                 bytes per base (0.25 B packed input + 6 x 8 B fp64 Frame_Scores) x bases per call /
@@ -41,6 +45,7 @@ HBM_PEAK_GBPS = 8000.0                    # MI355X spec peak, /opt/skills/guides
 SEED = 20260101
 MODEL = os.path.join(ROOT, "tests", "golden", "data", "NC_000915.icm")
 REF_BENCH = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+GENOME = os.path.join(ROOT, "tests", "golden", "data", "NC_000915.fna")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -121,11 +126,31 @@ def port_bench(first_read, n_reads, L, seed, gc, packed):
             "xor": "%016x" % int(np.bitwise_xor.reduce(bits)), "mix": "%016x" % mix}
 
 
-def cpu_sample(stream_first_read, local_first_read, n_reads, L, seed, gc, packed):
+def ref_bench_fasta(local_first_read, n_reads, L, gc, packed):
+    """the real reference on reads that are not the synthetic stream: the sample goes over as a FASTA file"""
+    import tempfile
+    import _gmg_pkg
+    gmg = _gmg_pkg.load()
+    seq = gmg.synth.unpack_ascii(packed, local_first_read * L, n_reads * L)
+    with tempfile.NamedTemporaryFile("wb", suffix=".fa", delete=False) as f:
+        for r in range(n_reads):
+            f.write(b">r%d\n" % r + seq[r * L:(r + 1) * L] + b"\n")
+        path = f.name
+    try:
+        res = subprocess.run([REF_BENCH, MODEL, str(n_reads), str(L), "@" + path, repr(float(gc))], check=True,
+                             stdout=subprocess.PIPE, timeout=900)
+    finally:
+        os.unlink(path)
+    return json.loads(res.stdout)
+
+
+def cpu_sample(stream_first_read, local_first_read, n_reads, L, seed, gc, packed, from_stream=True):
     """reads [stream_first_read, +n_reads) of the stream of `seed` = reads [local_first_read, +n_reads) of `packed`
     -> (result dict, kind)"""
     if os.access(REF_BENCH, os.X_OK):
         try:
+            if not from_stream:
+                return ref_bench_fasta(local_first_read, n_reads, L, gc, packed), "reference"
             return ref_bench(stream_first_read, n_reads, L, seed, gc), "reference"
         except Exception as e:          # fall through to the port, but say why
             sys.stderr.write("bench: oracle/_ref/ref_bench failed (%s); timing the oracle port\n" % e)
@@ -208,6 +233,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--cpu-reads", type=int, default=20_000, help="reads in each CPU sample (0 = no CPU legs, no check)")
     ap.add_argument("--no-cli", action="store_true", help="skip the CLI end-to-end leg")
+    ap.add_argument("--data", choices=("synthetic", "genome"), default="synthetic",
+                    help="genome: reads cut uniformly from tests/golden/data/NC_000915.fna, both strands (weak scaling only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -236,9 +263,14 @@ def main():
     L = args.length
     if args.scaling == "weak":
         n, seed, first_base = args.reads, SEED + rank, 0        # every rank has its own shard of the job
-        packed, off = gmg.synth.packed_reads(n, L, seed)
+        if args.data == "genome":
+            packed, off = gmg.synth.genome_reads(GENOME, n, L, seed)
+        else:
+            packed, off = gmg.synth.packed_reads(n, L, seed)
         job_reads = n * world
     else:                                     # one job of --reads reads, cut by gmg_shard_plan (equal base counts)
+        if args.data != "synthetic":
+            sys.exit("bench.py: --data genome runs with weak scaling only")
         job_off = np.arange(args.reads + 1, dtype=np.uint64) * np.uint64(L)
         plan = gmg.shard.shard_plan(job_off, world)
         lo, hi = int(plan[rank]), int(plan[rank + 1])
@@ -304,7 +336,7 @@ def main():
         achieved = ALGO_BYTES_PER_BASE * total / (kern_ms * 1e-3) / 1e9 if kern_ms else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.data == "synthetic":
             try:
                 traffic = json.load(open(tpath)).get("%dx%d" % (n, L))
             except Exception:
@@ -313,10 +345,12 @@ def main():
             "metric": "Mbases/s scored (6-frame IMM)", "value": round(value, 2), "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(seconds / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d x %d bp synthetic reads %s, one 3-periodic ICM (NC_000915.icm), "
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if args.data == "synthetic" else "genome: reads cut uniformly from NC_000915.fna (1.67 Mbp), both strands",
+            "config": {"workload": "%d x %d bp %s reads %s, one 3-periodic ICM (NC_000915.icm), "
                                    "6-frame per-position scoring, fp64 Frame_Scores"
-                                   % (args.reads, L, "per GPU" if args.scaling == "weak" else "in total, sharded by gmg_shard_plan"),
+                                   % (args.reads, L, "synthetic" if args.data == "synthetic" else "genome-sampled (NC_000915.fna)",
+                                      "per GPU" if args.scaling == "weak" else "in total, sharded by gmg_shard_plan"),
                        "reads_per_gpu": n, "read_len": L, "parallelism": "reads sharded, %d rank(s)" % world},
             "roofline": {"bound": "hbm", "kernel": "k_frame6t + k_frame6p (one gmg_frame_score6 call)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
@@ -333,7 +367,7 @@ def main():
             samples = [("first", 0), ("last", n - ns)] if n > ns else [("all", 0)]
             verdicts, head = [], None
             for name, r0 in samples:
-                cpu, kind = cpu_sample(first_read + r0, r0, ns, L, seed, gc, packed)
+                cpu, kind = cpu_sample(first_read + r0, r0, ns, L, seed, gc, packed, from_stream=args.data == "synthetic")
                 if head is None:
                     head = (cpu, kind)
                 x, mix = device_digest(out, total, r0, ns, L)
@@ -346,7 +380,7 @@ def main():
                 line["cpu_baseline"] = {"value": round(cpu["mbases_per_s"], 4), "unit": "Mbases/s", "cores": 1, "kind": kind,
                                         "sample": "first %d of the rank-0 reads (%d x %d bp, same stream)" % (ns, ns, L),
                                         "seconds": round(cpu["seconds"], 3)}
-                if kind == "reference":
+                if kind == "reference" and args.data == "synthetic":
                     line["cpu_baseline"]["all_cores"] = cpu_all_cores(max(ns // 2, 1), L, seed, gc)
         if not ok:
             line["value"] = None

@@ -5,6 +5,8 @@
 // cpu_baseline leg ("kind": "reference") and by tests as a cross-check of the oracle.
 //
 //   ref_bench <gene.icm> <n_reads> <L> <seed> <gc_frac> [first_read]
+//   ref_bench <gene.icm> <n_reads> <L> @<reads.fa> <gc_frac>        the first n_reads records of a FASTA file (each L bases) instead
+//                                                                  of the synthetic stream: bench.py --data genome hands its sample over this way
 //
 // Synthetic reads: the job is one stream of 2-bit bases; 64-bit word k of the stream is
 // SplitMix64 output number k+1 of <seed> (z = mix(seed + (k+1)*0x9E3779B97F4A7C15)), base j of
@@ -17,6 +19,8 @@
 // (the [6][n_reads * L] layout of the sample) -- a permuted or shifted table does not pass it.
 
 #include "icm.hh"
+#include "fasta.hh"
+#include "gene.hh"
 #include <string>
 #include <vector>
 #include <cstdio>
@@ -67,6 +71,16 @@ int main(int argc, char **argv)
     indep.Build_Indep_WO_Stops(gc, stops);
 
     vector<string> reads(n_reads);
+    if (argv[4][0] == '@') {                            // the sample as a FASTA file, read the way glimmer-mg reads its input
+        FILE *fp = fopen(argv[4] + 1, "r");
+        if (fp == NULL) { fprintf(stderr, "ref_bench: cannot open %s\n", argv[4] + 1); return 2; }
+        string hdr;
+        for (long r = 0; r < n_reads; r++) {
+            if (!Fasta_Read(fp, reads[r], hdr) || (int)reads[r].length() != L) { fprintf(stderr, "ref_bench: record %ld of %s is not %d bases\n", r, argv[4] + 1, L); return 2; }
+            for (int j = 0; j < L; j++) reads[r][j] = tolower(Filter(reads[r][j]));      // glimmer-mg.cc:381-382
+        }
+        fclose(fp);
+    } else
     for (long r = 0; r < n_reads; r++) {
         reads[r].resize(L);
         for (int j = 0; j < L; j++) reads[r][j] = stream_base(seed, (uint64_t)(first + r) * L + j);
