@@ -337,8 +337,15 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and args.data == "synthetic":
-            try:
-                traffic = json.load(open(tpath)).get("%dx%d" % (n, L))
+            try:                                            # only while the kernels are the ones the counters were taken with
+                import hashlib
+                doc = json.load(open(tpath))
+                src = os.path.join(ROOT, doc.get("source", "glimmer-mg_amd/csrc/gmg_frame6.hip"))
+                if doc.get("source_sha256") == hashlib.sha256(open(src, "rb").read()).hexdigest():
+                    traffic = doc.get("%dx%d" % (n, L))
+                else:
+                    sys.stderr.write("bench: profiles/traffic.json was measured with another gmg_frame6.hip; roofline.traffic = null "
+                                     "(tools/profile_frame6.sh + tools/update_traffic.py renew it)\n")
             except Exception:
                 traffic = None
         line = {
