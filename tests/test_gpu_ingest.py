@@ -61,3 +61,30 @@ def test_ingest_edge_inputs(gpu, oracle):
         reads, records, gc = device_records(gpu, data)
         want, want_gc = oracle.fasta_records(data)
         assert records == want and gc == want_gc, data
+
+
+def test_ingest_refuses_two_gibibytes_instead_of_wrapping(gpu):
+    """the parser's byte counters are 32-bit on the device: a call with >= 2^31 - 1 bytes is REFUSED (GMG_EINVAL) before a single byte
+    is looked at -- the length is a lie here, the buffer is 16 bytes -- and gmg_fasta_split gives the pieces that do fit"""
+    import ctypes as C
+    lib = gpu.capi.lib()
+    buf = C.create_string_buffer(b">r\nacgtacgtacg\n", 16)
+    reads, index = C.c_void_p(), C.c_void_p()
+    for n in (2 ** 31 - 1, 2 ** 31, 2 ** 32 + 5, 2 ** 40):
+        assert lib.gmg_fasta_ingest(buf, n, C.byref(reads), C.byref(index)) == -1          # GMG_EINVAL
+        assert b"2^31" in lib.gmg_last_error() and not reads.value and not index.value
+    # a 2.1 GiB "file" of one short record repeated: split into pieces of < 2^31 bytes each, cut at record starts
+    rec = b">read\n" + b"acgtacgtgg" * 50 + b"\n"
+    n_rec = (2 ** 31 + 2 ** 27) // len(rec)
+    data = rec * n_rec
+    cuts = np.zeros(16, np.uint64)
+    pieces = lib.gmg_fasta_split(data, len(data), 2 ** 30, cuts.ctypes.data_as(C.c_void_p), 15)
+    assert 2 <= pieces <= 15 and cuts[0] == 0 and cuts[pieces] == len(data)
+    sizes = np.diff(cuts[:pieces + 1].astype(np.int64))
+    assert sizes.max() < 2 ** 31 - 1 and all(data[int(c):int(c) + 1] == b">" for c in cuts[:pieces])
+    total = 0
+    for k in range(pieces):                             # every piece is a valid input of its own
+        r, _, _ = gpu.Reads.from_fasta_bytes(data[int(cuts[k]):int(cuts[k + 1])])
+        total += r.n_reads
+        r.close()
+    assert total == n_rec
