@@ -96,6 +96,93 @@ __device__ __forceinline__ uint32_t dev_reverse_fields(uint32_t y, int nfields)
     uint32_t z = __brev(y) >> (32 - 2 * nfields);
     return ((z & 0x55555555u) << 1) | ((z >> 1) & 0x55555555u);
 }
+// ---------------------------------------------------------------------------
+// Running sums over the steps of a walk, three classes at once (the three reading-frame classes of a strand: gmg_mg.hip's error
+// branch and gmg_orfs.hip's events path keep one running sum per class along a read).
+//
+// A wave takes 64 * EL consecutive steps per trip.  Loads and stores want a lane on every 64th step (coalesced), the sums want a
+// lane on EL consecutive steps (a serial prefix in registers, then ONE scan of the lane totals per class): the values change
+// owner through LDS in between.  With a lane per step and a wave scan per 64 steps the DPP scans were the bound (3 x 18
+// instructions per 64 steps: k_orf_walk_sums 270 wave-instructions per 64 steps, 1.34 ms per 100 Mbases x 2 strands).
+// ---------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double wcs_dpp_add(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return x + __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));      // (lanes without a source add 0)
+}
+__device__ __forceinline__ double wcs_wave_scan(double x)          // inclusive sum over the lanes of a wave
+{
+    x = wcs_dpp_add<0x111, 0xf>(x);                     // row_shr:1
+    x = wcs_dpp_add<0x112, 0xf>(x);
+    x = wcs_dpp_add<0x114, 0xf>(x);
+    x = wcs_dpp_add<0x118, 0xf>(x);
+    x = wcs_dpp_add<0x142, 0xa>(x);                     // row_bcast:15 into rows 1 and 3
+    x = wcs_dpp_add<0x143, 0xc>(x);                     // row_bcast:31 into rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ double wcs_last_lane(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return __longlong_as_double((long long)((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63) << 32 |
+                                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63)));
+}
 
+template <int EL> constexpr int wcs_lds_doubles() { return 64 * (3 * EL + 2); }      // per wave
+// the wave's lanes exchange values through LDS: the compiler must keep the accesses on either side in order (the hardware
+// completes one wave's LDS operations in order)
+__device__ __forceinline__ void wcs_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// x[u][c]: the term of class c at step 64 u + lane of the trip (0 for steps beyond the walk's end).  On return x[u][c] = the running
+// sum of class c over the steps BEFORE that one (EXCL) or up to and including it, carried over from the trips before; carry moves on.
+// s: the wave's own wcs_lds_doubles<EL>() doubles of LDS (16-byte aligned).  A lane's block is 3 EL + 2 doubles long: consecutive
+// lanes' 16-byte reads fall on different banks.
+template <int EL, bool EXCL>
+__device__ __forceinline__ void wave_class_scan(double *s, double (&x)[EL][3], double (&carry)[3], uint32_t lane)
+{
+    constexpr int STRIDE = 3 * EL + 2;
+#pragma unroll
+    for (int u = 0; u < EL; u++) {
+        const uint32_t t = 64u * (uint32_t)u + lane;                // step of the trip
+        double *d = s + (t / EL) * STRIDE + (t % EL) * 3;
+        d[0] = x[u][0]; d[1] = x[u][1]; d[2] = x[u][2];
+    }
+    wcs_sync();
+    double y[EL][3];
+    const double *mine = s + lane * STRIDE;
+#pragma unroll
+    for (int e = 0; e < EL; e++) { y[e][0] = mine[3 * e]; y[e][1] = mine[3 * e + 1]; y[e][2] = mine[3 * e + 2]; }
+#pragma unroll
+    for (int e = 1; e < EL; e++) { y[e][0] += y[e - 1][0]; y[e][1] += y[e - 1][1]; y[e][2] += y[e - 1][2]; }
+    double base[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double inc = wcs_wave_scan(y[EL - 1][c]);
+        base[c] = carry[c] + (inc - y[EL - 1][c]);                  // what the lanes in front of this one and the trips before add up to
+        carry[c] += wcs_last_lane(inc);
+    }
+    wcs_sync();
+    double *out = s + lane * STRIDE;
+#pragma unroll
+    for (int e = 0; e < EL; e++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            out[3 * e + c] = EXCL ? (e ? base[c] + y[e - 1][c] : base[c]) : base[c] + y[e][c];
+    wcs_sync();
+#pragma unroll
+    for (int u = 0; u < EL; u++) {
+        const uint32_t t = 64u * (uint32_t)u + lane;
+        const double *d = s + (t / EL) * STRIDE + (t % EL) * 3;
+        x[u][0] = d[0]; x[u][1] = d[1]; x[u][2] = d[2];
+    }
+    wcs_sync();
+}
 
 #endif

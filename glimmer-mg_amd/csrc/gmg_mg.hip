@@ -2023,6 +2023,10 @@ __device__ __forceinline__ double mg_wave_scan(double x)               // inclus
     x = mg_dpp_add<0x143, 0xc>(x);                      // row_bcast:31 into rows 2 and 3
     return x;
 }
+// G32: the rows come from the fp32 gene table and the read's null model (the values k_mg_apply_nulls would put into the fp64
+// table: one exact subtraction of two widened floats, partial windows at the read's ends from the partial tables) -- the
+// error branch then never builds or reads the 48 B/base table.
+template <bool G32>
 __global__ __launch_bounds__(256) void k_mg_walk_prefix(MgArgs a, double *walk)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -2032,15 +2036,28 @@ __global__ __launch_bounds__(256) void k_mg_walk_prefix(MgArgs a, double *walk)
         const bool fwd = (it & 1) == 0;
         const uint64_t off = a.read_off[r];
         const uint32_t n = (uint32_t)(a.read_off[r + 1] - off);
+        const float *nt = G32 ? a.null_tab + (size_t)(a.read_null ? a.read_null[r] : 0u) * MG_NULL_FLOATS : nullptr;
+        const uint32_t off_m3 = (uint32_t)(off % 3);
         double carry[3] = {0.0, 0.0, 0.0};
         for (uint32_t t0 = 0; t0 < n; t0 += 64) {
             const uint32_t t = t0 + lane;
             const bool in = t < n;
             const uint64_t g = in ? (fwd ? off + n - 1 - t : off + t) : off;      // base of walk step t
             double v[3];
+            if (G32) {
+                const uint32_t five = (uint32_t)dev_window_bits(a.packed, (int64_t)g - 2) & 0x3ffu, c0 = (five >> 4) & 3u;
+                const int si = (int)(g - off);
+#pragma unroll
+                for (int f = 0; f < 3; f++) {
+                    const float nv = fwd ? mg_null_value<true>(nt, f, si, (int)n, c0, (five >> 6) & 3u, (five >> 8) & 3u)
+                                         : mg_null_value<false>(nt, f, si, (int)n, c0, (five >> 2) & 3u, five & 3u);
+                    v[f] = in ? (double)a.gene32[(uint64_t)((fwd ? 0 : 3) + f) * a.fs_stride + g] - (double)nv : 0.0;
+                }
+            } else {
 #pragma unroll
             for (int f = 0; f < 3; f++) v[f] = in ? a.fs[(uint64_t)((fwd ? 0 : 3) + f) * a.fs_stride + g] : 0.0;
-            const int m = (int)(g % 3);
+            }
+            const int m = (int)((off_m3 + (uint32_t)(g - off)) % 3u);             // g % 3 without a 64-bit division per lane
             const uint64_t w = fwd ? a.total - 1 - g : g;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -2980,9 +2997,15 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         all_fast = all_fast && m.has_fast && m.D == 7 && m.W == gene->dev.W;
     }
     // (groups of any-shape models: their gene rows come from the exact kernel, group by group -- still the GENE32 form)
-    const bool g32 = !d_frame_scores && !err_mode && a.total &&
+    // the error branch on running sums (mg_err_skip) never reads the table itself, only the walk-order sums made from it: the
+    // gene rows as fp32 (GENE32) then save the 48 B/base table's write and half of what the sums' kernel reads.  Not with reads the
+    // level kernels cannot take (>= 2040 bases: k_mg_err_flat walks the table) or a forced per-ORF path; a call-array overflow
+    // builds the table then (k_mg_apply_nulls) before it falls back.
+    const bool err_g32 = err_mode && !d_frame_scores && a.total && g32_opt != 0 && nul_dense3 && all_fast && err_exact &&
+                         gmg_opt(GMG_OPT_MG_ERR_SKIP) && !gmg_opt(GMG_OPT_MG_ERR_FLAT) && reads->max_len && reads->max_len < 2040;
+    const bool g32 = err_g32 || (!d_frame_scores && !err_mode && a.total &&
                      (g32_opt == 2 || (g32_opt == 1 && (prm->nulls || fused_nw >= 2))) && nul_dense3 &&
-                     (all_fast || (groups && groups->n > 0));
+                     (all_fast || (groups && groups->n > 0)));
     if (prm->nulls && !nul_dense3) return fail(gmg_set_error(GMG_EBADMODEL, "gmg_mg_score_reads: per-read null models are (3,2,3) models"));
     a.fs_stride = a.total;
     if (g32) {
@@ -3202,7 +3225,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         a.pfx = err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) ? 1 : 0;
         if (a.pfx) {                                    // running sums + run lengths: the walks visit their events only
             MG_TRY(gmg_pool_alloc((void **)&d_run, (size_t)4 * a.walk_stride));
-            hipLaunchKernelGGL(k_mg_walk_prefix, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s, a, d_walk + 8);
+            if (a.gene32) hipLaunchKernelGGL(k_mg_walk_prefix<true>, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s, a, d_walk + 8);
+            else hipLaunchKernelGGL(k_mg_walk_prefix<false>, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s, a, d_walk + 8);
             a.run_q = d_run; a.run_n = d_run + 2 * a.walk_stride;
             hipLaunchKernelGGL(k_mg_run_tables, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s3, a, d_run, d_run + 2 * a.walk_stride);
         } else
@@ -3277,7 +3301,19 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
                 else { gmg_pool_release(d_calls[0]); d_calls[0] = nullptr; }
             }
             if (grown) { a.call_cap = want; a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; }
-            else err_path = 1;
+            else {
+                err_path = 1;
+                if (a.gene32 && !a.fs) {                // the per-ORF kernel walks the table itself: make it now
+                    const uint64_t fstride = (a.total + 15) & ~15ull;
+                    MG_TRY(gmg_pool_alloc((void **)&d_fs_own, (size_t)6 * fstride * sizeof(double)));
+                    hipLaunchKernelGGL(k_mg_apply_nulls, dim3(grid_for(a.total)), dim3(256), 0, s2, a, d_fs_own, fstride);
+                    MG_TRY(hipGetLastError());
+                    MG_TRY(hipStreamSynchronize(s2));
+                    a.fs = d_fs_own;
+                    a.fs_stride = fstride;
+                    a.gene32 = nullptr;
+                }
+            }
             MG_TRY(hipMemsetAsync(d_err_flag, 0, 80, s2));
             MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
             continue;

@@ -275,36 +275,10 @@ struct OrfWalkArgs {
     double *q;                   // [2][total]: forward-strand sums, reverse-strand sums
 };
 
-constexpr int OW_U = 4;          // trips of 64 walk steps whose loads are in flight together
+constexpr int OW_EL = 4;         // walk steps per lane and trip: 256 per wave
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double ow_dpp_add(double x)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xf, false);
-    return x + __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));      // (lanes without a source add 0)
-}
-__device__ __forceinline__ double ow_wave_scan(double x)           // inclusive sum over the lanes of a wave
-{
-    x = ow_dpp_add<0x111, 0xf>(x);                      // row_shr:1
-    x = ow_dpp_add<0x112, 0xf>(x);
-    x = ow_dpp_add<0x114, 0xf>(x);
-    x = ow_dpp_add<0x118, 0xf>(x);
-    x = ow_dpp_add<0x142, 0xa>(x);                      // row_bcast:15 into rows 1 and 3
-    x = ow_dpp_add<0x143, 0xc>(x);                      // row_bcast:31 into rows 2 and 3
-    return x;
-}
-__device__ __forceinline__ double ow_last_lane(double x)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-    return __longlong_as_double((long long)((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63) << 32 |
-                                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63)));
-}
-
-// One wave per (read, strand), 64 consecutive walk steps at a time, one per lane -- every load and store of a wave covers 64
-// consecutive bases (the first version gave a lane 8 consecutive steps: 2.8 ms per 200 k reads, an eighth of every line used per
-// instruction) --, the three class sums scanned over the wave with DPP moves, carries in scalar registers.
+// One wave per (read, strand), 256 walk steps per trip; wave_class_scan (gmg_device.h) keeps the loads and the store coalesced
+// (a lane on every 64th step) and the additions cheap (a lane on 4 consecutive steps, one DPP scan of the lane totals per class).
 //   forward ORFs (frame > 0) walk DOWN the read: step t <-> base p = L-1-t; at base p' an ORF whose in-frame positions are
 //     p == c - 1 (mod 3) takes row f = (c - p') mod 3 of rows 0-2 and the null value of window (S[p'+2], S[p'+1], S[p']);
 //   reverse ORFs walk UP: step t <-> p = t; an ORF with in-frame positions p == c (mod 3) takes row f = (1 + p' - c) mod 3 of rows
@@ -313,10 +287,12 @@ __device__ __forceinline__ double ow_last_lane(double x)
 // guard words): such terms are in both Q values an ORF subtracts, or in neither.
 __global__ __launch_bounds__(256) void k_orf_walk_sums(OrfWalkArgs a)
 {
-    __shared__ double s_null[3 * 64];
-    for (int i = threadIdx.x; i < 3 * 64; i += 256) s_null[i] = (double)a.null_dense[i];
+    __shared__ double s_null[3 * 64 + 1];                           // [192]: 0 for the steps beyond the walk's end
+    __shared__ __attribute__((aligned(16))) double s_scan[4 * wcs_lds_doubles<OW_EL>()];
+    for (int i = threadIdx.x; i < 3 * 64 + 1; i += 256) s_null[i] = i < 192 ? (double)a.null_dense[i] : 0.0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
+    double *s_mine = s_scan + (threadIdx.x >> 6) * wcs_lds_doubles<OW_EL>();
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t it = wave; it < 2 * a.n_reads; it += n_waves) {
         const uint64_t r = it >> 1;
@@ -326,41 +302,35 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums(OrfWalkArgs a)
         const float *rows = a.gene6 + (fwd ? 0 : 3) * a.total;
         double *q = a.q + (fwd ? 0 : a.total);
         double carry[3] = {0.0, 0.0, 0.0};
-        // OW_U trips of 64 steps per iteration, all of their loads requested before the first scan (one trip at a time left the
-        // wave waiting for memory eight times per 500-bp read: 1.36 ms per 200 k reads)
-        for (uint32_t t0 = 0; t0 < n; t0 += 64 * OW_U) {
-            float v[OW_U][3];
-            uint32_t w3[OW_U];
+        for (uint32_t t0 = 0; t0 < n; t0 += 64 * OW_EL) {
+            double x[OW_EL][3];
+            uint32_t cls[OW_EL];
 #pragma unroll
-            for (int u = 0; u < OW_U; u++) {
+            for (int u = 0; u < OW_EL; u++) {
                 const uint32_t t = t0 + 64 * u + lane;
-                const bool in = t < n;
-                const uint64_t g = off + (in ? (fwd ? n - 1 - t : t) : 0);
-#pragma unroll
-                for (int f = 0; f < 3; f++) v[u][f] = in ? rows[(uint64_t)f * a.total + g] : 0.0f;
-                w3[u] = (uint32_t)dev_window_bits(a.packed, (int64_t)g - 2) & 0xfffu;      // bases g-2 .. g+3 at fields 0 .. 5
-            }
-#pragma unroll
-            for (int u = 0; u < OW_U; u++) {
-                const uint32_t t = t0 + 64 * u + lane;
-                if (t0 + 64 * u >= n) break;                        // (wave-uniform)
                 const bool in = t < n;
                 const uint32_t p = in ? (fwd ? n - 1 - t : t) : 0;  // position in the read
-                // the three chars of the null window, oldest buffer char in the low bits
-                const uint32_t n6 = fwd ? (((w3[u] >> 8) & 3u) | (((w3[u] >> 6) & 3u) << 2) | (((w3[u] >> 4) & 3u) << 4)) : ((w3[u] & 63u) ^ 63u);
-                const uint32_t pm = p % 3u;
-                const uint32_t c_mine = fwd ? (p + 1u) % 3u : pm;
-                const double d0 = (double)v[u][0] - s_null[n6], d1 = (double)v[u][1] - s_null[64 + n6], d2 = (double)v[u][2] - s_null[128 + n6];
-                double mine = 0.0;
+                const uint64_t g = off + p;
+                float v[3];
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
+                for (int f = 0; f < 3; f++) v[f] = in ? rows[(uint64_t)f * a.total + g] : 0.0f;
+                const uint32_t w3 = (uint32_t)dev_window_bits(a.packed, (int64_t)g - 2) & 0xfffu;      // bases g-2 .. g+3 at fields 0 .. 5
+                // the three chars of the null window, oldest buffer char in the low bits
+                const uint32_t n6 = fwd ? (((w3 >> 8) & 3u) | (((w3 >> 6) & 3u) << 2) | (((w3 >> 4) & 3u) << 4)) : ((w3 & 63u) ^ 63u);
+                const uint32_t pm = p % 3u;
+                cls[u] = fwd ? (p + 1u) % 3u : pm;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {       // class c takes row (c - pm) mod 3 (forward) / (1 + pm - c) mod 3 (reverse)
                     const uint32_t f = fwd ? (uint32_t)(c + 3 - (int)pm) % 3u : (uint32_t)(1 + (int)pm + 3 - c) % 3u;
-                    const double x = in ? (f == 0 ? d0 : f == 1 ? d1 : d2) : 0.0;
-                    const double inc = ow_wave_scan(x);
-                    if (c_mine == (uint32_t)c) mine = carry[c] + (inc - x);     // exclusive: the steps before this one
-                    carry[c] += ow_last_lane(inc);
+                    const float gv = f == 0 ? v[0] : f == 1 ? v[1] : v[2];
+                    x[u][c] = (double)gv - s_null[in ? f * 64u + n6 : 192u];
                 }
-                if (in) q[off + p] = mine;
+            }
+            wave_class_scan<OW_EL, true>(s_mine, x, carry, lane);
+#pragma unroll
+            for (int u = 0; u < OW_EL; u++) {
+                const uint32_t t = t0 + 64 * u + lane;
+                if (t < n) q[off + (fwd ? n - 1 - t : t)] = cls[u] == 0 ? x[u][0] : cls[u] == 1 ? x[u][1] : x[u][2];
             }
         }
     }
