@@ -370,8 +370,12 @@ struct SubBatch {                                       // the reads of one ICM 
     Scored sc;
 };
 
+// shard / n_shards: with --shards N every shard (one forked process per GPU) ingests the whole file -- the plan of a chunk needs
+// every header of it, and 0.25 B/base per GPU is cheap -- and takes the positions [n k / N, n (k + 1) / N) of every chunk's
+// visiting order: reads are independent, so any consecutive run of the order is a valid piece of work; the pieces go to
+// <out>.part<k>.c<chunk> and the parent concatenates them chunk by chunk, shard by shard: the reference's bytes.
 static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t batch_bytes, const char *class_file,
-                       const string &icm_dir, const string &out_name)
+                       const string &icm_dir, const string &out_name, int shard, int n_shards)
 {
     if (gmg_init(device) != GMG_OK) die_gmg("gmg_init");
     const bool error_mode = Allow_Indels || Allow_Subs;
@@ -419,7 +423,7 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
 
     FILE *quality_fp = NULL;
     if (Allow_Indels && Quality_File_Name != NULL) quality_fp = File_Open(Quality_File_Name, "r", __FILE__, __LINE__);
-    FILE *predict_fp = File_Open(out_name, "w", __FILE__, __LINE__);
+    FILE *predict_fp = n_shards == 1 ? File_Open(out_name, "w", __FILE__, __LINE__) : NULL;
     vector<const char *> user_stops(Stop_Codon);         // -z / -Z: one set for every read
     std::map<string, ICM_t *> icm_cache;                // gene ICMs by file name, read once
 
@@ -473,11 +477,18 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
         }
 
         const uint64_t n_proc = icm_begin[n_groups];
+        // this shard's run of the chunk's visiting order
+        const uint64_t k_lo = n_shards == 1 ? 0 : n_proc * (uint64_t)shard / n_shards, k_hi = n_shards == 1 ? n_proc : n_proc * (uint64_t)(shard + 1) / n_shards;
+        if (n_shards > 1) {
+            char part[64];
+            snprintf(part, sizeof part, ".part%d.c%zu", shard, c);
+            predict_fp = File_Open(out_name + part, "w", __FILE__, __LINE__);
+        }
         // the gene ICMs of the groups that have reads in this chunk (the reference reads every ICM of the class file for every
         // chunk, used or not, and again for the next chunk, glimmer-mg.cc:364; here a file is read once)
         vector<const gmg_model *> group_model(n_groups, (const gmg_model *)NULL);
         for (uint32_t f = 0; f < n_groups; f++) {
-            if (icm_begin[f + 1] == icm_begin[f]) continue;
+            if (icm_begin[f + 1] <= k_lo || icm_begin[f] >= k_hi || icm_begin[f + 1] == icm_begin[f]) continue;      // no read of this shard
             if (User_ICM) { group_model[f] = Gene_ICM.Device_Model(); continue; }
             const string name = gmg_classes_icm_file(cls, f);
             std::map<string, ICM_t *>::iterator it = icm_cache.find(name);
@@ -491,7 +502,7 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
         // one gmg_mg_score_groups call per stop-codon set: its reads in visiting order, its ICM groups as consecutive ranges
         vector<SubBatch> sub;
         vector<pair<uint32_t, uint64_t> > where(n_proc);                // visiting position -> (sub-batch, index in it)
-        for (uint64_t k = 0; k < n_proc; k++) {
+        for (uint64_t k = k_lo; k < k_hi; k++) {
             const int code = User_Stop ? 0 : read_tt[k];
             size_t b = 0;
             while (b < sub.size() && sub[b].code != code) b++;
@@ -571,7 +582,7 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
         }
         // the back half, read by read in the reference's order (glimmer-mg.cc:367-450)
         string hs;
-        for (uint64_t k = 0; k < n_proc; k++) {
+        for (uint64_t k = k_lo; k < k_hi; k++) {
             const uint64_t i = order[k];
             hs.assign(hdr[i], hdr_len[i]);
             Fasta_Header = hs.c_str();
@@ -596,8 +607,9 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
         }
         gmg_reads_free(pc.reads);
         pc.reads = NULL;
+        if (n_shards > 1) { fclose(predict_fp); predict_fp = NULL; }
     }
-    fclose(predict_fp);
+    if (predict_fp) fclose(predict_fp);
     if (quality_fp) fclose(quality_fp);
     gmg_classes_free(cls);
     return EXIT_SUCCESS;
@@ -662,8 +674,45 @@ int main(int argc, char **argv)
         const string out = string(Output_Tag) + ".predict";
         const int env_dev = getenv("GMG_DEVICE") ? atoi(getenv("GMG_DEVICE")) : 0;
         if (!classifications.empty()) {
-            if (n_shards > 1) { fprintf(stderr, "glimmer-mg_gpu: -c with --shards > 1 is not supported yet\n"); return 2; }
-            return run_classes(bytes, n_bytes, env_dev, batch_bytes, class_file, icm_dir, out);
+            if (n_shards == 1) return run_classes(bytes, n_bytes, env_dev, batch_bytes, class_file, icm_dir, out, 0, 1);
+            vector<pid_t> cpid(n_shards);
+            for (int k = 0; k < n_shards; k++) {
+                fflush(NULL);
+                cpid[k] = fork();                       // nothing in this process has touched a GPU
+                if (cpid[k] < 0) { perror("fork"); return EXIT_FAILURE; }
+                if (cpid[k] == 0) {
+                    const int rc = run_classes(bytes, n_bytes, (env_dev + k) % n_gpus, batch_bytes, class_file, icm_dir, out, k, n_shards);
+                    fflush(NULL);
+                    _exit(rc);
+                }
+            }
+            int rc = EXIT_SUCCESS;
+            for (int k = 0; k < n_shards; k++) {
+                int status = 0;
+                waitpid(cpid[k], &status, 0);
+                if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) { fprintf(stderr, "glimmer-mg_gpu: shard %d failed\n", k); rc = EXIT_FAILURE; }
+            }
+            // chunk by chunk, shard by shard (every shard wrote a part for every chunk, empty ones included)
+            FILE *fo = rc == EXIT_SUCCESS ? File_Open(out, "w", __FILE__, __LINE__) : NULL;
+            vector<char> buf(1 << 20);
+            for (size_t c = 0;; c++) {
+                bool any = false;
+                for (int k = 0; k < n_shards; k++) {
+                    char part[64];
+                    snprintf(part, sizeof part, ".part%d.c%zu", k, c);
+                    const string name = out + part;
+                    FILE *fi = fopen(name.c_str(), "r");
+                    if (fi == NULL) continue;
+                    any = true;
+                    size_t got;
+                    while (fo && (got = fread(buf.data(), 1, buf.size(), fi)) > 0) fwrite(buf.data(), 1, got, fo);
+                    fclose(fi);
+                    unlink(name.c_str());
+                }
+                if (!any) break;
+            }
+            if (fo) fclose(fo);
+            return rc;
         }
         if (n_shards == 1) return run_shard(bytes, 0, n_bytes, env_dev, batch_bytes, -1, -1, out);
 

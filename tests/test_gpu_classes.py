@@ -54,6 +54,23 @@ def test_glimmer_mg_gpu_classification_mode_is_byte_identical(gpu, tmp_path, nam
     assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", "classes.%s.predict" % name), "rb").read()
 
 
+@pytest.mark.parametrize("name,flags,cls,own", [
+    ("default", [], "seqs.class.txt", ["--shards", "2"]),
+    ("mixed_chunks", [], "mixed.class.txt", ["--shards", "3", "--chunk-reads", "250"]),
+    ("indel", ["-i"], "seqs.class.txt", ["--shards", "4", "--gpus", "1"]),
+    ("user_icm", ["-m", os.path.join(DATA, "NC_000915.icm")], "seqs.class.txt", ["--shards", "2"])])
+def test_glimmer_mg_gpu_classification_mode_in_shards_is_byte_identical(gpu, tmp_path, name, flags, cls, own):
+    """--shards N with -c: every forked shard ingests the whole file, plans every chunk and takes its run of each chunk's visiting
+    order; the parent concatenates chunk by chunk, shard by shard -- the reference's bytes, no part file left behind"""
+    exe = built_binary("integration", "_build", "glimmer-mg_gpu")
+    tag = str(tmp_path / "out")
+    cmd = [exe, "--icm-dir", ".genomeData", *own, *flags, "-c", os.path.join(DATA, cls), os.path.join(DATA, "seqs.fa"), tag]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", "classes.%s.predict" % name), "rb").read()
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+
+
 def chunks(n, size):
     return [(b, min(n, b + size)) for b in range(0, n, size)] if size else [(0, n)]
 
