@@ -456,10 +456,11 @@ def score_orfs(gene, null, reads, orfs, min_gene_len=75, allow_truncated=False, 
     batch, max_starts = C.c_void_p(), C.c_uint64()
     _ck(capi.lib().gmg_orfs_upload(reads.h, _ptr(o), len(o), C.byref(max_starts), C.byref(batch)))
     res = np.zeros(len(o), ORF_RESULT_DTYPE)
-    starts = np.zeros(max(int(max_starts.value), 1), START_DTYPE)
     try:
-        _ck(capi.lib().gmg_score_orfs(gene.device(), null.device(), reads.h, batch, C.byref(prm), _ptr(res),
-                                      _ptr(starts), None))
+        n_st = C.c_uint64()
+        _ck(capi.lib().gmg_score_orfs_begin(gene.device(), null.device(), reads.h, batch, C.byref(prm), C.byref(n_st), None))
+        starts = np.zeros(max(int(n_st.value), 1), START_DTYPE)
+        _ck(capi.lib().gmg_score_orfs_fetch(batch, _ptr(res), _ptr(starts), None))
     finally:
         capi.lib().gmg_orf_batch_free(batch)
     return res, starts

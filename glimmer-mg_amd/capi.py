@@ -104,6 +104,8 @@ PROTOTYPES = {
     "gmg_orfs_upload": (i32, [vp, vp, u64, C.POINTER(u64), C.POINTER(vp)]),
     "gmg_orf_batch_free": (i32, [vp]),
     "gmg_score_orfs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gmg_score_orfs_begin": (i32, [vp, vp, vp, vp, vp, C.POINTER(u64), vp]),
+    "gmg_score_orfs_fetch": (i32, [vp, vp, vp, vp]),
     "gmg_classes_load": (i32, [C.c_char_p, u64, C.c_char_p, C.POINTER(vp)]),
     "gmg_classes_free": (i32, [vp]),
     "gmg_classes_info": (i32, [vp, C.POINTER(u64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(u64)]),

@@ -33,6 +33,8 @@ struct gmg_orf_batch {
     gmg_start *d_compact;        // the used slots back to back: what leaves the GPU (grown on demand)
     uint64_t compact_cap;
     uint64_t n, max_starts;
+    uint64_t n_packed;           // starts of the last gmg_score_orfs_begin, back to back in d_compact
+    int scored;
     const gmg_reads *reads;      // the batch the ORFs were validated against (gmg_orfs_upload): gmg_score_orfs takes no other
     uint64_t reads_total;
 };
@@ -661,8 +663,31 @@ extern "C" int gmg_score_orfs(const gmg_model *gene, const gmg_model *nul, const
                               const gmg_orf_batch *b, const gmg_orf_params *prm, gmg_orf_result *results,
                               gmg_start *starts, void *stream)
 {
-    if (!gene || !nul || !reads || !b || !prm || (b->n && !results) || (b->max_starts && !starts))
+    if ((b && b->n && !results) || (b && b->max_starts && !starts)) return gmg_set_error(GMG_EINVAL, "gmg_score_orfs: NULL argument");
+    uint64_t n_starts = 0;
+    const int rc = gmg_score_orfs_begin(gene, nul, reads, b, prm, &n_starts, stream);
+    return rc ? rc : gmg_score_orfs_fetch(b, results, starts, stream);
+}
+
+extern "C" int gmg_score_orfs_fetch(const gmg_orf_batch *b, gmg_orf_result *results, gmg_start *starts, void *stream)
+{
+    if (!b || (b->n && !results) || (b->n_packed && !starts)) return gmg_set_error(GMG_EINVAL, "gmg_score_orfs_fetch: NULL argument");
+    { int rc0 = gmg_enter("gmg_score_orfs_fetch"); if (rc0) return rc0; }
+    if (b->n == 0) return GMG_OK;
+    if (!b->scored) return gmg_set_error(GMG_EINVAL, "gmg_score_orfs_fetch: nothing scored yet (gmg_score_orfs_begin)");
+    hipStream_t s = (hipStream_t)stream;
+    GMG_HIP(hipMemcpyAsync(results, b->d_results, b->n * sizeof(gmg_orf_result), hipMemcpyDeviceToHost, s));
+    if (b->n_packed) GMG_HIP(hipMemcpyAsync(starts, b->d_compact, (size_t)b->n_packed * sizeof(gmg_start), hipMemcpyDeviceToHost, s));
+    GMG_HIP(hipStreamSynchronize(s));
+    return GMG_OK;
+}
+
+extern "C" int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads,
+                                    const gmg_orf_batch *b, const gmg_orf_params *prm, uint64_t *out_n_starts, void *stream)
+{
+    if (!gene || !nul || !reads || !b || !prm || !out_n_starts)
         return gmg_set_error(GMG_EINVAL, "gmg_score_orfs: NULL argument");
+    *out_n_starts = 0;
     if (prm->n_start_codons < 0 || prm->n_start_codons > 8 || prm->min_gene_len < 4)
         return gmg_set_error(GMG_EINVAL, "gmg_score_orfs: need 0..8 start codons and min_gene_len >= 4");
     // Cumulative_Score(buff, score, 1): frame 1 needs periodicity 1 or > 1 (src/ICM/icm.cc:367-369)
@@ -816,8 +841,8 @@ extern "C" int gmg_score_orfs(const gmg_model *gene, const gmg_model *nul, const
     hipLaunchKernelGGL(k_orf_compact, dim3(grid), dim3(256), 0, s, b->d_starts, b->d_start_off, b->d_coff, b->d_results,
                        b->d_compact, b->n);
     GMG_HIP(hipGetLastError());
-    GMG_HIP(hipMemcpyAsync(results, b->d_results, b->n * sizeof(gmg_orf_result), hipMemcpyDeviceToHost, s));
-    if (total) GMG_HIP(hipMemcpyAsync(starts, b->d_compact, (size_t)total * sizeof(gmg_start), hipMemcpyDeviceToHost, s));
-    GMG_HIP(hipStreamSynchronize(s));
+    mb->n_packed = total;
+    mb->scored = 1;
+    *out_n_starts = total;
     return GMG_OK;
 }

@@ -299,6 +299,13 @@ int gmg_score_orfs(const gmg_model *gene, const gmg_model *null_model, const gmg
                    const gmg_orf_batch *orfs, const gmg_orf_params *params,
                    gmg_orf_result *results, gmg_start *starts, void *stream);
 
+/* The same in two steps, for callers that do not want to reserve out_max_starts entries on the host (a slot per in-frame codon
+ * of every ORF: ~100 per ORF, of which ~3 % are used): gmg_score_orfs_begin scores and leaves the results on the device,
+ * *out_n_starts = the number of starts of all ORFs; gmg_score_orfs_fetch copies results[n_orfs] and starts[*out_n_starts]. */
+int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *null_model, const gmg_reads *reads,
+                         const gmg_orf_batch *orfs, const gmg_orf_params *params, uint64_t *out_n_starts, void *stream);
+int gmg_score_orfs_fetch(const gmg_orf_batch *orfs, gmg_orf_result *results, gmg_start *starts, void *stream);
+
 /* ---- glimmer-mg front half on the device -------------------------------------------
  * Everything between the reads and Add_Events_* for glimmer-mg's user-ICM mode (the -i / -s error branch: see the flags below):
  *   Score_All_Frames      src/Glimmer/glimmer-mg.cc:1468-1510   (gmg_frame_score6's kernels)

@@ -17,6 +17,11 @@
 
 #include "gmg.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 // the set-up steps of glimmer3's main (glimmer3.cc:175-223), in the same order
 static void setup_options(int argc, char **argv)
 {
@@ -54,17 +59,16 @@ int main(int argc, char **argv)
         // packing + the g/c count of Set_GC_Fraction) and Find_Orfs runs for every read at once (gmg_find_orfs)
         const char *dev = getenv("GMG_DEVICE");
         if (gmg_init(dev ? atoi(dev) : 0) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
-        string file_bytes;
-        {
-            FILE *fp = File_Open(Sequence_File_Name, "rb", __FILE__, __LINE__);
-            char buf[1 << 16];
-            size_t got;
-            while ((got = fread(buf, 1, sizeof buf, fp)) > 0) file_bytes.append(buf, got);
-            fclose(fp);
-        }
+        // the file, mapped (glimmer3 reads it with fgetc)
+        const int fd = open(Sequence_File_Name, O_RDONLY);
+        struct stat st;
+        if (fd < 0 || fstat(fd, &st) != 0) { fprintf(stderr, "ERROR:  Could not open file  %s \n", Sequence_File_Name); return EXIT_FAILURE; }
+        const size_t n_file = (size_t)st.st_size;
+        const char *file_bytes = n_file ? (const char *)mmap(NULL, n_file, PROT_READ, MAP_PRIVATE, fd, 0) : "";
+        if (file_bytes == MAP_FAILED) { perror("mmap"); return EXIT_FAILURE; }
         gmg_reads *reads = NULL;
         gmg_fasta *fasta = NULL;
-        if (gmg_fasta_ingest(file_bytes.data(), file_bytes.size(), &reads, &fasta) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+        if (gmg_fasta_ingest(file_bytes, n_file, &reads, &fasta) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
         uint64_t n_ing = 0, total_bases = 0, gc_ct = 0;
         gmg_fasta_info(fasta, &n_ing, &total_bases, &gc_ct);
         Sequence_Ct = (int)n_ing;
@@ -81,7 +85,7 @@ int main(int argc, char **argv)
         seq_list.resize(Sequence_Ct);
         hdr_list.resize(Sequence_Ct);
         for (int i = 0; i < Sequence_Ct; i++) {     // the event / DP code reads the global Sequence: filtered bases back from the device
-            hdr_list[i] = file_bytes.substr(hb[i], he[i] - hb[i]);
+            hdr_list[i].assign(file_bytes + hb[i], he[i] - hb[i]);
             string &sq = seq_list[i];
             sq.resize(off[i + 1] - off[i]);
             for (uint64_t k = 0; k < sq.size(); k++) { const uint64_t g = off[i] + k; sq[k] = "acgt"[(packed[g >> 4] >> (2 * (g & 15))) & 3]; }
@@ -129,9 +133,12 @@ int main(int argc, char **argv)
         uint64_t n_starts = 0;
         gmg_orf_batch *batch = NULL;
         if (gmg_orfs_upload(reads, orfs.data(), orfs.size(), &n_starts, &batch) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
-        vector<gmg_start> starts(n_starts);
-        if (gmg_score_orfs(Gene_ICM.Device_Model(), Indep_Model.Device_Model(), reads, batch, &prm, res.data(),
-                           starts.data(), NULL) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+        // (two steps: the start lists are a few per cent of the slots gmg_orfs_upload reserves -- only they get host memory)
+        uint64_t n_used = 0;
+        if (gmg_score_orfs_begin(Gene_ICM.Device_Model(), Indep_Model.Device_Model(), reads, batch, &prm, &n_used, NULL) != GMG_OK) {
+            fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+        vector<gmg_start> starts(n_used ? n_used : 1);
+        if (gmg_score_orfs_fetch(batch, res.data(), starts.data(), NULL) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
         // pass 2: events, DP and trace-back per read (host, unchanged reference code)
         string filename = Output_Tag;
         filename.append(".predict");
