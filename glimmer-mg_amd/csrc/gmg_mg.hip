@@ -178,6 +178,9 @@ struct MgClass {
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
 {
+    // (the counting write pass stores every ORF's number of starts; the extra element the scan wants is zeroed here -- a memset of its
+    // own waited 0.16 ms for a slot beside the partial-window pass, on the critical path)
+    if (WRITE && a.count_starts && blockIdx.x == 0 && threadIdx.x == 0) a.orf_cnt[a.n_orfs] = 0;
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t off = a.read_off[r];
         const int n = (int)(a.read_off[r + 1] - off);
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(128) void k_mg_find_orfs_ev(MgArgs a)
     const int mgl = a.min_gene_len;
     const bool trunc = a.allow_truncated != 0;
     const bool counting = a.count_starts != 0;
+    if (counting && blockIdx.x == 0 && threadIdx.x == 0) a.orf_cnt[a.n_orfs] = 0;       // (the scan's extra element: see k_mg_find_orfs)
     int j_lo = mgl - 3 > 1 ? mgl - 3 : 1;
     j_lo = (j_lo + 2) / 3 * 3;
     const int k0 = 1 + j_lo / 3;                        // (<= 64: mg_run)
@@ -3197,8 +3201,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             MG_TRY(gmg_pool_alloc((void **)&d_orf_cnt, (no + 1) * 4));
             // (the counting write pass stores every ORF's count itself: only the scan's extra element needs a zero -- the 30 MB
             // memset sat 0.26 ms on the critical path, in front of the write pass)
-            if (a.count_starts) MG_TRY(hipMemsetAsync(d_orf_cnt + no, 0, 4, s2));
-            else MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
+            if (!a.count_starts || nr == 0) MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));   // (else the write pass zeroes the last element)
             a.orf_cnt = d_orf_cnt;
         }
     }

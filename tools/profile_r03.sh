@@ -30,6 +30,6 @@ say ingest;       timeout -k 10 300 python3 tests/bench/bench_ingest.py > $R/ing
 say train;        timeout -k 10 300 python3 tests/bench/bench_train.py 1600 > $R/train_1600_bench.json 2>> $R/misc.err; timeout -k 10 400 python3 tests/bench/bench_train.py 64000 > $R/train_64000_bench.json 2>> $R/misc.err
 bash tools/prof_kernels.sh r03trn python3 tests/bench/bench_train.py 64000 > /dev/null 2>&1; kstats r03trn train_kernel_stats.csv
 say cli;          timeout -k 10 600 python3 tests/bench/bench_cli.py 200000 > $R/cli_bench.json 2>> $R/misc.err
-say cli-shards;   BENCH_TMP=/dev/shm timeout -k 10 500 python3 tests/bench/bench_cli_shards.py 2000000 > $R/cli_shards_2M.json 2>> $R/misc.err
-BENCH_TMP=/dev/shm timeout -k 10 900 python3 tests/bench/bench_cli_shards.py 10000000 > $R/cli_shards_10M.json 2>> $R/misc.err
+say cli-shards;   BENCH_TMP=/dev/shm timeout -k 10 500 python3 tests/bench/bench_cli_shards.py 2000000 1 2 4 > $R/cli_shards_2M.json 2>> $R/misc.err
+BENCH_TMP=/dev/shm timeout -k 10 900 python3 tests/bench/bench_cli_shards.py 10000000 1 2 4 > $R/cli_shards_10M.json 2>> $R/misc.err
 say done
