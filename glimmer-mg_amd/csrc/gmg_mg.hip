@@ -2923,6 +2923,13 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     MgTimer tm(s);
     // 1. Frame_Scores
     if (!find_only) {
+    if (err_mode) {
+        // the penalties go up FIRST: behind the six-frame kernels this 2 KB copy waited a millisecond for a free slot beside the
+        // side streams' kernels, and the running sums behind it (profiles/r03_mgerr_timeline_indel.txt of the build before)
+        MG_TRY(gmg_pool_alloc((void **)&d_pen, sizeof pen_host));
+        MG_TRY(hipMemcpyAsync(d_pen, pen_host, sizeof pen_host, hipMemcpyHostToDevice, s));    // (pen_host lives until this call returns)
+        a.pen = d_pen;
+    }
     // classification mode: the per-read tables go to the device once per call (4 + 4 bytes per read)
     // (a (3,2,3) model's partial-window table follows its full-window table in the model blob: gmg_model_upload)
     const float *d_null_tab = nul->dev.dense;
@@ -3033,9 +3040,6 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     }
     tm.lap("frame scores");
     if (err_mode) {                                     // the error branch sums per call; it needs the penalties and the qualities
-        MG_TRY(gmg_pool_alloc((void **)&d_pen, sizeof pen_host));
-        MG_TRY(hipMemcpyAsync(d_pen, pen_host, sizeof pen_host, hipMemcpyHostToDevice, s));    // (pen_host lives until this call returns)
-        a.pen = d_pen;
         if (err_mode == 1 && a.total) {
             MG_TRY(gmg_pool_alloc((void **)&d_qual, a.total + 8));     // (+8: the level kernels read four values at a time)
             if (prm->quality) MG_TRY(gmg_pool_alloc((void **)&d_user_q, a.total));
