@@ -43,6 +43,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 
 static const uint64_t DEFAULT_BATCH_BYTES = 256ull << 20;
@@ -374,9 +375,22 @@ struct SubBatch {                                       // the reads of one ICM 
 // every header of it, and 0.25 B/base per GPU is cheap -- and takes the positions [n k / N, n (k + 1) / N) of every chunk's
 // visiting order: reads are independent, so any consecutive run of the order is a valid piece of work; the pieces go to
 // <out>.part<k>.c<chunk> and the parent concatenates them chunk by chunk, shard by shard: the reference's bytes.
+static double wall_seconds()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t batch_bytes, const char *class_file,
                        const string &icm_dir, const string &out_name, int shard, int n_shards)
 {
+    // GMG_CLI_TIMING=1: where the wall time of this process goes, one line on stderr at the end
+    const bool timing = getenv("GMG_CLI_TIMING") != NULL;
+    double t_sec[6] = {0, 0, 0, 0, 0, 0};               // start-up, ingest, plan + device calls + fetch, Update_Meta_*, events / DP / trace-back, rest
+    double t_mark = wall_seconds();
+    const double t_begin = t_mark;
+#define LAP(slot) do { if (timing) { const double t_ = wall_seconds(); t_sec[slot] += t_ - t_mark; t_mark = t_; } } while (0)
     if (gmg_init(device) != GMG_OK) die_gmg("gmg_init");
     const bool error_mode = Allow_Indels || Allow_Subs;
     const uint64_t chunk_reads = (uint64_t)Chunk_Sequences;
@@ -398,6 +412,7 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
     gmg_classes_info(cls, NULL, &n_icms, NULL, &missing_gc);
     if (missing_gc) fprintf(stderr, "WARNING: GC classification file unavailable for %llu classes (0.5 taken)\n", (unsigned long long)missing_gc);
 
+    LAP(0);
     // every chunk onto the device (0.25 B/base stays resident); with -m the null model needs the whole file's GC first
     vector<Piece> chunks;
     uint64_t gc = 0, total = 0;
@@ -420,6 +435,7 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
         LogOdds_PWM.Make_Log_Odds_WRT_GC(Indep_GC_Frac);
     }
     const double file_gc = Indep_GC_Frac;
+    LAP(1);
 
     FILE *quality_fp = NULL;
     if (Allow_Indels && Quality_File_Name != NULL) quality_fp = File_Open(Quality_File_Name, "r", __FILE__, __LINE__);
@@ -580,6 +596,7 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
             gmg_reads_free(batch);
             gmg_null_set_free(nulls);
         }
+        LAP(2);
         // the back half, read by read in the reference's order (glimmer-mg.cc:367-450)
         string hs;
         for (uint64_t k = k_lo; k < k_hi; k++) {
@@ -588,6 +605,7 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
             Fasta_Header = hs.c_str();
             load_sequence(packed, off, i);
             fprintf(predict_fp, ">%s\n", Fasta_Header);
+            LAP(5);
             if (!User_RBS) Update_Meta_RBS();
             if (!User_Length) Update_Meta_Length();
             if (!User_Start) Update_Meta_Start();
@@ -603,7 +621,9 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
                 gmg_ignore_score_len(read_gc[k], st, ns, &isl);
                 Ignore_Score_Len = isl;
             }
+            LAP(3);
             back_half(predict_fp, sub[where[k].first].sc, where[k].second, error_mode);
+            LAP(4);
         }
         gmg_reads_free(pc.reads);
         pc.reads = NULL;
@@ -612,6 +632,12 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
     if (predict_fp) fclose(predict_fp);
     if (quality_fp) fclose(quality_fp);
     gmg_classes_free(cls);
+    LAP(5);
+    if (timing)
+        fprintf(stderr, "glimmer-mg_gpu timing (shard %d of %d): start-up %.3f s, ingest %.3f, plan + device calls + fetch %.3f, Update_Meta_* %.3f, "
+                        "events / DP / trace-back %.3f, rest %.3f; total %.3f\n", shard, n_shards, t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4], t_sec[5],
+                wall_seconds() - t_begin);
+#undef LAP
     return EXIT_SUCCESS;
 }
 

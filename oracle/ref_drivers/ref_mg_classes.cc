@@ -23,6 +23,7 @@
 #include "glimmer-mg.hh"
 
 static vector<Start_t> Presort_List;
+static bool Quiet = false;      // GMG_REF_QUIET=1: no dump (and none of its per-read look-ups) -- the reference as it runs, for timing
 template <class It> inline void gmg_hooked_sort(It a, It b) { std::sort(a, b); }
 template <class It, class Cmp> inline void gmg_hooked_sort(It a, It b, Cmp c) { std::sort(a, b, c); }
 inline void gmg_hooked_sort(vector<Start_t>::iterator a, vector<Start_t>::iterator b, bool (*c)(const Start_t &, const Start_t &))
@@ -61,12 +62,12 @@ static void dump_list(const Orf_t &orf)
 
 void wrap_Add_Events_Fwd(const Orf_t &orf, vector<Start_t> &sl, int &id)
 {
-    dump_list(orf);
+    if (!Quiet) dump_list(orf);
     real_Add_Events_Fwd(orf, sl, id);
 }
 void wrap_Add_Events_Rev(const Orf_t &orf, vector<Start_t> &sl, int &id)
 {
-    dump_list(orf);
+    if (!Quiet) dump_list(orf);
     real_Add_Events_Rev(orf, sl, id);
 }
 
@@ -75,6 +76,7 @@ void wrap_Add_Events_Rev(const Orf_t &orf, vector<Start_t> &sl, int &id)
 void wrap_Find_Orfs(vector<Orf_t> &orf_list)
 {
     real_Find_Orfs(orf_list);
+    if (Quiet) return;
     // which ICM is loaded: the group loop's iterator is local to main, but a read belongs to exactly one group
     // (Read_Meta_ICMs puts every classified header into one vector), so look it up
     const string prefix = split(string(Fasta_Header))[0];
@@ -97,6 +99,7 @@ int main(int argc, char **argv)
 {
     const char *dir = getenv("GMG_REF_ICM_DIR");
     if (dir == NULL) { fprintf(stderr, "ref_mg_classes: set GMG_REF_ICM_DIR (the .genomeData directory)\n"); return 2; }
+    Quiet = getenv("GMG_REF_QUIET") != NULL;
     ICM_dir = dir;                                      // what install_glimmer.py:121 writes into glimmer-mg.cc:147
     if (const char *c = getenv("GMG_REF_CHUNK")) Chunk_Sequences = atoi(c);   // glimmer-mg.cc:128 (500000): small chunks for the tests
     const int rc = glimmer_mg_reference_main(argc, argv);

@@ -3,7 +3,8 @@
 synthetic reads over G ICM groups (default 64) and N null models (default 100 GC values), reads resident in HBM.
 Timed: (a) ONE gmg_mg_score_reads over all reads with one ICM and a null model per read (the single-ICM time);
 (b) the grouped job: the reads gathered in group order (gmg_reads_select) and scored group by group with each group's own ICM
-handle -- one gmg_mg_score_reads per group, or gmg_mg_score_groups when the library has it (BENCH_GROUPS_API=1).
+handle -- one gmg_mg_score_reads per group (BENCH_PER_GROUP_CALLS=1), and ONE gmg_mg_score_groups.
+BENCH_ERR=indel|sub: the same with glimmer-mg -i / -s on ragged ~400-bp reads (BASELINE configs[4]: -c together with -i).
 Prints one JSON line."""
 import ctypes as C
 import json
@@ -33,7 +34,13 @@ files = ["NC_000915.icm", "seqs.cluster-0.run1.filt.gicm", "seqs.cluster-2.run1.
 # same work as the single-ICM call and must give the same records; 0: five different files in turn
 same = os.environ.get("BENCH_SAME_MODEL", "1") == "1"
 models = [gmg.Icm.open(os.path.join(DATA, files[0 if same else g % len(files)])) for g in range(n_groups)]
-packed, off = gmg.synth.packed_reads(n_reads, L, 7)
+err = os.environ.get("BENCH_ERR", "")
+if err:                                                 # clipped N(400, 60^2) lengths, as bench_mg.py's ragged reads
+    lens = np.clip(np.random.default_rng(12).normal(400, 60, n_reads).round(), 100, 700).astype(np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    packed, _ = gmg.synth.packed_reads(1, int(off[-1]), 7)
+else:
+    packed, off = gmg.synth.packed_reads(n_reads, L, 7)
 reads = gmg.Reads(packed, off)
 rng = np.random.default_rng(3)
 group = rng.integers(0, n_groups, n_reads)
@@ -50,7 +57,8 @@ for arr in (order, read_null, read_isl, rn_sorted):    # page-locked: the copies
 
 
 def params(rn, isl):
-    prm = capi.MgParams(75, 1, 2**31 - 1, 3, 3, 1, -6.0)            # GMG_MG_ACCEPTED_ONLY, as the driver asks
+    prm = capi.MgParams(75, 1, 2**31 - 1, 3, 3, {"": 1, "indel": 1 | 2, "sub": 1 | 4}[err], -6.0)      # GMG_MG_ACCEPTED_ONLY, as the driver asks
+    prm.min_indel_orf_len, prm.indel_quality_threshold, prm.indel_max, prm.indel_suffix_score_threshold = 15, 18, 2, -12.0
     for i, c in enumerate(("atg", "gtg", "ttg")):
         prm.start_codon[i].value = c.encode()
     for i, c in enumerate(("taa", "tag", "tga")):
@@ -114,7 +122,7 @@ def timed(fn):
 t_single, all_single, r1 = timed(single)
 t_grouped, all_grouped, r2 = timed(grouped) if os.environ.get("BENCH_PER_GROUP_CALLS", "1") == "1" else (float("nan"), [], (0, 0))
 t_one, all_one, r3 = timed(grouped_one_call)
-print(json.dumps({"reads": n_reads, "read_len": L, "groups": n_groups, "null_models": n_nulls, "single_icm_ms": round(t_single, 3),
+print(json.dumps({"reads": n_reads, "read_len": L if not err else "~400 (ragged)", "error_branch": err, "groups": n_groups, "null_models": n_nulls, "single_icm_ms": round(t_single, 3),
                   "score_groups_ms": round(t_one, 3), "ratio": round(t_one / t_single, 3),
                   "one_call_per_group_ms": round(t_grouped, 3), "single_all": all_single, "score_groups_all": all_one,
                   "one_call_per_group_all": all_grouped, "accepted_orfs_single": r1[0], "accepted_orfs_groups": r3[0],

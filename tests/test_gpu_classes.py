@@ -295,3 +295,62 @@ def test_score_groups_refuses_bad_group_lists(gpu):
             gpu.mg_score_reads(None, nulls, reads, read_null=rn, groups=bad)
     with pytest.raises(gpu.GmgError):                   # groups need the per-read null models
         gpu.mg_score_reads(None, gpu.Icm.indep(0.5), reads, groups=[(m, 0, 10)])
+
+
+def test_score_groups_full_size_with_error_branch(gpu, oracle):
+    """BASELINE configs[4] as glimmer-mg.py runs it: -c together with -i on 1M reads of ~400 bp -- 64 ICM groups over five model
+    files, 100 GC values (a null model per read), Ignore_Score_Len per read, accepted ORFs only, ONE gmg_mg_score_groups call.
+    (1) two calls give the same bytes; (2) the records are back to back; (3) three whole groups equal gmg_mg_score_reads on the
+    gathered group alone; (4) sampled reads of other groups equal the oracle with the group's ICM and the read's null model."""
+    from test_gpu_mg_err import dev_err_rows, err_rows
+    n, n_groups, n_gc = 1_000_000, 64, 100
+    lens = np.clip(np.random.default_rng(12).normal(400, 60, n).round(), 100, 700).astype(np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    packed, _ = gpu.synth.packed_reads(1, int(off[-1]), 7)
+    reads = gpu.Reads(packed, off)
+    rng = np.random.default_rng(5)
+    cuts = np.concatenate([[0], np.sort(rng.choice(np.arange(1, n), n_groups - 1, replace=False)), [n]]).astype(np.int64)
+    models = [gpu.Icm.open(os.path.join(DATA, f)) for f in GICMS]
+    groups = [(models[g % len(models)], int(cuts[g]), int(cuts[g + 1])) for g in range(n_groups)]
+    gcs = np.linspace(0.3, 0.7, n_gc)
+    nulls = gpu.NullSet.build(gcs)
+    read_null = rng.integers(0, n_gc, n).astype(np.uint32)
+    read_isl = rng.choice([2 ** 31 - 1, 300, 150], n).astype(np.int32)
+    kw = dict(allow_indels=True, accepted_only=True)
+    orfs, starts, first, errs = gpu.mg_score_reads(None, nulls, reads, read_null=read_null, read_ignore_score_len=read_isl, groups=groups, **kw)
+    again = gpu.mg_score_reads(None, nulls, reads, read_null=read_null, read_ignore_score_len=read_isl, groups=groups, **kw)
+    for x, y in zip((orfs, starts, first, errs), again):
+        assert x.tobytes() == y.tobytes()
+    del again
+    assert len(orfs) == first[-1] > n // 10 and np.all(orfs["accepted"] != 0)
+    assert np.array_equal(orfs["start_begin"], np.concatenate([[0], np.cumsum(orfs["n_starts"].astype(np.int64))[:-1]]))
+    assert int(orfs["n_starts"].astype(np.int64).sum()) == len(starts) == len(errs)
+    assert np.all(np.diff(orfs["read"].astype(np.int64)) >= 0)
+    for g in (0, 31, 63):
+        m, b, e = groups[g]
+        part = gpu.mg_score_reads(m, nulls, reads.select(np.arange(b, e, dtype=np.uint64)), read_null=read_null[b:e],
+                                  read_ignore_score_len=read_isl[b:e], **kw)
+        o0, o1 = int(first[b]), int(first[e])
+        mine = orfs[o0:o1].copy()
+        assert len(mine) == len(part[0]) > 0
+        s0, s1 = int(mine["start_begin"][0]), int(mine["start_begin"][-1]) + int(mine["n_starts"][-1])
+        mine["read"] -= b
+        mine["start_begin"] -= s0
+        assert mine.tobytes() == part[0].tobytes() and starts[s0:s1].tobytes() == part[1].tobytes() and errs[s0:s1].tobytes() == part[3].tobytes()
+    o_models = [oracle.read(os.path.join(DATA, f)) for f in GICMS]
+    ep = oracle.mg_err_params(allow_indels=True)
+    checked = 0
+    for g in (1, 2, 3, 4, 17, 40, 62):
+        for r in (groups[g][1], groups[g][2] - 1):      # the group's first and last read: the model changes right there
+            seq = gpu.synth.unpack_ascii(packed, int(off[r]), int(off[r + 1] - off[r]))
+            prm = oracle.mg_params(ignore_score_len=int(read_isl[r]))
+            want_orfs, _, scored = oracle.mg_read_errors(o_models[g % len(GICMS)], oracle.indep(float(gcs[read_null[r]])), seq, prm, ep)
+            acc = [(o, out, st) for o, (out, st) in zip(want_orfs, scored) if out.accepted]
+            mine = orfs[int(first[r]):int(first[r + 1])]
+            assert len(mine) == len(acc)
+            for d, (o, out, st) in zip(mine, acc):
+                assert (int(d["frame"]), int(d["stop_position"])) == (int(o[0]), int(o[1]))
+                sl = slice(d["start_begin"], d["start_begin"] + d["n_starts"])
+                assert dev_err_rows(starts[sl], errs[sl]) == err_rows(st)
+                checked += 1
+    assert checked >= 5

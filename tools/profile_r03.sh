@@ -13,6 +13,7 @@ say bench-genome; timeout -k 10 400 python3 bench.py --data genome --no-cli > $R
 say frame6-prof;  timeout -k 10 1200 bash tools/profile_frame6.sh r03f6 > $R/profile_frame6.log 2>&1
 cp gpurun_out/prof_r03f6/summary.txt $R/pmc_summary_k_frame6t.txt; cp gpurun_out/prof_r03f6/summary_k_frame6p.txt $R/pmc_summary_k_frame6p.txt
 cp $(find gpurun_out/prof_r03f6/trace -name "*kernel_stats.csv" | head -1) $R/frame6_kernel_stats.csv
+say f6-data-ab;   timeout -k 10 300 python3 tools/f6_data_ab.py > $R/f6_data_ab.json 2>> $R/misc.err
 say mg;           for m in "" ragged; do BENCH_OWN_TABLE=1 timeout -k 10 200 python3 tests/bench/bench_mg.py 1000000 5 $m >> $R/mg_own_table.jsonl 2>> $R/mg.err; timeout -k 10 200 python3 tests/bench/bench_mg.py 1000000 5 $m >> $R/mg_callers_table.jsonl 2>> $R/mg.err; BENCH_NULLS=100 timeout -k 10 200 python3 tests/bench/bench_mg.py 1000000 5 $m >> $R/mg_nulls.jsonl 2>> $R/mg.err; done
 say mg-trace;     BENCH_OWN_TABLE=1 bash tools/prof_kernels.sh r03mg python3 tests/bench/bench_mg.py 1000000 3 > /dev/null 2>&1; kstats r03mg mg_kernel_stats.csv
 f=$(find gpurun_out/prof_r03mg -name "*kernel_trace.csv" | head -1); python3 tools/mg_timeline.py $f > $R/mg_timeline.txt
@@ -22,6 +23,8 @@ f=$(find gpurun_out/prof_r03err -name "*kernel_trace.csv" | head -1); python3 to
 say classes;      BENCH_PER_GROUP_CALLS=1 timeout -k 10 300 python3 tests/bench/bench_classes.py 1000000 64 100 7 > $R/classes_bench.json 2>> $R/misc.err
 BENCH_PER_GROUP_CALLS=0 BENCH_SAME_MODEL=0 timeout -k 10 300 python3 tests/bench/bench_classes.py 1000000 64 100 7 > $R/classes_bench_five_models.json 2>> $R/misc.err
 BENCH_PER_GROUP_CALLS=0 bash tools/prof_kernels.sh r03cls python3 tests/bench/bench_classes.py 1000000 64 100 3 > /dev/null 2>&1; kstats r03cls classes_kernel_stats.csv
+BENCH_ERR=indel BENCH_PER_GROUP_CALLS=0 timeout -k 10 300 python3 tests/bench/bench_classes.py 1000000 64 100 5 > $R/classes_bench_indel.json 2>> $R/misc.err
+say cli-classes;  timeout -k 10 400 python3 tests/bench/bench_cli_classes.py 50000 > $R/cli_classes.json 2>> $R/misc.err; BENCH_CLI_FLAGS=-i timeout -k 10 400 python3 tests/bench/bench_cli_classes.py 50000 > $R/cli_classes_indel.json 2>> $R/misc.err
 say strings;      timeout -k 10 300 python3 tests/bench/bench_strings.py 1000000 64 > $R/strings_bench.json 2>> $R/misc.err
 bash tools/prof_kernels.sh r03str python3 tests/bench/bench_strings.py 1000000 8 > /dev/null 2>&1; kstats r03str strings_kernel_stats.csv
 say orfs;         timeout -k 10 300 python3 tests/bench/bench_orfs.py 200000 5 > $R/orfs_bench.json 2>> $R/misc.err; timeout -k 10 400 python3 tests/bench/bench_orfs.py 1000000 3 > $R/orfs_bench_1M.json 2>> $R/misc.err
