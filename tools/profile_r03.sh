@@ -25,6 +25,7 @@ BENCH_PER_GROUP_CALLS=0 BENCH_SAME_MODEL=0 timeout -k 10 300 python3 tests/bench
 BENCH_PER_GROUP_CALLS=0 bash tools/prof_kernels.sh r03cls python3 tests/bench/bench_classes.py 1000000 64 100 3 > /dev/null 2>&1; kstats r03cls classes_kernel_stats.csv
 BENCH_ERR=indel BENCH_PER_GROUP_CALLS=0 timeout -k 10 300 python3 tests/bench/bench_classes.py 1000000 64 100 5 > $R/classes_bench_indel.json 2>> $R/misc.err
 say cli-classes;  timeout -k 10 400 python3 tests/bench/bench_cli_classes.py 50000 > $R/cli_classes.json 2>> $R/misc.err; BENCH_CLI_FLAGS=-i timeout -k 10 400 python3 tests/bench/bench_cli_classes.py 50000 > $R/cli_classes_indel.json 2>> $R/misc.err
+BENCH_CLI_DEV_OPTS="--shards 4" timeout -k 10 400 python3 tests/bench/bench_cli_classes.py 50000 > $R/cli_classes_shards4.json 2>> $R/misc.err
 say strings;      timeout -k 10 300 python3 tests/bench/bench_strings.py 1000000 64 > $R/strings_bench.json 2>> $R/misc.err
 bash tools/prof_kernels.sh r03str python3 tests/bench/bench_strings.py 1000000 8 > /dev/null 2>&1; kstats r03str strings_kernel_stats.csv
 say orfs;         timeout -k 10 300 python3 tests/bench/bench_orfs.py 200000 5 > $R/orfs_bench.json 2>> $R/misc.err; timeout -k 10 400 python3 tests/bench/bench_orfs.py 1000000 3 > $R/orfs_bench_1M.json 2>> $R/misc.err
