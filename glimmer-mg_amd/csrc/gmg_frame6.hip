@@ -64,7 +64,10 @@ struct Frame6Args {
     const uint64_t *group_read = nullptr;       // [n_groups + 1] first read of every group (k_frame6p)
     uint32_t n_rounds = 0, n_ranges = 0, n_groups = 0;
 };
-struct F6Round { uint32_t chunk0; uint16_t n, group; };
+struct F6Round { uint32_t chunk0; uint32_t ng; };      // ng = chunks of the round (1 .. 16) | its group << 5
+#define F6_ROUND_N(r) ((r).ng & 31u)
+#define F6_ROUND_GROUP(r) ((r).ng >> 5)
+#define F6_MAX_GROUPS ((1 << 27) - 1)
 struct F6Range { uint64_t first; uint32_t count, group; };
 
 constexpr int f6_cstride(int dt) { return ((((1 << (2 * dt)) - 1) / 3) + 15) & ~15; }
@@ -336,14 +339,14 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
     constexpr uint32_t NRAW = (K * RAWW + BLOCK - 1) / BLOCK;
     uint32_t raw_t[NRAW];
     auto raw_issue = [&](uint32_t j0) __attribute__((always_inline)) {
-        F6Round nd = {0, 1, 0};
+        F6Round nd = {0, 1};
         if (MULTI) nd = a.rounds[r_lo + (j0 / K) * r_step];
 #pragma unroll
         for (uint32_t i = 0; i < NRAW; i++) {
             const uint32_t t = threadIdx.x + i * BLOCK;
             const uint32_t k = t / RAWW, w = t - k * RAWW;
             const uint32_t j = j0 + k < n_mine ? j0 + k : n_mine - 1;
-            const uint64_t c = MULTI ? (uint64_t)nd.chunk0 + (k < nd.n ? k : nd.n - 1u) : chunk0 + (uint64_t)j * chunk_step;
+            const uint64_t c = MULTI ? (uint64_t)nd.chunk0 + (k < F6_ROUND_N(nd) ? k : F6_ROUND_N(nd) - 1u) : chunk0 + (uint64_t)j * chunk_step;
             raw_t[i] = t < K * RAWW ? a.packed[c * (SPAN / 16) - 1 + w] : 0u;
         }
     };
@@ -433,12 +436,12 @@ __global__ __launch_bounds__(BLOCK) void k_frame6t(Frame6Args a)
         uint64_t round_chunk0 = 0;
         if (MULTI) {
             const F6Round rd = a.rounds[r_lo + (j0 / K) * r_step];
-            kk = rd.n;
+            kk = F6_ROUND_N(rd);
             round_chunk0 = rd.chunk0;
-            if (rd.group != cur_group) {                            // another group: its model instead of the one in LDS
-                cur_group = rd.group;
+            if (F6_ROUND_GROUP(rd) != cur_group) {                            // another group: its model instead of the one in LDS
+                cur_group = F6_ROUND_GROUP(rd);
                 __syncthreads();                                    // every wave has left the previous round's second phase
-                const GmgDevModel &gm = a.gmodels[rd.group];
+                const GmgDevModel &gm = a.gmodels[cur_group];
                 const uint8_t *sh_src = gm.cshift + (size_t)ftype * gm.cstride;
                 for (int i = threadIdx.x; i < CS; i += BLOCK) {
                     const uint8_t sh = sh_src[i];
@@ -963,7 +966,7 @@ __global__ void k_f6_gather_u64(const uint64_t *src, const uint64_t *idx, uint32
 int gmg_launch_gene6_groups(const gmg_model *const *models, const uint64_t *group_read, int n_groups, const gmg_reads *reads,
                             float *d_gene, uint64_t gstride, hipStream_t s)
 {
-    if (!models || !group_read || n_groups < 1 || n_groups > 65535 || group_read[0] != 0 || group_read[n_groups] != reads->n_reads)
+    if (!models || !group_read || n_groups < 1 || n_groups > F6_MAX_GROUPS || group_read[0] != 0 || group_read[n_groups] != reads->n_reads)
         return gmg_set_error(GMG_EINVAL, "gmg_launch_gene6_groups: bad group list");
     for (int g = 0; g < n_groups; g++)
         if (!models[g] || group_read[g + 1] < group_read[g] || models[g]->dev.P < 3)
@@ -1040,7 +1043,7 @@ int gmg_launch_gene6_groups(const gmg_model *const *models, const uint64_t *grou
         if (c1 > 0xffffffffull) return gmg_set_error(GMG_ETOOBIG, "gmg_launch_gene6_groups: batch too large");
         add_range(b0, c0 * SPAN, g);
         for (uint64_t c = c0; c < c1; c += KR)
-            rounds.push_back(F6Round{(uint32_t)c, (uint16_t)(c1 - c < KR ? c1 - c : KR), (uint16_t)g});
+            rounds.push_back(F6Round{(uint32_t)c, (uint32_t)(c1 - c < KR ? c1 - c : KR) | (uint32_t)g << 5});
         add_range(c1 * SPAN, b1, g);
     }
     F6Round *d_rounds = nullptr;

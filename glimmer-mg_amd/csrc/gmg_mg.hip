@@ -3535,7 +3535,7 @@ extern "C" int gmg_mg_score_groups(const gmg_mg_group *groups, int n_groups, con
                                    const gmg_mg_params *prm, gmg_mg_result **out, void *stream)
 {
     if (!groups || n_groups < 1 || !reads || !prm) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_groups: NULL argument");
-    if (n_groups > 65535) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_groups: at most 65,535 groups per call");
+    if (n_groups >= 1 << 27) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_groups: at most 2^27 - 1 groups per call");
     if (!prm->nulls) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_groups: needs the per-read null models (gmg_mg_params.nulls / read_null)");
     MgGroups g;
     g.n = n_groups;

@@ -395,8 +395,8 @@ int gmg_mg_score_reads(const gmg_model *gene, const gmg_model *null_model, const
  * reads gathered in visiting order (gmg_reads_select on the order of gmg_classes_plan), groups[k] = reads [read_begin, read_end)
  * of that batch (consecutive, from 0 to n_reads), params->nulls / read_null / read_ignore_score_len per read (required; one
  * stop-codon set per call).  The six-frame pass swaps the group's tables in LDS as it crosses from group to group -- one launch
- * whatever the number of groups; everything behind it never sees a gene model.  Results as gmg_mg_score_reads', reads in batch
- * order. */
+ * whatever the number of groups (up to 2^27 - 1: a chunk may meet one ICM file per read); everything behind it never sees a gene
+ * model.  Results as gmg_mg_score_reads', reads in batch order. */
 typedef struct gmg_mg_group {
     const gmg_model *gene;
     uint64_t read_begin, read_end;

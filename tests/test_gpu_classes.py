@@ -354,3 +354,36 @@ def test_score_groups_full_size_with_error_branch(gpu, oracle):
                 assert dev_err_rows(starts[sl], errs[sl]) == err_rows(st)
                 checked += 1
     assert checked >= 5
+
+
+def test_score_groups_with_more_groups_than_65535(gpu):
+    """a chunk of glimmer-mg -c may meet one ICM file per read (500,000 reads per chunk): 70,000 groups of one read each, five tables
+    in turn -- every read's records must be those of a single-ICM call with its group's table"""
+    rng = np.random.default_rng(77)
+    n = 70_000
+    seqs = ragged(rng, [int(x) for x in rng.integers(40, 300, n)])
+    reads = gpu.Reads.from_strings(seqs)
+    models = [gpu.Icm.open(os.path.join(DATA, f)) for f in GICMS]
+    groups = [(models[g % len(models)], g, g + 1) for g in range(n)]
+    gcs = np.linspace(0.35, 0.65, 11)
+    nulls = gpu.NullSet.build(gcs)
+    read_null = rng.integers(0, len(gcs), n).astype(np.uint32)
+    read_isl = np.full(n, 2 ** 31 - 1, np.int32)
+    kw = dict(min_gene_len=60, read_null=read_null, read_ignore_score_len=read_isl)
+    whole = gpu.mg_score_reads(None, nulls, reads, groups=groups, **kw)
+    fields = [f for f in whole[0].dtype.names if f not in ("read", "start_begin")]
+    seen = 0
+    for m in range(len(models)):
+        one = gpu.mg_score_reads(models[m], nulls, reads, **kw)
+        for r in range(m, n, len(models) * 97):         # a sample of this table's reads
+            a = whole[0][int(whole[2][r]):int(whole[2][r + 1])]
+            b = one[0][int(one[2][r]):int(one[2][r + 1])]
+            assert len(a) == len(b)
+            for f in fields:
+                assert a[f].tobytes() == b[f].tobytes(), (r, f)
+            for x, y in zip(a, b):
+                sa = whole[1][int(x["start_begin"]):int(x["start_begin"]) + int(x["n_starts"])]
+                sb = one[1][int(y["start_begin"]):int(y["start_begin"]) + int(y["n_starts"])]
+                assert sa.tobytes() == sb.tobytes(), r
+                seen += len(sa)
+    assert seen > 100
