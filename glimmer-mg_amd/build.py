@@ -96,3 +96,8 @@ def build_lib(force=False, verbose=False):
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
+
+
+if __name__ == "__main__":                              # python3 glimmer-mg_amd/build.py [--force]
+    import sys
+    print(build_lib(force="--force" in sys.argv[1:], verbose="-v" in sys.argv[1:]))

@@ -3296,6 +3296,12 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (no && err_mode && err_path == 0) {              // did a call array overflow?  (mg_scan has synchronised the stream)
         uint32_t st[20];
         MG_TRY(hipMemcpy(st, d_err_flag, 80, hipMemcpyDeviceToHost));
+        if (tm.on) {                                    // (mg_timing) how many calls the levels handed on
+            unsigned long long handed[2];
+            memcpy(handed, st + 2, 16);
+            fprintf(stderr, "[gmg_mg] calls handed to level 1: %llu, to level 2: %llu (capacity %llu each; %llu ORFs)\n", handed[0], handed[1],
+                    (unsigned long long)a.call_cap, (unsigned long long)no);
+        }
         if (st[0]) {
             // once more with arrays of twice what was asked for (level 2 is only partly known when level 1 overflows); if that is
             // not enough either, or does not fit, everything runs on the per-ORF kernel
