@@ -237,6 +237,12 @@ def main():
                     help="genome: reads cut uniformly from tests/golden/data/NC_000915.fna, both strands (weak scaling only)")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON: whatever libraries write to file descriptor 1 on the way (RCCL prints a version banner
+    # there when a process group is made) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import _gmg_pkg
@@ -393,7 +399,8 @@ def main():
             line["value"] = None
         if world == 1 and not args.no_cli and ok:
             line["cli_end_to_end"] = cli_end_to_end()
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

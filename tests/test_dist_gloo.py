@@ -85,6 +85,8 @@ def test_bench_under_torch_distributed_run_with_rccl_on_one_gpu(tmp_path):
            "--reads", "50000", "--cpu-reads", "0"]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-3000:]
-    line = json.loads([ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                       # ONE line on stdout: RCCL's version banner and the like go to stderr
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 1000
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
