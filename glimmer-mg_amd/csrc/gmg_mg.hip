@@ -2280,6 +2280,10 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                         if (WRITE && accepted_only && !rec.accepted) active = false;
                         off = (int64_t)a.read_off[rec.read];
                         n = (int)(a.read_off[rec.read + 1] - a.read_off[rec.read]);
+                        // Only accepted ORFs leave the GPU: an ORF is accepted only if one of its starts has j + 1 >= Min_Gene_Len
+                        // (glimmer-mg.cc:1655-1668), and no path can get further from the ORF's end than the read reaches that way (j counts
+                        // the positions walked, an insertion per level adds one, the entry itself two): such ORFs are not expanded at all.
+                        if (!WRITE && accepted_only && (fwd ? end_point : n - end_point + 1) + 12 < a.min_gene_len) active = false;
                     } else {
                         const MgCall c = a.calls[LEVEL - 1][i];
                         if (c.level == 0) active = false;                       // the unused end of a wave's chunk

@@ -178,3 +178,34 @@ def test_error_branch_full_size_properties(gpu, oracle, nc):
             assert dev_err_rows(starts[sl], errs[sl]) == err_rows(st)
             checked += 1
     assert checked >= 1
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("indel", dict(allow_indels=True)),
+    ("indel_short_genes", dict(allow_indels=True, min_gene_len=45)),
+    ("indel_long_genes", dict(allow_indels=True, min_gene_len=150)),
+    ("indel_one_level", dict(allow_indels=True, indel_max=1)),
+    ("indel_no_truncated", dict(allow_indels=True, allow_truncated=False)),
+    ("sub", dict(allow_subs=True)),
+    ("sub_long_genes", dict(allow_subs=True, min_gene_len=120)),
+])
+def test_accepted_only_is_the_full_result_filtered(gpu, nc, name, kw):
+    """GMG_MG_ACCEPTED_ONLY does not expand ORFs that cannot reach Min_Gene_Len before their read ends (no path gets further from the
+    ORF's end than the read does): what it returns must be exactly the accepted ORFs of the full result -- 30,000 ragged reads
+    (0 .. 1,500 bp, many ORFs near the read ends), every record, start and error list"""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    lens = np.clip(rng.normal(300, 200, 30_000).round(), 0, 1500).astype(np.int64)
+    reads = gpu.Reads.from_strings(["".join("acgt"[c] for c in rng.integers(0, 4, size=int(n))) for n in lens])
+    indep = gpu.Icm.indep(0.5)
+    full = gpu.mg_score_reads(nc, indep, reads, **kw)
+    kept = gpu.mg_score_reads(nc, indep, reads, accepted_only=True, **kw)
+    keep = full[0]["accepted"] != 0
+    assert len(kept[0]) == keep.sum() > 20
+    fo = full[0][keep]
+    for f in ("read", "frame", "stop_position", "n_starts", "accepted", "lo", "hi", "first_j"):
+        assert np.array_equal(fo[f], kept[0][f]), f
+    assert fo["best_score"].tobytes() == kept[0]["best_score"].tobytes()
+    idx = np.concatenate([np.arange(b, b + c) for b, c in zip(fo["start_begin"].astype(np.int64), fo["n_starts"].astype(np.int64))])
+    assert full[1][idx].tobytes() == kept[1].tobytes() and full[3][idx].tobytes() == kept[3].tobytes()
+    assert np.array_equal(kept[2], np.concatenate([[0], np.cumsum(keep)])[full[2].astype(np.int64)])
