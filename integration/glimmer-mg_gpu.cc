@@ -387,7 +387,8 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
 {
     // GMG_CLI_TIMING=1: where the wall time of this process goes, one line on stderr at the end
     const bool timing = getenv("GMG_CLI_TIMING") != NULL;
-    double t_sec[6] = {0, 0, 0, 0, 0, 0};               // start-up, ingest, plan + device calls + fetch, Update_Meta_*, events / DP / trace-back, rest
+    double t_sec[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (6 .. 10: Update_Meta_RBS, _Length, _Start, _Adj, _Stop)
+    //               // start-up, ingest, plan + device calls + fetch, Update_Meta_*, events / DP / trace-back, rest
     double t_mark = wall_seconds();
     const double t_begin = t_mark;
 #define LAP(slot) do { if (timing) { const double t_ = wall_seconds(); t_sec[slot] += t_ - t_mark; t_mark = t_; } } while (0)
@@ -607,10 +608,15 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
             fprintf(predict_fp, ">%s\n", Fasta_Header);
             LAP(5);
             if (!User_RBS) Update_Meta_RBS();
+            LAP(6);
             if (!User_Length) Update_Meta_Length();
+            LAP(7);
             if (!User_Start) Update_Meta_Start();
+            LAP(8);
             if (!User_Adj) Update_Meta_Adj();
+            LAP(9);
             if (!User_Stop) Update_Meta_Stop();
+            LAP(10);
             if (!User_ICM) {                            // what Update_Meta_Null_ICM leaves in the globals the back half reads
                 Indep_GC_Frac = read_gc[k];
                 int32_t isl = 0;
@@ -634,9 +640,10 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
     gmg_classes_free(cls);
     LAP(5);
     if (timing)
-        fprintf(stderr, "glimmer-mg_gpu timing (shard %d of %d): start-up %.3f s, ingest %.3f, plan + device calls + fetch %.3f, Update_Meta_* %.3f, "
-                        "events / DP / trace-back %.3f, rest %.3f; total %.3f\n", shard, n_shards, t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4], t_sec[5],
-                wall_seconds() - t_begin);
+        fprintf(stderr, "glimmer-mg_gpu timing (shard %d of %d): start-up %.3f s, ingest %.3f, plan + device calls + fetch %.3f, Update_Meta_* %.3f "
+                        "(RBS %.3f, Length %.3f, Start %.3f, Adj %.3f, Stop %.3f), events / DP / trace-back %.3f, rest %.3f; total %.3f\n", shard, n_shards,
+                t_sec[0], t_sec[1], t_sec[2], t_sec[3] + t_sec[6] + t_sec[7] + t_sec[8] + t_sec[9] + t_sec[10], t_sec[6], t_sec[7], t_sec[8], t_sec[9], t_sec[10],
+                t_sec[4], t_sec[5], wall_seconds() - t_begin);
 #undef LAP
     return EXIT_SUCCESS;
 }
