@@ -38,6 +38,7 @@
 
 #include "gmg.h"
 
+#include <errno.h>
 #include <fcntl.h>
 #include <signal.h>
 #include <sys/mman.h>
@@ -693,6 +694,19 @@ int main(int argc, char **argv)
             ICM_dir = icm_dir;                          // glimmer-mg.cc:147: what the reference's Read_Meta_* open
         }
         setup_options((int)rest.size(), rest.data());
+        if (Genome_Is_Circular) {
+            // -r (Find_Orfs with wrap-around, glimmer_base.cc:638-817) is not batched here: glimmer-mg_dropin beside this binary is the
+            // reference's own main() on the device-backed ICM_t (same bytes, one launch per ICM_t call); nothing has touched the GPU yet
+            char self[4096];
+            const ssize_t n_self = readlink("/proc/self/exe", self, sizeof self - 1);
+            string dir = n_self > 0 ? string(self, (size_t)n_self) : string(argv[0]);
+            const size_t slash = dir.rfind('/');
+            const string exe = (slash == string::npos ? string(".") : dir.substr(0, slash)) + "/glimmer-mg_dropin";
+            rest.push_back(NULL);
+            execv(exe.c_str(), rest.data());
+            fprintf(stderr, "glimmer-mg_gpu: -r needs %s (the reference's loop on the device-backed ICM_t), which could not be started: %s\n", exe.c_str(), strerror(errno));
+            return 2;
+        }
         if (n_shards > 1 && Quality_File_Name != NULL) {
             fprintf(stderr, "glimmer-mg_gpu: -q with --shards > 1 is not supported (the quality file is read in order)\n");
             return 2;

@@ -8,6 +8,7 @@
 //     Score_Orfs' scoring (buffers, two cumulative scores, start scan)  -> gmg_score_orfs  (glimmer3.cc:1275-1552)
 //
 //     glimmer3_gpu <glimmer3 options> <fasta> <tag>          (GMG_DEVICE selects the GPU)
+// -M, -L and -i select loops that are not batched here: such a command line is handed to glimmer3_dropin (same directory).
 //
 // Output: <tag>.predict, byte-identical to the reference's (tests/test_gpu_dropin_cli.py).
 
@@ -17,6 +18,7 @@
 
 #include "gmg.h"
 
+#include <errno.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -49,11 +51,30 @@ static void load_sequence(const vector<string> &seq_list, const vector<string> &
     Sequence_Len = Sequence.length();
 }
 
+// The modes whose loops are not batched here -- -M (every input sequence is one gene: Score_Separate_Input, glimmer3.cc:1555-1628),
+// -L (ORFs from a coordinate file: Score_Orflist, :1177-1271) and -i (ignore regions in Find_Orfs, glimmer_base.cc:833-943) -- run
+// in glimmer3_dropin beside this binary: the reference's own main() on the device-backed ICM_t (one launch per ICM_t call; same
+// bytes).  Nothing has touched the GPU yet, so this process simply becomes that one.
+static int run_dropin(const char *name, char **argv)
+{
+    char self[4096];
+    const ssize_t n = readlink("/proc/self/exe", self, sizeof self - 1);
+    string dir = n > 0 ? string(self, (size_t)n) : string(argv[0]);
+    const size_t slash = dir.rfind('/');
+    dir = slash == string::npos ? string(".") : dir.substr(0, slash);
+    const string exe = dir + "/" + name;
+    execv(exe.c_str(), argv);
+    fprintf(stderr, "glimmer3_gpu: this option set needs %s (the reference's loop on the device-backed ICM_t), which could not be started: %s\n",
+            exe.c_str(), strerror(errno));
+    return 2;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 3) { fprintf(stderr, "usage: glimmer3_gpu <glimmer3 options> <fasta> <tag>\n"); return 2; }
     try {
         setup_options(argc, argv);
+        if (Separate_Orf_Input || Orflist_File_Name != NULL || Ignore_File_Name != NULL || Genome_Is_Circular) return run_dropin("glimmer3_dropin", argv);
         vector<string> seq_list, hdr_list;
         // pass 1, on the device: the file's bytes are parsed there (gmg_fasta_ingest = Fasta_Read + tolower (Filter ()) +
         // packing + the g/c count of Set_GC_Fraction) and Find_Orfs runs for every read at once (gmg_find_orfs)

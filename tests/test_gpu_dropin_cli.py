@@ -70,3 +70,66 @@ def test_long_and_tiny_sequences_through_the_device_front_halves(gpu, tmp_path, 
         assert res.returncode == 0, res.stderr.decode()[-2000:]
         out.append(open(str(tmp_path / tag) + ".predict", "rb").read())
     assert out[0] == out[1] and out[0].count(b"orf") >= 1
+
+
+def _genome():
+    return "".join(line.strip() for line in open(os.path.join(DATA, "NC_000915.fna")) if not line.startswith(">"))
+
+
+def _write_fasta(path, records):
+    with open(path, "w") as f:
+        for name, s in records:
+            f.write(">%s\n" % name)
+            for i in range(0, len(s), 70):
+                f.write(s[i:i + 70] + "\n")
+
+
+@pytest.mark.parametrize("mode", ["separate_input", "orflist", "ignore_regions", "mg_circular"])
+def test_modes_outside_the_batched_loops_run_the_reference_loop_on_the_device_icm(gpu, tmp_path, mode):
+    """glimmer3 -M (every input sequence is one gene, Score_Separate_Input), -L (ORFs from a coordinate file, Score_Orflist), -i
+    (ignore regions) and glimmer-mg -r (circular genome) are not batched by the *_gpu drivers: they hand the command line to the
+    *_dropin binary beside them (the reference's own main() on the device-backed ICM_t) instead of silently running the default
+    loop -- the bytes must be the all-reference binary's."""
+    import numpy as np
+    rng = np.random.default_rng(21)
+    icm = os.path.join(DATA, "NC_000915.icm")
+    fa = str(tmp_path / "in.fa")
+    mg = mode == "mg_circular"
+    ref = built_binary("oracle", "_ref", "glimmer-mg" if mg else "glimmer3")
+    dev = built_binary("integration", "_build", "glimmer-mg_gpu" if mg else "glimmer3_gpu")
+    extra = []
+    if mode == "separate_input":
+        g = _genome()
+        _write_fasta(fa, [("gene%d" % i, g[int(b):int(b) + int(n)]) for i, (b, n) in enumerate(zip(rng.integers(0, 1_600_000, 40), rng.integers(90, 900, 40) // 3 * 3))])
+        extra = ["-M"]
+    elif mode == "orflist":
+        _write_fasta(fa, [("chromosome", _genome()[400_000:430_000])])
+        # coordinates: the genes the reference predicts on that sequence, as an ORF list (tag, start, stop, direction)
+        res = subprocess.run([ref, "-m", icm, fa, str(tmp_path / "pre")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert res.returncode == 0, res.stderr.decode()[-2000:]
+        coords = str(tmp_path / "orfs.coords")
+        n_lines = 0
+        with open(coords, "w") as f:
+            for line in open(str(tmp_path / "pre") + ".predict"):
+                if line.startswith("orf"):
+                    tag, a, b, frame = line.split()[:4]
+                    f.write("%s %s %s %d\n" % (tag, a, b, 1 if int(frame) > 0 else -1))
+                    n_lines += 1
+        assert n_lines >= 3
+        extra = ["-L", coords]
+    elif mode == "ignore_regions":
+        _write_fasta(fa, [("chromosome", _genome()[400_000:430_000])])
+        ign = str(tmp_path / "ignore.txt")
+        with open(ign, "w") as f:
+            f.write("# lo hi\n2000 3500\n9000 8000\n15000 15100\n")
+        extra = ["-i", ign]
+    else:
+        g = _genome()
+        _write_fasta(fa, [("plasmid", g[700_000:712_000]), ("plasmid2", g[900_000:904_000])])
+        extra = ["-r"]
+    out = []
+    for exe, tag in ((ref, "a"), (dev, "b")):
+        res = subprocess.run([exe, *extra, "-m", icm, fa, str(tmp_path / tag)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert res.returncode == 0, res.stderr.decode()[-2000:]
+        out.append(open(str(tmp_path / tag) + ".predict", "rb").read())
+    assert out[0] == out[1] and out[0].count(b"\n") >= 4
