@@ -23,6 +23,8 @@
 
 #include <fstream>
 #include <math.h>
+#include <memory>
+#include <new>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
@@ -97,10 +99,17 @@ static int classes_icm_file(const gmg_classes *c, const std::vector<std::string>
     return 0;
 }
 
-extern "C" int gmg_classes_load(const char *class_text, uint64_t n_bytes, const char *icm_dir, gmg_classes **out)
+// (no C++ exception leaves the C ABI: the entry points below turn them into GMG_ENOMEM / GMG_EINVAL)
+#define GMG_C_ABI_GUARD(name, call)                                                                              \
+    try { return call; }                                                                                         \
+    catch (const std::bad_alloc &) { return gmg_set_error(GMG_ENOMEM, name ": out of host memory"); }            \
+    catch (const std::exception &e) { return gmg_set_error(GMG_EINVAL, name ": %s", e.what()); }
+
+static int classes_load(const char *class_text, uint64_t n_bytes, const char *icm_dir, gmg_classes **out)
 {
     if ((!class_text && n_bytes) || !icm_dir || !out) return gmg_set_error(GMG_EINVAL, "gmg_classes_load: NULL argument");
-    gmg_classes *c = new gmg_classes;
+    std::unique_ptr<gmg_classes> holder(new gmg_classes);
+    gmg_classes *c = holder.get();
     c->icm_dir = icm_dir;
     c->n_missing_gc = 0;
     // Parse_Classes (glimmer-mg.cc:726-758): one line per read, "<header prefix> <class> <class> ..."; a later line for the
@@ -115,7 +124,6 @@ extern "C" int gmg_classes_load(const char *class_text, uint64_t n_bytes, const 
         // the reference indexes a[0] and, later, the first class of every read without a check (undefined behaviour on a blank
         // line or a read without classes): refused here
         if (a.size() < 2) {
-            delete c;
             return gmg_set_error(GMG_EINVAL, "gmg_classes_load: line %llu of the classification file names no %s",
                                  (unsigned long long)line_no, a.empty() ? "read" : "class");
         }
@@ -129,7 +137,6 @@ extern "C" int gmg_classes_load(const char *class_text, uint64_t n_bytes, const 
         std::string icm_file, strain, nc;
         if (classes_icm_file(c, cl, icm_file) != 0) {
             const std::string who = ci->first;
-            delete c;
             return gmg_set_error(GMG_EINVAL, "gmg_classes_load: a class of read %s is not of the form <strain>|<NC>", who.c_str());
         }
         ListMap::iterator isi = c->icm_sequences.find(icm_file);
@@ -142,8 +149,7 @@ extern "C" int gmg_classes_load(const char *class_text, uint64_t n_bytes, const 
             if (c->gc.find(cl[i]) != c->gc.end()) continue;
             if (!strain_nc(cl[i], strain, nc)) {
                 const std::string who = ci->first;
-                delete c;
-                return gmg_set_error(GMG_EINVAL, "gmg_classes_load: a class of read %s is not of the form <strain>|<NC>", who.c_str());
+                    return gmg_set_error(GMG_EINVAL, "gmg_classes_load: a class of read %s is not of the form <strain>|<NC>", who.c_str());
             }
             const std::string gc_file = c->icm_dir + "/" + strain + "/" + nc + ".gc.txt";
             std::ifstream gc_open(gc_file.c_str());
@@ -173,8 +179,12 @@ extern "C" int gmg_classes_load(const char *class_text, uint64_t n_bytes, const 
         c->icm_files.push_back(it->first);
         c->icm_reads.push_back(&it->second);
     }
-    *out = c;
+    *out = holder.release();
     return GMG_OK;
+}
+extern "C" int gmg_classes_load(const char *class_text, uint64_t n_bytes, const char *icm_dir, gmg_classes **out)
+{
+    GMG_C_ABI_GUARD("gmg_classes_load", classes_load(class_text, n_bytes, icm_dir, out))
 }
 
 extern "C" int gmg_classes_free(gmg_classes *c)
@@ -199,8 +209,8 @@ extern "C" const char *gmg_classes_icm_file(const gmg_classes *c, uint32_t k)
     return c->icm_files[k].c_str();
 }
 
-extern "C" int gmg_classes_plan(const gmg_classes *c, const char *const *hdr, const uint32_t *hdr_len, uint64_t n,
-                                uint64_t *order, uint64_t *icm_begin, double *gc, int32_t *transl, uint64_t *n_order)
+static int classes_plan(const gmg_classes *c, const char *const *hdr, const uint32_t *hdr_len, uint64_t n,
+                        uint64_t *order, uint64_t *icm_begin, double *gc, int32_t *transl, uint64_t *n_order)
 {
     if (!c || (!hdr && n) || (!hdr_len && n) || !order || !icm_begin || !n_order)
         return gmg_set_error(GMG_EINVAL, "gmg_classes_plan: NULL argument");
@@ -239,6 +249,11 @@ extern "C" int gmg_classes_plan(const gmg_classes *c, const char *const *hdr, co
     icm_begin[c->icm_files.size()] = k;
     *n_order = k;
     return GMG_OK;
+}
+extern "C" int gmg_classes_plan(const gmg_classes *c, const char *const *hdr, const uint32_t *hdr_len, uint64_t n,
+                                uint64_t *order, uint64_t *icm_begin, double *gc, int32_t *transl, uint64_t *n_order)
+{
+    GMG_C_ABI_GUARD("gmg_classes_plan", classes_plan(c, hdr, hdr_len, n, order, icm_begin, gc, transl, n_order))
 }
 
 // Set_Stop_Codons_By_Code (src/Common/gene.cc:1560-1624)
@@ -288,7 +303,7 @@ extern "C" int gmg_ignore_score_len(double gc_frac, const char (*stop_codon)[4],
 // The null models of one ICM group: Indep_Model . Build_Indep_WO_Stops (gc, Stop_Codon) (glimmer-mg.cc:2066; icm.cc:65-216) for
 // every GC value of the list, with the host ICM_t of this library (its libm, like the reference's), on a few host threads,
 // and up to the device as one gmg_null_set.
-extern "C" int gmg_null_set_build(const double *gc_frac, int n, const char (*stop_codon)[4], int n_stop_codons, gmg_null_set **out)
+static int null_set_build(const double *gc_frac, int n, const char (*stop_codon)[4], int n_stop_codons, gmg_null_set **out)
 {
     if (!gc_frac || n < 1 || !stop_codon || n_stop_codons < 1 || n_stop_codons > 8 || !out)
         return gmg_set_error(GMG_EINVAL, "gmg_null_set_build: bad argument");
@@ -315,4 +330,8 @@ extern "C" int gmg_null_set_build(const double *gc_frac, int n, const char (*sto
         }));
     for (size_t t = 0; t < pool.size(); t++) pool[t].join();
     return gmg_null_set_from_tables(mip.data(), prob.data(), n, out);
+}
+extern "C" int gmg_null_set_build(const double *gc_frac, int n, const char (*stop_codon)[4], int n_stop_codons, gmg_null_set **out)
+{
+    GMG_C_ABI_GUARD("gmg_null_set_build", null_set_build(gc_frac, n, stop_codon, n_stop_codons, out))
 }
