@@ -5,7 +5,8 @@
 integration/_build/glimmer-mg_gpu -c on one synthetic FASTA file of ~400-bp reads, every read with one to three classes drawn
 from the sample-run's class file (the synthetic .genomeData tree of tests/golden/make_genome_data.py: 240 ICM files, five
 tables, a GC value per class, three stop-codon sets).  The two .predict files must be byte-identical.
-bench_cli_classes.py [n_reads] ; BENCH_CLI_FLAGS="-i" adds glimmer-mg options to both runs; BENCH_CLI_DEV_OPTS="--shards 2".
+bench_cli_classes.py [n_reads] ; BENCH_CLI_FLAGS="-i" adds glimmer-mg options to both runs; BENCH_CLI_DEV_OPTS="--shards 2";
+BENCH_CHUNK=N: chunks of N reads in both (the reference's Chunk_Sequences, 500000 by default).
 Prints one JSON line."""
 import hashlib
 import json
@@ -28,6 +29,9 @@ DEV = os.path.join(ROOT, "integration", "_build", "glimmer-mg_gpu")
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000
 flags = os.environ.get("BENCH_CLI_FLAGS", "").split()
 dev_opts = os.environ.get("BENCH_CLI_DEV_OPTS", "").split()
+chunk = os.environ.get("BENCH_CHUNK")
+if chunk:
+    dev_opts += ["--chunk-reads", chunk]
 
 rng = np.random.default_rng(23)
 lens = np.clip(rng.normal(400, 60, n_reads).round(), 100, 700).astype(np.int64)
@@ -55,7 +59,7 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("BENCH_TMP")) as tmp:
         return dt, hashlib.md5(open(os.path.join(tmp, tag + ".predict"), "rb").read()).hexdigest(), res.stderr.decode()
 
     # ICM_dir as a RELATIVE name in both: the reference visits the ICM groups in the order of a hash of the file NAME
-    t_ref, md5_ref, _ = run([REF, *flags, "-c", cls], "ref", {"GMG_REF_ICM_DIR": ".genomeData", "GMG_REF_QUIET": "1"})
+    t_ref, md5_ref, _ = run([REF, *flags, "-c", cls], "ref", dict({"GMG_REF_ICM_DIR": ".genomeData", "GMG_REF_QUIET": "1"}, **({"GMG_REF_CHUNK": chunk} if chunk else {})))
     runs = [run([DEV, "--icm-dir", ".genomeData", *dev_opts, *flags, "-c", cls], "dev%d" % i, {"GMG_CLI_TIMING": "1"}) for i in range(2)]
     genes = sum(1 for line in open(os.path.join(tmp, "ref.predict")) if line.startswith("orf"))
 t_dev, _, err_dev = min(runs)
