@@ -387,3 +387,21 @@ def test_score_groups_with_more_groups_than_65535(gpu):
                 assert sa.tobytes() == sb.tobytes(), r
                 seen += len(sa)
     assert seen > 100
+
+
+@pytest.mark.parametrize("own", [[], ["--shards", "1", "--chunk-reads", "30"]])
+def test_classification_mode_with_a_quality_file_equals_the_reference_run_here(gpu, tmp_path, own):
+    """-c -i -q: the quality file is read chunk by chunk in FILE order (glimmer-mg.cc:334-359) while the reads are visited in the
+    ICM groups' order -- the reference's own main() (oracle/_ref/ref_mg_classes, run here) against glimmer-mg_gpu, 80 reads with
+    Phred values, also in chunks of 30 reads"""
+    ref = built_binary("oracle", "_ref", "ref_mg_classes")
+    dev = built_binary("integration", "_build", "glimmer-mg_gpu")
+    common = ["-i", "-q", os.path.join(DATA, "seqs80.qual"), "-c", os.path.join(DATA, "seqs.class.txt"), os.path.join(DATA, "seqs80.fa")]
+    chunk = own[own.index("--chunk-reads") + 1] if "--chunk-reads" in own else None
+    env = dict(os.environ, GMG_REF_ICM_DIR=".genomeData", GMG_REF_QUIET="1", **({"GMG_REF_CHUNK": chunk} if chunk else {}))
+    res = subprocess.run([ref, *common, str(tmp_path / "ref")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    res = subprocess.run([dev, "--icm-dir", ".genomeData", *own, *common, str(tmp_path / "dev")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    want = open(str(tmp_path / "ref") + ".predict", "rb").read()
+    assert open(str(tmp_path / "dev") + ".predict", "rb").read() == want and want.count(b"orf") > 20
