@@ -405,3 +405,33 @@ def test_classification_mode_with_a_quality_file_equals_the_reference_run_here(g
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     want = open(str(tmp_path / "ref") + ".predict", "rb").read()
     assert open(str(tmp_path / "dev") + ".predict", "rb").read() == want and want.count(b"orf") > 20
+
+
+OPTION_SETS = [
+    ["-Z", "taa,tag"], ["-z", "4"], ["-b", os.path.join(DATA, "seqs.cluster-2.run1.filt.motif")],
+    ["-f", os.path.join(DATA, "NC_000915.run1.features.txt")], ["-g", "60", "-o", "50"], ["-u", "2.5", "-s"],
+    ["-i", "-Z", "tga", "-g", "99"],
+]
+
+
+@pytest.mark.parametrize("mode", ["classes", "one_icm"])
+@pytest.mark.parametrize("opts", OPTION_SETS, ids=["_".join(o[:2]).replace(",", "").replace("/", "") [:24] for o in OPTION_SETS])
+def test_driver_options_against_the_reference_run_here(gpu, tmp_path, opts, mode):
+    """every glimmer-mg option that changes what is scored or how the events are weighed (-Z / -z stop codons for all reads, -b RBS
+    matrix, -f feature file, -g, -o, -u, -s, -i) with -c and with -m: the reference binary run in the test against glimmer-mg_gpu on
+    the first 80 reads"""
+    fa = os.path.join(DATA, "seqs80.fa")
+    if mode == "classes":
+        ref = built_binary("oracle", "_ref", "ref_mg_classes")
+        sel, own = ["-c", os.path.join(DATA, "seqs.class.txt")], ["--icm-dir", ".genomeData"]
+    else:
+        ref = built_binary("oracle", "_ref", "glimmer-mg")
+        sel, own = ["-m", os.path.join(DATA, "NC_000915.icm")], []
+    dev = built_binary("integration", "_build", "glimmer-mg_gpu")
+    env = dict(os.environ, GMG_REF_ICM_DIR=".genomeData", GMG_REF_QUIET="1")
+    res = subprocess.run([ref, *opts, *sel, fa, str(tmp_path / "ref")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    res = subprocess.run([dev, *own, *opts, *sel, fa, str(tmp_path / "dev")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    want = open(str(tmp_path / "ref") + ".predict", "rb").read()
+    assert open(str(tmp_path / "dev") + ".predict", "rb").read() == want and want.count(b">") == 80

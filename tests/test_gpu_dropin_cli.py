@@ -133,3 +133,25 @@ def test_modes_outside_the_batched_loops_run_the_reference_loop_on_the_device_ic
         assert res.returncode == 0, res.stderr.decode()[-2000:]
         out.append(open(str(tmp_path / tag) + ".predict", "rb").read())
     assert out[0] == out[1] and out[0].count(b"\n") >= 4
+
+
+G3_OPTION_SETS = [
+    ["-A", "atg,gtg"], ["-C", "38.5"], ["-f", "x"], ["-g", "60", "-o", "20"], ["-q", "150"], ["-t", "40"], ["-z", "4"], ["-Z", "taa,tga"],
+    ["-b", os.path.join(DATA, "seqs.cluster-2.run1.filt.motif")],
+    ["-X", "-g", "90", "-A", "atg", "-t", "20"], ["-u", "1.5", "-P", "0.6,0.3,0.1"], ["-n"], ["-l"],
+]       # (the reference's getopt string gives -f an argument it never reads and -F none although it reads one: -F cannot be used)
+
+
+@pytest.mark.parametrize("opts", G3_OPTION_SETS, ids=["_".join(o[:2]).replace(",", "").replace("/", "")[:20] for o in G3_OPTION_SETS])
+def test_glimmer3_gpu_options_against_the_reference_run_here(gpu, tmp_path, opts):
+    """every glimmer3 option that changes the ORFs, the scoring or the weights of the DP (start / stop codon sets, GC, first-start rule,
+    lengths, overlap, Ignore_Score_Len, threshold, RBS matrix, feature file, prior): oracle/_ref/glimmer3 run in the test against
+    glimmer3_gpu on the 999 sample reads"""
+    ref, dev = built_binary("oracle", "_ref", "glimmer3"), built_binary("integration", "_build", "glimmer3_gpu")
+    out = []
+    for exe, tag in ((ref, "a"), (dev, "b")):
+        res = subprocess.run([exe, *opts, "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, "seqs.fa"), str(tmp_path / tag)],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert res.returncode == 0, (opts, res.stderr.decode()[-2000:])
+        out.append(open(str(tmp_path / tag) + ".predict", "rb").read())
+    assert out[0] == out[1] and out[0].count(b">") == 999
