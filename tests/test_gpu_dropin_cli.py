@@ -155,3 +155,17 @@ def test_glimmer3_gpu_options_against_the_reference_run_here(gpu, tmp_path, opts
         assert res.returncode == 0, (opts, res.stderr.decode()[-2000:])
         out.append(open(str(tmp_path / tag) + ".predict", "rb").read())
     assert out[0] == out[1] and out[0].count(b">") == 999
+
+
+def test_glimmer3_gpu_on_the_nasty_fasta_file(gpu, tmp_path):
+    """junk before the first record, empty records, '>' inside lines, IUPAC letters, digits, CR LF, tabs: the headers and the filtered
+    sequences glimmer3 sees (Fasta_Read + tolower (Filter ())) come from gmg_fasta_ingest in glimmer3_gpu -- same .predict bytes"""
+    ref, dev = built_binary("oracle", "_ref", "glimmer3"), built_binary("integration", "_build", "glimmer3_gpu")
+    out = []
+    for exe, tag in ((ref, "a"), (dev, "b")):
+        # (default Min_Gene_Len: with -g 30 the reference itself never returns on this file)
+        res = subprocess.run([exe, "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, "nasty.fa"), str(tmp_path / tag)],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert res.returncode == 0, res.stderr.decode()[-2000:]
+        out.append(open(str(tmp_path / tag) + ".predict", "rb").read())
+    assert out[0] == out[1] and out[0].count(b">") >= 10
