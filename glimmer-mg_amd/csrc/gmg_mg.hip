@@ -123,6 +123,7 @@ struct MgArgs {
     uint64_t call_cap;           // entries per array
     struct MgOrfAgg *agg;        // [n_orfs] what the calls of an ORF add up to
     uint32_t *fill;              // [n_orfs] write pass: slots handed out inside the ORF's slice
+    uint32_t *acc_bits;          // [n_orfs / 32 + 1] bit i: ORF i is accepted (k_mg_err_verdict): what the write passes of levels 1 and 2 ask per call
     const double *walk;          // [6][walk_stride] Frame_Scores in walking order (k_mg_walk_tables), or, pfx: their running sums
                                  // inside every read (k_mg_walk_prefix)
     int pfx;                     // the level kernels take score[j] as a difference of two running sums and skip the codons nothing happens at
@@ -2146,6 +2147,7 @@ __global__ __launch_bounds__(256) void k_mg_err_prepare(MgArgs a)
         g.best = mg_ord(-DBL_MAX); g.ext_a = g.ext_b = fwd ? ~0ull : 0ull; g.cnt = 0; g.m0 = 0;
         a.agg[i] = g;
         a.fill[i] = 0;
+        if ((i & 31u) == 0) a.acc_bits[i >> 5] = 0;
     }
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += (uint64_t)gridDim.x * blockDim.x)
         a.read_fit[r] = a.read_off[r + 1] - a.read_off[r] < 2040;
@@ -2290,7 +2292,7 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                         else {
                             orf = c.orf; end_point = c.end_point; suffix_j = c.suffix_j; suffix_score = c.suffix_score; key = c.key; e0 = c.e0; e1 = c.e1;
                             off = (int64_t)c.off; n = c.n; fwd = (c.level >> 8) & 1;
-                            if (WRITE && accepted_only && !a.orfs[orf].accepted) active = false;
+                            if (WRITE && accepted_only && !((a.acc_bits[orf >> 5] >> (orf & 31u)) & 1u)) active = false;
                         }
                     }
                     if (active) {
@@ -2506,6 +2508,7 @@ __global__ __launch_bounds__(256) void k_mg_err_verdict(MgArgs a, const int acce
             }
         }
         a.orf_cnt[i] = (accepted_only && !rec.accepted) ? 0u : g.cnt;
+        if (rec.accepted) atomicOr(&a.acc_bits[i >> 5], 1u << (i & 31u));      // (one ORF in a hundred)
         rec.start_begin = 0;
         a.orfs[i] = rec;
     }
@@ -2879,7 +2882,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     uint8_t *d_qual = nullptr, *d_user_q = nullptr, *d_read_fit = nullptr;
     double *d_pen = nullptr;
     uint64_t *d_keys = nullptr;
-    uint32_t *d_err_flag = nullptr, *d_fill = nullptr;
+    uint32_t *d_err_flag = nullptr, *d_fill = nullptr, *d_acc_bits = nullptr;
     MgCall *d_calls[2] = {nullptr, nullptr};
     MgOrfAgg *d_agg = nullptr;
     double *d_walk = nullptr;
@@ -2907,6 +2910,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (d_keys) gmg_pool_release(d_keys);
         if (d_err_flag) gmg_pool_release(d_err_flag);
         if (d_fill) gmg_pool_release(d_fill);
+        if (d_acc_bits) gmg_pool_release(d_acc_bits);
         if (d_calls[0]) gmg_pool_release(d_calls[0]);
         if (d_calls[1]) gmg_pool_release(d_calls[1]);
         if (d_agg) gmg_pool_release(d_agg);
@@ -3277,6 +3281,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         MG_TRY(gmg_pool_alloc((void **)&d_calls[1], a.call_cap * sizeof(MgCall)));
         MG_TRY(gmg_pool_alloc((void **)&d_agg, no * sizeof(MgOrfAgg)));
         MG_TRY(gmg_pool_alloc((void **)&d_fill, no * 4));
+        MG_TRY(gmg_pool_alloc((void **)&d_acc_bits, (no / 32 + 1) * 4));
+        a.acc_bits = d_acc_bits;
         a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; a.agg = d_agg; a.fill = d_fill;
     }
     for (int attempt = 0; attempt < 3; attempt++) {
@@ -3522,6 +3528,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (d_keys) gmg_pool_release(d_keys);
     if (d_err_flag) gmg_pool_release(d_err_flag);
     if (d_fill) gmg_pool_release(d_fill);
+    if (d_acc_bits) gmg_pool_release(d_acc_bits);
     if (d_calls[0]) gmg_pool_release(d_calls[0]);
     if (d_calls[1]) gmg_pool_release(d_calls[1]);
     if (d_agg) gmg_pool_release(d_agg);
