@@ -1961,6 +1961,7 @@ __global__ __launch_bounds__(MG_ERR_BLOCK) void k_mg_err_flat(MgArgs a, const in
         }
         if (!WRITE) {
             a.orf_cnt[i] = (accepted_only && !o.accepted) ? 0u : R.count;
+            if (o.accepted && a.acc_bits) atomicOr(&a.acc_bits[i >> 5], 1u << (i & 31u));
             o.start_begin = 0;
         } else o.start_begin = (uint32_t)a.start_off[i];
         a.orfs[i] = o;
@@ -2274,7 +2275,9 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                     const uint64_t i = next + rank;
                     bool active = true;
                     suffix_j = 0; suffix_score = 0.0; key = 0; e0 = e1 = 0;
-                    if (LEVEL == 0) {
+                    if (LEVEL == 0 && WRITE && accepted_only && !((a.acc_bits[i >> 5] >> (i & 31u)) & 1u)) {
+                        active = false;                 // (not accepted, or a read of k_mg_err_flat: the record is not even loaded)
+                    } else if (LEVEL == 0) {
                         const gmg_mg_orf rec = a.orfs[i];
                         orf = (uint32_t)i; end_point = rec.frame > 0 ? rec.stop_position - 1 : rec.stop_position + 3;
                         fwd = rec.frame > 0;
@@ -2485,12 +2488,16 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
 }
 
 // Score_Orfs_Errors' verdict per ORF (:1647-1683) from what its calls added up to
-__global__ __launch_bounds__(256) void k_mg_err_verdict(MgArgs a, const int accepted_only)
+// accepted_only: only the accepted ORFs' records are ever read again (everything downstream asks the bitmap first), so an ORF
+// without starts (more than half of them) is settled from its 32-byte aggregate alone and a rejected one is not written back.
+// all_fit: no read is left to k_mg_err_flat (the usual case), so nothing here needs the record's read.
+__global__ __launch_bounds__(256) void k_mg_err_verdict(MgArgs a, const int accepted_only, const int all_fit)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x) {
-        gmg_mg_orf rec = a.orfs[i];
-        if (!a.read_fit[rec.read]) continue;
         const MgOrfAgg g = a.agg[i];
+        if (accepted_only && all_fit && g.cnt == 0) { a.orf_cnt[i] = 0; continue; }
+        gmg_mg_orf rec = a.orfs[i];
+        if (!all_fit && !a.read_fit[rec.read]) continue;
         const bool f = rec.frame > 0;
         const int m0 = (int)(g.m0 >> 1);
         if (f) { rec.hi = rec.stop_position - 1; rec.lo = rec.hi - m0; }
@@ -2509,16 +2516,21 @@ __global__ __launch_bounds__(256) void k_mg_err_verdict(MgArgs a, const int acce
         }
         a.orf_cnt[i] = (accepted_only && !rec.accepted) ? 0u : g.cnt;
         if (rec.accepted) atomicOr(&a.acc_bits[i >> 5], 1u << (i & 31u));      // (one ORF in a hundred)
+        if (accepted_only && !rec.accepted) continue;
         rec.start_begin = 0;
         a.orfs[i] = rec;
     }
 }
 
 // (after the scan) where each ORF's slice begins
-__global__ __launch_bounds__(256) void k_mg_err_begin(MgArgs a)
+// (accepted_only: the other ORFs' records never leave the GPU -- the bitmap of the accepted ones, set for the reads the level
+// kernels take, saves touching 99 % of the 56-byte records)
+__global__ __launch_bounds__(256) void k_mg_err_begin(MgArgs a, const int accepted_only)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x)
-        if (a.read_fit[a.orfs[i].read]) a.orfs[i].start_begin = (uint32_t)a.start_off[i];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (accepted_only ? !((a.acc_bits[i >> 5] >> (i & 31u)) & 1u) : !a.read_fit[a.orfs[i].read]) continue;
+        a.orfs[i].start_begin = (uint32_t)a.start_off[i];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_mg_seg_bounds(const gmg_mg_orf *orfs, uint64_t n, uint32_t *seg_begin, uint32_t *seg_end)
@@ -2545,7 +2557,9 @@ __global__ __launch_bounds__(256) void k_mg_permute_starts(const uint32_t *idx, 
 
 // (the accepted ORFs are one in a hundred in the error branch: a wave looks at 64 ORFs at a time, and all its lanes copy the list of each
 // accepted one together -- one lane per ORF copying its list entry by entry took 2.5 ms per 1M reads, five times this)
-__global__ __launch_bounds__(256) void k_mg_keep_gather_errs(const gmg_mg_orf *orfs, const gmg_start_errors *errs, const uint64_t *keys,
+// bits (may be NULL): bit i = ORF i is accepted (the error branch's bitmap): asked before a record is touched
+#define MG_KEPT(bits, orfs, i) ((bits) ? (((bits)[(i) >> 5] >> ((i) & 31u)) & 1u) != 0 : (orfs)[i].accepted != 0)
+__global__ __launch_bounds__(256) void k_mg_keep_gather_errs(const gmg_mg_orf *orfs, const uint32_t *bits, const gmg_start_errors *errs, const uint64_t *keys,
                                                              uint64_t n, const uint64_t *new_start, gmg_start_errors *out, uint64_t *keys_out)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -2555,7 +2569,7 @@ __global__ __launch_bounds__(256) void k_mg_keep_gather_errs(const gmg_mg_orf *o
         uint32_t b = 0, cnt = 0;
         uint64_t dst = 0;
         bool acc = false;
-        if (i < n && orfs[i].accepted) { acc = true; b = orfs[i].start_begin; cnt = orfs[i].n_starts; dst = new_start[i]; }
+        if (i < n && MG_KEPT(bits, orfs, i)) { acc = true; b = orfs[i].start_begin; cnt = orfs[i].n_starts; dst = new_start[i]; }
         for (uint64_t m = __ballot(acc); m; m &= m - 1) {
             const int src = __ffsll((long long)m) - 1;
             const uint32_t b_ = (uint32_t)__shfl((int)b, src), cnt_ = (uint32_t)__shfl((int)cnt, src);
@@ -2569,16 +2583,16 @@ __global__ __launch_bounds__(256) void k_mg_keep_gather_errs(const gmg_mg_orf *o
 }
 
 // GMG_MG_ACCEPTED_ONLY: keep the ORFs that go to Add_Events_* and their start lists, packed, in the same order
-__global__ __launch_bounds__(256) void k_mg_keep_counts(const gmg_mg_orf *orfs, uint64_t n, uint32_t *keep, uint32_t *keep_starts)
+__global__ __launch_bounds__(256) void k_mg_keep_counts(const gmg_mg_orf *orfs, const uint32_t *bits, uint64_t n, uint32_t *keep, uint32_t *keep_starts)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const bool k = orfs[i].accepted != 0;
+        const bool k = MG_KEPT(bits, orfs, i);
         keep[i] = k ? 1u : 0u;
         keep_starts[i] = k ? orfs[i].n_starts : 0u;
     }
 }
 
-__global__ __launch_bounds__(256) void k_mg_keep_gather(const gmg_mg_orf *orfs, const gmg_start *starts, uint64_t n,
+__global__ __launch_bounds__(256) void k_mg_keep_gather(const gmg_mg_orf *orfs, const uint32_t *bits, const gmg_start *starts, uint64_t n,
                                                         const uint64_t *new_orf, const uint64_t *new_start,
                                                         gmg_mg_orf *out_orfs, gmg_start *out_starts)
 {
@@ -2589,7 +2603,7 @@ __global__ __launch_bounds__(256) void k_mg_keep_gather(const gmg_mg_orf *orfs, 
         uint32_t b = 0, cnt = 0;
         uint64_t dst = 0;
         bool acc = false;
-        if (i < n && orfs[i].accepted) {
+        if (i < n && MG_KEPT(bits, orfs, i)) {
             gmg_mg_orf o = orfs[i];
             acc = true; b = o.start_begin; cnt = o.n_starts; dst = new_start[i];
             o.start_begin = (uint32_t)dst;
@@ -3295,7 +3309,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         else hipLaunchKernelGGL((k_mg_err_level<false, 1, false>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
         if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<false, 2, true>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
         else hipLaunchKernelGGL((k_mg_err_level<false, 2, false>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
-        hipLaunchKernelGGL(k_mg_err_verdict, dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only);
+        hipLaunchKernelGGL(k_mg_err_verdict, dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only, any_unfit ? 0 : 1);
         if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 1);
     } else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 0);
     else if (no && !a.count_starts) hipLaunchKernelGGL(k_mg_starts<false>, dim3(grid_for(no)), dim3(256), 0, s2, a);
@@ -3329,6 +3343,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             if (grown) { a.call_cap = want; a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; }
             else {
                 err_path = 1;
+                a.acc_bits = nullptr;                   // (the verdicts come from the per-ORF kernel from here on: no bitmap)
                 if (a.gene32 && !a.fs) {                // the per-ORF kernel walks the table itself: make it now
                     const uint64_t fstride = (a.total + 15) & ~15ull;
                     MG_TRY(gmg_pool_alloc((void **)&d_fs_own, (size_t)6 * fstride * sizeof(double)));
@@ -3364,7 +3379,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         MG_TRY(hipStreamWaitEvent(s, side_done, 0));
     }
     if (no && err_mode && err_path == 0) {
-        hipLaunchKernelGGL(k_mg_err_begin, dim3(grid_for(no)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_mg_err_begin, dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
         if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<true, 0, true>), dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
         else hipLaunchKernelGGL((k_mg_err_level<true, 0, false>), dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
         if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<true, 1, true>), lvl_grid, dim3(256), 0, s, a, err_acc_only);
@@ -3418,7 +3433,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (e == hipSuccess) e = hipMemsetAsync(d_keep_st + no, 0, 4, s);
         int rc2 = GMG_OK;
         if (e == hipSuccess) {
-            if (no) hipLaunchKernelGGL(k_mg_keep_counts, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, no, d_keep, d_keep_st);
+            // (error branch: the bitmap of the accepted ORFs is complete unless everything went to the per-ORF kernel)
+            const uint32_t *kept_bits = (err_mode && err_path == 0) ? d_acc_bits : nullptr;
+            if (no) hipLaunchKernelGGL(k_mg_keep_counts, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, kept_bits, no, d_keep, d_keep_st);
             rc2 = mg_scan(d_keep, d_new_orf, no, &n_keep, s);
             if (!rc2) rc2 = mg_scan(d_keep_st, d_new_st, no, &n_keep_st, s);
             if (!rc2) e = gmg_pool_alloc((void **)&d_orfs2, (n_keep ? n_keep : 1) * sizeof(gmg_mg_orf));
@@ -3426,9 +3443,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             if (!rc2 && e == hipSuccess && err_mode) e = gmg_pool_alloc((void **)&d_errs2, (n_keep_st ? n_keep_st : 1) * sizeof(gmg_start_errors));
             if (!rc2 && e == hipSuccess && d_keys) e = gmg_pool_alloc((void **)&d_keys2, (n_keep_st ? n_keep_st : 1) * 8);
             if (!rc2 && e == hipSuccess) {
-                if (no && err_mode) hipLaunchKernelGGL(k_mg_keep_gather_errs, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, res->d_errs, d_keys, no,
+                if (no && err_mode) hipLaunchKernelGGL(k_mg_keep_gather_errs, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, kept_bits, res->d_errs, d_keys, no,
                                                        d_new_st, d_errs2, d_keys2);
-                if (no) hipLaunchKernelGGL(k_mg_keep_gather, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, res->d_starts, no, d_new_orf,
+                if (no) hipLaunchKernelGGL(k_mg_keep_gather, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, kept_bits, res->d_starts, no, d_new_orf,
                                            d_new_st, d_orfs2, d_starts2);
                 hipLaunchKernelGGL(k_mg_keep_reads, dim3(grid_for(nr + 1)), dim3(256), 0, s, res->d_read_orf_off, nr, d_new_orf, d_new_first);
                 e = hipGetLastError();
