@@ -2555,40 +2555,15 @@ __global__ __launch_bounds__(256) void k_mg_permute_starts(const uint32_t *idx, 
     }
 }
 
-// (the accepted ORFs are one in a hundred in the error branch: a wave looks at 64 ORFs at a time, and all its lanes copy the list of each
-// accepted one together -- one lane per ORF copying its list entry by entry took 2.5 ms per 1M reads, five times this)
 // bits (may be NULL): bit i = ORF i is accepted (the error branch's bitmap): asked before a record is touched
 #define MG_KEPT(bits, orfs, i) ((bits) ? (((bits)[(i) >> 5] >> ((i) & 31u)) & 1u) != 0 : (orfs)[i].accepted != 0)
-__global__ __launch_bounds__(256) void k_mg_keep_gather_errs(const gmg_mg_orf *orfs, const uint32_t *bits, const gmg_start_errors *errs, const uint64_t *keys,
-                                                             uint64_t n, const uint64_t *new_start, gmg_start_errors *out, uint64_t *keys_out)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t base = wave * 64; base < n; base += n_waves * 64) {
-        const uint64_t i = base + lane;
-        uint32_t b = 0, cnt = 0;
-        uint64_t dst = 0;
-        bool acc = false;
-        if (i < n && MG_KEPT(bits, orfs, i)) { acc = true; b = orfs[i].start_begin; cnt = orfs[i].n_starts; dst = new_start[i]; }
-        for (uint64_t m = __ballot(acc); m; m &= m - 1) {
-            const int src = __ffsll((long long)m) - 1;
-            const uint32_t b_ = (uint32_t)__shfl((int)b, src), cnt_ = (uint32_t)__shfl((int)cnt, src);
-            const uint64_t dst_ = (uint64_t)(uint32_t)__shfl((int)(uint32_t)dst, src) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(dst >> 32), src) << 32;
-            for (uint32_t t = lane; t < cnt_; t += 64) {
-                out[dst_ + t] = errs[b_ + t];
-                if (keys) keys_out[dst_ + t] = keys[b_ + t];
-            }
-        }
-    }
-}
-
 // GMG_MG_ACCEPTED_ONLY: keep the ORFs that go to Add_Events_* and their start lists, packed, in the same order
 __global__ __launch_bounds__(256) void k_mg_keep_counts(const gmg_mg_orf *orfs, const uint32_t *bits, uint64_t n, uint32_t *keep, uint32_t *keep_starts)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const bool k = MG_KEPT(bits, orfs, i);
         keep[i] = k ? 1u : 0u;
-        keep_starts[i] = k ? orfs[i].n_starts : 0u;
+        if (keep_starts) keep_starts[i] = k ? orfs[i].n_starts : 0u;
     }
 }
 
@@ -2605,8 +2580,10 @@ __global__ __launch_bounds__(256) void k_mg_keep_gather(const gmg_mg_orf *orfs, 
         bool acc = false;
         if (i < n && MG_KEPT(bits, orfs, i)) {
             gmg_mg_orf o = orfs[i];
-            acc = true; b = o.start_begin; cnt = o.n_starts; dst = new_start[i];
-            o.start_begin = (uint32_t)dst;
+            if (new_start) {                            // (NULL: the start array is packed already -- the records alone move)
+                acc = true; b = o.start_begin; cnt = o.n_starts; dst = new_start[i];
+                o.start_begin = (uint32_t)dst;
+            }
             out_orfs[new_orf[i]] = o;
         }
         for (uint64_t m = __ballot(acc); m; m &= m - 1) {
@@ -3421,32 +3398,30 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         uint64_t *d_new_orf = nullptr, *d_new_st = nullptr, *d_new_first = nullptr;
         gmg_mg_orf *d_orfs2 = nullptr;
         gmg_start *d_starts2 = nullptr;
-        gmg_start_errors *d_errs2 = nullptr;
-        uint64_t *d_keys2 = nullptr;
         uint64_t n_keep = 0, n_keep_st = 0;
+        // Error branch: the write passes put an ORF's starts at the scan of the counts, and a rejected ORF counts 0 -- the start,
+        // error and key arrays hold the accepted ORFs' lists alone, in order: packed already.  Only the records move.
+        const bool starts_packed = err_mode != 0;
         hipError_t e = gmg_pool_alloc((void **)&d_keep, (no + 1) * 4);
-        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_keep_st, (no + 1) * 4);
+        if (e == hipSuccess && !starts_packed) e = gmg_pool_alloc((void **)&d_keep_st, (no + 1) * 4);
         if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_new_orf, (no + 1) * 8);
-        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_new_st, (no + 1) * 8);
+        if (e == hipSuccess && !starts_packed) e = gmg_pool_alloc((void **)&d_new_st, (no + 1) * 8);
         if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_new_first, (nr + 1) * 8);
         if (e == hipSuccess) e = hipMemsetAsync(d_keep + no, 0, 4, s);
-        if (e == hipSuccess) e = hipMemsetAsync(d_keep_st + no, 0, 4, s);
+        if (e == hipSuccess && !starts_packed) e = hipMemsetAsync(d_keep_st + no, 0, 4, s);
         int rc2 = GMG_OK;
         if (e == hipSuccess) {
             // (error branch: the bitmap of the accepted ORFs is complete unless everything went to the per-ORF kernel)
             const uint32_t *kept_bits = (err_mode && err_path == 0) ? d_acc_bits : nullptr;
             if (no) hipLaunchKernelGGL(k_mg_keep_counts, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, kept_bits, no, d_keep, d_keep_st);
             rc2 = mg_scan(d_keep, d_new_orf, no, &n_keep, s);
-            if (!rc2) rc2 = mg_scan(d_keep_st, d_new_st, no, &n_keep_st, s);
+            if (starts_packed) n_keep_st = res->n_starts;
+            else if (!rc2) rc2 = mg_scan(d_keep_st, d_new_st, no, &n_keep_st, s);
             if (!rc2) e = gmg_pool_alloc((void **)&d_orfs2, (n_keep ? n_keep : 1) * sizeof(gmg_mg_orf));
-            if (!rc2 && e == hipSuccess) e = gmg_pool_alloc((void **)&d_starts2, (n_keep_st ? n_keep_st : 1) * sizeof(gmg_start));
-            if (!rc2 && e == hipSuccess && err_mode) e = gmg_pool_alloc((void **)&d_errs2, (n_keep_st ? n_keep_st : 1) * sizeof(gmg_start_errors));
-            if (!rc2 && e == hipSuccess && d_keys) e = gmg_pool_alloc((void **)&d_keys2, (n_keep_st ? n_keep_st : 1) * 8);
+            if (!rc2 && e == hipSuccess && !starts_packed) e = gmg_pool_alloc((void **)&d_starts2, (n_keep_st ? n_keep_st : 1) * sizeof(gmg_start));
             if (!rc2 && e == hipSuccess) {
-                if (no && err_mode) hipLaunchKernelGGL(k_mg_keep_gather_errs, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, kept_bits, res->d_errs, d_keys, no,
-                                                       d_new_st, d_errs2, d_keys2);
                 if (no) hipLaunchKernelGGL(k_mg_keep_gather, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, kept_bits, res->d_starts, no, d_new_orf,
-                                           d_new_st, d_orfs2, d_starts2);
+                                           starts_packed ? (const uint64_t *)nullptr : d_new_st, d_orfs2, d_starts2);
                 hipLaunchKernelGGL(k_mg_keep_reads, dim3(grid_for(nr + 1)), dim3(256), 0, s, res->d_read_orf_off, nr, d_new_orf, d_new_first);
                 e = hipGetLastError();
                 if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -3459,19 +3434,13 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (rc2 || e != hipSuccess) {
             if (d_orfs2) gmg_pool_release(d_orfs2);
             if (d_starts2) gmg_pool_release(d_starts2);
-            if (d_errs2) gmg_pool_release(d_errs2);
-            if (d_keys2) gmg_pool_release(d_keys2);
             if (d_new_first) gmg_pool_release(d_new_first);
             return fail(rc2 ? rc2 : gmg_set_error(GMG_EHIP, "gmg_mg_score_reads: packing the accepted ORFs: %s", hipGetErrorString(e)));
         }
         gmg_pool_release(res->d_orfs);
-        gmg_pool_release(res->d_starts);
         gmg_pool_release(res->d_read_orf_off);
-        if (res->d_errs) gmg_pool_release(res->d_errs);
-        res->d_errs = d_errs2;
-        if (d_keys) { gmg_pool_release(d_keys); d_keys = d_keys2; }
+        if (!starts_packed) { gmg_pool_release(res->d_starts); res->d_starts = d_starts2; }     // (else: starts, errors and keys stay where they are)
         res->d_orfs = d_orfs2;
-        res->d_starts = d_starts2;
         res->d_read_orf_off = d_new_first;
         res->n_orfs = n_keep;
         res->n_starts = n_keep_st;
