@@ -48,16 +48,13 @@ struct gmg_mg_result {
     uint64_t n_reads, n_orfs, n_starts;
 };
 
-struct MgCall {                  // one Score_Orf_Starts call waiting to be walked (56 bytes)
-    double suffix_score;
-    uint64_t key;                // order of its starts among the ORF's: the fields of the levels above it
-    uint64_t off;                // its read: first base and length (so that taking a call is ONE load, not a chain of three)
-    uint32_t orf;
-    int32_t end_point, suffix_j, n;
-    uint32_t e0, e1;             // Error_t entries of the path: (pos + 8) << 2 | type
-    uint32_t level;              // 0: empty entry; else level | forward strand << 8
-    uint32_t pad;
-};
+// One Score_Orf_Starts call waiting to be walked, 32 bytes (the count passes write and read 100 M + 77 M of them per 1 M reads
+// with -i: as 56-byte structs with one field per value they were 30 GB of the call's traffic).  Reads of the level kernels are
+// shorter than 2,040 bases, so every position fits 12 bits:
+//   w[0] suffix_score;  w[1] key (39 bits: three 13-bit fields) | (end_point + 8) << 40 | suffix_j << 52;
+//   w[2] the read's first base (40 bits) | its length << 40 | (level | forward strand << 2) << 51  -- 0: an empty entry;
+//   w[3] orf | e0 << 32 | e1 << 46   (Error_t entries of the path: (pos + 8) << 2 | type, 14 bits each)
+struct __attribute__((aligned(16))) MgCall { unsigned long long w[4]; };
 struct MgOrfAgg { unsigned long long best, ext_a, ext_b; uint32_t cnt, m0; };
 
 struct MgTile { uint64_t w0; uint32_t first, nfit, span, pad; };   // reads [first, first + nfit), bases [w0, w0 + span)
@@ -2291,10 +2288,12 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                         if (!WRITE && accepted_only && (fwd ? end_point : n - end_point + 1) + 12 < a.min_gene_len) active = false;
                     } else {
                         const MgCall c = a.calls[LEVEL - 1][i];
-                        if (c.level == 0) active = false;                       // the unused end of a wave's chunk
+                        if ((c.w[2] >> 51) == 0) active = false;                // the unused end of a wave's chunk
                         else {
-                            orf = c.orf; end_point = c.end_point; suffix_j = c.suffix_j; suffix_score = c.suffix_score; key = c.key; e0 = c.e0; e1 = c.e1;
-                            off = (int64_t)c.off; n = c.n; fwd = (c.level >> 8) & 1;
+                            suffix_score = __longlong_as_double((long long)c.w[0]);
+                            key = c.w[1] & 0xffffffffffull; end_point = (int)((c.w[1] >> 40) & 0xfffu) - 8; suffix_j = (int)(c.w[1] >> 52);
+                            off = (int64_t)(c.w[2] & 0xffffffffffull); n = (int)((c.w[2] >> 40) & 0x7ffu); fwd = (c.w[2] >> 53) & 1;
+                            orf = (uint32_t)c.w[3]; e0 = (uint32_t)(c.w[3] >> 32) & 0x3fffu; e1 = (uint32_t)(c.w[3] >> 46) & 0x3fffu;
                             if (WRITE && accepted_only && !((a.acc_bits[orf >> 5] >> (orf & 31u)) & 1u)) active = false;
                         }
                     }
@@ -2457,7 +2456,7 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                     const uint32_t np = __popcll(pm);
                     if (chunk_used + np > MG_CALL_CHUNK) {
                         for (uint32_t x = chunk_used + lane; x < MG_CALL_CHUNK; x += 64)
-                            if (chunk_base + x < a.call_cap) a.calls[LEVEL][chunk_base + x].level = 0;
+                            if (chunk_base + x < a.call_cap) a.calls[LEVEL][chunk_base + x].w[2] = 0;
                         unsigned long long base = 0;
                         if (lane == 0) base = atomicAdd(&a.n_calls[LEVEL], (unsigned long long)MG_CALL_CHUNK);
                         chunk_base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base) |
@@ -2469,10 +2468,11 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                         const uint64_t slot = chunk_base + chunk_used + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
                         if (slot < a.call_cap) {
                             MgCall child;
-                            child.suffix_score = c_score; child.end_point = c_end; child.suffix_j = c_sj;
-                            child.key = key | (uint64_t)c_field << (26 - 13 * LEVEL);
-                            child.e0 = LEVEL == 0 ? c_err : e0; child.e1 = LEVEL == 1 ? c_err : 0;
-                            child.orf = orf; child.level = (uint32_t)(LEVEL + 1) | (fwd ? 256u : 0u); child.off = (uint64_t)off; child.n = n; child.pad = 0;
+                            const uint32_t ce0 = LEVEL == 0 ? c_err : e0, ce1 = LEVEL == 1 ? c_err : 0u;
+                            child.w[0] = (unsigned long long)__double_as_longlong(c_score);
+                            child.w[1] = (key | (uint64_t)c_field << (26 - 13 * LEVEL)) | (uint64_t)(uint32_t)(c_end + 8) << 40 | (uint64_t)(uint32_t)c_sj << 52;
+                            child.w[2] = (uint64_t)off | (uint64_t)(uint32_t)n << 40 | (uint64_t)((uint32_t)(LEVEL + 1) | (fwd ? 4u : 0u)) << 51;
+                            child.w[3] = (uint64_t)orf | (uint64_t)ce0 << 32 | (uint64_t)ce1 << 46;
                             a.calls[LEVEL][slot] = child;
                         }
                     }
@@ -2484,7 +2484,7 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
     }
     if (LEVEL < 2 && !WRITE)                            // give the rest of the last chunk back as empty entries
         for (uint32_t x = chunk_used + lane; x < MG_CALL_CHUNK; x += 64)
-            if (chunk_base + x < a.call_cap) a.calls[LEVEL][chunk_base + x].level = 0;
+            if (chunk_base + x < a.call_cap) a.calls[LEVEL][chunk_base + x].w[2] = 0;
 }
 
 // Score_Orfs_Errors' verdict per ORF (:1647-1683) from what its calls added up to
