@@ -2137,16 +2137,10 @@ __global__ __launch_bounds__(256) void k_mg_run_tables(MgArgs a, uint8_t *run_q,
     }
 }
 
+// (the ORFs' aggregates are initialised by the level-0 count pass as it takes them -- it has the record in hand; the slot
+// counters and the bitmap of the accepted ORFs are zeroed by memsets)
 __global__ __launch_bounds__(256) void k_mg_err_prepare(MgArgs a)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_orfs; i += (uint64_t)gridDim.x * blockDim.x) {
-        const bool fwd = a.orfs[i].frame > 0;
-        MgOrfAgg g;
-        g.best = mg_ord(-DBL_MAX); g.ext_a = g.ext_b = fwd ? ~0ull : 0ull; g.cnt = 0; g.m0 = 0;
-        a.agg[i] = g;
-        a.fill[i] = 0;
-        if ((i & 31u) == 0) a.acc_bits[i >> 5] = 0;
-    }
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += (uint64_t)gridDim.x * blockDim.x)
         a.read_fit[r] = a.read_off[r + 1] - a.read_off[r] < 2040;
 }
@@ -2278,6 +2272,11 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                         const gmg_mg_orf rec = a.orfs[i];
                         orf = (uint32_t)i; end_point = rec.frame > 0 ? rec.stop_position - 1 : rec.stop_position + 3;
                         fwd = rec.frame > 0;
+                        if (!WRITE) {                   // what the calls of this ORF will be merged into (every ORF is taken by exactly one lane)
+                            MgOrfAgg g0;
+                            g0.best = mg_ord(-DBL_MAX); g0.ext_a = g0.ext_b = fwd ? ~0ull : 0ull; g0.cnt = 0; g0.m0 = 0;
+                            a.agg[i] = g0;
+                        }
                         if (!a.read_fit[rec.read]) active = false;              // k_mg_err_flat has the read
                         if (WRITE && accepted_only && !rec.accepted) active = false;
                         off = (int64_t)a.read_off[rec.read];
@@ -3279,7 +3278,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     for (int attempt = 0; attempt < 3; attempt++) {
     const dim3 lvl_grid(256 * 16);
     if (no && err_mode && err_path == 0) {
-        hipLaunchKernelGGL(k_mg_err_prepare, dim3(grid_for(no > nr ? no : nr)), dim3(256), 0, s2, a);
+        MG_TRY(hipMemsetAsync(d_fill, 0, no * 4, s2));
+        MG_TRY(hipMemsetAsync(d_acc_bits, 0, (no / 32 + 1) * 4, s2));
+        hipLaunchKernelGGL(k_mg_err_prepare, dim3(grid_for(nr)), dim3(256), 0, s2, a);
         if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<false, 0, true>), dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only);
         else hipLaunchKernelGGL((k_mg_err_level<false, 0, false>), dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only);
         if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<false, 1, true>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
