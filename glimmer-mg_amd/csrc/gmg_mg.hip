@@ -2145,10 +2145,15 @@ __global__ __launch_bounds__(256) void k_mg_err_prepare(MgArgs a)
         a.read_fit[r] = a.read_off[r + 1] - a.read_off[r] < 2040;
 }
 
+#ifndef MG_CALL_CHUNK
 #define MG_CALL_CHUNK 256
+#endif
 // calls a wave works through before it asks for more (count pass per 1M reads: 64: 79 ms, 128: 62, 256: 59, 512: 61, 2048: 71,
 // 8192: 84 -- small tiles keep a wave's lanes on neighbouring reads; the write pass skips most calls and wants fewer atomics: 8 ms at 2048, 12 at 256)
-#define MG_LEVEL_TILE (WRITE ? 2048 : 256)
+#ifndef MG_COUNT_TILE
+#define MG_COUNT_TILE 512        // (count passes, 32-byte calls: 128: 56.9 ms per 1M reads with -i, 256: 51.3, 512: 50.6, 768: 50.6, 1024: 51.6, 2048: 52.3)
+#endif
+#define MG_LEVEL_TILE (WRITE ? 2048 : MG_COUNT_TILE)
 #ifndef MG_LEVEL_BATCH
 #define MG_LEVEL_BATCH 32        // lanes that wait before the wave runs the take / finish code (count pass per 1M reads: 4: 64 ms, 8: 61, 16: 60, 24 - 48: 58)
 #endif
@@ -2446,6 +2451,9 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                     else { atomicMax(&g2->ext_a, pa); atomicMax(&g2->ext_b, pb); }
                 }
             }
+            // a call that cannot reach Min_Gene_Len before its read ends emits nothing (a start needs j + 3 + suffix_j >= Min_Gene_Len),
+            // nor can a branch of it: it is not handed on
+            if (LEVEL < 2 && !WRITE && want_push && c_sj + (fwd ? c_end : n - c_end + 1) + 12 < mgl) want_push = false;
             if (LEVEL < 2 && !WRITE) {
                 // the branches of this trip go to the next level's array.  The wave owns a chunk of MG_CALL_CHUNK entries at a time
                 // (ONE atomic on the shared counter per chunk -- one per trip made the counter the bottleneck: 73 -> 9 ms); what is
