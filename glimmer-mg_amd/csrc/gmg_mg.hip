@@ -2111,9 +2111,14 @@ __global__ __launch_bounds__(256) void k_mg_run_tables(MgArgs a, uint8_t *run_q,
         const uint8_t *qp = a.err_mode == 1 ? (fwd ? a.walk_q + w_first : a.qual + off) : nullptr;  // quality of walk step t: qp[t]
         uint8_t *oq = run_q + (fwd ? 0 : a.walk_stride) + w_first, *on = run_n + (fwd ? 0 : a.walk_stride) + w_first;
         uint32_t cq[3] = {0, 0, 0}, cn[3] = {0, 0, 0};
+        uint64_t lq_next = 0;                           // "quality at or below the threshold" of the chunk behind (its steps 0 and 1 count here)
         for (int t0 = (n - 1) / 64 * 64; t0 >= 0; t0 -= 64) {
             const int t = t0 + (int)lane;
-            bool bn = false, bq = false;
+            bool bn = false;
+            // one quality per lane; a codon's three positions are this lane's bit and the two above it in the wave's mask
+            const uint64_t lq = __ballot(qp && t < n && qp[t] <= a.indel_q_thr);
+            const uint64_t low3 = lq | (lq >> 1 | lq_next << 63) | (lq >> 2 | lq_next << 62);
+            lq_next = lq;
             if (t + 5 <= n - 1) {                       // (the codon after this one is there)
                 // the six bases of walk steps t .. t + 5: forward strand bases g, g-1, .., g-5, reverse strand g, g+1, .., g+5 complemented
                 const int64_t g = fwd ? off + n - 1 - t : off + t, gs = fwd ? g - 5 : g;
@@ -2124,9 +2129,8 @@ __global__ __launch_bounds__(256) void k_mg_run_tables(MgArgs a, uint8_t *run_q,
                 const uint32_t idx = fwd ? (hi6 & 3u) << 4 | (hi6 & 12u) | hi6 >> 4 : lo6 ^ 63u;
                 const uint32_t nidx = fwd ? (lo6 & 3u) << 4 | (lo6 & 12u) | lo6 >> 4 : hi6 ^ 63u;
                 bn = s_which[idx] < 0 && !((a.fwd_stop >> nidx) & 1ull);
-                bq = bn && !(qp && (qp[t] <= a.indel_q_thr || qp[t + 1] <= a.indel_q_thr || qp[t + 2] <= a.indel_q_thr));
             }
-            const uint64_t mn = __ballot(bn), mq = __ballot(bq);
+            const uint64_t mn = __ballot(bn), mq = mn & ~low3;
             const uint32_t vn = mg_run_len(mn, lane, cn), vq = mg_run_len(mq, lane, cq);
             if (t < n) { on[t] = (uint8_t)vn; oq[t] = (uint8_t)vq; }
 #pragma unroll
