@@ -2067,7 +2067,8 @@ __global__ __launch_bounds__(256) void k_mg_walk_prefix(MgArgs a, double *walk)
                 const int row = ((fwd ? c - m + 3 : m - c + 3) % 3 + 1) % 3;          // as k_mg_walk_tables
                 const double x = row == 0 ? v[0] : row == 1 ? v[1] : v[2];
                 const double sc = mg_wave_scan(x) + carry[c];
-                if (in) walk[(uint64_t)((fwd ? 0 : 3) + c) * a.walk_stride + w] = sc;
+                // (streaming stores: 19 GB written once -- they leave the L2 to the run-length kernel beside this one; -0.7 ms per call)
+                if (in) __builtin_nontemporal_store(sc, walk + (uint64_t)((fwd ? 0 : 3) + c) * a.walk_stride + w);
                 const unsigned long long top = (unsigned long long)__double_as_longlong(sc);
                 carry[c] = __longlong_as_double((long long)((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(top >> 32), 63) << 32 |
                                                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)top, 63)));
