@@ -2546,6 +2546,8 @@ __global__ __launch_bounds__(256) void k_mg_err_begin(MgArgs a, const int accept
     }
 }
 
+#include "gmg_mg_errtile.h"
+
 __global__ __launch_bounds__(256) void k_mg_seg_bounds(const gmg_mg_orf *orfs, uint64_t n, uint32_t *seg_begin, uint32_t *seg_end)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -2877,6 +2879,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     double *d_cum = nullptr;
     int fused_nw = 0, fused_el = 9;                     // waves per tile of k_mg_tile_starts (0: the sequential kernels), elements per lane
     bool err_exact = false;                             // the batch's sums are exact in any order: the error branch may take differences of running sums
+    bool err_tile = false;                              // ... and runs tile by tile with the sums in LDS (k_mg_err_tile)
     uint8_t *d_run = nullptr;
     bool fused_rest = false;
     MgTile *d_tiles = nullptr, *d_all = nullptr;
@@ -2891,6 +2894,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     MgOrfAgg *d_agg = nullptr;
     double *d_walk = nullptr;
     uint8_t *d_walk_q = nullptr;
+    MgTile *d_et_tiles = nullptr;                       // the error branch tile by tile (k_mg_err_tile)
+    uint8_t *d_et_kept = nullptr;
+    MgCall *d_et_slabs = nullptr;
     int rc = GMG_OK;
     auto fail = [&](int code) {
         (void)hipDeviceSynchronize();                   // nothing (either stream) may still use the blocks that go back to the cache
@@ -2921,6 +2927,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (d_walk) gmg_pool_release(d_walk);
         if (d_walk_q) gmg_pool_release(d_walk_q);
         if (d_run) gmg_pool_release(d_run);
+        if (d_et_tiles) gmg_pool_release(d_et_tiles);
+        if (d_et_kept) gmg_pool_release(d_et_kept);
+        if (d_et_slabs) gmg_pool_release(d_et_slabs);
         gmg_mg_result_free(res);
         return code;
     };
@@ -3024,8 +3033,12 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     // gene rows as fp32 (GENE32) then save the 48 B/base table's write and half of what the sums' kernel reads.  Not with reads the
     // level kernels cannot take (>= 2040 bases: k_mg_err_flat walks the table) or a forced per-ORF path; a call-array overflow
     // builds the table then (k_mg_apply_nulls) before it falls back.
+    // the error branch tile by tile (k_mg_err_tile: the running sums in LDS) wants what the running-sum form wants; reads longer than
+    // half a tile go to k_mg_err_flat, which walks the fp64 table
+    err_tile = err_mode && err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) && gmg_opt(GMG_OPT_MG_ERR_TILE) && !gmg_opt(GMG_OPT_MG_ERR_FLAT);
+    const uint64_t err_fit_len = err_tile ? MG_ET_CAP / 2 + 1 : 2040;       // reads shorter than this are walked by the tile / level kernels
     const bool err_g32 = err_mode && !d_frame_scores && a.total && g32_opt != 0 && nul_dense3 && all_fast && err_exact &&
-                         gmg_opt(GMG_OPT_MG_ERR_SKIP) && !gmg_opt(GMG_OPT_MG_ERR_FLAT) && reads->max_len && reads->max_len < 2040;
+                         gmg_opt(GMG_OPT_MG_ERR_SKIP) && !gmg_opt(GMG_OPT_MG_ERR_FLAT) && reads->max_len && reads->max_len < err_fit_len;
     const bool g32 = err_g32 || (!d_frame_scores && !err_mode && a.total &&
                      (g32_opt == 2 || (g32_opt == 1 && (prm->nulls || fused_nw >= 2))) && nul_dense3 &&
                      (all_fast || (groups && groups->n > 0)));
@@ -3238,23 +3251,31 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     // error branch, level by level: 0 (k_mg_err_level; the default), 1 = one lane per ORF with an explicit stack
     // (k_mg_err_flat: exact slots; the fallback of 0, and on its own with GMG_MG_ERR_FLAT=1 for A/B runs and cross-checks)
     int err_path = gmg_opt(GMG_OPT_MG_ERR_FLAT) ? 1 : 0;
+    // the walk-order rows of the level kernels (running sums, or the values themselves): behind the six-frame table on stream st
+    auto build_walk_rows = [&](hipStream_t st) -> hipError_t {
+        hipError_t e = gmg_pool_alloc((void **)&d_walk, ((size_t)6 * a.walk_stride + 8) * sizeof(double));
+        if (e != hipSuccess) return e;
+        if (a.pfx) {
+            if (a.gene32) hipLaunchKernelGGL(k_mg_walk_prefix<true>, dim3(grid_for(2 * nr * 64)), dim3(256), 0, st, a, d_walk + 8);
+            else hipLaunchKernelGGL(k_mg_walk_prefix<false>, dim3(grid_for(2 * nr * 64)), dim3(256), 0, st, a, d_walk + 8);
+        } else
+            hipLaunchKernelGGL(k_mg_walk_tables, dim3(grid_for(a.total)), dim3(256), 0, st, a, d_walk + 8);
+        a.walk = d_walk + 8;                            // (8 spare entries in front: a call at the table's first entry looks one back)
+        return hipGetLastError();
+    };
     if (!find_only && res->n_orfs && err_mode && err_path == 0) {
         // the walk-order tables: the rows (running sums) need the six-frame table and go behind it on the caller's stream; the run
         // lengths need the reads and the qualities only and follow the quality kernel on a stream of their own, beside the ORF scan
-        // (second stream), the six-frame kernel and the rows
+        // (second stream), the six-frame kernel and the rows.  Tile by tile (k_mg_err_tile) the rows are built in LDS, tile by tile.
         a.walk_stride = ((a.total + 15) & ~15ull) + 16;
-        MG_TRY(gmg_pool_alloc((void **)&d_walk, ((size_t)6 * a.walk_stride + 8) * sizeof(double)));
         a.pfx = err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) ? 1 : 0;
         if (a.pfx) {                                    // running sums + run lengths: the walks visit their events only
             MG_TRY(gmg_pool_alloc((void **)&d_run, (size_t)4 * a.walk_stride));
-            if (a.gene32) hipLaunchKernelGGL(k_mg_walk_prefix<true>, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s, a, d_walk + 8);
-            else hipLaunchKernelGGL(k_mg_walk_prefix<false>, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s, a, d_walk + 8);
             a.run_q = d_run; a.run_n = d_run + 2 * a.walk_stride;
             hipLaunchKernelGGL(k_mg_run_tables, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s3, a, d_run, d_run + 2 * a.walk_stride);
-        } else
-            hipLaunchKernelGGL(k_mg_walk_tables, dim3(grid_for(a.total)), dim3(256), 0, s, a, d_walk + 8);
+        }
+        if (!err_tile) MG_TRY(build_walk_rows(s));
         MG_TRY(hipGetLastError());
-        a.walk = d_walk + 8;                            // (8 spare entries in front: a call at the table's first entry looks one back)
         tm.lap("walk-order tables");
     }
     if (err_mode && s2 != s) {                          // the error branch needs the six-frame table from here on: one stream again
@@ -3270,28 +3291,70 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (!find_only) {
     MG_TRY(gmg_pool_alloc((void **)&d_start_off, (no + 1) * 8));
     const int err_acc_only = (prm->flags & GMG_MG_ACCEPTED_ONLY) ? 1 : 0;
-    const bool any_unfit = reads->max_len >= 2040;
+    // the level kernels' scratch: call arrays, per-ORF aggregates, slot counters
+    auto alloc_level_scratch = [&]() -> hipError_t {
+        a.call_cap = a.total / 2 > 65536 ? a.total / 2 : 65536;
+        if (gmg_opt(GMG_OPT_MG_ERR_CALLS) > 0) a.call_cap = (uint64_t)gmg_opt(GMG_OPT_MG_ERR_CALLS);     // (tests: force the fallback)
+        hipError_t e = gmg_pool_alloc((void **)&d_calls[0], a.call_cap * sizeof(MgCall));
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_calls[1], a.call_cap * sizeof(MgCall));
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_agg, no * sizeof(MgOrfAgg));
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_fill, no * 4);
+        a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; a.agg = d_agg; a.fill = d_fill;
+        return e;
+    };
+    // k_mg_err_tile: work-groups (two per CU: 68 KB of LDS each), their call slabs, the tile list
+    unsigned et_grid = 0;
+    uint32_t et_qcap = gmg_opt(GMG_OPT_MG_ERR_TILE_Q) > 0 ? (uint32_t)gmg_opt(GMG_OPT_MG_ERR_TILE_Q) : (uint32_t)ET_QCAP;
+    uint32_t *d_et_ntiles = nullptr;
+    unsigned long long *d_et_items = nullptr;
     if (res->n_orfs && err_mode && err_path == 0) {
         MG_TRY(gmg_pool_alloc((void **)&d_read_fit, nr ? nr : 1));
-        MG_TRY(gmg_pool_alloc((void **)&d_err_flag, 80));           // the flag + the two call counters + six tile counters
-        MG_TRY(hipMemsetAsync(d_err_flag, 0, 80, s2));
+        MG_TRY(gmg_pool_alloc((void **)&d_err_flag, 128));          // the flag + the two call counters + six tile counters; tile path: + the number of tiles, two item counters
+        MG_TRY(hipMemsetAsync(d_err_flag, 0, 128, s2));
         a.read_fit = d_read_fit;
         a.err_flag = d_err_flag;
         a.n_calls = (unsigned long long *)(d_err_flag + 2);
         a.tile_ctr = (unsigned long long *)(d_err_flag + 6);
-        a.call_cap = a.total / 2 > 65536 ? a.total / 2 : 65536;
-        if (gmg_opt(GMG_OPT_MG_ERR_CALLS) > 0) a.call_cap = (uint64_t)gmg_opt(GMG_OPT_MG_ERR_CALLS);     // (tests: force the fallback)
-        MG_TRY(gmg_pool_alloc((void **)&d_calls[0], a.call_cap * sizeof(MgCall)));
-        MG_TRY(gmg_pool_alloc((void **)&d_calls[1], a.call_cap * sizeof(MgCall)));
-        MG_TRY(gmg_pool_alloc((void **)&d_agg, no * sizeof(MgOrfAgg)));
-        MG_TRY(gmg_pool_alloc((void **)&d_fill, no * 4));
+        d_et_ntiles = d_err_flag + 18;
+        d_et_items = (unsigned long long *)(d_err_flag + 20);
         MG_TRY(gmg_pool_alloc((void **)&d_acc_bits, (no / 32 + 1) * 4));
         a.acc_bits = d_acc_bits;
-        a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; a.agg = d_agg; a.fill = d_fill;
+        if (err_tile) {
+            int n_cu = 0;
+            MG_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id));
+            et_grid = (unsigned)(n_cu > 0 ? 2 * n_cu : 512);
+            MG_TRY(gmg_pool_alloc((void **)&d_et_tiles, (nr + 1) * sizeof(MgTile)));
+            MG_TRY(gmg_pool_alloc((void **)&d_et_kept, 2 * (nr + 1)));
+            MG_TRY(gmg_pool_alloc((void **)&d_et_slabs, (size_t)et_grid * 2 * et_qcap * sizeof(MgCall)));
+        } else MG_TRY(alloc_level_scratch());
     }
-    for (int attempt = 0; attempt < 3; attempt++) {
+    const size_t et_lds = sizeof(EtLds<MG_ET_CAP>);
+    auto launch_err_tile = [&](bool write, hipStream_t st, int acc_only) -> hipError_t {
+#define MG_ET_LAUNCH(W_, G_)                                                                                                     \
+        do {                                                                                                                     \
+            hipError_t e_ = hipFuncSetAttribute((const void *)k_mg_err_tile<W_, G_, MG_ET_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)et_lds); \
+            if (e_ != hipSuccess) return e_;                                                                                     \
+            hipLaunchKernelGGL((k_mg_err_tile<W_, G_, MG_ET_CAP>), dim3(et_grid), dim3(ET_BLOCK), et_lds, st, a, d_et_tiles, d_et_ntiles, \
+                               d_et_items + (W_ ? 1 : 0), d_et_kept, d_et_slabs, et_qcap, acc_only);                            \
+        } while (0)
+        if (write) { if (a.gene32) MG_ET_LAUNCH(true, true); else MG_ET_LAUNCH(true, false); }
+        else { if (a.gene32) MG_ET_LAUNCH(false, true); else MG_ET_LAUNCH(false, false); }
+#undef MG_ET_LAUNCH
+        return hipGetLastError();
+    };
+    int level_tries = 0;
+    for (int attempt = 0; attempt < 4; attempt++) {
     const dim3 lvl_grid(256 * 16);
-    if (no && err_mode && err_path == 0) {
+    const bool any_unfit = reads->max_len >= (err_tile ? (uint64_t)MG_ET_CAP / 2 + 1 : 2040);
+    if (no && err_mode && err_path == 0 && err_tile) {
+        MG_TRY(hipMemsetAsync(d_acc_bits, 0, (no / 32 + 1) * 4, s2));
+        MG_TRY(hipMemsetAsync(d_et_kept, 0, 2 * (nr + 1), s2));
+        const uint64_t chunk = (uint64_t)ET_CHUNK_TILES * MG_ET_CAP, n_chunks = a.total / chunk + 1;
+        hipLaunchKernelGGL(k_et_tiles, dim3(grid_for(n_chunks)), dim3(256), 0, s2, a, (uint32_t)MG_ET_CAP, (uint32_t)(MG_ET_CAP / 2), chunk, n_chunks,
+                           d_et_tiles, d_et_ntiles, d_read_fit);
+        MG_TRY(launch_err_tile(false, s2, err_acc_only));
+        if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 1);
+    } else if (no && err_mode && err_path == 0) {
         MG_TRY(hipMemsetAsync(d_fill, 0, no * 4, s2));
         MG_TRY(hipMemsetAsync(d_acc_bits, 0, (no / 32 + 1) * 4, s2));
         hipLaunchKernelGGL(k_mg_err_prepare, dim3(grid_for(nr)), dim3(256), 0, s2, a);
@@ -3310,13 +3373,23 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     rc = mg_scan(d_orf_cnt, d_start_off, no, &res->n_starts, s2);
     if (rc) return fail(rc);
     if (no && err_mode && err_path == 0) {              // did a call array overflow?  (mg_scan has synchronised the stream)
-        uint32_t st[20];
-        MG_TRY(hipMemcpy(st, d_err_flag, 80, hipMemcpyDeviceToHost));
-        if (tm.on) {                                    // (mg_timing) how many calls the levels handed on
+        uint32_t st[32];
+        MG_TRY(hipMemcpy(st, d_err_flag, 128, hipMemcpyDeviceToHost));
+        if (tm.on && err_tile) fprintf(stderr, "[gmg_mg] k_mg_err_tile: %u tiles (%llu ORFs)\n", st[18], (unsigned long long)no);
+        if (tm.on && !err_tile) {                       // (mg_timing) how many calls the levels handed on
             unsigned long long handed[2];
             memcpy(handed, st + 2, 16);
             fprintf(stderr, "[gmg_mg] calls handed to level 1: %llu, to level 2: %llu (capacity %llu each; %llu ORFs)\n", handed[0], handed[1],
                     (unsigned long long)a.call_cap, (unsigned long long)no);
+        }
+        if (st[0] && err_tile) {
+            // a work-group's call slab was full: the batch repeats on the level kernels (their call arrays grow with the batch)
+            err_tile = false;
+            MG_TRY(build_walk_rows(s2));
+            MG_TRY(alloc_level_scratch());
+            MG_TRY(hipMemsetAsync(d_err_flag, 0, 128, s2));
+            MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
+            continue;
         }
         if (st[0]) {
             // once more with arrays of twice what was asked for (level 2 is only partly known when level 1 overflows); if that is
@@ -3326,7 +3399,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             const uint64_t want = 2 * (asked[0] > asked[1] ? asked[0] : asked[1]) + 65536;
             gmg_pool_release(d_calls[0]); gmg_pool_release(d_calls[1]);
             d_calls[0] = d_calls[1] = nullptr;
-            const bool may_grow = attempt == 0 && want <= 8 * a.total + 65536 && (gmg_opt(GMG_OPT_MG_ERR_CALLS) <= 0 || gmg_opt(GMG_OPT_MG_ERR_CALLS_GROW));
+            const bool may_grow = level_tries == 0 && want <= 8 * a.total + 65536 && (gmg_opt(GMG_OPT_MG_ERR_CALLS) <= 0 || gmg_opt(GMG_OPT_MG_ERR_CALLS_GROW));
+            level_tries++;
             bool grown = false;
             if (may_grow && gmg_pool_alloc((void **)&d_calls[0], want * sizeof(MgCall)) == hipSuccess) {
                 if (gmg_pool_alloc((void **)&d_calls[1], want * sizeof(MgCall)) == hipSuccess) grown = true;
@@ -3347,7 +3421,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
                     a.gene32 = nullptr;
                 }
             }
-            MG_TRY(hipMemsetAsync(d_err_flag, 0, 80, s2));
+            MG_TRY(hipMemsetAsync(d_err_flag, 0, 128, s2));
             MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
             continue;
         }
@@ -3370,7 +3444,11 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         MG_TRY(hipEventRecord(side_done, s2));          //  the ordering explicit)
         MG_TRY(hipStreamWaitEvent(s, side_done, 0));
     }
-    if (no && err_mode && err_path == 0) {
+    if (no && err_mode && err_path == 0 && err_tile) {
+        hipLaunchKernelGGL(k_mg_err_begin, dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
+        MG_TRY(launch_err_tile(true, s, err_acc_only));
+        if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 1);
+    } else if (no && err_mode && err_path == 0) {
         hipLaunchKernelGGL(k_mg_err_begin, dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
         if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<true, 0, true>), dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
         else hipLaunchKernelGGL((k_mg_err_level<true, 0, false>), dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
@@ -3536,6 +3614,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (d_walk) gmg_pool_release(d_walk);
     if (d_walk_q) gmg_pool_release(d_walk_q);
     if (d_run) gmg_pool_release(d_run);
+    if (d_et_tiles) gmg_pool_release(d_et_tiles);
+    if (d_et_kept) gmg_pool_release(d_et_kept);
+    if (d_et_slabs) gmg_pool_release(d_et_slabs);
     tm.lap("free scratch");
     *out = res;
     return GMG_OK;

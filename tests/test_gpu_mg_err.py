@@ -61,19 +61,20 @@ def test_error_branch_matches_reference_push_order(gpu, oracle, nc, name):
     (dict(allow_subs=True), False),
 ])
 @pytest.mark.parametrize("kw", [dict(), dict(allow_truncated=False, min_gene_len=60), dict(ignore_score_len=150, start_codons=("atg", "rtg"))])
-@pytest.mark.parametrize("path", ["level", "flat", "level-overflow", "level-grow"])
+@pytest.mark.parametrize("path", ["tile", "tile-overflow", "level", "flat", "level-overflow", "level-grow"])
 def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path, monkeypatch, request_finalizers):
-    """path: level by level with one lane per call and the sort into push order (the default; the 2100-bp read goes to the
-    per-ORF kernel), the per-ORF kernel alone, the default with call arrays too small (everything repeats on the per-ORF
-    kernel), and the same with the arrays allowed to grow (the count pass repeats with larger ones)"""
-    opt = {"flat": "mg_err_flat", "level-overflow": "mg_err_calls", "level-grow": "mg_err_calls"}
-    if path in opt:
-        old = gpu.get_option(opt[path])
-        gpu.set_option(opt[path], 1 if path == "flat" else 7)
-        request_finalizers.append(lambda: gpu.set_option(opt[path], old))
-    if path == "level-grow":
-        gpu.set_option("mg_err_calls_grow", 1)
-        request_finalizers.append(lambda: gpu.set_option("mg_err_calls_grow", 0))
+    """path: tile by tile with the running sums in LDS (the default; reads beyond half a tile -- the 1300- and the 2100-bp read --
+    go to the per-ORF kernel), the same with call slabs too small (everything repeats on the level kernels), level by level with
+    one lane per call on the tables in HBM (the 2100-bp read goes to the per-ORF kernel), the per-ORF kernel alone, the level
+    kernels with call arrays too small (everything repeats on the per-ORF kernel), and the same with the arrays allowed to
+    grow (the count pass repeats with larger ones)"""
+    opts = {"tile": {}, "tile-overflow": {"mg_err_tile_q": 3}, "level": {"mg_err_tile": 0}, "flat": {"mg_err_flat": 1},
+            "level-overflow": {"mg_err_tile": 0, "mg_err_calls": 7},
+            "level-grow": {"mg_err_tile": 0, "mg_err_calls": 7, "mg_err_calls_grow": 1}}[path]
+    for k, v in opts.items():
+        old = gpu.get_option(k)
+        gpu.set_option(k, v)
+        request_finalizers.append(lambda k=k, old=old: gpu.set_option(k, old))
     rng = np.random.default_rng(99)
     lengths = [0, 1, 5, 14, 15, 16, 17, 18, 33, 74, 75, 76, 99, 150, 231, 300, 301, 302, 400, 523, 700]
     seqs = ["".join("acgt"[c] for c in rng.integers(0, 4, size=n)) for n in lengths]
