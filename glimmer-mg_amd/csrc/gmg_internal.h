@@ -117,9 +117,11 @@ enum GmgOpt {
                                  // models' values allow it), 0 = every walk adds up its own sum codon by codon
     GMG_OPT_MG_ORFS_EVENTS,      // glimmer-mg front half, default mode: 1 = the ORF scan's write pass queues the codons that are in a start or
                                  // stop set and runs the reference's steps over the queue (k_mg_find_orfs_ev), 0 = at every position
-    GMG_OPT_MG_ERR_TILE,         // glimmer-mg's error branch: 1 = tile by tile with the running sums in LDS (k_mg_err_tile; needs mg_err_skip and
-                                 // sums that are exact in any order), 0 = the level kernels on the walk-order tables in HBM
-    GMG_OPT_MG_ERR_TILE_Q,       // ... tests: calls per level a work-group's slab holds (0 = ET_QCAP); a full slab sends the batch to the level kernels
+    GMG_OPT_MG_ERR_TILE,         // glimmer-mg's error branch: 1 = tile by tile with the running sums in LDS, one lane per event (k_mg_err_tile; needs
+                                 // mg_err_skip and sums that are exact in any order), 0 = the level kernels on the walk-order tables in HBM (default:
+                                 // measured faster)
+    GMG_OPT_MG_ERR_TILE_Q,       // ... tests: calls per level a work-group's slab holds (0 = ET_QCAP; a full slab sends the batch to the level kernels);
+                                 // any value but 0 also starts with staging arrays of 64 entries (-1: only that: the kernel repeats with larger ones)
     GMG_OPT_COUNT
 };
 extern long long g_gmg_opt[GMG_OPT_COUNT];

@@ -2895,8 +2895,11 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     double *d_walk = nullptr;
     uint8_t *d_walk_q = nullptr;
     MgTile *d_et_tiles = nullptr;                       // the error branch tile by tile (k_mg_err_tile)
-    uint8_t *d_et_kept = nullptr;
     MgCall *d_et_slabs = nullptr;
+    EtEm *d_et_em = nullptr;
+    gmg_start *d_st_s = nullptr;                        // ... its staging arrays: the kept ORFs' slices in the order the tiles finish
+    gmg_start_errors *d_st_e = nullptr;
+    uint64_t *d_st_k = nullptr;
     int rc = GMG_OK;
     auto fail = [&](int code) {
         (void)hipDeviceSynchronize();                   // nothing (either stream) may still use the blocks that go back to the cache
@@ -2928,8 +2931,11 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (d_walk_q) gmg_pool_release(d_walk_q);
         if (d_run) gmg_pool_release(d_run);
         if (d_et_tiles) gmg_pool_release(d_et_tiles);
-        if (d_et_kept) gmg_pool_release(d_et_kept);
         if (d_et_slabs) gmg_pool_release(d_et_slabs);
+        if (d_et_em) gmg_pool_release(d_et_em);
+        if (d_st_s) gmg_pool_release(d_st_s);
+        if (d_st_e) gmg_pool_release(d_st_e);
+        if (d_st_k) gmg_pool_release(d_st_k);
         gmg_mg_result_free(res);
         return code;
     };
@@ -3034,9 +3040,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     // level kernels cannot take (>= 2040 bases: k_mg_err_flat walks the table) or a forced per-ORF path; a call-array overflow
     // builds the table then (k_mg_apply_nulls) before it falls back.
     // the error branch tile by tile (k_mg_err_tile: the running sums in LDS) wants what the running-sum form wants; reads longer than
-    // half a tile go to k_mg_err_flat, which walks the fp64 table
+    // a tile go to k_mg_err_flat, which walks the fp64 table
     err_tile = err_mode && err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) && gmg_opt(GMG_OPT_MG_ERR_TILE) && !gmg_opt(GMG_OPT_MG_ERR_FLAT);
-    const uint64_t err_fit_len = err_tile ? MG_ET_CAP / 2 + 1 : 2040;       // reads shorter than this are walked by the tile / level kernels
+    const uint64_t err_fit_len = err_tile ? MG_ET_CAP + 1 : 2040;       // reads shorter than this are walked by the tile / level kernels
     const bool err_g32 = err_mode && !d_frame_scores && a.total && g32_opt != 0 && nul_dense3 && all_fast && err_exact &&
                          gmg_opt(GMG_OPT_MG_ERR_SKIP) && !gmg_opt(GMG_OPT_MG_ERR_FLAT) && reads->max_len && reads->max_len < err_fit_len;
     const bool g32 = err_g32 || (!d_frame_scores && !err_mode && a.total &&
@@ -3251,6 +3257,14 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     // error branch, level by level: 0 (k_mg_err_level; the default), 1 = one lane per ORF with an explicit stack
     // (k_mg_err_flat: exact slots; the fallback of 0, and on its own with GMG_MG_ERR_FLAT=1 for A/B runs and cross-checks)
     int err_path = gmg_opt(GMG_OPT_MG_ERR_FLAT) ? 1 : 0;
+    // the run lengths of the level kernels' walks (they need the reads and the qualities only)
+    auto build_run_tables = [&](hipStream_t st) -> hipError_t {
+        hipError_t e = gmg_pool_alloc((void **)&d_run, (size_t)4 * a.walk_stride);
+        if (e != hipSuccess) return e;
+        a.run_q = d_run; a.run_n = d_run + 2 * a.walk_stride;
+        hipLaunchKernelGGL(k_mg_run_tables, dim3(grid_for(2 * nr * 64)), dim3(256), 0, st, a, d_run, d_run + 2 * a.walk_stride);
+        return hipGetLastError();
+    };
     // the walk-order rows of the level kernels (running sums, or the values themselves): behind the six-frame table on stream st
     auto build_walk_rows = [&](hipStream_t st) -> hipError_t {
         hipError_t e = gmg_pool_alloc((void **)&d_walk, ((size_t)6 * a.walk_stride + 8) * sizeof(double));
@@ -3269,11 +3283,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         // (second stream), the six-frame kernel and the rows.  Tile by tile (k_mg_err_tile) the rows are built in LDS, tile by tile.
         a.walk_stride = ((a.total + 15) & ~15ull) + 16;
         a.pfx = err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) ? 1 : 0;
-        if (a.pfx) {                                    // running sums + run lengths: the walks visit their events only
-            MG_TRY(gmg_pool_alloc((void **)&d_run, (size_t)4 * a.walk_stride));
-            a.run_q = d_run; a.run_n = d_run + 2 * a.walk_stride;
-            hipLaunchKernelGGL(k_mg_run_tables, dim3(grid_for(2 * nr * 64)), dim3(256), 0, s3, a, d_run, d_run + 2 * a.walk_stride);
-        }
+        if (a.pfx && !err_tile) MG_TRY(build_run_tables(s3));   // running sums + run lengths: the walks visit their events only
         if (!err_tile) MG_TRY(build_walk_rows(s));
         MG_TRY(hipGetLastError());
         tm.lap("walk-order tables");
@@ -3290,7 +3300,6 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     // 3. start lists
     if (!find_only) {
     MG_TRY(gmg_pool_alloc((void **)&d_start_off, (no + 1) * 8));
-    const int err_acc_only = (prm->flags & GMG_MG_ACCEPTED_ONLY) ? 1 : 0;
     // the level kernels' scratch: call arrays, per-ORF aggregates, slot counters
     auto alloc_level_scratch = [&]() -> hipError_t {
         a.call_cap = a.total / 2 > 65536 ? a.total / 2 : 65536;
@@ -3302,14 +3311,28 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; a.agg = d_agg; a.fill = d_fill;
         return e;
     };
-    // k_mg_err_tile: work-groups (two per CU: 68 KB of LDS each), their call slabs, the tile list
+    // k_mg_err_tile: work-groups (three per CU: 50 KB of LDS each), their slabs (calls per level, starts per batch of ORFs), the tile
+    // list, the staging arrays
     unsigned et_grid = 0;
-    uint32_t et_qcap = gmg_opt(GMG_OPT_MG_ERR_TILE_Q) > 0 ? (uint32_t)gmg_opt(GMG_OPT_MG_ERR_TILE_Q) : (uint32_t)ET_QCAP;
+    const uint32_t et_qcap = gmg_opt(GMG_OPT_MG_ERR_TILE_Q) > 0 ? (uint32_t)gmg_opt(GMG_OPT_MG_ERR_TILE_Q) : (uint32_t)ET_QCAP;
+    const uint32_t et_ecap = gmg_opt(GMG_OPT_MG_ERR_TILE_Q) > 0 ? (uint32_t)(4 * gmg_opt(GMG_OPT_MG_ERR_TILE_Q)) : (uint32_t)ET_ECAP;
+    uint64_t et_stage_cap = 0;
     uint32_t *d_et_ntiles = nullptr;
-    unsigned long long *d_et_items = nullptr;
+    unsigned long long *d_et_items = nullptr, *d_et_stage_ctr = nullptr;
+    const int err_acc_only = (prm->flags & GMG_MG_ACCEPTED_ONLY) ? 1 : 0;
+    auto alloc_staging = [&](uint64_t entries) -> hipError_t {
+        if (d_st_s) { gmg_pool_release(d_st_s); d_st_s = nullptr; }
+        if (d_st_e) { gmg_pool_release(d_st_e); d_st_e = nullptr; }
+        if (d_st_k) { gmg_pool_release(d_st_k); d_st_k = nullptr; }
+        et_stage_cap = entries;
+        hipError_t e = gmg_pool_alloc((void **)&d_st_s, entries * sizeof(gmg_start));
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_st_e, entries * sizeof(gmg_start_errors));
+        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_st_k, entries * 8);
+        return e;
+    };
     if (res->n_orfs && err_mode && err_path == 0) {
         MG_TRY(gmg_pool_alloc((void **)&d_read_fit, nr ? nr : 1));
-        MG_TRY(gmg_pool_alloc((void **)&d_err_flag, 128));          // the flag + the two call counters + six tile counters; tile path: + the number of tiles, two item counters
+        MG_TRY(gmg_pool_alloc((void **)&d_err_flag, 128));          // the flag + the two call counters + six tile counters; tile path: + the number of tiles, the item and staging counters
         MG_TRY(hipMemsetAsync(d_err_flag, 0, 128, s2));
         a.read_fit = d_read_fit;
         a.err_flag = d_err_flag;
@@ -3317,42 +3340,47 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         a.tile_ctr = (unsigned long long *)(d_err_flag + 6);
         d_et_ntiles = d_err_flag + 18;
         d_et_items = (unsigned long long *)(d_err_flag + 20);
+        d_et_stage_ctr = (unsigned long long *)(d_err_flag + 22);
         MG_TRY(gmg_pool_alloc((void **)&d_acc_bits, (no / 32 + 1) * 4));
         a.acc_bits = d_acc_bits;
         if (err_tile) {
             int n_cu = 0;
             MG_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id));
-            et_grid = (unsigned)(n_cu > 0 ? 2 * n_cu : 512);
+            et_grid = (unsigned)(n_cu > 0 ? ET_WG_PER_CU * n_cu : ET_WG_PER_CU * 256);
             MG_TRY(gmg_pool_alloc((void **)&d_et_tiles, (nr + 1) * sizeof(MgTile)));
-            MG_TRY(gmg_pool_alloc((void **)&d_et_kept, 2 * (nr + 1)));
             MG_TRY(gmg_pool_alloc((void **)&d_et_slabs, (size_t)et_grid * 2 * et_qcap * sizeof(MgCall)));
+            MG_TRY(gmg_pool_alloc((void **)&d_et_em, (size_t)et_grid * et_ecap * sizeof(EtEm)));
+            // what leaves the tiles: the accepted ORFs' starts (measured: one per 52 bases of 454-like reads) or every start (one per 4)
+            uint64_t want = (err_acc_only ? a.total / 16 : a.total / 3) + (1u << 20);
+            if (gmg_opt(GMG_OPT_MG_ERR_TILE_Q) != 0) want = 64;         // (tests; -1: only this: the first pass finds the arrays too small)
+            MG_TRY(alloc_staging(want));
         } else MG_TRY(alloc_level_scratch());
     }
     const size_t et_lds = sizeof(EtLds<MG_ET_CAP>);
-    auto launch_err_tile = [&](bool write, hipStream_t st, int acc_only) -> hipError_t {
-#define MG_ET_LAUNCH(W_, G_)                                                                                                     \
+    auto launch_err_tile = [&](hipStream_t st) -> hipError_t {
+        MgArgs at = a;                                  // the kernel's starts go to the staging arrays
+        at.starts = d_st_s; at.errs = d_st_e; at.keys = d_st_k;
+#define MG_ET_LAUNCH(G_)                                                                                                         \
         do {                                                                                                                     \
-            hipError_t e_ = hipFuncSetAttribute((const void *)k_mg_err_tile<W_, G_, MG_ET_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)et_lds); \
+            hipError_t e_ = hipFuncSetAttribute((const void *)k_mg_err_tile<G_, MG_ET_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)et_lds); \
             if (e_ != hipSuccess) return e_;                                                                                     \
-            hipLaunchKernelGGL((k_mg_err_tile<W_, G_, MG_ET_CAP>), dim3(et_grid), dim3(ET_BLOCK), et_lds, st, a, d_et_tiles, d_et_ntiles, \
-                               d_et_items + (W_ ? 1 : 0), d_et_kept, d_et_slabs, et_qcap, acc_only);                            \
+            hipLaunchKernelGGL((k_mg_err_tile<G_, MG_ET_CAP>), dim3(et_grid), dim3(ET_BLOCK), et_lds, st, at, d_et_tiles, d_et_ntiles, d_et_items, \
+                               d_et_slabs, et_qcap, d_et_em, et_ecap, d_et_stage_ctr, (unsigned long long)et_stage_cap, err_acc_only); \
         } while (0)
-        if (write) { if (a.gene32) MG_ET_LAUNCH(true, true); else MG_ET_LAUNCH(true, false); }
-        else { if (a.gene32) MG_ET_LAUNCH(false, true); else MG_ET_LAUNCH(false, false); }
+        if (a.gene32) MG_ET_LAUNCH(true); else MG_ET_LAUNCH(false);
 #undef MG_ET_LAUNCH
         return hipGetLastError();
     };
     int level_tries = 0;
-    for (int attempt = 0; attempt < 4; attempt++) {
+    for (int attempt = 0; attempt < 6; attempt++) {
     const dim3 lvl_grid(256 * 16);
-    const bool any_unfit = reads->max_len >= (err_tile ? (uint64_t)MG_ET_CAP / 2 + 1 : 2040);
+    const bool any_unfit = reads->max_len >= (err_tile ? (uint64_t)MG_ET_CAP + 1 : 2040);
     if (no && err_mode && err_path == 0 && err_tile) {
         MG_TRY(hipMemsetAsync(d_acc_bits, 0, (no / 32 + 1) * 4, s2));
-        MG_TRY(hipMemsetAsync(d_et_kept, 0, 2 * (nr + 1), s2));
         const uint64_t chunk = (uint64_t)ET_CHUNK_TILES * MG_ET_CAP, n_chunks = a.total / chunk + 1;
-        hipLaunchKernelGGL(k_et_tiles, dim3(grid_for(n_chunks)), dim3(256), 0, s2, a, (uint32_t)MG_ET_CAP, (uint32_t)(MG_ET_CAP / 2), chunk, n_chunks,
+        hipLaunchKernelGGL(k_et_tiles, dim3(grid_for(n_chunks)), dim3(256), 0, s2, a, (uint32_t)MG_ET_CAP, (uint32_t)MG_ET_CAP, chunk, n_chunks,
                            d_et_tiles, d_et_ntiles, d_read_fit);
-        MG_TRY(launch_err_tile(false, s2, err_acc_only));
+        MG_TRY(launch_err_tile(s2));
         if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 1);
     } else if (no && err_mode && err_path == 0) {
         MG_TRY(hipMemsetAsync(d_fill, 0, no * 4, s2));
@@ -3382,9 +3410,19 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             fprintf(stderr, "[gmg_mg] calls handed to level 1: %llu, to level 2: %llu (capacity %llu each; %llu ORFs)\n", handed[0], handed[1],
                     (unsigned long long)a.call_cap, (unsigned long long)no);
         }
+        if (!(st[0] & 1u) && (st[0] & 2u) && err_tile) {
+            // the staging arrays were too small: once more with what the kernel asked for (every batch of ORFs has added its wish)
+            unsigned long long asked = 0;
+            memcpy(&asked, st + 22, 8);
+            MG_TRY(alloc_staging(asked + 1024));
+            MG_TRY(hipMemsetAsync(d_err_flag, 0, 128, s2));
+            MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
+            continue;
+        }
         if (st[0] && err_tile) {
             // a work-group's call slab was full: the batch repeats on the level kernels (their call arrays grow with the batch)
             err_tile = false;
+            if (a.pfx) MG_TRY(build_run_tables(s2));
             MG_TRY(build_walk_rows(s2));
             MG_TRY(alloc_level_scratch());
             MG_TRY(hipMemsetAsync(d_err_flag, 0, 128, s2));
@@ -3445,8 +3483,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         MG_TRY(hipStreamWaitEvent(s, side_done, 0));
     }
     if (no && err_mode && err_path == 0 && err_tile) {
-        hipLaunchKernelGGL(k_mg_err_begin, dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
-        MG_TRY(launch_err_tile(true, s, err_acc_only));
+        hipLaunchKernelGGL(k_et_unstage, dim3(grid_for(no)), dim3(256), 0, s, a, d_st_s, d_st_e, d_st_k, err_acc_only);
         if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 1);
     } else if (no && err_mode && err_path == 0) {
         hipLaunchKernelGGL(k_mg_err_begin, dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
@@ -3615,8 +3652,11 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (d_walk_q) gmg_pool_release(d_walk_q);
     if (d_run) gmg_pool_release(d_run);
     if (d_et_tiles) gmg_pool_release(d_et_tiles);
-    if (d_et_kept) gmg_pool_release(d_et_kept);
     if (d_et_slabs) gmg_pool_release(d_et_slabs);
+    if (d_et_em) gmg_pool_release(d_et_em);
+    if (d_st_s) gmg_pool_release(d_st_s);
+    if (d_st_e) gmg_pool_release(d_st_e);
+    if (d_st_k) gmg_pool_release(d_st_k);
     tm.lap("free scratch");
     *out = res;
     return GMG_OK;

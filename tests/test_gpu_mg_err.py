@@ -61,15 +61,16 @@ def test_error_branch_matches_reference_push_order(gpu, oracle, nc, name):
     (dict(allow_subs=True), False),
 ])
 @pytest.mark.parametrize("kw", [dict(), dict(allow_truncated=False, min_gene_len=60), dict(ignore_score_len=150, start_codons=("atg", "rtg"))])
-@pytest.mark.parametrize("path", ["tile", "tile-overflow", "level", "flat", "level-overflow", "level-grow"])
+@pytest.mark.parametrize("path", ["tile", "tile-stage", "tile-overflow", "level", "flat", "level-overflow", "level-grow"])
 def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path, monkeypatch, request_finalizers):
-    """path: tile by tile with the running sums in LDS (the default; reads beyond half a tile -- the 1300- and the 2100-bp read --
-    go to the per-ORF kernel), the same with call slabs too small (everything repeats on the level kernels), level by level with
-    one lane per call on the tables in HBM (the 2100-bp read goes to the per-ORF kernel), the per-ORF kernel alone, the level
+    """path: tile by tile with the running sums in LDS, one lane per event (option mg_err_tile; the 2100-bp read, longer than a tile,
+    goes to the per-ORF kernel), the same with staging arrays too small (the kernel repeats with what it asked for) and
+    with slabs too small (everything repeats on the level kernels), level by level with
+    one lane per call on the tables in HBM (the default; the 2100-bp read goes to the per-ORF kernel), the per-ORF kernel alone, the level
     kernels with call arrays too small (everything repeats on the per-ORF kernel), and the same with the arrays allowed to
     grow (the count pass repeats with larger ones)"""
-    opts = {"tile": {}, "tile-overflow": {"mg_err_tile_q": 3}, "level": {"mg_err_tile": 0}, "flat": {"mg_err_flat": 1},
-            "level-overflow": {"mg_err_tile": 0, "mg_err_calls": 7},
+    opts = {"tile": {"mg_err_tile": 1}, "tile-stage": {"mg_err_tile": 1, "mg_err_tile_q": -1}, "tile-overflow": {"mg_err_tile": 1, "mg_err_tile_q": 3},
+            "level": {"mg_err_tile": 0}, "flat": {"mg_err_flat": 1}, "level-overflow": {"mg_err_tile": 0, "mg_err_calls": 7},
             "level-grow": {"mg_err_tile": 0, "mg_err_calls": 7, "mg_err_calls_grow": 1}}[path]
     for k, v in opts.items():
         old = gpu.get_option(k)
@@ -146,6 +147,11 @@ def test_error_branch_full_size_properties(gpu, oracle, nc):
     assert orfs.tobytes() == orfs2.tobytes() and starts.tobytes() == starts2.tobytes() and errs.tobytes() == errs2.tobytes()
     assert np.array_equal(first, first2)
     del orfs2, starts2, errs2
+    with gpu.option("mg_err_tile", 1):                  # tile by tile, one lane per event: the same bytes as the level kernels' at full size
+        orfs2, starts2, first2, errs2 = gpu.mg_score_reads(nc, indep, reads, allow_indels=True, accepted_only=True)
+    assert orfs.tobytes() == orfs2.tobytes() and starts.tobytes() == starts2.tobytes() and errs.tobytes() == errs2.tobytes()
+    assert np.array_equal(first, first2)
+    del orfs2, starts2, errs2
     assert len(orfs) == first[-1] > n // 10 and np.all(orfs["accepted"] != 0)
     assert np.array_equal(orfs["start_begin"], np.concatenate([[0], np.cumsum(orfs["n_starts"].astype(np.int64))[:-1]]))
     assert int(orfs["n_starts"].astype(np.int64).sum()) == len(starts) == len(errs)
@@ -201,6 +207,11 @@ def test_accepted_only_is_the_full_result_filtered(gpu, nc, name, kw):
     indep = gpu.Icm.indep(0.5)
     full = gpu.mg_score_reads(nc, indep, reads, **kw)
     kept = gpu.mg_score_reads(nc, indep, reads, accepted_only=True, **kw)
+    with gpu.option("mg_err_tile", 1):                  # (the tile kernel: every record, start and error list of both forms)
+        for want, acc in ((full, False), (kept, True)):
+            got = gpu.mg_score_reads(nc, indep, reads, accepted_only=acc, **kw)
+            for x, y in zip(want, got):
+                assert x.tobytes() == y.tobytes()
     keep = full[0]["accepted"] != 0
     assert len(kept[0]) == keep.sum() > 20
     fo = full[0][keep]

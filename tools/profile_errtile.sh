@@ -10,5 +10,4 @@ f=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
 head -16 "$f" | cut -d, -f1-5 | cut -c1-150
 timeout -k 10 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_SALU --output-format csv -d "$OUT/pmc1" -- python3 tests/bench/bench_mg.py $N 1 ragged > "$OUT/pmc1.log" 2>&1 || { tail -5 "$OUT/pmc1.log"; exit 1; }
 timeout -k 10 240 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_INSTS_SMEM --output-format csv -d "$OUT/pmc2" -- python3 tests/bench/bench_mg.py $N 1 ragged > "$OUT/pmc2.log" 2>&1 || { tail -5 "$OUT/pmc2.log"; exit 1; }
-timeout -k 10 240 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc3" -- python3 tests/bench/bench_mg.py $N 1 ragged > "$OUT/pmc3.log" 2>&1 || { tail -5 "$OUT/pmc3.log"; }
 for k in k_mg_err_tile k_mg_walk_prefix "k_mg_err_level"; do echo "== $k"; python3 tools/summarize_pmc.py "$OUT" $k | grep -v "other kernel"; done
