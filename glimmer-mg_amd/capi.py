@@ -66,6 +66,7 @@ PROTOTYPES = {
     "gmg_single_stage": (i32, [vp, C.c_char_p, u64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "gmg_single_fetch": (i32, [vp, vp, C.c_size_t]),
     "gmg_single_free": (i32, [vp]),
+    "gmg_single_window": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "gmg_segments_upload": (i32, [vp, vp, u64, vp, C.POINTER(u64), C.POINTER(vp)]),
     "gmg_segments_free": (i32, [vp]),
     "gmg_frame_score6": (i32, [vp, vp, vp, vp, vp]),

@@ -896,6 +896,34 @@ extern "C" int gmg_single_fetch(gmg_single *st, double *dst, size_t n)
     return GMG_OK;
 }
 
+// ICM_t::Full_Window_Prob / Full_Window_Distrib for ONE window (src/ICM/icm.cc:512-610) on the staging of a gmg_single: the codes and the
+// sub-model go up in one copy, gmg_window_distrib runs on them, prob and the four floats come back in one copy -- nothing is allocated
+extern "C" int gmg_single_window(gmg_single *st, const gmg_model *m, const uint8_t *codes, int model_len, int frame, float *dist4, double *prob)
+{
+    int rc = require_init("gmg_single_window");
+    if (rc) return rc;
+    if (!st || !m || !codes || model_len < 1 || model_len > 1024) return gmg_set_error(GMG_EINVAL, "gmg_single_window: bad argument");
+    if (st->in_flight) GMG_HIP(hipStreamSynchronize(0));
+    if ((rc = single_reserve(st, 4096)) != GMG_OK) return rc;
+    const size_t fr_off = ((size_t)model_len + 7) & ~(size_t)7;
+    memcpy(st->h_in, codes, (size_t)model_len);
+    const int32_t fr = frame;
+    memcpy(st->h_in + fr_off, &fr, 4);
+    unsigned char *d_blk = st->d_in + GMG_GUARD_WORDS * 4;
+    GMG_HIP(hipMemcpyAsync(d_blk, st->h_in, fr_off + 4, hipMemcpyHostToDevice, 0));
+    st->in_flight = true;
+    rc = gmg_window_distrib(m, (const uint8_t *)d_blk, (const int32_t *)(d_blk + fr_off), 1, (float *)(st->d_out + 1), st->d_out, nullptr);
+    if (rc) return rc;
+    GMG_HIP(hipMemcpyAsync(st->h_out, st->d_out, 24, hipMemcpyDeviceToHost, 0));
+    GMG_HIP(hipStreamSynchronize(0));
+    st->in_flight = false;
+    if (prob) memcpy(prob, st->h_out, 8);
+    if (dist4) memcpy(dist4, st->h_out + 1, 16);
+    // (the block is shared with gmg_single_stage, which rewrites the words of its read and GMG_GUARD_WORDS zero words behind them:
+    // more than a window occupies)
+    return GMG_OK;
+}
+
 // ---------------------------------------------------------------------------
 // segments
 // ---------------------------------------------------------------------------

@@ -596,28 +596,18 @@ double  ICM_t :: Score_String
 
 namespace {
 
-//  one explicit window through gmg_window_distrib
+//  one explicit window through gmg_window_distrib, on the calling thread's staging (nothing is allocated per call)
 void  One_Window
     (const gmg_model * m, const char * string, int model_len, int frame, float * dist, double * prob)
   {
    vector <uint8_t>  codes (model_len);
    for  (int k = 0;  k < model_len;  k ++)
      codes [k] = (uint8_t) gmg_base_code ((unsigned char) string [k]);
-   int32_t  fr = frame;
-   void  * d_win = NULL, * d_fr = NULL, * d_dist = NULL, * d_prob = NULL;
-   if  (gmg_device_malloc (& d_win, model_len) != GMG_OK || gmg_device_malloc (& d_fr, 4) != GMG_OK
-          || gmg_device_malloc (& d_dist, 16) != GMG_OK || gmg_device_malloc (& d_prob, 8) != GMG_OK
-          || gmg_memcpy_h2d (d_win, codes . data (), model_len, NULL) != GMG_OK
-          || gmg_memcpy_h2d (d_fr, & fr, 4, NULL) != GMG_OK
-          || gmg_window_distrib (m, (const uint8_t *) d_win, (const int32_t *) d_fr, 1,
-                                 (float *) d_dist, (double *) d_prob, NULL) != GMG_OK
-          || (dist && gmg_memcpy_d2h (dist, d_dist, 16, NULL) != GMG_OK)
-          || (prob && gmg_memcpy_d2h (prob, d_prob, 8, NULL) != GMG_OK))
+   static thread_local gmg_single  * mine = NULL;      // lives as long as the thread
+   if  (mine == NULL && gmg_single_create (& mine) != GMG_OK)
+       Device_Fatal ("gmg_single_create");
+   if  (gmg_single_window (mine, m, codes . data (), model_len, frame, dist, prob) != GMG_OK)
        Device_Fatal ("gmg_window_distrib");
-   gmg_device_free (d_win);
-   gmg_device_free (d_fr);
-   gmg_device_free (d_dist);
-   gmg_device_free (d_prob);
   }
 
 }  // namespace

@@ -4,7 +4,8 @@
 //  Same public interface, constants, field names and error behaviour as the
 //  reference's  ICM_t  (src/ICM/icm.hh:26-84,106-180,303), so that code written
 //  against it (src/Glimmer/glimmer3.cc, glimmer-mg.cc, glimmer_base.cc,
-//  src/ICM/score-fixed.cc) recompiles unchanged.  Everything that computes a
+//  src/ICM/build-icm.cc) recompiles unchanged.  (src/ICM/score-fixed.cc does NOT: it also
+//  needs Fixed_Length_ICM_t, src/ICM/icm.hh:216-289, which is out of scope -- SURVEY 2, row 10.)  Everything that computes a
 //  score goes through the extern "C" HIP layer declared in include/gmg.h;
 //  there is no CPU scoring path in this class.  Model I/O and the null-model
 //  builder are host code, as in the reference.

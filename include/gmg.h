@@ -145,6 +145,9 @@ int gmg_single_stage(gmg_single *st, const char *ascii, uint64_t n, int orient, 
                      const gmg_segments **segs, double **d_out);
 int gmg_single_fetch(gmg_single *st, double *dst, size_t n_doubles);
 int gmg_single_free(gmg_single *st);
+/* ICM_t::Full_Window_Prob / Full_Window_Distrib (src/ICM/icm.cc:512-610) for ONE window of model_len codes (0..3, one byte each)
+ * under sub-model `frame`, on the staging of st: dist4 (4 floats, may be NULL), prob (may be NULL). */
+int gmg_single_window(gmg_single *st, const gmg_model *m, const uint8_t *codes, int model_len, int frame, float *dist4, double *prob);
 
 /* ---- segments --------------------------------------------------------------- */
 

@@ -17,7 +17,16 @@
 //   ref_dump gc       <fasta>                                  1 double (Set_GC_Fraction semantics)
 //   ref_dump rewrite  <icm> <out.icm>                          ICM_t::Read then ::Output(binary)
 //   ref_dump fasta    <fasta>                                  text: per record "H <hdr>" and "S <tolower(Filter(seq))>", then "G <gc count> <total>"
+//   ref_dump cumstr   <icm> <fasta> <count>                    per read x frame: Cumulative_Score_String (icm.cc:409-452), len + 1 doubles
+//   ref_dump text     <icm>                                    ICM_t::Output (fp, false): the text form (Output_Node, icm.cc:729-803)
+//   ref_dump display  <icm>                                    ICM_t::Display (icm.cc:455-482)
+//   ref_dump copy     <icm> <fasta> <count>                    ICM_t::Copy (icm.cc:1000-1007) into a second object, then Score_String on it
+//
+// The same file is built a second time against glimmer-mg_amd/host/icm.hh + libgmg.so (integration/Makefile: ref_dump_dropin): the
+// C++ interface of the drop-in, method by method, against the reference's (tests/test_gpu_icm_class.py).
 
+#include "delcher.hh"
+#include "gene.hh"
 #include "icm.hh"
 #include "fasta.hh"
 #include <string>
@@ -26,6 +35,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdint.h>
+#include <unistd.h>
 
 using namespace std;
 
@@ -175,8 +185,42 @@ int main(int argc, char **argv)
         return 0;
     }
 
+    if (cmd == "text") {
+        gene.Output(stdout, false);
+        return 0;
+    }
+    if (cmd == "display") {
+        gene.Display(stdout);
+        return 0;
+    }
+
     Read_Set rs;
     load_reads(argv[3], rs);
+
+    if (cmd == "cumstr") {
+        int count = atoi(argv[4]);
+        for (int r = 0; r < count && r < (int)rs.seq.size(); r++) {
+            string S = rs.seq[r];
+            int L = S.length();
+            if (L < W - 1) continue;                    // (the reference scores the first model_len - 1 bases whatever len is)
+            vector<double> cum(L + 1);
+            for (int f = 0; f < P; f++) {
+                gene.Cumulative_Score_String(&S[0], L, f, &cum[0]);
+                put(&cum[0], 8 * (L + 1));
+            }
+        }
+        return 0;
+    }
+    if (cmd == "copy") {
+        // Copy shares the tables (the reference frees them twice if both objects die): the copy is never destroyed
+        ICM_t *twin = new ICM_t;
+        twin->Copy(gene);
+        int count = atoi(argv[4]);
+        for (int r = 0; r < count && r < (int)rs.seq.size(); r++)
+            put_d(twin->Score_String(rs.seq[r].c_str(), rs.seq[r].length(), r % P));
+        fflush(stdout);
+        _exit(0);
+    }
 
     if (cmd == "frames") {
         int first = atoi(argv[4]), count = atoi(argv[5]);
