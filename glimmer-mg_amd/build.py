@@ -51,19 +51,27 @@ def build_lib(force=False, verbose=False):
             # one object per source, only the stale ones, a few at a time (the box has 8 - 16 cores); then one link
             objdir = os.path.join(PKG, "lib", "obj")
             os.makedirs(objdir, exist_ok=True)
+            # the objects belong to ONE toolchain and ONE set of flags: a stamp beside them (flags, this file, hipcc --version);
+            # anything else in there is rebuilt
+            import hashlib
+            ver = subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+            stamp = hashlib.sha256((" ".join(FLAGS) + open(os.path.abspath(__file__)).read() + ver).encode()).hexdigest()
+            stamp_file = os.path.join(objdir, "STAMP")
+            if not os.path.exists(stamp_file) or open(stamp_file).read() != stamp:
+                force = True
             newest_header = max(os.path.getmtime(os.path.join(PKG, h)) for h in HEADERS)
             objs, jobs = [], []
             for src in SOURCES:
                 obj = os.path.join(objdir, os.path.basename(src) + ".o")
                 objs.append(obj)
                 if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(os.path.join(PKG, src)), newest_header):
-                    jobs.append((src, [hipcc, *[f for f in FLAGS if f != "-shared"], "-c", "-o", obj, src]))
+                    jobs.append((src, obj, [hipcc, *[f for f in FLAGS if f != "-shared"], "-c", "-o", obj + ".tmp", src]))
             running = []
             failed = []
 
             def reap(block):
                 for item in list(running):
-                    src, proc = item
+                    src, obj, proc = item
                     if block or proc.poll() is not None:
                         out = proc.communicate()[0]
                         running.remove(item)
@@ -71,18 +79,22 @@ def build_lib(force=False, verbose=False):
                             print(out)
                         if proc.returncode != 0:
                             failed.append(src)
+                        else:
+                            os.replace(obj + ".tmp", obj)           # (an interrupted compile leaves no half-written object behind)
                         if block:
                             return
 
             width = max(1, min(6, (os.cpu_count() or 2) - 1))
-            for src, cmd in jobs:
+            for src, obj, cmd in jobs:
                 while len(running) >= width:
                     reap(True)
-                running.append((src, subprocess.Popen(cmd, cwd=PKG, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+                running.append((src, obj, subprocess.Popen(cmd, cwd=PKG, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
             while running:
                 reap(True)
             if failed:
                 raise RuntimeError("hipcc failed compiling " + ", ".join(failed))
+            with open(stamp_file, "w") as f:
+                f.write(stamp)
             cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
             res = subprocess.run(cmd, cwd=PKG, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             if verbose or res.returncode != 0:

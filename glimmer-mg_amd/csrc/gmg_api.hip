@@ -673,6 +673,7 @@ extern "C" int gmg_reads_select(const gmg_reads *reads, const uint64_t *idx, uin
     unsigned long long *d_stats = nullptr;
     void *d_tmp = nullptr;
     auto fail = [&](int rc) {
+        (void)hipStreamSynchronize(0);                  // (kernels already queued may still use the blocks that go back to the cache)
         if (d_idx) gmg_pool_release(d_idx);
         if (d_len) gmg_pool_release(d_len);
         if (d_stats) gmg_pool_release(d_stats);
@@ -740,7 +741,9 @@ extern "C" int gmg_reads_select(const gmg_reads *reads, const uint64_t *idx, uin
 extern "C" int gmg_reads_free(gmg_reads *r)
 {
     if (!r) return GMG_OK;
-    // (gmg_pool_release: a block of the library's cache goes back to it, anything else is hipFree'd)
+    // (gmg_pool_release: a block of the library's cache goes back to it, anything else is hipFree'd.  A cached block is handed out
+    // again at once: kernels queued on a caller's stream may still read this batch -- hipFree waited for them, the cache does not)
+    (void)hipDeviceSynchronize();
     if (r->d_packed_alloc) gmg_pool_release(r->d_packed_alloc);
     if (r->owns_off && r->d_off) gmg_pool_release((void *)r->d_off);
     if (r->d_tile_read) gmg_pool_release(r->d_tile_read);

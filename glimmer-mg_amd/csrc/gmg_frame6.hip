@@ -980,8 +980,12 @@ int gmg_launch_gene6_groups(const gmg_model *const *models, const uint64_t *grou
     {
         uint64_t *d_idx = nullptr, *d_val = nullptr;
         GMG_HIP(gmg_pool_alloc((void **)&d_idx, (size_t)(n_groups + 1) * 8));
-        GMG_HIP(gmg_pool_alloc((void **)&d_val, (size_t)(n_groups + 1) * 8));
-        hipError_t e = hipMemcpyAsync(d_idx, group_read, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, s);
+        hipError_t e = gmg_pool_alloc((void **)&d_val, (size_t)(n_groups + 1) * 8);
+        if (e != hipSuccess) {                          // (a block handed out and not given back stays busy for good)
+            gmg_pool_release(d_idx);
+            return gmg_set_error(e == hipErrorOutOfMemory ? GMG_ENOMEM : GMG_EHIP, "gmg_launch_gene6_groups: %s", hipGetErrorString(e));
+        }
+        e = hipMemcpyAsync(d_idx, group_read, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_f6_gather_u64, dim3((n_groups + 256) / 256), dim3(256), 0, s, reads->d_off, d_idx, (uint32_t)(n_groups + 1), d_val);
             e = hipMemcpyAsync(base.data(), d_val, (size_t)(n_groups + 1) * 8, hipMemcpyDeviceToHost, s);
@@ -1077,23 +1081,23 @@ int gmg_launch_gene6_groups(const gmg_model *const *models, const uint64_t *grou
 
     if (!rounds.empty()) {
         int dev = 0, n_cu = 256;
-        GMG_HIP(hipGetDevice(&dev));
-        GMG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess)
+            return done(gmg_set_error(GMG_EHIP, "gmg_launch_gene6_groups: %s", hipGetErrorString(e)));
         unsigned nworkers = (unsigned)(n_cu / 3);
         if (nworkers < 1) nworkers = 1;
         if (nworkers > rounds.size()) nworkers = (unsigned)rounds.size();
         const unsigned grid = 3 * nworkers;
         const size_t lds = ((size_t)1 << (2 * DT)) * 8;
         if ((gstride & 1) == 0) {
-            GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, true, true, false, false, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, 0, true, true, false, false, true>), dim3(grid), dim3(BLOCK), lds, s, a);
+            e = hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, true, true, false, false, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, 0, true, true, false, false, true>), dim3(grid), dim3(BLOCK), lds, s, a);
         } else {
-            GMG_HIP(hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, false, true, false, false, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, 0, false, true, false, false, true>), dim3(grid), dim3(BLOCK), lds, s, a);
+            e = hipFuncSetAttribute((const void *)k_frame6t<BLOCK, DT, KR, 0, false, true, false, false, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) hipLaunchKernelGGL((k_frame6t<BLOCK, DT, KR, 0, false, true, false, false, true>), dim3(grid), dim3(BLOCK), lds, s, a);
         }
-        e = hipGetLastError();
+        if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) return done(gmg_set_error(GMG_EHIP, "gmg_launch_gene6_groups: %s", hipGetErrorString(e)));
     }
     // the partial-window heads of every read, group by group, and the ranges outside the rounds
@@ -1102,6 +1106,9 @@ int gmg_launch_gene6_groups(const gmg_model *const *models, const uint64_t *grou
         const unsigned grid = (unsigned)(blocks < 256 * 8 ? blocks : 256 * 8);
         const size_t lds_p = (size_t)3 * a.gene.cstride;
         a.p_blocks = grid;
+        // (eight blocks per range: with one ICM per read -- up to 2^27 groups -- that would pass the grid limit only at launch time)
+        if ((uint64_t)grid + 8ull * ranges.size() > 0x7fffffffull)
+            return done(gmg_set_error(GMG_ETOOBIG, "gmg_launch_gene6_groups: %llu group edges in one batch: split the batch", (unsigned long long)ranges.size()));
         hipLaunchKernelGGL((k_frame6p<7, 4, true, true>), dim3(grid + 8 * (unsigned)ranges.size()), dim3(256), lds_p, s, a);
         e = hipGetLastError();
         if (e != hipSuccess) return done(gmg_set_error(GMG_EHIP, "gmg_launch_gene6_groups: %s", hipGetErrorString(e)));

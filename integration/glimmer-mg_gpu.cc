@@ -46,6 +46,8 @@
 #include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
+#include <spawn.h>
+extern char **environ;
 
 static const uint64_t DEFAULT_BATCH_BYTES = 256ull << 20;
 
@@ -696,16 +698,30 @@ int main(int argc, char **argv)
         setup_options((int)rest.size(), rest.data());
         if (Genome_Is_Circular) {
             // -r (Find_Orfs with wrap-around, glimmer_base.cc:638-817) is not batched here: glimmer-mg_dropin beside this binary is the
-            // reference's own main() on the device-backed ICM_t (same bytes, one launch per ICM_t call); nothing has touched the GPU yet
+            // reference's own main() on the device-backed ICM_t (same bytes, one launch per ICM_t call).  It runs as a CHILD
+            // (posix_spawn + waitpid): under a profiler this process may have initialised the GPU before main(), and exec* from such
+            // a process is what this pool forbids.  Not with -c: the drop-in is the reference's main() with ITS compiled-in ICM_dir
+            // (glimmer-mg.cc:147), so --icm-dir could not reach it.
+            if (class_file != NULL) {
+                fprintf(stderr, "glimmer-mg_gpu: -r together with -c is not supported (circular sequences run in glimmer-mg_dropin, which has the reference's compiled-in ICM directory)\n");
+                return 2;
+            }
             char self[4096];
             const ssize_t n_self = readlink("/proc/self/exe", self, sizeof self - 1);
             string dir = n_self > 0 ? string(self, (size_t)n_self) : string(argv[0]);
             const size_t slash = dir.rfind('/');
             const string exe = (slash == string::npos ? string(".") : dir.substr(0, slash)) + "/glimmer-mg_dropin";
             rest.push_back(NULL);
-            execv(exe.c_str(), rest.data());
-            fprintf(stderr, "glimmer-mg_gpu: -r needs %s (the reference's loop on the device-backed ICM_t), which could not be started: %s\n", exe.c_str(), strerror(errno));
-            return 2;
+            pid_t pid = 0;
+            const int src = posix_spawn(&pid, exe.c_str(), NULL, NULL, rest.data(), environ);
+            if (src != 0) {
+                fprintf(stderr, "glimmer-mg_gpu: -r needs %s (the reference's loop on the device-backed ICM_t), which could not be started: %s\n", exe.c_str(), strerror(src));
+                return 2;
+            }
+            int status = 0;
+            while (waitpid(pid, &status, 0) < 0)
+                if (errno != EINTR) { perror("glimmer-mg_gpu: waitpid"); return 2; }
+            return WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
         }
         if (n_shards > 1 && Quality_File_Name != NULL) {
             fprintf(stderr, "glimmer-mg_gpu: -q with --shards > 1 is not supported (the quality file is read in order)\n");

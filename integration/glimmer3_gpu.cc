@@ -8,7 +8,10 @@
 //     Score_Orfs' scoring (buffers, two cumulative scores, start scan)  -> gmg_score_orfs  (glimmer3.cc:1275-1552)
 //
 //     glimmer3_gpu <glimmer3 options> <fasta> <tag>          (GMG_DEVICE selects the GPU)
-// -M, -L and -i select loops that are not batched here: such a command line is handed to glimmer3_dropin (same directory).
+// -L (Score_Orflist, glimmer3.cc:1177-1271) and -M (Score_Separate_Input, :1555-1628) are batched too: every ORF of the coordinate
+// list / every sequence of the file is one segment of ONE gmg_score_string call per model (score [m-4] of Cumulative_Score is
+// Score_String of the buffer's first m-3 bases).  -i (ignore regions) and circular genomes select loops that are not batched here:
+// such a command line is handed to glimmer3_dropin (same directory), as are coordinate lists with wrap-around entries.
 //
 // Output: <tag>.predict, byte-identical to the reference's (tests/test_gpu_dropin_cli.py).
 
@@ -23,6 +26,9 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <spawn.h>
+#include <sys/wait.h>
+extern char **environ;
 
 // the set-up steps of glimmer3's main (glimmer3.cc:175-223), in the same order
 static void setup_options(int argc, char **argv)
@@ -54,7 +60,8 @@ static void load_sequence(const vector<string> &seq_list, const vector<string> &
 // The modes whose loops are not batched here -- -M (every input sequence is one gene: Score_Separate_Input, glimmer3.cc:1555-1628),
 // -L (ORFs from a coordinate file: Score_Orflist, :1177-1271) and -i (ignore regions in Find_Orfs, glimmer_base.cc:833-943) -- run
 // in glimmer3_dropin beside this binary: the reference's own main() on the device-backed ICM_t (one launch per ICM_t call; same
-// bytes).  Nothing has touched the GPU yet, so this process simply becomes that one.
+// bytes).  It is started as a CHILD (posix_spawn + waitpid) and its exit status handed on: under a profiler this process may
+// have initialised the GPU before main(), and replacing a GPU-initialised process (exec*) is what this pool forbids.
 static int run_dropin(const char *name, char **argv)
 {
     char self[4096];
@@ -63,10 +70,128 @@ static int run_dropin(const char *name, char **argv)
     const size_t slash = dir.rfind('/');
     dir = slash == string::npos ? string(".") : dir.substr(0, slash);
     const string exe = dir + "/" + name;
-    execv(exe.c_str(), argv);
-    fprintf(stderr, "glimmer3_gpu: this option set needs %s (the reference's loop on the device-backed ICM_t), which could not be started: %s\n",
-            exe.c_str(), strerror(errno));
-    return 2;
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, exe.c_str(), NULL, NULL, argv, environ);
+    if (rc != 0) {
+        fprintf(stderr, "glimmer3_gpu: this option set needs %s (the reference's loop on the device-backed ICM_t), which could not be started: %s\n",
+                exe.c_str(), strerror(rc));
+        return 2;
+    }
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0)
+        if (errno != EINTR) { perror("glimmer3_gpu: waitpid"); return 2; }
+    return WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
+}
+
+// -L / -M on the device.  Per ORF the reference builds the buffer (Reverse_Transfer: forward strand, bases hi-1 downwards, not
+// complemented; Complement_Transfer: reverse strand, bases lo upwards, complemented, not reversed), takes Cumulative_Score of both
+// models from frame 1 and prints 100 * (score [m-4] - indep_score [m-4]) / (m - 3): the sums over the buffer's first m - 3 bases,
+// i.e. Score_String (buff, m - 3, 1) with the window rule of a buffer that starts at the ORF's 3' end (partial windows for its
+// first model_len - 1 bases).  Returns -1 when an entry is not a plain segment of the sequence (wrap-around, out of range, too
+// short): the caller hands the run to glimmer3_dropin.
+static int run_orf_scores_batched(char **argv)
+{
+    const char *dev = getenv("GMG_DEVICE");
+    const int fd = open(Sequence_File_Name, O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) { fprintf(stderr, "ERROR:  Could not open file  %s \n", Sequence_File_Name); return EXIT_FAILURE; }
+    const size_t n_file = (size_t)st.st_size;
+    const char *file_bytes = n_file ? (const char *)mmap(NULL, n_file, PROT_READ, MAP_PRIVATE, fd, 0) : "";
+    if (file_bytes == MAP_FAILED) { perror("mmap"); return EXIT_FAILURE; }
+    // the coordinates are checked against the sequence lengths on the host first (the first pass of Fasta_Read's state machine over
+    // the headers and bases is the device's: lengths come back with the ingest) -- so the device is needed from here
+    if (gmg_init(dev ? atoi(dev) : 0) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+    gmg_reads *reads = NULL;
+    gmg_fasta *fasta = NULL;
+    if (gmg_fasta_ingest(file_bytes, n_file, &reads, &fasta) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
+    uint64_t n_ing = 0, total_bases = 0, gc_ct = 0;
+    gmg_fasta_info(fasta, &n_ing, &total_bases, &gc_ct);
+    Sequence_Ct = (int)n_ing;
+    vector<uint64_t> hb(n_ing), he(n_ing), off(n_ing + 1);
+    gmg_fasta_headers(fasta, hb.data(), he.data());
+    vector<uint32_t> packed(gmg_packed_words(total_bases) + 1, 0);
+    gmg_reads_download(reads, packed.data(), off.data());
+    gmg_fasta_free(fasta);
+    vector<gmg_segment> segs;
+    vector<int> m_of;                                   // m = the buffer's length
+    bool plain = true;
+    if (Separate_Orf_Input) {                           // every sequence is one ORF in frame +1, its stop codon included (:1573-1574)
+        for (uint64_t i = 0; i < n_ing && plain; i++) {
+            const int64_t len = (int64_t)(off[i + 1] - off[i]) - 3;
+            if (len < 4) { plain = false; break; }
+            gmg_segment g = {(uint32_t)i, 3u, (uint32_t)(len - 3), (uint32_t)GMG_REVERSED};
+            segs.push_back(g);
+            m_of.push_back((int)len);
+        }
+    } else {                                            // the coordinate list against the FIRST sequence (:244-252)
+        if (n_ing == 0) plain = false;
+        const int64_t n = n_ing ? (int64_t)(off[1] - off[0]) : 0;
+        for (size_t i = 0; i < Orf_Pos_List.size() && plain; i++) {
+            const int64_t start = Orf_Pos_List[i].start, stop = Orf_Pos_List[i].stop;
+            if (Orf_Pos_List[i].dir > 0) {              // buffer = bases stop-4 .. start-1 (0-based), downwards
+                const int64_t len = 1 + stop - start - 3;
+                if (start < 1 || stop - 3 > n || stop - 3 <= 0 || len < 4) { plain = false; break; }
+                gmg_segment g = {0u, (uint32_t)(start + 2), (uint32_t)(len - 3), (uint32_t)GMG_REVERSED};
+                segs.push_back(g);
+                m_of.push_back((int)len);
+            } else {                                    // buffer = complement of bases stop+2 .. (0-based), upwards
+                const int64_t len = 1 + start - stop - 3;
+                if (stop < 1 || start > n || stop + 2 >= n || len < 4) { plain = false; break; }
+                gmg_segment g = {0u, (uint32_t)(stop + 2), (uint32_t)(len - 3), (uint32_t)GMG_COMPLEMENTED};
+                segs.push_back(g);
+                m_of.push_back((int)len);
+            }
+        }
+    }
+    if (!plain) { gmg_reads_free(reads); return -1; }
+    if (!GC_Frac_Set) {                                 // Set_GC_Fraction (glimmer_base.cc:2564-2595) without reading the file again
+        Indep_GC_Frac = gmg_gc_fraction(&gc_ct, &total_bases, 1, 1);
+        GC_Frac_Set = true;
+    }
+    setup_models();
+    const uint64_t ns = segs.size();
+    vector<double> gene_sum(ns ? ns : 1), indep_sum(ns ? ns : 1);
+    if (ns) {
+        gmg_segments *dsegs = NULL;
+        void *d_sums = NULL;
+        uint64_t total_len = 0;
+        if (gmg_segments_upload(reads, segs.data(), ns, NULL, &total_len, &dsegs) != GMG_OK || gmg_device_malloc(&d_sums, 2 * ns * sizeof(double)) != GMG_OK ||
+            gmg_score_string(Gene_ICM.Device_Model(), reads, dsegs, 1, (double *)d_sums, NULL) != GMG_OK ||
+            gmg_score_string(Indep_Model.Device_Model(), reads, dsegs, 1, (double *)d_sums + ns, NULL) != GMG_OK ||
+            gmg_memcpy_d2h(gene_sum.data(), d_sums, ns * sizeof(double), NULL) != GMG_OK ||
+            gmg_memcpy_d2h(indep_sum.data(), (double *)d_sums + ns, ns * sizeof(double), NULL) != GMG_OK) {
+            fprintf(stderr, "%s\n", gmg_last_error());
+            return 1;
+        }
+        gmg_device_free(d_sums);
+        gmg_segments_free(dsegs);
+    }
+    string filename = Output_Tag;
+    filename.append(".predict");
+    FILE *predict_fp = File_Open(filename, "w", __FILE__, __LINE__);
+    for (uint64_t i = 0; i < ns; i++) {
+        const int m = m_of[i];
+        const double gene_score = 100.0 * (gene_sum[i] - indep_sum[i]) / (m - 3);
+        if (Separate_Orf_Input) {
+            // the tag: the header's first token, or Seq%04d (:1575-1580)
+            char line[MAX_LINE], tag[MAX_LINE];
+            const size_t hl = he[i] - hb[i] < (uint64_t)MAX_LINE - 1 ? (size_t)(he[i] - hb[i]) : (size_t)MAX_LINE - 1;
+            memcpy(line, file_bytes + hb[i], hl);
+            line[hl] = 0;
+            char *p = strtok(line, " \t\n");
+            if (p == NULL) sprintf(tag, "Seq%04d", (int)i);
+            else strcpy(tag, p);
+            fprintf(predict_fp, "%-14s %8d %8d %+3d %8.2f\n", tag, 1, m, 1, gene_score);
+        } else {
+            const int start = Orf_Pos_List[i].start, stop = Orf_Pos_List[i].stop;
+            const int frame = Orf_Pos_List[i].dir > 0 ? 1 + (stop % 3) : -((stop - 1) % 3) - 1;
+            fprintf(predict_fp, "%-14s %8d %8d %+3d %8.2f\n", Orf_Pos_List[i].tag, start, stop, frame, gene_score);
+        }
+    }
+    fclose(predict_fp);
+    gmg_reads_free(reads);
+    (void)argv;
+    return 0;
 }
 
 int main(int argc, char **argv)
@@ -74,7 +199,12 @@ int main(int argc, char **argv)
     if (argc < 3) { fprintf(stderr, "usage: glimmer3_gpu <glimmer3 options> <fasta> <tag>\n"); return 2; }
     try {
         setup_options(argc, argv);
-        if (Separate_Orf_Input || Orflist_File_Name != NULL || Ignore_File_Name != NULL || Genome_Is_Circular) return run_dropin("glimmer3_dropin", argv);
+        if (Ignore_File_Name != NULL || Genome_Is_Circular) return run_dropin("glimmer3_dropin", argv);
+        if (Separate_Orf_Input || Orflist_File_Name != NULL) {
+            if (Orflist_File_Name != NULL && !Separate_Orf_Input) Get_Orf_Pos_List();      // (glimmer3.cc:182-183)
+            const int rc = run_orf_scores_batched(argv);
+            return rc >= 0 ? rc : run_dropin("glimmer3_dropin", argv);
+        }
         vector<string> seq_list, hdr_list;
         // pass 1, on the device: the file's bytes are parsed there (gmg_fasta_ingest = Fasta_Read + tolower (Filter ()) +
         // packing + the g/c count of Set_GC_Fraction) and Find_Orfs runs for every read at once (gmg_find_orfs)
