@@ -29,6 +29,10 @@ Extra objects on that line:
                 else the plain-C oracle ("port").  `value` is ONE core (the reference is single-threaded);
                 `all_cores` runs one process per host core on disjoint slices (process sharding).  Rank 0, N = 1 only.
   cli_end_to_end  FASTA file -> .predict, the reference CLI against integration/glimmer-mg_gpu (N = 1, when both are built).
+  extras        (N = 1, after the timed region, in a process of its own: tests/bench/bench_extras.py) the other device paths of
+                SURVEY section 8(f) on 1M reads, 3 warm-ups + 10 calls each, every leg with its own `roofline` object and a sampled
+                check against the oracle: gmg_mg_score_reads (500 bp, ragged, -i, -s), gmg_mg_score_groups (64 ICMs x 100 null
+                models), gmg_score_reads_strings (64 ICMs), gmg_score_orfs, gmg_fasta_ingest.  --no-extras skips it.
 """
 import argparse
 import json
@@ -206,6 +210,16 @@ def device_digest(out, total, first_read, n_reads, L):
     return "%016x" % int(np.bitwise_xor.reduce(x)), "%016x" % mix
 
 
+def extras(n_reads=1_000_000, reps=10):
+    try:
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench", "bench_extras.py"), str(n_reads), str(reps)],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+        j = json.loads(res.stdout.decode().strip().splitlines()[-1])
+        return j
+    except Exception as e:
+        return {"error": str(e)[:300]}
+
+
 def cli_end_to_end(n_reads=20000):
     exe = os.path.join(ROOT, "integration", "_build", "glimmer-mg_gpu")
     ref = os.path.join(ROOT, "oracle", "_ref", "glimmer-mg")
@@ -233,6 +247,7 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--cpu-reads", type=int, default=20_000, help="reads in each CPU sample (0 = no CPU legs, no check)")
     ap.add_argument("--no-cli", action="store_true", help="skip the CLI end-to-end leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the (f)-row legs (tests/bench/bench_extras.py)")
     ap.add_argument("--data", choices=("synthetic", "genome"), default="synthetic",
                     help="genome: reads cut uniformly from tests/golden/data/NC_000915.fna, both strands (weak scaling only)")
     args = ap.parse_args()
@@ -399,6 +414,10 @@ def main():
             line["value"] = None
         if world == 1 and not args.no_cli and ok:
             line["cli_end_to_end"] = cli_end_to_end()
+        if world == 1 and not args.no_extras and ok:
+            del out                                         # (24 GB back to the device before the other paths run in their own process)
+            torch.cuda.empty_cache()
+            line["extras"] = extras()
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
