@@ -335,6 +335,10 @@ extern "C" int gmg_model_upload(const int16_t *mip, const float *prob4, int W, i
         uint32_t b;
         memcpy(&b, &prob4[i], 4);
         const uint32_t ex = (b >> 23) & 0xffu;
+        // (a slot without a node -- mut_info_pos -2 -- is never read: a descent that meets it stops at the parent.  A model that comes
+        // from a file has zeros there, one that was just trained whatever the training left: probabilities, not logarithms.  Counting
+        // those made every freshly trained table look "odd" and sent it to the sequential kernels: 13.7 instead of 10.2 ms per 1M reads)
+        if (mip[i >> 2] == -2) continue;
         if ((b << 1) == 0) continue;                    // +-0: adds nothing
         if ((b >> 31) == 0 || ex == 0 || ex == 255) m->odd_values = 1;      // positive, denormal, infinity / NaN
         if ((int)ex < m->min_exp) m->min_exp = (int)ex;

@@ -3301,8 +3301,13 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (!find_only) {
     MG_TRY(gmg_pool_alloc((void **)&d_start_off, (no + 1) * 8));
     // the level kernels' scratch: call arrays, per-ORF aggregates, slot counters
+    // (what the level passes of this thread's last call handed on per base: a run's chunks are alike, and a count pass that finds its
+    // arrays too small runs twice -- weakly trained models keep several times the branches of a real one alive)
+    static thread_local double calls_per_base_hint = 0.0;
     auto alloc_level_scratch = [&]() -> hipError_t {
         a.call_cap = a.total / 2 > 65536 ? a.total / 2 : 65536;
+        const uint64_t hinted = (uint64_t)(calls_per_base_hint * 1.15 * (double)a.total) + 65536;
+        if (hinted > a.call_cap && hinted <= 8 * a.total + 65536) a.call_cap = hinted;
         if (gmg_opt(GMG_OPT_MG_ERR_CALLS) > 0) a.call_cap = (uint64_t)gmg_opt(GMG_OPT_MG_ERR_CALLS);     // (tests: force the fallback)
         hipError_t e = gmg_pool_alloc((void **)&d_calls[0], a.call_cap * sizeof(MgCall));
         if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_calls[1], a.call_cap * sizeof(MgCall));
@@ -3404,6 +3409,11 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         uint32_t st[32];
         MG_TRY(hipMemcpy(st, d_err_flag, 128, hipMemcpyDeviceToHost));
         if (tm.on && err_tile) fprintf(stderr, "[gmg_mg] k_mg_err_tile: %u tiles (%llu ORFs)\n", st[18], (unsigned long long)no);
+        if (!err_tile && !st[0] && a.total) {           // what this batch needed, for the next call's arrays
+            unsigned long long handed[2];
+            memcpy(handed, st + 2, 16);
+            calls_per_base_hint = (double)(handed[0] > handed[1] ? handed[0] : handed[1]) / (double)a.total;
+        }
         if (tm.on && !err_tile) {                       // (mg_timing) how many calls the levels handed on
             unsigned long long handed[2];
             memcpy(handed, st + 2, 16);

@@ -32,8 +32,23 @@ files = ["NC_000915.icm", "seqs.cluster-0.run1.filt.gicm", "seqs.cluster-2.run1.
          "seqs.cluster-5.run1.filt.gicm"]
 # one handle (one table in HBM) per group: BENCH_SAME_MODEL=1 (default) 64 copies of ONE file, so that the grouped job does the
 # same work as the single-ICM call and must give the same records; 0: five different files in turn
+# 0: five different files in turn; distinct: n_groups DIFFERENT 3-periodic tables (the five files + models trained on
+# disjoint slices of NC_000915.fna, tests/models64.py): 64 MB of tables against 4 MB of L2 per XCD
 same = os.environ.get("BENCH_SAME_MODEL", "1") == "1"
-models = [gmg.Icm.open(os.path.join(DATA, files[0 if same else g % len(files)])) for g in range(n_groups)]
+# relabel: n_groups different tables with the VALUES of the five files (each file with the bases renamed by a permutation): the
+# cache effect alone -- tables trained on 26-kb slices hold probabilities of zero, which take the exact paths
+distinct = os.environ.get("BENCH_SAME_MODEL", "1") in ("distinct", "relabel")
+if distinct:
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import models64
+    _tmp = tempfile.mkdtemp()
+    if os.environ["BENCH_SAME_MODEL"] == "relabel":
+        models = [m for m, _ in models64.relabeled_models(gmg, _tmp, models64.GENE_FILES, n_groups)]
+    else:
+        models = [m for m, _ in models64.gene_models(gmg, _tmp, n_groups)]
+else:
+    models = [gmg.Icm.open(os.path.join(DATA, files[0 if same else g % len(files)])) for g in range(n_groups)]
 err = os.environ.get("BENCH_ERR", "")
 if err:                                                 # clipped N(400, 60^2) lengths, as bench_mg.py's ragged reads
     lens = np.clip(np.random.default_rng(12).normal(400, 60, n_reads).round(), 100, 700).astype(np.uint64)
@@ -126,4 +141,4 @@ print(json.dumps({"reads": n_reads, "read_len": L if not err else "~400 (ragged)
                   "score_groups_ms": round(t_one, 3), "ratio": round(t_one / t_single, 3),
                   "one_call_per_group_ms": round(t_grouped, 3), "single_all": all_single, "score_groups_all": all_one,
                   "one_call_per_group_all": all_grouped, "accepted_orfs_single": r1[0], "accepted_orfs_groups": r3[0],
-                  "accepted_orfs_per_group_calls": r2[0], "same_model_file": same}))
+                  "accepted_orfs_per_group_calls": r2[0], "same_model_file": same, "distinct_models": n_groups if distinct else (1 if same else len(files)), "models": os.environ.get("BENCH_SAME_MODEL", "1")}))

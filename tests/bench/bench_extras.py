@@ -7,8 +7,8 @@
 Legs (1M reads; the shapes of BASELINE configs[1], [3], [4]):
   mg_500 / mg_ragged     gmg_mg_score_reads, default mode (Score_All_Frames + Find_Orfs + Score_Orf_Starts), 500 bp / ~400 bp ragged
   mg_indel / mg_sub      the same with glimmer-mg -i / -s on the ragged reads, accepted ORFs only (what the driver asks for)
-  mg_groups              gmg_reads_select + gmg_mg_score_groups: 64 ICM groups x 100 null models (glimmer-mg -c), accepted ORFs only
-  strings                gmg_score_reads_strings: every read and its reverse complement under 64 period-1 ICMs (configs[3] per 1M reads)
+  mg_groups              gmg_reads_select + gmg_mg_score_groups: 64 ICM groups (64 different tables) x 100 null models (glimmer-mg -c), accepted ORFs only
+  strings                gmg_score_reads_strings: every read and its reverse complement under 64 different period-1 ICMs (configs[3] per 1M reads)
   score_orfs             gmg_score_orfs: glimmer3's Score_Orfs inner loop for the ORFs gmg_find_orfs finds in 1M x 500 bp
   ingest                 gmg_fasta_ingest: FASTA bytes (page-locked host memory) -> packed reads in HBM
 HBM legs: algorithmic bytes as DESIGN.md section 4 states them per leg, against 8 TB/s.  The strings pass is bound by LDS look-ups,
@@ -163,8 +163,10 @@ for name, flags, kw in (("mg_indel", 1 | 2, dict(allow_indels=True, accepted_onl
 
 if want("mg_groups"):
     n_groups, n_nulls = 64, 100
-    files = ["NC_000915.icm", "seqs.cluster-0.run1.filt.gicm", "seqs.cluster-2.run1.filt.gicm", "seqs.cluster-4.run1.filt.gicm", "seqs.cluster-5.run1.filt.gicm"]
-    models = [gmg.Icm.open(os.path.join(DATA, files[g % len(files)])) for g in range(n_groups)]
+    import tempfile
+    import models64
+    gpairs = models64.gene_models(gmg, tempfile.mkdtemp(), n_groups)           # 64 DISTINCT 3-periodic tables
+    models = [m for m, _ in gpairs]
     rng = np.random.default_rng(3)
     group = rng.integers(0, n_groups, n_reads)
     order = np.argsort(group, kind="stable").astype(np.uint64)
@@ -194,7 +196,7 @@ if want("mg_groups"):
     # check: the first and the last read of three groups, each scored on its own under the group's ICM and its null model, against the oracle
     verdict, n_ck = "", 0
     for g in (0, n_groups // 2, n_groups - 1):
-        og_g = orc.read(os.path.join(DATA, files[g % len(files)]))
+        og_g = orc.read(gpairs[g][1])
         for k in (int(begin[g]), int(begin[g + 1]) - 1):
             r = int(order[k])
             seq = gmg.synth.unpack_ascii(packed5, int(off5[r]), L)
@@ -215,7 +217,10 @@ if want("mg_groups"):
 
 if want("strings"):
     n_models = 64
-    smodels = [gmg.Icm.open(os.path.join(DATA, "cluster-%d.icm" % (i % 6))) for i in range(n_models)]
+    import tempfile
+    import models64
+    spairs = models64.period1_models(gmg, tempfile.mkdtemp(), n_models)       # 64 DISTINCT period-1 tables
+    smodels = [m for m, _ in spairs]
     arr = (C.c_void_p * n_models)(*[m.device() for m in smodels])
     out = api._DeviceBuffer(n_models * n_reads * 2 * 8)
     ms, all_ms, _ = timed(lambda: api._ck(lib.gmg_score_reads_strings(arr, n_models, reads5.h, out.ptr, None)))
@@ -224,7 +229,7 @@ if want("strings"):
     ok, n_ck = True, 0
     comp = bytes.maketrans(b"acgt", b"tgca")
     for m in (0, 5, 63):
-        om = orc.read(os.path.join(DATA, "cluster-%d.icm" % (m % 6)))
+        om = orc.read(spairs[m][1])
         for r in sample:
             seq = gmg.synth.unpack_ascii(packed5, int(off5[r]), L)
             rc = seq.translate(comp)[::-1]

@@ -24,7 +24,16 @@ n_models = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 L = 500
 gmg.init(0)
 data = os.path.join(ROOT, "tests", "golden", "data")
-models = [gmg.Icm.open(os.path.join(data, "cluster-%d.icm" % (i % 6))) for i in range(n_models)]
+if os.environ.get("BENCH_DISTINCT", "1") == "1":     # 64 DIFFERENT period-1 tables (the six sample ICMs + models trained on slices of NC_000915.fna)
+    import tempfile
+    import models64
+    models = [m for m, _ in models64.period1_models(gmg, tempfile.mkdtemp(), n_models)]
+elif os.environ.get("BENCH_DISTINCT") == "relabel":  # 64 different tables with the six files' values (bases renamed)
+    import tempfile
+    import models64
+    models = [m for m, _ in models64.relabeled_models(gmg, tempfile.mkdtemp(), ["cluster-%d.icm" % i for i in range(6)], n_models)]
+else:
+    models = [gmg.Icm.open(os.path.join(data, "cluster-%d.icm" % (i % 6))) for i in range(n_models)]
 ragged = len(sys.argv) > 3 and sys.argv[3] == "ragged"
 if ragged:                                              # 454-like lengths ~ N(400, 60^2), clipped (as tests/bench/bench_mg.py)
     lens = np.clip(np.random.default_rng(12).normal(400, 60, n_reads).round(), 100, 700).astype(np.uint64)

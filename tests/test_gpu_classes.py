@@ -297,9 +297,11 @@ def test_score_groups_refuses_bad_group_lists(gpu):
         gpu.mg_score_reads(None, gpu.Icm.indep(0.5), reads, groups=[(m, 0, 10)])
 
 
-def test_score_groups_full_size_with_error_branch(gpu, oracle):
-    """BASELINE configs[4] as glimmer-mg.py runs it: -c together with -i on 1M reads of ~400 bp -- 64 ICM groups over five model
-    files, 100 GC values (a null model per read), Ignore_Score_Len per read, accepted ORFs only, ONE gmg_mg_score_groups call.
+def test_score_groups_full_size_with_error_branch(gpu, oracle, tmp_path):
+    """BASELINE configs[4] as glimmer-mg.py runs it: -c together with -i on 1M reads of ~400 bp -- 64 ICM groups under 64 DISTINCT
+    3-periodic gene models (the five sample files + 59 trained on disjoint slices of NC_000915.fna, tests/models64.py: 64 MB of
+    tables against 4 MB of L2 per XCD), 100 GC values (a null model per read), Ignore_Score_Len per read, accepted ORFs only, ONE
+    gmg_mg_score_groups call.
     (1) two calls give the same bytes; (2) the records are back to back; (3) three whole groups equal gmg_mg_score_reads on the
     gathered group alone; (4) sampled reads of other groups equal the oracle with the group's ICM and the read's null model."""
     from test_gpu_mg_err import dev_err_rows, err_rows
@@ -310,8 +312,10 @@ def test_score_groups_full_size_with_error_branch(gpu, oracle):
     reads = gpu.Reads(packed, off)
     rng = np.random.default_rng(5)
     cuts = np.concatenate([[0], np.sort(rng.choice(np.arange(1, n), n_groups - 1, replace=False)), [n]]).astype(np.int64)
-    models = [gpu.Icm.open(os.path.join(DATA, f)) for f in GICMS]
-    groups = [(models[g % len(models)], int(cuts[g]), int(cuts[g + 1])) for g in range(n_groups)]
+    import models64
+    pairs = models64.gene_models(gpu, tmp_path, n_groups)
+    models = [m for m, _ in pairs]
+    groups = [(models[g], int(cuts[g]), int(cuts[g + 1])) for g in range(n_groups)]
     gcs = np.linspace(0.3, 0.7, n_gc)
     nulls = gpu.NullSet.build(gcs)
     read_null = rng.integers(0, n_gc, n).astype(np.uint32)
@@ -337,14 +341,14 @@ def test_score_groups_full_size_with_error_branch(gpu, oracle):
         mine["read"] -= b
         mine["start_begin"] -= s0
         assert mine.tobytes() == part[0].tobytes() and starts[s0:s1].tobytes() == part[1].tobytes() and errs[s0:s1].tobytes() == part[3].tobytes()
-    o_models = [oracle.read(os.path.join(DATA, f)) for f in GICMS]
     ep = oracle.mg_err_params(allow_indels=True)
     checked = 0
     for g in (1, 2, 3, 4, 17, 40, 62):
+        o_model = oracle.read(pairs[g][1])              # (the group's own table, from the file the device model was written to)
         for r in (groups[g][1], groups[g][2] - 1):      # the group's first and last read: the model changes right there
             seq = gpu.synth.unpack_ascii(packed, int(off[r]), int(off[r + 1] - off[r]))
             prm = oracle.mg_params(ignore_score_len=int(read_isl[r]))
-            want_orfs, _, scored = oracle.mg_read_errors(o_models[g % len(GICMS)], oracle.indep(float(gcs[read_null[r]])), seq, prm, ep)
+            want_orfs, _, scored = oracle.mg_read_errors(o_model, oracle.indep(float(gcs[read_null[r]])), seq, prm, ep)
             acc = [(o, out, st) for o, (out, st) in zip(want_orfs, scored) if out.accepted]
             mine = orfs[int(first[r]):int(first[r + 1])]
             assert len(mine) == len(acc)

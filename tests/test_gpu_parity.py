@@ -286,6 +286,36 @@ def test_frame6_full_size_properties(gpu, nc, oracle, o_nc):
     assert np.array_equal(one[3:6, L:][:, ::-1], one[0:3, :L])
 
 
+def test_frame6_true_size_every_row_beyond_4_gib(gpu, nc, oracle, o_nc):
+    """BASELINE configs[1] at its TRUE size: 1M x 500 bp, the 24 GB fp64 table on the device (rows of 4.0e9 bytes: row 1 crosses byte
+    offset 2^32 inside read 73,741, row 4 crosses element index 2^31 inside read 294,967; rows 2 - 5 lie beyond 2^32 bytes
+    altogether).  Reads from the head, the middle, the tail and on both sides of those crossings, all six rows, against the oracle."""
+    import ctypes as C
+    n, L, seed = 1_000_000, 500, 20260101
+    packed, off = gpu.synth.packed_reads(n, L, seed)
+    reads = gpu.Reads(packed, off)
+    total = n * L
+    indep, o_indep = gpu.Icm.indep(0.5), oracle.indep(0.5)
+    buf = gpu.api._DeviceBuffer(6 * total * 8)
+    gpu.frame_score6(nc, indep, reads, d_out=buf.ptr.value)
+    lib = gpu.capi.lib()
+    gpu.api._ck(lib.gmg_synchronize(None))
+    cross_bytes = (2**32 - total * 8) // 8 // L           # read of row 1 that holds byte offset 2^32
+    cross_elems = (2**31 - 4 * total) // L                # read of row 4 that holds element index 2^31
+    assert (cross_bytes, cross_elems) == (73_741, 294_967)
+    rng = np.random.default_rng(11)
+    picks = [0, 1, 2, n // 2 - 1, n // 2, n - 2, n - 1, cross_bytes - 1, cross_bytes, cross_bytes + 1, cross_elems - 1, cross_elems, cross_elems + 1]
+    picks += [int(x) for x in rng.integers(0, n, 12)]
+    row = np.empty(L, np.float64)
+    for r in picks:
+        want = oracle.score_all_frames(o_nc, o_indep, gpu.synth.unpack_ascii(packed, r * L, L))
+        for f in range(6):
+            gpu.api._ck(lib.gmg_memcpy_d2h(row.ctypes.data_as(C.c_void_p), C.c_void_p(buf.ptr.value + (f * total + r * L) * 8), L * 8, None))
+            gpu.api._ck(lib.gmg_synchronize(None))
+            assert np.array_equal(row, want[f]), (r, f)
+    buf.free()
+
+
 # ---------------------------------------------------------------- a12: Score_Orfs inner loop
 
 ORF_PATHS = {"events": 0, "exact": 1, "fused": 2}        # option orfs_exact_path (gmg_orfs.hip)

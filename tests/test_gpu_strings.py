@@ -191,28 +191,31 @@ def test_zero_probability_leaves_on_uniform_batches(gpu, oracle, tmp_path):
         assert n_huge > 20                              # reads that met a zero probability, and their neighbours, are all right
 
 
-def test_configs3_shape_ten_million_reads_64_models_in_pieces(gpu, oracle):
-    """BASELINE configs[3]: 10M reads x 64 Phymm ICMs.  Ten pieces of 1M x 500 bp, 64 models per call (the six sample-run
-    ICMs in turn): determinism (first piece twice), model repeats agree, sampled (read, model) pairs of every piece --
-    incl. the last read of the job -- equal the oracle."""
+def test_configs3_shape_ten_million_reads_64_models_in_pieces(gpu, oracle, tmp_path):
+    """BASELINE configs[3]: 10M reads x 64 Phymm ICMs.  Ten pieces of 1M x 500 bp, 64 DISTINCT period-1 models per call (SURVEY 8d:
+    the six sample-run ICMs + 58 trained on disjoint slices of NC_000915.fna, tests/models64.py): determinism (first piece twice),
+    no two models agree on a read, sampled (read, model) pairs of every piece -- incl. the last read of the job and every one of the
+    64 models at least once -- equal the oracle reading the same .icm files."""
+    import models64
     n_piece, L, pieces = 1_000_000, 500, 10
-    paths = [os.path.join(DATA, "cluster-%d.icm" % (i % 6)) for i in range(64)]
-    models = [gpu.Icm.open(p) for p in paths[:6]]
-    models64 = [models[i % 6] for i in range(64)]
-    o_models = [oracle.read(p) for p in paths[:6]]
+    pairs = models64.period1_models(gpu, tmp_path, 64)
+    models = [m for m, _ in pairs]
+    o_models = [oracle.read(p) for _, p in pairs]
     rng = np.random.default_rng(9)
+    seen = set()
     for pc in range(pieces):
         packed, off = gpu.synth.packed_reads_range(pc * n_piece * L, n_piece * L, L, 41)
         reads = gpu.Reads(packed, off)
-        got = gpu.score_reads_strings(models64, reads)
+        got = gpu.score_reads_strings(models, reads)
         assert got.shape == (64, n_piece, 2)
         if pc == 0:
-            assert got.tobytes() == gpu.score_reads_strings(models64, reads).tobytes()
-        for k in range(6, 64):
-            assert np.array_equal(got[k], got[k % 6])
-        for r in [0, n_piece - 1] + [int(x) for x in rng.integers(0, n_piece, 3)]:
+            assert got.tobytes() == gpu.score_reads_strings(models, reads).tobytes()
+            assert len({got[k, 0, 0] for k in range(64)}) == 64          # 64 different tables
+        ks = [int(x) for x in rng.integers(0, 64, 3)] + [k for k in range(pc * 7, min(pc * 7 + 7, 64))]
+        for r, k in zip([0, n_piece - 1] + [int(x) for x in rng.integers(0, n_piece, len(ks) - 2)], ks):
             s_ = gpu.synth.unpack_ascii(packed, r * L, L).decode()
-            k = int(rng.integers(0, 6))
             assert got[k, r, 0] == oracle.score_string(o_models[k], s_, 0)
             assert got[k, r, 1] == oracle.score_string(o_models[k], revcomp(s_), 0)
+            seen.add(k)
         del reads, got
+    assert len(seen) == 64
