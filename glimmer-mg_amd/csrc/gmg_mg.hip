@@ -124,6 +124,8 @@ struct MgArgs {
     const double *walk;          // [6][walk_stride] Frame_Scores in walking order (k_mg_walk_tables), or, pfx: their running sums
                                  // inside every read (k_mg_walk_prefix)
     int pfx;                     // the level kernels take score[j] as a difference of two running sums and skip the codons nothing happens at
+    int qonly;                   // ... and the table holds ONE value per base and strand: the running sum of the base's own class over the steps
+                                 // before it (-s: a walk needs score[j-1] at its start codons and the region's total, nothing inside a codon)
     const uint8_t *run_q, *run_n;// [2][walk_stride] by strand and walk index: codons from here on at which nothing can happen (k_mg_run_tables),
                                  // with / without the low-quality bases as events
     const uint8_t *walk_q;       // [total + 8] the qualities, last base first (forward walks; reverse walks read a.qual)
@@ -2029,7 +2031,7 @@ __device__ __forceinline__ double mg_wave_scan(double x)               // inclus
 // G32: the rows come from the fp32 gene table and the read's null model (the values k_mg_apply_nulls would put into the fp64
 // table: one exact subtraction of two widened floats, partial windows at the read's ends from the partial tables) -- the
 // error branch then never builds or reads the 48 B/base table.
-template <bool G32>
+template <bool G32, bool QONLY = false>
 __global__ __launch_bounds__(256) void k_mg_walk_prefix(MgArgs a, double *walk)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -2068,6 +2070,9 @@ __global__ __launch_bounds__(256) void k_mg_walk_prefix(MgArgs a, double *walk)
                 const double x = row == 0 ? v[0] : row == 1 ? v[1] : v[2];
                 const double sc = mg_wave_scan(x) + carry[c];
                 // (streaming stores: 19 GB written once -- they leave the L2 to the run-length kernel beside this one; -0.7 ms per call)
+                if (QONLY) {                            // the base's own class (the codon that starts here: c == m): the sum BEFORE this step
+                    if (in && c == m) __builtin_nontemporal_store(sc - x, walk + (uint64_t)(fwd ? 0 : 1) * a.walk_stride + w);
+                } else
                 if (in) __builtin_nontemporal_store(sc, walk + (uint64_t)((fwd ? 0 : 3) + c) * a.walk_stride + w);
                 const unsigned long long top = (unsigned long long)__double_as_longlong(sc);
                 carry[c] = __longlong_as_double((long long)((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(top >> 32), 63) << 32 |
@@ -2315,12 +2320,14 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                         if (anchor >= 0 && anchor < n) {
                             const uint64_t ga = (uint64_t)g;
                             const uint64_t w = fwd ? a.total - 1 - ga : ga;
-                            wp = a.walk + (uint64_t)((fwd ? 0 : 3) + (int)(ga % 3)) * a.walk_stride + w;
+                            wp = a.qonly ? a.walk + (uint64_t)(fwd ? 0 : 1) * a.walk_stride + w
+                                         : a.walk + (uint64_t)((fwd ? 0 : 3) + (int)(ga % 3)) * a.walk_stride + w;
                             qp = fwd ? a.walk_q + w : a.qual + ga;
                             if (PFX) {
                                 const bool with_q = LEVEL < 2 && !WRITE && a.err_mode == 1 && LEVEL < a.indel_max;     // (branches can start here)
                                 rp = (with_q ? a.run_q : a.run_n) + (fwd ? 0 : a.walk_stride) + w;
-                                p0 = (fwd ? anchor == n - 1 : anchor == 0) ? 0.0 : wp[-1];         // (the sums restart with every read)
+                                // (the sums restart with every read; qonly: the entry at the anchor IS the sum in front of it)
+                                p0 = a.qonly ? wp[0] : (fwd ? anchor == n - 1 : anchor == 0) ? 0.0 : wp[-1];
                             }
                         }
                         is_last = false; trunc = false; first_done = false; walking = false;
@@ -2355,7 +2362,9 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                         const int64_t ga_ = g + (3 * (int64_t)nskip - 3) * dir, gb_ = ga_ + 3 * dir;
                         const uint32_t wa0 = a.packed[ga_ >> 4], wa1 = a.packed[(ga_ + 2 * dir) >> 4];
                         const uint32_t wb0 = a.packed[gb_ >> 4], wb1 = a.packed[(gb_ + 2 * dir) >> 4];      // (guard words around the batch)
-                        const MgD4 d = *(const MgD4 *)(wp + j0 - 1);               // (8 spare entries on both sides of the tables)
+                        MgD4 d;
+                        if (a.qonly) { d.v[0] = wp[j0]; d.v[1] = d.v[2] = d.v[3] = 0.0; }    // score[j0 - 1] = Q[j0] - Q[0]; nothing else is asked for
+                        else d = *(const MgD4 *)(wp + j0 - 1);                      // (8 spare entries on both sides of the tables)
                         if (LEVEL < 2 && !WRITE && a.err_mode == 1) qw = ((const MgU4 *)(qp + j0))->v;
                         auto codon = [&](int64_t gx, uint32_t w0, uint32_t w1) __attribute__((always_inline)) {
                             const int64_t g1 = gx + dir, g2 = gx + 2 * dir;
@@ -2438,7 +2447,7 @@ __global__ __launch_bounds__(256, MG_LEVEL_WAVES) void k_mg_err_level(MgArgs a, 
                             const uint32_t want = fwd ? 0u : 3u;
                             const int a1 = base(fwd ? lo - 2 : hi) == want, a2 = base(fwd ? lo - 1 : hi - 1) == want;
                             double es = suffix_score + a.pass_stop[a1 * 2 + a2];
-                            if (m > 0) es += sum - 0.0;
+                            if (m > 0) es += (a.qonly ? wp[m] - p0 : sum) - 0.0;       // (qonly: score[m - 1] = Q[m] - Q[0]; the stop codon behind the region is inside the read)
                             c_end = eep; c_score = es; c_sj = suffix_j + m;
                             c_err = (uint32_t)((fwd ? lo - 2 : hi + 2) + 8) << 2 | 2u;
                             c_field = 0;                    // before every position of the call
@@ -3267,9 +3276,17 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     };
     // the walk-order rows of the level kernels (running sums, or the values themselves): behind the six-frame table on stream st
     auto build_walk_rows = [&](hipStream_t st) -> hipError_t {
-        hipError_t e = gmg_pool_alloc((void **)&d_walk, ((size_t)6 * a.walk_stride + 8) * sizeof(double));
+        // -s on running sums: one value per base and strand is all its walks read (16 B/base instead of 48: a third of the table to
+        // write, a third to keep in the caches)
+        a.qonly = a.pfx && err_mode == 2 && gmg_opt(GMG_OPT_MG_ERR_QONLY) ? 1 : 0;
+        hipError_t e = gmg_pool_alloc((void **)&d_walk, ((size_t)(a.qonly ? 2 : 6) * a.walk_stride + 8) * sizeof(double));
         if (e != hipSuccess) return e;
-        if (a.pfx) {
+        if (a.qonly) {
+            // (tried: the same table codon by codon -- a lane on three consecutive steps, ONE scan per class per 192 steps instead of
+            // per 64: bit-exact, 23.5 against 22.0 ms per 1M reads with -s: the loads of a lane's three steps no longer coalesce)
+            if (a.gene32) hipLaunchKernelGGL((k_mg_walk_prefix<true, true>), dim3(grid_for(2 * nr * 64)), dim3(256), 0, st, a, d_walk + 8);
+            else hipLaunchKernelGGL((k_mg_walk_prefix<false, true>), dim3(grid_for(2 * nr * 64)), dim3(256), 0, st, a, d_walk + 8);
+        } else if (a.pfx) {
             if (a.gene32) hipLaunchKernelGGL(k_mg_walk_prefix<true>, dim3(grid_for(2 * nr * 64)), dim3(256), 0, st, a, d_walk + 8);
             else hipLaunchKernelGGL(k_mg_walk_prefix<false>, dim3(grid_for(2 * nr * 64)), dim3(256), 0, st, a, d_walk + 8);
         } else

@@ -61,16 +61,18 @@ def test_error_branch_matches_reference_push_order(gpu, oracle, nc, name):
     (dict(allow_subs=True), False),
 ])
 @pytest.mark.parametrize("kw", [dict(), dict(allow_truncated=False, min_gene_len=60), dict(ignore_score_len=150, start_codons=("atg", "rtg"))])
-@pytest.mark.parametrize("path", ["tile", "tile-stage", "tile-overflow", "level", "flat", "level-overflow", "level-grow"])
+@pytest.mark.parametrize("path", ["tile", "tile-stage", "tile-overflow", "level", "level-q0", "flat", "level-overflow", "level-grow"])
 def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path, monkeypatch, request_finalizers):
     """path: tile by tile with the running sums in LDS, one lane per event (option mg_err_tile; the 2100-bp read, longer than a tile,
     goes to the per-ORF kernel), the same with staging arrays too small (the kernel repeats with what it asked for) and
     with slabs too small (everything repeats on the level kernels), level by level with
-    one lane per call on the tables in HBM (the default; the 2100-bp read goes to the per-ORF kernel), the per-ORF kernel alone, the level
+    one lane per call on the tables in HBM (the default; the 2100-bp read goes to the per-ORF kernel; -s: the one-value-per-base
+    table -- q0: the three-row table instead), the per-ORF kernel alone, the level
     kernels with call arrays too small (everything repeats on the per-ORF kernel), and the same with the arrays allowed to
     grow (the count pass repeats with larger ones)"""
     opts = {"tile": {"mg_err_tile": 1}, "tile-stage": {"mg_err_tile": 1, "mg_err_tile_q": -1}, "tile-overflow": {"mg_err_tile": 1, "mg_err_tile_q": 3},
-            "level": {"mg_err_tile": 0}, "flat": {"mg_err_flat": 1}, "level-overflow": {"mg_err_tile": 0, "mg_err_calls": 7},
+            "level": {"mg_err_tile": 0}, "level-q0": {"mg_err_tile": 0, "mg_err_qonly": 0},
+            "flat": {"mg_err_flat": 1}, "level-overflow": {"mg_err_tile": 0, "mg_err_calls": 7},
             "level-grow": {"mg_err_tile": 0, "mg_err_calls": 7, "mg_err_calls_grow": 1}}[path]
     for k, v in opts.items():
         old = gpu.get_option(k)

@@ -7,10 +7,10 @@ TAG=${1:-run}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-BENCH="python3 bench.py --steps 5 --warmup 2 --cpu-reads 0 --no-cli $*"
+BENCH="python3 bench.py --steps 5 --warmup 2 --cpu-reads 0 --no-cli --no-extras $*"
 # the kernel trace runs the DEFAULT bench command's timed region (steps 100, warmup 10; no CPU legs), so that its averages are the
 # ones bench.py reports
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --cpu-reads 0 --no-cli $* > "$OUT/trace.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --cpu-reads 0 --no-cli --no-extras $* > "$OUT/trace.log" 2>&1
 i=1
 for set in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
