@@ -118,8 +118,9 @@ enum GmgOpt {
     GMG_OPT_MG_ORFS_EVENTS,      // glimmer-mg front half, default mode: 1 = the ORF scan's write pass queues the codons that are in a start or
                                  // stop set and runs the reference's steps over the queue (k_mg_find_orfs_ev), 0 = at every position
     GMG_OPT_MG_ERR_TILE,         // glimmer-mg's error branch: 1 = tile by tile with the running sums in LDS, one lane per event (k_mg_err_tile; needs
-                                 // mg_err_skip and sums that are exact in any order), 0 = the level kernels on the walk-order tables in HBM (default:
-                                 // measured faster)
+                                 // mg_err_skip and sums that are exact in any order), 0 = the level kernels on the walk-order tables in HBM, -1
+                                 // (default) = by the batch's size: the tile kernel up to 90 (-i) / 60 (-s) Mbases, the level kernels beyond
+                                 // 
     GMG_OPT_MG_ERR_TILE_Q,       // ... tests: calls per level a work-group's slab holds (0 = ET_QCAP; a full slab sends the batch to the level kernels);
                                  // any value but 0 also starts with staging arrays of 64 entries (-1: only that: the kernel repeats with larger ones)
     GMG_OPT_MG_ERR_QONLY,        // glimmer-mg -s on the level kernels: 1 = the running-sum table holds one value per base and strand (16 B/base), 0 = three (48)

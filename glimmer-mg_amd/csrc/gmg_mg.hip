@@ -3050,7 +3050,13 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     // builds the table then (k_mg_apply_nulls) before it falls back.
     // the error branch tile by tile (k_mg_err_tile: the running sums in LDS) wants what the running-sum form wants; reads longer than
     // a tile go to k_mg_err_flat, which walks the fp64 table
-    err_tile = err_mode && err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) && gmg_opt(GMG_OPT_MG_ERR_TILE) && !gmg_opt(GMG_OPT_MG_ERR_FLAT);
+    // Which of the two: measured on ragged ~400-bp reads (profiles/r04_errtile_crossover.txt), the tile kernel -- ONE launch, no table in
+    // HBM -- wins on batches up to ~200,000 reads (-i: 1.1 vs 2.4 ms at 5,000 reads, 3.4 vs 4.7 at 50,000, 11.3 vs 11.6 at 200,000), the
+    // level kernels from there on (22.1 vs 21.2 ms at 400,000, 54.3 vs 48.6 at 1M).  mg_err_tile: -1 (default) by the batch's size,
+    // 1 always, 0 never.
+    const long long tile_opt = gmg_opt(GMG_OPT_MG_ERR_TILE);
+    const bool tile_wanted = tile_opt > 0 || (tile_opt < 0 && a.total <= (err_mode == 1 ? (uint64_t)MG_ET_AUTO_BASES_INDEL : (uint64_t)MG_ET_AUTO_BASES_SUB));
+    err_tile = err_mode && err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) && tile_wanted && !gmg_opt(GMG_OPT_MG_ERR_FLAT);
     const uint64_t err_fit_len = err_tile ? MG_ET_CAP + 1 : 2040;       // reads shorter than this are walked by the tile / level kernels
     const bool err_g32 = err_mode && !d_frame_scores && a.total && g32_opt != 0 && nul_dense3 && all_fast && err_exact &&
                          gmg_opt(GMG_OPT_MG_ERR_SKIP) && !gmg_opt(GMG_OPT_MG_ERR_FLAT) && reads->max_len && reads->max_len < err_fit_len;

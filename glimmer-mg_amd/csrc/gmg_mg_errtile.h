@@ -67,6 +67,8 @@
 static_assert(ET_MAXO <= ET_BLOCK && ET_MAXO <= 256, "one lane per staged ORF record, its index in eight bits");
 static_assert(ET_CHUNK <= 4 * ET_BLOCK, "four calls per lane in the scan");
 static_assert(MG_ET_CAP <= 2048, "event entries hold the position in 11 bits");
+#define MG_ET_AUTO_BASES_INDEL 90000000ull   // mg_err_tile = -1: batches up to this many bases take the tile kernel (-i) ...
+#define MG_ET_AUTO_BASES_SUB 60000000ull     // ... (-s)
 #define ET_CHUNK_TILES 16        // tile builder: one lane lays out the tiles of 16 x CAP bases
 
 #ifndef GMG_ET_STAMPS
