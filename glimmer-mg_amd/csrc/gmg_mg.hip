@@ -3375,6 +3375,10 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             int n_cu = 0;
             MG_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id));
             et_grid = (unsigned)(n_cu > 0 ? ET_WG_PER_CU * n_cu : ET_WG_PER_CU * 256);
+            // (no more work-groups -- and slabs -- than (tile, strand) pairs: a tile that is closed before it is half full is closed by a
+            // read that did not fit, by its 64th read or by its chunk's end)
+            const uint64_t tiles_max = a.total / (MG_ET_CAP / 2) + nr / ET_MAXR + a.total / ((uint64_t)ET_CHUNK_TILES * MG_ET_CAP) + 2;
+            if (2 * tiles_max < et_grid) et_grid = (unsigned)(2 * tiles_max);
             MG_TRY(gmg_pool_alloc((void **)&d_et_tiles, (nr + 1) * sizeof(MgTile)));
             MG_TRY(gmg_pool_alloc((void **)&d_et_slabs, (size_t)et_grid * 2 * et_qcap * sizeof(MgCall)));
             MG_TRY(gmg_pool_alloc((void **)&d_et_em, (size_t)et_grid * et_ecap * sizeof(EtEm)));
