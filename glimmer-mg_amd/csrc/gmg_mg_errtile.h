@@ -69,6 +69,7 @@ static_assert(ET_CHUNK <= 4 * ET_BLOCK, "four calls per lane in the scan");
 static_assert(MG_ET_CAP <= 2048, "event entries hold the position in 11 bits");
 #define MG_ET_AUTO_BASES_INDEL 90000000ull   // mg_err_tile = -1: batches up to this many bases take the tile kernel (-i) ...
 #define MG_ET_AUTO_BASES_SUB 60000000ull     // ... (-s)
+#define ET_QNI 512                // calls per queue whose event count is also kept in LDS
 #define ET_CHUNK_TILES 16        // tile builder: one lane lays out the tiles of 16 x CAP bases
 
 #ifndef GMG_ET_STAMPS
@@ -158,6 +159,7 @@ struct EtLds {
     unsigned long long nxt_item, nxt_o[2], wmask[ET_BLOCK / 64];
     MgTile nxt_tile;
     uint16_t o_act[ET_MAXO];                            // the staged ORFs that have events (the level-0 calls)
+    uint16_t qni[2][ET_QNI];                            // event counts of the first calls of the two queues (the scan reads them here, not in the slab)
     // two event lists per class: [0] every event (the levels from which Score_Indels may branch), [1] without the events that
     // are LOWQ only (the last level: two events in three are of that kind, and there nothing happens at them)
     uint16_t fe[2][CAP + 8];                            // events of the class of u at positions below u = index of the first event at or behind u
@@ -167,6 +169,8 @@ struct EtLds {
     uint8_t fl[CAP + 8];                                // the flags of every position
     int8_t which[64];
 };
+
+static_assert(sizeof(EtLds<MG_ET_CAP>) * ET_WG_PER_CU <= 160 * 1024, "ET_WG_PER_CU work-groups must fit the CU's LDS");
 
 // a call as the items see it
 struct EtCall {
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(ET_BLOCK, ET_WAVES_PER_SIMD) void k_mg_err_tile(MgA
                     for (int x = 0; x < 4; x++) {
                         const uint32_t k = 4u * tid + (uint32_t)x;
                         v[x] = 0;
-                        if (k < nc) v[x] = level == 0 ? L.o_ev[L.o_act[cb + k]] >> 16 : (uint32_t)(q_in[cb + k].w[2] >> 32) & 0xfffu;
+                        if (k < nc) v[x] = level == 0 ? L.o_ev[L.o_act[cb + k]] >> 16 : cb + k < (uint32_t)ET_QNI ? (uint32_t)L.qni[level - 1][cb + k] : (uint32_t)(q_in[cb + k].w[2] >> 32) & 0xfffu;
                         tot4 += v[x];
                     }
                     uint32_t total = 0;
@@ -594,6 +598,7 @@ __global__ __launch_bounds__(ET_BLOCK, ET_WAVES_PER_SIMD) void k_mg_err_tile(MgA
                             child.w[2] = (uint64_t)c.rl | (uint64_t)u0c << 8 | (uint64_t)i0c << 20 | (uint64_t)nic << 32 | (uint64_t)(p0zc ? 1u : 0u) << 44;
                             child.w[3] = (uint64_t)c.oe | (uint64_t)ce0 << 32 | (uint64_t)ce1 << 46;
                             q_out[slot] = child;
+                            if (slot < (uint32_t)ET_QNI) L.qni[level][slot] = (uint16_t)nic;
                         };
                         if ((!is_tail || inclusive) && (f & (EV_START | EV_LOWQ))) {
                             // the codon at p: buffer positions j0, j0 + 1, j0 + 2 of the call
