@@ -10,8 +10,9 @@
 //     glimmer3_gpu <glimmer3 options> <fasta> <tag>          (GMG_DEVICE selects the GPU)
 // -L (Score_Orflist, glimmer3.cc:1177-1271) and -M (Score_Separate_Input, :1555-1628) are batched too: every ORF of the coordinate
 // list / every sequence of the file is one segment of ONE gmg_score_string call per model (score [m-4] of Cumulative_Score is
-// Score_String of the buffer's first m-3 bases).  -i (ignore regions) and circular genomes select loops that are not batched here:
-// such a command line is handed to glimmer3_dropin (same directory), as are coordinate lists with wrap-around entries.
+// Score_String of the buffer's first m-3 bases).  -i (ignore regions, glimmer_base.cc:689-731,833-943): the ORF lists come from the
+// reference's own Find_Orfs on the host, the scoring of all of them is the same single gmg_score_orfs call.  Coordinate lists with
+// wrap-around entries are handed to glimmer3_dropin (same directory).
 //
 // Output: <tag>.predict, byte-identical to the reference's (tests/test_gpu_dropin_cli.py).
 
@@ -57,8 +58,7 @@ static void load_sequence(const vector<string> &seq_list, const vector<string> &
     Sequence_Len = Sequence.length();
 }
 
-// The modes whose loops are not batched here -- -M (every input sequence is one gene: Score_Separate_Input, glimmer3.cc:1555-1628),
-// -L (ORFs from a coordinate file: Score_Orflist, :1177-1271) and -i (ignore regions in Find_Orfs, glimmer_base.cc:833-943) -- run
+// What is not batched here -- coordinate lists (-L) with entries that wrap around the sequence's end or leave it -- runs
 // in glimmer3_dropin beside this binary: the reference's own main() on the device-backed ICM_t (one launch per ICM_t call; same
 // bytes).  It is started as a CHILD (posix_spawn + waitpid) and its exit status handed on: under a profiler this process may
 // have initialised the GPU before main(), and replacing a GPU-initialised process (exec*) is what this pool forbids.
@@ -199,7 +199,8 @@ int main(int argc, char **argv)
     if (argc < 3) { fprintf(stderr, "usage: glimmer3_gpu <glimmer3 options> <fasta> <tag>\n"); return 2; }
     try {
         setup_options(argc, argv);
-        if (Ignore_File_Name != NULL || Genome_Is_Circular) return run_dropin("glimmer3_dropin", argv);
+        if (Genome_Is_Circular) return run_dropin("glimmer3_dropin", argv);      // (no option of this glimmer3 sets it: glimmer3.cc:53,874,959)
+        if (Ignore_File_Name != NULL) Get_Ignore_Regions();                        // (glimmer3.cc:179-180)
         if (Separate_Orf_Input || Orflist_File_Name != NULL) {
             if (Orflist_File_Name != NULL && !Separate_Orf_Input) Get_Orf_Pos_List();      // (glimmer3.cc:182-183)
             const int rc = run_orf_scores_batched(argv);
@@ -241,6 +242,21 @@ int main(int argc, char **argv)
             sq.resize(off[i + 1] - off[i]);
             for (uint64_t k = 0; k < sq.size(); k++) { const uint64_t g = off[i] + k; sq[k] = "acgt"[(packed[g >> 4] >> (2 * (g & 15))) & 3]; }
         }
+        vector<vector<Orf_t> > all_orfs(Sequence_Ct);
+        vector<gmg_orf> orfs;
+        if (Ignore_File_Name != NULL) {
+            // -i: the ORFs of a sequence depend on the ignore regions (glimmer_base.cc:689-731: the scan starts anew behind every
+            // region).  That list is the reference's own Find_Orfs, run here on the filtered bases (a linear pass over a genome: the
+            // ignore coordinates are those of ONE sequence); the scoring of all ORFs stays ONE device call below.
+            for (int i = 0; i < Sequence_Ct; i++) {
+                load_sequence(seq_list, hdr_list, i);
+                Find_Orfs(all_orfs[i]);
+                for (size_t o = 0; o < all_orfs[i].size(); o++) {
+                    gmg_orf g = {(uint32_t)i, all_orfs[i][o].Get_Frame(), all_orfs[i][o].Get_Stop_Position(), all_orfs[i][o].Get_Orf_Len()};
+                    orfs.push_back(g);
+                }
+            }
+        } else {
         gmg_mg_params fprm;
         memset(&fprm, 0, sizeof fprm);
         fprm.min_gene_len = Min_Gene_Len;
@@ -257,8 +273,6 @@ int main(int argc, char **argv)
         vector<uint64_t> first(Sequence_Ct + 1);
         if (gmg_mg_result_fetch(found, frec.data(), NULL, first.data()) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
         gmg_mg_result_free(found);
-        vector<vector<Orf_t> > all_orfs(Sequence_Ct);
-        vector<gmg_orf> orfs;
         for (int i = 0; i < Sequence_Ct; i++)
             for (uint64_t o = first[i]; o < first[i + 1]; o++) {
                 Orf_t orf;
@@ -270,6 +284,7 @@ int main(int argc, char **argv)
                 gmg_orf g = {(uint32_t)i, frec[o].frame, frec[o].stop_position, frec[o].orf_len};
                 orfs.push_back(g);
             }
+        }
         // ONE batch call for the Score_Orfs inner loops of all reads
         gmg_orf_params prm;
         memset(&prm, 0, sizeof prm);

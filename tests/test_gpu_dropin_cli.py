@@ -84,13 +84,16 @@ def _write_fasta(path, records):
                 f.write(s[i:i + 70] + "\n")
 
 
-@pytest.mark.parametrize("mode", ["separate_input", "orflist", "orflist_wrap", "ignore_regions", "mg_circular"])
+@pytest.mark.parametrize("mode", ["separate_input", "orflist", "orflist_wrap", "ignore_regions", "ignore_regions_truncated", "mg_circular"])
 def test_modes_outside_the_default_loop(gpu, tmp_path, mode):
     """glimmer3 -M (every input sequence is one gene, Score_Separate_Input) and -L (ORFs from a coordinate file, Score_Orflist) are
-    batched by glimmer3_gpu: one gmg_score_string call per model for all entries.  -i (ignore regions), glimmer-mg -r (circular
-    genome) and coordinate lists with an entry that is no plain segment of the sequence (wrap-around, out of range) are handed to
-    the *_dropin binary beside the driver (the reference's own main() on the device-backed ICM_t, started as a child process).  The
-    bytes must be the all-reference binary's in every case."""
+    batched by glimmer3_gpu: one gmg_score_string call per model for all entries.  -i (ignore regions): the ORF lists are the
+    reference's own Find_Orfs on the host, all ORFs scored by ONE gmg_score_orfs call.  Those three must work WITHOUT the drop-in
+    binary (the driver is run from a directory that holds nothing else).  glimmer-mg -r (circular genome) and coordinate lists
+    with an entry that is no plain segment of the sequence (wrap-around, out of range) are handed to the *_dropin binary beside the
+    driver (the reference's own main() on the device-backed ICM_t, started as a child process).  The bytes must be the all-reference
+    binary's in every case."""
+    import shutil
     import numpy as np
     rng = np.random.default_rng(21)
     icm = os.path.join(DATA, "NC_000915.icm")
@@ -126,13 +129,27 @@ def test_modes_outside_the_default_loop(gpu, tmp_path, mode):
         with open(ign, "w") as f:
             f.write("# lo hi\n2000 3500\n9000 8000\n15000 15100\n")
         extra = ["-i", ign]
+    elif mode == "ignore_regions_truncated":            # several sequences (the same regions apply to each), -X, overlapping regions, one at the very start
+        g = _genome()
+        _write_fasta(fa, [("c1", g[100_000:112_000]), ("c2 second", g[500_000:503_001]), ("c3", g[900_000:900_900])])
+        ign = str(tmp_path / "ignore.txt")
+        with open(ign, "w") as f:
+            f.write("1 40\n700 1300\n1200 1500\n2990 3005\n11000 13000\n")
+        extra = ["-X", "-i", ign]
     else:
         g = _genome()
         _write_fasta(fa, [("plasmid", g[700_000:712_000]), ("plasmid2", g[900_000:904_000])])
         extra = ["-r"]
     out = []
+    env = dict(os.environ)
+    if mode in ("separate_input", "orflist", "ignore_regions", "ignore_regions_truncated"):
+        alone = tmp_path / "alone"
+        alone.mkdir()
+        shutil.copy(dev, str(alone / "glimmer3_gpu"))
+        dev = str(alone / "glimmer3_gpu")
+        env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "glimmer-mg_amd", "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
     for exe, tag in ((ref, "a"), (dev, "b")):
-        res = subprocess.run([exe, *extra, "-m", icm, fa, str(tmp_path / tag)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        res = subprocess.run([exe, *extra, "-m", icm, fa, str(tmp_path / tag)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
         if mode == "orflist_wrap":
             # the reference itself cannot do this (Sequence_Len is not set in the -L branch: Reverse_Transfer's assertion, glimmer_base.cc:2517);
             # the driver must end the same way -- through the drop-in, not with a made-up score
