@@ -1105,7 +1105,7 @@ extern "C" int gmg_debug_mt_stamps(unsigned long long *out, int reset)
 #endif
 
 #ifndef MT_MIN_WAVES
-#define MT_MIN_WAVES 1           // waves per SIMD the register allocation aims at
+#define MT_MIN_WAVES 4           // waves per SIMD the register allocation aims at where the LDS allows as many (GENE32 table, one null model)
 #endif
 #define MT_EL 9                  // chain elements per lane (the kernel's EL: 9, or 8 when 504 bases per wave hold the batch's reads as well)
 #define MT_CL 21                 // lanes per class
@@ -1137,8 +1137,15 @@ struct MtTile { uint64_t w0; uint32_t first, nfit, span, o0, o1, rn0; };    // r
 // tables (icm.cc:807-842): the last two bases of a read on the forward strand, its first two on the reverse strand.
 // EL: elements per lane: 9 (567 bases per wave), or 8 (504) when that holds the batch's reads -- 500-bp reads: a ninth less of every loop
 // (nine elements: three waves per SIMD asked for -- 168 registers, three of them spilled, against 173 and two waves)
-template <int NW, bool G32, int EL>
-__global__ __launch_bounds__(64 * NW, EL == 9 ? 3 : MT_MIN_WAVES) void k_mg_tile_starts(MgArgs a)
+// Round 4: with one null model for the batch (PRN false: 6 KB less LDS) and the GENE32 table, FOUR waves per SIMD -- 127 / 128 registers with 4 / 14
+// spilled, 20.3 KB (two waves, eight elements) / 40.9 KB (four waves, nine) of LDS = 8 / 4 work-groups per CU: 10.25 -> 9.15 ms per 1 M x 500 bp
+// (the fp64-table form would spill 88 - 136 registers at 128: it keeps three / two waves; nine elements at 128 registers spill 14: 10.1 vs 9.9 ms on
+// ragged reads, kept at three waves -- ragged batches whose reads fit take the eight-element form instead).  Tried with it: the rows staged with
+// 16-byte loads (four consecutive bases per lane: 6 loads per lane and tile instead of 24) -- bit-exact, 9.27 vs 9.20 / 9.75 vs 9.62 ms: the
+// unaligned wide loads cost more than the shorter queue saves; dropped.
+// PRN: a null model per read (a.read_null; GENE32 only) -- the tables of the tile's reads live in LDS then (6 KB), one table for the batch otherwise (2 KB)
+template <int NW, bool G32, int EL, bool PRN>
+__global__ __launch_bounds__(64 * NW, G32 && !PRN && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 3 : 1) void k_mg_tile_starts(MgArgs a)
 {
     constexpr int BLOCK = 64 * NW, WV = 3 * MT_CL * EL, CAP = WV * NW;
     constexpr int NPK = CAP / 16 + 7;                                   // packed words staged (two in front, the windows of stage 2 behind)
@@ -1152,7 +1159,8 @@ __global__ __launch_bounds__(64 * NW, EL == 9 ? 3 : MT_MIN_WAVES) void k_mg_tile
     __shared__ int32_t s_isl[MG_TILE_READS];
     __shared__ uint8_t s_whf[64], s_whr[64];                             // which + 1 of the codon field C (see stage 2), forward / reverse strand
     __shared__ unsigned long long s_obest[MT_ORFS];
-    __shared__ uint32_t s_oso[MT_ORFS], s_ont[MT_ORFS], s_ofj[MT_ORFS];
+    __shared__ uint32_t s_oso[MT_ORFS], s_ont[MT_ORFS];
+    __shared__ uint16_t s_ofj[MT_ORFS];                                 // (j + 2 of an ORF's first start: below the tile's width)
     __shared__ double s_wsum[NW][3];
     __shared__ uint32_t s_wp[NW][3];
     __shared__ uint32_t s_nq;
@@ -1161,8 +1169,8 @@ __global__ __launch_bounds__(64 * NW, EL == 9 ? 3 : MT_MIN_WAVES) void k_mg_tile
     // v = S[x-2] | S[x-1] << 2 | S[x] << 4 (complemented read) -- and the partial-window tables as they are
     // ([0] forward, [1] reverse, each followed by the partial-window tables).  With a null model per read (a.read_null) the tables of
     // the tile's reads (MT_NC at most in this mode) are fetched with the tile, in the order of the strand it works on.
-    __shared__ float s_null1[G32 ? 2 : 1][G32 ? MG_NULL_FLOATS : 1], s_nullm[G32 ? MT_NC : 1][G32 ? MG_NULL_FLOATS : 1];
-    __shared__ uint32_t s_rnull[G32 ? MG_TILE_READS : 1];
+    __shared__ float s_null1[G32 && !PRN ? 2 : 1][G32 && !PRN ? MG_NULL_FLOATS : 1], s_nullm[G32 && PRN ? MT_NC : 1][G32 && PRN ? MG_NULL_FLOATS : 1];
+    __shared__ uint32_t s_rnull[G32 && PRN ? MG_TILE_READS : 1];
 
     const uint32_t tid = threadIdx.x;
     // entry e of a table in the strand's order <- entry of the (3,2,3) model's table as gmg_null_set / gmg_model_upload lay it out
@@ -1171,7 +1179,7 @@ __global__ __launch_bounds__(64 * NW, EL == 9 ? 3 : MT_MIN_WAVES) void k_mg_tile
         return e >= 192u ? e : (e & ~63u) + (fwd_order ? (v & 3u) << 4 | (v & 12u) | v >> 4      // window w[k]: B[j-2], B[j-1], B[j] = S[x+2], S[x+1], S[x]
                                                        : v ^ 63u);                               // ... = comp S[x-2], comp S[x-1], comp S[x]
     };
-    if (G32 && !a.read_null)
+    if (G32 && !PRN)
         for (uint32_t i = tid; i < MG_NULL_FLOATS; i += BLOCK) {
             s_null1[0][i] = a.null_tab[null_src(i, true)];
             s_null1[1][i] = a.null_tab[null_src(i, false)];
@@ -1217,7 +1225,7 @@ __global__ __launch_bounds__(64 * NW, EL == 9 ? 3 : MT_MIN_WAVES) void k_mg_tile
         const uint32_t *roo = (const uint32_t *)(a.read_orf_off + vzero);      // (low words: a batch has less than 2^31 ORFs)
         t.o0 = roo[2 * (uint64_t)t.first];
         t.o1 = roo[2 * ((uint64_t)t.first + t.nfit)];
-        if (G32 && a.read_null) t.rn0 = (a.read_null + vzero)[t.first];
+        if (G32 && PRN) t.rn0 = (a.read_null + vzero)[t.first];
     };
     // every global load of a tile is issued one tile ahead
     typename std::conditional<G32, float, double>::type tmp[3][EL];
@@ -1280,9 +1288,9 @@ __global__ __launch_bounds__(64 * NW, EL == 9 ? 3 : MT_MIN_WAVES) void k_mg_tile
             const uint32_t i = tid + (uint32_t)BLOCK * u;
             tro[u] = i <= nfit ? ((const uint32_t *)(a.read_off + first))[2 * i] : 0u;        // (the low word is all that is needed)
             tis[u] = a.read_isl && i < nfit ? (a.read_isl + first)[i] : a.ignore_score_len;
-            trn[u] = G32 && a.read_null && i < nfit ? (a.read_null + first)[i] : 0u;
+            trn[u] = G32 && PRN && i < nfit ? (a.read_null + first)[i] : 0u;
         }
-        if (G32 && a.read_null) {                       // (its index came with the tile's geometry: no wait here)
+        if (G32 && PRN) {                       // (its index came with the tile's geometry: no wait here)
             const float *nt = a.null_tab + (size_t)__builtin_amdgcn_readfirstlane(t.rn0) * MG_NULL_FLOATS;
 #pragma unroll
             for (int u = 0; u < PN1; u++) {
@@ -1341,9 +1349,9 @@ __global__ __launch_bounds__(64 * NW, EL == 9 ? 3 : MT_MIN_WAVES) void k_mg_tile
                 const uint32_t i = tid + (uint32_t)BLOCK * u;
                 if (i <= nfit) s_roff[i] = tro[u] - w0_lo;
                 if (i < nfit) s_isl[i] = tis[u];
-                if (G32 && i < nfit) s_rnull[i] = trn[u];
+                if (G32 && PRN && i < nfit) s_rnull[i] = trn[u];
             }
-            if (G32 && a.read_null) {
+            if (G32 && PRN) {
 #pragma unroll
                 for (int u = 0; u < PN1; u++) {
                     const uint32_t e = tid + (uint32_t)BLOCK * u;
@@ -1400,7 +1408,7 @@ __global__ __launch_bounds__(64 * NW, EL == 9 ? 3 : MT_MIN_WAVES) void k_mg_tile
                 orf_geo(rd, lo, hi, trunc, m, uh);
                 if (m > 0) s_oinfo[uh] = (uint16_t)(e + 1);
             }
-            if (G32 && a.read_null) {
+            if (G32 && PRN) {
                 const uint32_t nc = nfit < MT_NC ? nfit : MT_NC;
                 for (uint32_t i = MG_NULL_FLOATS + tid; i < nc * MG_NULL_FLOATS; i += BLOCK) {       // (the first read's came with the tile)
                     const uint32_t rl = i / MG_NULL_FLOATS, e = i - rl * MG_NULL_FLOATS;
@@ -1469,7 +1477,7 @@ __global__ __launch_bounds__(64 * NW, EL == 9 ? 3 : MT_MIN_WAVES) void k_mg_tile
                         const int bitb = FWD ? 2 * FW0 - 6 * i : 6 * i + 6;             // bit position of S[b] in the window
                         // entry `off` of the read's table in this strand's order
                         auto nullv = [&](uint32_t off, uint32_t) __attribute__((always_inline)) {
-                            if (!a.read_null) return s_null1[FWD ? 0 : 1][off];
+                            if (!PRN) return s_null1[FWD ? 0 : 1][off];
                             return s_nullm[rl < MT_NC ? rl : 0u][off];               // (mg_run lets a tile take MT_NC reads at most then)
                         };
                         double nsum;
@@ -1613,7 +1621,7 @@ __global__ __launch_bounds__(64 * NW, EL == 9 ? 3 : MT_MIN_WAVES) void k_mg_tile
                 st.which = (int32_t)(qe >> 12) - 1; st.truncated = 0; st.first = slot == 0 ? 1 : 0;
                 a.starts[(uint64_t)s_oso[e - e0] + slot] = st;
                 atomicMax(&s_obest[e - e0], (unsigned long long)mg_ord(sc));
-                if (slot == 0) s_ofj[e - e0] = (uint32_t)(j + 2);
+                if (slot == 0) s_ofj[e - e0] = (uint16_t)(j + 2);
             }
             __syncthreads();
             for (uint32_t i = tid; i < MT_ORFS && e0 + i < n_orf; i += BLOCK) {
@@ -3030,6 +3038,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
                 const int l = reads->uniform_len, c8 = 504 * fused_nw, c9 = (int)MT_W * fused_nw;
                 if (l <= c8 && (c8 / l) * 9 >= (c9 / l) * 8) fused_el = 8;
             }
+            // ragged batches too when no read needs the wider tile: the eight-element form runs four waves per SIMD (9.76 -> 9.54 ms per 1 M x ~400 bp)
+            else if (fused_nw && reads->max_len && reads->max_len <= (uint64_t)504 * fused_nw) fused_el = 8;
         }
     }
     // (the fused kernel reads whichever table there is.  Measured, 1M x 500 bp, one null model: the fp64 table 4.9 + 6.2 ms, the
@@ -3543,7 +3553,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             hipLaunchKernelGGL(k_mg_starts_unfit, dim3(grid_for(a.n_reads / 16 + 1)), dim3(256), 0, s2, a);
             MG_TRY(hipEventRecord(side_done, s2));
         }
-#define MG_LAUNCH_TILE(NW_, G_, EL_) hipLaunchKernelGGL((k_mg_tile_starts<NW_, G_, EL_>), dim3(grid), dim3(64 * NW_), 0, s, a)
+#define MG_LAUNCH_TILE(NW_, G_, EL_) do { if (G_ && a.read_null) hipLaunchKernelGGL((k_mg_tile_starts<NW_, G_, EL_, G_>), dim3(grid), dim3(64 * NW_), 0, s, a); \
+                                          else hipLaunchKernelGGL((k_mg_tile_starts<NW_, G_, EL_, false>), dim3(grid), dim3(64 * NW_), 0, s, a); } while (0)
 #define MG_LAUNCH_TILE_EL(NW_, G_) do { if (fused_el == 8) MG_LAUNCH_TILE(NW_, G_, 8); else MG_LAUNCH_TILE(NW_, G_, 9); } while (0)
         if (a.gene32) {
             if (fused_nw == 1) MG_LAUNCH_TILE_EL(1, true); else if (fused_nw == 2) MG_LAUNCH_TILE_EL(2, true); else MG_LAUNCH_TILE_EL(4, true);
