@@ -1145,7 +1145,7 @@ struct MtTile { uint64_t w0; uint32_t first, nfit, span, o0, o1, rn0; };    // r
 // unaligned wide loads cost more than the shorter queue saves; dropped.
 // PRN: a null model per read (a.read_null; GENE32 only) -- the tables of the tile's reads live in LDS then (6 KB), one table for the batch otherwise (2 KB)
 template <int NW, bool G32, int EL, bool PRN>
-__global__ __launch_bounds__(64 * NW, G32 && !PRN && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 3 : 1) void k_mg_tile_starts(MgArgs a)
+__global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 3 : 1) void k_mg_tile_starts(MgArgs a)
 {
     constexpr int BLOCK = 64 * NW, WV = 3 * MT_CL * EL, CAP = WV * NW;
     constexpr int NPK = CAP / 16 + 7;                                   // packed words staged (two in front, the windows of stage 2 behind)
@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(64 * NW, G32 && !PRN && EL == 8 ? MT_MIN_WAVES : EL
     // ([0] forward, [1] reverse, each followed by the partial-window tables).  With a null model per read (a.read_null) the tables of
     // the tile's reads (MT_NC at most in this mode) are fetched with the tile, in the order of the strand it works on.
     __shared__ float s_null1[G32 && !PRN ? 2 : 1][G32 && !PRN ? MG_NULL_FLOATS : 1], s_nullm[G32 && PRN ? MT_NC : 1][G32 && PRN ? MG_NULL_FLOATS : 1];
-    __shared__ uint32_t s_rnull[G32 && PRN ? MG_TILE_READS : 1];
+    __shared__ uint32_t s_rnull[G32 && PRN ? MT_NC + 2 : 1];               // (a tile takes MT_NC reads at most in that mode)
 
     const uint32_t tid = threadIdx.x;
     // entry e of a table in the strand's order <- entry of the (3,2,3) model's table as gmg_null_set / gmg_model_upload lay it out
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(64 * NW, G32 && !PRN && EL == 8 ? MT_MIN_WAVES : EL
                 const uint32_t i = tid + (uint32_t)BLOCK * u;
                 if (i <= nfit) s_roff[i] = tro[u] - w0_lo;
                 if (i < nfit) s_isl[i] = tis[u];
-                if (G32 && PRN && i < nfit) s_rnull[i] = trn[u];
+                if (G32 && PRN && i < nfit && i < MT_NC) s_rnull[i] = trn[u];
             }
             if (G32 && PRN) {
 #pragma unroll
