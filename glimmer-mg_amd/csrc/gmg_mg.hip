@@ -1157,7 +1157,8 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
     __shared__ uint32_t s_packed[NPK];
     __shared__ uint32_t s_roff[MG_TILE_READS + 1];
     __shared__ int32_t s_isl[MG_TILE_READS];
-    __shared__ uint8_t s_whf[64], s_whr[64];                             // which + 1 of the codon field C (see stage 2), forward / reverse strand
+    // (a work-group works on ONE strand: the grid is even and k advances by it, so the strand is blockIdx.x's parity -- one copy of the strand's tables)
+    __shared__ uint8_t s_wh[64];                                        // which + 1 of the codon field C (see stage 2) | 0x80: C is a stop codon, in the strand's order
     __shared__ unsigned long long s_obest[MT_ORFS];
     __shared__ uint32_t s_oso[MT_ORFS], s_ont[MT_ORFS];
     __shared__ uint16_t s_ofj[MT_ORFS];                                 // (j + 2 of an ORF's first start: below the tile's width)
@@ -1169,7 +1170,9 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
     // v = S[x-2] | S[x-1] << 2 | S[x] << 4 (complemented read) -- and the partial-window tables as they are
     // ([0] forward, [1] reverse, each followed by the partial-window tables).  With a null model per read (a.read_null) the tables of
     // the tile's reads (MT_NC at most in this mode) are fetched with the tile, in the order of the strand it works on.
-    __shared__ float s_null1[G32 && !PRN ? 2 : 1][G32 && !PRN ? MG_NULL_FLOATS : 1], s_nullm[G32 && PRN ? MT_NC : 1][G32 && PRN ? MG_NULL_FLOATS : 1];
+    __shared__ double s_nulld[G32 && !PRN ? 192 : 1];                   // one null model: the full-window values as doubles (no conversion per look-up), ...
+    __shared__ float s_nullp[G32 && !PRN ? MG_NULL_FLOATS - 192 : 1];   // ... the partial-window tables
+    __shared__ float s_nullm[G32 && PRN ? MT_NC : 1][G32 && PRN ? MG_NULL_FLOATS : 1];
     __shared__ uint32_t s_rnull[G32 && PRN ? MT_NC + 2 : 1];               // (a tile takes MT_NC reads at most in that mode)
 
     const uint32_t tid = threadIdx.x;
@@ -1179,17 +1182,18 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
         return e >= 192u ? e : (e & ~63u) + (fwd_order ? (v & 3u) << 4 | (v & 12u) | v >> 4      // window w[k]: B[j-2], B[j-1], B[j] = S[x+2], S[x+1], S[x]
                                                        : v ^ 63u);                               // ... = comp S[x-2], comp S[x-1], comp S[x]
     };
+    const bool fwd_wg = (blockIdx.x & 1u) == 0;
     if (G32 && !PRN)
         for (uint32_t i = tid; i < MG_NULL_FLOATS; i += BLOCK) {
-            s_null1[0][i] = a.null_tab[null_src(i, true)];
-            s_null1[1][i] = a.null_tab[null_src(i, false)];
+            const float v = a.null_tab[null_src(i, fwd_wg)];
+            if (i < 192u) s_nulld[i] = (double)v; else s_nullp[i - 192u] = v;
         }
     const uint64_t n_tiles = a.n_tiles_dev ? (uint64_t)*a.n_tiles_dev : a.n_tiles;
     if (tid < 64) {
         // forward: the codon (b-2, b-1, b) as Codon_t holds it = the field with its pairs reversed; reverse: the complement of
         // (b+2, b+1, b) = the field itself, complemented
-        s_whf[tid] = (uint8_t)(a.which[(tid & 3u) << 4 | (tid & 12u) | tid >> 4] + 1);
-        s_whr[tid] = (uint8_t)(a.which[tid ^ 63u] + 1);
+        const uint32_t wh = (uint32_t)(a.which[fwd_wg ? (tid & 3u) << 4 | (tid & 12u) | tid >> 4 : tid ^ 63u] + 1);
+        s_wh[tid] = (uint8_t)(wh | (((fwd_wg ? a.fwd_stop_nat : a.rev_stop_nat) >> tid) & 1ull ? 0x80u : 0u));
     }
     const int mgl = a.min_gene_len;
     int j_lo = mgl - 3 > 1 ? mgl - 3 : 1;               // as in mg_starts_one
@@ -1259,10 +1263,14 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
         const uint32_t d2 = fwd ? 1u : 3u, d0 = fwd ? 0u : 4u;                 // b -/+ 1 and b -/+ 2, + 2
         if (lo_lim == 0 && hi_lim >= (uint32_t)(EL * BLOCK) + 3u) {         // (every tile but the batch's first and last few)
             // no test against the span: a lane beyond it reads the next tile's entries (they are on their way anyway) and nobody uses them
+            // (scalar row pointers + ONE 32-bit byte offset per lane + an immediate per element: no address arithmetic per load --
+            // with 64-bit lane addresses every load cost four vector instructions, a tenth of the kernel's)
+            const char *c1 = (const char *)p1, *c2 = (const char *)(p2 + d2), *c0 = (const char *)(p0 + d0);
+            const uint32_t t4 = (uint32_t)sizeof(row_t) * tid;
 #pragma unroll
             for (int i = 0; i < EL; i++) {
-                const uint32_t b = tid + (uint32_t)BLOCK * i;
-                tmp[1][i] = p1[b]; tmp[2][i] = p2[b + d2]; tmp[0][i] = p0[b + d0];
+                const uint32_t bo = t4 + (uint32_t)(sizeof(row_t) * BLOCK * i);
+                tmp[1][i] = *(const row_t *)(c1 + bo); tmp[2][i] = *(const row_t *)(c2 + bo); tmp[0][i] = *(const row_t *)(c0 + bo);
             }
         } else {
 #pragma unroll
@@ -1451,8 +1459,10 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                 const uint64_t win = (uint64_t)whi << 32 | wlo;                    // base sb + t at bits 2t
                 uint32_t rl = 0; int rs = 0, n = 0;
                 if ((uint32_t)b0 < span) read_of((uint32_t)b0, rl, rs, n);
-                const uint64_t stops = FWD ? a.fwd_stop_nat : a.rev_stop_nat;
-                const uint8_t *wht = FWD ? s_whf : s_whr;
+                // the table bytes of the EL + 1 codon fields this lane's elements meet (element i: stop test on one, start test on the next)
+                uint32_t wb[EL + 1];
+#pragma unroll
+                for (int t = 0; t <= EL; t++) wb[t] = s_wh[(uint32_t)(win >> (6 * t)) & 63u];
 #pragma unroll
                 for (int i = 0; i < EL; i++) {
                     const uint32_t u = ub + 3 * i;
@@ -1463,22 +1473,25 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                         else while (b >= rs + n) { rl++; rs = (int)s_roff[rl]; n = (int)s_roff[rl + 1] - rs; }
                     }
                     const int si = b - rs;
-                    const uint32_t cs = (uint32_t)(win >> (6 * (FWD ? EL - i : i))) & 63u;
-                    const uint32_t cw = (uint32_t)(win >> (6 * (FWD ? EL - 1 - i : i + 1))) & 63u;
-                    const bool st = !valid || (FWD ? si + 3 >= n : si < 3) || ((stops >> cs) & 1ull);
+                    const uint32_t bs = wb[FWD ? EL - i : i], bw = wb[FWD ? EL - 1 - i : i + 1];
+                    const bool st = !valid || (FWD ? si + 3 >= n : si < 3) || (bs & 0x80u);
                     const bool geo = FWD ? si >= 2 : si + 2 <= n - 1;
-                    const uint32_t wh = wht[cw];
+                    const uint32_t wh = bw & 0x7fu;
                     // (a codon may be in the start set AND in the stop set -- "-A nnn": the stop codon that ends a region is no start)
-                    const uint32_t cand = valid && geo && wh != 0 && !((stops >> cw) & 1ull) ? 1u : 0u;
+                    const uint32_t cand = valid && geo && bw - 1u < 0x7fu ? 1u : 0u;
                     double T = s_val[u];
                     if (G32 && valid) {
                         // T holds the gene model's three values; the null model's: sub-model 1 at x = b, 2 at x = b -/+ 1, 0 at
                         // x = b -/+ 2 (forward / reverse), buffer position j = n-1-x / x
                         const int bitb = FWD ? 2 * FW0 - 6 * i : 6 * i + 6;             // bit position of S[b] in the window
                         // entry `off` of the read's table in this strand's order
-                        auto nullv = [&](uint32_t off, uint32_t) __attribute__((always_inline)) {
-                            if (!PRN) return s_null1[FWD ? 0 : 1][off];
-                            return s_nullm[rl < MT_NC ? rl : 0u][off];               // (mg_run lets a tile take MT_NC reads at most then)
+                        auto nullv = [&](uint32_t off, uint32_t) __attribute__((always_inline)) -> double {
+                            if (!PRN) return off < 192u ? s_nulld[off] : (double)s_nullp[off - 192u];
+                            return (double)s_nullm[rl < MT_NC ? rl : 0u][off];       // (mg_run lets a tile take MT_NC reads at most then)
+                        };
+                        auto nullf = [&](uint32_t off) __attribute__((always_inline)) -> double {        // a full-window entry
+                            if (!PRN) return s_nulld[off];
+                            return (double)s_nullm[rl < MT_NC ? rl : 0u][off];
                         };
                         double nsum;
                         if (FWD ? si + 2 >= n : si < 2) {                          // one of them is a partial window
@@ -1494,13 +1507,13 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                                 const uint32_t b0c = FWD ? c0 : c0 ^ 3u, b1c = FWD ? c1 : c1 ^ 3u;
                                 const uint32_t v = (uint32_t)(win >> (FWD ? bx : bx - 4)) & 63u;
                                 const uint32_t off = j >= 2 ? fr * 64 + v : 192u + fr * 20 + (j == 1 ? 4u + (b1c | b0c << 2) : b0c);
-                                const float nv = nullv(off, v);
-                                nsum += xs >= 0 && xs < n ? (double)nv : 0.0;      // (beyond the read: T is never used then)
+                                const double nv = nullv(off, v);
+                                nsum += xs >= 0 && xs < n ? nv : 0.0;              // (beyond the read: T is never used then)
                             }
                         } else {
                             const uint32_t v1 = (uint32_t)(win >> (FWD ? bitb : bitb - 4)) & 63u, v2 = (uint32_t)(win >> (bitb - 2)) & 63u;
                             const uint32_t v0 = (uint32_t)(win >> (FWD ? bitb - 4 : bitb)) & 63u;
-                            nsum = ((double)nullv(64 + v1, v1) + (double)nullv(128 + v2, v2)) + (double)nullv(v0, v0);
+                            nsum = (nullf(64 + v1) + nullf(128 + v2)) + nullf(v0);
                         }
                         T -= nsum;
                     }
@@ -3543,7 +3556,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 1);
     } else if (no && err_mode) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 0);
     else if (no && fused_nw) {
-        const unsigned grid = (unsigned)(2 * a.n_tiles < 64 * 1024 ? 2 * a.n_tiles : 64 * 1024);
+        const unsigned grid = (unsigned)(2 * a.n_tiles < 64 * 1024 ? 2 * a.n_tiles : 64 * 1024);     // (even: a work-group keeps its strand)
         // the few reads no tile takes (one lane per read, long loops): beside the tile kernel on the side stream, behind their
         // running sums (k_mg_cum, queued on the caller's stream long ago)
         const bool unfit_aside = fused_rest && s2 != s;
