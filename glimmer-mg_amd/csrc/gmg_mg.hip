@@ -1144,7 +1144,9 @@ struct MtTile { uint64_t w0; uint32_t first, nfit, span, o0, o1, rn0; };    // r
 // 16-byte loads (four consecutive bases per lane: 6 loads per lane and tile instead of 24) -- bit-exact, 9.27 vs 9.20 / 9.75 vs 9.62 ms: the
 // unaligned wide loads cost more than the shorter queue saves; dropped.
 // PRN: a null model per read (a.read_null; GENE32 only) -- the tables of the tile's reads live in LDS then (6 KB), one table for the batch otherwise (2 KB)
-template <int NW, bool G32, int EL, bool PRN>
+// NC: the per-read null tables held (PRN): MT_NC, or 2 when the batch's reads let a tile take two at most (uniform 500-bp reads in two-wave tiles:
+// 4 KB less LDS = eight work-groups per CU there too)
+template <int NW, bool G32, int EL, bool PRN, int NC = MT_NC>
 __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 3 : 1) void k_mg_tile_starts(MgArgs a)
 {
     constexpr int BLOCK = 64 * NW, WV = 3 * MT_CL * EL, CAP = WV * NW;
@@ -1172,8 +1174,8 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
     // the tile's reads (MT_NC at most in this mode) are fetched with the tile, in the order of the strand it works on.
     __shared__ double s_nulld[G32 && !PRN ? 192 : 1];                   // one null model: the full-window values as doubles (no conversion per look-up), ...
     __shared__ float s_nullp[G32 && !PRN ? MG_NULL_FLOATS - 192 : 1];   // ... the partial-window tables
-    __shared__ float s_nullm[G32 && PRN ? MT_NC : 1][G32 && PRN ? MG_NULL_FLOATS : 1];
-    __shared__ uint32_t s_rnull[G32 && PRN ? MT_NC + 2 : 1];               // (a tile takes MT_NC reads at most in that mode)
+    __shared__ float s_nullm[G32 && PRN ? NC : 1][G32 && PRN ? MG_NULL_FLOATS : 1];
+    __shared__ uint32_t s_rnull[G32 && PRN ? NC + 2 : 1];                  // (a tile takes NC reads at most in that mode)
 
     const uint32_t tid = threadIdx.x;
     // entry e of a table in the strand's order <- entry of the (3,2,3) model's table as gmg_null_set / gmg_model_upload lay it out
@@ -1357,7 +1359,7 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                 const uint32_t i = tid + (uint32_t)BLOCK * u;
                 if (i <= nfit) s_roff[i] = tro[u] - w0_lo;
                 if (i < nfit) s_isl[i] = tis[u];
-                if (G32 && PRN && i < nfit && i < MT_NC) s_rnull[i] = trn[u];
+                if (G32 && PRN && i < nfit && i < NC) s_rnull[i] = trn[u];
             }
             if (G32 && PRN) {
 #pragma unroll
@@ -1417,7 +1419,7 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                 if (m > 0) s_oinfo[uh] = (uint16_t)(e + 1);
             }
             if (G32 && PRN) {
-                const uint32_t nc = nfit < MT_NC ? nfit : MT_NC;
+                const uint32_t nc = nfit < NC ? nfit : NC;
                 for (uint32_t i = MG_NULL_FLOATS + tid; i < nc * MG_NULL_FLOATS; i += BLOCK) {       // (the first read's came with the tile)
                     const uint32_t rl = i / MG_NULL_FLOATS, e = i - rl * MG_NULL_FLOATS;
                     s_nullm[rl][e] = a.null_tab[(size_t)s_rnull[rl] * MG_NULL_FLOATS + null_src(e, fwd)];
@@ -1487,11 +1489,11 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                         // entry `off` of the read's table in this strand's order
                         auto nullv = [&](uint32_t off, uint32_t) __attribute__((always_inline)) -> double {
                             if (!PRN) return off < 192u ? s_nulld[off] : (double)s_nullp[off - 192u];
-                            return (double)s_nullm[rl < MT_NC ? rl : 0u][off];       // (mg_run lets a tile take MT_NC reads at most then)
+                            return (double)s_nullm[rl < NC ? rl : 0u][off];       // (mg_run lets a tile take MT_NC reads at most then)
                         };
                         auto nullf = [&](uint32_t off) __attribute__((always_inline)) -> double {        // a full-window entry
                             if (!PRN) return s_nulld[off];
-                            return (double)s_nullm[rl < MT_NC ? rl : 0u][off];
+                            return (double)s_nullm[rl < NC ? rl : 0u][off];
                         };
                         double nsum;
                         if (FWD ? si + 2 >= n : si < 2) {                          // one of them is a partial window
@@ -2907,6 +2909,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     uint32_t *d_read_cnt = nullptr, *d_orf_cnt = nullptr;
     uint64_t *d_start_off = nullptr;
     double *d_cum = nullptr;
+    bool fused_nc2 = false;
     int fused_nw = 0, fused_el = 9;                     // waves per tile of k_mg_tile_starts (0: the sequential kernels), elements per lane
     bool err_exact = false;                             // the batch's sums are exact in any order: the error branch may take differences of running sums
     bool err_tile = false;                              // ... and runs tile by tile with the sums in LDS (k_mg_err_tile)
@@ -3125,6 +3128,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         const uint32_t cap = fused_nw ? (uint32_t)(3 * MT_CL * fused_el * fused_nw) : small ? 512 : 1504;
         a.tile_cap = (int)cap;
         a.tile_reads_max = fused_nw && g32 && prm->nulls ? MT_NC : MG_TILE_READS;
+        // (two-wave tiles of eight elements over uniform reads of which two at most fit: the kernel form with two null tables)
+        fused_nc2 = fused_nw == 2 && fused_el == 8 && g32 && prm->nulls && reads->uniform_len > 0 && cap / (uint32_t)reads->uniform_len <= 2;
+        if (fused_nc2) a.tile_reads_max = 2;
         bool tiled = false, rest = true;
         if (reads->uniform_len > 0) {                  // every tile takes cap / L whole reads
             if ((uint32_t)reads->uniform_len <= cap) {
@@ -3566,7 +3572,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             hipLaunchKernelGGL(k_mg_starts_unfit, dim3(grid_for(a.n_reads / 16 + 1)), dim3(256), 0, s2, a);
             MG_TRY(hipEventRecord(side_done, s2));
         }
-#define MG_LAUNCH_TILE(NW_, G_, EL_) do { if (G_ && a.read_null) hipLaunchKernelGGL((k_mg_tile_starts<NW_, G_, EL_, G_>), dim3(grid), dim3(64 * NW_), 0, s, a); \
+#define MG_LAUNCH_TILE(NW_, G_, EL_) do { if (G_ && a.read_null && NW_ == 2 && EL_ == 8 && fused_nc2) hipLaunchKernelGGL((k_mg_tile_starts<2, G_, 8, G_, 2>), dim3(grid), dim3(128), 0, s, a); \
+                                          else if (G_ && a.read_null) hipLaunchKernelGGL((k_mg_tile_starts<NW_, G_, EL_, G_>), dim3(grid), dim3(64 * NW_), 0, s, a); \
                                           else hipLaunchKernelGGL((k_mg_tile_starts<NW_, G_, EL_, false>), dim3(grid), dim3(64 * NW_), 0, s, a); } while (0)
 #define MG_LAUNCH_TILE_EL(NW_, G_) do { if (fused_el == 8) MG_LAUNCH_TILE(NW_, G_, 8); else MG_LAUNCH_TILE(NW_, G_, 9); } while (0)
         if (a.gene32) {
