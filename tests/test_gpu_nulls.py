@@ -58,12 +58,14 @@ def test_frame6_nulls_ragged_reads_120_gcs_vs_oracle(gpu, nc, oracle):
 
 @pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("gene32", [2, 0])
-@pytest.mark.parametrize("uniform", [False, True])
+@pytest.mark.parametrize("uniform", [False, True, 500, 300, 151])
 def test_mg_per_read_null_and_ignore_score_len_vs_oracle(gpu, nc, oracle, gene32, uniform, fused):
     """every read against its own Indep_Model and its own Ignore_Score_Len, one call: ORFs, start lists (scores bit for bit),
-    best score and the accepted flag equal the oracle's, read by read"""
-    rng = np.random.default_rng(5 + uniform)
-    lens = [400] * 150 if uniform else [0, 2, 14, 75, 76, 300, 512, 513, 700, 1504, 1505, 2100] + [int(x) for x in rng.integers(60, 900, 140)]
+    best score and the accepted flag equal the oracle's, read by read.  Uniform batches: 400 / 500 bp = two reads per two-wave tile (the
+    tile kernel's form with two null tables in LDS), 300 = three, 151 = six (the form with six)"""
+    rng = np.random.default_rng(5 + int(uniform))
+    ulen = 400 if uniform is True else int(uniform)
+    lens = [ulen] * 150 if uniform else [0, 2, 14, 75, 76, 300, 512, 513, 700, 1504, 1505, 2100] + [int(x) for x in rng.integers(60, 900, 140)]
     seqs = ragged(rng, lens)
     gcs = np.linspace(0.25, 0.75, 101)
     read_null = rng.integers(0, len(gcs), len(seqs)).astype(np.uint32)
