@@ -24,7 +24,8 @@
 //              writes <tag>.predict.part<k>.  The one run-wide quantity, the null model's GC fraction
 //              (Set_GC_Fraction: a ratio of two counts over the whole file), is summed by the parent from the children's
 //              {gc, total} (two integers per child through a pipe) and handed back; the parent concatenates the parts
-//              in shard order.  No collective, no GPU-to-GPU traffic.
+//              in shard order.  No collective, no GPU-to-GPU traffic.  With -q every child passes over the
+//              quality records of the reads in front of its range and reads its own in order.
 // --batch-bytes B   inside a shard the bytes are ingested and scored in pieces of about B bytes (gmg_fasta_split;
 //              default 256 MiB = about 0.5 M reads of 500 bp): the 48 B/base table of a piece must fit the HBM, and a
 //              piece's ORF / start counts the 32-bit fields of the result records.  The packed reads of all pieces stay
@@ -261,7 +262,22 @@ static int run_shard(const char *bytes, uint64_t b0, uint64_t b1, int device, ui
     gmg_mg_params prm;
     fill_params(prm, error_mode);
     FILE *quality_fp = NULL;                            // -q: the values are read in file order, piece by piece
-    if (Allow_Indels && Quality_File_Name != NULL) quality_fp = File_Open(Quality_File_Name, "r", __FILE__, __LINE__);
+    if (Allow_Indels && Quality_File_Name != NULL) {
+        quality_fp = File_Open(Quality_File_Name, "r", __FILE__, __LINE__);
+        // a shard behind the first: the quality records of the reads in front of its byte range are passed over -- as many as there are
+        // header lines ('>' at a line's start: Fasta_Read's record rule, src/Common/fasta.cc:236-286) in bytes [0, b0)
+        uint64_t skip = 0;
+        for (uint64_t i = 0; i < b0; i++)
+            if (bytes[i] == '>' && (i == 0 || bytes[i - 1] == '\n')) skip++;
+        char *line = NULL;
+        size_t cap = 0;
+        for (uint64_t seen = 0; skip;) {
+            const long at = ftell(quality_fp);
+            if (getline(&line, &cap, quality_fp) < 0) break;       // (fewer quality records than reads: the length check below reports it)
+            if (line[0] == '>' && seen++ == skip) { fseek(quality_fp, at, SEEK_SET); break; }
+        }
+        free(line);
+    }
 
     // pass 2: piece by piece -- one gmg_mg_score_reads call, then events / DP / trace-back per read on the host
     FILE *predict_fp = File_Open(out_name, "w", __FILE__, __LINE__);
@@ -722,10 +738,6 @@ int main(int argc, char **argv)
             while (waitpid(pid, &status, 0) < 0)
                 if (errno != EINTR) { perror("glimmer-mg_gpu: waitpid"); return 2; }
             return WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
-        }
-        if (n_shards > 1 && Quality_File_Name != NULL) {
-            fprintf(stderr, "glimmer-mg_gpu: -q with --shards > 1 is not supported (the quality file is read in order)\n");
-            return 2;
         }
         // the whole file, mapped once; the children inherit the mapping
         const int fd = open(Sequence_File_Name, O_RDONLY);

@@ -152,6 +152,19 @@ def test_glimmer_mg_gpu_in_batches_and_shards_is_byte_identical(gpu, tmp_path, h
     assert not [f for f in os.listdir(tmp_path) if ".part" in f]
 
 
+@pytest.mark.parametrize("how", [["--shards", "3"], ["--shards", "2", "--batch-bytes", "9000"]])
+def test_glimmer_mg_gpu_shards_with_a_quality_file(gpu, tmp_path, how):
+    """-i -q with --shards: every shard passes over the quality records of the reads in front of its byte range (as many as there are
+    header lines there) and reads its own in order -- the bytes of the reference's single run"""
+    exe = built_binary("integration", "_build", "glimmer-mg_gpu")
+    tag = str(tmp_path / "out")
+    cmd = [exe, *how, "-i", "-q", os.path.join(DATA, "seqs80.qual"), "-m", os.path.join(DATA, "NC_000915.icm"), os.path.join(DATA, "seqs80.fa"), tag]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", "glimmer-mg.indel_q80.predict"), "rb").read()
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+
+
 def test_reads_select_groups_like_classification_mode(gpu, nc):
     """gmg_reads_select: the reads of one group gathered on the device (glimmer-mg -c scores every ICM's reads with that ICM
     and the classes' null model, glimmer-mg.cc:361-375); a group scored alone gives each read's records of the full batch"""
