@@ -15,7 +15,12 @@ import _gmg_pkg  # noqa: E402
 gmg = _gmg_pkg.load()
 gmg.init(0)
 n, L = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, int(sys.argv[2]) if len(sys.argv) > 2 else 500
-packed, off = gmg.synth.packed_reads(n, L, 7)
+if len(sys.argv) > 3 and sys.argv[3] == "ragged":         # the lengths of tests/bench/bench_mg.py's ragged batch
+    lens = np.clip(np.random.default_rng(12).normal(400, 60, n).round(), 100, 700).astype(np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    packed, _ = gmg.synth.packed_reads(1, int(off[-1]), 7)
+else:
+    packed, off = gmg.synth.packed_reads(n, L, 7)
 reads = gmg.Reads(packed, off)
 gene = gmg.Icm.open(os.path.join(ROOT, "tests", "golden", "data", "NC_000915.icm"))
 indep = gmg.Icm.indep(0.5)
