@@ -124,6 +124,7 @@ enum GmgOpt {
     GMG_OPT_MG_ERR_TILE_Q,       // ... tests: calls per level a work-group's slab holds (0 = ET_QCAP; a full slab sends the batch to the level kernels);
                                  // any value but 0 also starts with staging arrays of 64 entries (-1: only that: the kernel repeats with larger ones)
     GMG_OPT_MG_ERR_QONLY,        // glimmer-mg -s on the level kernels: 1 = the running-sum table holds one value per base and strand (16 B/base), 0 = three (48)
+    GMG_OPT_INGEST_SCANS,        // gmg_fasta_ingest: 1 = the first version (two hipcub scans over every byte + k_fa_pack), 0 = block summaries
     GMG_OPT_COUNT
 };
 extern long long g_gmg_opt[GMG_OPT_COUNT];

@@ -56,6 +56,27 @@ def test_ingest_random_byte_soup_vs_oracle(gpu, oracle, seed):
     assert records == want and gc == want_gc and len(want) > 50
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_ingest_block_summaries_equal_the_scans_on_a_large_soup(gpu, seed):
+    """the two device forms (block summaries -- the default -- and the first version's two scans over every byte, `ingest_scans` = 1) on
+    ~6 MB of byte soup with records, headers and blank runs that straddle the 4 KiB blocks and the 16-byte lanes: same reads, same
+    header extents, same g/c count; lengths that are no multiple of 16 or 4,096"""
+    rng = np.random.default_rng(seed)
+    alphabet = np.frombuffer(b"acgtACGTacgtacgtnNrRyY>\n\n\r\t  x-", np.uint8)
+    pieces = [b"junk in front of the first record\nacgt\n" if seed % 2 else b""]
+    for _ in range(3000):
+        pieces.append(alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 3000)))].tobytes())
+        if rng.random() < 0.4:
+            pieces.append(b">" + b" " * int(rng.integers(0, 40)) + b"hdr %d" % rng.integers(0, 10 ** 9) + b">" * int(rng.integers(0, 3)) + b"\n")
+    data = b"".join(pieces) + [b">  ", b"acg"][seed % 2]
+    out = []
+    for scans in (0, 1):
+        with gpu.option("ingest_scans", scans):
+            out.append(device_records(gpu, data))
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2] and len(out[0][1]) > 500
+    assert len(data) % 4096 not in (0, 1) and len(data) > 4_000_000
+
+
 def test_ingest_edge_inputs(gpu, oracle):
     for data in [b"", b"no record at all\nacgt\n", b">", b">only a header", b">h\n", b">a\nA", b"\n\n>  \n\n", b">x\nacgt>y\n>z"]:
         reads, records, gc = device_records(gpu, data)
