@@ -293,14 +293,17 @@ __global__ __launch_bounds__(256) void k_fa_summ(const uint8_t *bytes, uint64_t 
     }
 }
 
-// pass 2: ONE work-group of 1,024 lanes over the summaries: the state every block is entered in and the counts in front of it.
-// A lane takes a run of consecutive blocks, follows it from all three states, the lanes' runs are composed like the lanes of a block.
-__global__ __launch_bounds__(1024) void k_fa_blocks(const FaSumm *summ, uint64_t n_blocks, uint8_t *blk_state, uint64_t *blk_excl, uint64_t *totals)
+// pass 2: ONE work-group of 1,024 lanes over the summaries of blocks [b_lo, b_hi): the state every block is entered in and the counts
+// in front of it.  A lane takes a run of consecutive blocks, follows it from all three states, the lanes' runs are composed like the
+// lanes of a block.  carry[0] = the counts, carry[1] = the state in front of block b_lo (read and advanced: the pieces of a chunked
+// upload are done one after the other, each behind its own first pass).
+__global__ __launch_bounds__(1024) void k_fa_blocks(const FaSumm *summ, uint64_t b_lo, uint64_t b_hi, uint8_t *blk_state, uint64_t *blk_excl, uint64_t *carry)
 {
     __shared__ uint32_t s_f[1024];
     __shared__ uint64_t s_cnt[3][1024];
     const uint32_t t = threadIdx.x;
-    const uint64_t per = (n_blocks + 1023) / 1024, b0 = (uint64_t)t * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+    const uint64_t n_blocks = b_hi - b_lo;
+    const uint64_t per = (n_blocks + 1023) / 1024, b0 = b_lo + (uint64_t)t * per, b1 = b0 + per < b_hi ? b0 + per : b_hi;
     uint32_t s[3] = {ST_PRE, ST_HDR, ST_SEQ};
     uint64_t c[3] = {0, 0, 0};
     for (uint64_t b = b0; b < b1; b++) {
@@ -311,9 +314,9 @@ __global__ __launch_bounds__(1024) void k_fa_blocks(const FaSumm *summ, uint64_t
     s_f[t] = s[0] | s[1] << 2 | s[2] << 4;
     s_cnt[0][t] = c[0]; s_cnt[1][t] = c[1]; s_cnt[2][t] = c[2];
     __syncthreads();
-    if (t == 0) {                                       // 1,024 steps: the runs one after the other from the file's first state
-        uint32_t st = ST_PRE;
-        uint64_t acc = 0;
+    if (t == 0) {                                       // 1,024 steps: the runs one after the other from the state in front of them
+        uint32_t st = (uint32_t)carry[1];
+        uint64_t acc = carry[0];
         for (uint32_t k = 0; k < 1024; k++) {
             const uint32_t f = s_f[k];
             const uint64_t add = s_cnt[st][k];
@@ -322,8 +325,8 @@ __global__ __launch_bounds__(1024) void k_fa_blocks(const FaSumm *summ, uint64_t
             acc += add;
             st = fa_apply(f, st);
         }
-        totals[0] = acc;
-        totals[1] = st;
+        carry[0] = acc;
+        carry[1] = st;
     }
     __syncthreads();
     uint32_t st = s_f[t];
@@ -527,6 +530,7 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
             FA_TRY(dev.alloc(&d_bexcl, n_blocks * 8));
             FA_TRY(dev.alloc(&d_tot, 16));
         }
+        if (!scans) FA_TRY(hipMemsetAsync(d_tot, 0, 16, st));               // counts 0, state PRE in front of the first block
         lap("alloc");
         // the upload in up to 16 pieces on a stream of its own, the first pass over a piece as soon as it has arrived (the pass is
         // hidden behind the next piece's copy; small inputs, the scans' form and a busy copy lane take one plain copy)
@@ -546,6 +550,7 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
                 if (pe == hipSuccess) {
                     const uint64_t blk0 = b0 / FA_BLK, nb = (len + FA_BLK - 1) / FA_BLK;
                     hipLaunchKernelGGL(k_fa_summ, dim3((unsigned)(nb < 256 * 16 ? nb : 256 * 16)), dim3(256), 0, st, d_bytes + b0, len, nb, d_summ + blk0);
+                    hipLaunchKernelGGL(k_fa_blocks, dim3(1), dim3(1024), 0, st, d_summ, blk0, blk0 + nb, d_bstate, d_bexcl, d_tot);
                     pe = hipGetLastError();
                 }
             }
@@ -556,9 +561,10 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
             FA_TRY(hipMemcpyAsync(d_bytes, bytes, n, hipMemcpyHostToDevice, st));
         lap("copy file to device");
         if (!scans) {
-            if (!piecewise)
+            if (!piecewise) {
                 hipLaunchKernelGGL(k_fa_summ, dim3((unsigned)(n_blocks < 256 * 64 ? n_blocks : 256 * 64)), dim3(256), 0, st, d_bytes, n, n_blocks, d_summ);
-            hipLaunchKernelGGL(k_fa_blocks, dim3(1), dim3(1024), 0, st, d_summ, n_blocks, d_bstate, d_bexcl, d_tot);
+                hipLaunchKernelGGL(k_fa_blocks, dim3(1), dim3(1024), 0, st, d_summ, (uint64_t)0, n_blocks, d_bstate, d_bexcl, d_tot);
+            }
             FA_TRY(hipGetLastError());
             uint64_t tot[2] = {0, 0};
             FA_TRY(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, st));
