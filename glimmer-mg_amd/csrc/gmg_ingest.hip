@@ -344,7 +344,9 @@ struct FaPack2Args {
     const uint8_t *bytes;
     const uint8_t *blk_state;
     const uint64_t *blk_excl;
-    uint64_t n_bytes, n_blocks;
+    uint64_t n_bytes, b_lo, b_hi;    // the file's length; the blocks of this launch
+    uint64_t avail;                  // bytes that have arrived (a piece of a chunked upload: the blanks behind a '>' may run past them)
+    uint64_t rec_cap;                // records the arrays hold (a launch ahead of the totals: the arrays are sized by a bound)
     uint32_t *packed;                // zeroed
     uint64_t *read_off;              // [n_reads + 1]
     uint64_t *hdr_begin, *hdr_end;   // [n_reads]; hdr_end preset to n_bytes
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256) void k_fa_pack2(FaPack2Args a)
     __shared__ uint32_t s_w[4];
     __shared__ uint64_t s_c[4];
     unsigned long long gc = 0;
-    for (uint64_t b = blockIdx.x; b < a.n_blocks; b += gridDim.x) {
+    for (uint64_t b = a.b_lo + blockIdx.x; b < a.b_hi; b += gridDim.x) {
         const uint64_t i0 = b * FA_BLK + (uint64_t)threadIdx.x * 16;
         const FaLane L = fa_load16(a.bytes, a.n_bytes, i0);
         uint32_t total_f;
@@ -372,13 +374,16 @@ __global__ __launch_bounds__(256) void k_fa_pack2(FaPack2Args a)
             const uint8_t ch = L.b[k];
             const uint64_t i = i0 + (uint64_t)k;
             if (ch == '>' && st != ST_HDR) {            // a record starts: its bases begin at `base`, its header behind the '>'
-                a.read_off[rec] = base;
-                uint64_t hb = i + 1;                    // Fasta_Read skips the blanks behind '>' (fasta.cc:258-260)
-                while (hb < a.n_bytes && a.bytes[hb] == ' ') hb++;
-                a.hdr_begin[rec] = hb;
+                if (rec < a.rec_cap) {
+                    a.read_off[rec] = base;
+                    uint64_t hb = i + 1;                // Fasta_Read skips the blanks behind '>' (fasta.cc:258-260)
+                    while (hb < a.avail && a.bytes[hb] == ' ') hb++;
+                    // (blanks up to the last byte that has arrived, more to come: k_fa_hdr_fix goes on from there once all have)
+                    a.hdr_begin[rec] = hb == a.avail && a.avail < a.n_bytes ? hb | 1ull << 63 : hb;
+                }
                 rec++;
             } else if (ch == '\n' && st == ST_HDR) {
-                a.hdr_end[rec - 1] = i;                 // the header line of the record that is open
+                if (rec - 1 < a.rec_cap) a.hdr_end[rec - 1] = i;      // the header line of the record that is open
             } else if (st == ST_SEQ && ch != '>' && !fa_isspace(ch)) {
                 const uint32_t code = fa_code(ch);
                 gc += (code == 1 || code == 2);
@@ -392,6 +397,18 @@ __global__ __launch_bounds__(256) void k_fa_pack2(FaPack2Args a)
     }
     for (int o = 32; o > 0; o >>= 1) gc += __shfl_down(gc, o);
     if ((threadIdx.x & 63) == 0 && gc) atomicAdd(a.gc_count, gc);
+}
+
+// header extents whose blanks ran up to the end of a piece of the upload: on from there, all bytes being there now
+__global__ __launch_bounds__(256) void k_fa_hdr_fix(const uint8_t *bytes, uint64_t n_bytes, uint64_t *hdr_begin, uint64_t n_reads)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t hb = hdr_begin[i];
+        if (!(hb >> 63)) continue;
+        hb &= ~(1ull << 63);
+        while (hb < n_bytes && bytes[hb] == ' ') hb++;
+        hdr_begin[i] = hb;
+    }
 }
 
 // shortest / longest read and the reads over 512 bases (what gmg_reads keeps about a batch), from the offsets: stats[0] min, [1] max, [2] count
@@ -517,6 +534,15 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
     } while (0)
     const uint64_t n = n_bytes;
     uint64_t n_reads = 0, total = 0;
+    // what goes to the gmg_reads: the packed words in their guarded buffer, the offsets
+    uint32_t *d_alloc = nullptr;
+    struct BufGuard { uint32_t *&p; ~BufGuard() { if (p) gmg_pool_release(p); } } alloc_guard = {d_alloc};   // until the reads own it
+    struct OffGuard { uint64_t *&p; ~OffGuard() { if (p) gmg_pool_release(p); } } off_guard = {d_off};       // until then it is ours
+    // a chunked upload packs every piece as it arrives, into arrays sized by a bound: rec_cap records (16 file bytes per record; a file
+    // with more takes the plain order once the totals are known), one base per byte
+    bool spec = false;
+    uint64_t rec_cap = 0;
+    uint64_t *d_off_big = nullptr;
     if (n) {
         const bool scans = gmg_opt(GMG_OPT_INGEST_SCANS) != 0;       // the first version: two scans over every byte
         n_blocks = (n + FA_BLK - 1) / FA_BLK;
@@ -536,11 +562,27 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
         // hidden behind the next piece's copy; small inputs, the scans' form and a busy copy lane take one plain copy)
         FaCopyLane &cl = copy_lane();
         const uint64_t piece = ((n / 16 + FA_BLK - 1) / FA_BLK + 1) * FA_BLK;          // a multiple of the block size
-        bool piecewise = !scans && !timing && n >= (64u << 20) && cl.mu.try_lock();
+        bool piecewise = !scans && !timing && (long long)n >= gmg_opt(GMG_OPT_INGEST_PIECE_MIN) && cl.mu.try_lock();
         if (piecewise && !cl.init()) { cl.mu.unlock(); piecewise = false; }
         if (piecewise) {
             hipError_t pe = hipEventRecord(cl.start, st);                  // (the buffer is ours from here on in `st`'s order)
             if (pe == hipSuccess) pe = hipStreamWaitEvent(cl.copy, cl.start, 0);
+            // (queued on `st` behind the event: they run beside the first piece's copy)
+            rec_cap = n / 16 + 1024;
+            const uint64_t words_cap = (n + 15) / 16;
+            if (pe == hipSuccess) pe = gmg_pool_alloc((void **)&d_alloc, (words_cap + 2 * GMG_GUARD_WORDS + 1) * 4);
+            if (pe == hipSuccess) pe = dev.alloc(&d_off_big, (rec_cap + 1) * 8);
+            if (pe == hipSuccess) pe = dev.alloc(&d_hb, rec_cap * 8);
+            if (pe == hipSuccess) pe = dev.alloc(&d_he, rec_cap * 8);
+            if (pe == hipSuccess) pe = dev.alloc(&d_gc, 8);
+            if (pe == hipSuccess) pe = hipMemsetAsync(d_alloc, 0, (words_cap + 2 * GMG_GUARD_WORDS + 1) * 4, st);
+            if (pe == hipSuccess) pe = hipMemsetAsync(d_gc, 0, 8, st);
+            if (pe == hipSuccess) {
+                hipLaunchKernelGGL(k_fa_fill, dim3(4096), dim3(256), 0, st, d_he, rec_cap, n_bytes);
+                pe = hipGetLastError();
+                d_packed = d_alloc + GMG_GUARD_WORDS;
+                spec = true;
+            }
             int k = 0;
             for (uint64_t b0 = 0; pe == hipSuccess && b0 < n; b0 += piece, k++) {
                 const uint64_t len = n - b0 < piece ? n - b0 : piece;
@@ -551,6 +593,8 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
                     const uint64_t blk0 = b0 / FA_BLK, nb = (len + FA_BLK - 1) / FA_BLK;
                     hipLaunchKernelGGL(k_fa_summ, dim3((unsigned)(nb < 256 * 16 ? nb : 256 * 16)), dim3(256), 0, st, d_bytes + b0, len, nb, d_summ + blk0);
                     hipLaunchKernelGGL(k_fa_blocks, dim3(1), dim3(1024), 0, st, d_summ, blk0, blk0 + nb, d_bstate, d_bexcl, d_tot);
+                    FaPack2Args pa = {d_bytes, d_bstate, d_bexcl, n, blk0, blk0 + nb, b0 + len, rec_cap, d_packed, d_off_big, d_hb, d_he, d_gc};
+                    hipLaunchKernelGGL(k_fa_pack2, dim3((unsigned)(nb < 256 * 16 ? nb : 256 * 16)), dim3(256), 0, st, pa);
                     pe = hipGetLastError();
                 }
             }
@@ -607,32 +651,48 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
     // 3. pack, offsets, header extents, g/c count
     // (the packed words are written where they stay: the gmg_reads' buffer with its guard words on both sides)
     const uint64_t data_words = (total + 15) / 16;
-    uint32_t *d_alloc = nullptr;
-    FA_TRY(gmg_pool_alloc((void **)&d_alloc, (data_words + 2 * GMG_GUARD_WORDS + 1) * 4));
-    struct BufGuard { uint32_t *&p; ~BufGuard() { if (p) gmg_pool_release(p); } } alloc_guard = {d_alloc};   // until the reads own it
-    d_packed = d_alloc + GMG_GUARD_WORDS;
-    FA_TRY(hipMemsetAsync(d_alloc, 0, (data_words + 2 * GMG_GUARD_WORDS + 1) * 4, st));
-    FA_TRY(gmg_pool_alloc((void **)&d_off, (n_reads + 1) * 8));               // goes to the gmg_reads
-    struct OffGuard { uint64_t *&p; ~OffGuard() { if (p) gmg_pool_release(p); } } off_guard = {d_off};   // until then it is ours
     unsigned long long *d_stats = nullptr;
     FA_TRY(dev.alloc(&d_stats, 32));
-    hipError_t e2 = dev.alloc(&d_hb, n_reads * 8);
-    if (e2 == hipSuccess) e2 = dev.alloc(&d_he, n_reads * 8);
-    if (e2 == hipSuccess) e2 = dev.alloc(&d_gc, 8);
-    if (e2 == hipSuccess) e2 = hipMemsetAsync(d_gc, 0, 8, st);
-    if (e2 == hipSuccess) e2 = hipMemcpyAsync(d_off + n_reads, &total, 8, hipMemcpyHostToDevice, st);
-    if (e2 != hipSuccess) { delete idx; return gmg_set_error(GMG_ENOMEM, "gmg_fasta_ingest: %s", hipGetErrorString(e2)); }
-    if (n_reads) {
-        const uint64_t blocks = (n_reads + 255) / 256;
-        hipLaunchKernelGGL(k_fa_fill, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, d_he, n_reads, n_bytes);
-    }
-    if (n && d_summ) {
-        FaPack2Args a = {d_bytes, d_bstate, d_bexcl, n, n_blocks, d_packed, d_off, d_hb, d_he, d_gc};
-        hipLaunchKernelGGL(k_fa_pack2, dim3((unsigned)(n_blocks < 256 * 64 ? n_blocks : 256 * 64)), dim3(256), 0, st, a);
-    } else if (n) {
-        FaPackArgs a = {d_bytes, d_func, d_count, n, d_packed, d_off, d_hb, d_he, d_gc};
-        const uint64_t blocks = (n / 16 + 255) / 256 + 1;
-        hipLaunchKernelGGL(k_fa_pack, dim3((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32)), dim3(256), 0, st, a);
+    hipError_t e2 = hipSuccess;
+    if (spec && n_reads <= rec_cap) {
+        // the pieces are packed already: the offsets move into an array of their size, the header extents that ran up to a piece's end are completed
+        FA_TRY(gmg_pool_alloc((void **)&d_off, (n_reads + 1) * 8));           // goes to the gmg_reads
+        if (n_reads) e2 = hipMemcpyAsync(d_off, d_off_big, n_reads * 8, hipMemcpyDeviceToDevice, st);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(d_off + n_reads, &total, 8, hipMemcpyHostToDevice, st);
+        if (e2 == hipSuccess && n_reads) {
+            const uint64_t blocks = (n_reads + 255) / 256;
+            hipLaunchKernelGGL(k_fa_hdr_fix, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, d_bytes, n, d_hb, n_reads);
+        }
+        if (e2 != hipSuccess) { delete idx; return gmg_set_error(GMG_EHIP, "gmg_fasta_ingest: %s", hipGetErrorString(e2)); }
+    } else {
+        if (spec) {                                     // more records than the bound: the arrays again, in their real size
+            gmg_pool_release(d_alloc);
+            d_alloc = nullptr;
+            d_hb = d_he = nullptr;                      // (the bound-sized ones stay with `dev` until the call ends)
+            spec = false;
+        }
+        FA_TRY(gmg_pool_alloc((void **)&d_alloc, (data_words + 2 * GMG_GUARD_WORDS + 1) * 4));
+        d_packed = d_alloc + GMG_GUARD_WORDS;
+        FA_TRY(hipMemsetAsync(d_alloc, 0, (data_words + 2 * GMG_GUARD_WORDS + 1) * 4, st));
+        FA_TRY(gmg_pool_alloc((void **)&d_off, (n_reads + 1) * 8));           // goes to the gmg_reads
+        e2 = dev.alloc(&d_hb, n_reads * 8);
+        if (e2 == hipSuccess) e2 = dev.alloc(&d_he, n_reads * 8);
+        if (e2 == hipSuccess && !d_gc) e2 = dev.alloc(&d_gc, 8);
+        if (e2 == hipSuccess) e2 = hipMemsetAsync(d_gc, 0, 8, st);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(d_off + n_reads, &total, 8, hipMemcpyHostToDevice, st);
+        if (e2 != hipSuccess) { delete idx; return gmg_set_error(GMG_ENOMEM, "gmg_fasta_ingest: %s", hipGetErrorString(e2)); }
+        if (n_reads) {
+            const uint64_t blocks = (n_reads + 255) / 256;
+            hipLaunchKernelGGL(k_fa_fill, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, d_he, n_reads, n_bytes);
+        }
+        if (n && d_summ) {
+            FaPack2Args a = {d_bytes, d_bstate, d_bexcl, n, 0, n_blocks, n, n_reads, d_packed, d_off, d_hb, d_he, d_gc};
+            hipLaunchKernelGGL(k_fa_pack2, dim3((unsigned)(n_blocks < 256 * 64 ? n_blocks : 256 * 64)), dim3(256), 0, st, a);
+        } else if (n) {
+            FaPackArgs a = {d_bytes, d_func, d_count, n, d_packed, d_off, d_hb, d_he, d_gc};
+            const uint64_t blocks = (n / 16 + 255) / 256 + 1;
+            hipLaunchKernelGGL(k_fa_pack, dim3((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32)), dim3(256), 0, st, a);
+        }
     }
     e2 = hipGetLastError();
     if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);

@@ -125,6 +125,7 @@ enum GmgOpt {
                                  // any value but 0 also starts with staging arrays of 64 entries (-1: only that: the kernel repeats with larger ones)
     GMG_OPT_MG_ERR_QONLY,        // glimmer-mg -s on the level kernels: 1 = the running-sum table holds one value per base and strand (16 B/base), 0 = three (48)
     GMG_OPT_INGEST_SCANS,        // gmg_fasta_ingest: 1 = the first version (two hipcub scans over every byte + k_fa_pack), 0 = block summaries
+    GMG_OPT_INGEST_PIECE_MIN,    // gmg_fasta_ingest: inputs of at least this many bytes are uploaded in 16 pieces, every piece parsed and packed as it arrives
     GMG_OPT_COUNT
 };
 extern long long g_gmg_opt[GMG_OPT_COUNT];

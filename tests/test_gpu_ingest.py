@@ -75,6 +75,31 @@ def test_ingest_block_summaries_equal_the_scans_on_a_large_soup(gpu, seed):
             out.append(device_records(gpu, data))
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2] and len(out[0][1]) > 500
     assert len(data) % 4096 not in (0, 1) and len(data) > 4_000_000
+    # the chunked upload (inputs of 64 MiB and more): 16 pieces, each parsed and packed as it arrives, into arrays sized by a bound
+    with gpu.option("ingest_piece_min", 1 << 20):
+        piecewise = device_records(gpu, data)
+    assert piecewise[1] == out[1][1] and piecewise[2] == out[1][2]
+
+
+def test_ingest_piecewise_edges(gpu, oracle):
+    """the chunked upload on inputs built around its seams: a '>' whose blanks run across the end of a piece (the header's begin is
+    completed when all bytes are there), across several pieces, up to the end of the file; more records than the bound the arrays
+    were sized by (one per 16 bytes: the plain order takes over); a piece that ends inside a header line"""
+    def run(data):
+        with gpu.option("ingest_piece_min", 1):
+            _, records, gc = device_records(gpu, data)
+        want, want_gc = oracle.fasta_records(data)
+        assert records == want and gc == want_gc
+        return len(want)
+    n = 16 * 8192
+    for at in (8192 - 3, 8192 - 1, 8192, 3 * 8192 - 20):                      # (pieces of this input: 8,192 + 4,096 bytes)
+        body = bytearray(b"acgtacgtacgtacg\n" * (n // 16))
+        blanks = 40 if at != 3 * 8192 - 20 else 12_300 * 2                    # ... across two seams
+        body[at:at + 1 + blanks + 4] = b">" + b" " * blanks + b"hdr\n"
+        assert run(b">first\n" + bytes(body)) == 2
+    assert run(b">a\nacgt\n" * 30_000) == 30_000                             # 8 bytes per record: beyond the bound
+    assert run(b">x\n" + b"acgt" * 40_000 + b"\n>" + b" " * 5000) == 1         # "> <blanks> EOF" is no record
+    assert run(b">" + b"h" * 100_000 + b"\nacgt\n>y\nggg") == 2                 # pieces inside a header line
 
 
 def test_ingest_edge_inputs(gpu, oracle):
