@@ -315,7 +315,7 @@ if want("ingest"):
     lib.gmg_reads_free(r)
     a = data_arr.size / (ms * 1e-3) / 1e9
     leg("ingest", ms, all_ms, {"bound": "pcie + hbm", "achieved": round(a, 2), "peak": 64.0, "unit": "GB/s of file bytes (host to packed reads in HBM)", "frac": round(a / 64.0, 4),
-                               "algorithmic": "every file byte crosses PCIe once (x16 Gen5: 64 GB/s) and is read three times in HBM; 0.25 B/base written"},
+                               "algorithmic": "every file byte crosses PCIe once (x16 Gen5: 64 GB/s) and is read twice in HBM (block summaries, pack pass: both behind the chunked copy); 0.25 B/base written; the timed call frees its result too"},
         "%d records, lengths, first / last read and the first records against the oracle's Fasta_Read: %s" % (n_ing.value, "identical" if ok else "MISMATCH"),
         file_bytes=int(data_arr.size))
 
