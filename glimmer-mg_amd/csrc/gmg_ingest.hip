@@ -514,12 +514,18 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
     gmg_fasta *idx = new (std::nothrow) gmg_fasta();
     if (!idx) return gmg_set_error(GMG_ENOMEM, "gmg_fasta_ingest: out of host memory");
     idx->n_reads = idx->total_bases = idx->gc_count = 0;
+    // what goes to the gmg_reads: the packed words in their guarded buffer, the offsets (the guards are older than `dev`: on an early
+    // return they let go of the blocks AFTER dev's destructor has waited for the stream)
+    uint32_t *d_alloc = nullptr;
+    uint64_t *d_off = nullptr;
+    struct BufGuard { uint32_t *&p; ~BufGuard() { if (p) gmg_pool_release(p); } } alloc_guard = {d_alloc};   // until the reads own it
+    struct OffGuard { uint64_t *&p; ~OffGuard() { if (p) gmg_pool_release(p); } } off_guard = {d_off};       // until then it is ours
     DevFree dev;
     dev.st = st;
     uint8_t *d_bytes = nullptr, *d_func = nullptr, *d_bstate = nullptr;
     FaSumm *d_summ = nullptr;
     uint64_t *d_bexcl = nullptr, *d_tot = nullptr, n_blocks = 0;
-    uint64_t *d_count = nullptr, *d_off = nullptr, *d_hb = nullptr, *d_he = nullptr;
+    uint64_t *d_count = nullptr, *d_hb = nullptr, *d_he = nullptr;
     uint32_t *d_packed = nullptr;
     unsigned long long *d_gc = nullptr;
     void *d_tmp = nullptr;
@@ -534,10 +540,6 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
     } while (0)
     const uint64_t n = n_bytes;
     uint64_t n_reads = 0, total = 0;
-    // what goes to the gmg_reads: the packed words in their guarded buffer, the offsets
-    uint32_t *d_alloc = nullptr;
-    struct BufGuard { uint32_t *&p; ~BufGuard() { if (p) gmg_pool_release(p); } } alloc_guard = {d_alloc};   // until the reads own it
-    struct OffGuard { uint64_t *&p; ~OffGuard() { if (p) gmg_pool_release(p); } } off_guard = {d_off};       // until then it is ours
     // a chunked upload packs every piece as it arrives, into arrays sized by a bound: rec_cap records (16 file bytes per record; a file
     // with more takes the plain order once the totals are known), one base per byte
     bool spec = false;
