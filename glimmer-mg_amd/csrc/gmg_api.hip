@@ -1209,6 +1209,7 @@ extern "C" int gmg_trim_cache(void)
         if (b.busy && b.waiting && hipEventQuery(b.pending) == hipSuccess) { b.busy = false; b.waiting = false; }
     for (size_t i = 0; i < g_pool.size();)
         if (!g_pool[i].busy) { if (g_pool[i].pending) (void)hipEventDestroy(g_pool[i].pending); (void)hipFree(g_pool[i].p); g_pool.erase(g_pool.begin() + i); } else i++;
+    gmg_ingest_trim();                                  // (the page-locked header buffers gmg_fasta_ingest keeps)
     return GMG_OK;
 }
 

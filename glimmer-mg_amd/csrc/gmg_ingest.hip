@@ -77,6 +77,14 @@ struct PinnedCache {
 PinnedCache &pinned_cache() { static PinnedCache *c = new PinnedCache(); return *c; }
 }  // namespace
 
+void gmg_ingest_trim(void)
+{
+    PinnedCache &c = pinned_cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    for (auto &it : c.free_items) (void)hipHostFree(it.p);
+    c.free_items.clear();
+}
+
 namespace {
 
 enum { ST_PRE = 0, ST_HDR = 1, ST_SEQ = 2 };

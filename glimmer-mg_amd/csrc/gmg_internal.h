@@ -133,6 +133,7 @@ static inline long long gmg_opt(int k) { return g_gmg_opt[k]; }
 
 // cache of device blocks for scratch and result buffers (gmg_api.hip): hipMalloc / hipFree of GB-sized buffers cost up
 // to hundreds of milliseconds now and then; a released block is handed to the next request it fits
+void gmg_ingest_trim(void);                       // gmg_ingest.hip: frees its cached page-locked buffers
 hipError_t gmg_pool_alloc(void **out, size_t bytes);
 void gmg_pool_release(void *p);
 void gmg_pool_release_after(void *p, hipStream_t s);   // ... once the work queued on s so far is done
