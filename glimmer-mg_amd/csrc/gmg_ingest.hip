@@ -739,7 +739,7 @@ extern "C" int gmg_fasta_ingest_on(const char *bytes, uint64_t n_bytes, gmg_read
     if (e2 == hipSuccess) rc = gmg_launch_tile_read(d_off, n_reads, reads->n_tiles, reads->d_tile_read, st);
     if (e2 == hipSuccess && !rc && n_reads) {
         const uint64_t blocks = (n_reads + 255) / 256;
-        hipLaunchKernelGGL(k_fa_stats, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, d_off, n_reads, d_stats);
+        hipLaunchKernelGGL(k_fa_stats, dim3((unsigned)(blocks < 128 ? blocks : 128)), dim3(256), 0, st, d_off, n_reads, d_stats);      // (few waves: three atomics each)
         e2 = hipGetLastError();
     }
     if (e2 == hipSuccess && !rc) e2 = hipMemcpyAsync(stats, d_stats, 24, hipMemcpyDeviceToHost, st);
