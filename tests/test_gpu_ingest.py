@@ -81,6 +81,26 @@ def test_ingest_block_summaries_equal_the_scans_on_a_large_soup(gpu, seed):
     assert piecewise[1] == out[1][1] and piecewise[2] == out[1][2]
 
 
+def test_ingest_default_path_at_chunked_size(gpu):
+    """a 70 MB file with the default switches (>= 64 MiB: the 16-piece upload, every piece parsed and packed as it arrives) against the
+    first version (two scans over every byte, one plain copy): the same packed words, offsets, header extents and g/c count"""
+    rng = np.random.default_rng(23)
+    n_reads, L = 134_000, 500
+    bases = np.frombuffer(b"acgtacgtacgtacgn", np.uint8)[rng.integers(0, 16, size=(n_reads, L))]
+    body = np.full((n_reads, L + 8), ord("\n"), np.uint8)
+    body[:, np.arange(L) + np.arange(L) // 70] = bases
+    hdr = np.frombuffer(b"".join(b">r%06d  x y\n" % i for i in range(n_reads)), np.uint8).reshape(n_reads, -1)
+    data = np.ascontiguousarray(np.concatenate([hdr, body], axis=1).reshape(-1)).tobytes()
+    assert len(data) > 64 << 20
+    out = []
+    for scans in (0, 1):
+        with gpu.option("ingest_scans", scans):
+            reads, headers, gc = gpu.Reads.from_fasta_bytes(data)
+            packed, off = reads.download()
+            out.append((packed.tobytes(), off.tobytes(), headers, gc, reads.n_reads))
+    assert out[0] == out[1] and out[0][4] == n_reads and out[0][2][-1] == b"r%06d  x y" % (n_reads - 1)
+
+
 def test_ingest_piecewise_edges(gpu, oracle):
     """the chunked upload on inputs built around its seams: a '>' whose blanks run across the end of a piece (the header's begin is
     completed when all bytes are there), across several pieces, up to the end of the file; more records than the bound the arrays
