@@ -216,7 +216,22 @@ struct Piece {
 static int run_shard(const char *bytes, uint64_t b0, uint64_t b1, int device, uint64_t batch_bytes, int up, int down,
                      const string &out_name)
 {
+    // GMG_CLI_TIMING=1: where the wall time of this process goes, on stderr
+    const bool cli_timing = getenv("GMG_CLI_TIMING") != NULL;
+    struct CliClock {                                   // acc: device init, ingest, models, reads back to the host, scoring + fetch, events / DP / output
+        struct timespec prev;
+        double acc[6];
+        CliClock() { clock_gettime(CLOCK_MONOTONIC, &prev); for (int k = 0; k < 6; k++) acc[k] = 0.0; }
+        void lapse(int k)
+        {
+            struct timespec now;
+            clock_gettime(CLOCK_MONOTONIC, &now);
+            acc[k] += (double)(now.tv_sec - prev.tv_sec) + 1e-9 * (double)(now.tv_nsec - prev.tv_nsec);
+            prev = now;
+        }
+    } clk;
     if (gmg_init(device) != GMG_OK) die_gmg("gmg_init");
+    clk.lapse(0);
     const bool error_mode = Allow_Indels || Allow_Subs;
 
     // pass 1: every piece of the shard onto the device (parsed there); the shard's {gc, total}
@@ -257,7 +272,9 @@ static int run_shard(const char *bytes, uint64_t b0, uint64_t b1, int device, ui
             Indep_GC_Frac = gmg_gc_fraction(&gc, &total, 1, 1);
         GC_Frac_Set = true;
     }
+    clk.lapse(1);
     setup_models();
+    clk.lapse(2);
 
     gmg_mg_params prm;
     fill_params(prm, error_mode);
@@ -287,6 +304,7 @@ static int run_shard(const char *bytes, uint64_t b0, uint64_t b1, int device, ui
         vector<uint64_t> off(pc.n_reads + 1);
         vector<uint32_t> packed(gmg_packed_words(pc.total_bases) + 1, 0);
         if (gmg_reads_download(pc.reads, packed.data(), off.data()) != GMG_OK) die_gmg("gmg_reads_download");
+        clk.lapse(3);
         vector<uint8_t> qual_all;
         prm.quality = NULL;
         if (quality_fp) {                               // the user's Phred values, one byte per base
@@ -307,6 +325,7 @@ static int run_shard(const char *bytes, uint64_t b0, uint64_t b1, int device, ui
         score_batch(Gene_ICM.Device_Model(), Indep_Model.Device_Model(), pc.reads, pc.n_reads, prm, error_mode, sc);
         gmg_reads_free(pc.reads);
         pc.reads = NULL;
+        clk.lapse(4);
 
         string hdr;
         for (int i = 0; i < n_seq; i++) {
@@ -316,9 +335,13 @@ static int run_shard(const char *bytes, uint64_t b0, uint64_t b1, int device, ui
             fprintf(predict_fp, ">%s\n", Fasta_Header);
             back_half(predict_fp, sc, i, error_mode);
         }
+        clk.lapse(5);
     }
     fclose(predict_fp);
     if (quality_fp) fclose(quality_fp);
+    if (cli_timing)
+        fprintf(stderr, "glimmer-mg_gpu: device init %.3f s, ingest %.3f, models %.3f, reads back to the host %.3f, scoring + fetch %.3f, events / DP / output %.3f\n",
+                clk.acc[0], clk.acc[1], clk.acc[2], clk.acc[3], clk.acc[4], clk.acc[5]);
     return EXIT_SUCCESS;
 }
 
