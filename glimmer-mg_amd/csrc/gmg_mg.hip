@@ -1150,10 +1150,15 @@ template <int NW, bool G32, int EL, bool PRN, int NC = MT_NC>
 __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 3 : 1) void k_mg_tile_starts(MgArgs a)
 {
     constexpr int BLOCK = 64 * NW, WV = 3 * MT_CL * EL, CAP = WV * NW;
+    constexpr bool DIST = !(G32 && PRN);                                // a base's distance to its read's ends from s_oinfo instead of followed read offsets
     constexpr int NPK = CAP / 16 + 7;                                   // packed words staged (two in front, the windows of stage 2 behind)
     constexpr int PW = (NPK + BLOCK - 1) / BLOCK, PR = (MG_TILE_READS + 1 + BLOCK - 1) / BLOCK;
     __shared__ __attribute__((aligned(16))) double s_val[CAP];          // T in walk order, then the running sums
-    __shared__ uint16_t s_oinfo[CAP];                                   // at a region's first u: the ORF's index in the tile + 1
+    // at a region's first u: the ORF's index in the tile + 1 (bits 0-11; a tile's ORFs are fewer than its bases); for every u: how close its base lies
+    // to its read's ends -- bits 12-13: 3 - min (si, 3), bits 14-15: 3 - min (n - 1 - si, 3) (0 = three or more away: only the six edge bases
+    // of a read are marked) -- what stage 2 asks about a base's read (DIST; with a null model per read it follows the reads itself: it needs
+    // their index).  Marks and ORF indices are OR-ed in with 32-bit LDS atomics: any order.
+    __shared__ __attribute__((aligned(4))) uint16_t s_oinfo[CAP + 2];
     __shared__ uint32_t s_ch[CAP];                                      // start codons before u in its segment | the segment's first u << 12
     __shared__ uint16_t s_q[CAP];                                       // the starts found: u | (which + 1) << 12
     __shared__ uint32_t s_packed[NPK];
@@ -1416,8 +1421,20 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                 orf_of(e, rd, frame, lo, hi, so, nt);
                 if ((frame > 0) != fwd) continue;
                 orf_geo(rd, lo, hi, trunc, m, uh);
-                if (m > 0) s_oinfo[uh] = (uint16_t)(e + 1);
+                if (m > 0) atomicOr((uint32_t *)s_oinfo + (uh >> 1), (e + 1u) << (16u * (uh & 1u)));
             }
+            if (DIST)                                   // the six edge bases of every read of the tile
+                for (uint32_t r = tid; r < nfit; r += BLOCK) {
+                    const int rs = (int)s_roff[r], n = (int)s_roff[r + 1] - rs;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const int si = k < 3 ? k : n - 1 - (k - 3);
+                        if (si < 0 || si >= n) continue;
+                        const uint32_t ds = si < 3 ? (uint32_t)si : 3u, de = n - 1 - si < 3 ? (uint32_t)(n - 1 - si) : 3u;
+                        const uint32_t b = (uint32_t)(rs + si), u = fwd ? span - 1u - b : b;
+                        atomicOr((uint32_t *)s_oinfo + (u >> 1), ((3u - ds) | (3u - de) << 2) << (12u + 16u * (u & 1u)));
+                    }
+                }
             if (G32 && PRN) {
                 const uint32_t nc = nfit < NC ? nfit : NC;
                 for (uint32_t i = MG_NULL_FLOATS + tid; i < nc * MG_NULL_FLOATS; i += BLOCK) {       // (the first read's came with the tile)
@@ -1426,7 +1443,7 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                 }
             }
         }
-        if (G32) __syncthreads();
+        __syncthreads();                                // (the null tables of the tile's reads, the edge marks: stage 2 reads both)
         MT_STAMP(2);                                    // stage 1
         // ---- stage 2: the scan.  Lane (class c, part jl) owns elements u = ub + 3 i, i < EL: every third base of 27
         // consecutive ones.  The ten codons of its class that surround them come out of ONE 64-bit window of the packed bases as
@@ -1460,7 +1477,7 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                 const uint32_t wlo = __builtin_amdgcn_alignbit(q1, q0, X & 31u), whi = __builtin_amdgcn_alignbit(q2, q1, X & 31u);
                 const uint64_t win = (uint64_t)whi << 32 | wlo;                    // base sb + t at bits 2t
                 uint32_t rl = 0; int rs = 0, n = 0;
-                if ((uint32_t)b0 < span) read_of((uint32_t)b0, rl, rs, n);
+                if (!DIST && (uint32_t)b0 < span) read_of((uint32_t)b0, rl, rs, n);
                 // the table bytes of the EL + 1 codon fields this lane's elements meet (element i: stop test on one, start test on the next)
                 uint32_t wb[EL + 1];
 #pragma unroll
@@ -1470,14 +1487,17 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                     const uint32_t u = ub + 3 * i;
                     const int b = FWD ? b0 - 3 * i : b0 + 3 * i;
                     const bool valid = (uint32_t)b < span;
-                    if (valid) {
+                    if (!DIST && valid) {
                         if (FWD) while (b < rs) { rl--; rs = (int)s_roff[rl]; n = (int)s_roff[rl + 1] - rs; }
                         else while (b >= rs + n) { rl++; rs = (int)s_roff[rl]; n = (int)s_roff[rl + 1] - rs; }
                     }
                     const int si = b - rs;
+                    // DIST: 3 - (distance to the read's first base, to its last base), both capped at 3; the walk runs away from `near`
+                    const uint32_t dd = DIST ? (uint32_t)s_oinfo[u] >> 12 : 0u;
+                    const uint32_t near3 = FWD ? dd >> 2 : dd & 3u, far3 = FWD ? dd & 3u : dd >> 2;
                     const uint32_t bs = wb[FWD ? EL - i : i], bw = wb[FWD ? EL - 1 - i : i + 1];
-                    const bool st = !valid || (FWD ? si + 3 >= n : si < 3) || (bs & 0x80u);
-                    const bool geo = FWD ? si >= 2 : si + 2 <= n - 1;
+                    const bool st = !valid || (DIST ? near3 != 0 : (FWD ? si + 3 >= n : si < 3)) || (bs & 0x80u);
+                    const bool geo = DIST ? far3 <= 1u : (FWD ? si >= 2 : si + 2 <= n - 1);
                     const uint32_t wh = bw & 0x7fu;
                     // (a codon may be in the start set AND in the stop set -- "-A nnn": the stop codon that ends a region is no start)
                     const uint32_t cand = valid && geo && bw - 1u < 0x7fu ? 1u : 0u;
@@ -1496,13 +1516,13 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                             return (double)s_nullm[rl < NC ? rl : 0u][off];
                         };
                         double nsum;
-                        if (FWD ? si + 2 >= n : si < 2) {                          // one of them is a partial window
+                        if (DIST ? near3 >= 2u : (FWD ? si + 2 >= n : si < 2)) {   // one of them is a partial window
                             nsum = 0.0;
 #pragma unroll
                             for (int t = 0; t < 3; t++) {                          // (no branches in here: selects)
                                 const int fr = t == 0 ? 1 : t == 1 ? 2 : 0;
                                 const int xs = FWD ? si - t : si + t;              // the term's base in its read
-                                const int j = FWD ? n - 1 - xs : xs;
+                                const int j = DIST ? 3 - (int)near3 + t : (FWD ? n - 1 - xs : xs);
                                 const int bx = bitb + (FWD ? -2 * t : 2 * t);      // bit position of S[x]
                                 const uint32_t c0 = (uint32_t)(win >> bx) & 3u;
                                 const uint32_t c1 = (uint32_t)(win >> (FWD ? bx + 2 : bx - 2)) & 3u;
@@ -1510,7 +1530,7 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                                 const uint32_t v = (uint32_t)(win >> (FWD ? bx : bx - 4)) & 63u;
                                 const uint32_t off = j >= 2 ? fr * 64 + v : 192u + fr * 20 + (j == 1 ? 4u + (b1c | b0c << 2) : b0c);
                                 const double nv = nullv(off, v);
-                                nsum += xs >= 0 && xs < n ? nv : 0.0;              // (beyond the read: T is never used then)
+                                nsum += (DIST ? 3 - (int)far3 >= t : (xs >= 0 && xs < n)) ? nv : 0.0;       // (beyond the read: T is never used then)
                             }
                         } else {
                             const uint32_t v1 = (uint32_t)(win >> (FWD ? bitb : bitb - 4)) & 63u, v2 = (uint32_t)(win >> (bitb - 2)) & 63u;
@@ -1580,7 +1600,7 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                     s_ch[u] = ch;
                     if ((ep[i] >> 26) & 1u) {           // a start codon inside the read: a start if an ORF's region holds it at j >= lowest j
                         const uint32_t hd = ch >> 12;
-                        if (s_oinfo[hd] != 0 && (int)(u - hd) >= j_lo) s_q[atomicAdd(&s_nq, 1u)] = (uint16_t)(u | (ep[i] >> 27) << 12);
+                        if ((s_oinfo[hd] & 0xfffu) != 0 && (int)(u - hd) >= j_lo) s_q[atomicAdd(&s_nq, 1u)] = (uint16_t)(u | (ep[i] >> 27) << 12);
                     }
                 }
             }
@@ -1617,7 +1637,7 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
             for (uint32_t qi = tid; qi < nq; qi += BLOCK) {
                 const uint32_t qe = s_q[qi], u = qe & 0xfffu;
                 const uint32_t ch = s_ch[u], hd = ch >> 12;
-                const uint32_t info = s_oinfo[hd];
+                const uint32_t info = s_oinfo[hd] & 0xfffu;
                 const uint32_t e = info - 1u;
                 if (e < e0 || e >= e0 + MT_ORFS) continue;
                 const int j = (int)(u - hd);
