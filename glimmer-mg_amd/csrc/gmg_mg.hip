@@ -1177,8 +1177,7 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
     // v = S[x-2] | S[x-1] << 2 | S[x] << 4 (complemented read) -- and the partial-window tables as they are
     // ([0] forward, [1] reverse, each followed by the partial-window tables).  With a null model per read (a.read_null) the tables of
     // the tile's reads (MT_NC at most in this mode) are fetched with the tile, in the order of the strand it works on.
-    __shared__ double s_nulld[G32 && !PRN ? 192 : 1];                   // one null model: the full-window values as doubles (no conversion per look-up), ...
-    __shared__ float s_nullp[G32 && !PRN ? MG_NULL_FLOATS - 192 : 1];   // ... the partial-window tables
+    __shared__ double s_nulld[G32 && !PRN ? MG_NULL_FLOATS : 1];        // one null model: its values as doubles (no conversion, one table for the full and the partial windows)
     __shared__ float s_nullm[G32 && PRN ? NC : 1][G32 && PRN ? MG_NULL_FLOATS : 1];
     __shared__ uint32_t s_rnull[G32 && PRN ? NC + 2 : 1];                  // (a tile takes NC reads at most in that mode)
 
@@ -1192,8 +1191,7 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
     const bool fwd_wg = (blockIdx.x & 1u) == 0;
     if (G32 && !PRN)
         for (uint32_t i = tid; i < MG_NULL_FLOATS; i += BLOCK) {
-            const float v = a.null_tab[null_src(i, fwd_wg)];
-            if (i < 192u) s_nulld[i] = (double)v; else s_nullp[i - 192u] = v;
+            s_nulld[i] = (double)a.null_tab[null_src(i, fwd_wg)];
         }
     const uint64_t n_tiles = a.n_tiles_dev ? (uint64_t)*a.n_tiles_dev : a.n_tiles;
     if (tid < 64) {
@@ -1508,7 +1506,7 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                         const int bitb = FWD ? 2 * FW0 - 6 * i : 6 * i + 6;             // bit position of S[b] in the window
                         // entry `off` of the read's table in this strand's order
                         auto nullv = [&](uint32_t off, uint32_t) __attribute__((always_inline)) -> double {
-                            if (!PRN) return off < 192u ? s_nulld[off] : (double)s_nullp[off - 192u];
+                            if (!PRN) return s_nulld[off];
                             return (double)s_nullm[rl < NC ? rl : 0u][off];       // (mg_run lets a tile take MT_NC reads at most then)
                         };
                         auto nullf = [&](uint32_t off) __attribute__((always_inline)) -> double {        // a full-window entry
