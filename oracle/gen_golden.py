@@ -17,6 +17,10 @@ Vectors produced by oracle/_ref/ref_dump (our driver over the reference's ICM_t)
   partial.npz       Partial_Window_Prob (icm.cc:807-842) for every prefix position of 64 reads x 3 frames
   indep.npz         Build_Indep_WO_Stops tables (icm.cc:65-216) for GC x stop-codon sets
   predict/*.predict reference CLI outputs on seqs.fa (glimmer3, glimmer3 -X..., glimmer-mg, glimmer-mg -i)
+  predict/NC_000915.run1.predict   the reference's own committed answer file (sample-run/glimmer3/results; scripts/g3-iterated.py:58),
+                    copied as data and re-made here as a check; NC_000915.{step6,glimmer-mg,glimmer3.X_l}.predict: the same genome
+                    through step 6's shape (-b motif -m gicm), glimmer-mg and glimmer3 -X -l
+  revcodon.npz      Build_Reverse_Codon_WO_Stops (icm.cc:219-350) models + probe scores
 """
 import hashlib
 import os
@@ -73,9 +77,15 @@ def main():
     for i in range(6):
         copies["cluster-%d.icm" % i] = "glimmer-mg/results/cluster-%d.icm" % i
         copies["icm-%d.scores.tmp" % i] = "glimmer-mg/results/icm-%d.scores.tmp" % i
+    # the reference's whole-path known-answer case (scripts/g3-iterated.py:58: glimmer3 -u -12 -m NC_000915.icm NC_000915.fna):
+    # the genome, the answer file it holds, and the second iteration's model + RBS matrix (step 6's inputs, g3-iterated.py:74)
+    copies.update({"NC_000915.fna": "glimmer3/NC_000915.fna", "NC_000915.run1.gicm": "glimmer3/results/NC_000915.run1.gicm",
+                   "NC_000915.run1.motif": "glimmer3/results/NC_000915.run1.motif"})
     for dst, src in copies.items():
         shutil.copyfile(os.path.join(sr, src), os.path.join(DATA, dst))
         os.chmod(os.path.join(DATA, dst), 0o644)
+    shutil.copyfile(os.path.join(sr, "glimmer3/results/NC_000915.run1.predict"), os.path.join(GOLD, "predict", "NC_000915.run1.predict"))
+    os.chmod(os.path.join(GOLD, "predict", "NC_000915.run1.predict"), 0o644)
 
     fa = os.path.join(DATA, "seqs.fa")
     nc = os.path.join(DATA, "NC_000915.icm")
@@ -152,6 +162,12 @@ def main():
             out[key + "_mip"] = mip
     np.savez_compressed(os.path.join(GOLD, "indep.npz"), seqs_gc=gc, **out)
 
+    # ---- Build_Reverse_Codon_WO_Stops (icm.cc:219-350; public, no caller in the reference): seeded codon weights x stop sets
+    rc = {}
+    for seed, stops in ((1, "taa,tag,tga"), (20260105, "taa,tag"), (7, "tga")):
+        rc["s%d_%s" % (seed, stops.replace(",", "_"))] = np.frombuffer(run("revcodon", seed, stops), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "revcodon.npz"), **rc)
+
     # ---- writer round trip (icm.cc:729-803): reference Read -> Output must reproduce the file
     tmp = os.path.join(RB, "rewrite.icm")
     run("rewrite", nc, tmp)
@@ -172,6 +188,23 @@ def main():
         subprocess.run([os.path.join(RB, cmd[0]), *cmd[1:], fa, tag], check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=RB)
         shutil.copyfile(tag + ".predict", os.path.join(GOLD, "predict", name + ".predict"))
+    # ---- the whole path at genome scale: one 1.67 Mbp sequence (ORFs of several kb, ~100 k ORFs in one record list)
+    fna = os.path.join(DATA, "NC_000915.fna")
+    genome_clis = {
+        "NC_000915.run1.rerun": ["glimmer3", "-u", "-12", "-m", nc],          # must reproduce the reference-held answer file
+        "NC_000915.step6": ["glimmer3", "-b", os.path.join(DATA, "NC_000915.run1.motif"), "-m", os.path.join(DATA, "NC_000915.run1.gicm")],
+        "NC_000915.glimmer-mg": ["glimmer-mg", "-m", nc],
+        "NC_000915.glimmer3.X_l": ["glimmer3", "-X", "-l", "-m", nc],
+    }
+    for name, cmd in genome_clis.items():
+        tag = os.path.join(RB, "cli_" + name)
+        subprocess.run([os.path.join(RB, cmd[0]), *cmd[1:], fna, tag], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=RB)
+        if name.endswith(".rerun"):
+            assert open(tag + ".predict", "rb").read() == open(os.path.join(GOLD, "predict", "NC_000915.run1.predict"), "rb").read(), \
+                "the reference built here does not reproduce sample-run/glimmer3/results/NC_000915.run1.predict"
+        else:
+            shutil.copyfile(tag + ".predict", os.path.join(GOLD, "predict", name + ".predict"))
     # ---- Score_Orfs inner loop (glimmer3.cc:1275-1552): ORFs from Find_Orfs + the start lists handed to Add_Events_*
     for name, flags in (("orfs_default", []), ("orfs_X", ["-X"]), ("orfs_g90_first", ["-g", "90", "-f", "x"])):
         txt = subprocess.run([os.path.join(RB, "ref_orfs"), "dump", *flags, "-m", nc, fa, os.path.join(RB, "orfs_tag")],

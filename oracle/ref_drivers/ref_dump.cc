@@ -21,6 +21,8 @@
 //   ref_dump text     <icm>                                    ICM_t::Output (fp, false): the text form (Output_Node, icm.cc:729-803)
 //   ref_dump display  <icm>                                    ICM_t::Display (icm.cc:455-482)
 //   ref_dump copy     <icm> <fasta> <count>                    ICM_t::Copy (icm.cc:1000-1007) into a second object, then Score_String on it
+//   ref_dump revcodon <seed> <stop1,stop2,...> [model]         Build_Reverse_Codon_WO_Stops (icm.cc:219-350) on 64 seeded codon weights: the
+//                                                              model through ::Output(binary), then 9 Score_String doubles of three probe strings
 //
 // The same file is built a second time against glimmer-mg_amd/host/icm.hh + libgmg.so (integration/Makefile: ref_dump_dropin): the
 // C++ interface of the drop-in, method by method, against the reference's (tests/test_gpu_icm_class.py).
@@ -144,6 +146,39 @@ int main(int argc, char **argv)
         build_indep(indep, atof(argv[2]), argc > 3 ? argv[3] : NULL);
         // dump through the public writer, then the caller parses the .icm stream
         indep.Output(stdout, true);
+        return 0;
+    }
+    if (cmd == "revcodon") {                            // Build_Reverse_Codon_WO_Stops (icm.cc:219-350; no caller in the reference)
+        // 64 codon weights from a seed (SplitMix64; the method normalises them), stop codons from the command line
+        unsigned long long x = strtoull(argv[2], NULL, 10);
+        double cp[64];
+        for (int j = 0; j < 64; j++) {
+            x += 0x9E3779B97F4A7C15ULL;
+            unsigned long long z = x;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            z ^= z >> 31;
+            cp[j] = 0.001 + double(z >> 11) / 9007199254740992.0;
+        }
+        static vector<string> keep;
+        vector<const char *> stops;
+        string csv = argc > 3 ? argv[3] : "taa,tag,tga";
+        for (size_t a = 0; a <= csv.size(); ) {
+            size_t b = csv.find(',', a);
+            if (b == string::npos) b = csv.size();
+            if (b > a) keep.push_back(csv.substr(a, b - a));
+            a = b + 1;
+        }
+        for (size_t i = 0; i < keep.size(); i++) stops.push_back(keep[i].c_str());
+        ICM_t m(3, 2, 3);
+        m.Build_Reverse_Codon_WO_Stops(cp, stops);
+        m.Output(stdout, true);
+        if (argc > 4 && !strcmp(argv[4], "model")) return 0;       // the tables alone (needs no device in the drop-in build)
+        // and what the model then scores: three short strings in every frame
+        const char *probe[3] = {"atggcgtaaacgtgatag", "ttagcatcacgcgcgcat", "acgtacgtacgtaacc"};
+        for (int s = 0; s < 3; s++)
+            for (int f = 0; f < 3; f++)
+                put_d(m.Score_String(probe[s], strlen(probe[s]), f));
         return 0;
     }
     if (cmd == "rewrite") {

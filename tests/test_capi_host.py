@@ -147,3 +147,18 @@ def test_fasta_split_cuts_only_where_a_record_starts(gmg):
         assert data[int(c) - 1:int(c) + 1] == b"\n>"
     assert np.all(np.diff(cuts[:n + 1].astype(np.int64)) > 0)
     assert lib.gmg_fasta_split(data, len(data), 10**9, cuts.ctypes.data_as(C.c_void_p), 63) == 1 and cuts[1] == len(data)
+
+
+def test_build_reverse_codon_wo_stops_tables_without_a_device():
+    """ICM_t::Build_Reverse_Codon_WO_Stops (src/ICM/icm.cc:219-350; host/icm.cc) is host arithmetic: the drop-in build of
+    ref_dump writes the tables the reference's class wrote into tests/golden/revcodon.npz (the 72 bytes behind them are
+    Score_String values, which need the device: tests/test_gpu_icm_class.py)"""
+    import subprocess
+    from conftest import built_binary
+    exe = built_binary("integration", "_build", "ref_dump_dropin")
+    g = np.load(os.path.join(GOLD, "revcodon.npz"))
+    for key, seed, stops in (("s1_taa_tag_tga", 1, "taa,tag,tga"), ("s20260105_taa_tag", 20260105, "taa,tag"), ("s7_tga", 7, "tga")):
+        res = subprocess.run([exe, "revcodon", str(seed), stops, "model"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        assert res.returncode == 0, res.stderr.decode()[-500:]
+        want = g[key].tobytes()
+        assert len(res.stdout) == len(want) - 72 and res.stdout == want[:-72]

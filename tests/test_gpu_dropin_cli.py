@@ -220,3 +220,42 @@ def test_glimmer3_gpu_on_the_nasty_fasta_file(gpu, tmp_path):
         assert res.returncode == 0, res.stderr.decode()[-2000:]
         out.append(open(str(tmp_path / tag) + ".predict", "rb").read())
     assert out[0] == out[1] and out[0].count(b">") >= 10
+
+
+# ---- the whole path at genome scale --------------------------------------------------------------------------------------
+# One 1.67 Mbp sequence = one "read" that spans > 800 tiles of the six-frame pass, ORFs of several kb, ~100 k ORFs in ONE
+# record list: where a tile / offset bug of gmg_find_orfs / gmg_score_orfs (events path: Q[p_j] - Q[p_12] over long ORFs)
+# would hide.  tests/golden/predict/NC_000915.run1.predict is the REFERENCE'S OWN committed answer file
+# (sample-run/glimmer3/results, made by scripts/g3-iterated.py:58); the other three goldens are oracle/_ref runs of
+# oracle/gen_golden.py, and the reference binary is run again beside the device path in the test.
+
+GENOME = os.path.join(DATA, "NC_000915.fna")
+RUN1 = ["-u", "-12", "-m", os.path.join(DATA, "NC_000915.icm")]
+STEP6 = ["-b", os.path.join(DATA, "NC_000915.run1.motif"), "-m", os.path.join(DATA, "NC_000915.run1.gicm")]
+
+
+def _predict(exe, opts, tag, timeout=900):
+    res = subprocess.run([exe, *opts, GENOME, tag], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    return open(tag + ".predict", "rb").read()
+
+
+@pytest.mark.parametrize("binary", ["glimmer3_gpu", "glimmer3_dropin"])
+def test_genome_run1_is_the_answer_file_the_reference_holds(gpu, tmp_path, binary):
+    """glimmer3 -u -12 -m NC_000915.icm NC_000915.fna (g3-iterated.py step 4): 1,549 genes, byte for byte"""
+    want = open(os.path.join(GOLD, "predict", "NC_000915.run1.predict"), "rb").read()
+    got = _predict(built_binary("integration", "_build", binary), RUN1, str(tmp_path / "run1"))
+    assert want.count(b"\norf") == 1549
+    assert got == want
+
+
+@pytest.mark.parametrize("name,ref,dev,opts", [
+    ("NC_000915.step6", "glimmer3", "glimmer3_gpu", STEP6),                     # g3-iterated.py:74 without -f (SURVEY section 4: -f ignores its file)
+    ("NC_000915.glimmer-mg", "glimmer-mg", "glimmer-mg_gpu", RUN1[2:]),
+    ("NC_000915.glimmer3.X_l", "glimmer3", "glimmer3_gpu", ["-X", "-l"] + RUN1[2:]),
+], ids=["step6", "glimmer-mg", "glimmer3_X_l"])
+def test_genome_other_shapes_against_the_reference_run_here(gpu, tmp_path, name, ref, dev, opts):
+    want = open(os.path.join(GOLD, "predict", name + ".predict"), "rb").read()
+    again = _predict(built_binary("oracle", "_ref", ref), opts, str(tmp_path / "ref"))
+    assert again == want and want.count(b"\norf") >= 2000
+    assert _predict(built_binary("integration", "_build", dev), opts, str(tmp_path / "dev")) == want

@@ -2,7 +2,7 @@
 the driver that made the golden vectors from the REFERENCE's ICM_t -- is built a second time against OUR ICM_t and libgmg.so
 (integration/Makefile: ref_dump_dropin) and must write the same bytes as the all-reference build (oracle/_ref/ref_dump, run here
 beside it) for every command: Read, Score_String, Frame_Score, Cumulative_Score, Cumulative_Score_String, Full_Window_Prob,
-Full_Window_Distrib, Partial_Window_Prob, Build_Indep_WO_Stops, Output (binary and text), Display, Copy.  Where tests/golden holds
+Full_Window_Distrib, Partial_Window_Prob, Build_Indep_WO_Stops, Build_Reverse_Codon_WO_Stops, Output (binary and text), Display, Copy.  Where tests/golden holds
 the vector of a command (oracle/gen_golden.py), the drop-in's bytes are also compared with the committed fixture."""
 import os
 import subprocess
@@ -54,6 +54,9 @@ CASES = {
     "text_gicm": ("text", GICM),
     "display": ("display", GICM),
     "copy": ("copy", NC, FA, 24),
+    "revcodon": ("revcodon", 1, "taa,tag,tga"),
+    "revcodon_two_stops": ("revcodon", 20260105, "taa,tag"),
+    "revcodon_one_stop": ("revcodon", 7, "tga"),
 }
 
 
@@ -93,6 +96,9 @@ def test_against_the_committed_goldens(exes, segfile):
     g = np.load(os.path.join(GOLD, "partial.npz"))
     key = "partial" if "partial" in g.files else g.files[0]
     assert np.frombuffer(run(mine, "partial", NC, FA, 64), "<f8").tobytes() == np.ascontiguousarray(g[key]).tobytes()
+    g = np.load(os.path.join(GOLD, "revcodon.npz"))           # Build_Reverse_Codon_WO_Stops (icm.cc:219-350): tables + 9 probe scores
+    for key, seed, stops in (("s1_taa_tag_tga", 1, "taa,tag,tga"), ("s20260105_taa_tag", 20260105, "taa,tag"), ("s7_tga", 7, "tga")):
+        assert run(mine, "revcodon", seed, stops) == g[key].tobytes()
     g = np.load(os.path.join(GOLD, "segs.npz"))
     raw = np.frombuffer(run(mine, "segs", NC, FA, segfile, -1), "<f8")
     gene, indep, off = [], [], 0
