@@ -2191,10 +2191,10 @@ __global__ __launch_bounds__(256) void k_mg_run_tables(MgArgs a, uint8_t *run_q,
 
 // (the ORFs' aggregates are initialised by the level-0 count pass as it takes them -- it has the record in hand; the slot
 // counters and the bitmap of the accepted ORFs are zeroed by memsets)
-__global__ __launch_bounds__(256) void k_mg_err_prepare(MgArgs a)
+__global__ __launch_bounds__(256) void k_mg_err_prepare(MgArgs a, const uint64_t fit_len)
 {
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += (uint64_t)gridDim.x * blockDim.x)
-        a.read_fit[r] = a.read_off[r + 1] - a.read_off[r] < 2040;
+        a.read_fit[r] = a.read_off[r + 1] - a.read_off[r] < fit_len;
 }
 
 #ifndef MG_CALL_CHUNK
@@ -2597,6 +2597,7 @@ __global__ __launch_bounds__(256) void k_mg_err_begin(MgArgs a, const int accept
 }
 
 #include "gmg_mg_errtile.h"
+#include "gmg_mg_errwave.h"
 
 __global__ __launch_bounds__(256) void k_mg_seg_bounds(const gmg_mg_orf *orfs, uint64_t n, uint32_t *seg_begin, uint32_t *seg_end)
 {
@@ -2931,6 +2932,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     int fused_nw = 0, fused_el = 9;                     // waves per tile of k_mg_tile_starts (0: the sequential kernels), elements per lane
     bool err_exact = false;                             // the batch's sums are exact in any order: the error branch may take differences of running sums
     bool err_tile = false;                              // ... and runs tile by tile with the sums in LDS (k_mg_err_tile)
+    bool err_wave = false;                              // ... or with one wave per (read, strand), everything in the wave's LDS (k_mg_err_wave)
+    uint32_t ew_cap = 0;
     uint8_t *d_run = nullptr;
     bool fused_rest = false;
     MgTile *d_tiles = nullptr, *d_all = nullptr;
@@ -3101,7 +3104,16 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     const long long tile_opt = gmg_opt(GMG_OPT_MG_ERR_TILE);
     const bool tile_wanted = tile_opt > 0 || (tile_opt < 0 && a.total <= (err_mode == 1 ? (uint64_t)MG_ET_AUTO_BASES_INDEL : (uint64_t)MG_ET_AUTO_BASES_SUB));
     err_tile = err_mode && err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) && tile_wanted && !gmg_opt(GMG_OPT_MG_ERR_FLAT);
-    const uint64_t err_fit_len = err_tile ? MG_ET_CAP + 1 : 2040;       // reads shorter than this are walked by the tile / level kernels
+    // one wave per (read, strand) (k_mg_err_wave; the default whenever the sums are exact, unless the tile kernel is forced):
+    // its LDS share is sized by the batch's longest read, reads beyond EW_MAX_CAP go to k_mg_err_flat
+    err_wave = err_mode && err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) && !gmg_opt(GMG_OPT_MG_ERR_FLAT) && gmg_opt(GMG_OPT_MG_ERR_WAVE) > 0 &&
+               tile_opt <= 0 && reads->max_len > 0 && a.total;
+    if (err_wave) {
+        err_tile = false;
+        const uint64_t longest = reads->max_len < EW_MAX_CAP ? reads->max_len : EW_MAX_CAP;
+        ew_cap = (uint32_t)((longest + 63) & ~63ull);
+    }
+    const uint64_t err_fit_len = err_wave ? (uint64_t)ew_cap + 1 : err_tile ? MG_ET_CAP + 1 : 2040;   // reads shorter than this are walked by the wave / tile / level kernels
     const bool err_g32 = err_mode && !d_frame_scores && a.total && g32_opt != 0 && nul_dense3 && all_fast && err_exact &&
                          gmg_opt(GMG_OPT_MG_ERR_SKIP) && !gmg_opt(GMG_OPT_MG_ERR_FLAT) && reads->max_len && reads->max_len < err_fit_len;
     const bool g32 = err_g32 || (!d_frame_scores && !err_mode && a.total &&
@@ -3353,8 +3365,8 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         // (second stream), the six-frame kernel and the rows.  Tile by tile (k_mg_err_tile) the rows are built in LDS, tile by tile.
         a.walk_stride = ((a.total + 15) & ~15ull) + 16;
         a.pfx = err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) ? 1 : 0;
-        if (a.pfx && !err_tile) MG_TRY(build_run_tables(s3));   // running sums + run lengths: the walks visit their events only
-        if (!err_tile) MG_TRY(build_walk_rows(s));
+        if (a.pfx && !err_tile && !err_wave) MG_TRY(build_run_tables(s3));   // running sums + run lengths: the walks visit their events only
+        if (!err_tile && !err_wave) MG_TRY(build_walk_rows(s));
         MG_TRY(hipGetLastError());
         tm.lap("walk-order tables");
     }
@@ -3433,8 +3445,27 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             uint64_t want = (err_acc_only ? a.total / 16 : a.total / 3) + (1u << 20);
             if (gmg_opt(GMG_OPT_MG_ERR_TILE_Q) != 0) want = 64;         // (tests; -1: only this: the first pass finds the arrays too small)
             MG_TRY(alloc_staging(want));
-        } else MG_TRY(alloc_level_scratch());
+        } else if (!err_wave) MG_TRY(alloc_level_scratch());
     }
+    // k_mg_err_wave: as many one-wave work-groups per CU as their LDS shares allow (the grid strides over the (read, strand) pairs)
+    const uint32_t ew_qcap = gmg_opt(GMG_OPT_MG_ERR_WAVE_Q) > 0 ? (uint32_t)gmg_opt(GMG_OPT_MG_ERR_WAVE_Q) : (uint32_t)EW_QCAP;
+    auto launch_err_wave = [&](hipStream_t st, bool write) -> hipError_t {
+        const EwLayout lay = ew_layout(ew_cap, ew_qcap, write);
+        int n_cu = 0;
+        hipError_t e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
+        if (e != hipSuccess) return e;
+        uint32_t per_cu = (uint32_t)((160u * 1024u) / (lay.bytes + 1024u));
+        if (per_cu > 16) per_cu = 16;
+        if (per_cu < 1) per_cu = 1;
+        uint64_t grid = (uint64_t)(n_cu > 0 ? n_cu : 256) * per_cu * 4;
+        if (grid > 2 * nr) grid = 2 * nr;
+        if (grid == 0) return hipSuccess;
+#define MG_EW_LAUNCH(W_, G_) hipLaunchKernelGGL((k_mg_err_wave<W_, G_>), dim3((unsigned)grid), dim3(EW_BLOCK), lay.bytes, st, a, err_acc_only, ew_cap, ew_qcap)
+        if (write) { if (a.gene32) MG_EW_LAUNCH(true, true); else MG_EW_LAUNCH(true, false); }
+        else { if (a.gene32) MG_EW_LAUNCH(false, true); else MG_EW_LAUNCH(false, false); }
+#undef MG_EW_LAUNCH
+        return hipGetLastError();
+    };
     const size_t et_lds = sizeof(EtLds<MG_ET_CAP>);
     auto launch_err_tile = [&](hipStream_t st) -> hipError_t {
         MgArgs at = a;                                  // the kernel's starts go to the staging arrays
@@ -3453,8 +3484,13 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     int level_tries = 0;
     for (int attempt = 0; attempt < 6; attempt++) {
     const dim3 lvl_grid(256 * 16);
-    const bool any_unfit = reads->max_len >= (err_tile ? (uint64_t)MG_ET_CAP + 1 : 2040);
-    if (no && err_mode && err_path == 0 && err_tile) {
+    const bool any_unfit = reads->max_len >= (err_wave ? (uint64_t)ew_cap + 1 : err_tile ? (uint64_t)MG_ET_CAP + 1 : 2040);
+    if (no && err_mode && err_path == 0 && err_wave) {
+        MG_TRY(hipMemsetAsync(d_acc_bits, 0, (no / 32 + 1) * 4, s2));
+        hipLaunchKernelGGL(k_mg_err_prepare, dim3(grid_for(nr)), dim3(256), 0, s2, a, (uint64_t)ew_cap + 1);
+        MG_TRY(launch_err_wave(s2, false));
+        if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 1);
+    } else if (no && err_mode && err_path == 0 && err_tile) {
         MG_TRY(hipMemsetAsync(d_acc_bits, 0, (no / 32 + 1) * 4, s2));
         const uint64_t chunk = (uint64_t)ET_CHUNK_TILES * MG_ET_CAP, n_chunks = a.total / chunk + 1;
         hipLaunchKernelGGL(k_et_tiles, dim3(grid_for(n_chunks)), dim3(256), 0, s2, a, (uint32_t)MG_ET_CAP, (uint32_t)MG_ET_CAP, chunk, n_chunks,
@@ -3464,7 +3500,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     } else if (no && err_mode && err_path == 0) {
         MG_TRY(hipMemsetAsync(d_fill, 0, no * 4, s2));
         MG_TRY(hipMemsetAsync(d_acc_bits, 0, (no / 32 + 1) * 4, s2));
-        hipLaunchKernelGGL(k_mg_err_prepare, dim3(grid_for(nr)), dim3(256), 0, s2, a);
+        hipLaunchKernelGGL(k_mg_err_prepare, dim3(grid_for(nr)), dim3(256), 0, s2, a, (uint64_t)2040);
         if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<false, 0, true>), dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only);
         else hipLaunchKernelGGL((k_mg_err_level<false, 0, false>), dim3(grid_for(no)), dim3(256), 0, s2, a, err_acc_only);
         if (a.pfx) hipLaunchKernelGGL((k_mg_err_level<false, 1, true>), lvl_grid, dim3(256), 0, s2, a, err_acc_only);
@@ -3483,12 +3519,12 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         uint32_t st[32];
         MG_TRY(hipMemcpy(st, d_err_flag, 128, hipMemcpyDeviceToHost));
         if (tm.on && err_tile) fprintf(stderr, "[gmg_mg] k_mg_err_tile: %u tiles (%llu ORFs)\n", st[18], (unsigned long long)no);
-        if (!err_tile && !st[0] && a.total) {           // what this batch needed, for the next call's arrays
+        if (!err_tile && !err_wave && !st[0] && a.total) {   // what this batch needed, for the next call's arrays
             unsigned long long handed[2];
             memcpy(handed, st + 2, 16);
             calls_per_base_hint = (double)(handed[0] > handed[1] ? handed[0] : handed[1]) / (double)a.total;
         }
-        if (tm.on && !err_tile) {                       // (mg_timing) how many calls the levels handed on
+        if (tm.on && !err_tile && !err_wave) {          // (mg_timing) how many calls the levels handed on
             unsigned long long handed[2];
             memcpy(handed, st + 2, 16);
             fprintf(stderr, "[gmg_mg] calls handed to level 1: %llu, to level 2: %llu (capacity %llu each; %llu ORFs)\n", handed[0], handed[1],
@@ -3503,9 +3539,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
             continue;
         }
-        if (st[0] && err_tile) {
-            // a work-group's call slab was full: the batch repeats on the level kernels (their call arrays grow with the batch)
-            err_tile = false;
+        if (st[0] && (err_tile || err_wave)) {
+            // a work-group's call slab / a wave's call stack was full: the batch repeats on the level kernels (their call arrays grow with the batch)
+            err_tile = err_wave = false;
             if (a.pfx) MG_TRY(build_run_tables(s2));
             MG_TRY(build_walk_rows(s2));
             MG_TRY(alloc_level_scratch());
@@ -3566,7 +3602,11 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         MG_TRY(hipEventRecord(side_done, s2));          //  the ordering explicit)
         MG_TRY(hipStreamWaitEvent(s, side_done, 0));
     }
-    if (no && err_mode && err_path == 0 && err_tile) {
+    if (no && err_mode && err_path == 0 && err_wave) {
+        hipLaunchKernelGGL(k_mg_err_begin, dim3(grid_for(no)), dim3(256), 0, s, a, err_acc_only);
+        MG_TRY(launch_err_wave(s, true));
+        if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 1);
+    } else if (no && err_mode && err_path == 0 && err_tile) {
         hipLaunchKernelGGL(k_et_unstage, dim3(grid_for(no)), dim3(256), 0, s, a, d_st_s, d_st_e, d_st_k, err_acc_only);
         if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<true>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s, a, err_acc_only, 1);
     } else if (no && err_mode && err_path == 0) {

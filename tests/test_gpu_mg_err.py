@@ -61,19 +61,24 @@ def test_error_branch_matches_reference_push_order(gpu, oracle, nc, name):
     (dict(allow_subs=True), False),
 ])
 @pytest.mark.parametrize("kw", [dict(), dict(allow_truncated=False, min_gene_len=60), dict(ignore_score_len=150, start_codons=("atg", "rtg"))])
-@pytest.mark.parametrize("path", ["tile", "tile-stage", "tile-overflow", "level", "level-q0", "flat", "level-overflow", "level-grow"])
+@pytest.mark.parametrize("path", ["wave", "wave-overflow", "wave-table", "tile", "tile-stage", "tile-overflow", "level", "level-q0", "flat", "level-overflow", "level-grow"])
 def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path, monkeypatch, request_finalizers):
-    """path: tile by tile with the running sums in LDS, one lane per event (option mg_err_tile; the 2100-bp read, longer than a tile,
+    """path: one wave per (read, strand) with sums, masks and the call stack in its LDS (k_mg_err_wave, the default; the 1300- and
+    2100-bp reads, longer than a wave takes, go to the per-ORF kernel), the same with a stack of 5 entries (the batch repeats on the
+    level kernels) and on a batch without the long reads (the fp32 gene rows instead of the fp64 table),
+    tile by tile with the running sums in LDS, one lane per event (option mg_err_tile; the 2100-bp read, longer than a tile,
     goes to the per-ORF kernel), the same with staging arrays too small (the kernel repeats with what it asked for) and
     with slabs too small (everything repeats on the level kernels), level by level with
     one lane per call on the tables in HBM (the default; the 2100-bp read goes to the per-ORF kernel; -s: the one-value-per-base
     table -- q0: the three-row table instead), the per-ORF kernel alone, the level
     kernels with call arrays too small (everything repeats on the per-ORF kernel), and the same with the arrays allowed to
     grow (the count pass repeats with larger ones)"""
-    opts = {"tile": {"mg_err_tile": 1}, "tile-stage": {"mg_err_tile": 1, "mg_err_tile_q": -1}, "tile-overflow": {"mg_err_tile": 1, "mg_err_tile_q": 3},
-            "level": {"mg_err_tile": 0}, "level-q0": {"mg_err_tile": 0, "mg_err_qonly": 0},
-            "flat": {"mg_err_flat": 1}, "level-overflow": {"mg_err_tile": 0, "mg_err_calls": 7},
-            "level-grow": {"mg_err_tile": 0, "mg_err_calls": 7, "mg_err_calls_grow": 1}}[path]
+    opts = {"wave": {"mg_err_wave": 1, "mg_err_tile": 0}, "wave-overflow": {"mg_err_wave": 1, "mg_err_tile": 0, "mg_err_wave_q": 5},
+            "wave-table": {"mg_err_wave": 1, "mg_err_tile": 0},
+            "tile": {"mg_err_tile": 1}, "tile-stage": {"mg_err_tile": 1, "mg_err_tile_q": -1}, "tile-overflow": {"mg_err_tile": 1, "mg_err_tile_q": 3},
+            "level": {"mg_err_tile": 0, "mg_err_wave": 0}, "level-q0": {"mg_err_tile": 0, "mg_err_wave": 0, "mg_err_qonly": 0},
+            "flat": {"mg_err_flat": 1}, "level-overflow": {"mg_err_tile": 0, "mg_err_wave": 0, "mg_err_calls": 7},
+            "level-grow": {"mg_err_tile": 0, "mg_err_wave": 0, "mg_err_calls": 7, "mg_err_calls_grow": 1}}[path]
     for k, v in opts.items():
         old = gpu.get_option(k)
         gpu.set_option(k, v)
@@ -85,6 +90,8 @@ def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path
     seqs.append("a" * 40 + "".join("acgt"[c] for c in rng.integers(0, 4, size=200)) + "tttttttt" + "gggg" * 9)   # long runs
     seqs.append("".join("acgt"[c] for c in rng.integers(0, 4, size=1300)))
     seqs.append("".join("acgt"[c] for c in rng.integers(0, 4, size=2100)))      # too long for the order keys
+    if path == "wave-table":                            # every read fits a wave: the call's own table is the fp32 gene rows
+        seqs = seqs[:-2] + ["".join("acgt"[c] for c in rng.integers(0, 4, size=n)) for n in (959, 960)]
     quals = [np.where(rng.random(len(s)) < 0.12, rng.integers(0, 19, len(s)), rng.integers(19, 41, len(s))).astype(np.int32)
              for s in seqs] if with_q else [None] * len(seqs)
     gc, stops = 0.5, kw.get("stop_codons", ("taa", "tag", "tga"))
@@ -149,7 +156,12 @@ def test_error_branch_full_size_properties(gpu, oracle, nc):
     assert orfs.tobytes() == orfs2.tobytes() and starts.tobytes() == starts2.tobytes() and errs.tobytes() == errs2.tobytes()
     assert np.array_equal(first, first2)
     del orfs2, starts2, errs2
-    with gpu.option("mg_err_tile", 1):                  # tile by tile, one lane per event: the same bytes as the level kernels' at full size
+    with gpu.option("mg_err_tile", 1):                  # tile by tile, one lane per event: the same bytes as the wave kernel's at full size
+        orfs2, starts2, first2, errs2 = gpu.mg_score_reads(nc, indep, reads, allow_indels=True, accepted_only=True)
+    assert orfs.tobytes() == orfs2.tobytes() and starts.tobytes() == starts2.tobytes() and errs.tobytes() == errs2.tobytes()
+    assert np.array_equal(first, first2)
+    del orfs2, starts2, errs2
+    with gpu.option("mg_err_tile", 0), gpu.option("mg_err_wave", 0):    # ... and the level kernels on the running sums in HBM
         orfs2, starts2, first2, errs2 = gpu.mg_score_reads(nc, indep, reads, allow_indels=True, accepted_only=True)
     assert orfs.tobytes() == orfs2.tobytes() and starts.tobytes() == starts2.tobytes() and errs.tobytes() == errs2.tobytes()
     assert np.array_equal(first, first2)
@@ -210,6 +222,11 @@ def test_accepted_only_is_the_full_result_filtered(gpu, nc, name, kw):
     full = gpu.mg_score_reads(nc, indep, reads, **kw)
     kept = gpu.mg_score_reads(nc, indep, reads, accepted_only=True, **kw)
     with gpu.option("mg_err_tile", 1):                  # (the tile kernel: every record, start and error list of both forms)
+        for want, acc in ((full, False), (kept, True)):
+            got = gpu.mg_score_reads(nc, indep, reads, accepted_only=acc, **kw)
+            for x, y in zip(want, got):
+                assert x.tobytes() == y.tobytes()
+    with gpu.option("mg_err_tile", 0), gpu.option("mg_err_wave", 0):    # (... and the level kernels)
         for want, acc in ((full, False), (kept, True)):
             got = gpu.mg_score_reads(nc, indep, reads, accepted_only=acc, **kw)
             for x, y in zip(want, got):
