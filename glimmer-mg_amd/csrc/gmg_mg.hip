@@ -2834,8 +2834,23 @@ struct MgTimer {
     }
 };
 
+#define MG_RETRY_NO_WAVE 1000    // (internal) the write pass of k_mg_err_wave ran out of stack: the call repeats without the wave kernels
+static thread_local int tl_mg_no_wave = 0;
+static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, const gmg_mg_params *prm,
+                       double *d_frame_scores, gmg_mg_result **out, void *stream, const bool find_only, const MgGroups *groups);
 static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, const gmg_mg_params *prm,
                   double *d_frame_scores, gmg_mg_result **out, void *stream, const bool find_only, const MgGroups *groups = nullptr)
+{
+    int rc = mg_run_once(gene, nul, reads, prm, d_frame_scores, out, stream, find_only, groups);
+    if (rc == MG_RETRY_NO_WAVE) {
+        tl_mg_no_wave = 1;
+        rc = mg_run_once(gene, nul, reads, prm, d_frame_scores, out, stream, find_only, groups);
+        tl_mg_no_wave = 0;
+    }
+    return rc;
+}
+static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_reads *reads, const gmg_mg_params *prm,
+                       double *d_frame_scores, gmg_mg_result **out, void *stream, const bool find_only, const MgGroups *groups)
 {
     { int rc_enter = gmg_enter(find_only ? "gmg_find_orfs" : "gmg_mg_score_reads"); if (rc_enter) return rc_enter; }
     if ((!find_only && (!gene || !nul)) || !reads || !prm || !out) return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: NULL argument");
@@ -2934,6 +2949,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     bool err_tile = false;                              // ... and runs tile by tile with the sums in LDS (k_mg_err_tile)
     bool err_wave = false;                              // ... or with one wave per (read, strand), everything in the wave's LDS (k_mg_err_wave)
     uint32_t ew_cap = 0;
+    uint8_t *d_item_flag = nullptr;
     uint8_t *d_run = nullptr;
     bool fused_rest = false;
     MgTile *d_tiles = nullptr, *d_all = nullptr;
@@ -2984,6 +3000,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         if (d_walk) gmg_pool_release(d_walk);
         if (d_walk_q) gmg_pool_release(d_walk_q);
         if (d_run) gmg_pool_release(d_run);
+        if (d_item_flag) gmg_pool_release(d_item_flag);
         if (d_et_tiles) gmg_pool_release(d_et_tiles);
         if (d_et_slabs) gmg_pool_release(d_et_slabs);
         if (d_et_em) gmg_pool_release(d_et_em);
@@ -3106,8 +3123,10 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     err_tile = err_mode && err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) && tile_wanted && !gmg_opt(GMG_OPT_MG_ERR_FLAT);
     // one wave per (read, strand) (k_mg_err_wave; the default whenever the sums are exact, unless the tile kernel is forced):
     // its LDS share is sized by the batch's longest read, reads beyond EW_MAX_CAP go to k_mg_err_flat
+    // mg_err_wave: 1 (default) for -i only (-s: the level kernels on the one-value table are faster: DESIGN 4.7), 2 with the stack walker
+    // as the count pass, 3 for -i and -s
     err_wave = err_mode && err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) && !gmg_opt(GMG_OPT_MG_ERR_FLAT) && gmg_opt(GMG_OPT_MG_ERR_WAVE) > 0 &&
-               tile_opt <= 0 && reads->max_len > 0 && a.total;
+               (err_mode == 1 || gmg_opt(GMG_OPT_MG_ERR_WAVE) >= 2) && !tl_mg_no_wave && tile_opt <= 0 && reads->max_len > 0 && a.total;
     if (err_wave) {
         err_tile = false;
         const uint64_t longest = reads->max_len < EW_MAX_CAP ? reads->max_len : EW_MAX_CAP;
@@ -3446,25 +3465,46 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
             if (gmg_opt(GMG_OPT_MG_ERR_TILE_Q) != 0) want = 64;         // (tests; -1: only this: the first pass finds the arrays too small)
             MG_TRY(alloc_staging(want));
         } else if (!err_wave) MG_TRY(alloc_level_scratch());
+        if (err_wave) MG_TRY(gmg_pool_alloc((void **)&d_item_flag, 2 * nr + 64));
     }
     // k_mg_err_wave: as many one-wave work-groups per CU as their LDS shares allow (the grid strides over the (read, strand) pairs)
     const uint32_t ew_qcap = gmg_opt(GMG_OPT_MG_ERR_WAVE_Q) > 0 ? (uint32_t)gmg_opt(GMG_OPT_MG_ERR_WAVE_Q) : (uint32_t)EW_QCAP;
     auto launch_err_wave = [&](hipStream_t st, bool write) -> hipError_t {
-        const EwLayout lay = ew_layout(ew_cap, ew_qcap, write);
+        // two length classes, a launch each: reads up to 512 bases (8 walk steps per lane, a small LDS share: more waves per CU) and
+        // the longer ones up to ew_cap.  Count pass: the walk-free kernel (k_mg_err_wcount); mg_err_wave = 2: the stack walker's
         int n_cu = 0;
         hipError_t e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
         if (e != hipSuccess) return e;
-        uint32_t per_cu = (uint32_t)((160u * 1024u) / (lay.bytes + 1024u));
-        if (per_cu > 16) per_cu = 16;
-        if (per_cu < 1) per_cu = 1;
-        uint64_t grid = (uint64_t)(n_cu > 0 ? n_cu : 256) * per_cu * 4;
-        if (grid > 2 * nr) grid = 2 * nr;
-        if (grid == 0) return hipSuccess;
-#define MG_EW_LAUNCH(W_, G_) hipLaunchKernelGGL((k_mg_err_wave<W_, G_>), dim3((unsigned)grid), dim3(EW_BLOCK), lay.bytes, st, a, err_acc_only, ew_cap, ew_qcap)
-        if (write) { if (a.gene32) MG_EW_LAUNCH(true, true); else MG_EW_LAUNCH(true, false); }
-        else { if (a.gene32) MG_EW_LAUNCH(false, true); else MG_EW_LAUNCH(false, false); }
+        const uint64_t n_blocks = (2 * nr + 63) / 64;
+        const bool walk_count = gmg_opt(GMG_OPT_MG_ERR_WAVE) == 2;
+        uint32_t *st_ptr = tm.on && !write ? d_err_flag + 24 : (uint32_t *)nullptr;
+        for (int cls = 0; cls < 2; cls++) {
+            const uint32_t lo = cls == 0 ? 0u : 512u, hi = cls == 0 ? (ew_cap < 512u ? ew_cap : 512u) : ew_cap;
+            if (hi <= lo) continue;
+            if (cls == 1 && reads->max_len <= 512) continue;
+            const bool wcount = !write && !walk_count;
+            const uint32_t bytes = wcount ? ewc_layout(hi).bytes : ew_layout(hi, ew_qcap, write).bytes;
+            uint32_t per_cu = (uint32_t)((160u * 1024u) / (bytes + 1024u));
+            if (per_cu > 16) per_cu = 16;
+            if (per_cu < 1) per_cu = 1;
+            uint64_t grid = (uint64_t)(n_cu > 0 ? n_cu : 256) * per_cu * 2;
+            if (grid > n_blocks) grid = n_blocks;
+            if (grid == 0) continue;
+#define MG_EW_LAUNCH(W_, G_, K_) hipLaunchKernelGGL((k_mg_err_wave<W_, G_, K_>), dim3((unsigned)grid), dim3(EW_BLOCK), bytes, st, a, err_acc_only, lo, hi, ew_qcap, d_item_flag, st_ptr)
+#define MG_EWC_LAUNCH(G_, K_) hipLaunchKernelGGL((k_mg_err_wcount<G_, K_>), dim3((unsigned)grid), dim3(EW_BLOCK), bytes, st, a, err_acc_only, lo, hi, d_item_flag, st_ptr)
+#define MG_EW_LAUNCH_K(W_, G_) do { if (cls == 0) MG_EW_LAUNCH(W_, G_, 8); else MG_EW_LAUNCH(W_, G_, 15); } while (0)
+#define MG_EWC_LAUNCH_K(G_) do { if (cls == 0) MG_EWC_LAUNCH(G_, 8); else MG_EWC_LAUNCH(G_, 15); } while (0)
+            if (wcount) { if (a.gene32) MG_EWC_LAUNCH_K(true); else MG_EWC_LAUNCH_K(false); }
+            else if (write) { if (a.gene32) MG_EW_LAUNCH_K(true, true); else MG_EW_LAUNCH_K(true, false); }
+            else { if (a.gene32) MG_EW_LAUNCH_K(false, true); else MG_EW_LAUNCH_K(false, false); }
+#undef MG_EWC_LAUNCH_K
+#undef MG_EW_LAUNCH_K
+#undef MG_EWC_LAUNCH
 #undef MG_EW_LAUNCH
-        return hipGetLastError();
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
     };
     const size_t et_lds = sizeof(EtLds<MG_ET_CAP>);
     auto launch_err_tile = [&](hipStream_t st) -> hipError_t {
@@ -3487,6 +3527,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     const bool any_unfit = reads->max_len >= (err_wave ? (uint64_t)ew_cap + 1 : err_tile ? (uint64_t)MG_ET_CAP + 1 : 2040);
     if (no && err_mode && err_path == 0 && err_wave) {
         MG_TRY(hipMemsetAsync(d_acc_bits, 0, (no / 32 + 1) * 4, s2));
+        MG_TRY(hipMemsetAsync(d_item_flag, 0, 2 * nr + 64, s2));
         hipLaunchKernelGGL(k_mg_err_prepare, dim3(grid_for(nr)), dim3(256), 0, s2, a, (uint64_t)ew_cap + 1);
         MG_TRY(launch_err_wave(s2, false));
         if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 1);
@@ -3519,6 +3560,9 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
         uint32_t st[32];
         MG_TRY(hipMemcpy(st, d_err_flag, 128, hipMemcpyDeviceToHost));
         if (tm.on && err_tile) fprintf(stderr, "[gmg_mg] k_mg_err_tile: %u tiles (%llu ORFs)\n", st[18], (unsigned long long)no);
+        if (tm.on && err_wave)
+            fprintf(stderr, "[gmg_mg] k_mg_err_wave: flag %u, deepest stack %u, most ORFs on a strand %u, %u trips and %u calls in %u (read, strand) pairs\n",
+                    st[0], st[24], st[25], st[26], st[27], st[28]);
         if (!err_tile && !err_wave && !st[0] && a.total) {   // what this batch needed, for the next call's arrays
             unsigned long long handed[2];
             memcpy(handed, st + 2, 16);
@@ -3749,6 +3793,11 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     }
     MG_TRY(hipStreamSynchronize(s));
     tm.lap("start lists");
+    if (err_wave && res->n_orfs && d_err_flag) {        // did a wave's stack overflow in the WRITE pass?  (the count pass was checked behind its scan)
+        uint32_t flag = 0;
+        MG_TRY(hipMemcpy(&flag, d_err_flag, 4, hipMemcpyDeviceToHost));
+        if (flag) return fail(MG_RETRY_NO_WAVE);
+    }
 #undef MG_TRY
     if (d_fs_own) gmg_pool_release(d_fs_own);
     if (d_gene32) gmg_pool_release(d_gene32);
@@ -3777,6 +3826,7 @@ static int mg_run(const gmg_model *gene, const gmg_model *nul, const gmg_reads *
     if (d_walk) gmg_pool_release(d_walk);
     if (d_walk_q) gmg_pool_release(d_walk_q);
     if (d_run) gmg_pool_release(d_run);
+    if (d_item_flag) gmg_pool_release(d_item_flag);
     if (d_et_tiles) gmg_pool_release(d_et_tiles);
     if (d_et_slabs) gmg_pool_release(d_et_slabs);
     if (d_et_em) gmg_pool_release(d_et_em);

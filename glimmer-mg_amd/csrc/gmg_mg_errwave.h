@@ -45,9 +45,9 @@ __host__ __device__ inline EwLayout ew_layout(uint32_t cap, uint32_t qcap, bool 
     L.msk = o; o += 5 * L.nw * 8;
     L.st_ss = o; o += qcap * 8;
     L.st_key = o; o += write ? qcap * 8 : 0;
-    L.a_best = o; o += write ? 0 : EW_MAXO * 8;
-    L.a_exa = o; o += write ? 0 : EW_MAXO * 8;
-    L.a_exb = o; o += write ? 0 : EW_MAXO * 8;
+    L.a_best = o; o += EW_MAXO * 8;          // (WRITE too: first_j and best_score of the kept ORFs)
+    L.a_exa = o; o += EW_MAXO * 8;
+    L.a_exb = o; o += EW_MAXO * 8;
     L.st_w = o; o += qcap * 4;
     L.st_e = o; o += write ? qcap * 4 : 0;
     L.a_cnt = o; o += EW_MAXO * 4;          // WRITE: slots handed out inside the ORF's slice
@@ -66,8 +66,144 @@ __device__ __forceinline__ uint64_t ew_window(const uint64_t *row, uint32_t t)
     return (lo >> sh) | ((hi << 1) << (63u - sh));
 }
 
-template <bool WRITE, bool G32>
-__global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int accepted_only, const uint32_t cap, const uint32_t qcap)
+// 64-bit value of lane `src` (uniform)
+__device__ __forceinline__ uint64_t ew_readlane64(uint64_t v, uint32_t src)
+{
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)src) |
+           (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)src) << 32;
+}
+// the 2-bit fields of y in reversed order (nfields of them, held in the low bits)
+__device__ __forceinline__ uint64_t ew_reverse_fields64(uint64_t y, uint32_t nfields)
+{
+    const uint64_t z = __brevll(y) >> (64u - 2u * nfields);
+    return ((z & 0x5555555555555555ull) << 1) | ((z >> 1) & 0x5555555555555555ull);
+}
+
+// What a lane holds of its K consecutive walk steps between the loads and the sums
+template <bool G32, int KMAX>
+struct EwRegs {
+    float gv[KMAX][3];           // G32: the gene model's values of the strand's three rows
+    double fv[KMAX][3];          // else: the caller's Frame_Scores
+    uint32_t qv[KMAX];           // qualities (255 without -i)
+    uint64_t win;                // 32 bases from the lowest base the lane looks at
+    int64_t g0;                  // base of the lane's first step
+    uint32_t K, tb;              // steps per lane, the lane's first step
+};
+
+// Everything a (read, strand) pair needs from HBM, asked for in one go: lane L takes the K = ceil (n / 64) consecutive steps from L K on
+// (base of step t: forward off + n - 1 - t, reverse off + t)
+template <bool G32, int KMAX>
+__device__ __forceinline__ void ew_load(const MgArgs &a, const uint64_t off, const uint32_t n, const bool fwd, const bool indels, const uint32_t lane,
+                                        EwRegs<G32, KMAX> &R)
+{
+    const uint32_t K = (n + 63u) >> 6, tb = lane * K;
+    R.K = K; R.tb = tb;
+    // the walk codes of steps tb - 2 .. tb + K + 1 come from one 32-base window
+    const int64_t g_lo = fwd ? (int64_t)(off + n - 1) - (int64_t)(tb + K + 1) : (int64_t)(off + tb) - 2;
+    R.win = dev_window_bits(a.packed, g_lo);
+    const int64_t g0 = fwd ? (int64_t)(off + n - 1) - (int64_t)tb : (int64_t)(off + tb);
+    R.g0 = g0;
+#pragma unroll
+    for (int e = 0; e < KMAX; e++) {
+        const bool in = (uint32_t)e < K && tb + (uint32_t)e < n;
+        const int64_t g = in ? (fwd ? g0 - e : g0 + e) : (int64_t)off;
+        R.qv[e] = 255u;
+        if (G32) {
+#pragma unroll
+            for (int f = 0; f < 3; f++) R.gv[e][f] = in ? a.gene32[(uint64_t)((fwd ? 0 : 3) + f) * a.fs_stride + (uint64_t)g] : 0.0f;
+        } else {
+#pragma unroll
+            for (int f = 0; f < 3; f++) R.fv[e][f] = in ? a.fs[(uint64_t)((fwd ? 0 : 3) + f) * a.fs_stride + (uint64_t)g] : 0.0;
+        }
+        if (indels && in) R.qv[e] = a.qual[g];
+    }
+}
+
+// The running sums of the three classes (S[c * srow + t + 1] = the sum through step t, [0] = 0), the masks over the walk steps (codon
+// that starts here is a start / stop codon; base of low quality), the quality bytes.  A lane sums its K steps serially, ONE wave scan
+// of the lanes' totals per class (exact in any order: mg_run's test).  zero / n_zero: the mask words to clear first.
+// f_low_out: the lane's own low-quality bits (bit e = step tb + e).
+template <bool G32, int KMAX>
+__device__ __forceinline__ void ew_build(const MgArgs &a, const uint64_t r, const uint64_t off, const uint32_t n, const bool fwd, const bool indels,
+                                         const uint32_t lane, const EwRegs<G32, KMAX> &R, double *S, const uint32_t srow, uint64_t *Mstart,
+                                         uint64_t *Mstop, uint64_t *Mlow, const uint32_t nw, uint64_t *zero, const uint32_t n_zero, uint8_t *s_q,
+                                         uint32_t &f_low_out)
+{
+    const uint32_t K = R.K, tb = R.tb;
+    const float *nt = G32 ? a.null_tab + (size_t)(a.read_null ? a.read_null[r] : 0u) * MG_NULL_FLOATS : nullptr;
+    if (lane < 3) S[lane * srow] = 0.0;
+    for (uint32_t w = lane; w < n_zero; w += 64) zero[w] = 0;
+    const uint64_t W = fwd ? ew_reverse_fields64(R.win, K + 4u) : ~R.win;    // field p = the walk code of step tb - 2 + p
+    // the class of step t's base is (off + position) % 3; relabelled per lane so that the unrolled loop below indexes statically:
+    // forward c' = (c - m0 + 1) % 3, reverse c' = (m0 - c + 1) % 3 (m0 = the class of the lane's first base): step e adds value
+    // row (c' + e) % 3 to relabelled class c' (k_mg_walk_prefix's rows, rotated)
+    const uint32_t m0 = (uint32_t)((uint64_t)R.g0 % 3ull);
+    double P[KMAX][3];
+    double acc3[3] = {0.0, 0.0, 0.0};
+    uint32_t f_start = 0, f_stop = 0, f_low = 0;
+#pragma unroll
+    for (int e = 0; e < KMAX; e++) {
+        const uint32_t t = tb + (uint32_t)e;
+        const bool in = (uint32_t)e < K && t < n;
+        double v[3];
+        if (G32) {
+            // the (3,2,3) null model's value at walk step t (mg_null_value in walk codes: the window is steps t - 2, t - 1, t)
+            const uint32_t full = (uint32_t)(W >> (2 * e)) & 63u, b0 = full >> 4, b1 = (full >> 2) & 3u;
+            const uint32_t i0 = t >= 2u ? full : t == 1u ? 192u + 4u + (b1 | b0 << 2) : 192u + b0;
+            const uint32_t stride = t >= 2u ? 64u : 20u;
+#pragma unroll
+            for (int f = 0; f < 3; f++) v[f] = in ? (double)R.gv[e][f] - (double)nt[i0 + (uint32_t)f * stride] : 0.0;
+        } else {
+#pragma unroll
+            for (int f = 0; f < 3; f++) v[f] = in ? R.fv[e][f] : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) { acc3[c] += v[(c + e) % 3]; P[e][c] = acc3[c]; }
+        const uint32_t idx = (uint32_t)(W >> (2 * e + 4)) & 63u;          // code (t) | code (t + 1) << 2 | code (t + 2) << 4
+        const bool codon = in && t + 2 < n;
+        if (codon && ((a.fwd_start >> idx) & 1ull)) f_start |= 1u << e;
+        if (codon && ((a.fwd_stop >> idx) & 1ull)) f_stop |= 1u << e;
+        if (in && R.qv[e] <= (uint32_t)a.indel_q_thr) f_low |= 1u << e;
+        if (s_q && indels && in) s_q[t] = (uint8_t)R.qv[e];
+    }
+    f_low_out = f_low;
+    // lane totals -> true classes -> scan -> back
+    double tot[3], basec[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {                   // true class c holds relabelled class cp
+        const uint32_t cp = fwd ? ((uint32_t)c + 4u - m0) % 3u : (m0 + 4u - (uint32_t)c) % 3u;
+        tot[c] = cp == 0u ? acc3[0] : cp == 1u ? acc3[1] : acc3[2];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) basec[c] = mg_wave_scan(tot[c]) - tot[c];      // what the lanes in front add up to
+    wcs_sync();                                     // (the zeroed masks before the ORs)
+#pragma unroll
+    for (int cp = 0; cp < 3; cp++) {
+        const uint32_t c = fwd ? ((uint32_t)cp + m0 + 2u) % 3u : (m0 + 4u - (uint32_t)cp) % 3u;      // the true class of relabelled cp
+        const double b = c == 0u ? basec[0] : c == 1u ? basec[1] : basec[2];
+        double *row = S + c * srow + tb + 1;
+#pragma unroll
+        for (int e = 0; e < KMAX; e++)
+            if ((uint32_t)e < K && tb + (uint32_t)e < n) row[e] = b + P[e][cp];
+    }
+    if (tb < n) {                                   // the lane's K bits of every mask, at bit tb
+        const uint32_t wi = tb >> 6, sh = tb & 63u;
+        const bool two = sh + K > 64u;
+        if (f_start) { atomicOr((unsigned long long *)&Mstart[wi], (unsigned long long)f_start << sh); if (two) atomicOr((unsigned long long *)&Mstart[wi + 1], (unsigned long long)f_start >> (64u - sh)); }
+        if (f_stop) { atomicOr((unsigned long long *)&Mstop[wi], (unsigned long long)f_stop << sh); if (two) atomicOr((unsigned long long *)&Mstop[wi + 1], (unsigned long long)f_stop >> (64u - sh)); }
+        if (f_low) { atomicOr((unsigned long long *)&Mlow[wi], (unsigned long long)f_low << sh); if (two) atomicOr((unsigned long long *)&Mlow[wi + 1], (unsigned long long)f_low >> (64u - sh)); }
+    }
+    wcs_sync();
+}
+
+
+// KMAX: walk steps per lane when the wave builds the running sums (a read of n bases: K = ceil (n / 64) consecutive steps per lane):
+// 8 for reads up to 512 bases, 15 up to EW_MAX_CAP.  The grid strides over blocks of 64 (read, strand) pairs; a wave takes the pairs
+// of its block whose read is longer than cap_lo and at most cap (the other length class has a launch of its own).
+// item_flag [2 n_reads]: COUNT sets it for the pairs that hold an accepted ORF, WRITE (accepted_only) takes only those.
+template <bool WRITE, bool G32, int KMAX>
+__global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int accepted_only, const uint32_t cap_lo, const uint32_t cap, const uint32_t qcap,
+                                                          uint8_t *item_flag, uint32_t *stats)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ew_lds[];
     __shared__ double s_pen[64];
@@ -93,16 +229,51 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
     const int lowest_j = mgl - 3 < 3 ? mgl - 3 : 3;
     const bool indels = a.err_mode == 1;
     const uint32_t nw = L.nw, srow = L.srow;
+    const uint64_t n_items = 2 * a.n_reads;
 
-    for (uint64_t it = blockIdx.x; it < 2 * a.n_reads; it += gridDim.x) {
+    for (uint64_t blk = blockIdx.x; blk * 64 < n_items; blk += gridDim.x) {
+    // what the block's 64 pairs are: one lane each
+    uint64_t l_off = 0, l_ob = 0;
+    uint32_t l_n = 0, l_no = 0;
+    bool elig = false;
+    {
+        const uint64_t my = blk * 64 + lane;
+        if (my < n_items) {
+            const uint64_t r_ = my >> 1;
+            l_off = a.read_off[r_];
+            l_n = (uint32_t)(a.read_off[r_ + 1] - l_off);
+            l_ob = a.read_orf_off[r_];
+            const uint64_t no_ = a.read_orf_off[r_ + 1] - l_ob;
+            l_no = no_ > 0xffffffffull ? 0xffffffffu : (uint32_t)no_;
+            elig = l_n > cap_lo && l_n <= cap && l_no > 0;              // (longer reads: k_mg_err_flat, read_fit = 0)
+            if (WRITE && accepted_only && elig) elig = item_flag[my] != 0;
+        }
+    }
+    uint64_t todo = __ballot(elig);
+    while (todo) {
+        const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint64_t it = blk * 64 + src;
         const uint64_t r = it >> 1;
         const bool fwd = (it & 1) == 0;
-        const uint64_t off = a.read_off[r];
-        const uint32_t n = (uint32_t)(a.read_off[r + 1] - off);
-        const uint64_t ob = a.read_orf_off[r], oe = a.read_orf_off[r + 1];
-        if (n == 0 || n > cap || ob == oe) continue;    // (longer reads: k_mg_err_flat, read_fit = 0)
+        const uint64_t off = ew_readlane64(l_off, src), ob = ew_readlane64(l_ob, src);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)l_n, (int)src);
+        const uint64_t oe = ob + (uint32_t)__builtin_amdgcn_readlane((int)l_no, (int)src);
         const int isl = a.read_isl ? a.read_isl[r] : a.ignore_score_len;
-        const uint32_t off_m3 = (uint32_t)(off % 3);
+
+        // ---- everything the pair needs from HBM is asked for first: the lane's K walk steps (bases, gene rows, qualities) and
+        //      the read's first 64 ORF records
+        EwRegs<G32, KMAX> R;
+        ew_load<G32, KMAX>(a, off, n, fwd, indels, lane, R);
+        int o_frame = 0, o_stop = 0;
+        uint32_t o_acc = 1, o_sbeg = 0;
+        if (ob + lane < oe) {
+            o_frame = a.orfs[ob + lane].frame; o_stop = a.orfs[ob + lane].stop_position;
+            if (WRITE) {
+                o_sbeg = (uint32_t)a.start_off[ob + lane];
+                if (accepted_only) o_acc = (a.acc_bits[(ob + lane) >> 5] >> ((ob + lane) & 31u)) & 1u;
+            }
+        }
 
         // ---- the ORFs of this strand: level-0 calls onto the stack
         uint32_t top = 0, nloc = 0;
@@ -110,8 +281,15 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
         for (uint64_t o0 = ob; o0 < oe; o0 += 64) {
             const uint64_t i = o0 + lane;
             const bool have = i < oe;
-            int frame = 0, stop_position = 0;
-            if (have) { frame = a.orfs[i].frame; stop_position = a.orfs[i].stop_position; }
+            int frame = o_frame, stop_position = o_stop;
+            uint32_t acc = o_acc, sbeg = o_sbeg;
+            if (o0 != ob && have) {                     // (a read with more than 64 ORFs: the next records)
+                frame = a.orfs[i].frame; stop_position = a.orfs[i].stop_position;
+                if (WRITE) {
+                    sbeg = (uint32_t)a.start_off[i];
+                    if (accepted_only) acc = (a.acc_bits[i >> 5] >> (i & 31u)) & 1u;
+                }
+            }
             const bool mine = have && (frame > 0) == fwd;
             const uint64_t mm = __ballot(mine);
             const uint32_t idx = nloc + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
@@ -122,13 +300,13 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
             const int xs = fwd ? (int)n - end_point : end_point - 1;               // the call's first walk step
             if (mine) {
                 s_gi[idx] = (uint32_t)i;
+                a_best[idx] = mg_ord(-DBL_MAX);
+                a_exa[idx] = a_exb[idx] = fwd ? ~0ull : 0ull;
                 if (WRITE) {
                     a_cnt[idx] = 0;
-                    a_m0[idx] = (uint32_t)a.start_off[i];
-                    if (accepted_only && !((a.acc_bits[i >> 5] >> (i & 31u)) & 1u)) act = false;
+                    a_m0[idx] = sbeg;
+                    if (accepted_only && !acc) act = false;
                 } else {
-                    a_best[idx] = mg_ord(-DBL_MAX);
-                    a_exa[idx] = a_exb[idx] = fwd ? ~0ull : 0ull;
                     a_cnt[idx] = 0; a_m0[idx] = 0;
                     // accepted_only: an ORF is kept only if one of its starts has j + 1 >= Min_Gene_Len (glimmer-mg.cc:1655-1668) and no
                     // path gets further from the ORF's end than the read reaches that way (as k_mg_err_level)
@@ -150,51 +328,8 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
         if (overflow || top > qcap) { if (lane == 0) atomicOr(a.err_flag, 1u); continue; }
         if (top == 0 && (WRITE || accepted_only)) continue;          // (every ORF's record is written otherwise: the verdict below)
         if (top) {
-        // ---- the running sums of the three classes, the masks, the qualities
-        const float *nt = G32 ? a.null_tab + (size_t)(a.read_null ? a.read_null[r] : 0u) * MG_NULL_FLOATS : nullptr;
-        if (lane < 3) S[lane * srow] = 0.0;
-        for (uint32_t w = lane; w < 5 * nw; w += 64) msk[w] = 0;
-        wcs_sync();
-        double carry[3] = {0.0, 0.0, 0.0};
-        for (uint32_t t0 = 0; t0 < n; t0 += 64) {
-            const uint32_t t = t0 + lane;
-            const bool in = t < n;
-            const uint64_t g = in ? (fwd ? off + n - 1 - t : off + t) : off;
-            const uint32_t five = (uint32_t)dev_window_bits(a.packed, (int64_t)g - 2) & 0x3ffu, c0 = (five >> 4) & 3u;   // bases g - 2 .. g + 2
-            double v[3];
-            if (G32) {
-                const int si = (int)(g - off);
-#pragma unroll
-                for (int f = 0; f < 3; f++) {
-                    const float nv = fwd ? mg_null_value<true>(nt, f, si, (int)n, c0, (five >> 6) & 3u, (five >> 8) & 3u)
-                                         : mg_null_value<false>(nt, f, si, (int)n, c0, (five >> 2) & 3u, five & 3u);
-                    v[f] = in ? (double)a.gene32[(uint64_t)((fwd ? 0 : 3) + f) * a.fs_stride + g] - (double)nv : 0.0;
-                }
-            } else {
-#pragma unroll
-                for (int f = 0; f < 3; f++) v[f] = in ? a.fs[(uint64_t)((fwd ? 0 : 3) + f) * a.fs_stride + g] : 0.0;
-            }
-            const int m = (int)((off_m3 + (uint32_t)(g - off)) % 3u);
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const int row = ((fwd ? c - m + 3 : m - c + 3) % 3 + 1) % 3;          // as k_mg_walk_prefix
-                const double x = row == 0 ? v[0] : row == 1 ? v[1] : v[2];
-                const double sc = mg_wave_scan(x) + carry[c];
-                if (in) S[c * srow + t + 1] = sc;
-                carry[c] = wcs_last_lane(sc);
-            }
-            // the codon that starts at this step, as the walks form it: code (step) | code (step + 1) << 2 | code (step + 2) << 4
-            const uint32_t idx = fwd ? c0 | ((five >> 2) & 3u) << 2 | (five & 3u) << 4
-                                     : (c0 | ((five >> 6) & 3u) << 2 | ((five >> 8) & 3u) << 4) ^ 63u;
-            const bool codon = t + 2 < n;
-            int q = 255;
-            if (indels && in) q = a.qual[g];
-            const uint64_t b_start = __ballot(codon && s_which[idx] >= 0), b_stop = __ballot(codon && ((a.fwd_stop >> idx) & 1ull)),
-                           b_low = __ballot(in && q <= a.indel_q_thr);
-            if (lane == 0) { Mstart[t0 >> 6] = b_start; Mstop[t0 >> 6] = b_stop; Mlow[t0 >> 6] = b_low; }
-            if (indels && in) s_q[t] = (uint8_t)q;
-        }
-        wcs_sync();
+        uint32_t f_low_bits = 0;
+        ew_build<G32, KMAX>(a, r, off, n, fwd, indels, lane, R, S, srow, Mstart, Mstop, Mlow, nw, msk, 5 * nw, s_q, f_low_bits);
         // events of a walk: a start codon, the last codon of a region (the next one is a stop codon or does not fit the read), and (Eq) a
         // codon with a base of low quality
         for (uint32_t w = lane; w < nw - 1; w += 64) {
@@ -212,6 +347,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
             Eq[w] = en | lo | (lo >> 1 | lo1 << 63) | (lo >> 2 | lo1 << 62);
         }
         wcs_sync();
+        const uint32_t off_m3 = (uint32_t)(off % 3);
 
         // ---- the call tree
         uint32_t state = 0;                             // 0: no call, 1: walking, 2: the call has ended
@@ -221,6 +357,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
         uint64_t key = 0;
         int last_pos = 0, last_j = 0;
         bool trunc = false, first_done = false;
+        uint32_t st_trips = 0, st_calls = 0, st_deep = top;     // (mg_timing: trips, calls, deepest stack of this pair)
         for (;;) {
             const uint64_t im = __ballot(state == 0);
             if (top && im) {
@@ -243,6 +380,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
                     }
                 }
                 top -= take;
+                st_calls += take;
                 wcs_sync();
             }
             if (!__ballot(state != 0)) {
@@ -294,11 +432,10 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
                                 a.errs[slot] = er;
                                 a.keys[slot] = key | (uint64_t)((uint32_t)(2047 - (int)j0) << 2 | (e2 == 0 ? 3u : 2u)) << (26 - 13 * (int)level);
                                 if (e2 == 0) last_own = slot; else first_done = true;
-                            } else {
-                                last_pos = k; last_j = j_full;
-                                if (sc > best) best = sc;
-                                cnt++;
                             }
+                            last_pos = k; last_j = j_full;
+                            if (sc > best) best = sc;
+                            cnt++;
                         }
                     }
                     if (branching) {
@@ -343,8 +480,8 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
                     if ((int)(sj + m_end) + ((int)n - (int)(x + m_end + 3)) + 12 >= mgl) pm |= 64u;
                 }
                 if (WRITE) { if (!first_done && last_own != MG_NO_SLOT) a.starts[last_own].first = 1; }
-                else if (cnt) {
-                    atomicAdd(&a_cnt[lidx], cnt);
+                if (cnt) {
+                    if (!WRITE) atomicAdd(&a_cnt[lidx], cnt);
                     atomicMax(&a_best[lidx], (unsigned long long)mg_ord(best));
                     const unsigned long long pa = (unsigned long long)(uint32_t)(last_pos + 16) << 32 | (uint32_t)last_j,
                                              pb = (unsigned long long)(uint32_t)(last_pos + 16) << 32 | (0xffffffffu - (uint32_t)last_j);
@@ -386,15 +523,34 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
                 }
                 top += (uint32_t)__popcll(wm);
             }
+            st_trips++;
+            if (top > st_deep) st_deep = top;
             if (top > qcap) { overflow = true; break; }
             wcs_sync();
         }
+        if (stats && lane == 0) {
+            atomicMax(&stats[0], st_deep); atomicMax(&stats[1], nloc); atomicAdd(&stats[2], st_trips); atomicAdd(&stats[3], st_calls);
+            atomicAdd(&stats[4], 1u);
+        }
         }
         if (overflow) { if (lane == 0) atomicOr(a.err_flag, 1u); continue; }
-        if (WRITE) continue;
+        if (WRITE) {
+            // first_j and best_score of the ORFs whose starts were written (the walk-free count pass leaves them to this pass)
+            wcs_sync();
+            if (lane < nloc && a_cnt[lane]) {
+                const uint64_t i = s_gi[lane];
+                const uint32_t ja = (uint32_t)a_exa[lane], jb = 0xffffffffu - (uint32_t)a_exb[lane];
+                const int jmin = (int)(fwd ? ja : jb), jmax = (int)(fwd ? jb : ja);
+                a.orfs[i].first_j = jmin;
+                if (jmax + 1 >= a.min_gene_len) a.orfs[i].best_score = mg_unord(a_best[lane]);
+            }
+            wcs_sync();
+            continue;
+        }
 
         // ---- Score_Orfs_Errors' verdict per ORF (:1647-1683; as k_mg_err_verdict)
         wcs_sync();
+        bool kept = false;
         if (lane < nloc) {
             const uint32_t g_cnt = a_cnt[lane];
             const uint64_t i = s_gi[lane];
@@ -417,11 +573,472 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
                     }
                 }
                 a.orf_cnt[i] = (accepted_only && !rec.accepted) ? 0u : g_cnt;
-                if (rec.accepted) atomicOr(&a.acc_bits[i >> 5], 1u << (i & 31u));
+                if (rec.accepted) { atomicOr(&a.acc_bits[i >> 5], 1u << (i & 31u)); kept = true; }
                 if (!(accepted_only && !rec.accepted)) { rec.start_begin = 0; a.orfs[i] = rec; }
             }
         }
+        if (__ballot(kept) && lane == 0) item_flag[it] = 1;            // (the write pass takes this pair)
         wcs_sync();
+    }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_mg_err_wcount -- the COUNT pass without walks.  What the count pass must deliver per ORF is the NUMBER of starts its call tree
+// pushes and whether any of them scores above Start_Threshold (Score_Orfs_Errors' filter, glimmer-mg.cc:1647-1683; first_j and
+// best_score of the kept ORFs come from the write pass, which meets every start anyway).  With the running sums and the masks in LDS
+// neither needs a walk:
+//   * a call (first step x, suffix score ss, D = x - suffix_j) pushes one start per start codon of its phase between
+//     max (x + 3, D + Min_Gene_Len - 3) and the last codon in front of the next in-phase stop codon: a popcount of the start mask
+//     (+ 1 for the truncated start when the region runs into the read's end); their scores are ss + S[t] - S[x]: a few look-ups
+//     at the set bits (ew_own);
+//   * a call branches only at bases of low quality: the (call, low-quality base) pairs are enumerated DENSELY, one lane each --
+//     level 0: every low-quality base in each of the three phases belongs to at most one ORF's region (found from the stop mask
+//     backwards); level 1: the bases between the call's first step and its region's end, by rank in the sorted list of the
+//     read's low-quality bases.  A pair evaluates its two candidates (insertion, deletion) and appends the children to the next
+//     level's list (wave-wide ballots); level 2 never branches: its calls are ew_own alone.
+// The tree is processed breadth first, every trip with full lanes: ~10 trips per (read, strand) instead of the ~15 dependent
+// event trips of the stack walker at 28 % of the lanes (mg_timing prints both kernels' counts).  -s: level 0 + one child per ORF.
+// ---------------------------------------------------------------------------------------------------
+#define EWC_CAP1 256             // level-1 calls of one (read, strand)
+#define EWC_CAP2 192             // level-2 calls waiting (drained whenever fewer than 128 slots are free)
+#define EWC_PCAP 512             // (level-1 call, low-quality base) pairs of one batch of 64 calls
+#define EWC_PMAX 160             // low-quality bases of one read
+
+struct EwcLayout {
+    uint32_t S, msk, l1_ss, l2_ss, l1_w, l2_w, l1_x, pcall, plist, pq, cum, orf_at, a_cnt, a_m0, gi, acc, bytes;
+    uint32_t srow, nw;           // doubles per class row; words per mask row (one guard word in front, zero words behind)
+};
+__host__ __device__ inline EwcLayout ewc_layout(uint32_t cap)
+{
+    EwcLayout L;
+    L.srow = cap + 4;
+    L.nw = cap / 64 + 3;
+    uint32_t o = 0;
+    L.S = o; o += 3 * L.srow * 8;
+    L.msk = o; o += 3 * L.nw * 8;
+    L.l1_ss = o; o += EWC_CAP1 * 8;
+    L.l2_ss = o; o += EWC_CAP2 * 8;
+    L.acc = o; o += 8;
+    L.l1_w = o; o += EWC_CAP1 * 4;
+    L.l2_w = o; o += EWC_CAP2 * 4;
+    L.a_cnt = o; o += EW_MAXO * 4;
+    L.a_m0 = o; o += EW_MAXO * 4;
+    L.gi = o; o += EW_MAXO * 4;
+    L.l1_x = o; o += EWC_CAP1 * 2;
+    L.pcall = o; o += EWC_PCAP * 2;
+    L.plist = o; o += EWC_PMAX * 2;
+    L.cum = o; o += ((L.nw + 1) * 2 + 3) & ~3u;
+    L.pq = o; o += EWC_PMAX;
+    L.orf_at = o; o += (cap + 8 + 7) & ~7u;
+    L.bytes = (o + 15) & ~15u;
+    return L;
+}
+
+// the 64 steps from step t on of a mask row; t may be negative (the row has a zero guard word in front)
+__device__ __forceinline__ uint64_t ewc_window(const uint64_t *row, int t)
+{
+    const int wi = t >> 6;
+    const uint32_t sh = (uint32_t)t & 63u;
+    const uint64_t lo = row[wi], hi = row[wi + 1];
+    return (lo >> sh) | ((hi << 1) << (63u - sh));
+}
+__device__ __forceinline__ uint32_t ewc_scan_u32(uint32_t x)       // inclusive sum over the lanes of a wave
+{
+#define EWC_DPP_ADD(CTRL, RM) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, RM, 0xf, false)
+    EWC_DPP_ADD(0x111, 0xf); EWC_DPP_ADD(0x112, 0xf); EWC_DPP_ADD(0x114, 0xf); EWC_DPP_ADD(0x118, 0xf);
+    EWC_DPP_ADD(0x142, 0xa); EWC_DPP_ADD(0x143, 0xc);
+#undef EWC_DPP_ADD
+    return x;
+}
+
+struct EwOwn { uint32_t cnt, t_last, m_end; bool acc, has, trunc; };
+// What one Score_Orf_Starts call pushes itself (glimmer-mg.cc:1812-1861), from the masks: the number of starts and whether one of
+// them scores above the threshold; the last codon of its region (has: there is one).  Exactly the stack walker's emissions:
+// a start codon at j0 = t - x counts when j0 >= lowest_j (j0 >= 3: j0 is a multiple of 3 and lowest_j >= 1) and
+// j0 + 3 + suffix_j >= Min_Gene_Len, i.e. t + 3 - D >= Min_Gene_Len; the truncated start sits on the last codon of a region that
+// runs into the read's end.
+__device__ __forceinline__ EwOwn ew_own(const double *S, const uint32_t srow, const uint64_t *Mstart, const uint64_t *Mstop, const uint32_t n,
+                                        const bool fwd, const uint32_t off_m3, const uint32_t x, const double ss, const int D, const int mgl,
+                                        const int isl, const double thr, const bool allow_trunc)
+{
+    EwOwn o;
+    o.cnt = 0; o.t_last = 0; o.m_end = 0; o.acc = false; o.has = false; o.trunc = false;
+    if (x >= n) return o;
+    if (n - x < 3) { o.trunc = allow_trunc; return o; }
+    uint32_t t = x, s = 0;
+    bool found = false;
+    while (t + 2 < n) {                                 // the first stop codon of the call's phase at or behind x
+        const uint64_t win = ewc_window(Mstop, (int)t) & EW_THIN;
+        if (win) { s = t + (uint32_t)__builtin_ctzll(win); found = true; break; }
+        t += 66u;
+    }
+    if (found && s == x) return o;
+    const uint32_t t_last = found ? s - 3u : x + (n - 3u - x) / 3u * 3u;
+    o.has = true; o.t_last = t_last; o.trunc = !found && allow_trunc; o.m_end = t_last + 3u - x;
+    int jmin = D + mgl - 3 - (int)x;
+    if (jmin < 3) jmin = 3;
+    jmin = (jmin + 2) / 3 * 3;
+    const uint32_t tq = x + (uint32_t)jmin;
+    if (tq > t_last) return o;
+    const uint32_t cls = (off_m3 + (fwd ? n - 1u - x : x)) % 3u;
+    const double *Sc = S + cls * srow;
+    const double p0 = Sc[x];
+    for (t = tq; t <= t_last; t += 66u) {
+        uint64_t win = ewc_window(Mstart, (int)t) & EW_THIN;
+        const uint32_t span = t_last - t;
+        if (span < 63u) win &= (2ull << span) - 1ull;
+        o.cnt += (uint32_t)__popcll(win);
+        while (win) {
+            const uint32_t tt = t + (uint32_t)__builtin_ctzll(win);
+            win &= win - 1ull;
+            const double raw = ((Sc[tt] - p0) - 0.0) + ss;
+            const int j_full = (int)tt + 2 - D;
+            const double sc = (j_full > isl && 0.0 > raw) ? 0.0 : raw;
+            if (sc > thr) o.acc = true;
+        }
+    }
+    if (o.trunc) {
+        o.cnt++;
+        const double raw = ((Sc[t_last] - p0) - 0.0) + ss;
+        const int j_full = (int)t_last + 2 - D;
+        const double sc = (j_full > isl && 0.0 > raw) ? 0.0 : raw;
+        if (sc > thr) o.acc = true;
+    }
+    return o;
+}
+
+template <bool G32, int KMAX>
+__global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int accepted_only, const uint32_t cap_lo, const uint32_t cap,
+                                                            uint8_t *item_flag, uint32_t *stats)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ew_lds[];
+    __shared__ double s_pen[64];
+    const uint32_t lane = threadIdx.x;
+    s_pen[lane] = a.err_mode == 1 ? a.pen[lane] : 0.0;
+    const EwcLayout L = ewc_layout(cap);
+    double *S = (double *)(ew_lds + L.S);
+    uint64_t *msk = (uint64_t *)(ew_lds + L.msk);
+    uint64_t *Mstart = msk + 1, *Mstop = msk + L.nw + 1, *Mlow = msk + 2 * L.nw + 1;       // (row[-1]: the guard word)
+    double *l1_ss = (double *)(ew_lds + L.l1_ss), *l2_ss = (double *)(ew_lds + L.l2_ss);
+    uint32_t *l1_w = (uint32_t *)(ew_lds + L.l1_w), *l2_w = (uint32_t *)(ew_lds + L.l2_w);
+    uint16_t *l1_x = (uint16_t *)(ew_lds + L.l1_x), *pcall = (uint16_t *)(ew_lds + L.pcall), *plist = (uint16_t *)(ew_lds + L.plist),
+             *cum = (uint16_t *)(ew_lds + L.cum);
+    uint8_t *pq = ew_lds + L.pq, *orf_at = ew_lds + L.orf_at;
+    uint32_t *a_cnt = (uint32_t *)(ew_lds + L.a_cnt), *a_m0 = (uint32_t *)(ew_lds + L.a_m0), *s_gi = (uint32_t *)(ew_lds + L.gi);
+    unsigned long long *acc_mask = (unsigned long long *)(ew_lds + L.acc);
+    __syncthreads();
+    const bool pen_lds = a.indel_q_thr < 64;
+    const int mgl = a.min_gene_len;
+    const int lowest_j = mgl - 3 < 3 ? mgl - 3 : 3;
+    const bool indels = a.err_mode == 1;
+    const uint32_t nw = L.nw, srow = L.srow;
+    const uint64_t n_items = 2 * a.n_reads;
+    const bool trunc_ok = a.allow_truncated != 0;
+    const double thr = a.start_threshold;
+
+    for (uint64_t blk = blockIdx.x; blk * 64 < n_items; blk += gridDim.x) {
+    uint64_t l_off = 0, l_ob = 0;
+    uint32_t l_n = 0, l_no = 0;
+    bool elig = false;
+    {
+        const uint64_t my = blk * 64 + lane;
+        if (my < n_items) {
+            const uint64_t r_ = my >> 1;
+            l_off = a.read_off[r_];
+            l_n = (uint32_t)(a.read_off[r_ + 1] - l_off);
+            l_ob = a.read_orf_off[r_];
+            const uint64_t no_ = a.read_orf_off[r_ + 1] - l_ob;
+            l_no = no_ > 0xffffffffull ? 0xffffffffu : (uint32_t)no_;
+            elig = l_n > cap_lo && l_n <= cap && l_no > 0;
+        }
+    }
+    uint64_t todo = __ballot(elig);
+    while (todo) {
+        const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint64_t it = blk * 64 + src;
+        const uint64_t r = it >> 1;
+        const bool fwd = (it & 1) == 0;
+        const uint64_t off = ew_readlane64(l_off, src), ob = ew_readlane64(l_ob, src);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)l_n, (int)src);
+        const uint64_t oe = ob + (uint32_t)__builtin_amdgcn_readlane((int)l_no, (int)src);
+        const int isl = a.read_isl ? a.read_isl[r] : a.ignore_score_len;
+        const uint32_t off_m3 = (uint32_t)(off % 3);
+
+        EwRegs<G32, KMAX> R;
+        ew_load<G32, KMAX>(a, off, n, fwd, indels, lane, R);
+        int o_frame = 0, o_stop = 0;
+        if (ob + lane < oe) { o_frame = a.orfs[ob + lane].frame; o_stop = a.orfs[ob + lane].stop_position; }
+
+        // ---- sums, masks, the sorted list of the low-quality bases
+        uint32_t f_low = 0;
+        ew_build<G32, KMAX>(a, r, off, n, fwd, indels, lane, R, S, srow, Mstart, Mstop, Mlow, nw - 1, msk, 3 * nw, (uint8_t *)nullptr, f_low);
+        uint32_t npos = 0;
+        bool overflow = false;
+        if (indels) {
+            const uint32_t mine = (uint32_t)__popc(f_low), incl = ewc_scan_u32(mine);
+            npos = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (npos > EWC_PMAX) overflow = true;
+            else {
+                uint32_t o = incl - mine;
+#pragma unroll
+                for (int e = 0; e < KMAX; e++)
+                    if ((f_low >> e) & 1u) { plist[o] = (uint16_t)(R.tb + (uint32_t)e); pq[o] = (uint8_t)R.qv[e]; o++; }
+                // low-quality bases in front of every 64-step word
+                if (lane < nw) {
+                    uint32_t c = 0;
+                    for (uint32_t w = 0; w < lane && w < nw - 1; w++) c += (uint32_t)__popcll(Mlow[w]);
+                    cum[lane] = (uint16_t)c;
+                }
+            }
+        }
+        for (uint32_t t = lane; t < n + 8; t += 64) orf_at[t] = 255;
+        if (lane == 0) *acc_mask = 0;
+        wcs_sync();
+
+        // ---- level 0: the ORFs of this strand
+        uint32_t nloc = 0, n1 = 0;
+        for (uint64_t o0 = ob; o0 < oe && !overflow; o0 += 64) {
+            const uint64_t i = o0 + lane;
+            const bool have = i < oe;
+            int frame = o_frame, stop_position = o_stop;
+            if (o0 != ob && have) { frame = a.orfs[i].frame; stop_position = a.orfs[i].stop_position; }
+            const bool mine = have && (frame > 0) == fwd;
+            const uint64_t mm = __ballot(mine);
+            const uint32_t idx = nloc + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+            nloc += (uint32_t)__popcll(mm);
+            if (nloc > EW_MAXO) { overflow = true; break; }
+            bool act = mine;
+            const int end_point = fwd ? stop_position - 1 : stop_position + 3;
+            const int xs = fwd ? (int)n - end_point : end_point - 1;               // the call's first walk step
+            bool child = false;
+            double es_sub = 0.0;
+            uint32_t child_w = 0;
+            if (mine) {
+                s_gi[idx] = (uint32_t)i;
+                a_cnt[idx] = 0; a_m0[idx] = 0;
+                if (accepted_only && ((int)n - xs) + 12 < mgl) act = false;          // (as k_mg_err_level: cannot reach Min_Gene_Len)
+                if (xs < 0 || xs >= (int)n) act = false;
+                if (act) {
+                    const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, (uint32_t)xs, 0.0, xs, mgl, isl, thr, trunc_ok);
+                    a_cnt[idx] = o.cnt;
+                    a_m0[idx] = o.m_end << 1 | (o.trunc ? 1u : 0u);
+                    if (o.acc) atomicOr(acc_mask, 1ull << idx);
+                    if (indels && a.indel_max >= 1 && o.has) orf_at[xs] = (uint8_t)idx;
+#ifdef EWC_DEBUG
+                    printf("ORF it %llu idx %u xs %d has %d cnt %u m_end %u\n", (unsigned long long)it, idx, xs, (int)o.has, o.cnt, o.m_end);
+#endif
+                    if (a.err_mode == 2 && (uint32_t)xs + o.m_end + 3u <= n) {
+                        // the substitution branch (:1771-1806): through the stop codon behind the region (steps x + m .. x + m + 2)
+                        const uint32_t sa = (uint32_t)xs + o.m_end;
+                        const uint64_t g = fwd ? off + n - 1 - sa : off + sa;
+                        const uint32_t five = (uint32_t)dev_window_bits(a.packed, (int64_t)g - 2) & 0x3ffu;
+                        const int a2 = fwd ? ((five >> 4) & 3u) == 0u : ((five >> 4) & 3u) == 3u;
+                        const int a1 = fwd ? ((five >> 2) & 3u) == 0u : ((five >> 6) & 3u) == 3u;
+                        es_sub = 0.0 + a.pass_stop[a1 * 2 + a2];
+                        if (o.m_end > 0) {
+                            const uint32_t cls = (off_m3 + (fwd ? n - 1u - (uint32_t)xs : (uint32_t)xs)) % 3u;
+                            es_sub += (S[cls * srow + sa] - S[cls * srow + (uint32_t)xs]) - 0.0;       // score[m - 1]
+                        }
+                        if ((int)o.m_end + ((int)n - (int)(sa + 3u)) + 12 >= mgl) {
+                            child = true;
+                            child_w = (sa + 3u) | (uint32_t)(xs + 3) << 10 | idx << 21;     // step | D << 10 | ORF << 21
+                        }
+                    }
+                }
+            }
+            const uint64_t cm = __ballot(child);
+            if (child) {
+                const uint32_t e = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                if (e < EWC_CAP1) { l1_ss[e] = es_sub; l1_w[e] = child_w; }
+            }
+            n1 += (uint32_t)__popcll(cm);
+        }
+        if (n1 > EWC_CAP1) overflow = true;
+        wcs_sync();
+
+        // ---- level 0 -> 1: every (low-quality base, phase) pair
+        if (indels && a.indel_max >= 1 && !overflow) {
+            for (uint32_t i0 = 0; i0 < 3u * npos; i0 += 64) {
+                const uint32_t id = i0 + lane;
+                bool pi = false, pd = false;
+                double es_i = 0.0, es_d = 0.0;
+                uint32_t t = 0, xs = 0, lidx = 0;
+                if (id < 3u * npos) {
+                    const uint32_t k = id / 3u, phi = id - 3u * k, p = plist[k];
+                    const uint32_t pj = (p + 3u - phi) % 3u;
+                    if (pj <= p && p - pj + 2u < n) {
+                        t = p - pj;
+                        if (!((Mstop[t >> 6] >> (t & 63u)) & 1ull)) {
+                            // the nearest stop codon of the phase in front of t: the region's call begins behind it
+                            int u = (int)t - 3;
+                            xs = phi;
+                            while (u >= 0) {
+                                const uint64_t m = ewc_window(Mstop, u - 63) & EW_THIN;
+                                if (m) { xs = (uint32_t)(u - __builtin_clzll(m)) + 3u; break; }
+                                u -= 66;
+                            }
+                            lidx = orf_at[xs];
+                            const uint32_t j0 = t - xs, j = j0 + pj;
+                            if (lidx != 255u && (int)j >= lowest_j) {
+                                const uint32_t cls = (off_m3 + (fwd ? n - 1u - xs : xs)) % 3u;
+                                const double *Sc = S + cls * srow;
+                                const double p0 = Sc[xs], before = Sc[p] - p0, at = Sc[p + 1] - p0;
+                                const int q = pq[k];
+                                const double pen = pen_lds ? s_pen[q & 63] : a.pen[q];
+                                es_i = ((0.0 + before) - 0.0) + pen;
+                                es_d = ((0.0 + at) - 0.0) + pen;
+                                const int c_sj = (int)j0 + 2;
+                                pi = c_sj + ((int)n - (int)(t + 4u)) + 12 >= mgl && es_i > a.indel_suffix_thr;
+                                pd = c_sj + ((int)n - (int)(t + 2u)) + 12 >= mgl && es_d > a.indel_suffix_thr;
+                            }
+                        }
+                    }
+                }
+#ifdef EWC_DEBUG
+                if (id < 3u * npos && t < 40) printf("PAIR it %llu id %u p %u t %u xs %u lidx %u pi %d pd %d es %g %g\n", (unsigned long long)it, id, (unsigned)plist[id / 3u], t, xs, lidx, (int)pi, (int)pd, es_i, es_d);
+#endif
+                const uint64_t mi = __ballot(pi), md = __ballot(pd);
+                if (pi) {
+                    const uint32_t e = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
+                    if (e < EWC_CAP1) { l1_ss[e] = es_i; l1_w[e] = (t + 4u) | (xs + 2u) << 10 | lidx << 21; }
+                }
+                n1 += (uint32_t)__popcll(mi);
+                if (pd) {
+                    const uint32_t e = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(md >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md, 0u));
+                    if (e < EWC_CAP1) { l1_ss[e] = es_d; l1_w[e] = (t + 2u) | xs << 10 | lidx << 21; }
+                }
+                n1 += (uint32_t)__popcll(md);
+                if (n1 > EWC_CAP1) { overflow = true; break; }
+            }
+        }
+        wcs_sync();
+
+        // ---- level 1 (own starts), level 1 -> 2 (pairs), level 2 (own starts), batch by batch
+        uint32_t n2 = 0;
+        auto drain2 = [&]() __attribute__((always_inline)) {
+            wcs_sync();
+            for (uint32_t b0 = 0; b0 < n2; b0 += 64) {
+                const uint32_t i = b0 + lane;
+                if (i < n2) {
+                    const uint32_t w = l2_w[i];
+                    const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, w & 1023u, l2_ss[i], (int)((w >> 10) & 2047u), mgl, isl, thr, trunc_ok);
+                    if (o.cnt) atomicAdd(&a_cnt[w >> 21], o.cnt);
+                    if (o.acc) atomicOr(acc_mask, 1ull << (w >> 21));
+                }
+            }
+            n2 = 0;
+            wcs_sync();
+        };
+        const bool expand1 = indels && a.indel_max >= 2;
+        for (uint32_t b0 = 0; b0 < n1 && !overflow; b0 += 64) {
+            const uint32_t i = b0 + lane;
+            uint32_t nq = 0;
+            if (i < n1) {
+                const uint32_t w = l1_w[i], x1 = w & 1023u;
+                const int D1 = (int)((w >> 10) & 2047u);
+                const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, x1, l1_ss[i], D1, mgl, isl, thr, trunc_ok);
+                if (o.cnt) atomicAdd(&a_cnt[w >> 21], o.cnt);
+                if (o.acc) atomicOr(acc_mask, 1ull << (w >> 21));
+                if (expand1 && o.has) {
+                    // the low-quality bases from the call's first step to the last base of its region, by rank
+                    const uint32_t e = o.t_last + 3u;
+                    const uint32_t r0 = cum[x1 >> 6] + (uint32_t)__popcll(Mlow[x1 >> 6] & ((1ull << (x1 & 63u)) - 1ull));
+                    const uint32_t r1 = cum[e >> 6] + (uint32_t)__popcll(Mlow[e >> 6] & ((1ull << (e & 63u)) - 1ull));
+                    nq = r1 - r0;
+                    l1_x[i] = (uint16_t)r0;
+                }
+            }
+            if (!expand1) continue;
+            const uint32_t incl = ewc_scan_u32(nq), T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            for (uint32_t pb = 0; pb < T; pb += EWC_PCAP) {             // (the pair table holds EWC_PCAP pairs at a time)
+            const uint32_t Tn = T - pb < EWC_PCAP ? T - pb : EWC_PCAP;
+            for (uint32_t u = 0; __ballot(u < nq); u++) {
+                const uint32_t gq = incl - nq + u;
+                if (u < nq && gq >= pb && gq < pb + EWC_PCAP) pcall[gq - pb] = (uint16_t)(lane | u << 6);
+            }
+            wcs_sync();
+            for (uint32_t q0 = 0; q0 < Tn; q0 += 64) {
+                const uint32_t qi = q0 + lane;
+                bool pi = false, pd = false;
+                double es_i = 0.0, es_d = 0.0;
+                uint32_t t = 0, lidx = 0;
+                int D1 = 0;
+                if (qi < Tn) {
+                    const uint32_t pc = pcall[qi], ci = b0 + (pc & 63u), u = pc >> 6;
+                    const uint32_t w = l1_w[ci], x1 = w & 1023u;
+                    D1 = (int)((w >> 10) & 2047u); lidx = w >> 21;
+                    const double ss1 = l1_ss[ci];
+                    const uint32_t k = (uint32_t)l1_x[ci] + u, p = plist[k];
+                    const uint32_t pj = (p - x1) % 3u;
+                    t = p - pj;
+                    const uint32_t j0 = t - x1, j = j0 + pj;
+                    if ((int)j >= lowest_j) {
+                        const uint32_t cls = (off_m3 + (fwd ? n - 1u - x1 : x1)) % 3u;
+                        const double *Sc = S + cls * srow;
+                        const double p0 = Sc[x1], before = Sc[p] - p0, at = Sc[p + 1] - p0;
+                        const int q = pq[k];
+                        const double pen = pen_lds ? s_pen[q & 63] : a.pen[q];
+                        es_i = ((ss1 + before) - 0.0) + pen;
+                        es_d = ((ss1 + at) - 0.0) + pen;
+                        const int c_sj = ((int)x1 - D1) + (int)j0 + 2;
+                        pi = c_sj + ((int)n - (int)(t + 4u)) + 12 >= mgl && es_i > a.indel_suffix_thr;
+                        pd = c_sj + ((int)n - (int)(t + 2u)) + 12 >= mgl && es_d > a.indel_suffix_thr;
+                    }
+                }
+                const uint64_t mi = __ballot(pi), md = __ballot(pd);
+                if (pi) {
+                    const uint32_t e = n2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
+                    l2_ss[e] = es_i; l2_w[e] = (t + 4u) | (uint32_t)(D1 + 2) << 10 | lidx << 21;
+                }
+                n2 += (uint32_t)__popcll(mi);
+                if (pd) {
+                    const uint32_t e = n2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(md >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md, 0u));
+                    l2_ss[e] = es_d; l2_w[e] = (t + 2u) | (uint32_t)D1 << 10 | lidx << 21;
+                }
+                n2 += (uint32_t)__popcll(md);
+                if (n2 > EWC_CAP2 - 128u) drain2();
+            }
+            wcs_sync();
+            }
+        }
+        if (n2 && !overflow) drain2();
+        if (stats && lane == 0) { atomicMax(&stats[0], n1); atomicMax(&stats[1], nloc); atomicMax(&stats[2], npos); atomicAdd(&stats[4], 1u); }
+        if (overflow) { if (lane == 0) atomicOr(a.err_flag, 1u); continue; }
+
+        // ---- Score_Orfs_Errors' verdict per ORF (:1647-1683): kept = one start above Start_Threshold (every pushed start passes
+        //      the length test, glimmer-mg.cc:1821); first_j and best_score come from the write pass
+        wcs_sync();
+        bool kept = false;
+        if (lane < nloc) {
+            uint32_t g_cnt = a_cnt[lane], src_l = lane;
+            const uint64_t i = s_gi[lane];
+            if (indels && a.indel_max >= 1) {
+                // ORFs that begin at the same step (Find_Orfs gives the reverse frames without a stop codon in front the same virtual
+                // stop) have the same call tree; the branches were credited to the one the step's table entry names
+                const int sp = a.orfs[i].stop_position;
+                const int xs = fwd ? (int)n - (sp - 1) : sp + 2;
+                if (xs >= 0 && xs < (int)n && orf_at[xs] != 255 && orf_at[xs] != lane) { src_l = orf_at[xs]; g_cnt = a_cnt[src_l]; }
+            }
+            if (!(accepted_only && g_cnt == 0)) {
+                gmg_mg_orf rec = a.orfs[i];
+                const uint32_t g_m0 = a_m0[lane];
+                const int m0 = (int)(g_m0 >> 1);
+                if (fwd) { rec.hi = rec.stop_position - 1; rec.lo = rec.hi - m0; }
+                else { rec.lo = rec.stop_position + 3; rec.hi = rec.lo + m0; }
+                rec.orf_is_truncated = (int16_t)(g_m0 & 1u);
+                rec.n_starts = g_cnt;
+                rec.first_j = 0; rec.best_score = -DBL_MAX;
+                rec.accepted = (int16_t)((g_cnt && ((*acc_mask >> src_l) & 1ull)) ? 1 : 0);
+                a.orf_cnt[i] = (accepted_only && !rec.accepted) ? 0u : g_cnt;
+                if (rec.accepted) { atomicOr(&a.acc_bits[i >> 5], 1u << (i & 31u)); kept = true; }
+                if (!(accepted_only && !rec.accepted)) { rec.start_begin = 0; a.orfs[i] = rec; }
+            }
+        }
+        if (__ballot(kept) && lane == 0) item_flag[it] = 1;
+        wcs_sync();
+    }
     }
 }
 

@@ -61,11 +61,12 @@ def test_error_branch_matches_reference_push_order(gpu, oracle, nc, name):
     (dict(allow_subs=True), False),
 ])
 @pytest.mark.parametrize("kw", [dict(), dict(allow_truncated=False, min_gene_len=60), dict(ignore_score_len=150, start_codons=("atg", "rtg"))])
-@pytest.mark.parametrize("path", ["wave", "wave-overflow", "wave-table", "tile", "tile-stage", "tile-overflow", "level", "level-q0", "flat", "level-overflow", "level-grow"])
+@pytest.mark.parametrize("path", ["wave", "wave-walk", "wave-overflow", "wave-table", "tile", "tile-stage", "tile-overflow", "level", "level-q0", "flat", "level-overflow", "level-grow"])
 def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path, monkeypatch, request_finalizers):
-    """path: one wave per (read, strand) with sums, masks and the call stack in its LDS (k_mg_err_wave, the default; the 1300- and
-    2100-bp reads, longer than a wave takes, go to the per-ORF kernel), the same with a stack of 5 entries (the batch repeats on the
-    level kernels) and on a batch without the long reads (the fp32 gene rows instead of the fp64 table),
+    """path: one wave per (read, strand) with running sums and masks in its LDS (k_mg_err_wcount: the count pass without walks, breadth
+    first; k_mg_err_wave: the write pass, a stack of calls per wave; the default for -i, here for -s too; the 1300- and 2100-bp
+    reads, longer than a wave takes, go to the per-ORF kernel), the same with the stack walker as the count pass, with a stack of 5
+    entries (the call repeats on the level kernels) and on a batch without the long reads (the fp32 gene rows instead of the fp64 table),
     tile by tile with the running sums in LDS, one lane per event (option mg_err_tile; the 2100-bp read, longer than a tile,
     goes to the per-ORF kernel), the same with staging arrays too small (the kernel repeats with what it asked for) and
     with slabs too small (everything repeats on the level kernels), level by level with
@@ -73,8 +74,8 @@ def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path
     table -- q0: the three-row table instead), the per-ORF kernel alone, the level
     kernels with call arrays too small (everything repeats on the per-ORF kernel), and the same with the arrays allowed to
     grow (the count pass repeats with larger ones)"""
-    opts = {"wave": {"mg_err_wave": 1, "mg_err_tile": 0}, "wave-overflow": {"mg_err_wave": 1, "mg_err_tile": 0, "mg_err_wave_q": 5},
-            "wave-table": {"mg_err_wave": 1, "mg_err_tile": 0},
+    opts = {"wave": {"mg_err_wave": 3, "mg_err_tile": 0}, "wave-walk": {"mg_err_wave": 2, "mg_err_tile": 0},
+            "wave-overflow": {"mg_err_wave": 3, "mg_err_tile": 0, "mg_err_wave_q": 5}, "wave-table": {"mg_err_wave": 3, "mg_err_tile": 0},
             "tile": {"mg_err_tile": 1}, "tile-stage": {"mg_err_tile": 1, "mg_err_tile_q": -1}, "tile-overflow": {"mg_err_tile": 1, "mg_err_tile_q": 3},
             "level": {"mg_err_tile": 0, "mg_err_wave": 0}, "level-q0": {"mg_err_tile": 0, "mg_err_wave": 0, "mg_err_qonly": 0},
             "flat": {"mg_err_flat": 1}, "level-overflow": {"mg_err_tile": 0, "mg_err_wave": 0, "mg_err_calls": 7},
@@ -222,6 +223,11 @@ def test_accepted_only_is_the_full_result_filtered(gpu, nc, name, kw):
     full = gpu.mg_score_reads(nc, indep, reads, **kw)
     kept = gpu.mg_score_reads(nc, indep, reads, accepted_only=True, **kw)
     with gpu.option("mg_err_tile", 1):                  # (the tile kernel: every record, start and error list of both forms)
+        for want, acc in ((full, False), (kept, True)):
+            got = gpu.mg_score_reads(nc, indep, reads, accepted_only=acc, **kw)
+            for x, y in zip(want, got):
+                assert x.tobytes() == y.tobytes()
+    with gpu.option("mg_err_tile", 0), gpu.option("mg_err_wave", 2):    # (... the stack walker as the count pass)
         for want, acc in ((full, False), (kept, True)):
             got = gpu.mg_score_reads(nc, indep, reads, accepted_only=acc, **kw)
             for x, y in zip(want, got):
