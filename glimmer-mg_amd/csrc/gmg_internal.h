@@ -125,8 +125,8 @@ enum GmgOpt {
                                  // any value but 0 also starts with staging arrays of 64 entries (-1: only that: the kernel repeats with larger ones)
     GMG_OPT_MG_ERR_QONLY,        // glimmer-mg -s on the level kernels: 1 = the running-sum table holds one value per base and strand (16 B/base), 0 = three (48)
     GMG_OPT_MG_ERR_WAVE,         // glimmer-mg's error branch with one wave per (read, strand), running sums and masks in the wave's LDS (k_mg_err_wcount +
-                                 // k_mg_err_wave; needs mg_err_skip and sums that are exact in any order): 1 (default) = for -i, 3 = for -i and -s,
-                                 // 2 = as 3 with the stack walker as the count pass too (cross-check), 0 = the tile / level kernels
+                                 // k_mg_err_wave; needs mg_err_skip and sums that are exact in any order): 1 (default), 2 = with the stack walker
+                                 // as the count pass too (cross-check), 0 = the tile / level kernels
     GMG_OPT_MG_ERR_WAVE_Q,       // ... tests: entries of a wave's call stack (0 = EW_QCAP; a full stack sends the batch to the level kernels)
     GMG_OPT_INGEST_SCANS,        // gmg_fasta_ingest: 1 = the first version (two hipcub scans over every byte + k_fa_pack), 0 = block summaries
     GMG_OPT_INGEST_PIECE_MIN,    // gmg_fasta_ingest: inputs of at least this many bytes are uploaded in 16 pieces, every piece parsed and packed as it arrives

@@ -130,6 +130,7 @@ struct MgArgs {
                                  // with / without the low-quality bases as events
     const uint8_t *walk_q;       // [total + 8] the qualities, last base first (forward walks; reverse walks read a.qual)
     uint64_t walk_stride;
+    int ew_slack;                // k_mg_err_wave / _wcount: gene32 and qual have 64 spare entries on both sides (unpredicated loads)
 };
 
 // Ch_Mask (src/Common/gene.cc:954-995)
@@ -3123,10 +3124,9 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     err_tile = err_mode && err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) && tile_wanted && !gmg_opt(GMG_OPT_MG_ERR_FLAT);
     // one wave per (read, strand) (k_mg_err_wave; the default whenever the sums are exact, unless the tile kernel is forced):
     // its LDS share is sized by the batch's longest read, reads beyond EW_MAX_CAP go to k_mg_err_flat
-    // mg_err_wave: 1 (default) for -i only (-s: the level kernels on the one-value table are faster: DESIGN 4.7), 2 with the stack walker
-    // as the count pass, 3 for -i and -s
+    // mg_err_wave: 1 (default), 2 = with the stack walker as the count pass too (cross-check), 0 = the tile / level kernels
     err_wave = err_mode && err_exact && gmg_opt(GMG_OPT_MG_ERR_SKIP) && !gmg_opt(GMG_OPT_MG_ERR_FLAT) && gmg_opt(GMG_OPT_MG_ERR_WAVE) > 0 &&
-               (err_mode == 1 || gmg_opt(GMG_OPT_MG_ERR_WAVE) >= 2) && !tl_mg_no_wave && tile_opt <= 0 && reads->max_len > 0 && a.total;
+               !tl_mg_no_wave && tile_opt <= 0 && reads->max_len > 0 && a.total;
     if (err_wave) {
         err_tile = false;
         const uint64_t longest = reads->max_len < EW_MAX_CAP ? reads->max_len : EW_MAX_CAP;
@@ -3142,10 +3142,12 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     a.fs_stride = a.total;
     if (g32) {
         a.fs_stride = (a.total + 31) & ~31ull;          // every fp32 row on a 128-byte line
-        MG_TRY(gmg_pool_alloc((void **)&d_gene32, (size_t)6 * a.fs_stride * sizeof(float)));
-        rc = mg_gene6_full(gene, groups, reads, d_gene32, a.fs_stride, s);
+        // (64 spare floats on both sides: the wave kernels of the error branch load their lanes' steps without predicates)
+        MG_TRY(gmg_pool_alloc((void **)&d_gene32, ((size_t)6 * a.fs_stride + 128) * sizeof(float)));
+        rc = mg_gene6_full(gene, groups, reads, d_gene32 + 64, a.fs_stride, s);
         if (rc) return fail(rc);
-        a.gene32 = d_gene32;
+        a.gene32 = d_gene32 + 64;
+        a.ew_slack = 1;
     } else {
         if (!d_frame_scores && a.total) {
             a.fs_stride = (a.total + 15) & ~15ull;      // our own table: every row on a 128-byte line
@@ -3162,9 +3164,9 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     tm.lap("frame scores");
     if (err_mode) {                                     // the error branch sums per call; it needs the penalties and the qualities
         if (err_mode == 1 && a.total) {
-            MG_TRY(gmg_pool_alloc((void **)&d_qual, a.total + 8));     // (+8: the level kernels read four values at a time)
+            MG_TRY(gmg_pool_alloc((void **)&d_qual, a.total + 8 + 128));     // (+8: the level kernels read four values at a time; 64 spare bytes on both sides)
             if (prm->quality) MG_TRY(gmg_pool_alloc((void **)&d_user_q, a.total));
-            a.qual = d_qual;                            // filled below, beside Find_Orfs on the second stream
+            a.qual = d_qual + 64;                       // filled below, beside Find_Orfs on the second stream
         }
     }
     // running sums of every reading-frame class (what Cumulative_Frame_Score would give any ORF)
@@ -3342,7 +3344,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     if (err_mode == 1 && a.total && !find_only) {       // Set_Quality_454 / Clean_Quality_454: needs the reads only
         if (prm->quality) MG_TRY(hipMemcpyAsync(d_user_q, prm->quality, a.total, hipMemcpyHostToDevice, s3));
         MG_TRY(gmg_pool_alloc((void **)&d_walk_q, a.total + 8));
-        hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(nr * 64)), dim3(256), 0, s3, a, d_user_q, d_qual, d_walk_q);
+        hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(nr * 64)), dim3(256), 0, s3, a, d_user_q, d_qual + 64, d_walk_q);
         MG_TRY(hipGetLastError());
         a.walk_q = d_walk_q;
         tm.lap("quality values");
@@ -3470,20 +3472,22 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     // k_mg_err_wave: as many one-wave work-groups per CU as their LDS shares allow (the grid strides over the (read, strand) pairs)
     const uint32_t ew_qcap = gmg_opt(GMG_OPT_MG_ERR_WAVE_Q) > 0 ? (uint32_t)gmg_opt(GMG_OPT_MG_ERR_WAVE_Q) : (uint32_t)EW_QCAP;
     auto launch_err_wave = [&](hipStream_t st, bool write) -> hipError_t {
-        // two length classes, a launch each: reads up to 512 bases (8 walk steps per lane, a small LDS share: more waves per CU) and
-        // the longer ones up to ew_cap.  Count pass: the walk-free kernel (k_mg_err_wcount); mg_err_wave = 2: the stack walker's
+        // Length classes, a launch each (a wave's LDS share is sized by its class: more waves per CU for the short reads).  Count
+        // pass: the walk-free kernel (k_mg_err_wcount), classes of up to 384 / 448 / 512 / EW_MAX_CAP bases; mg_err_wave = 2: the
+        // stack walker's count form.  Write pass: the stack walker, up to 512 / ew_cap bases.
         int n_cu = 0;
         hipError_t e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
         if (e != hipSuccess) return e;
         const uint64_t n_blocks = (2 * nr + 63) / 64;
-        const bool walk_count = gmg_opt(GMG_OPT_MG_ERR_WAVE) == 2;
+        const bool wcount = !write && gmg_opt(GMG_OPT_MG_ERR_WAVE) != 2;
         uint32_t *st_ptr = tm.on && !write ? d_err_flag + 24 : (uint32_t *)nullptr;
-        for (int cls = 0; cls < 2; cls++) {
-            const uint32_t lo = cls == 0 ? 0u : 512u, hi = cls == 0 ? (ew_cap < 512u ? ew_cap : 512u) : ew_cap;
-            if (hi <= lo) continue;
-            if (cls == 1 && reads->max_len <= 512) continue;
-            const bool wcount = !write && !walk_count;
-            const uint32_t bytes = wcount ? ewc_layout(hi).bytes : ew_layout(hi, ew_qcap, write).bytes;
+        static const uint32_t bounds_c[5] = {0, 384, 448, 512, EW_MAX_CAP}, bounds_w[3] = {0, 512, EW_MAX_CAP};
+        const uint32_t *bounds = wcount ? bounds_c : bounds_w;
+        const int n_cls = wcount ? 4 : 2;
+        for (int cls = 0; cls < n_cls; cls++) {
+            const uint32_t lo = bounds[cls], hi = bounds[cls + 1] < ew_cap ? bounds[cls + 1] : ew_cap;
+            if (hi <= lo || reads->max_len <= lo || reads->min_len > hi) continue;
+            const uint32_t bytes = wcount ? ewc_layout(bounds[cls + 1]).bytes : ew_layout(hi, ew_qcap, write).bytes;
             uint32_t per_cu = (uint32_t)((160u * 1024u) / (bytes + 1024u));
             if (per_cu > 16) per_cu = 16;
             if (per_cu < 1) per_cu = 1;
@@ -3491,9 +3495,9 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
             if (grid > n_blocks) grid = n_blocks;
             if (grid == 0) continue;
 #define MG_EW_LAUNCH(W_, G_, K_) hipLaunchKernelGGL((k_mg_err_wave<W_, G_, K_>), dim3((unsigned)grid), dim3(EW_BLOCK), bytes, st, a, err_acc_only, lo, hi, ew_qcap, d_item_flag, st_ptr)
-#define MG_EWC_LAUNCH(G_, K_) hipLaunchKernelGGL((k_mg_err_wcount<G_, K_>), dim3((unsigned)grid), dim3(EW_BLOCK), bytes, st, a, err_acc_only, lo, hi, d_item_flag, st_ptr)
+#define MG_EWC_LAUNCH(G_, K_) hipLaunchKernelGGL((k_mg_err_wcount<G_, K_>), dim3((unsigned)grid), dim3(EW_BLOCK), 0, st, a, err_acc_only, lo, hi, d_item_flag, st_ptr)
 #define MG_EW_LAUNCH_K(W_, G_) do { if (cls == 0) MG_EW_LAUNCH(W_, G_, 8); else MG_EW_LAUNCH(W_, G_, 15); } while (0)
-#define MG_EWC_LAUNCH_K(G_) do { if (cls == 0) MG_EWC_LAUNCH(G_, 8); else MG_EWC_LAUNCH(G_, 15); } while (0)
+#define MG_EWC_LAUNCH_K(G_) do { if (cls == 0) MG_EWC_LAUNCH(G_, 6); else if (cls == 1) MG_EWC_LAUNCH(G_, 7); else if (cls == 2) MG_EWC_LAUNCH(G_, 8); else MG_EWC_LAUNCH(G_, 15); } while (0)
             if (wcount) { if (a.gene32) MG_EWC_LAUNCH_K(true); else MG_EWC_LAUNCH_K(false); }
             else if (write) { if (a.gene32) MG_EW_LAUNCH_K(true, true); else MG_EW_LAUNCH_K(true, false); }
             else { if (a.gene32) MG_EW_LAUNCH_K(false, true); else MG_EW_LAUNCH_K(false, false); }

@@ -28,7 +28,7 @@
 #define EW_BLOCK 64
 #define EW_MAXO 64               // ORFs of one (read, strand)
 #define EW_MAX_CAP 960           // longest read a wave takes (10 bits of a stack entry hold a walk step; a child may start 1 step behind the end)
-#define EW_QCAP 192              // stack entries (the deepest stack of 1M 454-like reads: see DESIGN 4.7)
+#define EW_QCAP 384              // stack entries (the deepest stack of 1M 454-like reads: see DESIGN 4.7)
 #define EW_THIN 0x9249249249249249ull     // every third bit: the codons of one reading frame in a 64-step window
 
 struct EwLayout {                // byte offsets inside the wave's LDS
@@ -88,6 +88,7 @@ struct EwRegs {
     uint64_t win;                // 32 bases from the lowest base the lane looks at
     int64_t g0;                  // base of the lane's first step
     uint32_t K, tb;              // steps per lane, the lane's first step
+    float ntv[4];                // per-read null models: the lane's four floats of the read's table (copied to LDS before the sums)
 };
 
 // Everything a (read, strand) pair needs from HBM, asked for in one go: lane L takes the K = ceil (n / 64) consecutive steps from L K on
@@ -103,6 +104,34 @@ __device__ __forceinline__ void ew_load(const MgArgs &a, const uint64_t off, con
     R.win = dev_window_bits(a.packed, g_lo);
     const int64_t g0 = fwd ? (int64_t)(off + n - 1) - (int64_t)tb : (int64_t)(off + tb);
     R.g0 = g0;
+    if (G32 && a.ew_slack) {
+        // the call's own gene rows and quality bytes have 64 spare entries on both sides: no lane needs a predicate, every load is
+        // the lane's pointer + a constant (what lies outside the read is masked where it is used)
+        const float *p0 = a.gene32 + (uint64_t)(fwd ? 0 : 3) * a.fs_stride + g0, *p1 = p0 + a.fs_stride, *p2 = p1 + a.fs_stride;
+        const uint8_t *pq_ = a.qual + g0;
+        if (fwd) {
+#pragma unroll
+            for (int e = 0; e < KMAX; e++) {
+                R.qv[e] = 255u;
+                R.gv[e][0] = R.gv[e][1] = R.gv[e][2] = 0.0f;
+                if ((uint32_t)e < K) {
+                    R.gv[e][0] = p0[-e]; R.gv[e][1] = p1[-e]; R.gv[e][2] = p2[-e];
+                    if (indels) R.qv[e] = pq_[-e];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < KMAX; e++) {
+                R.qv[e] = 255u;
+                R.gv[e][0] = R.gv[e][1] = R.gv[e][2] = 0.0f;
+                if ((uint32_t)e < K) {
+                    R.gv[e][0] = p0[e]; R.gv[e][1] = p1[e]; R.gv[e][2] = p2[e];
+                    if (indels) R.qv[e] = pq_[e];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < KMAX; e++) {
         const bool in = (uint32_t)e < K && tb + (uint32_t)e < n;
@@ -123,14 +152,15 @@ __device__ __forceinline__ void ew_load(const MgArgs &a, const uint64_t off, con
 // that starts here is a start / stop codon; base of low quality), the quality bytes.  A lane sums its K steps serially, ONE wave scan
 // of the lanes' totals per class (exact in any order: mg_run's test).  zero / n_zero: the mask words to clear first.
 // f_low_out: the lane's own low-quality bits (bit e = step tb + e).
-template <bool G32, int KMAX>
+template <bool G32, int KMAX, bool NTL = false>
 __device__ __forceinline__ void ew_build(const MgArgs &a, const uint64_t r, const uint64_t off, const uint32_t n, const bool fwd, const bool indels,
                                          const uint32_t lane, const EwRegs<G32, KMAX> &R, double *S, const uint32_t srow, uint64_t *Mstart,
                                          uint64_t *Mstop, uint64_t *Mlow, const uint32_t nw, uint64_t *zero, const uint32_t n_zero, uint8_t *s_q,
-                                         uint32_t &f_low_out)
+                                         uint32_t &f_low_out, const float *nt_lds = nullptr)
 {
     const uint32_t K = R.K, tb = R.tb;
-    const float *nt = G32 ? a.null_tab + (size_t)(a.read_null ? a.read_null[r] : 0u) * MG_NULL_FLOATS : nullptr;
+    // (the null model's table: the wave's copy in LDS when the batch has one null model, else the read's own in global memory)
+    const float *nt = !G32 ? nullptr : NTL ? nt_lds : a.null_tab + (size_t)(a.read_null ? a.read_null[r] : 0u) * MG_NULL_FLOATS;
     if (lane < 3) S[lane * srow] = 0.0;
     for (uint32_t w = lane; w < n_zero; w += 64) zero[w] = 0;
     const uint64_t W = fwd ? ew_reverse_fields64(R.win, K + 4u) : ~R.win;    // field p = the walk code of step tb - 2 + p
@@ -163,7 +193,7 @@ __device__ __forceinline__ void ew_build(const MgArgs &a, const uint64_t r, cons
         const bool codon = in && t + 2 < n;
         if (codon && ((a.fwd_start >> idx) & 1ull)) f_start |= 1u << e;
         if (codon && ((a.fwd_stop >> idx) & 1ull)) f_stop |= 1u << e;
-        if (in && R.qv[e] <= (uint32_t)a.indel_q_thr) f_low |= 1u << e;
+        if (in && indels && R.qv[e] <= (uint32_t)a.indel_q_thr) f_low |= 1u << e;
         if (s_q && indels && in) s_q[t] = (uint8_t)R.qv[e];
     }
     f_low_out = f_low;
@@ -250,9 +280,37 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
         }
     }
     uint64_t todo = __ballot(elig);
-    while (todo) {
-        const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+    // what the NEXT pair needs from HBM (the lanes' K walk steps: bases, gene rows, qualities; the read's first 64 ORF records) is
+    // asked for before this one is worked on and waits in registers
+    EwRegs<G32, KMAX> Rn;
+    int on_frame = 0, on_stop = 0;
+    uint32_t on_acc = 1, on_sbeg = 0, src_n = 0;
+    bool have_n = todo != 0;
+    auto fetch_next = [&]() __attribute__((always_inline)) {
+        src_n = (uint32_t)__builtin_ctzll(todo);
         todo &= todo - 1ull;
+        const uint64_t it_ = blk * 64 + src_n;
+        const uint64_t off_ = ew_readlane64(l_off, src_n), ob_ = ew_readlane64(l_ob, src_n);
+        const uint32_t n_ = (uint32_t)__builtin_amdgcn_readlane((int)l_n, (int)src_n);
+        const uint64_t oe_ = ob_ + (uint32_t)__builtin_amdgcn_readlane((int)l_no, (int)src_n);
+        ew_load<G32, KMAX>(a, off_, n_, (it_ & 1) == 0, indels, lane, Rn);
+        on_frame = 0; on_stop = 0; on_acc = 1; on_sbeg = 0;
+        if (ob_ + lane < oe_) {
+            on_frame = a.orfs[ob_ + lane].frame; on_stop = a.orfs[ob_ + lane].stop_position;
+            if (WRITE) {
+                on_sbeg = (uint32_t)a.start_off[ob_ + lane];
+                if (accepted_only) on_acc = (a.acc_bits[(ob_ + lane) >> 5] >> ((ob_ + lane) & 31u)) & 1u;
+            }
+        }
+    };
+    if (have_n) fetch_next();
+    while (have_n) {
+        const uint32_t src = src_n;
+        const EwRegs<G32, KMAX> R = Rn;
+        const int o_frame = on_frame, o_stop = on_stop;
+        const uint32_t o_acc = on_acc, o_sbeg = on_sbeg;
+        have_n = todo != 0;
+        if (have_n) fetch_next();
         const uint64_t it = blk * 64 + src;
         const uint64_t r = it >> 1;
         const bool fwd = (it & 1) == 0;
@@ -260,20 +318,6 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
         const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)l_n, (int)src);
         const uint64_t oe = ob + (uint32_t)__builtin_amdgcn_readlane((int)l_no, (int)src);
         const int isl = a.read_isl ? a.read_isl[r] : a.ignore_score_len;
-
-        // ---- everything the pair needs from HBM is asked for first: the lane's K walk steps (bases, gene rows, qualities) and
-        //      the read's first 64 ORF records
-        EwRegs<G32, KMAX> R;
-        ew_load<G32, KMAX>(a, off, n, fwd, indels, lane, R);
-        int o_frame = 0, o_stop = 0;
-        uint32_t o_acc = 1, o_sbeg = 0;
-        if (ob + lane < oe) {
-            o_frame = a.orfs[ob + lane].frame; o_stop = a.orfs[ob + lane].stop_position;
-            if (WRITE) {
-                o_sbeg = (uint32_t)a.start_off[ob + lane];
-                if (accepted_only) o_acc = (a.acc_bits[(ob + lane) >> 5] >> ((ob + lane) & 31u)) & 1u;
-            }
-        }
 
         // ---- the ORFs of this strand: level-0 calls onto the stack
         uint32_t top = 0, nloc = 0;
@@ -606,12 +650,12 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
 #define EWC_PMAX 160             // low-quality bases of one read
 
 struct EwcLayout {
-    uint32_t S, msk, l1_ss, l2_ss, l1_w, l2_w, l1_x, pcall, plist, pq, cum, orf_at, a_cnt, a_m0, gi, acc, bytes;
+    uint32_t S, msk, l1_ss, l2_ss, l1_w, l2_w, l1_x, pcall, plist, pq, cum, orf_at, a_cnt, a_m0, gi, xs, acc, bytes;
     uint32_t srow, nw;           // doubles per class row; words per mask row (one guard word in front, zero words behind)
 };
-__host__ __device__ inline EwcLayout ewc_layout(uint32_t cap)
+__host__ __device__ constexpr EwcLayout ewc_layout(uint32_t cap)
 {
-    EwcLayout L;
+    EwcLayout L = {};
     L.srow = cap + 4;
     L.nw = cap / 64 + 3;
     uint32_t o = 0;
@@ -626,6 +670,7 @@ __host__ __device__ inline EwcLayout ewc_layout(uint32_t cap)
     L.a_m0 = o; o += EW_MAXO * 4;
     L.gi = o; o += EW_MAXO * 4;
     L.l1_x = o; o += EWC_CAP1 * 2;
+    L.xs = o; o += EW_MAXO * 2;
     L.pcall = o; o += EWC_PCAP * 2;
     L.plist = o; o += EWC_PMAX * 2;
     L.cum = o; o += ((L.nw + 1) * 2 + 3) & ~3u;
@@ -712,18 +757,22 @@ template <bool G32, int KMAX>
 __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int accepted_only, const uint32_t cap_lo, const uint32_t cap,
                                                             uint8_t *item_flag, uint32_t *stats)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ew_lds[];
+    // (the LDS share is sized by the length class, 64 KMAX bases: every offset a constant; reads of cap_lo < n <= cap are taken)
+    constexpr EwcLayout L = ewc_layout(64u * (uint32_t)KMAX);
+    __shared__ __attribute__((aligned(16))) unsigned char ew_lds[L.bytes];
     __shared__ double s_pen[64];
+    __shared__ float s_nt[G32 ? MG_NULL_FLOATS + 4 : 4];
     const uint32_t lane = threadIdx.x;
     s_pen[lane] = a.err_mode == 1 ? a.pen[lane] : 0.0;
-    const EwcLayout L = ewc_layout(cap);
+    if (G32 && !a.read_null)
+        for (uint32_t k = lane; k < MG_NULL_FLOATS; k += 64) s_nt[k] = a.null_tab[k];
     double *S = (double *)(ew_lds + L.S);
     uint64_t *msk = (uint64_t *)(ew_lds + L.msk);
     uint64_t *Mstart = msk + 1, *Mstop = msk + L.nw + 1, *Mlow = msk + 2 * L.nw + 1;       // (row[-1]: the guard word)
     double *l1_ss = (double *)(ew_lds + L.l1_ss), *l2_ss = (double *)(ew_lds + L.l2_ss);
     uint32_t *l1_w = (uint32_t *)(ew_lds + L.l1_w), *l2_w = (uint32_t *)(ew_lds + L.l2_w);
     uint16_t *l1_x = (uint16_t *)(ew_lds + L.l1_x), *pcall = (uint16_t *)(ew_lds + L.pcall), *plist = (uint16_t *)(ew_lds + L.plist),
-             *cum = (uint16_t *)(ew_lds + L.cum);
+             *cum = (uint16_t *)(ew_lds + L.cum), *s_xs = (uint16_t *)(ew_lds + L.xs);
     uint8_t *pq = ew_lds + L.pq, *orf_at = ew_lds + L.orf_at;
     uint32_t *a_cnt = (uint32_t *)(ew_lds + L.a_cnt), *a_m0 = (uint32_t *)(ew_lds + L.a_m0), *s_gi = (uint32_t *)(ew_lds + L.gi);
     unsigned long long *acc_mask = (unsigned long long *)(ew_lds + L.acc);
@@ -754,9 +803,35 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         }
     }
     uint64_t todo = __ballot(elig);
-    while (todo) {
-        const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+    // The pairs of the block one after the other; what the NEXT pair needs from HBM (its lanes' walk steps, its ORF records) is asked
+    // for before this one is worked on and waits in registers: the pair's own phases then wait for LDS alone.
+    EwRegs<G32, KMAX> Rn;
+    int on_frame = 0, on_stop = 0;
+    uint32_t src_n = 0;
+    bool have_n = todo != 0;
+    auto fetch_next = [&]() __attribute__((always_inline)) {
+        src_n = (uint32_t)__builtin_ctzll(todo);
         todo &= todo - 1ull;
+        const uint64_t it_ = blk * 64 + src_n;
+        const uint64_t off_ = ew_readlane64(l_off, src_n), ob_ = ew_readlane64(l_ob, src_n);
+        const uint32_t n_ = (uint32_t)__builtin_amdgcn_readlane((int)l_n, (int)src_n);
+        const uint64_t oe_ = ob_ + (uint32_t)__builtin_amdgcn_readlane((int)l_no, (int)src_n);
+        ew_load<G32, KMAX>(a, off_, n_, (it_ & 1) == 0, indels, lane, Rn);
+        if (G32 && a.read_null) {                       // the read's own null model: 252 floats, four per lane
+            const float *nt_ = a.null_tab + (size_t)a.read_null[it_ >> 1] * MG_NULL_FLOATS;
+#pragma unroll
+            for (int k = 0; k < 4; k++) Rn.ntv[k] = 4u * lane + (uint32_t)k < MG_NULL_FLOATS ? nt_[4u * lane + (uint32_t)k] : 0.0f;
+        }
+        on_frame = 0; on_stop = 0;
+        if (ob_ + lane < oe_) { on_frame = a.orfs[ob_ + lane].frame; on_stop = a.orfs[ob_ + lane].stop_position; }
+    };
+    if (have_n) fetch_next();
+    while (have_n) {
+        const uint32_t src = src_n;
+        const EwRegs<G32, KMAX> R = Rn;
+        const int o_frame = on_frame, o_stop = on_stop;
+        have_n = todo != 0;
+        if (have_n) fetch_next();
         const uint64_t it = blk * 64 + src;
         const uint64_t r = it >> 1;
         const bool fwd = (it & 1) == 0;
@@ -766,14 +841,14 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         const int isl = a.read_isl ? a.read_isl[r] : a.ignore_score_len;
         const uint32_t off_m3 = (uint32_t)(off % 3);
 
-        EwRegs<G32, KMAX> R;
-        ew_load<G32, KMAX>(a, off, n, fwd, indels, lane, R);
-        int o_frame = 0, o_stop = 0;
-        if (ob + lane < oe) { o_frame = a.orfs[ob + lane].frame; o_stop = a.orfs[ob + lane].stop_position; }
-
         // ---- sums, masks, the sorted list of the low-quality bases
         uint32_t f_low = 0;
-        ew_build<G32, KMAX>(a, r, off, n, fwd, indels, lane, R, S, srow, Mstart, Mstop, Mlow, nw - 1, msk, 3 * nw, (uint8_t *)nullptr, f_low);
+        if (G32 && a.read_null) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) s_nt[4u * lane + (uint32_t)k] = R.ntv[k];       // (s_nt has four spare floats)
+            wcs_sync();
+        }
+        ew_build<G32, KMAX, true>(a, r, off, n, fwd, indels, lane, R, S, srow, Mstart, Mstop, Mlow, nw - 1, msk, 3 * nw, (uint8_t *)nullptr, f_low, s_nt);
         uint32_t npos = 0;
         bool overflow = false;
         if (indels) {
@@ -786,14 +861,11 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 for (int e = 0; e < KMAX; e++)
                     if ((f_low >> e) & 1u) { plist[o] = (uint16_t)(R.tb + (uint32_t)e); pq[o] = (uint8_t)R.qv[e]; o++; }
                 // low-quality bases in front of every 64-step word
-                if (lane < nw) {
-                    uint32_t c = 0;
-                    for (uint32_t w = 0; w < lane && w < nw - 1; w++) c += (uint32_t)__popcll(Mlow[w]);
-                    cum[lane] = (uint16_t)c;
-                }
+                const uint32_t pw = lane < nw - 1 ? (uint32_t)__popcll(Mlow[lane]) : 0u, iw = ewc_scan_u32(pw);
+                if (lane < nw) cum[lane] = (uint16_t)(iw - pw);
             }
         }
-        for (uint32_t t = lane; t < n + 8; t += 64) orf_at[t] = 255;
+        for (uint32_t t = lane; 4u * t < n + 8u; t += 64) ((uint32_t *)orf_at)[t] = 0xffffffffu;
         if (lane == 0) *acc_mask = 0;
         wcs_sync();
 
@@ -818,6 +890,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
             if (mine) {
                 s_gi[idx] = (uint32_t)i;
                 a_cnt[idx] = 0; a_m0[idx] = 0;
+                s_xs[idx] = 0xffffu;
                 if (accepted_only && ((int)n - xs) + 12 < mgl) act = false;          // (as k_mg_err_level: cannot reach Min_Gene_Len)
                 if (xs < 0 || xs >= (int)n) act = false;
                 if (act) {
@@ -825,7 +898,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                     a_cnt[idx] = o.cnt;
                     a_m0[idx] = o.m_end << 1 | (o.trunc ? 1u : 0u);
                     if (o.acc) atomicOr(acc_mask, 1ull << idx);
-                    if (indels && a.indel_max >= 1 && o.has) orf_at[xs] = (uint8_t)idx;
+                    if (indels && a.indel_max >= 1 && o.has) { orf_at[xs] = (uint8_t)idx; s_xs[idx] = (uint16_t)xs; }
 #ifdef EWC_DEBUG
                     printf("ORF it %llu idx %u xs %d has %d cnt %u m_end %u\n", (unsigned long long)it, idx, xs, (int)o.has, o.cnt, o.m_end);
 #endif
@@ -1014,14 +1087,14 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         if (lane < nloc) {
             uint32_t g_cnt = a_cnt[lane], src_l = lane;
             const uint64_t i = s_gi[lane];
-            if (indels && a.indel_max >= 1) {
+            {
                 // ORFs that begin at the same step (Find_Orfs gives the reverse frames without a stop codon in front the same virtual
                 // stop) have the same call tree; the branches were credited to the one the step's table entry names
-                const int sp = a.orfs[i].stop_position;
-                const int xs = fwd ? (int)n - (sp - 1) : sp + 2;
-                if (xs >= 0 && xs < (int)n && orf_at[xs] != 255 && orf_at[xs] != lane) { src_l = orf_at[xs]; g_cnt = a_cnt[src_l]; }
+                const uint32_t xs = s_xs[lane];
+                if (xs != 0xffffu && orf_at[xs] != lane) { src_l = orf_at[xs]; g_cnt = a_cnt[src_l]; }
             }
-            if (!(accepted_only && g_cnt == 0)) {
+            const bool accepted = g_cnt && ((*acc_mask >> src_l) & 1ull);
+            if (!(accepted_only && !accepted)) {        // (accepted_only: a rejected ORF's record is never read again, its count stays 0)
                 gmg_mg_orf rec = a.orfs[i];
                 const uint32_t g_m0 = a_m0[lane];
                 const int m0 = (int)(g_m0 >> 1);
@@ -1030,10 +1103,11 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 rec.orf_is_truncated = (int16_t)(g_m0 & 1u);
                 rec.n_starts = g_cnt;
                 rec.first_j = 0; rec.best_score = -DBL_MAX;
-                rec.accepted = (int16_t)((g_cnt && ((*acc_mask >> src_l) & 1ull)) ? 1 : 0);
-                a.orf_cnt[i] = (accepted_only && !rec.accepted) ? 0u : g_cnt;
-                if (rec.accepted) { atomicOr(&a.acc_bits[i >> 5], 1u << (i & 31u)); kept = true; }
-                if (!(accepted_only && !rec.accepted)) { rec.start_begin = 0; a.orfs[i] = rec; }
+                rec.accepted = (int16_t)(accepted ? 1 : 0);
+                a.orf_cnt[i] = g_cnt;
+                if (accepted) { atomicOr(&a.acc_bits[i >> 5], 1u << (i & 31u)); kept = true; }
+                rec.start_begin = 0;
+                a.orfs[i] = rec;
             }
         }
         if (__ballot(kept) && lane == 0) item_flag[it] = 1;

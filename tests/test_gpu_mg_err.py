@@ -64,7 +64,7 @@ def test_error_branch_matches_reference_push_order(gpu, oracle, nc, name):
 @pytest.mark.parametrize("path", ["wave", "wave-walk", "wave-overflow", "wave-table", "tile", "tile-stage", "tile-overflow", "level", "level-q0", "flat", "level-overflow", "level-grow"])
 def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path, monkeypatch, request_finalizers):
     """path: one wave per (read, strand) with running sums and masks in its LDS (k_mg_err_wcount: the count pass without walks, breadth
-    first; k_mg_err_wave: the write pass, a stack of calls per wave; the default for -i, here for -s too; the 1300- and 2100-bp
+    first; k_mg_err_wave: the write pass, a stack of calls per wave; the default; the 1300- and 2100-bp
     reads, longer than a wave takes, go to the per-ORF kernel), the same with the stack walker as the count pass, with a stack of 5
     entries (the call repeats on the level kernels) and on a batch without the long reads (the fp32 gene rows instead of the fp64 table),
     tile by tile with the running sums in LDS, one lane per event (option mg_err_tile; the 2100-bp read, longer than a tile,
@@ -74,8 +74,8 @@ def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path
     table -- q0: the three-row table instead), the per-ORF kernel alone, the level
     kernels with call arrays too small (everything repeats on the per-ORF kernel), and the same with the arrays allowed to
     grow (the count pass repeats with larger ones)"""
-    opts = {"wave": {"mg_err_wave": 3, "mg_err_tile": 0}, "wave-walk": {"mg_err_wave": 2, "mg_err_tile": 0},
-            "wave-overflow": {"mg_err_wave": 3, "mg_err_tile": 0, "mg_err_wave_q": 5}, "wave-table": {"mg_err_wave": 3, "mg_err_tile": 0},
+    opts = {"wave": {"mg_err_wave": 1, "mg_err_tile": 0}, "wave-walk": {"mg_err_wave": 2, "mg_err_tile": 0},
+            "wave-overflow": {"mg_err_wave": 1, "mg_err_tile": 0, "mg_err_wave_q": 5}, "wave-table": {"mg_err_wave": 1, "mg_err_tile": 0},
             "tile": {"mg_err_tile": 1}, "tile-stage": {"mg_err_tile": 1, "mg_err_tile_q": -1}, "tile-overflow": {"mg_err_tile": 1, "mg_err_tile_q": 3},
             "level": {"mg_err_tile": 0, "mg_err_wave": 0}, "level-q0": {"mg_err_tile": 0, "mg_err_wave": 0, "mg_err_qonly": 0},
             "flat": {"mg_err_flat": 1}, "level-overflow": {"mg_err_tile": 0, "mg_err_wave": 0, "mg_err_calls": 7},
