@@ -8,7 +8,8 @@
 One "step" = one pass of the hot path (gmg_frame_score6, include/gmg.h) over one rank's shard of
 synthetic reads already resident in HBM: 1M x 500 bp per GPU (BASELINE.json configs[1]); with N > 1
 every rank scores its own shard (weak scaling, no collective in the data path -- reads shard
-embarrassingly).  `--scaling strong` keeps the job fixed instead: --reads reads in total, cut over
+embarrassingly).  `--batches B`: the rank's --reads reads as B batches into ONE reused table (BASELINE configs[2] at its stated
+size: --reads 12500000 --batches 13; a step = all batches, the check runs on the last one).  `--scaling strong` keeps the job fixed instead: --reads reads in total, cut over
 the ranks by gmg_shard_plan (contiguous ranges of equal base count).  Rank 0 prints ONE JSON line.
 
 `--data genome`: SURVEY.md 8(d)'s second input distribution -- the same job shape with every read cut uniformly from
@@ -213,7 +214,7 @@ def device_digest(out, total, first_read, n_reads, L):
 def extras(n_reads=1_000_000, reps=10):
     try:
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench", "bench_extras.py"), str(n_reads), str(reps)],
-                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=max(240, int(120 + 12 * reps * n_reads / 1e6)))
         j = json.loads(res.stdout.decode().strip().splitlines()[-1])
         return j
     except Exception as e:
@@ -248,6 +249,9 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=20_000, help="reads in each CPU sample (0 = no CPU legs, no check)")
     ap.add_argument("--no-cli", action="store_true", help="skip the CLI end-to-end leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the (f)-row legs (tests/bench/bench_extras.py)")
+    ap.add_argument("--batches", type=int, default=1,
+                    help="score a rank's --reads reads as this many batches (<= 1M reads each is the tested shape) into ONE reused table: "
+                         "BASELINE configs[2]'s 12.5M reads per GPU = --reads 12500000 --batches 13; a step = all batches")
     ap.add_argument("--data", choices=("synthetic", "genome"), default="synthetic",
                     help="genome: reads cut uniformly from tests/golden/data/NC_000915.fna, both strands (weak scaling only)")
     args = ap.parse_args()
@@ -282,13 +286,24 @@ def main():
     gmg.init(local_rank)                      # raises if there is no gfx950 device: no fallback
 
     L = args.length
+    n_batches = max(1, args.batches)
+    if n_batches > 1 and (args.scaling != "weak" or args.data != "synthetic"):
+        sys.exit("bench.py: --batches runs with weak scaling on the synthetic stream")
     if args.scaling == "weak":
         n, seed, first_base = args.reads, SEED + rank, 0        # every rank has its own shard of the job
+        if n_batches > 1:                                   # the LAST batch is the one kept on the host for the check; all are resident in HBM
+            per = -(-args.reads // n_batches)
+            sizes = [min(per, args.reads - b * per) for b in range(n_batches) if args.reads - b * per > 0]
+            n_batches = len(sizes)
+            n = sizes[-1]
+            first_base = sum(sizes[:-1]) * L
         if args.data == "genome":
             packed, off = gmg.synth.genome_reads(GENOME, n, L, seed)
+        elif n_batches > 1:                                 # one stream per rank, cut into the batches (the same bases as one 12.5M-read batch would hold)
+            packed, off = gmg.synth.packed_reads_range(first_base, n * L, L, seed)
         else:
             packed, off = gmg.synth.packed_reads(n, L, seed)
-        job_reads = n * world
+        job_reads = args.reads * world
     else:                                     # one job of --reads reads, cut by gmg_shard_plan (equal base counts)
         if args.data != "synthetic":
             sys.exit("bench.py: --data genome runs with weak scaling only")
@@ -312,18 +327,31 @@ def main():
     gene = gmg.Icm.open(MODEL)
     indep = gmg.Icm.indep(gc)
     reads = gmg.Reads(packed, off)
-    out = torch.empty(6 * max(total, 1), dtype=torch.float64, device="cuda")
+    batches = [reads]
+    table_bases = total
+    if n_batches > 1:                                       # the earlier batches: packed reads resident in HBM, no host copy kept
+        batches, b0 = [], 0
+        for nb in sizes[:-1]:
+            pk, of = gmg.synth.packed_reads_range(b0 * L, nb * L, L, seed)
+            batches.append(gmg.Reads(pk, of))
+            b0 += nb
+            del pk, of
+        batches.append(reads)
+        table_bases = max(sizes) * L
+    out = torch.empty(6 * max(table_bases, 1), dtype=torch.float64, device="cuda")      # ONE table, reused by every batch
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
     ev = []
 
     def step():
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(stream)
-        gmg.frame_score6(gene, indep, reads, d_out=out.data_ptr(), stream=sptr)
-        b.record(stream)
-        ev.append((a, b))
+        for bi, batch in enumerate(batches):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            gmg.frame_score6(gene, indep, batch, d_out=out.data_ptr(), stream=sptr)
+            b.record(stream)
+            if bi == 0:                                     # (the roofline's call: a full-size batch)
+                ev.append((a, b))
 
     seconds, _ = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, dist)
     per_call = sorted(a.elapsed_time(b) for a, b in ev[args.warmup:])
@@ -354,7 +382,8 @@ def main():
     ok = True
     if rank == 0:
         value = aggregate(job_reads * L, args.steps, seconds) / 1e6
-        achieved = ALGO_BYTES_PER_BASE * total / (kern_ms * 1e-3) / 1e9 if kern_ms else 0.0
+        call_bases = (sizes[0] if n_batches > 1 else n) * L        # bases of the call the events bracket
+        achieved = ALGO_BYTES_PER_BASE * call_bases / (kern_ms * 1e-3) / 1e9 if kern_ms else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and args.data == "synthetic":
@@ -363,7 +392,7 @@ def main():
                 doc = json.load(open(tpath))
                 src = os.path.join(ROOT, doc.get("source", "glimmer-mg_amd/csrc/gmg_frame6.hip"))
                 if doc.get("source_sha256") == hashlib.sha256(open(src, "rb").read()).hexdigest():
-                    traffic = doc.get("%dx%d" % (n, L))
+                    traffic = doc.get("%dx%d" % (sizes[0] if n_batches > 1 else n, L))
                 else:
                     sys.stderr.write("bench: profiles/traffic.json was measured with another gmg_frame6.hip; roofline.traffic = null "
                                      "(tools/profile_frame6.sh + tools/update_traffic.py renew it)\n")
@@ -375,11 +404,14 @@ def main():
             "ms_per_step": round(seconds / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if args.data == "synthetic" else "genome: reads cut uniformly from NC_000915.fna (1.67 Mbp), both strands",
-            "config": {"workload": "%d x %d bp %s reads %s, one 3-periodic ICM (NC_000915.icm), "
+            "config": {"workload": "%s x %d bp %s reads %s%s, one 3-periodic ICM (NC_000915.icm), "
                                    "6-frame per-position scoring, fp64 Frame_Scores"
-                                   % (args.reads, L, "synthetic" if args.data == "synthetic" else "genome-sampled (NC_000915.fna)",
-                                      "per GPU" if args.scaling == "weak" else "in total, sharded by gmg_shard_plan"),
-                       "reads_per_gpu": n, "read_len": L, "parallelism": "reads sharded, %d rank(s)" % world},
+                                   % ("{:,}".format(args.reads) if n_batches > 1 else str(args.reads), L,
+                                      "synthetic" if args.data == "synthetic" else "genome-sampled (NC_000915.fna)",
+                                      "per GPU" if args.scaling == "weak" else "in total, sharded by gmg_shard_plan",
+                                      " in %d batches of <= %s reads into one reused table" % (n_batches, "{:,}".format(max(sizes))) if n_batches > 1 else ""),
+                       "reads_per_gpu": args.reads if args.scaling == "weak" else n, "read_len": L, "batches": n_batches,
+                       "parallelism": "reads sharded, %d rank(s)" % world},
             "roofline": {"bound": "hbm", "kernel": "k_frame6t + k_frame6p (one gmg_frame_score6 call)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "kernel_ms": round(kern_ms, 4), "kernel_ms_min_max": [round(kern_min, 4), round(kern_max, 4)],
@@ -418,6 +450,9 @@ def main():
             del out                                         # (24 GB back to the device before the other paths run in their own process)
             torch.cuda.empty_cache()
             line["extras"] = extras()
+            if isinstance(line["extras"], dict) and (line["extras"].get("error") or line["extras"].get("mismatch")):
+                ok = False                                  # a wrong or crashed (f)-row leg fails the whole line
+                line["value"] = None
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:

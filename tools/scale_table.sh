@@ -11,8 +11,10 @@ export MASTER_ADDR=127.0.0.1 HSA_ENABLE_IPC_MODE_LEGACY=0
 PORT=29500
 for N in 1 2 4 8; do
   [ "$N" -gt "$MAXG" ] && break
-  for MODE in weak strong; do
+  for MODE in weak strong configs2; do
     EXTRA=""; [ "$MODE" = strong ] && EXTRA="--scaling strong --reads $((N * 1000000))"
+    # BASELINE configs[2] at its stated size: 12.5M reads per GPU as 13 batches into one reused table (5 steps: 31 Gbases per rank)
+    [ "$MODE" = configs2 ] && EXTRA="--reads 12500000 --batches 13 --steps 5 --warmup 1 --no-extras"
     if [ "$N" = 1 ]; then
       timeout -k 10 600 python3 bench.py --gpus 1 --no-cli $EXTRA > $OUT/${MODE}_$N.json 2> $OUT/${MODE}_$N.err
     else
@@ -31,16 +33,17 @@ def last_json(p):
         return json.loads([l for l in open(p).read().splitlines() if l.startswith("{")][-1])
     except Exception:
         return None
-print("| GPUs | weak Mbases/s | x | strong Mbases/s (N x 1M reads) | CLI 2 M reads, one shard per GPU: s | Mbases/s |")
-print("|---|---|---|---|---|---|")
+print("| GPUs | weak Mbases/s | x | strong Mbases/s (N x 1M reads) | configs[2]: 12.5M reads per GPU in 13 batches, Mbases/s | CLI 2 M reads, one shard per GPU: s | Mbases/s |")
+print("|---|---|---|---|---|---|---|")
 base = None
 for n in (1, 2, 4, 8):
-    w, s, c = (last_json(os.path.join(out, "%s_%d.json" % (k, n))) for k in ("weak", "strong", "cli"))
+    w, s, c, c2 = (last_json(os.path.join(out, "%s_%d.json" % (k, n))) for k in ("weak", "strong", "cli", "configs2"))
     if not w:
         continue
     base = base or w["value"]
     run = c["runs"][0] if c else {}
-    print("| %d | %.0f | %.2f | %s | %s | %s |" % (n, w["value"], w["value"] / base, "%.0f" % s["value"] if s and s.get("value") else "-",
-                                              run.get("seconds", "-"), run.get("mbases_per_s", "-")))
+    print("| %d | %.0f | %.2f | %s | %s | %s | %s |" % (n, w["value"], w["value"] / base, "%.0f" % s["value"] if s and s.get("value") else "-",
+                                                   "%.0f" % c2["value"] if c2 and c2.get("value") else "-",
+                                                   run.get("seconds", "-"), run.get("mbases_per_s", "-")))
 PY
 cat $OUT/table.md
