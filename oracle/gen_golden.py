@@ -21,6 +21,8 @@ Vectors produced by oracle/_ref/ref_dump (our driver over the reference's ICM_t)
                     copied as data and re-made here as a check; NC_000915.{step6,glimmer-mg,glimmer3.X_l}.predict: the same genome
                     through step 6's shape (-b motif -m gicm), glimmer-mg and glimmer3 -X -l
   revcodon.npz      Build_Reverse_Codon_WO_Stops (icm.cc:219-350) models + probe scores
+  find_orfs_general.npz   Find_Orfs (glimmer_base.cc:638-817) with ignore regions and on circular sequences: every Orf_t of six genome
+                    slices under six option sets (oracle/_ref/ref_orfs orfs | orfs-circular)
 """
 import hashlib
 import os
@@ -205,6 +207,39 @@ def main():
                 "the reference built here does not reproduce sample-run/glimmer3/results/NC_000915.run1.predict"
         else:
             shutil.copyfile(tag + ".predict", os.path.join(GOLD, "predict", name + ".predict"))
+    # ---- Find_Orfs in full (glimmer_base.cc:638-817): ignore regions (glimmer3 -i) and circular sequences (Wrap_Around_Back /
+    #      Wrap_Through_Front), on slices of the sample genome -- the slices are named here and cut again by the tests
+    genome = "".join(line.strip() for line in open(fna) if not line.startswith(">"))
+    fo_slices = [(400_000, 30_000), (900_000, 4_000), (100_000, 12_001), (500_000, 900), (100, 95), (1_200_000, 20_002)]
+    fo_fa = os.path.join(RB, "find_orfs_general.fa")
+    with open(fo_fa, "w") as f:
+        for k, (at, ln) in enumerate(fo_slices):
+            f.write(">s%d\n%s\n" % (k, genome[at:at + ln]))
+    fo_ign = os.path.join(RB, "find_orfs_general.ignore")
+    with open(fo_ign, "w") as f:
+        f.write("# lo hi\n1 40\n700 1300\n1200 1500\n2990 3005\n9000 8000\n11000 13000\n19990 20002 trailing words\n25000 25001\n")
+    fo_ign2 = os.path.join(RB, "find_orfs_general.ignore2")         # (with the first file the reference itself aborts on a circular sequence:
+    with open(fo_ign2, "w") as f:                                   #  Wrap_Around_Back's assert (pos > 0) behind a region that reaches the end)
+        f.write("700 1300\n2990 3005\n")
+    fo = {"slices": np.array(fo_slices, np.int64)}
+    for name, mode, opts in (("ignore", "orfs", ["-i", fo_ign]), ("ignore_X_g60", "orfs", ["-X", "-g", "60", "-i", fo_ign]),
+                             ("circular", "orfs-circular", []), ("circular_X_Z2", "orfs-circular", ["-X", "-Z", "taa,tag"]),
+                             ("circular_ignore", "orfs-circular", ["-i", fo_ign2]), ("plain_g60", "orfs", ["-g", "60"])):
+        txt = subprocess.run([os.path.join(RB, "ref_orfs"), mode, *opts, fo_fa, os.path.join(RB, "fo_tag")], check=True,
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=RB).stdout.decode()
+        rows, regions, read = [], [], -1
+        for line in txt.splitlines():
+            p_ = line.split()
+            if p_[0] == "I":
+                regions.append((int(p_[1]), int(p_[2])))
+            elif p_[0] == "R":
+                read = int(p_[1])
+            elif p_[0] == "O":
+                rows.append((read, int(p_[1]), int(p_[2]), int(p_[3]), int(p_[4])))
+        fo[name + "_orfs"] = np.array(rows, np.int32).reshape(-1, 5)          # sequence, frame, stop_position, gene_len, orf_len
+        fo[name + "_regions"] = np.array(regions, np.int32).reshape(-1, 2)
+        fo[name + "_opts"] = " ".join(o for o in opts if o not in (fo_ign, fo_ign2))
+    np.savez_compressed(os.path.join(GOLD, "find_orfs_general.npz"), **fo)
     # ---- Score_Orfs inner loop (glimmer3.cc:1275-1552): ORFs from Find_Orfs + the start lists handed to Add_Events_*
     for name, flags in (("orfs_default", []), ("orfs_X", ["-X"]), ("orfs_g90_first", ["-g", "90", "-f", "x"])):
         txt = subprocess.run([os.path.join(RB, "ref_orfs"), "dump", *flags, "-m", nc, fa, os.path.join(RB, "orfs_tag")],

@@ -770,6 +770,180 @@ int orc_find_orfs_err(const char *seq, int n, const orc_mg_params *prm, int min_
     return st.n_orfs;
 }
 
+/* ---- Find_Orfs in full: ignore regions (glimmer3 -i) and circular sequences (glimmer-mg -r) ------------------------
+ * glimmer_base.cc:638-779 with Do_Fwd_Stop_Codon :460-504, Do_Rev_Stop_Codon :506-537, Finish_Orfs :783-817,
+ * Handle_First_Forward_Stop :946-985, Handle_First_Reverse_Stop :989-1015, Handle_Last_Reverse_Stop :1019-1072,
+ * Wrap_Around_Back :2793-2850, Wrap_Through_Front :2854-2900.  ign_lo / ign_hi: the regions as Get_Ignore_Regions
+ * (:833-930) leaves them (0-based lo, hi = one past the last ignored base; sorted, overlaps merged).
+ * Returns the number of ORFs, or -1 where the reference's assert (pos > 0) in Wrap_Around_Back would fire. */
+typedef struct orc_fg {
+    orc_find_state st;
+    const char *seq;
+    int len;                                            /* Sequence_Len */
+    int circular, hit_ignore, first_base, failed;
+    const unsigned *fwd_start, *rev_start, *fwd_stop, *rev_stop;
+} orc_fg;
+
+/* Codon_t::Reverse_Shift_In (gene.cc): the new base becomes the codon's FIRST position */
+static unsigned orc_rev_shift(unsigned codon, int ch) { return (codon >> 4) | (orc_ch_mask(ch) << 8); }
+
+static void orc_wrap_through_front(orc_fg *g, int pos, int *gene_len, int *orf_len)
+{
+    unsigned codon = 0;
+    int start_at = -1, s = (pos - 1) % 3, check_len = g->len + s - pos - 4, i, j, which;
+    for (i = 0; i < check_len; i += 3) {
+        for (j = 0; j < 3; j++) {
+            s--;
+            if (s < 0) s += g->len;
+            codon = orc_rev_shift(codon, g->seq[s]);
+        }
+        if (orc_must_be(codon, g->fwd_stop, g->st.prm->n_stop_codons)) break;
+        if (orc_can_be(codon, g->fwd_start, g->st.prm->n_start_codons, &which)) start_at = i + 3;
+    }
+    *orf_len = i + 3 * ((pos - 1) / 3);
+    *gene_len = start_at == -1 ? 0 : start_at + 3 * ((pos - 1) / 3);
+}
+
+static void orc_wrap_around_back(orc_fg *g, int wfr, int pos, int *gene_len, int *orf_len)
+{
+    unsigned codon = 0;
+    int start_at = -1, orf_add = 0, frame = 0, check_len = pos - 1, i, which;
+    if (pos <= 0) { g->failed = 1; *gene_len = *orf_len = 0; return; }     /* the reference: assert (pos > 0) */
+    for (i = 0; i < check_len; i++) {
+        codon = ((codon & 0xff) << 4) | orc_ch_mask(g->seq[i]);
+        if (frame == wfr) {
+            if (orc_must_be(codon, g->rev_stop, g->st.prm->n_stop_codons)) { orf_add = i - 2; break; }
+            orf_add = i + 1;
+        }
+        if (frame == wfr && orc_can_be(codon, g->rev_start, g->st.prm->n_start_codons, &which)) start_at = i + 1;
+        frame = frame == 2 ? 0 : frame + 1;
+    }
+    *orf_len = orf_add + g->len - pos - 2;
+    *orf_len -= *orf_len % 3;
+    *gene_len = start_at == -1 ? 0 : start_at + g->len - pos - 2;
+}
+
+static void orc_fg_fwd_stop(orc_fg *g, int i, int frame)
+{
+    orc_find_state *st = &g->st;
+    int gene_len, orf_len;
+    if (st->prev_fwd_stop[frame] == 0) {
+        const int pos = i - 1, start_pos = st->first_fwd_start[frame];
+        if (g->circular && !g->hit_ignore) {            /* Handle_First_Forward_Stop with use_wraparound */
+            orc_wrap_through_front(g, pos, &gene_len, &orf_len);
+            if (gene_len == 0 && start_pos != ORC_INT_MAX) gene_len = pos - start_pos;
+        } else {
+            orf_len = pos - g->first_base;
+            orf_len -= orf_len % 3;
+            gene_len = start_pos == ORC_INT_MAX ? 0 : pos - start_pos;
+            if (st->prm->allow_truncated && gene_len < st->prm->min_gene_len) gene_len = orf_len;
+        }
+    } else {
+        gene_len = i - st->first_fwd_start[frame] - 1;
+        orf_len = i - st->prev_fwd_stop[frame] - 4;
+    }
+    orc_push_orf(st, i - 1, 1 + (frame + 1) % 3, gene_len, orf_len);
+    st->first_fwd_start[frame] = ORC_INT_MAX;
+    st->prev_fwd_stop[frame] = i - 1;
+}
+
+static void orc_fg_rev_stop(orc_fg *g, int i, int frame)
+{
+    orc_find_state *st = &g->st;
+    int gene_len, orf_len, orf_stop = 0;
+    if (st->prev_rev_stop[frame] == 0) {
+        if (g->hit_ignore || !st->prm->allow_truncated) gene_len = 0;
+        else {
+            orf_stop = (i - 1) % 3;
+            if (orf_stop > 0) orf_stop -= 3;
+            gene_len = st->last_rev_start[frame] - orf_stop;
+        }
+    } else {
+        orf_stop = st->prev_rev_stop[frame];
+        gene_len = st->last_rev_start[frame] - orf_stop;
+    }
+    orf_len = i - orf_stop - 4;
+    orc_push_orf(st, orf_stop, -1 - (frame + 1) % 3, gene_len, orf_len);
+    st->last_rev_start[frame] = 0;
+    st->prev_rev_stop[frame] = i - 1;
+}
+
+static void orc_fg_finish(orc_fg *g, int use_wraparound, int last_position)
+{
+    orc_find_state *st = &g->st;
+    int fr;
+    for (fr = 0; fr < 3; fr++) {
+        int orf_stop, orf_len, gene_len;
+        if (st->prev_rev_stop[fr] == 0) orf_stop = fr == 0 ? -1 : fr == 1 ? 0 : -2;
+        else orf_stop = st->prev_rev_stop[fr];
+        if (use_wraparound) {
+            const int wrap_fr = (3 + fr - (g->len % 3)) % 3;
+            orc_wrap_around_back(g, wrap_fr, st->prev_rev_stop[fr], &gene_len, &orf_len);
+            if (gene_len == 0 && st->last_rev_start[fr] > 0) gene_len = st->last_rev_start[fr] - st->prev_rev_stop[fr];
+        } else {
+            orf_len = last_position - orf_stop - 2;
+            orf_len -= orf_len % 3;
+            gene_len = st->last_rev_start[fr] == 0 ? 0 : st->last_rev_start[fr] - orf_stop;
+            if (st->prm->allow_truncated && gene_len < st->prm->min_gene_len) gene_len = orf_len;
+        }
+        orc_push_orf(st, orf_stop, -1 - (fr + 1) % 3, gene_len, orf_len);
+    }
+}
+
+int orc_find_orfs_general(const char *seq, int len, const orc_mg_params *prm, int min_indel_orf_len, int circular,
+                          const int *ign_lo, const int *ign_hi, int n_ignore, orc_orf *orfs, int cap)
+{
+    orc_fg g;
+    unsigned fwd_start[8], rev_start[8], fwd_stop[8], rev_stop[8], codon = 0;
+    int i, j, n = len, frame = 0, ignoring = 0, ignore_sub = 0, ignore_start, ignore_stop, which;
+    g.st.prm = prm; g.st.orfs = orfs; g.st.cap = cap; g.st.n_orfs = 0; g.st.min_indel_orf_len = min_indel_orf_len;
+    g.seq = seq; g.len = len; g.circular = circular; g.hit_ignore = 0; g.first_base = 1; g.failed = 0;
+    g.fwd_start = fwd_start; g.rev_start = rev_start; g.fwd_stop = fwd_stop; g.rev_stop = rev_stop;
+    for (i = 0; i < 3; i++) {
+        g.st.first_fwd_start[i] = ORC_INT_MAX;
+        g.st.last_rev_start[i] = g.st.prev_fwd_stop[i] = g.st.prev_rev_stop[i] = 0;
+    }
+    for (i = 0; i < prm->n_start_codons; i++) { fwd_start[i] = orc_codon_from(prm->start_codon[i]); rev_start[i] = orc_codon_revcomp(fwd_start[i]); }
+    for (i = 0; i < prm->n_stop_codons; i++) { fwd_stop[i] = orc_codon_from(prm->stop_codon[i]); rev_stop[i] = orc_codon_revcomp(fwd_stop[i]); }
+    if (len < prm->min_gene_len) return 0;
+    if (circular) n += 2;                               /* two bases of overhang: codons that span the end */
+    ignore_start = ignore_stop = ORC_INT_MAX;
+    if (n_ignore > 0) { ignore_start = ign_lo[0]; ignore_stop = ign_hi[0]; }
+    for (i = 0; i < n; i++) {
+        if (i == ignore_start) {
+            orc_fg_finish(&g, 0, i);
+            g.hit_ignore = ignoring = 1;
+        } else if (i == ignore_stop) {
+            for (j = 0; j < 3; j++) {
+                g.st.first_fwd_start[j] = ORC_INT_MAX;
+                g.st.last_rev_start[j] = g.st.prev_fwd_stop[j] = g.st.prev_rev_stop[j] = 0;
+            }
+            codon = 0;
+            g.first_base = i + 1;
+            ignoring = 0;
+            ignore_sub++;
+            if (ignore_sub >= n_ignore) ignore_start = ignore_stop = ORC_INT_MAX;
+            else { ignore_start = ign_lo[ignore_sub]; ignore_stop = ign_hi[ignore_sub]; }
+        }
+        if (!ignoring) {
+            codon = ((codon & 0xff) << 4) | orc_ch_mask(seq[i < len ? i : i - len]);
+            if (orc_can_be(codon, fwd_start, prm->n_start_codons, &which) && g.st.first_fwd_start[frame] == ORC_INT_MAX)
+                g.st.first_fwd_start[frame] = i - 1;
+            if (orc_can_be(codon, rev_start, prm->n_start_codons, &which)) g.st.last_rev_start[frame] = i - 1;
+            if (orc_must_be(codon, fwd_stop, prm->n_stop_codons)) orc_fg_fwd_stop(&g, i, frame);
+            if (orc_must_be(codon, rev_stop, prm->n_stop_codons)) orc_fg_rev_stop(&g, i, frame);
+        }
+        frame = frame == 2 ? 0 : frame + 1;
+    }
+    orc_fg_finish(&g, circular, len);
+    if (!circular && prm->allow_truncated)
+        for (; i < n + 3; i++) {
+            if (!ignoring) orc_fg_fwd_stop(&g, i, frame);
+            frame = frame == 2 ? 0 : frame + 1;
+        }
+    return g.failed ? -1 : g.st.n_orfs;
+}
+
 void orc_save_prev_stops(const char *seq, int n, const orc_mg_params *prm, int *fwd_prev, int *rev_next)
 {
     unsigned fwd_stop[8], codon = 0;                    /* one Codon_t for both loops, like the reference */

@@ -126,6 +126,11 @@ typedef struct orc_mg_params {
  * Finish_Orfs :783-817, Handle_First_Forward_Stop :946-985, Handle_First_Reverse_Stop :989-1015,
  * Handle_Last_Reverse_Stop :1019-1072.  Returns the number of ORFs (only the first cap are written). */
 int orc_find_orfs(const char *seq, int n, const orc_mg_params *prm, orc_orf *orfs, int cap);
+/* Find_Orfs in full: ignore regions (Ignore_Region as Get_Ignore_Regions leaves it, glimmer_base.cc:833-930) and circular sequences
+ * (Wrap_Around_Back :2793-2850, Wrap_Through_Front :2854-2900); min_indel_orf_len < 0: Allow_Indels = Allow_Subs = false.
+ * Returns the number of ORFs, -1 where the reference's assert in Wrap_Around_Back would fire. */
+int orc_find_orfs_general(const char *seq, int len, const orc_mg_params *prm, int min_indel_orf_len, int circular,
+                          const int *ign_lo, const int *ign_hi, int n_ignore, orc_orf *orfs, int cap);
 /* Save_Prev_Stops (src/Glimmer/glimmer-mg.cc:675-729): fwd_prev[n], rev_next[n] */
 void orc_save_prev_stops(const char *seq, int n, const orc_mg_params *prm, int *fwd_prev, int *rev_next);
 typedef struct orc_mg_out { int lo, hi, first_j, accepted, orf_is_truncated; double best_score; } orc_mg_out;

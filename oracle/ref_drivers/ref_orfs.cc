@@ -11,6 +11,9 @@
 //        O <frame> <stop_position> <orf_len>                 every ORF Find_Orfs produced, in order
 //        G <orf index> <gene_score %.17g> <gene_len> <n_starts>   every ORF Score_Orfs accepted
 //        S <j> <pos> <score %a> <which> <truncated> <first>  its start list as handed to Add_Events_*
+//   ref_orfs orfs | orfs-circular  <glimmer3 options, e.g. -i regions.txt> <fasta> <tag>
+//        I <lo> <hi> per ignore region as Get_Ignore_Regions leaves them; R <read index> <n_orfs>, then  O <frame> <stop_position> <gene_len> <orf_len>  for every ORF of Find_Orfs with the ignore
+//        regions of -i and (orfs-circular) Genome_Is_Circular set
 // (The drop-in driver that runs these loops on the GPU is product code: integration/glimmer3_gpu.cc.)
 
 #define main glimmer3_reference_main
@@ -81,6 +84,26 @@ int main(int argc, char **argv)
         vector<Orf_t> orf_list;
         vector<Gene_t> gene_list;
 
+        if (mode == "orfs" || mode == "orfs-circular") {
+            // Find_Orfs alone (glimmer_base.cc:638-817), with the ignore regions of -i (Get_Ignore_Regions, glimmer3.cc:179-180) and, for
+            // "orfs-circular", Genome_Is_Circular (glimmer-mg's -r; this glimmer3 has no option for it): every ORF with all four fields
+            if (Ignore_File_Name != NULL) Get_Ignore_Regions();
+            Genome_Is_Circular = mode == "orfs-circular";
+            for (size_t k = 0; k < Ignore_Region.size(); k++) printf("I %d %d\n", Ignore_Region[k].lo, Ignore_Region[k].hi);
+            FILE *fp = File_Open(Sequence_File_Name, "r", __FILE__, __LINE__);
+            Read_Sequences(fp, seq_list, hdr_list, Sequence_Ct);
+            fclose(fp);
+            for (int i = 0; i < Sequence_Ct; i++) {
+                load_sequence(seq_list, hdr_list, i);
+                Find_Orfs(orf_list);
+                printf("R %d %d\n", i, (int)orf_list.size());
+                for (size_t o = 0; o < orf_list.size(); o++)
+                    printf("O %d %d %d %d\n", orf_list[o].Get_Frame(), orf_list[o].Get_Stop_Position(), orf_list[o].Get_Gene_Len(),
+                           orf_list[o].Get_Orf_Len());
+                orf_list.clear();
+            }
+            return 0;
+        }
         if (mode == "dump") {
             setup_models();
             FILE *fp = File_Open(Sequence_File_Name, "r", __FILE__, __LINE__);

@@ -277,6 +277,23 @@ class Oracle:
         assert n <= cap
         return np.array([(o.frame, o.stop_position, o.gene_len, o.orf_len) for o in buf[:n]], np.int32).reshape(-1, 4)
 
+    def find_orfs_general(self, seq, prm, circular=False, regions=(), min_indel_orf_len=-1):
+        """Find_Orfs with ignore regions [(lo, hi)] (as Get_Ignore_Regions leaves them) and on a circular sequence
+        -> int32 [n, 4]: frame, stop_position, gene_len, orf_len; None where the reference's assert would fire"""
+        s = seq.encode() if isinstance(seq, str) else seq
+        cap = 2 * len(s) + 16
+        buf = (Orf * cap)()
+        lo = (C.c_int * max(len(regions), 1))(*[int(r[0]) for r in regions])
+        hi = (C.c_int * max(len(regions), 1))(*[int(r[1]) for r in regions])
+        self.L.orc_find_orfs_general.argtypes = [C.c_char_p, C.c_int, C.POINTER(MgParams), C.c_int, C.c_int, C.POINTER(C.c_int),
+                                                 C.POINTER(C.c_int), C.c_int, C.POINTER(Orf), C.c_int]
+        self.L.orc_find_orfs_general.restype = C.c_int
+        n = self.L.orc_find_orfs_general(s, len(s), C.byref(prm), int(min_indel_orf_len), int(circular), lo, hi, len(regions), buf, cap)
+        if n < 0:
+            return None
+        assert n <= cap
+        return np.array([(o.frame, o.stop_position, o.gene_len, o.orf_len) for o in buf[:n]], np.int32).reshape(-1, 4)
+
     def save_prev_stops(self, seq, prm):
         s = seq.encode() if isinstance(seq, str) else seq
         fwd, rev = np.zeros(max(len(s), 1), np.int32), np.zeros(max(len(s), 1), np.int32)

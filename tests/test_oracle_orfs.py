@@ -45,3 +45,40 @@ def test_score_orfs_matches_reference_start_lists(oracle, seqs_fa, name):
         else:
             assert n < 0 or not out.is_tentative_gene
     assert n_checked == len(g["gene_orf"]) > 200
+
+
+# ---- Find_Orfs in full: ignore regions and circular sequences (glimmer_base.cc:638-817, 2793-2900) -----------------------
+FIND_ORFS_GENERAL = {                                   # golden name -> (mg_params keywords, circular); glimmer3 defaults: -g 75, no -X
+    "ignore": (dict(min_gene_len=75, allow_truncated=False), False),
+    "ignore_X_g60": (dict(min_gene_len=60, allow_truncated=True), False),
+    "circular": (dict(min_gene_len=75, allow_truncated=False), True),
+    "circular_X_Z2": (dict(min_gene_len=75, allow_truncated=True, stop_codons=("taa", "tag")), True),
+    "circular_ignore": (dict(min_gene_len=75, allow_truncated=False), True),
+    "plain_g60": (dict(min_gene_len=60, allow_truncated=False), False),
+}
+
+
+def genome_slices(oracle):
+    """the slices the goldens were made on, as the callers hand them to Find_Orfs: tolower (Filter ()) (one of them holds a 'k')"""
+    g = np.load(os.path.join(GOLD, "find_orfs_general.npz"))
+    genome = "".join(line.strip() for line in open(os.path.join(DATA, "NC_000915.fna")) if not line.startswith(">"))
+    return g, [oracle.filter_lower(genome[int(a):int(a) + int(n)]).decode() for a, n in g["slices"]]
+
+
+@pytest.mark.parametrize("name", sorted(FIND_ORFS_GENERAL))
+def test_find_orfs_with_ignore_regions_and_circular_sequences(oracle, name):
+    """every Orf_t the reference's Find_Orfs makes on six genome slices (30 kb .. 95 bases), with the ignore regions of -i (regions at the
+    very start, overlapping, swapped, reaching past a sequence's end) and with Genome_Is_Circular: oracle/_ref/ref_orfs orfs[-circular]"""
+    g, slices = genome_slices(oracle)
+    kw, circular = FIND_ORFS_GENERAL[name]
+    prm = oracle.mg_params(**kw)
+    regions = [tuple(int(x) for x in r) for r in g[name + "_regions"]]
+    want = g[name + "_orfs"]
+    for k, s in enumerate(slices):
+        got = oracle.find_orfs_general(s, prm, circular=circular, regions=regions)
+        assert got is not None
+        assert np.array_equal(got, want[want[:, 0] == k][:, 1:]), (name, k)
+    assert len(want) > 400
+    if not circular and not regions:                    # the plain case is the old entry point's too
+        for k, s in enumerate(slices):
+            assert np.array_equal(oracle.find_orfs(s, prm), want[want[:, 0] == k][:, 1:])
