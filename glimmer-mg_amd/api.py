@@ -473,13 +473,20 @@ MG_ORF_DTYPE = np.dtype([("read", "<u4"), ("frame", "<i4"), ("stop_position", "<
 
 
 def find_orfs(reads, min_gene_len=75, allow_truncated=False, start_codons=("atg", "gtg", "ttg"),
-              stop_codons=("taa", "tag", "tga")):
-    """gmg_find_orfs: Find_Orfs for every read -> (orfs[MG_ORF_DTYPE], read_orf_off[uint64 n_reads+1])"""
+              stop_codons=("taa", "tag", "tga"), circular=False, ignore_regions=()):
+    """gmg_find_orfs: Find_Orfs for every read -> (orfs[MG_ORF_DTYPE], read_orf_off[uint64 n_reads+1]).
+    circular: Genome_Is_Circular; ignore_regions: [(lo, hi)] as Get_Ignore_Regions leaves them (0-based lo, hi one past the end)"""
     prm = capi.MgParams(min_gene_len, int(allow_truncated), 2**31 - 1, len(start_codons), len(stop_codons), 0, 0.0)
     for i, c in enumerate(start_codons):
         prm.start_codon[i].value = c.encode()
     for i, c in enumerate(stop_codons):
         prm.stop_codon[i].value = c.encode()
+    prm.circular = int(bool(circular))
+    lo = np.ascontiguousarray([r[0] for r in ignore_regions], np.int32)
+    hi = np.ascontiguousarray([r[1] for r in ignore_regions], np.int32)
+    prm.n_ignore_regions = len(lo)
+    if len(lo):
+        prm.ignore_lo, prm.ignore_hi = lo.ctypes.data, hi.ctypes.data
     res = C.c_void_p()
     _ck(capi.lib().gmg_find_orfs(reads.h, C.byref(prm), C.byref(res), None))
     try:

@@ -33,9 +33,11 @@ class MgParams(C.Structure):
                 ("stop_codon", (C.c_char * 4) * 8),
                 # the error branch (GMG_MG_ALLOW_INDELS / GMG_MG_ALLOW_SUBS)
                 ("min_indel_orf_len", C.c_int32), ("indel_quality_threshold", C.c_int32), ("indel_max", C.c_int32),
-                ("reserved", C.c_int32), ("indel_suffix_score_threshold", C.c_double), ("quality", C.c_void_p),
+                ("circular", C.c_int32), ("indel_suffix_score_threshold", C.c_double), ("quality", C.c_void_p),
                 # classification mode: per-read null model / Ignore_Score_Len
-                ("nulls", C.c_void_p), ("read_null", C.c_void_p), ("read_ignore_score_len", C.c_void_p)]
+                ("nulls", C.c_void_p), ("read_null", C.c_void_p), ("read_ignore_score_len", C.c_void_p),
+                # gmg_find_orfs only: ignore regions (glimmer3 -i)
+                ("n_ignore_regions", C.c_int32), ("reserved2", C.c_int32), ("ignore_lo", C.c_void_p), ("ignore_hi", C.c_void_p)]
 
 
 PROTOTYPES = {

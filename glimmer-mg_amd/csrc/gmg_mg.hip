@@ -324,6 +324,191 @@ __global__ __launch_bounds__(256) void k_mg_find_orfs(MgArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_find_orfs_general: Find_Orfs in full (glimmer_base.cc:638-817) -- ignore regions (glimmer3 -i: the scan stops at a region,
+// closes the reverse ORFs and starts anew behind it, :689-731) and circular sequences (glimmer-mg -r: two bases of overhang, the
+// first forward stop of a frame looks back through the sequence's end, Wrap_Through_Front :2854-2900, the last reverse ORFs look
+// on through its front, Wrap_Around_Back :2793-2850).  One lane per sequence, the reference's own order of steps: these are
+// genome-scale inputs of a few sequences, nothing here is hot.  Records carry the Orf_t fields (lo / hi = 0: the start scan of
+// glimmer-mg's front half does not take such ORFs).  fail: set where the reference's assert (pos > 0) in Wrap_Around_Back fires.
+// ---------------------------------------------------------------------------------------------------
+struct FgClass { int first_fwd_start, last_rev_start, prev_fwd_stop, prev_rev_stop; };
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_find_orfs_general(MgArgs a, const int circular, const int n_ign, const int32_t *ign_lo, const int32_t *ign_hi,
+                                                          uint32_t *fail)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t off = a.read_off[r];
+        const int L = (int)(a.read_off[r + 1] - off);
+        const int mgl = a.min_gene_len;
+        const bool trunc = a.allow_truncated != 0;
+        uint32_t cnt = 0;
+        gmg_mg_orf *out = WRITE ? a.orfs + a.read_orf_off[r] : nullptr;
+        auto code = [&](int i) __attribute__((always_inline)) -> uint32_t {
+            const uint64_t g = off + (uint64_t)(i < L ? i : i - L);
+            return (a.packed[g >> 4] >> (2u * (unsigned)(g & 15))) & 3u;
+        };
+        auto emit = [&](int stop_position, int frame, int gene_len, int orf_len) __attribute__((always_inline)) {
+            if (gene_len >= mgl || (a.err_mode && orf_len >= a.min_indel_orf_len)) {
+                if (WRITE) {
+                    gmg_mg_orf o;
+                    o.read = (uint32_t)r; o.frame = frame; o.stop_position = stop_position;
+                    o.orf_len = orf_len; o.gene_len = gene_len; o.lo = 0; o.hi = 0;
+                    o.first_j = 0; o.start_begin = 0; o.n_starts = 0; o.accepted = 0; o.orf_is_truncated = 0;
+                    o.reserved = 0; o.best_score = -DBL_MAX;
+                    out[cnt] = o;
+                }
+                cnt++;
+            }
+        };
+        if (L >= mgl) {
+            const int n = L + (circular ? 2 : 0);
+            bool hit_ignore = false, ignoring = false;
+            int first_base = 1, ignore_sub = 0;
+            int ignore_start = n_ign > 0 ? ign_lo[0] : INT_MAX, ignore_stop = n_ign > 0 ? ign_hi[0] : INT_MAX;
+            FgClass cs[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { cs[c].first_fwd_start = INT_MAX; cs[c].last_rev_start = cs[c].prev_fwd_stop = cs[c].prev_rev_stop = 0; }
+            // Wrap_Through_Front: the forward ORF whose stop codon begins at pos (1-based) looked at backwards through the sequence's end
+            auto wrap_front = [&](int pos, int &gene_len, int &orf_len) {
+                int start_at = -1, s_ = (pos - 1) % 3, i;
+                const int check_len = L + s_ - pos - 4;
+                uint32_t idx6 = 0;
+                for (i = 0; i < check_len; i += 3) {
+                    for (int j = 0; j < 3; j++) {
+                        s_--;
+                        if (s_ < 0) s_ += L;
+                        idx6 = (idx6 >> 2) | code(s_) << 4;          // Reverse_Shift_In: the new base becomes the codon's first
+                    }
+                    if ((a.fwd_stop >> idx6) & 1ull) break;
+                    if ((a.fwd_start >> idx6) & 1ull) start_at = i + 3;
+                }
+                orf_len = i + 3 * ((pos - 1) / 3);
+                gene_len = start_at == -1 ? 0 : start_at + 3 * ((pos - 1) / 3);
+            };
+            // Wrap_Around_Back: the reverse ORF behind the stop codon at pos goes on through the sequence's front, frame wfr there
+            auto wrap_back = [&](int wfr, int pos, int &gene_len, int &orf_len) {
+                int start_at = -1, orf_add = 0, frame = 0;
+                if (pos <= 0) { atomicOr(fail, 1u); gene_len = orf_len = 0; return; }
+                uint32_t idx6 = 0;
+                for (int i = 0; i < pos - 1; i++) {
+                    idx6 = ((idx6 << 2) | code(i)) & 63u;
+                    const bool full = i >= 2;
+                    if (frame == wfr) {
+                        if (full && ((a.rev_stop >> idx6) & 1ull)) { orf_add = i - 2; break; }
+                        orf_add = i + 1;
+                    }
+                    if (frame == wfr && full && ((a.rev_start >> idx6) & 1ull)) start_at = i + 1;
+                    frame = frame == 2 ? 0 : frame + 1;
+                }
+                orf_len = orf_add + L - pos - 2;
+                orf_len -= orf_len % 3;
+                gene_len = start_at == -1 ? 0 : start_at + L - pos - 2;
+            };
+            auto fwd_stop = [&](int i, FgClass &S, int cls) {
+                int gene_len, orf_len;
+                if (S.prev_fwd_stop == 0) {             // Handle_First_Forward_Stop (:946-985)
+                    const int pos = i - 1;
+                    if (circular && !hit_ignore) {
+                        wrap_front(pos, gene_len, orf_len);
+                        if (gene_len == 0 && S.first_fwd_start != INT_MAX) gene_len = pos - S.first_fwd_start;
+                    } else {
+                        orf_len = pos - first_base;
+                        orf_len -= orf_len % 3;
+                        gene_len = S.first_fwd_start == INT_MAX ? 0 : pos - S.first_fwd_start;
+                        if (trunc && gene_len < mgl) gene_len = orf_len;
+                    }
+                } else {
+                    gene_len = i - S.first_fwd_start - 1;
+                    orf_len = i - S.prev_fwd_stop - 4;
+                }
+                emit(i - 1, 1 + (cls + 1) % 3, gene_len, orf_len);
+                S.first_fwd_start = INT_MAX;
+                S.prev_fwd_stop = i - 1;
+            };
+            auto rev_stop = [&](int i, FgClass &S, int cls) {
+                int gene_len, orf_stop = 0;
+                if (S.prev_rev_stop == 0) {             // Handle_First_Reverse_Stop (:989-1015)
+                    if (hit_ignore || !trunc) gene_len = 0;
+                    else {
+                        orf_stop = (i - 1) % 3;
+                        if (orf_stop > 0) orf_stop -= 3;
+                        gene_len = S.last_rev_start - orf_stop;
+                    }
+                } else {
+                    orf_stop = S.prev_rev_stop;
+                    gene_len = S.last_rev_start - orf_stop;
+                }
+                emit(orf_stop, -1 - (cls + 1) % 3, gene_len, i - orf_stop - 4);
+                S.last_rev_start = 0;
+                S.prev_rev_stop = i - 1;
+            };
+            auto finish = [&](bool use_wrap, int last_position) {       // Finish_Orfs (:783-817) + Handle_Last_Reverse_Stop (:1019-1072)
+#pragma unroll
+                for (int fr = 0; fr < 3; fr++) {
+                    const FgClass &S = cs[fr];
+                    const int orf_stop = S.prev_rev_stop == 0 ? (fr == 0 ? -1 : fr == 1 ? 0 : -2) : S.prev_rev_stop;
+                    int gene_len, orf_len;
+                    if (use_wrap) {
+                        wrap_back((3 + fr - (L % 3)) % 3, S.prev_rev_stop, gene_len, orf_len);
+                        if (gene_len == 0 && S.last_rev_start > 0) gene_len = S.last_rev_start - S.prev_rev_stop;
+                    } else {
+                        orf_len = last_position - orf_stop - 2;
+                        orf_len -= orf_len % 3;
+                        gene_len = S.last_rev_start == 0 ? 0 : S.last_rev_start - orf_stop;
+                        if (trunc && gene_len < mgl) gene_len = orf_len;
+                    }
+                    emit(orf_stop, -1 - (fr + 1) % 3, gene_len, orf_len);
+                }
+            };
+            uint32_t idx6 = 0;
+            int fill = 0;                               // bases in the codon register (it is cleared behind an ignore region)
+            for (int i0 = 0; i0 < n; i0 += 3) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const int i = i0 + c;
+                    if (i >= n) continue;
+                    if (i == ignore_start) {
+                        finish(false, i);
+                        hit_ignore = ignoring = true;
+                    } else if (i == ignore_stop) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) { cs[k].first_fwd_start = INT_MAX; cs[k].last_rev_start = cs[k].prev_fwd_stop = cs[k].prev_rev_stop = 0; }
+                        idx6 = 0; fill = 0;
+                        first_base = i + 1;
+                        ignoring = false;
+                        ignore_sub++;
+                        if (ignore_sub >= n_ign) ignore_start = ignore_stop = INT_MAX;
+                        else { ignore_start = ign_lo[ignore_sub]; ignore_stop = ign_hi[ignore_sub]; }
+                    }
+                    if (!ignoring) {
+                        idx6 = ((idx6 << 2) | code(i)) & 63u;
+                        if (fill < 3) fill++;
+                        if (fill == 3) {                // (a Codon_t with an empty position matches nothing)
+                            const uint64_t bit = 1ull << idx6;
+                            if ((a.fwd_start & bit) && cs[c].first_fwd_start == INT_MAX) cs[c].first_fwd_start = i - 1;
+                            if (a.rev_start & bit) cs[c].last_rev_start = i - 1;
+                            if (a.fwd_stop & bit) fwd_stop(i, cs[c], c);
+                            if (a.rev_stop & bit) rev_stop(i, cs[c], c);
+                        }
+                    }
+                }
+            }
+            finish(circular != 0, L);
+            if (!circular && trunc)                     // :765-776: 3 bp past the end count as forward stops
+                for (int i = n; i < n + 3; i++) {
+                    if (ignoring) continue;
+                    const int c = i % 3;
+                    if (c == 0) fwd_stop(i, cs[0], 0);
+                    else if (c == 1) fwd_stop(i, cs[1], 1);
+                    else fwd_stop(i, cs[2], 2);
+                }
+        }
+        if (!WRITE) a.read_cnt[r] = cnt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k_mg_find_orfs_ev: the write pass of Find_Orfs in two phases per 64 positions.  In k_mg_find_orfs a wave pays at every position
 // for the stop-codon code of whichever lane met one (88 vector instructions per position and wave; one codon in five is a start or
 // a stop codon of either strand).  Here phase A only LOOKS -- four set bits per codon from a 64-entry table, the codons that
@@ -2874,6 +3059,16 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: cannot use indels and substitutions simultaneously");
     if (err_mode && (prm->indel_max < 0 || prm->indel_max > 2 || prm->indel_quality_threshold < 0 || prm->indel_quality_threshold > 254))
         return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: need indel_max in 0..2 and indel_quality_threshold in 0..254");
+    // Find_Orfs' other two modes (ignore regions, circular sequences): gmg_find_orfs alone -- the start scan of the front half
+    // indexes Frame_Scores inside one linear read
+    const bool general = prm->circular != 0 || prm->n_ignore_regions != 0;
+    if (general && !find_only)
+        return gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: circular sequences / ignore regions are taken by gmg_find_orfs only");
+    if (prm->n_ignore_regions < 0 || (prm->n_ignore_regions > 0 && (!prm->ignore_lo || !prm->ignore_hi)))
+        return gmg_set_error(GMG_EINVAL, "gmg_find_orfs: n_ignore_regions without ignore_lo / ignore_hi");
+    for (int k = 0; k < prm->n_ignore_regions; k++)     // as Get_Ignore_Regions leaves them: lo < hi, sorted, disjoint
+        if (prm->ignore_lo[k] < 0 || prm->ignore_lo[k] >= prm->ignore_hi[k] || (k > 0 && prm->ignore_lo[k] < prm->ignore_hi[k - 1]))
+            return gmg_set_error(GMG_EINVAL, "gmg_find_orfs: ignore region %d is not sorted / disjoint / lo < hi", k);
     hipStream_t s = (hipStream_t)stream;
 
     MgArgs a;
@@ -3312,7 +3507,18 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     MG_TRY(hipMemsetAsync(d_read_cnt, 0, (nr + 1) * 4, s2));
     MG_TRY(gmg_pool_alloc((void **)&res->d_read_orf_off, (nr + 1) * 8));
     a.read_cnt = d_read_cnt;
-    if (nr) hipLaunchKernelGGL(k_mg_find_orfs<false>, dim3(grid_for(nr)), dim3(256), 0, s2, a);
+    int32_t *d_ign = nullptr;                           // general form: the regions' lo values, then their hi values; [2 n]: the failure flag
+    const int n_ign = general ? prm->n_ignore_regions : 0;
+    if (general) {
+        MG_TRY(gmg_pool_alloc((void **)&d_ign, (size_t)(2 * n_ign + 1) * 4));
+        if (n_ign) {
+            MG_TRY(hipMemcpyAsync(d_ign, prm->ignore_lo, (size_t)n_ign * 4, hipMemcpyHostToDevice, s2));
+            MG_TRY(hipMemcpyAsync(d_ign + n_ign, prm->ignore_hi, (size_t)n_ign * 4, hipMemcpyHostToDevice, s2));
+        }
+        MG_TRY(hipMemsetAsync(d_ign + 2 * n_ign, 0, 4, s2));
+        if (nr) hipLaunchKernelGGL(k_find_orfs_general<false>, dim3(grid_for(nr)), dim3(64), 0, s2, a, prm->circular ? 1 : 0, n_ign, d_ign, d_ign + n_ign,
+                                   (uint32_t *)(d_ign + 2 * n_ign));
+    } else if (nr) hipLaunchKernelGGL(k_mg_find_orfs<false>, dim3(grid_for(nr)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
     rc = mg_scan(d_read_cnt, res->d_read_orf_off, nr, &res->n_orfs, s2);
     if (rc) return fail(rc);
@@ -3335,7 +3541,18 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
             a.orf_cnt = d_orf_cnt;
         }
     }
-    if (nr && gmg_opt(GMG_OPT_MG_ORFS_EVENTS)) {
+    if (general) {
+        if (nr) hipLaunchKernelGGL(k_find_orfs_general<true>, dim3(grid_for(nr)), dim3(64), 0, s2, a, prm->circular ? 1 : 0, n_ign, d_ign, d_ign + n_ign,
+                                   (uint32_t *)(d_ign + 2 * n_ign));
+        uint32_t failed = 0;
+        MG_TRY(hipMemcpyAsync(&failed, d_ign + 2 * n_ign, 4, hipMemcpyDeviceToHost, s2));
+        MG_TRY(hipStreamSynchronize(s2));
+        gmg_pool_release(d_ign);
+        d_ign = nullptr;
+        if (failed)     // Wrap_Around_Back: assert (pos > 0) -- a circular sequence with a reverse frame that has no stop codon (behind the last ignore region)
+            return fail(gmg_set_error(GMG_EINVAL, "gmg_find_orfs: a circular sequence has a reverse reading frame without a stop codon (the reference aborts: "
+                                                  "Wrap_Around_Back, glimmer_base.cc:2793)"));
+    } else if (nr && gmg_opt(GMG_OPT_MG_ORFS_EVENTS)) {
         const uint64_t blocks = (nr + 127) / 128;
         hipLaunchKernelGGL(k_mg_find_orfs_ev, dim3((unsigned)(blocks < 256 * 64 ? blocks : 256 * 64)), dim3(128), 0, s2, a);
     } else if (nr) hipLaunchKernelGGL(k_mg_find_orfs<true>, dim3(grid_for(nr)), dim3(256), 0, s2, a);

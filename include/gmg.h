@@ -343,7 +343,8 @@ typedef struct gmg_mg_params {
     int32_t min_indel_orf_len;   /* Min_Indel_ORF_Len (glimmer_base.cc:40: 15)                    */
     int32_t indel_quality_threshold;     /* Indel_Quality_Threshold (glimmer-mg.cc:136: 18)       */
     int32_t indel_max;           /* Indel_Max (glimmer-mg.cc:138: 2); 0..2                        */
-    int32_t reserved;
+    int32_t circular;            /* gmg_find_orfs only: Genome_Is_Circular (glimmer-mg -r): every sequence of the batch is circular
+                                    (glimmer_base.cc:680-688, Wrap_Around_Back :2793-2850, Wrap_Through_Front :2854-2900)   */
     double indel_suffix_score_threshold; /* Indel_Suffix_Score_Threshold (glimmer-mg.cc:134: -12) */
     const uint8_t *quality;      /* HOST, one Phred value per base, reads back to back (total_bases): the user's quality
                                     file (-q), Clean_Quality_454 (glimmer-mg.cc:519-546) is applied on the device;
@@ -356,6 +357,11 @@ typedef struct gmg_mg_params {
     const struct gmg_null_set *nulls;
     const uint32_t *read_null;           /* HOST [n_reads] */
     const int32_t *read_ignore_score_len;/* HOST [n_reads], or NULL with nulls set: ignore_score_len for every read */
+    /* gmg_find_orfs only: glimmer3 -i, Ignore_Region as Get_Ignore_Regions leaves it (glimmer_base.cc:833-930): 0-based lo, hi one past
+     * the last ignored base, sorted, overlaps merged; the same regions apply to EVERY sequence of the batch (:844-847) */
+    int32_t n_ignore_regions;
+    int32_t reserved2;
+    const int32_t *ignore_lo, *ignore_hi;        /* HOST [n_ignore_regions] */
 } gmg_mg_params;
 
 /* the Error_t list (src/Common/gene.hh:138-146) of one start: type 0 insertion, 1 deletion, 2 substitution */
@@ -406,10 +412,11 @@ typedef struct gmg_mg_group {
 } gmg_mg_group;
 int gmg_mg_score_groups(const gmg_mg_group *groups, int n_groups, const gmg_model *null_model, const gmg_reads *reads,
                         const gmg_mg_params *params, gmg_mg_result **out, void *stream);
-/* Find_Orfs alone (src/Glimmer/glimmer_base.cc:638-779; linear sequences, no ignore regions) for every read of the
- * batch -- the ORF list glimmer3's Score_Orfs / gmg_score_orfs and glimmer-mg's Score_Orfs_Errors start from.  Uses
- * min_gene_len, allow_truncated and the codon lists of `params`; the result holds the Orf_t fields (and lo / hi), no
- * start lists (n_starts = 0). */
+/* Find_Orfs alone (src/Glimmer/glimmer_base.cc:638-817) for every read of the batch -- the ORF list glimmer3's Score_Orfs /
+ * gmg_score_orfs and glimmer-mg's Score_Orfs_Errors start from.  Uses min_gene_len, allow_truncated and the codon lists of
+ * `params`; the result holds the Orf_t fields (and lo / hi), no start lists (n_starts = 0).  With params->n_ignore_regions
+ * (glimmer3 -i) or params->circular (glimmer-mg -r) the scan follows the reference's other two modes (lo = hi = 0 then);
+ * GMG_EINVAL where the reference itself aborts (a circular sequence with a reverse frame that holds no stop codon). */
 int gmg_find_orfs(const gmg_reads *reads, const gmg_mg_params *params, gmg_mg_result **out, void *stream);
 /* Sizes of the result: ORFs of all reads (Find_Orfs order, read by read) and start entries. */
 int gmg_mg_result_info(const gmg_mg_result *r, uint64_t *n_orfs, uint64_t *n_starts);

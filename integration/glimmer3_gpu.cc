@@ -244,19 +244,7 @@ int main(int argc, char **argv)
         }
         vector<vector<Orf_t> > all_orfs(Sequence_Ct);
         vector<gmg_orf> orfs;
-        if (Ignore_File_Name != NULL) {
-            // -i: the ORFs of a sequence depend on the ignore regions (glimmer_base.cc:689-731: the scan starts anew behind every
-            // region).  That list is the reference's own Find_Orfs, run here on the filtered bases (a linear pass over a genome: the
-            // ignore coordinates are those of ONE sequence); the scoring of all ORFs stays ONE device call below.
-            for (int i = 0; i < Sequence_Ct; i++) {
-                load_sequence(seq_list, hdr_list, i);
-                Find_Orfs(all_orfs[i]);
-                for (size_t o = 0; o < all_orfs[i].size(); o++) {
-                    gmg_orf g = {(uint32_t)i, all_orfs[i][o].Get_Frame(), all_orfs[i][o].Get_Stop_Position(), all_orfs[i][o].Get_Orf_Len()};
-                    orfs.push_back(g);
-                }
-            }
-        } else {
+        {
         gmg_mg_params fprm;
         memset(&fprm, 0, sizeof fprm);
         fprm.min_gene_len = Min_Gene_Len;
@@ -265,6 +253,13 @@ int main(int argc, char **argv)
         fprm.n_stop_codons = Stop_Codon.size();
         for (size_t c = 0; c < Start_Codon.size() && c < 8; c++) memcpy(fprm.start_codon[c], Start_Codon[c], 3);
         for (size_t c = 0; c < Stop_Codon.size() && c < 8; c++) memcpy(fprm.stop_codon[c], Stop_Codon[c], 3);
+        // -i: the ignore regions (Get_Ignore_Regions has sorted and merged them; the same regions screen every sequence,
+        // glimmer_base.cc:844-847) go with the call: Find_Orfs' scan stops at a region and starts anew behind it on the device too
+        vector<int32_t> ign_lo, ign_hi;
+        for (size_t k = 0; k < Ignore_Region.size(); k++) { ign_lo.push_back(Ignore_Region[k].lo); ign_hi.push_back(Ignore_Region[k].hi); }
+        fprm.n_ignore_regions = (int32_t)ign_lo.size();
+        fprm.ignore_lo = ign_lo.empty() ? NULL : ign_lo.data();
+        fprm.ignore_hi = ign_hi.empty() ? NULL : ign_hi.data();
         gmg_mg_result *found = NULL;
         if (gmg_find_orfs(reads, &fprm, &found, NULL) != GMG_OK) { fprintf(stderr, "%s\n", gmg_last_error()); return 1; }
         uint64_t n_found = 0;

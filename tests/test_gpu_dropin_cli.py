@@ -87,8 +87,8 @@ def _write_fasta(path, records):
 @pytest.mark.parametrize("mode", ["separate_input", "orflist", "orflist_wrap", "ignore_regions", "ignore_regions_truncated", "mg_circular"])
 def test_modes_outside_the_default_loop(gpu, tmp_path, mode):
     """glimmer3 -M (every input sequence is one gene, Score_Separate_Input) and -L (ORFs from a coordinate file, Score_Orflist) are
-    batched by glimmer3_gpu: one gmg_score_string call per model for all entries.  -i (ignore regions): the ORF lists are the
-    reference's own Find_Orfs on the host, all ORFs scored by ONE gmg_score_orfs call.  Those three must work WITHOUT the drop-in
+    batched by glimmer3_gpu: one gmg_score_string call per model for all entries.  -i (ignore regions): Find_Orfs with the regions on
+    the device too (gmg_find_orfs, gmg_mg_params.n_ignore_regions), all ORFs scored by ONE gmg_score_orfs call.  Those three must work WITHOUT the drop-in
     binary (the driver is run from a directory that holds nothing else).  glimmer-mg -r (circular genome) and coordinate lists
     with an entry that is no plain segment of the sequence (wrap-around, out of range) are handed to the *_dropin binary beside the
     driver (the reference's own main() on the device-backed ICM_t, started as a child process).  The bytes must be the all-reference

@@ -448,3 +448,42 @@ def test_mg_models_whose_sums_could_round_take_the_sequential_kernels(gpu, oracl
         for o, (out, want) in zip(mine, scored):
             sl = slice(o["start_begin"], o["start_begin"] + o["n_starts"])
             assert dev_err_rows(e_starts[sl], e_errs[sl]) == err_rows(want), (doctor, "-i", r)
+
+
+# ---- Find_Orfs in full on the device: ignore regions (glimmer3 -i) and circular sequences (glimmer-mg -r) ----------------------
+@pytest.mark.parametrize("name", ["ignore", "ignore_X_g60", "circular", "circular_X_Z2", "circular_ignore", "plain_g60"])
+def test_find_orfs_ignore_regions_and_circular_on_the_device(gpu, oracle, name):
+    """gmg_find_orfs with gmg_mg_params.n_ignore_regions / .circular (k_find_orfs_general) against the reference's own Find_Orfs on six
+    genome slices (tests/golden/find_orfs_general.npz: oracle/_ref/ref_orfs orfs | orfs-circular) and against the oracle on random
+    sequences with random regions: every Orf_t field, in the reference's order"""
+    from test_oracle_orfs import FIND_ORFS_GENERAL, genome_slices
+    g, slices = genome_slices(oracle)
+    kw, circular = FIND_ORFS_GENERAL[name]
+    regions = [tuple(int(x) for x in r) for r in g[name + "_regions"]]
+    reads = gpu.Reads.from_strings(slices)
+    orfs, off = gpu.find_orfs(reads, circular=circular, ignore_regions=regions, **kw)
+    got = np.stack([orfs["read"].astype(np.int32), orfs["frame"], orfs["stop_position"], orfs["gene_len"], orfs["orf_len"]], 1)
+    assert np.array_equal(got, g[name + "_orfs"])
+    assert int(off[-1]) == len(orfs) > 400
+    # random sequences (0 .. 3,000 bases), random disjoint regions, both modes: the oracle, sequence by sequence
+    rng = np.random.default_rng(len(name) * 7 + len(regions))
+    seqs = ["".join("acgt"[c] for c in rng.integers(0, 4, size=int(n))) for n in rng.integers(0, 3000, 40)]
+    cuts = np.sort(rng.choice(np.arange(1, 2900), size=8, replace=False))
+    rnd_regions = [(int(cuts[k]), int(cuts[k + 1])) for k in range(0, 8, 2)] if regions else []
+    prm = oracle.mg_params(**kw)
+    want = [oracle.find_orfs_general(s, prm, circular=circular, regions=rnd_regions) for s in seqs]
+    keep = [k for k, w in enumerate(want) if w is not None]          # (None: the reference's assert in Wrap_Around_Back)
+    reads = gpu.Reads.from_strings([seqs[k] for k in keep])
+    orfs, off = gpu.find_orfs(reads, circular=circular, ignore_regions=rnd_regions, **kw)
+    for j, k in enumerate(keep):
+        mine = orfs[int(off[j]):int(off[j + 1])]
+        assert np.array_equal(np.stack([mine["frame"], mine["stop_position"], mine["gene_len"], mine["orf_len"]], 1).reshape(-1, 4), want[k]), (name, k)
+    for k, w in enumerate(want):                            # where the reference aborts the call refuses (and says why)
+        if w is None:
+            with pytest.raises(gpu.GmgError) as e:
+                gpu.find_orfs(gpu.Reads.from_strings([seqs[k]]), circular=circular, ignore_regions=rnd_regions, **kw)
+            assert "Wrap_Around_Back" in str(e.value)
+            break
+    # the front half itself does not take such calls
+    with pytest.raises(gpu.GmgError):
+        gpu.find_orfs(reads, ignore_regions=[(50, 40)], **kw)
