@@ -128,6 +128,7 @@ enum GmgOpt {
                                  // k_mg_err_wave; needs mg_err_skip and sums that are exact in any order): 1 (default), 2 = with the stack walker
                                  // as the count pass too (cross-check), 0 = the tile / level kernels
     GMG_OPT_MG_ERR_WAVE_Q,       // ... tests: entries of a wave's call stack (0 = EW_QCAP; a full stack sends the batch to the level kernels)
+    GMG_OPT_ORFS_WALK8,          // gmg_score_orfs, events path: 1 = the running sums with a lane on eight consecutive walk steps (k_orf_walk_sums8), 0 = k_orf_walk_sums
     GMG_OPT_INGEST_SCANS,        // gmg_fasta_ingest: 1 = the first version (two hipcub scans over every byte + k_fa_pack), 0 = block summaries
     GMG_OPT_INGEST_PIECE_MIN,    // gmg_fasta_ingest: inputs of at least this many bytes are uploaded in 16 pieces, every piece parsed and packed as it arrives
     GMG_OPT_COUNT

@@ -1618,6 +1618,38 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                         const uint32_t b = (uint32_t)(rs + si), u = fwd ? span - 1u - b : b;
                         atomicOr((uint32_t *)s_oinfo + (u >> 1), ((3u - ds) | (3u - de) << 2) << (12u + 16u * (u & 1u)));
                     }
+                    if (G32 && !PRN) {
+                        // The null model's PARTIAL windows (a buffer's first two positions: the read's last two bases on the forward strand, its
+                        // first two on the reverse strand) are settled here, once per read, instead of in a branch of the scan's element loop (a
+                        // wave took it in 2 - 3 of its 8 iterations: a tenth of the kernel's instructions): the scan subtracts the FULL-window
+                        // values everywhere; the two elements of the read that hold a partial-window term get (full - partial) added in front.
+                        // Exact: every quantity is a multiple of the batch's grid and far below 2^53 of it (mg_run's test), in any order.
+                        // Element at base si, term t: sub-model (1, 2, 0)[t] at base x = si -/+ t, buffer position j = n - 1 - x / x.
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; e2++) {                // the read's last / first base, and the one beside it
+                            const int si = fwd ? n - 1 - e2 : e2;
+                            if (si < 0 || si >= n) continue;
+                            double fix = 0.0;
+#pragma unroll
+                            for (int t = 0; t < 2 - e2; t++) {          // (e2 = 0: terms 0 and 1 sit at j = 0, 1; e2 = 1: term 0 at j = 1)
+                                const int x = fwd ? si - t : si + t, j = e2 + t;
+                                if (x < 0 || x >= n) continue;
+                                const int fr = t == 0 ? 1 : 2;
+                                // six bits from base y = x (forward) / x - 2 (reverse) of the tile, as stage 2's window holds them
+                                const int y = rs + (fwd ? x : x - 2);
+                                const uint32_t X = 2u * (uint32_t)(32 + (int)(w0_lo & 15u) + y);
+                                const uint64_t two = (uint64_t)s_packed[(X >> 5) + 1] << 32 | s_packed[X >> 5];
+                                const uint32_t v = (uint32_t)(two >> (X & 31u)) & 63u;
+                                // S[x] and its neighbour towards the read's inside (forward S[x+1], reverse S[x-1]), as the buffer holds them
+                                const uint32_t c0 = fwd ? v & 3u : (v >> 4) & 3u, c1 = (v >> 2) & 3u;
+                                const uint32_t b0c = fwd ? c0 : c0 ^ 3u, b1c = fwd ? c1 : c1 ^ 3u;
+                                const uint32_t part = 192u + (uint32_t)fr * 20u + (j == 1 ? 4u + (b1c | b0c << 2) : b0c);
+                                fix += s_nulld[(uint32_t)fr * 64u + v] - s_nulld[part];
+                            }
+                            const uint32_t b = (uint32_t)(rs + si), u = fwd ? span - 1u - b : b;
+                            s_val[u] += fix;
+                        }
+                    }
                 }
             if (G32 && PRN) {
                 const uint32_t nc = nfit < NC ? nfit : NC;
@@ -1700,7 +1732,8 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                             return (double)s_nullm[rl < NC ? rl : 0u][off];
                         };
                         double nsum;
-                        if (DIST ? near3 >= 2u : (FWD ? si + 2 >= n : si < 2)) {   // one of them is a partial window
+                        // (one null model for the batch: the partial windows were settled in stage 1, the scan takes full windows everywhere)
+                        if (PRN && (DIST ? near3 >= 2u : (FWD ? si + 2 >= n : si < 2))) {   // one of them is a partial window
                             nsum = 0.0;
 #pragma unroll
                             for (int t = 0; t < 3; t++) {                          // (no branches in here: selects)

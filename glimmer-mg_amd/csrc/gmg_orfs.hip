@@ -338,6 +338,121 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums(OrfWalkArgs a)
     }
 }
 
+// The same sums with a lane on EIGHT CONSECUTIVE walk steps (k_orf_walk_sums keeps a lane on every 64th step for coalescing and moves the
+// values through LDS twice per 256 steps: 957 vector instructions per (read, strand) of 500 bases, the kernel's bound).  Here a
+// trip is 512 steps: the lane's 8 x 3 gene values are two 16-byte loads per row (the 32 bytes a lane reads are its own), the class of
+// a step is relabelled per lane so that the unrolled loop indexes statically (class c' takes row (c' + e) % 3 at the lane's step e), the
+// lane sums its steps serially, ONE wave scan of the lane totals per class carries on, and the lane's eight Q values leave as four
+// 16-byte stores.  Exact in any order (the events path's test), so the bits are k_orf_walk_sums' bits.
+struct __attribute__((packed, aligned(4))) OwF4 { float v[4]; };
+struct __attribute__((packed, aligned(8))) OwD2 { double v[2]; };
+
+__global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
+{
+    __shared__ double s_null[3 * 64];
+    for (int i = threadIdx.x; i < 3 * 64; i += 256) s_null[i] = (double)a.null_dense[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t it = wave; it < 2 * a.n_reads; it += n_waves) {
+        const uint64_t r = it >> 1;
+        const bool fwd = (it & 1) == 0;
+        const uint64_t off = a.read_off[r];
+        const uint32_t n = (uint32_t)(a.read_off[r + 1] - off);
+        const float *rows = a.gene6 + (fwd ? 0 : 3) * a.total;
+        double *q = a.q + (fwd ? 0 : a.total);
+        double carry[3] = {0.0, 0.0, 0.0};              // by TRUE class
+        for (uint32_t t0 = 0; t0 < n; t0 += 512) {
+            const uint32_t tb = t0 + 8u * lane;         // the lane's first step; its steps tb .. tb + 7 are bases p0, p0 -/+ 1, ..
+            const bool any = tb < n;
+            const uint32_t cnt = any ? (n - tb < 8u ? n - tb : 8u) : 0u;
+            // the lowest base of the lane's eight (forward: the last step's), clamped into the read: what lies outside is masked below
+            const int64_t p_first = fwd ? (int64_t)n - 1 - (int64_t)tb : (int64_t)tb;       // position of step tb in the read
+            const int64_t p_lo = fwd ? p_first - 7 : p_first;
+            const int64_t g_lo = (int64_t)off + p_lo;
+            float gv[3][8];
+            const bool whole = any && cnt == 8u && g_lo >= 0 && (uint64_t)g_lo + 8 <= a.total;
+            if (whole) {
+#pragma unroll
+                for (int f = 0; f < 3; f++) {
+                    const OwF4 lo4 = *(const OwF4 *)(rows + (uint64_t)f * a.total + (uint64_t)g_lo), hi4 = *(const OwF4 *)(rows + (uint64_t)f * a.total + (uint64_t)g_lo + 4);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { gv[f][k] = lo4.v[k]; gv[f][4 + k] = hi4.v[k]; }
+                }
+            } else {
+#pragma unroll
+                for (int f = 0; f < 3; f++)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int64_t p = p_lo + k;
+                        gv[f][k] = (any && p >= 0 && p < (int64_t)n) ? rows[(uint64_t)f * a.total + off + (uint64_t)p] : 0.0f;
+                    }
+            }
+            // bases p_lo - 2 .. p_lo + 9 as 2-bit fields (the null model's window reaches two bases beyond a step's own)
+            const uint64_t win = any ? dev_window_bits(a.packed, g_lo - 2) : 0ull;
+            // step e of the lane sits at index k = 7 - e (forward) / e (reverse) of the eight; its class: forward (p + 1) % 3, reverse p % 3.
+            // Relabelled class c' = (true class - class of step 0 + ..): see below -- value row f of class c at base p is (c - p) % 3
+            // forward and (1 + p - c) % 3 reverse (k_orf_walk_sums); with p = p_first -/+ e both become (c' + e) % 3 for
+            // c' = (c - p_first) % 3 forward, (1 + p_first - c) % 3 reverse... reverse runs the other way: (c' - e) % 3
+            const uint32_t pm = (uint32_t)(((p_first % 3) + 3) % 3);
+            double acc[3] = {0.0, 0.0, 0.0}, P[8][3];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int k = fwd ? 7 - e : e;
+                const bool in = (uint32_t)e < cnt;
+                // null window of the base at index k: forward (S[p+2], S[p+1], S[p]) oldest first, reverse the complement of (S[p-2], S[p-1], S[p])
+                const uint32_t w3 = (uint32_t)(win >> (2 * k)) & 0xfffu;            // fields: bases p - 2 .. p + 3
+                const uint32_t n6 = fwd ? (((w3 >> 8) & 3u) | (((w3 >> 6) & 3u) << 2) | (((w3 >> 4) & 3u) << 4)) : ((w3 & 63u) ^ 63u);
+                double v[3];
+#pragma unroll
+                for (int f = 0; f < 3; f++) v[f] = in ? (double)gv[f][k] - s_null[f * 64 + n6] : 0.0;
+                // relabelled class cp takes row (cp + e) % 3 (forward) / (cp + 3 - e % 3) % 3 ... reverse: p grows with e: row = (1 + p - c) % 3
+#pragma unroll
+                for (int cp = 0; cp < 3; cp++) {
+                    const int f = fwd ? (cp + e) % 3 : (cp + e) % 3;
+                    P[e][cp] = acc[cp];                 // the sum over the steps BEFORE this one
+                    acc[cp] += v[f];
+                }
+            }
+            // relabelling: forward row f = (c - p) % 3 with p = p_first - e  ->  (c - pm + e) % 3: cp = (c - pm) % 3
+            //              reverse row f = (1 + p - c) % 3 with p = p_first + e -> (1 + pm - c + e) % 3: cp = (1 + pm - c) % 3
+            double tot[3], base[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const uint32_t cp = fwd ? ((uint32_t)c + 3u - pm) % 3u : (1u + pm + 3u - (uint32_t)c) % 3u;
+                tot[c] = cp == 0u ? acc[0] : cp == 1u ? acc[1] : acc[2];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double inc = wcs_wave_scan(tot[c]);
+                base[c] = carry[c] + (inc - tot[c]);
+                carry[c] += wcs_last_lane(inc);
+            }
+            // Q of step e: the sum of the class OF ITS BASE: forward class (p + 1) % 3, reverse p % 3 -- relabelled: forward
+            // cp = (p + 1 - pm) % 3 with p = p_first - e -> (1 - e) % 3; reverse cp = (1 + pm - p) % 3 -> (1 - e) % 3: static
+            double qv[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int cp = ((1 - e) % 3 + 3) % 3;
+                const uint32_t c = fwd ? ((uint32_t)cp + pm) % 3u : (1u + pm + 3u - (uint32_t)cp) % 3u;     // the true class of cp
+                const double b = c == 0u ? base[0] : c == 1u ? base[1] : base[2];
+                qv[fwd ? 7 - e : e] = b + P[e][cp];
+            }
+            if (whole) {
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) { OwD2 d; d.v[0] = qv[k]; d.v[1] = qv[k + 1]; *(OwD2 *)(q + (uint64_t)g_lo + k) = d; }
+            } else if (any) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int64_t p = p_lo + k;
+                    const uint32_t e = (uint32_t)(fwd ? 7 - k : k);
+                    if (e < cnt && p >= 0 && p < (int64_t)n) q[off + (uint64_t)p] = qv[k];
+                }
+            }
+        }
+    }
+}
+
 struct OrfEventArgs {
     OrfScanArgs sc;
     GmgDevModel gene, nul;
@@ -735,7 +850,9 @@ extern "C" int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *nul,
         wa.null_dense = nul->dev.dense;
         wa.q = mb->d_walk;
         const uint64_t waves = 2 * reads->n_reads, wblocks = (waves + 3) / 4;
-        hipLaunchKernelGGL(k_orf_walk_sums, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
+        // (option orfs_walk8: the lane-on-eight-steps form, the default; 0: the lane-on-every-64th-step form it is checked against)
+        if (gmg_opt(GMG_OPT_ORFS_WALK8)) hipLaunchKernelGGL(k_orf_walk_sums8, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
+        else hipLaunchKernelGGL(k_orf_walk_sums, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
         GMG_HIP(hipGetLastError());
     } else if (fused) {
         if (!mb->d_gene6 || !mb->d_tmp) {                          // both or neither: a failed second allocation leaves nothing behind
