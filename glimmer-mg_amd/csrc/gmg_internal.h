@@ -124,9 +124,10 @@ enum GmgOpt {
     GMG_OPT_MG_ERR_TILE_Q,       // ... tests: calls per level a work-group's slab holds (0 = ET_QCAP; a full slab sends the batch to the level kernels);
                                  // any value but 0 also starts with staging arrays of 64 entries (-1: only that: the kernel repeats with larger ones)
     GMG_OPT_MG_ERR_QONLY,        // glimmer-mg -s on the level kernels: 1 = the running-sum table holds one value per base and strand (16 B/base), 0 = three (48)
-    GMG_OPT_MG_ERR_WAVE,         // glimmer-mg's error branch with one wave per (read, strand), running sums and masks in the wave's LDS (k_mg_err_wcount +
-                                 // k_mg_err_wave; needs mg_err_skip and sums that are exact in any order): 1 (default), 2 = with the stack walker
-                                 // as the count pass too (cross-check), 0 = the tile / level kernels
+    GMG_OPT_MG_ERR_WAVE,         // glimmer-mg's error branch with one wave per (read, strand), running sums and masks in the wave's LDS (needs mg_err_skip
+                                 // and sums that are exact in any order): 1 (default) = both passes breadth first without walks (k_mg_err_wcount),
+                                 // 2 = both on the stack walker (k_mg_err_wave), 3 = count pass breadth first, write pass on the stack walker
+                                 // (cross-checks), 0 = the tile / level kernels
     GMG_OPT_MG_ERR_WAVE_Q,       // ... tests: entries of a wave's call stack (0 = EW_QCAP; a full stack sends the batch to the level kernels)
     GMG_OPT_ORFS_WALK8,          // gmg_score_orfs, events path: 1 = the running sums with a lane on eight consecutive walk steps (k_orf_walk_sums8), 0 = k_orf_walk_sums
     GMG_OPT_INGEST_SCANS,        // gmg_fasta_ingest: 1 = the first version (two hipcub scans over every byte + k_fa_pack), 0 = block summaries

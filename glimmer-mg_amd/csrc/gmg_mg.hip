@@ -1598,6 +1598,39 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
             uh = fwd ? span - 1 - bh : bh;
         };
 
+        // The null model's PARTIAL windows (a buffer's first two positions: the read's last two bases on the forward strand, its first
+        // two on the reverse strand) are settled once per read instead of in a branch of the scan's element loop (a wave took it in
+        // 2 - 3 of its 8 iterations: a tenth of the kernel's instructions): the scan subtracts the FULL-window values everywhere; the
+        // two elements of the read that hold a partial-window term get (full - partial) added in front.  Exact: every quantity is a
+        // multiple of the batch's grid and far below 2^53 of it (mg_run's test), in any order.
+        // Element at base si, term t: sub-model (1, 2, 0)[t] at base x = si -/+ t, buffer position j = n - 1 - x / x.
+        auto partial_fix = [&](uint32_t r, int rs, int n, auto tab) __attribute__((always_inline)) {
+            (void)r;
+#pragma unroll
+            for (int e2 = 0; e2 < 2; e2++) {                // the read's last / first base, and the one beside it
+                const int si = fwd ? n - 1 - e2 : e2;
+                if (si < 0 || si >= n) continue;
+                double fix = 0.0;
+#pragma unroll
+                for (int t = 0; t < 2 - e2; t++) {          // (e2 = 0: terms 0 and 1 sit at j = 0, 1; e2 = 1: term 0 at j = 1)
+                    const int x = fwd ? si - t : si + t, j = e2 + t;
+                    if (x < 0 || x >= n) continue;
+                    const int fr = t == 0 ? 1 : 2;
+                    // six bits from base y = x (forward) / x - 2 (reverse) of the tile, as stage 2's window holds them
+                    const int y = rs + (fwd ? x : x - 2);
+                    const uint32_t X = 2u * (uint32_t)(32 + (int)(w0_lo & 15u) + y);
+                    const uint64_t two = (uint64_t)s_packed[(X >> 5) + 1] << 32 | s_packed[X >> 5];
+                    const uint32_t v = (uint32_t)(two >> (X & 31u)) & 63u;
+                    // S[x] and its neighbour towards the read's inside (forward S[x+1], reverse S[x-1]), as the buffer holds them
+                    const uint32_t c0 = fwd ? v & 3u : (v >> 4) & 3u, c1 = (v >> 2) & 3u;
+                    const uint32_t b0c = fwd ? c0 : c0 ^ 3u, b1c = fwd ? c1 : c1 ^ 3u;
+                    const uint32_t part = 192u + (uint32_t)fr * 20u + (j == 1 ? 4u + (b1c | b0c << 2) : b0c);
+                    fix += (double)tab[(uint32_t)fr * 64u + v] - (double)tab[part];
+                }
+                const uint32_t b = (uint32_t)(rs + si), u = fwd ? span - 1u - b : b;
+                s_val[u] += fix;
+            }
+        };
         // ---- stage 1: one lane per ORF of the tile: where its region starts
         if (nfit) {
             for (uint32_t e = tid; e < n_orf; e += BLOCK) {
@@ -1618,38 +1651,7 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                         const uint32_t b = (uint32_t)(rs + si), u = fwd ? span - 1u - b : b;
                         atomicOr((uint32_t *)s_oinfo + (u >> 1), ((3u - ds) | (3u - de) << 2) << (12u + 16u * (u & 1u)));
                     }
-                    if (G32 && !PRN) {
-                        // The null model's PARTIAL windows (a buffer's first two positions: the read's last two bases on the forward strand, its
-                        // first two on the reverse strand) are settled here, once per read, instead of in a branch of the scan's element loop (a
-                        // wave took it in 2 - 3 of its 8 iterations: a tenth of the kernel's instructions): the scan subtracts the FULL-window
-                        // values everywhere; the two elements of the read that hold a partial-window term get (full - partial) added in front.
-                        // Exact: every quantity is a multiple of the batch's grid and far below 2^53 of it (mg_run's test), in any order.
-                        // Element at base si, term t: sub-model (1, 2, 0)[t] at base x = si -/+ t, buffer position j = n - 1 - x / x.
-#pragma unroll
-                        for (int e2 = 0; e2 < 2; e2++) {                // the read's last / first base, and the one beside it
-                            const int si = fwd ? n - 1 - e2 : e2;
-                            if (si < 0 || si >= n) continue;
-                            double fix = 0.0;
-#pragma unroll
-                            for (int t = 0; t < 2 - e2; t++) {          // (e2 = 0: terms 0 and 1 sit at j = 0, 1; e2 = 1: term 0 at j = 1)
-                                const int x = fwd ? si - t : si + t, j = e2 + t;
-                                if (x < 0 || x >= n) continue;
-                                const int fr = t == 0 ? 1 : 2;
-                                // six bits from base y = x (forward) / x - 2 (reverse) of the tile, as stage 2's window holds them
-                                const int y = rs + (fwd ? x : x - 2);
-                                const uint32_t X = 2u * (uint32_t)(32 + (int)(w0_lo & 15u) + y);
-                                const uint64_t two = (uint64_t)s_packed[(X >> 5) + 1] << 32 | s_packed[X >> 5];
-                                const uint32_t v = (uint32_t)(two >> (X & 31u)) & 63u;
-                                // S[x] and its neighbour towards the read's inside (forward S[x+1], reverse S[x-1]), as the buffer holds them
-                                const uint32_t c0 = fwd ? v & 3u : (v >> 4) & 3u, c1 = (v >> 2) & 3u;
-                                const uint32_t b0c = fwd ? c0 : c0 ^ 3u, b1c = fwd ? c1 : c1 ^ 3u;
-                                const uint32_t part = 192u + (uint32_t)fr * 20u + (j == 1 ? 4u + (b1c | b0c << 2) : b0c);
-                                fix += s_nulld[(uint32_t)fr * 64u + v] - s_nulld[part];
-                            }
-                            const uint32_t b = (uint32_t)(rs + si), u = fwd ? span - 1u - b : b;
-                            s_val[u] += fix;
-                        }
-                    }
+                    if (G32 && !PRN) partial_fix(r, rs, n, s_nulld);
                 }
             if (G32 && PRN) {
                 const uint32_t nc = nfit < NC ? nfit : NC;
@@ -1660,6 +1662,13 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
             }
         }
         __syncthreads();                                // (the null tables of the tile's reads, the edge marks: stage 2 reads both)
+        if (G32 && PRN && nfit) {                       // a null model per read: its table has arrived with stage 1
+            for (uint32_t r = threadIdx.x; r < nfit; r += BLOCK) {
+                const int rs = (int)s_roff[r], n = (int)s_roff[r + 1] - rs;
+                partial_fix(r, rs, n, s_nullm[r < NC ? r : 0u]);
+            }
+            __syncthreads();
+        }
         MT_STAMP(2);                                    // stage 1
         // ---- stage 2: the scan.  Lane (class c, part jl) owns elements u = ub + 3 i, i < EL: every third base of 27
         // consecutive ones.  The ten codons of its class that surround them come out of ONE 64-bit window of the packed bases as
@@ -1723,37 +1732,14 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                         // x = b -/+ 2 (forward / reverse), buffer position j = n-1-x / x
                         const int bitb = FWD ? 2 * FW0 - 6 * i : 6 * i + 6;             // bit position of S[b] in the window
                         // entry `off` of the read's table in this strand's order
-                        auto nullv = [&](uint32_t off, uint32_t) __attribute__((always_inline)) -> double {
+                        auto nullf = [&](uint32_t off) __attribute__((always_inline)) -> double {        // a full-window entry
                             if (!PRN) return s_nulld[off];
                             return (double)s_nullm[rl < NC ? rl : 0u][off];       // (mg_run lets a tile take MT_NC reads at most then)
                         };
-                        auto nullf = [&](uint32_t off) __attribute__((always_inline)) -> double {        // a full-window entry
-                            if (!PRN) return s_nulld[off];
-                            return (double)s_nullm[rl < NC ? rl : 0u][off];
-                        };
-                        double nsum;
-                        // (one null model for the batch: the partial windows were settled in stage 1, the scan takes full windows everywhere)
-                        if (PRN && (DIST ? near3 >= 2u : (FWD ? si + 2 >= n : si < 2))) {   // one of them is a partial window
-                            nsum = 0.0;
-#pragma unroll
-                            for (int t = 0; t < 3; t++) {                          // (no branches in here: selects)
-                                const int fr = t == 0 ? 1 : t == 1 ? 2 : 0;
-                                const int xs = FWD ? si - t : si + t;              // the term's base in its read
-                                const int j = DIST ? 3 - (int)near3 + t : (FWD ? n - 1 - xs : xs);
-                                const int bx = bitb + (FWD ? -2 * t : 2 * t);      // bit position of S[x]
-                                const uint32_t c0 = (uint32_t)(win >> bx) & 3u;
-                                const uint32_t c1 = (uint32_t)(win >> (FWD ? bx + 2 : bx - 2)) & 3u;
-                                const uint32_t b0c = FWD ? c0 : c0 ^ 3u, b1c = FWD ? c1 : c1 ^ 3u;
-                                const uint32_t v = (uint32_t)(win >> (FWD ? bx : bx - 4)) & 63u;
-                                const uint32_t off = j >= 2 ? fr * 64 + v : 192u + fr * 20 + (j == 1 ? 4u + (b1c | b0c << 2) : b0c);
-                                const double nv = nullv(off, v);
-                                nsum += (DIST ? 3 - (int)far3 >= t : (xs >= 0 && xs < n)) ? nv : 0.0;       // (beyond the read: T is never used then)
-                            }
-                        } else {
-                            const uint32_t v1 = (uint32_t)(win >> (FWD ? bitb : bitb - 4)) & 63u, v2 = (uint32_t)(win >> (bitb - 2)) & 63u;
-                            const uint32_t v0 = (uint32_t)(win >> (FWD ? bitb - 4 : bitb)) & 63u;
-                            nsum = (nullf(64 + v1) + nullf(128 + v2)) + nullf(v0);
-                        }
+                        // (the partial windows at the read's end were settled in front of the scan -- partial_fix: full windows everywhere here)
+                        const uint32_t v1 = (uint32_t)(win >> (FWD ? bitb : bitb - 4)) & 63u, v2 = (uint32_t)(win >> (bitb - 2)) & 63u;
+                        const uint32_t v0 = (uint32_t)(win >> (FWD ? bitb - 4 : bitb)) & 63u;
+                        const double nsum = (nullf(64 + v1) + nullf(128 + v2)) + nullf(v0);
                         T -= nsum;
                     }
                     if (st) { acc = 0.0; p = (u << 12) | MT_REAL | MT_BLK; }
@@ -3536,6 +3522,17 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         }
     }
     const uint64_t nr = a.n_reads;
+    // (in front of the ORF scan's count pass: behind it the launch waited for the host to come back from the scan's total -- it then
+    // ran beside the ORF write pass, both at half speed, 1 ms on the error branch's critical path; here it runs in the six-frame
+    // kernel's shadow: no LDS, few registers)
+    if (err_mode == 1 && a.total && !find_only) {       // Set_Quality_454 / Clean_Quality_454: needs the reads only
+        if (prm->quality) MG_TRY(hipMemcpyAsync(d_user_q, prm->quality, a.total, hipMemcpyHostToDevice, s3));
+        MG_TRY(gmg_pool_alloc((void **)&d_walk_q, a.total + 8));
+        hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(nr * 64)), dim3(256), 0, s3, a, d_user_q, d_qual + 64, d_walk_q);
+        MG_TRY(hipGetLastError());
+        a.walk_q = d_walk_q;
+        tm.lap("quality values");
+    }
     MG_TRY(gmg_pool_alloc((void **)&d_read_cnt, (nr + 1) * 4));
     MG_TRY(hipMemsetAsync(d_read_cnt, 0, (nr + 1) * 4, s2));
     MG_TRY(gmg_pool_alloc((void **)&res->d_read_orf_off, (nr + 1) * 8));
@@ -3591,14 +3588,6 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     } else if (nr) hipLaunchKernelGGL(k_mg_find_orfs<true>, dim3(grid_for(nr)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
     tm.lap("find orfs");
-    if (err_mode == 1 && a.total && !find_only) {       // Set_Quality_454 / Clean_Quality_454: needs the reads only
-        if (prm->quality) MG_TRY(hipMemcpyAsync(d_user_q, prm->quality, a.total, hipMemcpyHostToDevice, s3));
-        MG_TRY(gmg_pool_alloc((void **)&d_walk_q, a.total + 8));
-        hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(nr * 64)), dim3(256), 0, s3, a, d_user_q, d_qual + 64, d_walk_q);
-        MG_TRY(hipGetLastError());
-        a.walk_q = d_walk_q;
-        tm.lap("quality values");
-    }
     // error branch, level by level: 0 (k_mg_err_level; the default), 1 = one lane per ORF with an explicit stack
     // (k_mg_err_flat: exact slots; the fallback of 0, and on its own with GMG_MG_ERR_FLAT=1 for A/B runs and cross-checks)
     int err_path = gmg_opt(GMG_OPT_MG_ERR_FLAT) ? 1 : 0;
@@ -3722,14 +3711,15 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     // k_mg_err_wave: as many one-wave work-groups per CU as their LDS shares allow (the grid strides over the (read, strand) pairs)
     const uint32_t ew_qcap = gmg_opt(GMG_OPT_MG_ERR_WAVE_Q) > 0 ? (uint32_t)gmg_opt(GMG_OPT_MG_ERR_WAVE_Q) : (uint32_t)EW_QCAP;
     auto launch_err_wave = [&](hipStream_t st, bool write) -> hipError_t {
-        // Length classes, a launch each (a wave's LDS share is sized by its class: more waves per CU for the short reads).  Count
-        // pass: the walk-free kernel (k_mg_err_wcount), classes of up to 384 / 448 / 512 / EW_MAX_CAP bases; mg_err_wave = 2: the
-        // stack walker's count form.  Write pass: the stack walker, up to 512 / ew_cap bases.
+        // Length classes, a launch each (a wave's LDS share is sized by its class: more waves per CU for the short reads): up to
+        // 384 / 448 / 512 / EW_MAX_CAP bases.  Both passes on k_mg_err_wcount (breadth first, no walks); mg_err_wave = 2: the stack
+        // walker (k_mg_err_wave) for both, 3: the stack walker as the write pass only (cross-checks), up to 512 / ew_cap bases.
         int n_cu = 0;
         hipError_t e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
         if (e != hipSuccess) return e;
         const uint64_t n_blocks = (2 * nr + 63) / 64;
-        const bool wcount = !write && gmg_opt(GMG_OPT_MG_ERR_WAVE) != 2;
+        const long long mode = gmg_opt(GMG_OPT_MG_ERR_WAVE);
+        const bool wcount = mode == 1 || (mode == 3 && !write);
         uint32_t *st_ptr = tm.on && !write ? d_err_flag + 24 : (uint32_t *)nullptr;
         static const uint32_t bounds_c[5] = {0, 384, 448, 512, EW_MAX_CAP}, bounds_w[3] = {0, 512, EW_MAX_CAP};
         const uint32_t *bounds = wcount ? bounds_c : bounds_w;
@@ -3737,7 +3727,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         for (int cls = 0; cls < n_cls; cls++) {
             const uint32_t lo = bounds[cls], hi = bounds[cls + 1] < ew_cap ? bounds[cls + 1] : ew_cap;
             if (hi <= lo || reads->max_len <= lo || reads->min_len > hi) continue;
-            const uint32_t bytes = wcount ? ewc_layout(bounds[cls + 1]).bytes : ew_layout(hi, ew_qcap, write).bytes;
+            const uint32_t bytes = wcount ? ewc_layout(bounds[cls + 1], write).bytes : ew_layout(hi, ew_qcap, write).bytes;
             uint32_t per_cu = (uint32_t)((160u * 1024u) / (bytes + 1024u));
             if (per_cu > 16) per_cu = 16;
             if (per_cu < 1) per_cu = 1;
@@ -3745,10 +3735,11 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
             if (grid > n_blocks) grid = n_blocks;
             if (grid == 0) continue;
 #define MG_EW_LAUNCH(W_, G_, K_) hipLaunchKernelGGL((k_mg_err_wave<W_, G_, K_>), dim3((unsigned)grid), dim3(EW_BLOCK), bytes, st, a, err_acc_only, lo, hi, ew_qcap, d_item_flag, st_ptr)
-#define MG_EWC_LAUNCH(G_, K_) hipLaunchKernelGGL((k_mg_err_wcount<G_, K_>), dim3((unsigned)grid), dim3(EW_BLOCK), 0, st, a, err_acc_only, lo, hi, d_item_flag, st_ptr)
+#define MG_EWC_LAUNCH(W_, G_, K_) hipLaunchKernelGGL((k_mg_err_wcount<W_, G_, K_>), dim3((unsigned)grid), dim3(EW_BLOCK), 0, st, a, err_acc_only, lo, hi, d_item_flag, st_ptr)
 #define MG_EW_LAUNCH_K(W_, G_) do { if (cls == 0) MG_EW_LAUNCH(W_, G_, 8); else MG_EW_LAUNCH(W_, G_, 15); } while (0)
-#define MG_EWC_LAUNCH_K(G_) do { if (cls == 0) MG_EWC_LAUNCH(G_, 6); else if (cls == 1) MG_EWC_LAUNCH(G_, 7); else if (cls == 2) MG_EWC_LAUNCH(G_, 8); else MG_EWC_LAUNCH(G_, 15); } while (0)
-            if (wcount) { if (a.gene32) MG_EWC_LAUNCH_K(true); else MG_EWC_LAUNCH_K(false); }
+#define MG_EWC_LAUNCH_K(W_, G_) do { if (cls == 0) MG_EWC_LAUNCH(W_, G_, 6); else if (cls == 1) MG_EWC_LAUNCH(W_, G_, 7); else if (cls == 2) MG_EWC_LAUNCH(W_, G_, 8); else MG_EWC_LAUNCH(W_, G_, 15); } while (0)
+            if (wcount && write) { if (a.gene32) MG_EWC_LAUNCH_K(true, true); else MG_EWC_LAUNCH_K(true, false); }
+            else if (wcount) { if (a.gene32) MG_EWC_LAUNCH_K(false, true); else MG_EWC_LAUNCH_K(false, false); }
             else if (write) { if (a.gene32) MG_EW_LAUNCH_K(true, true); else MG_EW_LAUNCH_K(true, false); }
             else { if (a.gene32) MG_EW_LAUNCH_K(false, true); else MG_EW_LAUNCH_K(false, false); }
 #undef MG_EWC_LAUNCH_K

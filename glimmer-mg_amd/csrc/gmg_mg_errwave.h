@@ -651,9 +651,10 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
 
 struct EwcLayout {
     uint32_t S, msk, l1_ss, l2_ss, l1_w, l2_w, l1_x, pcall, plist, pq, cum, orf_at, a_cnt, a_m0, gi, xs, acc, bytes;
+    uint32_t l1_key, l2_key, l1_e, l2_e, a_best, a_exa, a_exb;   // WRITE only
     uint32_t srow, nw;           // doubles per class row; words per mask row (one guard word in front, zero words behind)
 };
-__host__ __device__ constexpr EwcLayout ewc_layout(uint32_t cap)
+__host__ __device__ constexpr EwcLayout ewc_layout(uint32_t cap, bool write = false)
 {
     EwcLayout L = {};
     L.srow = cap + 4;
@@ -664,6 +665,13 @@ __host__ __device__ constexpr EwcLayout ewc_layout(uint32_t cap)
     L.l1_ss = o; o += EWC_CAP1 * 8;
     L.l2_ss = o; o += EWC_CAP2 * 8;
     L.acc = o; o += 8;
+    L.l1_key = o; o += write ? EWC_CAP1 * 8 : 0;
+    L.l2_key = o; o += write ? EWC_CAP2 * 8 : 0;
+    L.a_best = o; o += write ? EW_MAXO * 8 : 0;
+    L.a_exa = o; o += write ? EW_MAXO * 8 : 0;
+    L.a_exb = o; o += write ? EW_MAXO * 8 : 0;
+    L.l1_e = o; o += write ? EWC_CAP1 * 4 : 0;
+    L.l2_e = o; o += write ? EWC_CAP2 * 4 : 0;
     L.l1_w = o; o += EWC_CAP1 * 4;
     L.l2_w = o; o += EWC_CAP2 * 4;
     L.a_cnt = o; o += EW_MAXO * 4;
@@ -753,17 +761,99 @@ __device__ __forceinline__ EwOwn ew_own(const double *S, const uint32_t srow, co
     return o;
 }
 
-template <bool G32, int KMAX>
+// The same call in the WRITE pass: every start it pushes goes to a slot of its ORF's slice (handed out by a counter in LDS; the
+// order key restores the reference's push order afterwards, as for k_mg_err_level), with the Error_t entries of its path; the
+// call's best score and its entry at the extreme pos are merged into the ORF's aggregates (first_j / best_score of the record).
+// Returns the region's last codon through t_last / has (what the branching needs).
+__device__ __forceinline__ void ew_own_write(const MgArgs &a, const double *S, const uint32_t srow, const uint64_t *Mstart, const uint64_t *Mstop,
+                                             const uint32_t n, const bool fwd, const uint64_t off, const uint32_t off_m3, const uint32_t x, const double ss,
+                                             const int D, const int mgl, const int isl, const bool allow_trunc, const uint32_t lidx, const uint32_t level,
+                                             const uint64_t key, const uint32_t ee, uint32_t *fill, const uint32_t *sbeg, unsigned long long *a_best,
+                                             unsigned long long *a_exa, unsigned long long *a_exb, const int8_t *s_which, uint32_t &t_last_out, bool &has_out)
+{
+    has_out = false; t_last_out = 0;
+    if (x >= n || n - x < 3) return;
+    uint32_t t = x, s = 0;
+    bool found = false;
+    while (t + 2 < n) {
+        const uint64_t win = ewc_window(Mstop, (int)t) & EW_THIN;
+        if (win) { s = t + (uint32_t)__builtin_ctzll(win); found = true; break; }
+        t += 66u;
+    }
+    if (found && s == x) return;
+    const uint32_t t_last = found ? s - 3u : x + (n - 3u - x) / 3u * 3u;
+    const bool trunc = !found && allow_trunc;
+    has_out = true; t_last_out = t_last;
+    int jmin = D + mgl - 3 - (int)x;
+    if (jmin < 3) jmin = 3;
+    jmin = (jmin + 2) / 3 * 3;
+    const uint32_t tq = x + (uint32_t)jmin;
+    if (tq > t_last) return;
+    const uint32_t cls = (off_m3 + (fwd ? n - 1u - x : x)) % 3u;
+    const double *Sc = S + cls * srow;
+    const double p0 = Sc[x];
+    uint32_t cnt = 0, last_own = MG_NO_SLOT;
+    double best = -DBL_MAX;
+    int last_pos = 0, last_j = 0;
+    auto put = [&](uint32_t tt, int which, bool truncated) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t j0 = tt - x;
+        const int k = fwd ? (int)n - (int)x - 2 - (int)j0 : (int)x + (int)j0 + 3;
+        const double raw = ((Sc[tt] - p0) - 0.0) + ss;
+        const int j_full = (int)tt + 2 - D;
+        const double sc = (j_full > isl && 0.0 > raw) ? 0.0 : raw;
+        const uint32_t slot = sbeg[lidx] + atomicAdd(&fill[lidx], 1u);
+        gmg_start st;
+        st.score = sc; st.j = j_full; st.pos = k; st.which = which; st.truncated = (int16_t)(truncated ? 1 : 0); st.first = (int16_t)(truncated ? 1 : 0);
+        a.starts[slot] = st;
+        gmg_start_errors er;
+        er.pos[0] = level > 0 ? (int)((ee & 0x3fffu) >> 2) - 8 : 0; er.pos[1] = level > 1 ? (int)((ee >> 14) >> 2) - 8 : 0;
+        er.type[0] = (int8_t)(level > 0 ? (ee & 3u) : 0); er.type[1] = (int8_t)(level > 1 ? ((ee >> 14) & 3u) : 0);
+        er.n = (int8_t)level; er.reserved = 0;
+        a.errs[slot] = er;
+        a.keys[slot] = key | (uint64_t)((uint32_t)(2047 - (int)j0) << 2 | (truncated ? 2u : 3u)) << (26 - 13 * (int)level);
+        last_pos = k; last_j = j_full;
+        if (sc > best) best = sc;
+        cnt++;
+        return slot;
+    };
+    for (t = tq; t <= t_last; t += 66u) {
+        uint64_t win = ewc_window(Mstart, (int)t) & EW_THIN;
+        const uint32_t span = t_last - t;
+        if (span < 63u) win &= (2ull << span) - 1ull;
+        while (win) {
+            const uint32_t tt = t + (uint32_t)__builtin_ctzll(win);
+            win &= win - 1ull;
+            // which start codon: the codon's index as the walks form it
+            const uint64_t g = fwd ? off + n - 1 - tt : off + tt;
+            const uint32_t five = (uint32_t)dev_window_bits(a.packed, (int64_t)g - 2) & 0x3ffu, c0 = (five >> 4) & 3u;
+            const int which = s_which[fwd ? c0 | ((five >> 2) & 3u) << 2 | (five & 3u) << 4 : (c0 | ((five >> 6) & 3u) << 2 | ((five >> 8) & 3u) << 4) ^ 63u];
+            last_own = put(tt, which, false);
+        }
+    }
+    if (trunc) put(t_last, -1, true);                   // (behind the codon's real start: kind 2 < kind 3 in the key)
+    else if (last_own != MG_NO_SLOT) a.starts[last_own].first = 1;
+    if (cnt) {
+        atomicMax(&a_best[lidx], (unsigned long long)mg_ord(best));
+        const unsigned long long pa = (unsigned long long)(uint32_t)(last_pos + 16) << 32 | (uint32_t)last_j,
+                                 pb = (unsigned long long)(uint32_t)(last_pos + 16) << 32 | (0xffffffffu - (uint32_t)last_j);
+        if (fwd) { atomicMin(&a_exa[lidx], pa); atomicMin(&a_exb[lidx], pb); }
+        else { atomicMax(&a_exa[lidx], pa); atomicMax(&a_exb[lidx], pb); }
+    }
+}
+
+template <bool WRITE, bool G32, int KMAX>
 __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int accepted_only, const uint32_t cap_lo, const uint32_t cap,
                                                             uint8_t *item_flag, uint32_t *stats)
 {
     // (the LDS share is sized by the length class, 64 KMAX bases: every offset a constant; reads of cap_lo < n <= cap are taken)
-    constexpr EwcLayout L = ewc_layout(64u * (uint32_t)KMAX);
+    constexpr EwcLayout L = ewc_layout(64u * (uint32_t)KMAX, WRITE);
     __shared__ __attribute__((aligned(16))) unsigned char ew_lds[L.bytes];
     __shared__ double s_pen[64];
     __shared__ float s_nt[G32 ? MG_NULL_FLOATS + 4 : 4];
+    __shared__ int8_t s_which[64];
     const uint32_t lane = threadIdx.x;
     s_pen[lane] = a.err_mode == 1 ? a.pen[lane] : 0.0;
+    s_which[lane] = a.which[lane];
     if (G32 && !a.read_null)
         for (uint32_t k = lane; k < MG_NULL_FLOATS; k += 64) s_nt[k] = a.null_tab[k];
     double *S = (double *)(ew_lds + L.S);
@@ -776,6 +866,12 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
     uint8_t *pq = ew_lds + L.pq, *orf_at = ew_lds + L.orf_at;
     uint32_t *a_cnt = (uint32_t *)(ew_lds + L.a_cnt), *a_m0 = (uint32_t *)(ew_lds + L.a_m0), *s_gi = (uint32_t *)(ew_lds + L.gi);
     unsigned long long *acc_mask = (unsigned long long *)(ew_lds + L.acc);
+    // WRITE: the lists carry the order key and the Error_t entries of every call; a_cnt = slots handed out inside the ORF's slice,
+    // a_m0 = where the slice begins; the ORFs' best score / entry at the extreme pos for first_j and best_score
+    uint64_t *l1_key = (uint64_t *)(ew_lds + L.l1_key), *l2_key = (uint64_t *)(ew_lds + L.l2_key);
+    uint32_t *l1_e = (uint32_t *)(ew_lds + L.l1_e), *l2_e = (uint32_t *)(ew_lds + L.l2_e);
+    unsigned long long *a_best = (unsigned long long *)(ew_lds + L.a_best), *a_exa = (unsigned long long *)(ew_lds + L.a_exa),
+                       *a_exb = (unsigned long long *)(ew_lds + L.a_exb);
     __syncthreads();
     const bool pen_lds = a.indel_q_thr < 64;
     const int mgl = a.min_gene_len;
@@ -800,6 +896,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
             const uint64_t no_ = a.read_orf_off[r_ + 1] - l_ob;
             l_no = no_ > 0xffffffffull ? 0xffffffffu : (uint32_t)no_;
             elig = l_n > cap_lo && l_n <= cap && l_no > 0;
+            if (WRITE && accepted_only && elig) elig = item_flag[my] != 0;
         }
     }
     uint64_t todo = __ballot(elig);
@@ -807,6 +904,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
     // for before this one is worked on and waits in registers: the pair's own phases then wait for LDS alone.
     EwRegs<G32, KMAX> Rn;
     int on_frame = 0, on_stop = 0;
+    uint32_t on_acc = 1, on_sbeg = 0;
     uint32_t src_n = 0;
     bool have_n = todo != 0;
     auto fetch_next = [&]() __attribute__((always_inline)) {
@@ -822,14 +920,21 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
 #pragma unroll
             for (int k = 0; k < 4; k++) Rn.ntv[k] = 4u * lane + (uint32_t)k < MG_NULL_FLOATS ? nt_[4u * lane + (uint32_t)k] : 0.0f;
         }
-        on_frame = 0; on_stop = 0;
-        if (ob_ + lane < oe_) { on_frame = a.orfs[ob_ + lane].frame; on_stop = a.orfs[ob_ + lane].stop_position; }
+        on_frame = 0; on_stop = 0; on_acc = 1; on_sbeg = 0;
+        if (ob_ + lane < oe_) {
+            on_frame = a.orfs[ob_ + lane].frame; on_stop = a.orfs[ob_ + lane].stop_position;
+            if (WRITE) {
+                on_sbeg = (uint32_t)a.start_off[ob_ + lane];
+                if (accepted_only) on_acc = (a.acc_bits[(ob_ + lane) >> 5] >> ((ob_ + lane) & 31u)) & 1u;
+            }
+        }
     };
     if (have_n) fetch_next();
     while (have_n) {
         const uint32_t src = src_n;
         const EwRegs<G32, KMAX> R = Rn;
         const int o_frame = on_frame, o_stop = on_stop;
+        const uint32_t o_acc = on_acc, o_sbeg = on_sbeg;
         have_n = todo != 0;
         if (have_n) fetch_next();
         const uint64_t it = blk * 64 + src;
@@ -869,62 +974,97 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         if (lane == 0) *acc_mask = 0;
         wcs_sync();
 
-        // ---- level 0: the ORFs of this strand
+        // ---- level 0: the ORFs of this strand.  First every ORF's first step is put down (s_xs; with -i the step's table entry names the
+        //      ORF that takes the branches of that step: ORFs that begin at the same step -- Find_Orfs gives the reverse frames
+        //      without a stop codon in front the same virtual stop -- have the same call tree), then one lane per ORF
         uint32_t nloc = 0, n1 = 0;
         for (uint64_t o0 = ob; o0 < oe && !overflow; o0 += 64) {
             const uint64_t i = o0 + lane;
             const bool have = i < oe;
             int frame = o_frame, stop_position = o_stop;
-            if (o0 != ob && have) { frame = a.orfs[i].frame; stop_position = a.orfs[i].stop_position; }
+            uint32_t acc = o_acc, sbeg = o_sbeg;
+            if (o0 != ob && have) {
+                frame = a.orfs[i].frame; stop_position = a.orfs[i].stop_position;
+                if (WRITE) {
+                    sbeg = (uint32_t)a.start_off[i];
+                    if (accepted_only) acc = (a.acc_bits[i >> 5] >> (i & 31u)) & 1u;
+                }
+            }
             const bool mine = have && (frame > 0) == fwd;
             const uint64_t mm = __ballot(mine);
             const uint32_t idx = nloc + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
             nloc += (uint32_t)__popcll(mm);
             if (nloc > EW_MAXO) { overflow = true; break; }
-            bool act = mine;
-            const int end_point = fwd ? stop_position - 1 : stop_position + 3;
-            const int xs = fwd ? (int)n - end_point : end_point - 1;               // the call's first walk step
+            if (mine) {
+                const int end_point = fwd ? stop_position - 1 : stop_position + 3;
+                const int xs = fwd ? (int)n - end_point : end_point - 1;           // the call's first walk step
+                bool act = true;
+                if (WRITE) { if (accepted_only && !acc) act = false; }
+                else if (accepted_only && ((int)n - xs) + 12 < mgl) act = false;     // (as k_mg_err_level: cannot reach Min_Gene_Len)
+                if (xs < 0 || xs >= (int)n) act = false;
+                s_gi[idx] = (uint32_t)i;
+                a_cnt[idx] = 0;
+                a_m0[idx] = WRITE ? sbeg : 0u;
+                if (WRITE) { a_best[idx] = mg_ord(-DBL_MAX); a_exa[idx] = a_exb[idx] = fwd ? ~0ull : 0ull; }
+                s_xs[idx] = act ? (uint16_t)xs : (uint16_t)0xffffu;
+                if (act && indels && a.indel_max >= 1) orf_at[xs] = (uint8_t)idx;
+            }
+        }
+        wcs_sync();
+        if (!overflow) {
             bool child = false;
             double es_sub = 0.0;
-            uint32_t child_w = 0;
-            if (mine) {
-                s_gi[idx] = (uint32_t)i;
-                a_cnt[idx] = 0; a_m0[idx] = 0;
-                s_xs[idx] = 0xffffu;
-                if (accepted_only && ((int)n - xs) + 12 < mgl) act = false;          // (as k_mg_err_level: cannot reach Min_Gene_Len)
-                if (xs < 0 || xs >= (int)n) act = false;
-                if (act) {
-                    const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, (uint32_t)xs, 0.0, xs, mgl, isl, thr, trunc_ok);
-                    a_cnt[idx] = o.cnt;
-                    a_m0[idx] = o.m_end << 1 | (o.trunc ? 1u : 0u);
-                    if (o.acc) atomicOr(acc_mask, 1ull << idx);
-                    if (indels && a.indel_max >= 1 && o.has) { orf_at[xs] = (uint8_t)idx; s_xs[idx] = (uint16_t)xs; }
-#ifdef EWC_DEBUG
-                    printf("ORF it %llu idx %u xs %d has %d cnt %u m_end %u\n", (unsigned long long)it, idx, xs, (int)o.has, o.cnt, o.m_end);
-#endif
-                    if (a.err_mode == 2 && (uint32_t)xs + o.m_end + 3u <= n) {
-                        // the substitution branch (:1771-1806): through the stop codon behind the region (steps x + m .. x + m + 2)
-                        const uint32_t sa = (uint32_t)xs + o.m_end;
-                        const uint64_t g = fwd ? off + n - 1 - sa : off + sa;
-                        const uint32_t five = (uint32_t)dev_window_bits(a.packed, (int64_t)g - 2) & 0x3ffu;
-                        const int a2 = fwd ? ((five >> 4) & 3u) == 0u : ((five >> 4) & 3u) == 3u;
-                        const int a1 = fwd ? ((five >> 2) & 3u) == 0u : ((five >> 6) & 3u) == 3u;
-                        es_sub = 0.0 + a.pass_stop[a1 * 2 + a2];
-                        if (o.m_end > 0) {
-                            const uint32_t cls = (off_m3 + (fwd ? n - 1u - (uint32_t)xs : (uint32_t)xs)) % 3u;
-                            es_sub += (S[cls * srow + sa] - S[cls * srow + (uint32_t)xs]) - 0.0;       // score[m - 1]
-                        }
-                        if ((int)o.m_end + ((int)n - (int)(sa + 3u)) + 12 >= mgl) {
-                            child = true;
-                            child_w = (sa + 3u) | (uint32_t)(xs + 3) << 10 | idx << 21;     // step | D << 10 | ORF << 21
-                        }
+            uint32_t child_w = 0, child_e = 0;
+            const uint32_t xs = lane < nloc ? (uint32_t)s_xs[lane] : 0xffffu;
+            if (xs != 0xffffu) {
+                uint32_t m_end = 0;
+                bool reach = false;
+                if (WRITE) {
+                    // (the ORF the step's table entry names writes the tree; the others at that step copy its slice at the end)
+                    if (!(indels && a.indel_max >= 1) || orf_at[xs] == lane) {
+                        uint32_t t_last = 0;
+                        bool has = false;
+                        ew_own_write(a, S, srow, Mstart, Mstop, n, fwd, off, off_m3, xs, 0.0, (int)xs, mgl, isl, trunc_ok, lane, 0u, 0ull, 0u, a_cnt, a_m0,
+                                     a_best, a_exa, a_exb, s_which, t_last, has);
+                        m_end = has ? t_last + 3u - xs : 0u;
+                        reach = true;
+                    }
+                } else {
+                    const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, xs, 0.0, (int)xs, mgl, isl, thr, trunc_ok);
+                    a_cnt[lane] = o.cnt;
+                    a_m0[lane] = o.m_end << 1 | (o.trunc ? 1u : 0u);
+                    if (o.acc) atomicOr(acc_mask, 1ull << lane);
+                    m_end = o.m_end;
+                    reach = true;
+                }
+                if (reach && a.err_mode == 2 && xs + m_end + 3u <= n) {
+                    // the substitution branch (:1771-1806): through the stop codon behind the region (steps x + m .. x + m + 2)
+                    const uint32_t sa = xs + m_end;
+                    const uint64_t g = fwd ? off + n - 1 - sa : off + sa;
+                    const uint32_t five = (uint32_t)dev_window_bits(a.packed, (int64_t)g - 2) & 0x3ffu;
+                    const int a2 = fwd ? ((five >> 4) & 3u) == 0u : ((five >> 4) & 3u) == 3u;
+                    const int a1 = fwd ? ((five >> 2) & 3u) == 0u : ((five >> 6) & 3u) == 3u;
+                    es_sub = 0.0 + a.pass_stop[a1 * 2 + a2];
+                    if (m_end > 0) {
+                        const uint32_t cls = (off_m3 + (fwd ? n - 1u - xs : xs)) % 3u;
+                        es_sub += (S[cls * srow + sa] - S[cls * srow + xs]) - 0.0;               // score[m - 1]
+                    }
+                    if ((int)m_end + ((int)n - (int)(sa + 3u)) + 12 >= mgl) {
+                        child = true;
+                        child_w = (sa + 3u) | (xs + 3u) << 10 | lane << 21;                      // step | D << 10 | ORF << 21
+                        // Error_t (lo - 2 / hi + 2, substitution): forward lo = n - x - m, reverse hi = x + 1 + m
+                        const int epos = fwd ? (int)n - (int)xs - (int)m_end - 2 : (int)xs + (int)m_end + 3;
+                        child_e = (uint32_t)(epos + 8) << 2 | 2u;
                     }
                 }
             }
             const uint64_t cm = __ballot(child);
             if (child) {
                 const uint32_t e = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-                if (e < EWC_CAP1) { l1_ss[e] = es_sub; l1_w[e] = child_w; }
+                if (e < EWC_CAP1) {
+                    l1_ss[e] = es_sub; l1_w[e] = child_w;
+                    if (WRITE) { l1_key[e] = 0ull; l1_e[e] = child_e; }      // (key field 0: before every position of the call)
+                }
             }
             n1 += (uint32_t)__popcll(cm);
         }
@@ -937,7 +1077,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 const uint32_t id = i0 + lane;
                 bool pi = false, pd = false;
                 double es_i = 0.0, es_d = 0.0;
-                uint32_t t = 0, xs = 0, lidx = 0;
+                uint32_t t = 0, xs = 0, lidx = 0, jj = 0;
                 if (id < 3u * npos) {
                     const uint32_t k = id / 3u, phi = id - 3u * k, p = plist[k];
                     const uint32_t pj = (p + 3u - phi) % 3u;
@@ -954,6 +1094,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                             }
                             lidx = orf_at[xs];
                             const uint32_t j0 = t - xs, j = j0 + pj;
+                            jj = j;
                             if (lidx != 255u && (int)j >= lowest_j) {
                                 const uint32_t cls = (off_m3 + (fwd ? n - 1u - xs : xs)) % 3u;
                                 const double *Sc = S + cls * srow;
@@ -975,12 +1116,26 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 const uint64_t mi = __ballot(pi), md = __ballot(pd);
                 if (pi) {
                     const uint32_t e = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
-                    if (e < EWC_CAP1) { l1_ss[e] = es_i; l1_w[e] = (t + 4u) | (xs + 2u) << 10 | lidx << 21; }
+                    if (e < EWC_CAP1) {
+                        l1_ss[e] = es_i; l1_w[e] = (t + 4u) | (xs + 2u) << 10 | lidx << 21;
+                        if (WRITE) {                    // Error_t of an insertion: k + 2 / k - 2 at the start's pos k of position j (Score_Indels)
+                            const int kj = fwd ? (int)n - (int)xs - 2 - (int)jj : (int)xs + 3 + (int)jj;
+                            l1_key[e] = (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 1u) << 26;
+                            l1_e[e] = (uint32_t)((fwd ? kj + 2 : kj - 2) + 8) << 2 | 0u;
+                        }
+                    }
                 }
                 n1 += (uint32_t)__popcll(mi);
                 if (pd) {
                     const uint32_t e = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(md >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md, 0u));
-                    if (e < EWC_CAP1) { l1_ss[e] = es_d; l1_w[e] = (t + 2u) | xs << 10 | lidx << 21; }
+                    if (e < EWC_CAP1) {
+                        l1_ss[e] = es_d; l1_w[e] = (t + 2u) | xs << 10 | lidx << 21;
+                        if (WRITE) {                    // ... of a deletion: k + 3 / k - 1
+                            const int kj = fwd ? (int)n - (int)xs - 2 - (int)jj : (int)xs + 3 + (int)jj;
+                            l1_key[e] = (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 0u) << 26;
+                            l1_e[e] = (uint32_t)((fwd ? kj + 3 : kj - 1) + 8) << 2 | 1u;
+                        }
+                    }
                 }
                 n1 += (uint32_t)__popcll(md);
                 if (n1 > EWC_CAP1) { overflow = true; break; }
@@ -996,9 +1151,15 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 const uint32_t i = b0 + lane;
                 if (i < n2) {
                     const uint32_t w = l2_w[i];
-                    const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, w & 1023u, l2_ss[i], (int)((w >> 10) & 2047u), mgl, isl, thr, trunc_ok);
-                    if (o.cnt) atomicAdd(&a_cnt[w >> 21], o.cnt);
-                    if (o.acc) atomicOr(acc_mask, 1ull << (w >> 21));
+                    if (WRITE) {
+                        uint32_t tl; bool hs;
+                        ew_own_write(a, S, srow, Mstart, Mstop, n, fwd, off, off_m3, w & 1023u, l2_ss[i], (int)((w >> 10) & 2047u), mgl, isl, trunc_ok, w >> 21, 2u,
+                                     l2_key[i], l2_e[i], a_cnt, a_m0, a_best, a_exa, a_exb, s_which, tl, hs);
+                    } else {
+                        const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, w & 1023u, l2_ss[i], (int)((w >> 10) & 2047u), mgl, isl, thr, trunc_ok);
+                        if (o.cnt) atomicAdd(&a_cnt[w >> 21], o.cnt);
+                        if (o.acc) atomicOr(acc_mask, 1ull << (w >> 21));
+                    }
                 }
             }
             n2 = 0;
@@ -1011,12 +1172,20 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
             if (i < n1) {
                 const uint32_t w = l1_w[i], x1 = w & 1023u;
                 const int D1 = (int)((w >> 10) & 2047u);
-                const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, x1, l1_ss[i], D1, mgl, isl, thr, trunc_ok);
-                if (o.cnt) atomicAdd(&a_cnt[w >> 21], o.cnt);
-                if (o.acc) atomicOr(acc_mask, 1ull << (w >> 21));
-                if (expand1 && o.has) {
+                uint32_t o_t_last = 0;
+                bool o_has = false;
+                if (WRITE)
+                    ew_own_write(a, S, srow, Mstart, Mstop, n, fwd, off, off_m3, x1, l1_ss[i], D1, mgl, isl, trunc_ok, w >> 21, 1u, l1_key[i], l1_e[i], a_cnt, a_m0,
+                                 a_best, a_exa, a_exb, s_which, o_t_last, o_has);
+                else {
+                    const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, x1, l1_ss[i], D1, mgl, isl, thr, trunc_ok);
+                    if (o.cnt) atomicAdd(&a_cnt[w >> 21], o.cnt);
+                    if (o.acc) atomicOr(acc_mask, 1ull << (w >> 21));
+                    o_t_last = o.t_last; o_has = o.has;
+                }
+                if (expand1 && o_has) {
                     // the low-quality bases from the call's first step to the last base of its region, by rank
-                    const uint32_t e = o.t_last + 3u;
+                    const uint32_t e = o_t_last + 3u;
                     const uint32_t r0 = cum[x1 >> 6] + (uint32_t)__popcll(Mlow[x1 >> 6] & ((1ull << (x1 & 63u)) - 1ull));
                     const uint32_t r1 = cum[e >> 6] + (uint32_t)__popcll(Mlow[e >> 6] & ((1ull << (e & 63u)) - 1ull));
                     nq = r1 - r0;
@@ -1036,10 +1205,12 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 const uint32_t qi = q0 + lane;
                 bool pi = false, pd = false;
                 double es_i = 0.0, es_d = 0.0;
-                uint32_t t = 0, lidx = 0;
+                uint32_t t = 0, lidx = 0, jj = 0, x1k = 0, e1 = 0;
+                uint64_t key1 = 0;
                 int D1 = 0;
                 if (qi < Tn) {
                     const uint32_t pc = pcall[qi], ci = b0 + (pc & 63u), u = pc >> 6;
+                    if (WRITE) { key1 = l1_key[ci]; e1 = l1_e[ci]; }
                     const uint32_t w = l1_w[ci], x1 = w & 1023u;
                     D1 = (int)((w >> 10) & 2047u); lidx = w >> 21;
                     const double ss1 = l1_ss[ci];
@@ -1047,6 +1218,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                     const uint32_t pj = (p - x1) % 3u;
                     t = p - pj;
                     const uint32_t j0 = t - x1, j = j0 + pj;
+                    jj = j; x1k = x1;
                     if ((int)j >= lowest_j) {
                         const uint32_t cls = (off_m3 + (fwd ? n - 1u - x1 : x1)) % 3u;
                         const double *Sc = S + cls * srow;
@@ -1064,11 +1236,21 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 if (pi) {
                     const uint32_t e = n2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
                     l2_ss[e] = es_i; l2_w[e] = (t + 4u) | (uint32_t)(D1 + 2) << 10 | lidx << 21;
+                    if (WRITE) {
+                        const int kj = fwd ? (int)n - (int)x1k - 2 - (int)jj : (int)x1k + 3 + (int)jj;
+                        l2_key[e] = key1 | (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 1u) << 13;
+                        l2_e[e] = (e1 & 0x3fffu) | ((uint32_t)((fwd ? kj + 2 : kj - 2) + 8) << 2 | 0u) << 14;
+                    }
                 }
                 n2 += (uint32_t)__popcll(mi);
                 if (pd) {
                     const uint32_t e = n2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(md >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md, 0u));
                     l2_ss[e] = es_d; l2_w[e] = (t + 2u) | (uint32_t)D1 << 10 | lidx << 21;
+                    if (WRITE) {
+                        const int kj = fwd ? (int)n - (int)x1k - 2 - (int)jj : (int)x1k + 3 + (int)jj;
+                        l2_key[e] = key1 | (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 0u) << 13;
+                        l2_e[e] = (e1 & 0x3fffu) | ((uint32_t)((fwd ? kj + 3 : kj - 1) + 8) << 2 | 1u) << 14;
+                    }
                 }
                 n2 += (uint32_t)__popcll(md);
                 if (n2 > EWC_CAP2 - 128u) drain2();
@@ -1079,6 +1261,30 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         if (n2 && !overflow) drain2();
         if (stats && lane == 0) { atomicMax(&stats[0], n1); atomicMax(&stats[1], nloc); atomicMax(&stats[2], npos); atomicAdd(&stats[4], 1u); }
         if (overflow) { if (lane == 0) atomicOr(a.err_flag, 1u); continue; }
+        if (WRITE) {
+            // first_j and best_score of the ORFs whose starts were written; an ORF that shares its first step with the one that wrote the
+            // tree gets a copy of that slice (same tree, same order keys) and of its two values
+            wcs_sync();
+            if (lane < nloc && s_xs[lane] != 0xffffu) {
+                uint32_t src_l = lane;
+                if (indels && a.indel_max >= 1 && orf_at[s_xs[lane]] != lane) src_l = orf_at[s_xs[lane]];
+                const uint32_t cnt_w = a_cnt[src_l];
+                if (cnt_w) {
+                    const uint64_t i = s_gi[lane];
+                    const uint32_t ja = (uint32_t)a_exa[src_l], jb = 0xffffffffu - (uint32_t)a_exb[src_l];
+                    const int jmin = (int)(fwd ? ja : jb), jmax = (int)(fwd ? jb : ja);
+                    a.orfs[i].first_j = jmin;
+                    if (jmax + 1 >= a.min_gene_len) a.orfs[i].best_score = mg_unord(a_best[src_l]);
+                    if (src_l != lane) {
+                        __threadfence();                // (the slice was written by other lanes of this wave: visible before it is read back)
+                        const uint32_t from = a_m0[src_l], to = a_m0[lane];
+                        for (uint32_t k = 0; k < cnt_w; k++) { a.starts[to + k] = a.starts[from + k]; a.errs[to + k] = a.errs[from + k]; a.keys[to + k] = a.keys[from + k]; }
+                    }
+                }
+            }
+            wcs_sync();
+            continue;
+        }
 
         // ---- Score_Orfs_Errors' verdict per ORF (:1647-1683): kept = one start above Start_Threshold (every pushed start passes
         //      the length test, glimmer-mg.cc:1821); first_j and best_score come from the write pass
@@ -1091,7 +1297,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 // ORFs that begin at the same step (Find_Orfs gives the reverse frames without a stop codon in front the same virtual
                 // stop) have the same call tree; the branches were credited to the one the step's table entry names
                 const uint32_t xs = s_xs[lane];
-                if (xs != 0xffffu && orf_at[xs] != lane) { src_l = orf_at[xs]; g_cnt = a_cnt[src_l]; }
+                if (xs != 0xffffu && indels && a.indel_max >= 1 && orf_at[xs] != lane) { src_l = orf_at[xs]; g_cnt = a_cnt[src_l]; }
             }
             const bool accepted = g_cnt && ((*acc_mask >> src_l) & 1ull);
             if (!(accepted_only && !accepted)) {        // (accepted_only: a rejected ORF's record is never read again, its count stays 0)

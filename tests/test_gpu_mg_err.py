@@ -61,10 +61,11 @@ def test_error_branch_matches_reference_push_order(gpu, oracle, nc, name):
     (dict(allow_subs=True), False),
 ])
 @pytest.mark.parametrize("kw", [dict(), dict(allow_truncated=False, min_gene_len=60), dict(ignore_score_len=150, start_codons=("atg", "rtg"))])
-@pytest.mark.parametrize("path", ["wave", "wave-walk", "wave-overflow", "wave-table", "tile", "tile-stage", "tile-overflow", "level", "level-q0", "flat", "level-overflow", "level-grow"])
+@pytest.mark.parametrize("path", ["wave", "wave-walk", "wave-mixed", "wave-overflow", "wave-table", "tile", "tile-stage", "tile-overflow", "level", "level-q0", "flat", "level-overflow", "level-grow"])
 def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path, monkeypatch, request_finalizers):
-    """path: one wave per (read, strand) with running sums and masks in its LDS (k_mg_err_wcount: the count pass without walks, breadth
-    first; k_mg_err_wave: the write pass, a stack of calls per wave; the default; the 1300- and 2100-bp
+    """path: one wave per (read, strand) with running sums and masks in its LDS (k_mg_err_wcount: both passes without walks, breadth
+    first; the default; wave-walk: k_mg_err_wave, a stack of calls per wave, for both passes; wave-mixed: the stack walker as the
+    write pass only; the 1300- and 2100-bp
     reads, longer than a wave takes, go to the per-ORF kernel), the same with the stack walker as the count pass, with a stack of 5
     entries (the call repeats on the level kernels) and on a batch without the long reads (the fp32 gene rows instead of the fp64 table),
     tile by tile with the running sums in LDS, one lane per event (option mg_err_tile; the 2100-bp read, longer than a tile,
@@ -74,7 +75,7 @@ def test_error_branch_every_orf_vs_oracle(gpu, oracle, nc, kw, ekw, with_q, path
     table -- q0: the three-row table instead), the per-ORF kernel alone, the level
     kernels with call arrays too small (everything repeats on the per-ORF kernel), and the same with the arrays allowed to
     grow (the count pass repeats with larger ones)"""
-    opts = {"wave": {"mg_err_wave": 1, "mg_err_tile": 0}, "wave-walk": {"mg_err_wave": 2, "mg_err_tile": 0},
+    opts = {"wave": {"mg_err_wave": 1, "mg_err_tile": 0}, "wave-walk": {"mg_err_wave": 2, "mg_err_tile": 0}, "wave-mixed": {"mg_err_wave": 3, "mg_err_tile": 0},
             "wave-overflow": {"mg_err_wave": 1, "mg_err_tile": 0, "mg_err_wave_q": 5}, "wave-table": {"mg_err_wave": 1, "mg_err_tile": 0},
             "tile": {"mg_err_tile": 1}, "tile-stage": {"mg_err_tile": 1, "mg_err_tile_q": -1}, "tile-overflow": {"mg_err_tile": 1, "mg_err_tile_q": 3},
             "level": {"mg_err_tile": 0, "mg_err_wave": 0}, "level-q0": {"mg_err_tile": 0, "mg_err_wave": 0, "mg_err_qonly": 0},
@@ -227,7 +228,7 @@ def test_accepted_only_is_the_full_result_filtered(gpu, nc, name, kw):
             got = gpu.mg_score_reads(nc, indep, reads, accepted_only=acc, **kw)
             for x, y in zip(want, got):
                 assert x.tobytes() == y.tobytes()
-    with gpu.option("mg_err_tile", 0), gpu.option("mg_err_wave", 2):    # (... the stack walker as the count pass)
+    with gpu.option("mg_err_tile", 0), gpu.option("mg_err_wave", 2):    # (... the stack walker for both passes)
         for want, acc in ((full, False), (kept, True)):
             got = gpu.mg_score_reads(nc, indep, reads, accepted_only=acc, **kw)
             for x, y in zip(want, got):
