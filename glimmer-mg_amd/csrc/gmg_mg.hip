@@ -131,6 +131,7 @@ struct MgArgs {
     const uint8_t *walk_q;       // [total + 8] the qualities, last base first (forward walks; reverse walks read a.qual)
     uint64_t walk_stride;
     int ew_slack;                // k_mg_err_wave / _wcount: gene32 and qual have 64 spare entries on both sides (unpredicated loads)
+    int q454;                    // ... Set_Quality_454 is computed in the kernel from the bases (no quality file): a.qual is not read
 };
 
 // Ch_Mask (src/Common/gene.cc:954-995)
@@ -3525,12 +3526,20 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     // (in front of the ORF scan's count pass: behind it the launch waited for the host to come back from the scan's total -- it then
     // ran beside the ORF write pass, both at half speed, 1 ms on the error branch's critical path; here it runs in the six-frame
     // kernel's shadow: no LDS, few registers)
-    if (err_mode == 1 && a.total && !find_only) {       // Set_Quality_454 / Clean_Quality_454: needs the reads only
-        if (prm->quality) MG_TRY(hipMemcpyAsync(d_user_q, prm->quality, a.total, hipMemcpyHostToDevice, s3));
-        MG_TRY(gmg_pool_alloc((void **)&d_walk_q, a.total + 8));
-        hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(nr * 64)), dim3(256), 0, s3, a, d_user_q, d_qual + 64, d_walk_q);
-        MG_TRY(hipGetLastError());
+    // The wave kernels compute Set_Quality_454 themselves from the bases they hold (no quality file, every read short enough for them):
+    // no quality kernel, no 2 B/base of quality arrays written and read back; a fall-back to the level kernels makes them then
+    auto build_qualities = [&](hipStream_t st) -> hipError_t {
+        hipError_t e = hipSuccess;
+        if (prm->quality) e = hipMemcpyAsync(d_user_q, prm->quality, a.total, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && !d_walk_q) e = gmg_pool_alloc((void **)&d_walk_q, a.total + 8);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_mg_quality, dim3(grid_for(nr * 64)), dim3(256), 0, st, a, d_user_q, d_qual + 64, d_walk_q);
         a.walk_q = d_walk_q;
+        return hipGetLastError();
+    };
+    a.q454 = err_mode == 1 && err_wave && !prm->quality && reads->max_len <= (uint64_t)ew_cap && gmg_opt(GMG_OPT_MG_ERR_WAVE) != 0 ? 1 : 0;
+    if (err_mode == 1 && a.total && !find_only && !a.q454) {   // Set_Quality_454 / Clean_Quality_454: needs the reads only
+        MG_TRY(build_qualities(s3));
         tm.lap("quality values");
     }
     MG_TRY(gmg_pool_alloc((void **)&d_read_cnt, (nr + 1) * 4));
@@ -3724,7 +3733,30 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         static const uint32_t bounds_c[5] = {0, 384, 448, 512, EW_MAX_CAP}, bounds_w[3] = {0, 512, EW_MAX_CAP};
         const uint32_t *bounds = wcount ? bounds_c : bounds_w;
         const int n_cls = wcount ? 4 : 2;
+        // the classes' launches go to streams of their own (forked from st, joined into it): a class's last work-groups run beside the
+        // next class's first instead of holding the device for the launch's tail
+        static thread_local hipStream_t cls_stream[16][3] = {};
+        static thread_local hipEvent_t cls_fork[16] = {}, cls_done[16][3] = {};
+        const bool forked = !tm.on && dev_id >= 0 && dev_id < 16 && !gmg_opt(GMG_OPT_MG_ONE_STREAM);
+        if (forked) {
+            if (!cls_fork[dev_id]) {
+                e = hipEventCreateWithFlags(&cls_fork[dev_id], hipEventDisableTiming);
+                for (int k = 0; k < 3 && e == hipSuccess; k++) {
+                    e = hipStreamCreateWithFlags(&cls_stream[dev_id][k], hipStreamNonBlocking);
+                    if (e == hipSuccess) e = hipEventCreateWithFlags(&cls_done[dev_id][k], hipEventDisableTiming);
+                }
+                if (e != hipSuccess) return e;
+            }
+            e = hipEventRecord(cls_fork[dev_id], st);
+            if (e != hipSuccess) return e;
+        }
+        bool used[3] = {false, false, false};
+        hipStream_t st0 = st;
         for (int cls = 0; cls < n_cls; cls++) {
+            if (forked && cls > 0) {
+                st = cls_stream[dev_id][cls - 1];
+                if (!used[cls - 1]) { e = hipStreamWaitEvent(st, cls_fork[dev_id], 0); if (e != hipSuccess) return e; used[cls - 1] = true; }
+            } else st = st0;
             const uint32_t lo = bounds[cls], hi = bounds[cls + 1] < ew_cap ? bounds[cls + 1] : ew_cap;
             if (hi <= lo || reads->max_len <= lo || reads->min_len > hi) continue;
             const uint32_t bytes = wcount ? ewc_layout(bounds[cls + 1], write).bytes : ew_layout(hi, ew_qcap, write).bytes;
@@ -3749,6 +3781,12 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }
+        for (int k = 0; k < 3; k++)
+            if (used[k]) {
+                e = hipEventRecord(cls_done[dev_id][k], cls_stream[dev_id][k]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(st0, cls_done[dev_id][k], 0);
+                if (e != hipSuccess) return e;
+            }
         return hipSuccess;
     };
     const size_t et_lds = sizeof(EtLds<MG_ET_CAP>);
@@ -3831,6 +3869,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         if (st[0] && (err_tile || err_wave)) {
             // a work-group's call slab / a wave's call stack was full: the batch repeats on the level kernels (their call arrays grow with the batch)
             err_tile = err_wave = false;
+            if (a.q454) { a.q454 = 0; MG_TRY(build_qualities(s2)); }
             if (a.pfx) MG_TRY(build_run_tables(s2));
             MG_TRY(build_walk_rows(s2));
             MG_TRY(alloc_level_scratch());

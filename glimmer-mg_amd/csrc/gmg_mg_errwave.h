@@ -86,6 +86,7 @@ struct EwRegs {
     double fv[KMAX][3];          // else: the caller's Frame_Scores
     uint32_t qv[KMAX];           // qualities (255 without -i)
     uint64_t win;                // 32 bases from the lowest base the lane looks at
+    uint64_t winq;               // Set_Quality_454 in the kernel: 32 bases from four bases lower (a homopolymer run is followed 5 bases back)
     int64_t g0;                  // base of the lane's first step
     uint32_t K, tb;              // steps per lane, the lane's first step
     float ntv[4];                // per-read null models: the lane's four floats of the read's table (copied to LDS before the sums)
@@ -101,7 +102,10 @@ __device__ __forceinline__ void ew_load(const MgArgs &a, const uint64_t off, con
     R.K = K; R.tb = tb;
     // the walk codes of steps tb - 2 .. tb + K + 1 come from one 32-base window
     const int64_t g_lo = fwd ? (int64_t)(off + n - 1) - (int64_t)(tb + K + 1) : (int64_t)(off + tb) - 2;
-    R.win = dev_window_bits(a.packed, g_lo);
+    if (indels && a.q454) {                             // (one load serves both: the lane's K + 4 fields begin four fields up)
+        R.winq = dev_window_bits(a.packed, g_lo - 4);
+        R.win = R.winq >> 8;
+    } else R.win = dev_window_bits(a.packed, g_lo);
     const int64_t g0 = fwd ? (int64_t)(off + n - 1) - (int64_t)tb : (int64_t)(off + tb);
     R.g0 = g0;
     if (G32 && a.ew_slack) {
@@ -109,6 +113,7 @@ __device__ __forceinline__ void ew_load(const MgArgs &a, const uint64_t off, con
         // the lane's pointer + a constant (what lies outside the read is masked where it is used)
         const float *p0 = a.gene32 + (uint64_t)(fwd ? 0 : 3) * a.fs_stride + g0, *p1 = p0 + a.fs_stride, *p2 = p1 + a.fs_stride;
         const uint8_t *pq_ = a.qual + g0;
+        const bool ldq = indels && !a.q454;
         if (fwd) {
 #pragma unroll
             for (int e = 0; e < KMAX; e++) {
@@ -116,7 +121,7 @@ __device__ __forceinline__ void ew_load(const MgArgs &a, const uint64_t off, con
                 R.gv[e][0] = R.gv[e][1] = R.gv[e][2] = 0.0f;
                 if ((uint32_t)e < K) {
                     R.gv[e][0] = p0[-e]; R.gv[e][1] = p1[-e]; R.gv[e][2] = p2[-e];
-                    if (indels) R.qv[e] = pq_[-e];
+                    if (ldq) R.qv[e] = pq_[-e];
                 }
             }
         } else {
@@ -126,7 +131,7 @@ __device__ __forceinline__ void ew_load(const MgArgs &a, const uint64_t off, con
                 R.gv[e][0] = R.gv[e][1] = R.gv[e][2] = 0.0f;
                 if ((uint32_t)e < K) {
                     R.gv[e][0] = p0[e]; R.gv[e][1] = p1[e]; R.gv[e][2] = p2[e];
-                    if (indels) R.qv[e] = pq_[e];
+                    if (ldq) R.qv[e] = pq_[e];
                 }
             }
         }
@@ -144,7 +149,7 @@ __device__ __forceinline__ void ew_load(const MgArgs &a, const uint64_t off, con
 #pragma unroll
             for (int f = 0; f < 3; f++) R.fv[e][f] = in ? a.fs[(uint64_t)((fwd ? 0 : 3) + f) * a.fs_stride + (uint64_t)g] : 0.0;
         }
-        if (indels && in) R.qv[e] = a.qual[g];
+        if (indels && !a.q454 && in) R.qv[e] = a.qual[g];
     }
 }
 
@@ -156,9 +161,12 @@ template <bool G32, int KMAX, bool NTL = false>
 __device__ __forceinline__ void ew_build(const MgArgs &a, const uint64_t r, const uint64_t off, const uint32_t n, const bool fwd, const bool indels,
                                          const uint32_t lane, const EwRegs<G32, KMAX> &R, double *S, const uint32_t srow, uint64_t *Mstart,
                                          uint64_t *Mstop, uint64_t *Mlow, const uint32_t nw, uint64_t *zero, const uint32_t n_zero, uint8_t *s_q,
-                                         uint32_t &f_low_out, const float *nt_lds = nullptr)
+                                         uint32_t &f_low_out, const float *nt_lds = nullptr, uint32_t *q_out = nullptr)
 {
     const uint32_t K = R.K, tb = R.tb;
+    uint32_t Rq[KMAX];                                  // (the qualities computed here, for the caller's list of low-quality bases)
+#pragma unroll
+    for (int e = 0; e < KMAX; e++) Rq[e] = R.qv[e];
     // (the null model's table: the wave's copy in LDS when the batch has one null model, else the read's own in global memory)
     const float *nt = !G32 ? nullptr : NTL ? nt_lds : a.null_tab + (size_t)(a.read_null ? a.read_null[r] : 0u) * MG_NULL_FLOATS;
     if (lane < 3) S[lane * srow] = 0.0;
@@ -171,6 +179,15 @@ __device__ __forceinline__ void ew_build(const MgArgs &a, const uint64_t r, cons
     double P[KMAX][3];
     double acc3[3] = {0.0, 0.0, 0.0};
     uint32_t f_start = 0, f_stop = 0, f_low = 0;
+    // Set_Quality_454 (glimmer-mg.cc:1865-1906) from the bases themselves: the last base of a homopolymer run of `run` bases gets
+    // 31 - 5 run (6 from six on), every other base 31.  winq: base index k = the lane's lowest base - 6 + k; eq: bit 2 k set when
+    // base k equals base k - 1; a run is followed down the READ (forward coordinates), whichever strand the wave walks.
+    const bool q454 = indels && a.q454;
+    uint64_t eq = 0;
+    if (q454) {
+        const uint64_t x = R.winq ^ (R.winq << 2);
+        eq = ~(x | x >> 1) & 0x5555555555555554ull;
+    }
 #pragma unroll
     for (int e = 0; e < KMAX; e++) {
         const uint32_t t = tb + (uint32_t)e;
@@ -193,10 +210,26 @@ __device__ __forceinline__ void ew_build(const MgArgs &a, const uint64_t r, cons
         const bool codon = in && t + 2 < n;
         if (codon && ((a.fwd_start >> idx) & 1ull)) f_start |= 1u << e;
         if (codon && ((a.fwd_stop >> idx) & 1ull)) f_stop |= 1u << e;
-        if (in && indels && R.qv[e] <= (uint32_t)a.indel_q_thr) f_low |= 1u << e;
-        if (s_q && indels && in) s_q[t] = (uint8_t)R.qv[e];
+        uint32_t q = R.qv[e];
+        if (q454) {
+            const uint32_t kq = fwd ? 6u + K - 1u - (uint32_t)e : 6u + (uint32_t)e;       // the base's index in winq
+            const uint32_t si = fwd ? n - 1u - t : t;                           // ... and its position in the read
+            // equal pairs at k, k - 1, ..: the even bits from bit 2 k downwards, brought to the top of the word
+            const uint64_t z = (eq << (62u - 2u * kq)) | 0xAAAAAAAAAAAAAAAAull;
+            uint32_t run = 1u + (((uint32_t)__builtin_clzll(~z | 1ull) - 1u) >> 1);
+            if (run > si + 1u) run = si + 1u;                                   // (not beyond the read's first base)
+            const bool inside = si + 1u < n && ((eq >> (2u * kq + 2u)) & 1ull);   // the next base continues the run
+            q = inside ? 31u : run < 6u ? 31u - 5u * run : 6u;
+        }
+        if (in && indels && q <= (uint32_t)a.indel_q_thr) f_low |= 1u << e;
+        if (s_q && indels && in) s_q[t] = (uint8_t)q;
+        if (q454) Rq[e] = q;
     }
     f_low_out = f_low;
+    if (q_out) {
+#pragma unroll
+        for (int e = 0; e < KMAX; e++) q_out[e] = Rq[e];
+    }
     // lane totals -> true classes -> scan -> back
     double tot[3], basec[3];
 #pragma unroll
@@ -953,7 +986,8 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
             for (int k = 0; k < 4; k++) s_nt[4u * lane + (uint32_t)k] = R.ntv[k];       // (s_nt has four spare floats)
             wcs_sync();
         }
-        ew_build<G32, KMAX, true>(a, r, off, n, fwd, indels, lane, R, S, srow, Mstart, Mstop, Mlow, nw - 1, msk, 3 * nw, (uint8_t *)nullptr, f_low, s_nt);
+        uint32_t qv_lane[KMAX];
+        ew_build<G32, KMAX, true>(a, r, off, n, fwd, indels, lane, R, S, srow, Mstart, Mstop, Mlow, nw - 1, msk, 3 * nw, (uint8_t *)nullptr, f_low, s_nt, qv_lane);
         uint32_t npos = 0;
         bool overflow = false;
         if (indels) {
@@ -964,7 +998,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 uint32_t o = incl - mine;
 #pragma unroll
                 for (int e = 0; e < KMAX; e++)
-                    if ((f_low >> e) & 1u) { plist[o] = (uint16_t)(R.tb + (uint32_t)e); pq[o] = (uint8_t)R.qv[e]; o++; }
+                    if ((f_low >> e) & 1u) { plist[o] = (uint16_t)(R.tb + (uint32_t)e); pq[o] = (uint8_t)qv_lane[e]; o++; }
                 // low-quality bases in front of every 64-step word
                 const uint32_t pw = lane < nw - 1 ? (uint32_t)__popcll(Mlow[lane]) : 0u, iw = ewc_scan_u32(pw);
                 if (lane < nw) cum[lane] = (uint16_t)(iw - pw);
