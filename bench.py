@@ -203,7 +203,8 @@ def cpu_all_cores(n_reads_each, L, seed, gc):
 def device_digest(out, total, first_read, n_reads, L):
     """XOR and position-weighted sum of the sample's slice of the device table, computed on the device"""
     import torch
-    v = out.view(6, total)[:, first_read * L:(first_read + n_reads) * L].contiguous().view(torch.int64).ravel()
+    # (the table of the call that ran last: 6 rows of `total` doubles at the buffer's start -- with --batches the buffer is sized by the largest batch)
+    v = out[:6 * total].view(6, total)[:, first_read * L:(first_read + n_reads) * L].contiguous().view(torch.int64).ravel()
     w = 2 * torch.arange(v.numel(), dtype=torch.int64, device=v.device) + 1
     mix = int((v * w).sum().item()) & (2 ** 64 - 1)                       # int64 arithmetic wraps: mod 2^64
     x = v.cpu().numpy().view("uint64")

@@ -162,16 +162,16 @@ def test_one_gpus_share_of_configs2_in_batches(gpu, oracle, nc):
 
 def test_bench_batches_one_reused_table(gpu):
     """bench.py --batches: a rank's reads scored as B batches into ONE reused table (how BASELINE configs[2]'s 12.5M reads per GPU
-    run: --reads 12500000 --batches 13) -- here 30,000 reads in 4 batches (the last one shorter): the line's contract fields, the
+    run: --reads 12500000 --batches 13) -- here 30,001 reads in 4 batches (7,501 + 7,501 + 7,501 + 7,498: the last one shorter): the line's contract fields, the
     workload string, the check on the LAST batch (bit-exact against the CPU), value = all reads' bases over the timed region"""
     import json
     import subprocess
     import sys
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "30000", "--batches", "4", "--steps", "3", "--warmup", "1",
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "30001", "--batches", "4", "--steps", "3", "--warmup", "1",
                           "--cpu-reads", "500", "--no-cli", "--no-extras"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     line = json.loads(res.stdout.decode().strip().splitlines()[-1])
-    assert line["config"]["batches"] == 4 and line["config"]["reads_per_gpu"] == 30000 and "in 4 batches of <= 7,500 reads" in line["config"]["workload"]
-    assert line["value"] and abs(line["value"] - 30000 * 500 / (line["ms_per_step"] * 1e-3) / 1e6) < 0.01 * line["value"]   # all four batches per step
+    assert line["config"]["batches"] == 4 and line["config"]["reads_per_gpu"] == 30001 and "in 4 batches of <= 7,501 reads" in line["config"]["workload"]
+    assert line["value"] and abs(line["value"] - 30001 * 500 / (line["ms_per_step"] * 1e-3) / 1e6) < 0.01 * line["value"]   # all four batches per step
     assert "MISMATCH" not in line["check"] and line["check"].count("bit-exact") == 2
     assert line["roofline"]["frac"] > 0 and line["scaling"] == "weak" and line["dtype"] == "f64"
