@@ -40,6 +40,10 @@ say classes;      for m in 1 distinct; do BENCH_PER_GROUP_CALLS=0 BENCH_SAME_MOD
 for m in 1 distinct; do BENCH_ERR=indel BENCH_PER_GROUP_CALLS=0 BENCH_SAME_MODEL=$m timeout -k 10 300 python3 tests/bench/bench_classes.py 1000000 64 100 5 >> $R/classes_bench_indel.jsonl 2>> $R/misc.err; done
 say cli;          timeout -k 10 600 python3 tests/bench/bench_cli.py 200000 > $R/cli_bench.json 2>> $R/misc.err
 say stress;       timeout -k 10 400 python3 tests/bench/stress_mg.py 20000 5 > $R/stress_mg.txt 2>&1; timeout -k 10 300 python3 tests/bench/stress_mg_fused.py > $R/stress_mg_fused.txt 2>&1
-say tests;        timeout -k 10 1100 python3 -m pytest tests -m gpu -q -x > $R/pytest_gpu.txt 2>&1; tail -3 $R/pytest_gpu.txt
+say batches;      timeout -k 10 400 python3 bench.py --reads 12500000 --batches 13 --steps 3 --warmup 1 --no-extras --no-cli > $R/bench_configs2_one_gpu.json 2> $R/bench3.err
 say done-c
+fi
+if [ $PART = d ]; then
+say tests;        timeout -k 10 1150 python3 -m pytest tests -m gpu -q -x > $R/pytest_gpu.txt 2>&1; tail -3 $R/pytest_gpu.txt
+say done-d
 fi
