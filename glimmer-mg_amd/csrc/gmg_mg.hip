@@ -1663,13 +1663,6 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
             }
         }
         __syncthreads();                                // (the null tables of the tile's reads, the edge marks: stage 2 reads both)
-        if (G32 && PRN && nfit) {                       // a null model per read: its table has arrived with stage 1
-            for (uint32_t r = threadIdx.x; r < nfit; r += BLOCK) {
-                const int rs = (int)s_roff[r], n = (int)s_roff[r + 1] - rs;
-                partial_fix(r, rs, n, s_nullm[r < NC ? r : 0u]);
-            }
-            __syncthreads();
-        }
         MT_STAMP(2);                                    // stage 1
         // ---- stage 2: the scan.  Lane (class c, part jl) owns elements u = ub + 3 i, i < EL: every third base of 27
         // consecutive ones.  The ten codons of its class that surround them come out of ONE 64-bit window of the packed bases as
@@ -1737,10 +1730,32 @@ __global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 
                             if (!PRN) return s_nulld[off];
                             return (double)s_nullm[rl < NC ? rl : 0u][off];       // (mg_run lets a tile take MT_NC reads at most then)
                         };
-                        // (the partial windows at the read's end were settled in front of the scan -- partial_fix: full windows everywhere here)
-                        const uint32_t v1 = (uint32_t)(win >> (FWD ? bitb : bitb - 4)) & 63u, v2 = (uint32_t)(win >> (bitb - 2)) & 63u;
-                        const uint32_t v0 = (uint32_t)(win >> (FWD ? bitb - 4 : bitb)) & 63u;
-                        const double nsum = (nullf(64 + v1) + nullf(128 + v2)) + nullf(v0);
+                        // (one null model: the partial windows at the read's end were settled in front of the scan -- partial_fix: full
+                        // windows everywhere here.  A null model per read keeps the branch: its tables arrive in LDS with stage 1, and
+                        // a pass over the tile's reads behind that barrier costs more than the branch -- 11.36 against 10.73 ms per
+                        // 1 M reads, the fix from the set in L2 11.64: profiles/r05_prn_ab.txt)
+                        double nsum;
+                        if (PRN && (FWD ? si + 2 >= n : si < 2)) {                  // one of them is a partial window
+                            nsum = 0.0;
+#pragma unroll
+                            for (int t = 0; t < 3; t++) {                          // (no branches in here: selects)
+                                const int fr = t == 0 ? 1 : t == 1 ? 2 : 0;
+                                const int xs = FWD ? si - t : si + t;              // the term's base in its read
+                                const int j = FWD ? n - 1 - xs : xs;
+                                const int bx = bitb + (FWD ? -2 * t : 2 * t);      // bit position of S[x]
+                                const uint32_t c0 = (uint32_t)(win >> bx) & 3u;
+                                const uint32_t c1 = (uint32_t)(win >> (FWD ? bx + 2 : bx - 2)) & 3u;
+                                const uint32_t b0c = FWD ? c0 : c0 ^ 3u, b1c = FWD ? c1 : c1 ^ 3u;
+                                const uint32_t v = (uint32_t)(win >> (FWD ? bx : bx - 4)) & 63u;
+                                const uint32_t off = j >= 2 ? fr * 64 + v : 192u + fr * 20 + (j == 1 ? 4u + (b1c | b0c << 2) : b0c);
+                                const double nv = nullf(off);
+                                nsum += xs >= 0 && xs < n ? nv : 0.0;              // (beyond the read: T is never used then)
+                            }
+                        } else {
+                            const uint32_t v1 = (uint32_t)(win >> (FWD ? bitb : bitb - 4)) & 63u, v2 = (uint32_t)(win >> (bitb - 2)) & 63u;
+                            const uint32_t v0 = (uint32_t)(win >> (FWD ? bitb - 4 : bitb)) & 63u;
+                            nsum = (nullf(64 + v1) + nullf(128 + v2)) + nullf(v0);
+                        }
                         T -= nsum;
                     }
                     if (st) { acc = 0.0; p = (u << 12) | MT_REAL | MT_BLK; }
@@ -2804,6 +2819,7 @@ __global__ __launch_bounds__(256) void k_mg_err_begin(MgArgs a, const int accept
 
 #include "gmg_mg_errtile.h"
 #include "gmg_mg_errwave.h"
+#include "gmg_mg_orfbits.h"
 
 __global__ __launch_bounds__(256) void k_mg_seg_bounds(const gmg_mg_orf *orfs, uint64_t n, uint32_t *seg_begin, uint32_t *seg_end)
 {
@@ -3546,6 +3562,25 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     MG_TRY(hipMemsetAsync(d_read_cnt, 0, (nr + 1) * 4, s2));
     MG_TRY(gmg_pool_alloc((void **)&res->d_read_orf_off, (nr + 1) * 8));
     a.read_cnt = d_read_cnt;
+    // Find_Orfs on bit masks (k_mg_find_orfs_bits): a wave per window of whole reads under its OB_WORDS x 32 bases, ten reads at a time.
+    // Uniform batches: up to ten reads per window; ragged ones: the reads that begin in a stretch of about ten mean read lengths (and
+    // no more than the window holds with the longest read at its end).  Not with reads beyond OB_MAX_LEN.
+    const bool orf_bits = !general && nr && a.total && gmg_opt(GMG_OPT_MG_ORFS_BITS) && reads->max_len <= OB_MAX_LEN && reads->max_len > 0;
+    uint32_t ob_win_bases = 0, ob_rpw = 0, ob_grid = 1;
+    uint64_t ob_windows = 0;
+    if (orf_bits) {
+        if (reads->uniform_len > 0) {
+            ob_rpw = (uint32_t)((OB_SPAN - 31) / reads->uniform_len);
+            if (ob_rpw > OB_GROUP) ob_rpw = OB_GROUP;
+            ob_windows = (nr + ob_rpw - 1) / ob_rpw;
+        } else {
+            const uint64_t room = OB_SPAN - 31 - reads->max_len, want = (a.total * 19 / 2) / nr;      // 9.5 mean lengths
+            ob_win_bases = (uint32_t)(want < room ? (want > 0 ? want : 1) : room);
+            ob_windows = (a.total + ob_win_bases - 1) / ob_win_bases;
+        }
+        const uint64_t blocks = (ob_windows + OB_WAVES - 1) / OB_WAVES;
+        ob_grid = (uint32_t)(blocks < 256 * 32 ? blocks : 256 * 32);
+    }
     int32_t *d_ign = nullptr;                           // general form: the regions' lo values, then their hi values; [2 n]: the failure flag
     const int n_ign = general ? prm->n_ignore_regions : 0;
     if (general) {
@@ -3557,6 +3592,8 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         MG_TRY(hipMemsetAsync(d_ign + 2 * n_ign, 0, 4, s2));
         if (nr) hipLaunchKernelGGL(k_find_orfs_general<false>, dim3(grid_for(nr)), dim3(64), 0, s2, a, prm->circular ? 1 : 0, n_ign, d_ign, d_ign + n_ign,
                                    (uint32_t *)(d_ign + 2 * n_ign));
+    } else if (orf_bits) {
+        hipLaunchKernelGGL(k_mg_find_orfs_bits<false>, dim3(ob_grid), dim3(64 * OB_WAVES), 0, s2, a, ob_windows, ob_win_bases, ob_rpw);
     } else if (nr) hipLaunchKernelGGL(k_mg_find_orfs<false>, dim3(grid_for(nr)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
     rc = mg_scan(d_read_cnt, res->d_read_orf_off, nr, &res->n_orfs, s2);
@@ -3591,6 +3628,8 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         if (failed)     // Wrap_Around_Back: assert (pos > 0) -- a circular sequence with a reverse frame that has no stop codon (behind the last ignore region)
             return fail(gmg_set_error(GMG_EINVAL, "gmg_find_orfs: a circular sequence has a reverse reading frame without a stop codon (the reference aborts: "
                                                   "Wrap_Around_Back, glimmer_base.cc:2793)"));
+    } else if (orf_bits) {
+        hipLaunchKernelGGL(k_mg_find_orfs_bits<true>, dim3(ob_grid), dim3(64 * OB_WAVES), 0, s2, a, ob_windows, ob_win_bases, ob_rpw);
     } else if (nr && gmg_opt(GMG_OPT_MG_ORFS_EVENTS)) {
         const uint64_t blocks = (nr + 127) / 128;
         hipLaunchKernelGGL(k_mg_find_orfs_ev, dim3((unsigned)(blocks < 256 * 64 ? blocks : 256 * 64)), dim3(128), 0, s2, a);
