@@ -7,7 +7,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(PKG, "lib", "libgmg.so")
 SOURCES = ["csrc/gmg_api.hip", "csrc/gmg_kernels.hip", "csrc/gmg_frame6.hip", "csrc/gmg_orfs.hip", "csrc/gmg_mg.hip", "csrc/gmg_ingest.hip", "csrc/gmg_strings.hip", "csrc/gmg_train.hip", "host/icm.cc", "host/icm_train.cc", "host/gmg_icm_c.cc", "host/gmg_shard.cc", "host/gmg_classes.cc"]
-HEADERS = ["csrc/gmg_internal.h", "csrc/gmg_device.h", "csrc/gmg_mg_errtile.h", "csrc/gmg_mg_errwave.h", "csrc/gmg_mg_orfbits.h", "host/icm.hh", "../include/gmg.h", "../include/gmg_icm.h"]
+HEADERS = ["csrc/gmg_internal.h", "csrc/gmg_device.h", "csrc/gmg_scan.h", "csrc/gmg_mg_errtile.h", "csrc/gmg_mg_errwave.h", "csrc/gmg_mg_orfbits.h", "host/icm.hh", "../include/gmg.h", "../include/gmg_icm.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
 

@@ -3,7 +3,7 @@
 // No CPU fallback: without a gfx950 device every scoring entry point fails loudly.
 
 #include "gmg_internal.h"
-#include <hipcub/hipcub.hpp>
+#include "gmg_scan.h"
 
 #include <ctype.h>
 #include <stdarg.h>
@@ -697,10 +697,7 @@ extern "C" int gmg_reads_select(const gmg_reads *reads, const uint64_t *idx, uin
     SEL_TRY(hipMemcpyAsync(d_stats, stats0, sizeof stats0, hipMemcpyHostToDevice, s));
     if (n) SEL_TRY(hipMemcpyAsync(d_idx, idx, n * 8, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_sel_len, dim3((unsigned)((n + 256) / 256 < 512 ? (n + 256) / 256 : 512)), dim3(256), 0, s, reads->d_off, d_idx, n, reads->n_reads, d_len, d_stats);
-    size_t tmp_bytes = 0;
-    SEL_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_len, d_off, (int)(n + 1), s));
-    SEL_TRY(gmg_pool_alloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
-    SEL_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_len, d_off, (int)(n + 1), s));
+    SEL_TRY((gmg_scan_excl<uint64_t, uint64_t>(d_len, d_off, n + 1, s)));
     SEL_TRY(hipMemcpyAsync(&stats[5], d_off + n, 8, hipMemcpyDeviceToHost, s));
     SEL_TRY(hipMemcpyAsync(stats, d_stats, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     SEL_TRY(hipStreamSynchronize(s));
@@ -733,7 +730,7 @@ extern "C" int gmg_reads_select(const gmg_reads *reads, const uint64_t *idx, uin
     gmg_pool_release(d_idx);
     gmg_pool_release(d_len);
     gmg_pool_release(d_stats);
-    gmg_pool_release(d_tmp);
+    if (d_tmp) gmg_pool_release(d_tmp);
     r->min_len = n ? stats[0] : 0;
     r->max_len = stats[1];
     r->n_over_512 = stats[2];

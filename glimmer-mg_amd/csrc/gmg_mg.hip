@@ -2817,6 +2817,7 @@ __global__ __launch_bounds__(256) void k_mg_err_begin(MgArgs a, const int accept
     }
 }
 
+#include "gmg_scan.h"
 #include "gmg_mg_errtile.h"
 #include "gmg_mg_errwave.h"
 #include "gmg_mg_orfbits.h"
@@ -2887,11 +2888,6 @@ __global__ __launch_bounds__(256) void k_mg_keep_reads(const uint64_t *read_orf_
 {
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_reads; r += (uint64_t)gridDim.x * blockDim.x)
         out[r] = new_orf[read_orf_off[r]];              // new_orf has n_orfs + 1 entries: the last one is the total
-}
-
-__global__ __launch_bounds__(256) void k_mg_widen(const uint32_t *in, uint64_t *out, uint64_t n)
-{
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = in[i];
 }
 
 // Frame_Scores with one null model per read from the complete fp32 gene rows: out[row][g] = (double) gene - (double) null
@@ -3012,20 +3008,12 @@ static unsigned grid_for(uint64_t n)
 }
 
 // exclusive sum of cnt[0..n] (cnt[n] = 0) into off[0..n] as 64-bit offsets; *total = off[n]
+// d_off[i] = d_cnt[0] + ... + d_cnt[i-1], i <= n, and *total = d_off[n] (synchronises s): one launch (gmg_scan.h)
 static int mg_scan(uint32_t *d_cnt, uint64_t *d_off, uint64_t n, uint64_t *total, hipStream_t s)
 {
-    uint64_t *d_wide = nullptr;
-    void *d_tmp = nullptr;
-    size_t tmp_bytes = 0;
-    GMG_HIP(gmg_pool_alloc((void **)&d_wide, (n + 1) * 8));
-    hipLaunchKernelGGL(k_mg_widen, dim3(grid_for(n + 1)), dim3(256), 0, s, d_cnt, d_wide, n + 1);
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_wide, d_off, (int)(n + 1), s);
-    if (e == hipSuccess) e = gmg_pool_alloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
-    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_wide, d_off, (int)(n + 1), s);
+    hipError_t e = gmg_scan_excl<uint32_t, uint64_t>(d_cnt, d_off, n + 1, s);
     if (e == hipSuccess) e = hipMemcpyAsync(total, d_off + n, 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    gmg_pool_release(d_wide);
-    if (d_tmp) gmg_pool_release(d_tmp);
     if (e != hipSuccess) return gmg_set_error(GMG_EHIP, "gmg_mg_score_reads: scan: %s", hipGetErrorString(e));
     return GMG_OK;
 }

@@ -7,7 +7,7 @@
 
 #include "gmg_device.h"
 
-#include <hipcub/hipcub.hpp>
+#include "gmg_scan.h"
 
 #include <float.h>
 #include <stdlib.h>
@@ -752,8 +752,8 @@ extern "C" int gmg_orfs_upload(const gmg_reads *reads, const gmg_orf *orfs, uint
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_nst, (n + 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_coff, (n + 1) * 4);
     if (e == hipSuccess) e = hipMemset(b->d_nst, 0, (n + 1) * 4);
-    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(nullptr, b->scan_tmp_bytes, b->d_nst, b->d_coff, (int)(n + 1));
-    if (e == hipSuccess) e = hipMalloc(&b->d_scan_tmp, b->scan_tmp_bytes ? b->scan_tmp_bytes : 1);
+    b->d_scan_tmp = nullptr;
+    b->scan_tmp_bytes = 0;
     if (e == hipSuccess && n) e = hipMemcpy(b->d_orfs, orfs, n * sizeof(gmg_orf), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_start_off, start_off.data(), (n + 1) * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) { gmg_orf_batch_free(b); return gmg_set_error(GMG_ENOMEM, "gmg_orfs_upload: %s", hipGetErrorString(e)); }
@@ -939,8 +939,7 @@ extern "C" int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *nul,
     }
     GMG_HIP(hipGetLastError());
     // only the used slots leave the GPU: prefix sum of the per-ORF counts, then pack the lists back to back
-    size_t tmp_bytes = b->scan_tmp_bytes;
-    GMG_HIP(hipcub::DeviceScan::ExclusiveSum(b->d_scan_tmp, tmp_bytes, b->d_nst, b->d_coff, (int)(b->n + 1), s));
+    GMG_HIP((gmg_scan_excl<uint32_t, uint32_t>(b->d_nst, b->d_coff, b->n + 1, s)));
     uint32_t total = 0;
     GMG_HIP(hipMemcpyAsync(&total, b->d_coff + b->n, 4, hipMemcpyDeviceToHost, s));
     GMG_HIP(hipStreamSynchronize(s));
