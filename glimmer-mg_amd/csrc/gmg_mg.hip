@@ -519,9 +519,10 @@ __global__ __launch_bounds__(64) void k_find_orfs_general(MgArgs a, const int ci
 // Same records, same order; the count pass stays k_mg_find_orfs<false> (30 registers: it runs beside the six-frame kernel).
 // ---------------------------------------------------------------------------------------------------
 #define MG_EV_CH 64
-__global__ __launch_bounds__(128) void k_mg_find_orfs_ev(MgArgs a)
+#define MG_EV_LANES 64            // one-wave work-groups (8 KB of LDS: one of them fits beside the six-frame kernel's work-group on a CU)
+__global__ __launch_bounds__(MG_EV_LANES) void k_mg_find_orfs_ev(MgArgs a)
 {
-    __shared__ uint16_t s_q[MG_EV_CH][128];             // events of the chunk: position in the chunk | set bits << 8
+    __shared__ uint16_t s_q[MG_EV_CH][MG_EV_LANES];             // events of the chunk: position in the chunk | set bits << 8
     __shared__ uint8_t s_evt[64];                       // by codon index: bit 0 forward start, 1 reverse start, 2 forward stop, 3 reverse stop
     if (threadIdx.x < 64) {
         const uint64_t bit = 1ull << threadIdx.x;
@@ -3619,8 +3620,8 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     } else if (orf_bits) {
         hipLaunchKernelGGL(k_mg_find_orfs_bits<true>, dim3(ob_grid), dim3(64 * OB_WAVES), 0, s2, a, ob_windows, ob_win_bases, ob_rpw);
     } else if (nr && gmg_opt(GMG_OPT_MG_ORFS_EVENTS)) {
-        const uint64_t blocks = (nr + 127) / 128;
-        hipLaunchKernelGGL(k_mg_find_orfs_ev, dim3((unsigned)(blocks < 256 * 64 ? blocks : 256 * 64)), dim3(128), 0, s2, a);
+        const uint64_t blocks = (nr + MG_EV_LANES - 1) / MG_EV_LANES;
+        hipLaunchKernelGGL(k_mg_find_orfs_ev, dim3((unsigned)(blocks < 256 * 128 ? blocks : 256 * 128)), dim3(MG_EV_LANES), 0, s2, a);
     } else if (nr) hipLaunchKernelGGL(k_mg_find_orfs<true>, dim3(grid_for(nr)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
     tm.lap("find orfs");
