@@ -3667,15 +3667,6 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         MG_TRY(hipGetLastError());
         tm.lap("walk-order tables");
     }
-    if (err_mode && s2 != s) {                          // the error branch needs the six-frame table from here on: one stream again
-        MG_TRY(hipEventRecord(side_done, s2));
-        MG_TRY(hipStreamWaitEvent(s, side_done, 0));
-        if (s3 != s2) {
-            MG_TRY(hipEventRecord(side2_done, s3));
-            MG_TRY(hipStreamWaitEvent(s, side2_done, 0));
-        }
-        s2 = s;
-    }
     // 3. start lists
     if (!find_only) {
     MG_TRY(gmg_pool_alloc((void **)&d_start_off, (no + 1) * 8));
@@ -3717,7 +3708,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     if (res->n_orfs && err_mode && err_path == 0) {
         MG_TRY(gmg_pool_alloc((void **)&d_read_fit, nr ? nr : 1));
         MG_TRY(gmg_pool_alloc((void **)&d_err_flag, 128));          // the flag + the two call counters + six tile counters; tile path: + the number of tiles, the item and staging counters
-        MG_TRY(hipMemsetAsync(d_err_flag, 0, 128, s2));
+        MG_TRY(hipMemsetAsync(d_err_flag, 0, 128, s3));             // (not behind the ORF write pass on the first side stream; both join the caller's below)
         a.read_fit = d_read_fit;
         a.err_flag = d_err_flag;
         a.n_calls = (unsigned long long *)(d_err_flag + 2);
@@ -3832,14 +3823,36 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
 #undef MG_ET_LAUNCH
         return hipGetLastError();
     };
+    // (the wave kernels' zeroed arrays and the reads' fit flags need nothing of the six-frame table: on a side stream, beside the
+    // partial-window pass and the ORF write pass -- they sat 0.3 ms between those and the count pass)
+    bool wave_reset_done = false;
+    if (no && err_mode && err_path == 0 && err_wave && s3 != s) {      // (the second side stream: the first one is busy with the ORF write pass)
+        MG_TRY(hipMemsetAsync(d_acc_bits, 0, (no / 32 + 1) * 4, s3));
+        MG_TRY(hipMemsetAsync(d_item_flag, 0, 2 * nr + 64, s3));
+        hipLaunchKernelGGL(k_mg_err_prepare, dim3(grid_for(nr)), dim3(256), 0, s3, a, (uint64_t)ew_cap + 1);
+        MG_TRY(hipGetLastError());
+        wave_reset_done = true;
+    }
+    if (err_mode && s2 != s) {                          // the error branch needs the six-frame table from here on: one stream again
+        MG_TRY(hipEventRecord(side_done, s2));
+        MG_TRY(hipStreamWaitEvent(s, side_done, 0));
+        if (s3 != s2) {
+            MG_TRY(hipEventRecord(side2_done, s3));
+            MG_TRY(hipStreamWaitEvent(s, side2_done, 0));
+        }
+        s2 = s;
+    }
     int level_tries = 0;
     for (int attempt = 0; attempt < 6; attempt++) {
     const dim3 lvl_grid(256 * 16);
     const bool any_unfit = reads->max_len >= (err_wave ? (uint64_t)ew_cap + 1 : err_tile ? (uint64_t)MG_ET_CAP + 1 : 2040);
     if (no && err_mode && err_path == 0 && err_wave) {
-        MG_TRY(hipMemsetAsync(d_acc_bits, 0, (no / 32 + 1) * 4, s2));
-        MG_TRY(hipMemsetAsync(d_item_flag, 0, 2 * nr + 64, s2));
-        hipLaunchKernelGGL(k_mg_err_prepare, dim3(grid_for(nr)), dim3(256), 0, s2, a, (uint64_t)ew_cap + 1);
+        if (!wave_reset_done) {
+            MG_TRY(hipMemsetAsync(d_acc_bits, 0, (no / 32 + 1) * 4, s2));
+            MG_TRY(hipMemsetAsync(d_item_flag, 0, 2 * nr + 64, s2));
+            hipLaunchKernelGGL(k_mg_err_prepare, dim3(grid_for(nr)), dim3(256), 0, s2, a, (uint64_t)ew_cap + 1);
+        }
+        wave_reset_done = false;                        // (a repeat of the call starts from zeroed arrays again)
         MG_TRY(launch_err_wave(s2, false));
         if (any_unfit) hipLaunchKernelGGL(k_mg_err_flat<false>, dim3(grid_for(no)), dim3(MG_ERR_BLOCK), 0, s2, a, err_acc_only, 1);
     } else if (no && err_mode && err_path == 0 && err_tile) {

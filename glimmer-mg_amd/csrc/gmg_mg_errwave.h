@@ -874,6 +874,21 @@ __device__ __forceinline__ void ew_own_write(const MgArgs &a, const double *S, c
     }
 }
 
+#ifndef GMG_EW_STAMPS
+#define GMG_EW_STAMPS 0          // diagnostic build: cycles per phase of k_mg_err_wcount<count>, summed over all waves (tools/ew_stamps.py); not in the product
+#endif
+#if GMG_EW_STAMPS
+__device__ unsigned long long g_ew_stamps[8];
+extern "C" int gmg_debug_ew_stamps(unsigned long long *out, int reset)
+{
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return hipMemcpyToSymbol(HIP_SYMBOL(g_ew_stamps), z, sizeof z) == hipSuccess ? 0 : -1; }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ew_stamps), 64) == hipSuccess ? 0 : -1;
+}
+#define EW_STAMP(i) do { if (!WRITE) { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_prev; st_prev = now_; } } while (0)
+#else
+#define EW_STAMP(i) do { } while (0)
+#endif
+
 template <bool WRITE, bool G32, int KMAX>
 __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int accepted_only, const uint32_t cap_lo, const uint32_t cap,
                                                             uint8_t *item_flag, uint32_t *stats)
@@ -915,6 +930,9 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
     const bool trunc_ok = a.allow_truncated != 0;
     const double thr = a.start_threshold;
 
+#if GMG_EW_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
+#endif
     for (uint64_t blk = blockIdx.x; blk * 64 < n_items; blk += gridDim.x) {
     uint64_t l_off = 0, l_ob = 0;
     uint32_t l_n = 0, l_no = 0;
@@ -963,6 +981,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         }
     };
     if (have_n) fetch_next();
+    EW_STAMP(0);                                        // the block's reads and ORF ranges, the first pair's loads issued
     while (have_n) {
         const uint32_t src = src_n;
         const EwRegs<G32, KMAX> R = Rn;
@@ -970,6 +989,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         const uint32_t o_acc = on_acc, o_sbeg = on_sbeg;
         have_n = todo != 0;
         if (have_n) fetch_next();
+        EW_STAMP(1);                                    // the next pair's loads issued
         const uint64_t it = blk * 64 + src;
         const uint64_t r = it >> 1;
         const bool fwd = (it & 1) == 0;
@@ -1007,6 +1027,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         for (uint32_t t = lane; 4u * t < n + 8u; t += 64) ((uint32_t *)orf_at)[t] = 0xffffffffu;
         if (lane == 0) *acc_mask = 0;
         wcs_sync();
+        EW_STAMP(2);                                    // sums, masks, lists (waits for the pair's loads)
 
         // ---- level 0: the ORFs of this strand.  First every ORF's first step is put down (s_xs; with -i the step's table entry names the
         //      ORF that takes the branches of that step: ORFs that begin at the same step -- Find_Orfs gives the reverse frames
@@ -1105,6 +1126,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         if (n1 > EWC_CAP1) overflow = true;
         wcs_sync();
 
+        EW_STAMP(3);                                    // level 0
         // ---- level 0 -> 1: every (low-quality base, phase) pair
         if (indels && a.indel_max >= 1 && !overflow) {
             for (uint32_t i0 = 0; i0 < 3u * npos; i0 += 64) {
@@ -1177,6 +1199,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         }
         wcs_sync();
 
+        EW_STAMP(4);                                    // level 0 -> 1
         // ---- level 1 (own starts), level 1 -> 2 (pairs), level 2 (own starts), batch by batch
         uint32_t n2 = 0;
         auto drain2 = [&]() __attribute__((always_inline)) {
@@ -1293,6 +1316,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
             }
         }
         if (n2 && !overflow) drain2();
+        EW_STAMP(5);                                    // levels 1 and 2
         if (stats && lane == 0) { atomicMax(&stats[0], n1); atomicMax(&stats[1], nloc); atomicMax(&stats[2], npos); atomicAdd(&stats[4], 1u); }
         if (overflow) { if (lane == 0) atomicOr(a.err_flag, 1u); continue; }
         if (WRITE) {
@@ -1352,8 +1376,13 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         }
         if (__ballot(kept) && lane == 0) item_flag[it] = 1;
         wcs_sync();
+        EW_STAMP(6);                                    // verdicts
     }
     }
+#if GMG_EW_STAMPS
+    if (!WRITE && lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&g_ew_stamps[i], st_acc[i]);
+#endif
 }
 
 #endif
