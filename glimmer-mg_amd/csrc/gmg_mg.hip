@@ -26,8 +26,6 @@
 
 #include "gmg_device.h"
 
-#include <hipcub/hipcub.hpp>
-#include <hipcub/device/device_segmented_sort.hpp>
 
 #include <float.h>
 #include <limits.h>
@@ -858,9 +856,18 @@ __global__ __launch_bounds__(256) void k_mg_tile_table(MgArgs a, uint64_t n_wind
     }
 }
 
-struct MgTileNonEmpty {
-    __host__ __device__ bool operator()(const MgTile &t) const { return t.nfit != 0; }
-};
+// ... the non-empty ones in their order: flags (k_mg_tile_flags), their exclusive sums (gmg_scan.h), then every such tile to its place
+__global__ __launch_bounds__(256) void k_mg_tile_flags(const MgTile *tab, uint64_t n_windows, uint32_t *flag)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= n_windows; k += (uint64_t)gridDim.x * blockDim.x)
+        flag[k] = k < n_windows && tab[k].nfit != 0 ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_mg_tile_compact(const MgTile *tab, uint64_t n_windows, const uint32_t *pos, MgTile *tiles, uint32_t *n_tiles)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_windows; k += (uint64_t)gridDim.x * blockDim.x)
+        if (tab[k].nfit != 0) tiles[pos[k]] = tab[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_tiles = pos[n_windows];
+}
 
 template <int MG_CAP, int BLOCK, bool GENE32 = false>
 __global__ __launch_bounds__(BLOCK) void k_mg_cum_tiled(MgArgs a)
@@ -2823,25 +2830,96 @@ __global__ __launch_bounds__(256) void k_mg_err_begin(MgArgs a, const int accept
 #include "gmg_mg_errwave.h"
 #include "gmg_mg_orfbits.h"
 
-__global__ __launch_bounds__(256) void k_mg_seg_bounds(const gmg_mg_orf *orfs, uint64_t n, uint32_t *seg_begin, uint32_t *seg_end)
+// Every ORF's slice of the start array into the reference's push order: ascending order key, ties by place (the level kernels and
+// the wave kernels hand the starts out in whatever order their lanes came by).  Slices are short (2 - 3 starts per accepted ORF with
+// -s, ~24 with -i, more with a quality file), so a start's place is COUNTED, not sorted: the number of starts of its ORF with a
+// smaller (key, place).  k_mg_order_starts: a wave per ORF -- up to 64 starts: the keys sit in the lanes, one pass of readlanes; up to
+// 512: the keys in the wave's LDS share, eight starts per lane -- longer slices go on a list for k_mg_order_long (a work-group per ORF,
+// the keys in LDS 2,048 at a time).  Starts and Error_t lists move
+// to their places in the same pass.  (Replaces a library segmented sort of (key, index) pairs + three helper launches.)
+#define MG_ORDER_MID 512          // longest slice a wave orders (its keys in the wave's LDS share, up to eight starts per lane)
+__global__ __launch_bounds__(256) void k_mg_order_starts(const gmg_mg_orf *orfs, const uint64_t n_orfs, const uint64_t *keys, const gmg_start *s_in,
+                                                         const gmg_start_errors *e_in, gmg_start *s_out, gmg_start_errors *e_out, uint32_t *long_list,
+                                                         uint32_t *n_long)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        seg_begin[i] = orfs[i].start_begin;
-        seg_end[i] = orfs[i].start_begin + orfs[i].n_starts;
+    __shared__ uint64_t s_keys[4][MG_ORDER_MID];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t *sk = s_keys[threadIdx.x >> 6];
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < n_orfs; i += n_waves) {
+        const uint32_t b = orfs[i].start_begin, n = orfs[i].n_starts;
+        if (n == 0) continue;
+        if (n > MG_ORDER_MID) { if (lane == 0) long_list[atomicAdd(n_long, 1u)] = (uint32_t)i; continue; }
+        if (n <= 64) {                                  // the keys sit in the lanes
+            const uint64_t key = lane < n ? keys[b + lane] : ~0ull;
+            gmg_start st;
+            gmg_start_errors er;
+            if (lane < n) { st = s_in[b + lane]; er = e_in[b + lane]; }
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                const uint64_t kj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, (int)j) |
+                                    (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), (int)j) << 32;
+                rank += (kj < key || (kj == key && j < lane)) ? 1u : 0u;
+            }
+            if (lane < n) { s_out[b + rank] = st; e_out[b + rank] = er; }
+            continue;
+        }
+        // up to eight starts per lane (start lane + 64 e), every key read once from LDS by all lanes
+        wcs_sync();                                     // (the lanes are through with the slice before)
+        auto mid = [&](auto E_) __attribute__((always_inline)) {
+            constexpr int E = decltype(E_)::value;
+            uint64_t key[E];
+            uint32_t rank[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t m = lane + 64u * (uint32_t)e;
+                key[e] = m < n ? keys[b + m] : ~0ull;
+                if (m < n) sk[m] = key[e];
+                rank[e] = 0;
+            }
+            wcs_sync();
+            for (uint32_t t = 0; t < n; t++) {
+                const uint64_t kj = sk[t];
+#pragma unroll
+                for (int e = 0; e < E; e++) rank[e] += (kj < key[e] || (kj == key[e] && t < lane + 64u * (uint32_t)e)) ? 1u : 0u;
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t m = lane + 64u * (uint32_t)e;
+                if (m < n) { s_out[b + rank[e]] = s_in[b + m]; e_out[b + rank[e]] = e_in[b + m]; }
+            }
+        };
+        if (n <= 128) mid(std::integral_constant<int, 2>());
+        else if (n <= 256) mid(std::integral_constant<int, 4>());
+        else mid(std::integral_constant<int, 8>());
     }
 }
 
-__global__ __launch_bounds__(256) void k_mg_iota(uint32_t *v, uint64_t n)
+#define MG_ORDER_CHUNK 2048
+__global__ __launch_bounds__(256) void k_mg_order_long(const gmg_mg_orf *orfs, const uint64_t *keys, const gmg_start *s_in, const gmg_start_errors *e_in,
+                                                       gmg_start *s_out, gmg_start_errors *e_out, const uint32_t *long_list, const uint32_t *n_long)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
-}
-
-__global__ __launch_bounds__(256) void k_mg_permute_starts(const uint32_t *idx, uint64_t n, const gmg_start *s_in, const gmg_start_errors *e_in,
-                                                           gmg_start *s_out, gmg_start_errors *e_out)
-{
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        s_out[i] = s_in[idx[i]];
-        e_out[i] = e_in[idx[i]];
+    __shared__ uint64_t s_k[MG_ORDER_CHUNK];
+    const uint32_t nl = *n_long;
+    for (uint32_t q = blockIdx.x; q < nl; q += gridDim.x) {
+        const uint64_t i = long_list[q];
+        const uint32_t b = orfs[i].start_begin, n = orfs[i].n_starts;
+        for (uint32_t m0 = 0; m0 < n; m0 += 256) {      // 256 starts at a time: their places
+            const uint32_t m = m0 + threadIdx.x;
+            const uint64_t key = m < n ? keys[b + m] : ~0ull;
+            uint32_t rank = 0;
+            for (uint32_t c0 = 0; c0 < n; c0 += MG_ORDER_CHUNK) {
+                const uint32_t cn = n - c0 < MG_ORDER_CHUNK ? n - c0 : MG_ORDER_CHUNK;
+                __syncthreads();
+                for (uint32_t t = threadIdx.x; t < cn; t += 256) s_k[t] = keys[b + c0 + t];
+                __syncthreads();
+                for (uint32_t t = 0; t < cn; t++) {
+                    const uint64_t kj = s_k[t];
+                    rank += (kj < key || (kj == key && c0 + t < m)) ? 1u : 0u;
+                }
+            }
+            if (m < n) { s_out[b + rank] = s_in[b + m]; e_out[b + rank] = e_in[b + m]; }
+        }
     }
 }
 
@@ -2882,6 +2960,33 @@ __global__ __launch_bounds__(256) void k_mg_keep_gather(const gmg_mg_orf *orfs, 
             const uint64_t dst_ = (uint64_t)(uint32_t)__shfl((int)(uint32_t)dst, src) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(dst >> 32), src) << 32;
             for (uint32_t t = lane; t < cnt_; t += 64) out_starts[dst_ + t] = starts[b_ + t];
         }
+    }
+}
+
+// The same with the accepted ORFs as a bitmap (error branch; the start lists are packed already): the scan runs over the bitmap's WORDS
+// (a 32nd of the entries), a record's new place is its word's offset + the set bits below it
+__global__ __launch_bounds__(256) void k_mg_keep_words(const uint32_t *bits, uint64_t n_words, uint32_t *cnt)
+{
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w <= n_words; w += (uint64_t)gridDim.x * blockDim.x)
+        cnt[w] = w < n_words ? (uint32_t)__popc(bits[w]) : 0u;
+}
+__global__ __launch_bounds__(256) void k_mg_keep_gather_bits(const gmg_mg_orf *orfs, const uint32_t *bits, const uint32_t *word_off, uint64_t n_words, uint64_t n,
+                                                             gmg_mg_orf *out_orfs)
+{
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t m = bits[w], dst = word_off[w];
+        while (m) {
+            const uint64_t i = 32 * w + (uint32_t)__ffs((int)m) - 1u;
+            m &= m - 1u;
+            if (i < n) out_orfs[dst++] = orfs[i];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_mg_keep_reads_bits(const uint64_t *read_orf_off, uint64_t n_reads, const uint32_t *bits, const uint32_t *word_off, uint64_t *out)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = read_orf_off[r];             // (<= n_orfs: inside the bitmap's last word, whose unused bits are zero)
+        out[r] = (uint64_t)word_off[i >> 5] + (uint32_t)__popc(bits[i >> 5] & ((1u << (i & 31u)) - 1u));
     }
 }
 
@@ -3418,17 +3523,20 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
             tiled = true;
             rest = reads->max_len > longest || reads->min_len * (uint64_t)a.tile_reads_max < a.tile_window;
             if (n_windows >= 0x7fffffffull) return fail(gmg_set_error(GMG_EINVAL, "gmg_mg_score_reads: batch too large"));
-            uint32_t *d_n = nullptr;
-            size_t sel_bytes = 0;
+            uint32_t *d_n = nullptr, *d_flag = nullptr;     // d_flag: [n_windows + 1] flags, then [n_windows + 1] their exclusive sums
             hipError_t e = gmg_pool_alloc((void **)&d_all, n_windows * sizeof(MgTile));
             if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_tiles, n_windows * sizeof(MgTile));
             if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_n, 4);
+            if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_flag, (2 * (n_windows + 4)) * 4);
+            d_sel_tmp = d_flag;
             if (e == hipSuccess) {
+                uint32_t *d_pos = d_flag + ((n_windows + 4) & ~3ull);
                 hipLaunchKernelGGL(k_mg_tile_table, dim3(grid_for(n_windows)), dim3(256), 0, s, a, n_windows, cap, d_all);
-                e = hipcub::DeviceSelect::If(nullptr, sel_bytes, d_all, d_tiles, d_n, (int)n_windows, MgTileNonEmpty(), s);
+                hipLaunchKernelGGL(k_mg_tile_flags, dim3(grid_for(n_windows + 1)), dim3(256), 0, s, d_all, n_windows, d_flag);
+                e = gmg_scan_excl<uint32_t, uint32_t>(d_flag, d_pos, n_windows + 1, s);
+                if (e == hipSuccess) hipLaunchKernelGGL(k_mg_tile_compact, dim3(grid_for(n_windows)), dim3(256), 0, s, d_all, n_windows, d_pos, d_tiles, d_n);
+                if (e == hipSuccess) e = hipGetLastError();
             }
-            if (e == hipSuccess) e = gmg_pool_alloc(&d_sel_tmp, sel_bytes);
-            if (e == hipSuccess) e = hipcub::DeviceSelect::If(d_sel_tmp, sel_bytes, d_all, d_tiles, d_n, (int)n_windows, MgTileNonEmpty(), s);
             d_ntiles = d_n;                                 // (all of these go back to the cache after the call's final synchronise)
             if (e != hipSuccess) return fail(gmg_set_error(GMG_EHIP, "gmg_mg_score_reads: tile table: %s", hipGetErrorString(e)));
             a.tiles = d_tiles;
@@ -4035,9 +4143,30 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         if (e == hipSuccess) e = hipMemsetAsync(d_keep + no, 0, 4, s);
         if (e == hipSuccess && !starts_packed) e = hipMemsetAsync(d_keep_st + no, 0, 4, s);
         int rc2 = GMG_OK;
-        if (e == hipSuccess) {
-            // (error branch: the bitmap of the accepted ORFs is complete unless everything went to the per-ORF kernel)
-            const uint32_t *kept_bits = (err_mode && err_path == 0) ? d_acc_bits : nullptr;
+        // (error branch: the bitmap of the accepted ORFs is complete unless everything went to the per-ORF kernel)
+        const uint32_t *kept_bits = (err_mode && err_path == 0) ? d_acc_bits : nullptr;
+        if (e == hipSuccess && starts_packed && kept_bits && no) {
+            const uint64_t n_words = no / 32 + 1;
+            uint32_t *d_wc = nullptr, n_keep32 = 0;       // [n_words + 1] set bits per word, then [n_words + 1] their exclusive sums
+            e = gmg_pool_alloc((void **)&d_wc, 2 * (n_words + 4) * 4);
+            uint32_t *d_wo = d_wc ? d_wc + ((n_words + 4) & ~3ull) : nullptr;
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_mg_keep_words, dim3(grid_for(n_words + 1)), dim3(256), 0, s, kept_bits, n_words, d_wc);
+                e = gmg_scan_excl<uint32_t, uint32_t>(d_wc, d_wo, n_words + 1, s);
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(&n_keep32, d_wo + n_words, 4, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            n_keep = n_keep32;
+            n_keep_st = res->n_starts;
+            if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_orfs2, (n_keep ? n_keep : 1) * sizeof(gmg_mg_orf));
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_mg_keep_gather_bits, dim3(grid_for(n_words)), dim3(256), 0, s, res->d_orfs, kept_bits, d_wo, n_words, no, d_orfs2);
+                hipLaunchKernelGGL(k_mg_keep_reads_bits, dim3(grid_for(nr + 1)), dim3(256), 0, s, res->d_read_orf_off, nr, kept_bits, d_wo, d_new_first);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipStreamSynchronize(s);
+            }
+            if (d_wc) gmg_pool_release(d_wc);
+        } else if (e == hipSuccess) {
             if (no) hipLaunchKernelGGL(k_mg_keep_counts, dim3(grid_for(no)), dim3(256), 0, s, res->d_orfs, kept_bits, no, d_keep, d_keep_st);
             rc2 = mg_scan(d_keep, d_new_orf, no, &n_keep, s);
             if (starts_packed) n_keep_st = res->n_starts;
@@ -4071,40 +4200,24 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         res->n_starts = n_keep_st;
     }
     if (d_keys && res->n_starts) {
-        // 5. error branch, per-read kernel: every ORF's slice of the start array into the reference's push order
-        //    (segmented sort of (key, index) pairs, segments = ORFs, then one permuting copy)
+        // 5. error branch: every ORF's slice of the start array into the reference's push order (k_mg_order_starts)
         const uint64_t ns = res->n_starts, nseg = res->n_orfs;
-        uint32_t *d_seg = nullptr, *d_idx = nullptr, *d_idx2 = nullptr;
-        uint64_t *d_keys_sorted = nullptr;
+        uint32_t *d_long = nullptr;                     // [0]: how many ORFs have more than 64 starts, [1 ..]: which
         gmg_start *d_starts3 = nullptr;
         gmg_start_errors *d_errs3 = nullptr;
-        void *d_tmp = nullptr;
-        size_t tmp_bytes = 0;
-        hipError_t e = gmg_pool_alloc((void **)&d_seg, (2 * nseg + 2) * 4);
-        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_idx, ns * 4);
-        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_idx2, ns * 4);
-        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_keys_sorted, ns * 8);
+        hipError_t e = gmg_pool_alloc((void **)&d_long, (nseg + 1) * 4);
         if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_starts3, ns * sizeof(gmg_start));
         if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_errs3, ns * sizeof(gmg_start_errors));
+        if (e == hipSuccess) e = hipMemsetAsync(d_long, 0, 4, s);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_mg_seg_bounds, dim3(grid_for(nseg)), dim3(256), 0, s, res->d_orfs, nseg, d_seg, d_seg + nseg + 1);
-            hipLaunchKernelGGL(k_mg_iota, dim3(grid_for(ns)), dim3(256), 0, s, d_idx, ns);
-            e = hipcub::DeviceSegmentedSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys_sorted, d_idx, d_idx2, (int)ns, (int)nseg, d_seg,
-                                                       d_seg + nseg + 1, s);
-        }
-        if (e == hipSuccess) e = gmg_pool_alloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
-        if (e == hipSuccess) e = hipcub::DeviceSegmentedSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_idx, d_idx2, (int)ns, (int)nseg,
-                                                                        d_seg, d_seg + nseg + 1, s);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_mg_permute_starts, dim3(grid_for(ns)), dim3(256), 0, s, d_idx2, ns, res->d_starts, res->d_errs, d_starts3, d_errs3);
+            const uint64_t blocks = (nseg + 3) / 4;
+            hipLaunchKernelGGL(k_mg_order_starts, dim3((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32)), dim3(256), 0, s, res->d_orfs, nseg, d_keys, res->d_starts,
+                               res->d_errs, d_starts3, d_errs3, d_long + 1, d_long);
+            hipLaunchKernelGGL(k_mg_order_long, dim3(1024), dim3(256), 0, s, res->d_orfs, d_keys, res->d_starts, res->d_errs, d_starts3, d_errs3, d_long + 1, d_long);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (d_seg) gmg_pool_release(d_seg);
-        if (d_idx) gmg_pool_release(d_idx);
-        if (d_idx2) gmg_pool_release(d_idx2);
-        if (d_keys_sorted) gmg_pool_release(d_keys_sorted);
-        if (d_tmp) gmg_pool_release(d_tmp);
+        if (d_long) gmg_pool_release(d_long);
         if (e != hipSuccess) {
             if (d_starts3) gmg_pool_release(d_starts3);
             if (d_errs3) gmg_pool_release(d_errs3);
