@@ -2832,15 +2832,13 @@ __global__ __launch_bounds__(256) void k_mg_err_begin(MgArgs a, const int accept
 
 // Every ORF's slice of the start array into the reference's push order: ascending order key, ties by place (the level kernels and
 // the wave kernels hand the starts out in whatever order their lanes came by).  Slices are short (2 - 3 starts per accepted ORF with
-// -s, ~24 with -i, more with a quality file), so a start's place is COUNTED, not sorted: the number of starts of its ORF with a
-// smaller (key, place).  k_mg_order_starts: a wave per ORF -- up to 64 starts: the keys sit in the lanes, one pass of readlanes; up to
-// 512: the keys in the wave's LDS share, eight starts per lane -- longer slices go on a list for k_mg_order_long (a work-group per ORF,
-// the keys in LDS 2,048 at a time).  Starts and Error_t lists move
-// to their places in the same pass.  (Replaces a library segmented sort of (key, index) pairs + three helper launches.)
-#define MG_ORDER_MID 512          // longest slice a wave orders (its keys in the wave's LDS share, up to eight starts per lane)
+// -s, ~24 with -i, a few of several hundred), so a start's place is COUNTED, not sorted: the number of starts of its ORF with a
+// smaller (key, place).  k_mg_order_starts: a wave per ORF -- up to 64 starts: the keys sit in the lanes, one pass of readlanes; more:
+// the keys in the wave's LDS share 512 at a time, up to eight starts per lane and round.  Starts and Error_t lists move to their
+// places in the same pass.  (Replaces a library segmented sort of (key, index) pairs + three helper launches.)
+#define MG_ORDER_MID 512
 __global__ __launch_bounds__(256) void k_mg_order_starts(const gmg_mg_orf *orfs, const uint64_t n_orfs, const uint64_t *keys, const gmg_start *s_in,
-                                                         const gmg_start_errors *e_in, gmg_start *s_out, gmg_start_errors *e_out, uint32_t *long_list,
-                                                         uint32_t *n_long)
+                                                         const gmg_start_errors *e_in, gmg_start *s_out, gmg_start_errors *e_out)
 {
     __shared__ uint64_t s_keys[4][MG_ORDER_MID];
     const uint32_t lane = threadIdx.x & 63u;
@@ -2849,7 +2847,6 @@ __global__ __launch_bounds__(256) void k_mg_order_starts(const gmg_mg_orf *orfs,
     for (uint64_t i = wave; i < n_orfs; i += n_waves) {
         const uint32_t b = orfs[i].start_begin, n = orfs[i].n_starts;
         if (n == 0) continue;
-        if (n > MG_ORDER_MID) { if (lane == 0) long_list[atomicAdd(n_long, 1u)] = (uint32_t)i; continue; }
         if (n <= 64) {                                  // the keys sit in the lanes
             const uint64_t key = lane < n ? keys[b + lane] : ~0ull;
             gmg_start st;
@@ -2864,62 +2861,40 @@ __global__ __launch_bounds__(256) void k_mg_order_starts(const gmg_mg_orf *orfs,
             if (lane < n) { s_out[b + rank] = st; e_out[b + rank] = er; }
             continue;
         }
-        // up to eight starts per lane (start lane + 64 e), every key read once from LDS by all lanes
-        wcs_sync();                                     // (the lanes are through with the slice before)
+        // E starts per lane and round (start m0 + lane + 64 e), every key read once per round from LDS by all lanes
         auto mid = [&](auto E_) __attribute__((always_inline)) {
             constexpr int E = decltype(E_)::value;
-            uint64_t key[E];
-            uint32_t rank[E];
+            for (uint32_t m0 = 0; m0 < n; m0 += 64u * E) {
+                uint64_t key[E];
+                uint32_t rank[E];
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                const uint32_t m = lane + 64u * (uint32_t)e;
-                key[e] = m < n ? keys[b + m] : ~0ull;
-                if (m < n) sk[m] = key[e];
-                rank[e] = 0;
-            }
-            wcs_sync();
-            for (uint32_t t = 0; t < n; t++) {
-                const uint64_t kj = sk[t];
+                for (int e = 0; e < E; e++) {
+                    const uint32_t m = m0 + lane + 64u * (uint32_t)e;
+                    key[e] = m < n ? keys[b + m] : ~0ull;
+                    rank[e] = 0;
+                }
+                for (uint32_t c0 = 0; c0 < n; c0 += MG_ORDER_MID) {
+                    const uint32_t cn = n - c0 < MG_ORDER_MID ? n - c0 : MG_ORDER_MID;
+                    wcs_sync();                         // (the lanes are through with the keys before)
+                    for (uint32_t t = lane; t < cn; t += 64) sk[t] = keys[b + c0 + t];
+                    wcs_sync();
+#pragma unroll 4
+                    for (uint32_t t = 0; t < cn; t++) {
+                        const uint64_t kj = sk[t];
 #pragma unroll
-                for (int e = 0; e < E; e++) rank[e] += (kj < key[e] || (kj == key[e] && t < lane + 64u * (uint32_t)e)) ? 1u : 0u;
-            }
+                        for (int e = 0; e < E; e++) rank[e] += (kj < key[e] || (kj == key[e] && c0 + t < m0 + lane + 64u * (uint32_t)e)) ? 1u : 0u;
+                    }
+                }
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                const uint32_t m = lane + 64u * (uint32_t)e;
-                if (m < n) { s_out[b + rank[e]] = s_in[b + m]; e_out[b + rank[e]] = e_in[b + m]; }
+                for (int e = 0; e < E; e++) {
+                    const uint32_t m = m0 + lane + 64u * (uint32_t)e;
+                    if (m < n) { s_out[b + rank[e]] = s_in[b + m]; e_out[b + rank[e]] = e_in[b + m]; }
+                }
             }
         };
         if (n <= 128) mid(std::integral_constant<int, 2>());
         else if (n <= 256) mid(std::integral_constant<int, 4>());
         else mid(std::integral_constant<int, 8>());
-    }
-}
-
-#define MG_ORDER_CHUNK 2048
-__global__ __launch_bounds__(256) void k_mg_order_long(const gmg_mg_orf *orfs, const uint64_t *keys, const gmg_start *s_in, const gmg_start_errors *e_in,
-                                                       gmg_start *s_out, gmg_start_errors *e_out, const uint32_t *long_list, const uint32_t *n_long)
-{
-    __shared__ uint64_t s_k[MG_ORDER_CHUNK];
-    const uint32_t nl = *n_long;
-    for (uint32_t q = blockIdx.x; q < nl; q += gridDim.x) {
-        const uint64_t i = long_list[q];
-        const uint32_t b = orfs[i].start_begin, n = orfs[i].n_starts;
-        for (uint32_t m0 = 0; m0 < n; m0 += 256) {      // 256 starts at a time: their places
-            const uint32_t m = m0 + threadIdx.x;
-            const uint64_t key = m < n ? keys[b + m] : ~0ull;
-            uint32_t rank = 0;
-            for (uint32_t c0 = 0; c0 < n; c0 += MG_ORDER_CHUNK) {
-                const uint32_t cn = n - c0 < MG_ORDER_CHUNK ? n - c0 : MG_ORDER_CHUNK;
-                __syncthreads();
-                for (uint32_t t = threadIdx.x; t < cn; t += 256) s_k[t] = keys[b + c0 + t];
-                __syncthreads();
-                for (uint32_t t = 0; t < cn; t++) {
-                    const uint64_t kj = s_k[t];
-                    rank += (kj < key || (kj == key && c0 + t < m)) ? 1u : 0u;
-                }
-            }
-            if (m < n) { s_out[b + rank] = s_in[b + m]; e_out[b + rank] = e_in[b + m]; }
-        }
     }
 }
 
@@ -4202,22 +4177,17 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     if (d_keys && res->n_starts) {
         // 5. error branch: every ORF's slice of the start array into the reference's push order (k_mg_order_starts)
         const uint64_t ns = res->n_starts, nseg = res->n_orfs;
-        uint32_t *d_long = nullptr;                     // [0]: how many ORFs have more than 64 starts, [1 ..]: which
         gmg_start *d_starts3 = nullptr;
         gmg_start_errors *d_errs3 = nullptr;
-        hipError_t e = gmg_pool_alloc((void **)&d_long, (nseg + 1) * 4);
-        if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_starts3, ns * sizeof(gmg_start));
+        hipError_t e = gmg_pool_alloc((void **)&d_starts3, ns * sizeof(gmg_start));
         if (e == hipSuccess) e = gmg_pool_alloc((void **)&d_errs3, ns * sizeof(gmg_start_errors));
-        if (e == hipSuccess) e = hipMemsetAsync(d_long, 0, 4, s);
         if (e == hipSuccess) {
             const uint64_t blocks = (nseg + 3) / 4;
             hipLaunchKernelGGL(k_mg_order_starts, dim3((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32)), dim3(256), 0, s, res->d_orfs, nseg, d_keys, res->d_starts,
-                               res->d_errs, d_starts3, d_errs3, d_long + 1, d_long);
-            hipLaunchKernelGGL(k_mg_order_long, dim3(1024), dim3(256), 0, s, res->d_orfs, d_keys, res->d_starts, res->d_errs, d_starts3, d_errs3, d_long + 1, d_long);
+                               res->d_errs, d_starts3, d_errs3);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (d_long) gmg_pool_release(d_long);
         if (e != hipSuccess) {
             if (d_starts3) gmg_pool_release(d_starts3);
             if (d_errs3) gmg_pool_release(d_errs3);

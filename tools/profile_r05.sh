@@ -47,3 +47,9 @@ if [ $PART = d ]; then
 say tests;        timeout -k 10 1150 python3 -m pytest tests -m gpu -q -x > $R/pytest_gpu.txt 2>&1; tail -3 $R/pytest_gpu.txt
 say done-d
 fi
+if [ $PART = e ]; then
+say lds-probe;    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/lds_table_probe tools/probes/lds_table_probe.hip > $R/lds_probe_build.log 2>&1 && timeout -k 10 200 /tmp/lds_table_probe > $R/lds_table_probe.txt 2>&1
+say ew-stamps;    for m in indel sub; do GMG_LIB_PATH=$PWD/glimmer-mg_amd/lib/variants/libgmg_ewstamps.so timeout -k 10 200 python3 tools/ew_stamps.py $m >> $R/ew_stamps.txt 2>&1; done
+say orfbits;      timeout -k 10 300 python3 tools/mg_ab.py glimmer-mg_amd/lib/libgmg.so glimmer-mg_amd/lib/libgmg.so:mg_orfs_bits=1 > $R/mg_ab_orfs_bits.txt 2>&1
+say done-e
+fi
