@@ -19,6 +19,7 @@ struct OrfTmp { double s; int32_t which, pad; };   // one in-frame position of t
 
 struct gmg_orf_batch {
     double *d_walk;              // events path: running sums in walking order, [2][total_bases] (allocated on first use)
+    uint32_t *d_heads;           // ... and one bit per base and strand: an ORF asks for the sum there (its HEAD position), [2][total_bases / 32 + 4]
     float *d_gene6;              // fused / events path: per-base gene values, [6][total_bases] (allocated on first use)
     OrfTmp *d_tmp;               // fused path: one slot per in-frame position, same offsets as the start lists
     gmg_orf *d_orfs;
@@ -275,6 +276,10 @@ struct OrfWalkArgs {
     const float *gene6;          // [6][total]: rows 0-2 reversed buffer (forward ORFs), rows 3-5 complemented buffer
     const float *null_dense;     // [3][64] full-window values of the (3,2,3) null model
     double *q;                   // [2][total]: forward-strand sums, reverse-strand sums
+    // k_orf_walk_sums8, sparse form: Q is written only where k_orf_events can ask for it
+    const uint32_t *heads;       // [2][head_words] bit g of strand s: an ORF's HEAD position (k_orf_mark_heads); NULL: every base is written
+    uint64_t head_words;
+    uint64_t start_set;          // codons (first char << 4 | second << 2 | third) that match a start pattern
 };
 
 constexpr int OW_EL = 4;         // walk steps per lane and trip: 256 per wave
@@ -347,7 +352,13 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums(OrfWalkArgs a)
 struct __attribute__((packed, aligned(4))) OwF4 { float v[4]; };
 struct __attribute__((packed, aligned(8))) OwD2 { double v[2]; };
 
+// (154 registers: three waves per SIMD, and the kernel waits -- 20 GB in 4.3 ms is half of what the memory does.  Asking the compiler for
+// four / five waves (-DOW8_WAVES) makes it spill 10 / 24 registers: 10.7 / 12.4 ms per gmg_score_orfs call against 9.7; profiles/r05_orfs_walk8_ab.txt)
+#ifdef OW8_WAVES
+__global__ __launch_bounds__(256, OW8_WAVES) void k_orf_walk_sums8(OrfWalkArgs a)
+#else
 __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
+#endif
 {
     __shared__ double s_null[3 * 64];
     for (int i = threadIdx.x; i < 3 * 64; i += 256) s_null[i] = (double)a.null_dense[i];
@@ -379,14 +390,17 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
 #pragma unroll
                     for (int k = 0; k < 4; k++) { gv[f][k] = lo4.v[k]; gv[f][4 + k] = hi4.v[k]; }
                 }
-            } else {
+            } else {                                    // (one address per row, the eight elements at constant offsets: registers)
+                const float *rb = rows + ((int64_t)off + p_lo);
 #pragma unroll
-                for (int f = 0; f < 3; f++)
+                for (int f = 0; f < 3; f++) {
+                    const float *rf = rb + (uint64_t)f * a.total;
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
                         const int64_t p = p_lo + k;
-                        gv[f][k] = (any && p >= 0 && p < (int64_t)n) ? rows[(uint64_t)f * a.total + off + (uint64_t)p] : 0.0f;
+                        gv[f][k] = (any && p >= 0 && p < (int64_t)n) ? rf[k] : 0.0f;
                     }
+                }
             }
             // bases p_lo - 2 .. p_lo + 9 as 2-bit fields (the null model's window reaches two bases beyond a step's own)
             const uint64_t win = any ? dev_window_bits(a.packed, g_lo - 2) : 0ull;
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
             // forward and (1 + p - c) % 3 reverse (k_orf_walk_sums); with p = p_first -/+ e both become (c' + e) % 3 for
             // c' = (c - p_first) % 3 forward, (1 + p_first - c) % 3 reverse... reverse runs the other way: (c' - e) % 3
             const uint32_t pm = (uint32_t)(((p_first % 3) + 3) % 3);
-            double acc[3] = {0.0, 0.0, 0.0}, P[8][3];
+            double acc[3] = {0.0, 0.0, 0.0}, Pq[8];     // Pq[e]: the relabelled class (1 - e) % 3 -- the class of step e's own base -- before step e
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const int k = fwd ? 7 - e : e;
@@ -407,12 +421,9 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
 #pragma unroll
                 for (int f = 0; f < 3; f++) v[f] = in ? (double)gv[f][k] - s_null[f * 64 + n6] : 0.0;
                 // relabelled class cp takes row (cp + e) % 3 (forward) / (cp + 3 - e % 3) % 3 ... reverse: p grows with e: row = (1 + p - c) % 3
+                Pq[e] = acc[((1 - e) % 3 + 3) % 3];     // the sum over the steps BEFORE this one
 #pragma unroll
-                for (int cp = 0; cp < 3; cp++) {
-                    const int f = fwd ? (cp + e) % 3 : (cp + e) % 3;
-                    P[e][cp] = acc[cp];                 // the sum over the steps BEFORE this one
-                    acc[cp] += v[f];
-                }
+                for (int cp = 0; cp < 3; cp++) acc[cp] += v[(cp + e) % 3];
             }
             // relabelling: forward row f = (c - p) % 3 with p = p_first - e  ->  (c - pm + e) % 3: cp = (c - pm) % 3
             //              reverse row f = (1 + p - c) % 3 with p = p_first + e -> (1 + pm - c + e) % 3: cp = (1 + pm - c) % 3
@@ -436,20 +447,58 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
                 const int cp = ((1 - e) % 3 + 3) % 3;
                 const uint32_t c = fwd ? ((uint32_t)cp + pm) % 3u : (1u + pm + 3u - (uint32_t)cp) % 3u;     // the true class of cp
                 const double b = c == 0u ? base[0] : c == 1u ? base[1] : base[2];
-                qv[fwd ? 7 - e : e] = b + P[e][cp];
+                qv[fwd ? 7 - e : e] = b + Pq[e];
+            }
+            // Sparse form (a.heads): k_orf_events reads Q at an ORF's HEAD position (marked by k_orf_mark_heads), at a start codon --
+            // forward: the codon that ENDS at the base, reverse: the reverse complement of the codon that BEGINS there -- and at the first
+            // in-frame position of an ORF that runs into the read's end (within five bases of it).  Everything else is never read.
+            uint32_t need = 0xffu;
+            if (a.heads && any) {
+                need = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t f5 = (uint32_t)(win >> (2 * k)) & 0x3ffu;           // bases p - 2 .. p + 2 of the base at index k
+                    const uint32_t c = fwd ? ((f5 & 3u) << 4 | (f5 & 12u) | ((f5 >> 4) & 3u))
+                                           : ((((f5 >> 8) & 3u) << 4 | ((f5 >> 6) & 3u) << 2 | ((f5 >> 4) & 3u)) ^ 63u);
+                    const int64_t p = p_lo + k;
+                    const bool edge = p < 8 || p + 8 >= (int64_t)n;
+                    need |= (((a.start_set >> c) & 1ull) || edge ? 1u : 0u) << k;
+                }
+                const uint64_t gb = (uint64_t)(g_lo < 0 ? 0 : g_lo);
+                const uint32_t *hw = a.heads + (fwd ? 0 : a.head_words) + (gb >> 5);
+                const uint64_t two = (uint64_t)hw[1] << 32 | hw[0];
+                need |= (uint32_t)(two >> (gb & 31u)) & 0xffu;
             }
             if (whole) {
 #pragma unroll
-                for (int k = 0; k < 8; k += 2) { OwD2 d; d.v[0] = qv[k]; d.v[1] = qv[k + 1]; *(OwD2 *)(q + (uint64_t)g_lo + k) = d; }
+                for (int k = 0; k < 8; k += 2)
+                    if ((need >> k) & 3u) { OwD2 d; d.v[0] = qv[k]; d.v[1] = qv[k + 1]; *(OwD2 *)(q + (uint64_t)g_lo + k) = d; }
             } else if (any) {
+                double *qb = q + ((int64_t)off + p_lo);
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const int64_t p = p_lo + k;
                     const uint32_t e = (uint32_t)(fwd ? 7 - k : k);
-                    if (e < cnt && p >= 0 && p < (int64_t)n) q[off + (uint64_t)p] = qv[k];
+                    if (e < cnt && p >= 0 && p < (int64_t)n) qb[k] = qv[k];
                 }
             }
         }
+    }
+}
+
+// the HEAD position of every ORF (what k_orf_events reads as q_head), one bit per base and strand
+__global__ __launch_bounds__(256) void k_orf_mark_heads(const gmg_orf *orfs, const uint64_t n, const uint64_t *read_off, const int W, uint32_t *heads,
+                                                        const uint64_t head_words)
+{
+    const int HEAD = (W - 1 + 2) / 3 * 3;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const gmg_orf orf = orfs[i];
+        if (orf.orf_len <= HEAD) continue;
+        const uint64_t r_off = read_off[orf.read];
+        const bool fwd = orf.frame > 0;
+        const int64_t g_b0 = (int64_t)r_off + (fwd ? orf.stop_position - 1 - 1 : orf.stop_position + 2);      // (k_orf_events: hi - 1 / lo)
+        const uint64_t g = (uint64_t)(g_b0 + (fwd ? -HEAD : HEAD));
+        atomicOr(heads + (fwd ? 0 : head_words) + (g >> 5), 1u << (g & 31u));
     }
 }
 
@@ -766,7 +815,7 @@ extern "C" int gmg_orf_batch_free(gmg_orf_batch *b)
 {
     if (!b) return GMG_OK;
     if (b->segs) gmg_segments_free(b->segs);
-    void *ptrs[] = {b->d_orfs, b->d_start_off, b->d_score, b->d_indep, b->d_results, b->d_starts, b->d_gene6, b->d_tmp, b->d_walk,
+    void *ptrs[] = {b->d_orfs, b->d_start_off, b->d_score, b->d_indep, b->d_results, b->d_starts, b->d_gene6, b->d_tmp, b->d_walk, b->d_heads,
                     b->d_nst, b->d_coff, b->d_scan_tmp, b->d_compact};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -827,17 +876,22 @@ extern "C" int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *nul,
         events = !gene->odd_values && !nul->odd_values && (mx < mn || clog + mx - mn <= 28) && nul->dev.dense_part == nul->dev.dense + 192;
     }
     if (events) {
-        if (!mb->d_gene6 || !mb->d_walk) {
+        const uint64_t head_words = reads->total_bases / 32 + 4;
+        if (!mb->d_gene6 || !mb->d_walk || !mb->d_heads) {
             float *g6 = mb->d_gene6;
-            double *wk = nullptr;
+            double *wk = mb->d_walk;
+            uint32_t *hd = mb->d_heads;
             hipError_t e = g6 ? hipSuccess : hipMalloc((void **)&g6, (size_t)6 * reads->total_bases * sizeof(float));
-            if (e == hipSuccess) e = hipMalloc((void **)&wk, (size_t)2 * reads->total_bases * sizeof(double));
+            if (e == hipSuccess && !wk) e = hipMalloc((void **)&wk, (size_t)2 * reads->total_bases * sizeof(double));
+            if (e == hipSuccess && !hd) e = hipMalloc((void **)&hd, (size_t)2 * head_words * 4);
             if (e != hipSuccess) {
                 if (g6 && !mb->d_gene6) (void)hipFree(g6);
+                if (wk && !mb->d_walk) (void)hipFree(wk);
                 return gmg_set_error(GMG_ENOMEM, "gmg_score_orfs: scratch: %s", hipGetErrorString(e));
             }
             mb->d_gene6 = g6;
             mb->d_walk = wk;
+            mb->d_heads = hd;
         }
         int rc = gmg_launch_gene6(gene, reads, mb->d_gene6, s);
         if (rc) return gmg_set_error(rc, "gmg_score_orfs: gene-only pass refused the model");
@@ -849,6 +903,28 @@ extern "C" int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *nul,
         wa.gene6 = mb->d_gene6;
         wa.null_dense = nul->dev.dense;
         wa.q = mb->d_walk;
+        wa.heads = nullptr;
+        wa.head_words = head_words;
+        wa.start_set = 0;
+        // orfs_walk8 = 1 (default): Q only where k_orf_events can ask for it -- the ORFs' HEAD positions (marked here), start codons, the reads' ends;
+        // 2: every base (the form it is checked against); orfs_q_poison (tests): the array is filled with NaNs first, so that a read of an
+        // entry that was not written cannot go unnoticed
+        if (gmg_opt(GMG_OPT_ORFS_Q_POISON)) GMG_HIP(hipMemsetAsync(mb->d_walk, 0xff, (size_t)2 * reads->total_bases * sizeof(double), s));
+        if (gmg_opt(GMG_OPT_ORFS_WALK8) == 1) {
+            for (uint32_t c = 0; c < 64; c++) {         // Codon_t::Can_Be (gene.cc:39-66) for every definite codon, as k_orf_events' s_which
+                const uint32_t m = (1u << ((c >> 4) & 3u)) << 8 | (1u << ((c >> 2) & 3u)) << 4 | (1u << (c & 3u));
+                for (int p = 0; p < prm->n_start_codons && p < 8; p++) {
+                    uint32_t d = 0;
+                    for (int k = 0; k < 3 && prm->start_codon[p][k]; k++) d = ((d & 0xffu) << 4) | ch_mask(prm->start_codon[p][k]);
+                    const uint32_t x = m & d;
+                    if ((x & 0xf00u) && (x & 0xf0u) && (x & 0x0fu)) wa.start_set |= 1ull << c;
+                }
+            }
+            GMG_HIP(hipMemsetAsync(mb->d_heads, 0, (size_t)2 * head_words * 4, s));
+            if (b->n) hipLaunchKernelGGL(k_orf_mark_heads, dim3((unsigned)((b->n + 255) / 256 < 256 * 16 ? (b->n + 255) / 256 : 256 * 16)), dim3(256), 0, s, b->d_orfs, b->n,
+                                         reads->d_off, gene->dev.W, mb->d_heads, head_words);
+            wa.heads = mb->d_heads;
+        }
         const uint64_t waves = 2 * reads->n_reads, wblocks = (waves + 3) / 4;
         // (option orfs_walk8: the lane-on-eight-steps form, the default; 0: the lane-on-every-64th-step form it is checked against)
         if (gmg_opt(GMG_OPT_ORFS_WALK8)) hipLaunchKernelGGL(k_orf_walk_sums8, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
