@@ -352,192 +352,152 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums(OrfWalkArgs a)
 struct __attribute__((packed, aligned(4))) OwF4 { float v[4]; };
 struct __attribute__((packed, aligned(8))) OwD2 { double v[2]; };
 
-// What bounds it: nothing the counters name, and nothing tried moves it.  4.3 ms per 1 M reads whatever the form (one box, processes in turn,
-// the whole gmg_score_orfs call; profiles/r05_orfs_walk8_ab.txt, r05_pmc_summary_k_orf_walk_sums8_*.txt): every base of Q written (7.8 GB) or
-// only what can be read (1.7 GB): 10.11 / 10.07 ms; E = 8 at three or four waves per SIMD (158 / 114 registers), E = 4 at six (80 registers, two
-// trips per 500-bp read): 10.07 / 10.17; the next unit's rows in flight while this one is worked on (PF; a unit = 64 E steps of one (read,
-// strand); offsets two items ahead): 10.13 / 10.15; more waves by force (-DOW8_WAVES on the first form: spills): 10.7 / 12.4.  It reads 12.3 GB
-// in that time (2.9 TB/s) with the vector pipes a sixth busy.
-#ifndef OW8_WAVES
-#define OW8_WAVES 1
+// What bounds it: its vector instructions (a wave-instruction takes four cycles on a SIMD: 1.5e9 of them on 1,024 SIMDs = 2.8 of the
+// 4.3 ms the first form took; it reads its 12 GB at 2.9 TB/s where a probe with the same pattern and no arithmetic reaches 6.0,
+// tools/probes/read_rows_probe.hip).  Measured and of no effect on that form (profiles/r05_orfs_walk8_ab.txt): Q written only where it
+// can be read (7.8 -> 1.7 GB), four steps per lane at six waves per SIMD, the next unit's loads in flight; -DOW8_WAVES (more waves by
+// force) spills.  A struct of the unit's registers handed to lambdas went to scratch memory (5.6 ms): the body stays in the loop.
+#ifdef OW8_WAVES
+__global__ __launch_bounds__(256, OW8_WAVES) void k_orf_walk_sums8(OrfWalkArgs a)
+#else
+__global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
 #endif
-template <int E>
-struct OwUnit {
-    uint64_t off, win;
-    uint32_t n, t0, fwd, headbits;
-    float gv[3][E];
-};
-template <int E, bool PF>       // E = 8 or 4 consecutive walk steps per lane
-__global__ __launch_bounds__(256, E == 4 ? 5 : (PF ? 4 : OW8_WAVES)) void k_orf_walk_sums8(OrfWalkArgs a)
 {
     __shared__ double s_null[3 * 64];
     for (int i = threadIdx.x; i < 3 * 64; i += 256) s_null[i] = (double)a.null_dense[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const uint64_t n_items = 2 * a.n_reads;
-    // where the lane's E steps of a unit lie
-    struct Geo { uint32_t tb, cnt; bool any, whole; int64_t p_first, p_lo, g_lo; };
-    auto geo = [&](const uint64_t off, const uint32_t n, const uint32_t t0, const bool fwd) __attribute__((always_inline)) -> Geo {
-        Geo g;
-        g.tb = t0 + (uint32_t)E * lane;                 // the lane's first step; its steps tb .. tb + E - 1 are bases p0, p0 -/+ 1, ..
-        g.any = g.tb < n;
-        g.cnt = g.any ? (n - g.tb < (uint32_t)E ? n - g.tb : (uint32_t)E) : 0u;
-        // the lowest base of the lane's E (forward: the last step's), clamped into the read: what lies outside is masked below
-        g.p_first = fwd ? (int64_t)n - 1 - (int64_t)g.tb : (int64_t)g.tb;       // position of step tb in the read
-        g.p_lo = fwd ? g.p_first - (E - 1) : g.p_first;
-        g.g_lo = (int64_t)off + g.p_lo;
-        g.whole = g.any && g.cnt == (uint32_t)E && g.g_lo >= 0 && (uint64_t)g.g_lo + E <= a.total;
-        return g;
-    };
-    auto fetch = [&](OwUnit<E> &U) __attribute__((always_inline)) {
-        const bool fwd = U.fwd != 0;
-        const Geo g = geo(U.off, U.n, U.t0, fwd);
-        const float *rows = a.gene6 + (fwd ? 0 : 3) * a.total;
-        if (g.whole) {
+    for (uint64_t it = wave; it < 2 * a.n_reads; it += n_waves) {
+        const uint64_t r = it >> 1;
+        const bool fwd_item = (it & 1) == 0;
+        const uint64_t off = a.read_off[r];
+        const uint32_t n = (uint32_t)(a.read_off[r + 1] - off);
+        const float *rows = a.gene6 + (fwd_item ? 0 : 3) * a.total;
+        double *q = a.q + (fwd_item ? 0 : a.total);
+        double carry[3] = {0.0, 0.0, 0.0};              // by TRUE class
+        // (the body once per strand: which of a lane's eight values belongs to which step is then known at compile time -- with the strand as
+        // data the compiler indexed the lane's values dynamically, i.e. kept them in scratch memory)
+        auto trip = [&](auto FWD_, const uint32_t t0) __attribute__((always_inline)) {
+            constexpr bool fwd = decltype(FWD_)::value;
+            const uint32_t tb = t0 + 8u * lane;         // the lane's first step; its steps tb .. tb + 7 are bases p0, p0 -/+ 1, ..
+            const bool any = tb < n;
+            const uint32_t cnt = any ? (n - tb < 8u ? n - tb : 8u) : 0u;
+            // the lowest base of the lane's eight (forward: the last step's), clamped into the read: what lies outside is masked below
+            const int64_t p_first = fwd ? (int64_t)n - 1 - (int64_t)tb : (int64_t)tb;       // position of step tb in the read
+            const int64_t p_lo = fwd ? p_first - 7 : p_first;
+            const int64_t g_lo = (int64_t)off + p_lo;
+            float gv[3][8];
+            const bool whole = any && cnt == 8u && g_lo >= 0 && (uint64_t)g_lo + 8 <= a.total;
+            // Always the eight values at g_lo .. g_lo + 7 of every row, also for the lane that holds a read's last steps and for the lanes
+            // behind it: what lies beyond the read enters only sums that nobody reads -- the lane's own Q values BEHIND its last valid
+            // step (not stored), the totals of the lanes behind it (they store nothing), the carry into a next trip (a read that has
+            // one fills all lanes of this one).  One load path, no selects: the kernel is bound by its vector instructions (1.5e9
+            // wave-instructions x 4 cycles on 1,024 SIMDs = 2.8 of its 4.3 ms; a wave-instruction takes four cycles on a SIMD).
+            const bool oob = g_lo < 0 || (uint64_t)g_lo + 8 > a.total;         // (the batch's first / last read, or a lane without steps)
+            {
+                const float *rb = rows + (oob ? 0 : g_lo);
 #pragma unroll
-            for (int f = 0; f < 3; f++) {
+                for (int f = 0; f < 3; f++) {
+                    const OwF4 lo4 = *(const OwF4 *)(rb + (uint64_t)f * a.total), hi4 = *(const OwF4 *)(rb + (uint64_t)f * a.total + 4);
 #pragma unroll
-                for (int h = 0; h < E; h += 4) {
-                    const OwF4 q4 = *(const OwF4 *)(rows + (uint64_t)f * a.total + (uint64_t)g.g_lo + h);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) U.gv[f][h + k] = q4.v[k];
+                    for (int k = 0; k < 4; k++) { gv[f][k] = lo4.v[k]; gv[f][4 + k] = hi4.v[k]; }
                 }
             }
-        } else {                                        // (one address per row, the E elements at constant offsets: registers)
-            const float *rb = rows + ((int64_t)U.off + g.p_lo);
+            if (any && oob) {                           // (a handful of lanes of the whole grid: element by element, inside the array)
 #pragma unroll
-            for (int f = 0; f < 3; f++) {
-                const float *rf = rb + (uint64_t)f * a.total;
+                for (int f = 0; f < 3; f++)
 #pragma unroll
-                for (int k = 0; k < E; k++) {
-                    const int64_t p = g.p_lo + k;
-                    U.gv[f][k] = (g.any && p >= 0 && p < (int64_t)U.n) ? rf[k] : 0.0f;
+                    for (int k = 0; k < 8; k++) {
+                        const int64_t gk = g_lo + k;
+                        gv[f][k] = gk >= 0 && (uint64_t)gk < a.total ? rows[(uint64_t)f * a.total + (uint64_t)gk] : 0.0f;
+                    }
+            }
+            // bases p_lo - 2 .. p_lo + 9 as 2-bit fields (the null model's window reaches two bases beyond a step's own); E = 8: all in its low word
+            const uint32_t win = (uint32_t)dev_window_bits(a.packed, any ? g_lo - 2 : 0);
+            // step e of the lane sits at index k = 7 - e (forward) / e (reverse) of the eight; its class: forward (p + 1) % 3, reverse p % 3.
+            // Relabelled class c' = (true class - class of step 0 + ..): see below -- value row f of class c at base p is (c - p) % 3
+            // forward and (1 + p - c) % 3 reverse (k_orf_walk_sums); with p = p_first -/+ e both become (c' + e) % 3 for
+            // c' = (c - p_first) % 3 forward, (1 + p_first - c) % 3 reverse... reverse runs the other way: (c' - e) % 3
+            const uint32_t pm = (uint32_t)(((p_first % 3) + 3) % 3);
+            double acc[3] = {0.0, 0.0, 0.0}, Pq[8];     // Pq[e]: the relabelled class (1 - e) % 3 -- the class of step e's own base -- before step e
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int k = fwd ? 7 - e : e;
+                // null window of the base at index k: forward (S[p+2], S[p+1], S[p]) oldest first, reverse the complement of (S[p-2], S[p-1], S[p])
+                const uint32_t w3 = (win >> (2 * k)) & 0xfffu;                        // fields: bases p - 2 .. p + 3
+                const uint32_t n6 = fwd ? (((w3 >> 8) & 3u) | (((w3 >> 6) & 3u) << 2) | (((w3 >> 4) & 3u) << 4)) : ((w3 & 63u) ^ 63u);
+                double v[3];
+#pragma unroll
+                for (int f = 0; f < 3; f++) v[f] = (double)(fwd ? gv[f][7 - e] : gv[f][e]) - s_null[f * 64 + n6];
+                // relabelled class cp takes row (cp + e) % 3 (forward) / (cp + 3 - e % 3) % 3 ... reverse: p grows with e: row = (1 + p - c) % 3
+                Pq[e] = acc[((1 - e) % 3 + 3) % 3];     // the sum over the steps BEFORE this one
+#pragma unroll
+                for (int cp = 0; cp < 3; cp++) acc[cp] += v[(cp + e) % 3];
+            }
+            // relabelling: forward row f = (c - p) % 3 with p = p_first - e  ->  (c - pm + e) % 3: cp = (c - pm) % 3
+            //              reverse row f = (1 + p - c) % 3 with p = p_first + e -> (1 + pm - c + e) % 3: cp = (1 + pm - c) % 3
+            double tot[3], base[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const uint32_t cp = fwd ? ((uint32_t)c + 3u - pm) % 3u : (1u + pm + 3u - (uint32_t)c) % 3u;
+                tot[c] = cp == 0u ? acc[0] : cp == 1u ? acc[1] : acc[2];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double inc = wcs_wave_scan(tot[c]);
+                base[c] = carry[c] + (inc - tot[c]);
+                carry[c] += wcs_last_lane(inc);
+            }
+            // Q of step e: the sum of the class OF ITS BASE: forward class (p + 1) % 3, reverse p % 3 -- relabelled: forward
+            // cp = (p + 1 - pm) % 3 with p = p_first - e -> (1 - e) % 3; reverse cp = (1 + pm - p) % 3 -> (1 - e) % 3: static
+            double qv[8], base_r[3];                    // base_r[cp]: what lies in front of the lane for relabelled class cp
+#pragma unroll
+            for (int cp = 0; cp < 3; cp++) {
+                const uint32_t c = fwd ? ((uint32_t)cp + pm) % 3u : (1u + pm + 3u - (uint32_t)cp) % 3u;     // the true class of cp
+                base_r[cp] = c == 0u ? base[0] : c == 1u ? base[1] : base[2];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) Pq[e] += base_r[((1 - e) % 3 + 3) % 3];      // Q of step e
+#pragma unroll
+            for (int k = 0; k < 8; k++) qv[k] = fwd ? Pq[7 - k] : Pq[k];            // ... of the base at index k (static indices: registers)
+            // Sparse form (a.heads): k_orf_events reads Q at an ORF's HEAD position (marked by k_orf_mark_heads), at a start codon --
+            // forward: the codon that ENDS at the base, reverse: the reverse complement of the codon that BEGINS there -- and at the first
+            // in-frame position of an ORF that runs into the read's end (within five bases of it).  Everything else is never read.
+            uint32_t need = 0xffu;
+            if (a.heads && any) {
+                need = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t f5 = (win >> (2 * k)) & 0x3ffu;                       // bases p - 2 .. p + 2 of the base at index k
+                    const uint32_t c = fwd ? ((f5 & 3u) << 4 | (f5 & 12u) | ((f5 >> 4) & 3u))
+                                           : ((((f5 >> 8) & 3u) << 4 | ((f5 >> 6) & 3u) << 2 | ((f5 >> 4) & 3u)) ^ 63u);
+                    const int64_t p = p_lo + k;
+                    const bool edge = p < 8 || p + 8 >= (int64_t)n;
+                    need |= (((a.start_set >> c) & 1ull) || edge ? 1u : 0u) << k;
+                }
+                const uint64_t gb = (uint64_t)(g_lo < 0 ? 0 : g_lo);
+                const uint32_t *hw = a.heads + (fwd ? 0 : a.head_words) + (gb >> 5);
+                const uint64_t two = (uint64_t)hw[1] << 32 | hw[0];
+                need |= (uint32_t)(two >> (gb & 31u)) & 0xffu;
+            }
+            if (whole) {
+#pragma unroll
+                for (int k = 0; k < 8; k += 2)
+                    if ((need >> k) & 3u) { OwD2 d; d.v[0] = qv[k]; d.v[1] = qv[k + 1]; *(OwD2 *)(q + (uint64_t)g_lo + k) = d; }
+            } else if (any) {
+                double *qb = q + ((int64_t)off + p_lo);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int64_t p = p_lo + k;
+                    const uint32_t e = (uint32_t)(fwd ? 7 - k : k);
+                    if (e < cnt && p >= 0 && p < (int64_t)n) qb[k] = qv[k];
                 }
             }
+        };
+        for (uint32_t t0 = 0; t0 < n; t0 += 512) {
+            if (fwd_item) trip(std::integral_constant<bool, true>(), t0); else trip(std::integral_constant<bool, false>(), t0);
         }
-        // bases p_lo - 2 .. p_lo + 9 as 2-bit fields (the null model's window reaches two bases beyond a step's own)
-        U.win = g.any ? dev_window_bits(a.packed, g.g_lo - 2) : 0ull;
-        U.headbits = 0;
-        if (a.heads && g.any) {
-            const uint64_t gb = (uint64_t)(g.g_lo < 0 ? 0 : g.g_lo);
-            const uint32_t *hw = a.heads + (fwd ? 0 : a.head_words) + (gb >> 5);
-            const uint64_t two = (uint64_t)hw[1] << 32 | hw[0];
-            U.headbits = (uint32_t)(two >> (gb & 31u)) & ((1u << E) - 1u);
-        }
-    };
-    auto compute = [&](const OwUnit<E> &U, double (&carry)[3]) __attribute__((always_inline)) {
-        const bool fwd = U.fwd != 0;
-        const Geo g = geo(U.off, U.n, U.t0, fwd);
-        const uint32_t n = U.n, cnt = g.cnt;
-        const uint64_t win = U.win;
-        double *q = a.q + (fwd ? 0 : a.total);
-        // step e of the lane sits at index k = E - 1 - e (forward) / e (reverse) of the E; its class: forward (p + 1) % 3, reverse p % 3.
-        // Relabelled class c' = (true class - class of step 0 + ..): see below -- value row f of class c at base p is (c - p) % 3
-        // forward and (1 + p - c) % 3 reverse (k_orf_walk_sums); with p = p_first -/+ e both become (c' + e) % 3 for
-        // c' = (c - p_first) % 3 forward, (1 + p_first - c) % 3 reverse
-        const uint32_t pm = (uint32_t)(((g.p_first % 3) + 3) % 3);
-        double acc[3] = {0.0, 0.0, 0.0}, Pq[E];         // Pq[e]: the relabelled class (1 - e) % 3 -- the class of step e's own base -- before step e
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int k = fwd ? E - 1 - e : e;
-            const bool in = (uint32_t)e < cnt;
-            // null window of the base at index k: forward (S[p+2], S[p+1], S[p]) oldest first, reverse the complement of (S[p-2], S[p-1], S[p])
-            const uint32_t w3 = (uint32_t)(win >> (2 * k)) & 0xfffu;            // fields: bases p - 2 .. p + 3
-            const uint32_t n6 = fwd ? (((w3 >> 8) & 3u) | (((w3 >> 6) & 3u) << 2) | (((w3 >> 4) & 3u) << 4)) : ((w3 & 63u) ^ 63u);
-            double v[3];
-#pragma unroll
-            for (int f = 0; f < 3; f++) v[f] = in ? (double)U.gv[f][k] - s_null[f * 64 + n6] : 0.0;
-            Pq[e] = acc[((1 - e) % 3 + 3) % 3];         // the sum over the steps BEFORE this one
-#pragma unroll
-            for (int cp = 0; cp < 3; cp++) acc[cp] += v[(cp + e) % 3];     // relabelled class cp takes row (cp + e) % 3
-        }
-        // relabelling: forward row f = (c - p) % 3 with p = p_first - e  ->  (c - pm + e) % 3: cp = (c - pm) % 3
-        //              reverse row f = (1 + p - c) % 3 with p = p_first + e -> (1 + pm - c + e) % 3: cp = (1 + pm - c) % 3
-        double tot[3], base[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const uint32_t cp = fwd ? ((uint32_t)c + 3u - pm) % 3u : (1u + pm + 3u - (uint32_t)c) % 3u;
-            tot[c] = cp == 0u ? acc[0] : cp == 1u ? acc[1] : acc[2];
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const double inc = wcs_wave_scan(tot[c]);
-            base[c] = carry[c] + (inc - tot[c]);
-            carry[c] += wcs_last_lane(inc);
-        }
-        // Q of step e: the sum of the class OF ITS BASE: forward class (p + 1) % 3, reverse p % 3 -- relabelled: forward
-        // cp = (p + 1 - pm) % 3 with p = p_first - e -> (1 - e) % 3; reverse cp = (1 + pm - p) % 3 -> (1 - e) % 3: static
-        double qv[E];
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int cp = ((1 - e) % 3 + 3) % 3;
-            const uint32_t c = fwd ? ((uint32_t)cp + pm) % 3u : (1u + pm + 3u - (uint32_t)cp) % 3u;     // the true class of cp
-            const double b = c == 0u ? base[0] : c == 1u ? base[1] : base[2];
-            qv[fwd ? E - 1 - e : e] = b + Pq[e];
-        }
-        // Sparse form (a.heads): k_orf_events reads Q at an ORF's HEAD position (marked by k_orf_mark_heads), at a start codon --
-        // forward: the codon that ENDS at the base, reverse: the reverse complement of the codon that BEGINS there -- and at the first
-        // in-frame position of an ORF that runs into the read's end (within five bases of it).  Everything else is never read.
-        uint32_t need = (1u << E) - 1u;
-        if (a.heads && g.any) {
-            need = U.headbits;
-#pragma unroll
-            for (int k = 0; k < E; k++) {
-                const uint32_t f5 = (uint32_t)(win >> (2 * k)) & 0x3ffu;               // bases p - 2 .. p + 2 of the base at index k
-                const uint32_t c = fwd ? ((f5 & 3u) << 4 | (f5 & 12u) | ((f5 >> 4) & 3u))
-                                       : ((((f5 >> 8) & 3u) << 4 | ((f5 >> 6) & 3u) << 2 | ((f5 >> 4) & 3u)) ^ 63u);
-                const int64_t p = g.p_lo + k;
-                const bool edge = p < 8 || p + 8 >= (int64_t)n;
-                need |= (((a.start_set >> c) & 1ull) || edge ? 1u : 0u) << k;
-            }
-        }
-        if (g.whole) {
-#pragma unroll
-            for (int k = 0; k < E; k += 2)
-                if ((need >> k) & 3u) { OwD2 d; d.v[0] = qv[k]; d.v[1] = qv[k + 1]; *(OwD2 *)(q + (uint64_t)g.g_lo + k) = d; }
-        } else if (g.any) {
-            double *qb = q + ((int64_t)U.off + g.p_lo);
-#pragma unroll
-            for (int k = 0; k < E; k++) {
-                const int64_t p = g.p_lo + k;
-                const uint32_t e = (uint32_t)(fwd ? E - 1 - k : k);
-                if (e < cnt && p >= 0 && p < (int64_t)n) qb[k] = qv[k];
-            }
-        }
-    };
-
-    uint64_t it = wave;
-    bool valid = it < n_items;
-    uint64_t off_b = 0, end_b = 0;                      // the offsets of the item after this one
-    OwUnit<E> cur;
-    cur.off = 0; cur.n = 0; cur.t0 = 0; cur.fwd = 0;
-    if (valid) {
-        cur.off = a.read_off[it >> 1];
-        cur.n = (uint32_t)(a.read_off[(it >> 1) + 1] - cur.off);
-        cur.fwd = (it & 1) == 0 ? 1u : 0u;
-        if (it + n_waves < n_items) { off_b = a.read_off[(it + n_waves) >> 1]; end_b = a.read_off[((it + n_waves) >> 1) + 1]; }
-        fetch(cur);
-    }
-    double carry[3] = {0.0, 0.0, 0.0};                  // by TRUE class
-    while (valid) {
-        OwUnit<E> nxt;
-        bool have_next;
-        if (cur.t0 + 64u * E < cur.n) {                 // the read's next 64 E steps
-            nxt.off = cur.off; nxt.n = cur.n; nxt.t0 = cur.t0 + 64u * E; nxt.fwd = cur.fwd;
-            have_next = true;
-        } else {
-            it += n_waves;
-            have_next = it < n_items;
-            nxt.off = off_b; nxt.n = (uint32_t)(end_b - off_b); nxt.t0 = 0; nxt.fwd = (it & 1) == 0 ? 1u : 0u;
-            if (it + n_waves < n_items) { off_b = a.read_off[(it + n_waves) >> 1]; end_b = a.read_off[((it + n_waves) >> 1) + 1]; }
-        }
-        if (PF && have_next) fetch(nxt);
-        if (cur.t0 == 0) { carry[0] = 0.0; carry[1] = 0.0; carry[2] = 0.0; }
-        compute(cur, carry);
-        if (!PF && have_next) fetch(nxt);
-        cur = nxt;
-        valid = have_next;
     }
 }
 
@@ -965,7 +925,7 @@ extern "C" int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *nul,
         // 2: every base (the form it is checked against); orfs_q_poison (tests): the array is filled with NaNs first, so that a read of an
         // entry that was not written cannot go unnoticed
         if (gmg_opt(GMG_OPT_ORFS_Q_POISON)) GMG_HIP(hipMemsetAsync(mb->d_walk, 0xff, (size_t)2 * reads->total_bases * sizeof(double), s));
-        if (gmg_opt(GMG_OPT_ORFS_WALK8) == 1 || gmg_opt(GMG_OPT_ORFS_WALK8) >= 3) {
+        if (gmg_opt(GMG_OPT_ORFS_WALK8) == 1) {
             for (uint32_t c = 0; c < 64; c++) {         // Codon_t::Can_Be (gene.cc:39-66) for every definite codon, as k_orf_events' s_which
                 const uint32_t m = (1u << ((c >> 4) & 3u)) << 8 | (1u << ((c >> 2) & 3u)) << 4 | (1u << (c & 3u));
                 for (int p = 0; p < prm->n_start_codons && p < 8; p++) {
@@ -982,12 +942,7 @@ extern "C" int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *nul,
         }
         const uint64_t waves = 2 * reads->n_reads, wblocks = (waves + 3) / 4;
         // (option orfs_walk8: the lane-on-eight-steps form, the default; 0: the lane-on-every-64th-step form it is checked against)
-        const dim3 wgrid((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64));
-        const long long w8 = gmg_opt(GMG_OPT_ORFS_WALK8);  // 1, 2: E = 8; 3: E = 4; 4: E = 4 with the next unit's loads in flight; 5: E = 8 with them
-        if (w8 == 3) hipLaunchKernelGGL((k_orf_walk_sums8<4, false>), wgrid, dim3(256), 0, s, wa);
-        else if (w8 == 4) hipLaunchKernelGGL((k_orf_walk_sums8<4, true>), wgrid, dim3(256), 0, s, wa);
-        else if (w8 == 5) hipLaunchKernelGGL((k_orf_walk_sums8<8, true>), wgrid, dim3(256), 0, s, wa);
-        else if (w8) hipLaunchKernelGGL((k_orf_walk_sums8<8, false>), wgrid, dim3(256), 0, s, wa);
+        if (gmg_opt(GMG_OPT_ORFS_WALK8)) hipLaunchKernelGGL(k_orf_walk_sums8, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
         else hipLaunchKernelGGL(k_orf_walk_sums, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
         GMG_HIP(hipGetLastError());
     } else if (fused) {
