@@ -352,11 +352,15 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums(OrfWalkArgs a)
 struct __attribute__((packed, aligned(4))) OwF4 { float v[4]; };
 struct __attribute__((packed, aligned(8))) OwD2 { double v[2]; };
 
-// What bounds it: its vector instructions (a wave-instruction takes four cycles on a SIMD: 1.5e9 of them on 1,024 SIMDs = 2.8 of the
-// 4.3 ms the first form took; it reads its 12 GB at 2.9 TB/s where a probe with the same pattern and no arithmetic reaches 6.0,
-// tools/probes/read_rows_probe.hip).  Measured and of no effect on that form (profiles/r05_orfs_walk8_ab.txt): Q written only where it
-// can be read (7.8 -> 1.7 GB), four steps per lane at six waves per SIMD, the next unit's loads in flight; -DOW8_WAVES (more waves by
-// force) spills.  A struct of the unit's registers handed to lambdas went to scratch memory (5.6 ms): the body stays in the loop.
+// What bounds it is not found.  4.1 - 4.3 ms per 1 M reads in every form (profiles/r05_orfs_walk8_ab.txt, r05_pmc_summary_k_orf_walk_sums8_*.txt):
+//   * it reads its 12 GB at 2.9 TB/s; a probe with the same read pattern and no arithmetic reaches 6.0 (tools/probes/read_rows_probe.hip);
+//   * Q written only where it can be read (7.8 -> 1.7 GB written): 4.33 -> 4.29 ms;
+//   * 1.7e9 -> 1.0e9 vector instructions (this form: the trip's body once per strand, so that every register index is static and no value
+//     of a step beyond the read needs a select; one load path; 32-bit window): 63 % -> 38 % of the vector pipes' time, 4.3 -> 4.1 ms;
+//   * three, four (this form), six waves per SIMD (four steps per lane): no change; more waves by force (-DOW8_WAVES): spills, slower;
+//   * the next unit's loads issued before this one is worked on (offsets two items ahead): 10.24 against 10.17 ms per call.
+// Two traps on the way: a struct of the unit's registers handed to lambdas by reference, and `fwd ? gv[7 - e] : gv[e]` with the strand as
+// data, both put the lane's 24 values into scratch memory (5.6 ms) -- hence the per-strand body.
 #ifdef OW8_WAVES
 __global__ __launch_bounds__(256, OW8_WAVES) void k_orf_walk_sums8(OrfWalkArgs a)
 #else
