@@ -361,6 +361,20 @@ struct __attribute__((packed, aligned(8))) OwD2 { double v[2]; };
 //   * the next unit's loads issued before this one is worked on (offsets two items ahead): 10.24 against 10.17 ms per call.
 // Two traps on the way: a struct of the unit's registers handed to lambdas by reference, and `fwd ? gv[7 - e] : gv[e]` with the strand as
 // data, both put the lane's 24 values into scratch memory (5.6 ms) -- hence the per-strand body.
+#ifndef GMG_OW_STAMPS
+#define GMG_OW_STAMPS 0          // diagnostic build: cycles per phase of k_orf_walk_sums8, summed over all waves (tools/ow_stamps.py); not in the product
+#endif
+#if GMG_OW_STAMPS
+__device__ unsigned long long g_ow_stamps[8];
+extern "C" int gmg_debug_ow_stamps(unsigned long long *out, int reset)
+{
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return hipMemcpyToSymbol(HIP_SYMBOL(g_ow_stamps), z, sizeof z) == hipSuccess ? 0 : -1; }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ow_stamps), 64) == hipSuccess ? 0 : -1;
+}
+#define OW_STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_prev; st_prev = now_; } while (0)
+#else
+#define OW_STAMP(i) do { } while (0)
+#endif
 #ifdef OW8_WAVES
 __global__ __launch_bounds__(256, OW8_WAVES) void k_orf_walk_sums8(OrfWalkArgs a)
 #else
@@ -372,6 +386,9 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+#if GMG_OW_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
+#endif
     for (uint64_t it = wave; it < 2 * a.n_reads; it += n_waves) {
         const uint64_t r = it >> 1;
         const bool fwd_item = (it & 1) == 0;
@@ -384,6 +401,7 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
         // data the compiler indexed the lane's values dynamically, i.e. kept them in scratch memory)
         auto trip = [&](auto FWD_, const uint32_t t0) __attribute__((always_inline)) {
             constexpr bool fwd = decltype(FWD_)::value;
+            OW_STAMP(0);                                // the item's offsets (a dependent load), loop overhead
             const uint32_t tb = t0 + 8u * lane;         // the lane's first step; its steps tb .. tb + 7 are bases p0, p0 -/+ 1, ..
             const bool any = tb < n;
             const uint32_t cnt = any ? (n - tb < 8u ? n - tb : 8u) : 0u;
@@ -419,6 +437,10 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
             }
             // bases p_lo - 2 .. p_lo + 9 as 2-bit fields (the null model's window reaches two bases beyond a step's own); E = 8: all in its low word
             const uint32_t win = (uint32_t)dev_window_bits(a.packed, any ? g_lo - 2 : 0);
+#if GMG_OW_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            OW_STAMP(1);                                // the unit's loads issued and waited for
             // step e of the lane sits at index k = 7 - e (forward) / e (reverse) of the eight; its class: forward (p + 1) % 3, reverse p % 3.
             // Relabelled class c' = (true class - class of step 0 + ..): see below -- value row f of class c at base p is (c - p) % 3
             // forward and (1 + p - c) % 3 reverse (k_orf_walk_sums); with p = p_first -/+ e both become (c' + e) % 3 for
@@ -441,6 +463,7 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
             }
             // relabelling: forward row f = (c - p) % 3 with p = p_first - e  ->  (c - pm + e) % 3: cp = (c - pm) % 3
             //              reverse row f = (1 + p - c) % 3 with p = p_first + e -> (1 + pm - c + e) % 3: cp = (1 + pm - c) % 3
+            OW_STAMP(2);                                // the eight steps
             double tot[3], base[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -455,6 +478,7 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
             }
             // Q of step e: the sum of the class OF ITS BASE: forward class (p + 1) % 3, reverse p % 3 -- relabelled: forward
             // cp = (p + 1 - pm) % 3 with p = p_first - e -> (1 - e) % 3; reverse cp = (1 + pm - p) % 3 -> (1 - e) % 3: static
+            OW_STAMP(3);                                // the three wave scans
             double qv[8], base_r[3];                    // base_r[cp]: what lies in front of the lane for relabelled class cp
 #pragma unroll
             for (int cp = 0; cp < 3; cp++) {
@@ -485,6 +509,7 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
                 const uint64_t two = (uint64_t)hw[1] << 32 | hw[0];
                 need |= (uint32_t)(two >> (gb & 31u)) & 0xffu;
             }
+            OW_STAMP(4);                                // Q values, which of them are needed
             if (whole) {
 #pragma unroll
                 for (int k = 0; k < 8; k += 2)
@@ -498,11 +523,16 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
                     if (e < cnt && p >= 0 && p < (int64_t)n) qb[k] = qv[k];
                 }
             }
+            OW_STAMP(5);                                // stores issued
         };
         for (uint32_t t0 = 0; t0 < n; t0 += 512) {
             if (fwd_item) trip(std::integral_constant<bool, true>(), t0); else trip(std::integral_constant<bool, false>(), t0);
         }
     }
+#if GMG_OW_STAMPS
+    if ((threadIdx.x & 63u) == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&g_ow_stamps[i], st_acc[i]);
+#endif
 }
 
 // the HEAD position of every ORF (what k_orf_events reads as q_head), one bit per base and strand
