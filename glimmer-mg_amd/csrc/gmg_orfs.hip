@@ -535,6 +535,166 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
 #endif
 }
 
+// k_orf_walk_sums8p: the same sums with the phases of consecutive units overlapped inside a wave.  The stamped build of k_orf_walk_sums8
+// (tools/ow_stamps.py) shows a wave's time as four phases one after the other -- its item's offsets (a dependent load) 21 %, the unit's
+// rows 30 %, arithmetic 27 %, stores 22 % -- and three to four waves per SIMD do not overlap them.  Here a wave's items are all of one
+// strand (the grid has an even number of waves), the whole item loop runs once per strand, and the NEXT unit's loads are issued before
+// this unit's arithmetic (its offsets two items ahead); a scheduling barrier keeps the compiler from moving them down again.
+__global__ __launch_bounds__(256) void k_orf_walk_sums8p(OrfWalkArgs a)
+{
+    __shared__ double s_null[3 * 64];
+    for (int i = threadIdx.x; i < 3 * 64; i += 256) s_null[i] = (double)a.null_dense[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t n_items = 2 * a.n_reads;             // item it = (read it / 2, strand it % 2)
+    if (wave >= n_items) return;
+
+    auto run = [&](auto FWD_) __attribute__((always_inline)) {
+        constexpr bool fwd = decltype(FWD_)::value;
+        const float *rows = a.gene6 + (fwd ? 0 : 3) * a.total;
+        double *q = a.q + (fwd ? 0 : a.total);
+        const uint32_t *heads = a.heads ? a.heads + (fwd ? 0 : a.head_words) : nullptr;
+        // where the lane's eight steps of a unit lie (k_orf_walk_sums8)
+#define OWP_GEO(OFF, N, T0)                                                                                                       \
+        const uint32_t tb = (T0) + 8u * lane;                                                                                    \
+        const bool any = tb < (N);                                                                                               \
+        const int64_t p_first = fwd ? (int64_t)(N) - 1 - (int64_t)tb : (int64_t)tb;                                              \
+        const int64_t p_lo = fwd ? p_first - 7 : p_first;                                                                        \
+        const int64_t g_lo = (int64_t)(OFF) + p_lo;
+        // a unit's loads into gn / wn / hn (plain locals: a struct of them handed on by reference went to scratch memory)
+#define OWP_LOAD(OFF, N, T0)                                                                                                      \
+        {                                                                                                                        \
+            OWP_GEO(OFF, N, T0)                                                                                                  \
+            const bool oob = g_lo < 0 || (uint64_t)g_lo + 8 > a.total;                                                           \
+            const float *rb = rows + (oob ? 0 : g_lo);                                                                           \
+            _Pragma("unroll") for (int f = 0; f < 3; f++) {                                                                      \
+                const OwF4 lo4 = *(const OwF4 *)(rb + (uint64_t)f * a.total), hi4 = *(const OwF4 *)(rb + (uint64_t)f * a.total + 4); \
+                _Pragma("unroll") for (int k = 0; k < 4; k++) { gn[f][k] = lo4.v[k]; gn[f][4 + k] = hi4.v[k]; }                 \
+            }                                                                                                                    \
+            if (any && oob) {                                                                                                    \
+                _Pragma("unroll") for (int f = 0; f < 3; f++)                                                                    \
+                    _Pragma("unroll") for (int k = 0; k < 8; k++) {                                                              \
+                        const int64_t gk = g_lo + k;                                                                             \
+                        gn[f][k] = gk >= 0 && (uint64_t)gk < a.total ? rows[(uint64_t)f * a.total + (uint64_t)gk] : 0.0f;      \
+                    }                                                                                                            \
+            }                                                                                                                    \
+            /* the window's and the head bits' WORDS only: shifting them here would wait for every load in front of them */       \
+            const int64_t wfirst = any ? g_lo - 2 : 0;                                                                            \
+            const uint32_t *pw = a.packed + (wfirst >> 4);       /* (arithmetic shift: floor for negatives; guard words) */       \
+            wn0 = pw[0]; wn1 = pw[1]; wsh = 2u * (uint32_t)(wfirst & 15);                                                         \
+            hn0 = 0; hn1 = 0; hsh = 0;                                                                                           \
+            if (heads && any) {                                                                                                  \
+                const uint64_t gb = (uint64_t)(g_lo < 0 ? 0 : g_lo);                                                             \
+                const uint32_t *hw = heads + (gb >> 5);                                                                          \
+                hn0 = hw[0]; hn1 = hw[1]; hsh = (uint32_t)(gb & 31u);                                                            \
+            }                                                                                                                    \
+        }
+        uint64_t it = wave;
+        uint64_t off = a.read_off[it >> 1];
+        uint32_t n = (uint32_t)(a.read_off[(it >> 1) + 1] - off), t0 = 0;
+        uint64_t off_b = 0, end_b = 0;                  // the offsets of the item after this one
+        if (it + n_waves < n_items) { off_b = a.read_off[(it + n_waves) >> 1]; end_b = a.read_off[((it + n_waves) >> 1) + 1]; }
+        float gn[3][8];
+        uint32_t wn0, wn1, wsh, hn0, hn1, hsh;
+        OWP_LOAD(off, n, t0)
+        double carry[3] = {0.0, 0.0, 0.0};              // by TRUE class
+        while (true) {
+            float gv[3][8];
+#pragma unroll
+            for (int f = 0; f < 3; f++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) gv[f][k] = gn[f][k];
+            // bases p_lo - 2 .. p_lo + 13 as 2-bit fields (bits 0 .. 25 are used); the head bits of the lane's eight bases
+            const uint32_t win = __builtin_amdgcn_alignbit(wn1, wn0, wsh), headbits = __builtin_amdgcn_alignbit(hn1, hn0, hsh) & 0xffu;
+            // the unit after this one: the read's next 512 steps, or the wave's next item
+            uint64_t n_off;
+            uint32_t n_n, n_t0;
+            bool have_next;
+            if (t0 + 512u < n) { n_off = off; n_n = n; n_t0 = t0 + 512u; have_next = true; }
+            else {
+                it += n_waves;
+                have_next = it < n_items;
+                n_off = off_b; n_n = (uint32_t)(end_b - off_b); n_t0 = 0;
+                if (it + n_waves < n_items) { off_b = a.read_off[(it + n_waves) >> 1]; end_b = a.read_off[((it + n_waves) >> 1) + 1]; }
+            }
+            if (have_next) OWP_LOAD(n_off, n_n, n_t0)
+            __builtin_amdgcn_sched_barrier(0);          // (the loads stay in front of the arithmetic)
+            if (t0 == 0) { carry[0] = 0.0; carry[1] = 0.0; carry[2] = 0.0; }
+            {
+                OWP_GEO(off, n, t0)
+                const uint32_t cnt = any ? (n - tb < 8u ? n - tb : 8u) : 0u;
+                const bool whole = any && cnt == 8u && g_lo >= 0 && (uint64_t)g_lo + 8 <= a.total;
+                const uint32_t pm = (uint32_t)(((p_first % 3) + 3) % 3);
+                double acc[3] = {0.0, 0.0, 0.0}, Pq[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int k = fwd ? 7 - e : e;
+                    const uint32_t w3 = (win >> (2 * k)) & 0xfffu;
+                    const uint32_t n6 = fwd ? (((w3 >> 8) & 3u) | (((w3 >> 6) & 3u) << 2) | (((w3 >> 4) & 3u) << 4)) : ((w3 & 63u) ^ 63u);
+                    double v[3];
+#pragma unroll
+                    for (int f = 0; f < 3; f++) v[f] = (double)gv[f][k] - s_null[f * 64 + n6];
+                    Pq[e] = acc[((1 - e) % 3 + 3) % 3];
+#pragma unroll
+                    for (int cp = 0; cp < 3; cp++) acc[cp] += v[(cp + e) % 3];
+                }
+                double tot[3], base[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const uint32_t cp = fwd ? ((uint32_t)c + 3u - pm) % 3u : (1u + pm + 3u - (uint32_t)c) % 3u;
+                    tot[c] = cp == 0u ? acc[0] : cp == 1u ? acc[1] : acc[2];
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const double inc = wcs_wave_scan(tot[c]);
+                    base[c] = carry[c] + (inc - tot[c]);
+                    carry[c] += wcs_last_lane(inc);
+                }
+                double qv[8], base_r[3];
+#pragma unroll
+                for (int cp = 0; cp < 3; cp++) {
+                    const uint32_t c = fwd ? ((uint32_t)cp + pm) % 3u : (1u + pm + 3u - (uint32_t)cp) % 3u;
+                    base_r[cp] = c == 0u ? base[0] : c == 1u ? base[1] : base[2];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) qv[fwd ? 7 - e : e] = base_r[((1 - e) % 3 + 3) % 3] + Pq[e];
+                uint32_t need = 0xffu;
+                if (heads && any) {
+                    need = headbits;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const uint32_t f5 = (win >> (2 * k)) & 0x3ffu;
+                        const uint32_t c = fwd ? ((f5 & 3u) << 4 | (f5 & 12u) | ((f5 >> 4) & 3u))
+                                               : ((((f5 >> 8) & 3u) << 4 | ((f5 >> 6) & 3u) << 2 | ((f5 >> 4) & 3u)) ^ 63u);
+                        const int64_t p = p_lo + k;
+                        const bool edge = p < 8 || p + 8 >= (int64_t)n;
+                        need |= (((a.start_set >> c) & 1ull) || edge ? 1u : 0u) << k;
+                    }
+                }
+                if (whole) {
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2)
+                        if ((need >> k) & 3u) { OwD2 d; d.v[0] = qv[k]; d.v[1] = qv[k + 1]; *(OwD2 *)(q + (uint64_t)g_lo + k) = d; }
+                } else if (any) {
+                    double *qb = q + ((int64_t)off + p_lo);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int64_t p = p_lo + k;
+                        const uint32_t e = (uint32_t)(fwd ? 7 - k : k);
+                        if (e < cnt && p >= 0 && p < (int64_t)n) qb[k] = qv[k];
+                    }
+                }
+            }
+            if (!have_next) break;
+            off = n_off; n = n_n; t0 = n_t0;
+        }
+#undef OWP_LOAD
+#undef OWP_GEO
+    };
+    if ((wave & 1) == 0) run(std::integral_constant<bool, true>()); else run(std::integral_constant<bool, false>());
+}
+
 // the HEAD position of every ORF (what k_orf_events reads as q_head), one bit per base and strand
 __global__ __launch_bounds__(256) void k_orf_mark_heads(const gmg_orf *orfs, const uint64_t n, const uint64_t *read_off, const int W, uint32_t *heads,
                                                         const uint64_t head_words)
@@ -959,7 +1119,7 @@ extern "C" int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *nul,
         // 2: every base (the form it is checked against); orfs_q_poison (tests): the array is filled with NaNs first, so that a read of an
         // entry that was not written cannot go unnoticed
         if (gmg_opt(GMG_OPT_ORFS_Q_POISON)) GMG_HIP(hipMemsetAsync(mb->d_walk, 0xff, (size_t)2 * reads->total_bases * sizeof(double), s));
-        if (gmg_opt(GMG_OPT_ORFS_WALK8) == 1) {
+        if (gmg_opt(GMG_OPT_ORFS_WALK8) == 1 || gmg_opt(GMG_OPT_ORFS_WALK8) == 3) {
             for (uint32_t c = 0; c < 64; c++) {         // Codon_t::Can_Be (gene.cc:39-66) for every definite codon, as k_orf_events' s_which
                 const uint32_t m = (1u << ((c >> 4) & 3u)) << 8 | (1u << ((c >> 2) & 3u)) << 4 | (1u << (c & 3u));
                 for (int p = 0; p < prm->n_start_codons && p < 8; p++) {
@@ -976,7 +1136,8 @@ extern "C" int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *nul,
         }
         const uint64_t waves = 2 * reads->n_reads, wblocks = (waves + 3) / 4;
         // (option orfs_walk8: the lane-on-eight-steps form, the default; 0: the lane-on-every-64th-step form it is checked against)
-        if (gmg_opt(GMG_OPT_ORFS_WALK8)) hipLaunchKernelGGL(k_orf_walk_sums8, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
+        if (gmg_opt(GMG_OPT_ORFS_WALK8) == 3) hipLaunchKernelGGL(k_orf_walk_sums8p, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
+        else if (gmg_opt(GMG_OPT_ORFS_WALK8)) hipLaunchKernelGGL(k_orf_walk_sums8, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
         else hipLaunchKernelGGL(k_orf_walk_sums, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
         GMG_HIP(hipGetLastError());
     } else if (fused) {

@@ -318,10 +318,10 @@ def test_frame6_true_size_every_row_beyond_4_gib(gpu, nc, oracle, o_nc):
 
 # ---------------------------------------------------------------- a12: Score_Orfs inner loop
 
-ORF_PATHS = {"events": 0, "exact": 1, "fused": 2, "events-walk64": 0, "events-dense": 0}    # option orfs_exact_path (gmg_orfs.hip); events-walk64: the
+ORF_PATHS = {"events": 0, "exact": 1, "fused": 2, "events-walk64": 0, "events-dense": 0, "events-prefetch": 0}    # option orfs_exact_path (gmg_orfs.hip); events-walk64: the
 # running sums by k_orf_walk_sums (option orfs_walk8 = 0), events-dense: by k_orf_walk_sums8 with every base written (= 2) instead of only
 # where k_orf_events can ask (= 1, the default).  orfs_q_poison: the array is NaNs before the sums are written -- a read of an unwritten entry shows.
-ORF_WALK = {"events-walk64": 0, "events-dense": 2}
+ORF_WALK = {"events-walk64": 0, "events-dense": 2, "events-prefetch": 3}
 
 
 @pytest.mark.parametrize("name,kw", [("orfs_default", {}), ("orfs_X", {"allow_truncated": True}),
@@ -441,7 +441,7 @@ def test_score_orfs_full_size_properties(gpu, nc, oracle, o_nc, request_finalize
     gpu.set_option("orfs_exact_path", 0)
     gpu.set_option("orfs_walk8", 1)
     gpu.set_option("orfs_q_poison", 0)
-    assert got["events"] == got["fused"] == got["exact"] == got["events-walk64"] == got["events-dense"]
+    assert got["events"] == got["fused"] == got["exact"] == got["events-walk64"] == got["events-dense"] == got["events-prefetch"]
     assert got["events"][0] == res[:len(sl_rows)].tobytes()                 # ... and the slice of the big batch
     # (4) the oracle on sampled ORFs
     o_indep = oracle.indep(0.5)
