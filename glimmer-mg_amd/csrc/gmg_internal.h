@@ -129,9 +129,10 @@ enum GmgOpt {
                                  // 2 = both on the stack walker (k_mg_err_wave), 3 = count pass breadth first, write pass on the stack walker
                                  // (cross-checks), 0 = the tile / level kernels
     GMG_OPT_MG_ERR_WAVE_Q,       // ... tests: entries of a wave's call stack (0 = EW_QCAP; a full stack sends the batch to the level kernels)
-    GMG_OPT_ORFS_WALK8,          // gmg_score_orfs, events path, the running sums: 1 (default) = a lane on eight consecutive walk steps, written only where
-                                 // k_orf_events can ask for them (k_orf_walk_sums8 + k_orf_mark_heads), 2 = the same with every base written, 3 = with the next unit's loads in
-                                 // flight (k_orf_walk_sums8p: no faster), 0 = k_orf_walk_sums
+    GMG_OPT_ORFS_WALK8,          // gmg_score_orfs, events path, the running sums Q: 4 (default) = only the values k_orf_events can ask for, back to back per unit of
+                                 // 512 walk steps + a (prefix, need bits) pair per lane (k_orf_walk_sums8p<compact>); 1 = those values at their own bases
+                                 // (k_orf_walk_sums8 + k_orf_mark_heads: scattered partial-sector stores, as slow as 2 = every base written); 3 = as 1 with
+                                 // the next unit's loads in flight; 0 = k_orf_walk_sums (a lane on every 64th step)
     GMG_OPT_INGEST_SCANS,        // gmg_fasta_ingest: 1 = the first version (two hipcub scans over every byte + k_fa_pack), 0 = block summaries
     GMG_OPT_INGEST_PIECE_MIN,    // gmg_fasta_ingest: inputs of at least this many bytes are uploaded in 16 pieces, every piece parsed and packed as it arrives
     GMG_OPT_MG_ORFS_BITS,        // glimmer-mg front half: 1 = Find_Orfs on bit masks, a wave per window of reads, six lanes per read hopping from stop codon

@@ -20,6 +20,8 @@ struct OrfTmp { double s; int32_t which, pad; };   // one in-frame position of t
 struct gmg_orf_batch {
     double *d_walk;              // events path: running sums in walking order, [2][total_bases] (allocated on first use)
     uint32_t *d_heads;           // ... and one bit per base and strand: an ORF asks for the sum there (its HEAD position), [2][total_bases / 32 + 4]
+    uint16_t *d_qpre;            // ... compact form: per lane of every unit the values in front of its own, [2][total_bases / 8 + n_reads + 64]
+    uint8_t *d_qneed;            // ... and its need bits
     float *d_gene6;              // fused / events path: per-base gene values, [6][total_bases] (allocated on first use)
     OrfTmp *d_tmp;               // fused path: one slot per in-frame position, same offsets as the start lists
     gmg_orf *d_orfs;
@@ -280,6 +282,11 @@ struct OrfWalkArgs {
     const uint32_t *heads;       // [2][head_words] bit g of strand s: an ORF's HEAD position (k_orf_mark_heads); NULL: every base is written
     uint64_t head_words;
     uint64_t start_set;          // codons (first char << 4 | second << 2 | third) that match a start pattern
+    // compact form (k_orf_walk_sums8p<true>): the values a unit's lanes need are written back to back at the unit's first step;
+    // per lane of every unit the number of values in front of its own and its eight need bits
+    uint16_t *q_pre;             // [2][meta_stride]
+    uint8_t *q_need;             // [2][meta_stride]
+    uint64_t meta_stride;        // total / 8 + n_reads + 64: lane L of the unit (read r at off, first step t0) sits at (off >> 3) + r + (t0 >> 3) + L
 };
 
 constexpr int OW_EL = 4;         // walk steps per lane and trip: 256 per wave
@@ -540,6 +547,7 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8(OrfWalkArgs a)
 // rows 30 %, arithmetic 27 %, stores 22 % -- and three to four waves per SIMD do not overlap them.  Here a wave's items are all of one
 // strand (the grid has an even number of waves), the whole item loop runs once per strand, and the NEXT unit's loads are issued before
 // this unit's arithmetic (its offsets two items ahead); a scheduling barrier keeps the compiler from moving them down again.
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void k_orf_walk_sums8p(OrfWalkArgs a)
 {
     __shared__ double s_null[3 * 64];
@@ -607,6 +615,7 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8p(OrfWalkArgs a)
                 for (int k = 0; k < 8; k++) gv[f][k] = gn[f][k];
             // bases p_lo - 2 .. p_lo + 13 as 2-bit fields (bits 0 .. 25 are used); the head bits of the lane's eight bases
             const uint32_t win = __builtin_amdgcn_alignbit(wn1, wn0, wsh), headbits = __builtin_amdgcn_alignbit(hn1, hn0, hsh) & 0xffu;
+            const uint64_t it_of_unit = it;            // (it moves on below when the next unit is another item)
             // the unit after this one: the read's next 512 steps, or the wave's next item
             uint64_t n_off;
             uint32_t n_n, n_t0;
@@ -627,6 +636,10 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8p(OrfWalkArgs a)
                 const bool whole = any && cnt == 8u && g_lo >= 0 && (uint64_t)g_lo + 8 <= a.total;
                 const uint32_t pm = (uint32_t)(((p_first % 3) + 3) % 3);
                 double acc[3] = {0.0, 0.0, 0.0}, Pq[8];
+#ifdef OWP_NOCOMPUTE
+#pragma unroll
+                for (int e = 0; e < 8; e++) { Pq[e] = (double)gv[0][e] + (double)gv[1][e] + (double)gv[2][e]; acc[e % 3] += Pq[e]; }   // (diagnostic build)
+#else
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const int k = fwd ? 7 - e : e;
@@ -639,6 +652,7 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8p(OrfWalkArgs a)
 #pragma unroll
                     for (int cp = 0; cp < 3; cp++) acc[cp] += v[(cp + e) % 3];
                 }
+#endif
                 double tot[3], base[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
@@ -672,7 +686,32 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8p(OrfWalkArgs a)
                         need |= (((a.start_set >> c) & 1ull) || edge ? 1u : 0u) << k;
                     }
                 }
-                if (whole) {
+#ifdef OWP_NOSTORE
+                if (qv[0] == 1.2345e300) need = 0xffu; else need = 0;      // (diagnostic build: nothing is written)
+#endif
+                if (COMPACT) {
+                    // Scattered 16-byte stores of one value in seven cost what writing every base costs (the memory rewrites whole sectors:
+                    // 2.1 of the kernel's 4.3 ms either way, profiles/r05_orfs_walk8_elimination.txt).  So the unit's needed values go
+                    // back to back to the unit's first entries, in lane order and inside a lane by base, and k_orf_events finds a
+                    // value by its rank: the values in front of the lane's (q_pre) + the need bits below its own (q_need).
+                    need &= fwd ? (0xffu << (8u - cnt)) & 0xffu : (1u << cnt) - 1u;     // (only steps of the read)
+                    const uint32_t mine = (uint32_t)__popc(need);
+                    uint32_t incl = mine;
+#define OWP_ADD(CTRL, RM) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, CTRL, RM, 0xf, false)
+                    OWP_ADD(0x111, 0xf); OWP_ADD(0x112, 0xf); OWP_ADD(0x114, 0xf); OWP_ADD(0x118, 0xf); OWP_ADD(0x142, 0xa); OWP_ADD(0x143, 0xc);
+#undef OWP_ADD
+                    const uint32_t excl = incl - mine;
+                    if (any) {
+                        double *qu = q + off + t0 + excl;
+                        uint32_t slot = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                            if ((need >> k) & 1u) { qu[slot] = qv[k]; slot++; }
+                        const uint64_t mi = (fwd ? 0 : a.meta_stride) + (off >> 3) + (it_of_unit >> 1) + (t0 >> 3) + lane;
+                        a.q_pre[mi] = (uint16_t)excl;
+                        a.q_need[mi] = (uint8_t)need;
+                    }
+                } else if (whole) {
 #pragma unroll
                     for (int k = 0; k < 8; k += 2)
                         if ((need >> k) & 3u) { OwD2 d; d.v[0] = qv[k]; d.v[1] = qv[k + 1]; *(OwD2 *)(q + (uint64_t)g_lo + k) = d; }
@@ -717,6 +756,9 @@ struct OrfEventArgs {
     const float *gene6;
     const double *q;
     uint64_t total;
+    const uint16_t *q_pre;       // compact form of Q (k_orf_walk_sums8p<true>), or NULL: Q[strand][base]
+    const uint8_t *q_need;
+    uint64_t meta_stride;
 };
 
 // One lane per ORF: the HEAD positions by descent, then the codons from the 5' end down to the stop as the reference visits them
@@ -801,7 +843,16 @@ __global__ __launch_bounds__(256) void k_orf_events(OrfEventArgs fa)
                 f = f == 2 ? 0 : f + 1;
             }
         }
-        const double q_head = len > HEAD ? fa.q[(fwd ? 0 : fa.total) + (uint64_t)(g_b0 + dirg * HEAD)] : 0.0;
+        // Q at base g of this read and strand: the array itself, or (compact form) the value's rank inside its unit of 512 walk steps
+        auto q_at = [&](const int64_t g) __attribute__((always_inline)) -> double {
+            if (!fa.q_pre) return fa.q[(fwd ? 0 : fa.total) + (uint64_t)g];
+            const uint32_t p = (uint32_t)(g - (int64_t)r_off), t = fwd ? (uint32_t)L - 1u - p : p;     // the base's walk step
+            const uint32_t t0 = t & ~511u, ln = (t & 511u) >> 3, k = fwd ? 7u - (t & 7u) : (t & 7u);
+            const uint64_t mi = (fwd ? 0 : fa.meta_stride) + (r_off >> 3) + orf.read + (t0 >> 3) + ln;
+            const uint32_t rank = (uint32_t)fa.q_pre[mi] + (uint32_t)__popc((uint32_t)fa.q_need[mi] & ((1u << k) - 1u));
+            return fa.q[(fwd ? 0 : fa.total) + r_off + t0 + rank];
+        };
+        const double q_head = len > HEAD ? q_at(g_b0 + dirg * HEAD) : 0.0;
 
         // ---- the scan, from the 5' end (j = len - 1) down; only in-frame positions j >= j_lo can carry a start
         gmg_start *out = a.starts + a.start_off[i];
@@ -830,7 +881,7 @@ __global__ __launch_bounds__(256) void k_orf_events(OrfEventArgs fa)
                     const int k = fwd ? k0 + (len - 1 - j) : k0 - (len - 1 - j);
                     double next_s;
                     if (j <= HEAD) next_s = dh[j / 3];
-                    else next_s = dh[HEAD / 3] + (fa.q[(fwd ? 0 : fa.total) + (uint64_t)(g_b0 + dirg * j)] - q_head);
+                    else next_s = dh[HEAD / 3] + (q_at(g_b0 + dirg * j) - q_head);
                     const double pushed = (j + 2 > a.ignore_score_len && next_s < 0.0) ? 0.0 : next_s;
                     gmg_start st;
                     st.score = pushed; st.j = j + 2; st.pos = k; st.first = (first_pos == 0);
@@ -1024,7 +1075,7 @@ extern "C" int gmg_orf_batch_free(gmg_orf_batch *b)
 {
     if (!b) return GMG_OK;
     if (b->segs) gmg_segments_free(b->segs);
-    void *ptrs[] = {b->d_orfs, b->d_start_off, b->d_score, b->d_indep, b->d_results, b->d_starts, b->d_gene6, b->d_tmp, b->d_walk, b->d_heads,
+    void *ptrs[] = {b->d_orfs, b->d_start_off, b->d_score, b->d_indep, b->d_results, b->d_starts, b->d_gene6, b->d_tmp, b->d_walk, b->d_heads, b->d_qpre, b->d_qneed,
                     b->d_nst, b->d_coff, b->d_scan_tmp, b->d_compact};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1086,6 +1137,16 @@ extern "C" int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *nul,
     }
     if (events) {
         const uint64_t head_words = reads->total_bases / 32 + 4;
+        const uint64_t meta_stride = reads->total_bases / 8 + reads->n_reads + 64;
+        if (!mb->d_qpre) {
+            uint16_t *qp = nullptr;
+            uint8_t *qn = nullptr;
+            hipError_t e = hipMalloc((void **)&qp, (size_t)2 * meta_stride * 2);
+            if (e == hipSuccess) e = hipMalloc((void **)&qn, (size_t)2 * meta_stride);
+            if (e != hipSuccess) { if (qp) (void)hipFree(qp); return gmg_set_error(GMG_ENOMEM, "gmg_score_orfs: scratch: %s", hipGetErrorString(e)); }
+            mb->d_qpre = qp;
+            mb->d_qneed = qn;
+        }
         if (!mb->d_gene6 || !mb->d_walk || !mb->d_heads) {
             float *g6 = mb->d_gene6;
             double *wk = mb->d_walk;
@@ -1115,11 +1176,14 @@ extern "C" int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *nul,
         wa.heads = nullptr;
         wa.head_words = head_words;
         wa.start_set = 0;
+        wa.q_pre = mb->d_qpre;
+        wa.q_need = mb->d_qneed;
+        wa.meta_stride = meta_stride;
         // orfs_walk8 = 1 (default): Q only where k_orf_events can ask for it -- the ORFs' HEAD positions (marked here), start codons, the reads' ends;
         // 2: every base (the form it is checked against); orfs_q_poison (tests): the array is filled with NaNs first, so that a read of an
         // entry that was not written cannot go unnoticed
         if (gmg_opt(GMG_OPT_ORFS_Q_POISON)) GMG_HIP(hipMemsetAsync(mb->d_walk, 0xff, (size_t)2 * reads->total_bases * sizeof(double), s));
-        if (gmg_opt(GMG_OPT_ORFS_WALK8) == 1 || gmg_opt(GMG_OPT_ORFS_WALK8) == 3) {
+        if (gmg_opt(GMG_OPT_ORFS_WALK8) == 1 || gmg_opt(GMG_OPT_ORFS_WALK8) >= 3) {
             for (uint32_t c = 0; c < 64; c++) {         // Codon_t::Can_Be (gene.cc:39-66) for every definite codon, as k_orf_events' s_which
                 const uint32_t m = (1u << ((c >> 4) & 3u)) << 8 | (1u << ((c >> 2) & 3u)) << 4 | (1u << (c & 3u));
                 for (int p = 0; p < prm->n_start_codons && p < 8; p++) {
@@ -1136,7 +1200,8 @@ extern "C" int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *nul,
         }
         const uint64_t waves = 2 * reads->n_reads, wblocks = (waves + 3) / 4;
         // (option orfs_walk8: the lane-on-eight-steps form, the default; 0: the lane-on-every-64th-step form it is checked against)
-        if (gmg_opt(GMG_OPT_ORFS_WALK8) == 3) hipLaunchKernelGGL(k_orf_walk_sums8p, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
+        if (gmg_opt(GMG_OPT_ORFS_WALK8) == 4) hipLaunchKernelGGL(k_orf_walk_sums8p<true>, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
+        else if (gmg_opt(GMG_OPT_ORFS_WALK8) == 3) hipLaunchKernelGGL(k_orf_walk_sums8p<false>, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
         else if (gmg_opt(GMG_OPT_ORFS_WALK8)) hipLaunchKernelGGL(k_orf_walk_sums8, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
         else hipLaunchKernelGGL(k_orf_walk_sums, dim3((unsigned)(wblocks < 256 * 64 ? wblocks : 256 * 64)), dim3(256), 0, s, wa);
         GMG_HIP(hipGetLastError());
@@ -1207,6 +1272,9 @@ extern "C" int gmg_score_orfs_begin(const gmg_model *gene, const gmg_model *nul,
         ea.nul = nul->dev;
         ea.gene6 = b->d_gene6;
         ea.q = b->d_walk;
+        ea.q_pre = gmg_opt(GMG_OPT_ORFS_WALK8) == 4 ? b->d_qpre : nullptr;
+        ea.q_need = b->d_qneed;
+        ea.meta_stride = reads->total_bases / 8 + reads->n_reads + 64;
         ea.total = reads->total_bases;
         const size_t lds = (size_t)3 * gene->dev.cstride + (3 * 64 + 3 * 20) * sizeof(float);
         hipLaunchKernelGGL(k_orf_events, dim3(grid), dim3(256), lds, s, ea);

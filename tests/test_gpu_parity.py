@@ -318,10 +318,10 @@ def test_frame6_true_size_every_row_beyond_4_gib(gpu, nc, oracle, o_nc):
 
 # ---------------------------------------------------------------- a12: Score_Orfs inner loop
 
-ORF_PATHS = {"events": 0, "exact": 1, "fused": 2, "events-walk64": 0, "events-dense": 0, "events-prefetch": 0}    # option orfs_exact_path (gmg_orfs.hip); events-walk64: the
-# running sums by k_orf_walk_sums (option orfs_walk8 = 0), events-dense: by k_orf_walk_sums8 with every base written (= 2) instead of only
-# where k_orf_events can ask (= 1, the default).  orfs_q_poison: the array is NaNs before the sums are written -- a read of an unwritten entry shows.
-ORF_WALK = {"events-walk64": 0, "events-dense": 2, "events-prefetch": 3}
+ORF_PATHS = {"events": 0, "exact": 1, "fused": 2, "events-walk64": 0, "events-dense": 0, "events-prefetch": 0, "events-sparse": 0}    # option orfs_exact_path (gmg_orfs.hip); events-walk64: the
+# running sums by k_orf_walk_sums (option orfs_walk8 = 0), events-dense: by k_orf_walk_sums8 with every base written (= 2), events-sparse: only where
+# k_orf_events can ask (= 1), events-prefetch (= 3), instead of the compact form (= 4, the default: those values back to back per unit).  orfs_q_poison: the array is NaNs before the sums are written -- a read of an unwritten entry shows.
+ORF_WALK = {"events-walk64": 0, "events-dense": 2, "events-prefetch": 3, "events-sparse": 1}
 
 
 @pytest.mark.parametrize("name,kw", [("orfs_default", {}), ("orfs_X", {"allow_truncated": True}),
@@ -333,9 +333,9 @@ def test_score_orfs_golden_start_lists(gpu, nc, fa_reads, name, kw, path, reques
     through the events path (running sums per strand and class, an ORF visits its start codons only), the fused path
     (gene-only six-frame pass + k_orf_fused: one lane walks the ORF) and the exact any-model path."""
     gpu.set_option("orfs_exact_path", ORF_PATHS[path])
-    gpu.set_option("orfs_walk8", ORF_WALK.get(path, 1))
+    gpu.set_option("orfs_walk8", ORF_WALK.get(path, 4))
     gpu.set_option("orfs_q_poison", 1)
-    request_finalizers.append(lambda: (gpu.set_option("orfs_exact_path", 0), gpu.set_option("orfs_walk8", 1), gpu.set_option("orfs_q_poison", 0)))
+    request_finalizers.append(lambda: (gpu.set_option("orfs_exact_path", 0), gpu.set_option("orfs_walk8", 4), gpu.set_option("orfs_q_poison", 0)))
     g = np.load(os.path.join(GOLD, name + ".npz"))
     gc = float(np.load(os.path.join(GOLD, "frames_nc.npz"))["gc"])
     res, starts = gpu.score_orfs(nc, gpu.Icm.indep(gc), fa_reads, g["orfs"], **kw)
@@ -358,9 +358,9 @@ def test_score_orfs_random_orfs_on_ragged_reads_vs_oracle(gpu, nc, oracle, o_nc,
     """random in-range ORFs (both strands, lengths 3..read length, also not a multiple of 3) on reads of ragged lengths:
     every field of every start and of the per-ORF result must equal the oracle's Score_Orfs restatement"""
     gpu.set_option("orfs_exact_path", ORF_PATHS[path])
-    gpu.set_option("orfs_walk8", ORF_WALK.get(path, 1))
+    gpu.set_option("orfs_walk8", ORF_WALK.get(path, 4))
     gpu.set_option("orfs_q_poison", 1)
-    request_finalizers.append(lambda: (gpu.set_option("orfs_exact_path", 0), gpu.set_option("orfs_walk8", 1), gpu.set_option("orfs_q_poison", 0)))
+    request_finalizers.append(lambda: (gpu.set_option("orfs_exact_path", 0), gpu.set_option("orfs_walk8", 4), gpu.set_option("orfs_q_poison", 0)))
     rng = np.random.default_rng(77)
     lengths = [int(x) for x in rng.integers(40, 900, size=120)] + [12, 13, 30, 500, 2100]
     seqs = ["".join("acgt"[c] for c in rng.integers(0, 4, size=n)) for n in lengths]
@@ -433,15 +433,15 @@ def test_score_orfs_full_size_properties(gpu, nc, oracle, o_nc, request_finalize
     got = {}
     for name, opt in ORF_PATHS.items():
         gpu.set_option("orfs_exact_path", opt)
-        gpu.set_option("orfs_walk8", ORF_WALK.get(name, 1))
+        gpu.set_option("orfs_walk8", ORF_WALK.get(name, 4))
         gpu.set_option("orfs_q_poison", 1)
-        request_finalizers.append(lambda: (gpu.set_option("orfs_exact_path", 0), gpu.set_option("orfs_walk8", 1), gpu.set_option("orfs_q_poison", 0)))
+        request_finalizers.append(lambda: (gpu.set_option("orfs_exact_path", 0), gpu.set_option("orfs_walk8", 4), gpu.set_option("orfs_q_poison", 0)))
         r_, s_ = gpu.score_orfs(nc, indep, sl_reads, sl_rows, **kw)
         got[name] = (r_.tobytes(), s_[:int(r_["start_begin"][-1]) + int(r_["n_starts"][-1])].tobytes())
     gpu.set_option("orfs_exact_path", 0)
-    gpu.set_option("orfs_walk8", 1)
+    gpu.set_option("orfs_walk8", 4)
     gpu.set_option("orfs_q_poison", 0)
-    assert got["events"] == got["fused"] == got["exact"] == got["events-walk64"] == got["events-dense"] == got["events-prefetch"]
+    assert got["events"] == got["fused"] == got["exact"] == got["events-walk64"] == got["events-dense"] == got["events-prefetch"] == got["events-sparse"]
     assert got["events"][0] == res[:len(sl_rows)].tobytes()                 # ... and the slice of the big batch
     # (4) the oracle on sampled ORFs
     o_indep = oracle.indep(0.5)
