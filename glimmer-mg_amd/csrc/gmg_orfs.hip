@@ -636,10 +636,6 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8p(OrfWalkArgs a)
                 const bool whole = any && cnt == 8u && g_lo >= 0 && (uint64_t)g_lo + 8 <= a.total;
                 const uint32_t pm = (uint32_t)(((p_first % 3) + 3) % 3);
                 double acc[3] = {0.0, 0.0, 0.0}, Pq[8];
-#ifdef OWP_NOCOMPUTE
-#pragma unroll
-                for (int e = 0; e < 8; e++) { Pq[e] = (double)gv[0][e] + (double)gv[1][e] + (double)gv[2][e]; acc[e % 3] += Pq[e]; }   // (diagnostic build)
-#else
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const int k = fwd ? 7 - e : e;
@@ -652,7 +648,6 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8p(OrfWalkArgs a)
 #pragma unroll
                     for (int cp = 0; cp < 3; cp++) acc[cp] += v[(cp + e) % 3];
                 }
-#endif
                 double tot[3], base[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
@@ -686,9 +681,6 @@ __global__ __launch_bounds__(256) void k_orf_walk_sums8p(OrfWalkArgs a)
                         need |= (((a.start_set >> c) & 1ull) || edge ? 1u : 0u) << k;
                     }
                 }
-#ifdef OWP_NOSTORE
-                if (qv[0] == 1.2345e300) need = 0xffu; else need = 0;      // (diagnostic build: nothing is written)
-#endif
                 if (COMPACT) {
                     // Scattered 16-byte stores of one value in seven cost what writing every base costs (the memory rewrites whole sectors:
                     // 2.1 of the kernel's 4.3 ms either way, profiles/r05_orfs_walk8_elimination.txt).  So the unit's needed values go
