@@ -34,7 +34,7 @@ extern "C" const char *gmg_last_error(void) { return g_err; }
 long long g_gmg_opt[GMG_OPT_COUNT] = {
     /* seg_plain */ 0, /* mg_tile */ 0, /* mg_one_stream */ 0, /* mg_err_flat */ 0, /* mg_err_calls */ 0, /* mg_err_calls_grow */ 0,
     /* orfs_exact_path */ 0, /* train_sort_min */ -1, /* mg_max_entries */ 0x7ffffffell, /* mg_timing */ 0, /* ingest_timing */ 0,
-    /* train_timing */ 0, /* diag */ 0, /* strings_fused */ 1, /* mg_gene32 */ 1, /* mg_fused */ 1, /* mg_err_skip */ 1, /* mg_orfs_events */ 1,
+    /* train_timing */ 0, /* diag */ 0, /* strings_fused */ 1, /* mg_gene32 */ 1, /* mg_fused */ 1, /* mg_err_skip */ 1, /* mg_orfs_events */ 2,
     /* mg_err_tile */ -1, /* mg_err_tile_q */ 0, /* mg_err_qonly */ 1, /* mg_err_wave */ 1, /* mg_err_wave_q */ 0, /* orfs_walk8 */ 4, /* ingest_scans */ 0, /* ingest_piece_min */ 64ll << 20, /* mg_orfs_bits */ 0, /* orfs_q_poison */ 0};
 static const char *const g_opt_name[GMG_OPT_COUNT] = {
     "seg_plain", "mg_tile", "mg_one_stream", "mg_err_flat", "mg_err_calls", "mg_err_calls_grow", "orfs_exact_path",

@@ -115,8 +115,9 @@ enum GmgOpt {
                                  // when the models' values allow it (k_mg_tile_starts), 0 = always the sequential walks
     GMG_OPT_MG_ERR_SKIP,         // glimmer-mg's error branch: 1 = scores as differences of running sums, walks visit their events only (when the
                                  // models' values allow it), 0 = every walk adds up its own sum codon by codon
-    GMG_OPT_MG_ORFS_EVENTS,      // glimmer-mg front half, default mode: 1 = the ORF scan's write pass queues the codons that are in a start or
-                                 // stop set and runs the reference's steps over the queue (k_mg_find_orfs_ev), 0 = at every position
+    GMG_OPT_MG_ORFS_EVENTS,      // glimmer-mg front half, the ORF scan's write pass (k_mg_find_orfs_ev): the reference's steps only at the codons that are in a
+                                 // start or stop set -- 2 (default) = found as the set bits of four 32-codon masks in registers, 1 = queued in LDS
+                                 // 64 positions at a time; 0 = the steps at every position (k_mg_find_orfs<write>)
     GMG_OPT_MG_ERR_TILE,         // glimmer-mg's error branch: 1 = tile by tile with the running sums in LDS, one lane per event (k_mg_err_tile; needs
                                  // mg_err_skip and sums that are exact in any order), 0 = the level kernels on the walk-order tables in HBM, -1
                                  // (default) = by the batch's size: the tile kernel up to 90 (-i) / 60 (-s) Mbases, the level kernels beyond

@@ -518,14 +518,30 @@ __global__ __launch_bounds__(64) void k_find_orfs_general(MgArgs a, const int ci
 // ---------------------------------------------------------------------------------------------------
 #define MG_EV_CH 64
 #define MG_EV_LANES 64            // one-wave work-groups (8 KB of LDS: one of them fits beside the six-frame kernel's work-group on a CU)
-__global__ __launch_bounds__(MG_EV_LANES) void k_mg_find_orfs_ev(MgArgs a)
+// MASKS (the default): phase A without a queue -- the four tests of 32 consecutive codons as four 32-bit masks in registers (16 look-ups
+// of a 256-entry table: four bases -> two codons x four tests; the word-aligned 32 bases that hold them), phase B over the set bits of
+// their union.  A sixth of phase A's instructions, and 1 KB of LDS instead of 8: up to four of these waves fit beside the six-frame
+// kernel's work-group on a CU (registers), so most of the pass runs in its shadow.
+template <bool MASKS>
+__global__ __launch_bounds__(MG_EV_LANES, 5) void k_mg_find_orfs_ev(MgArgs a)       // (five waves per SIMD = 96 registers: what the six-frame kernel leaves free)
 {
-    __shared__ uint16_t s_q[MG_EV_CH][MG_EV_LANES];             // events of the chunk: position in the chunk | set bits << 8
+    __shared__ uint16_t s_q[MASKS ? 1 : MG_EV_CH][MG_EV_LANES];     // events of the chunk: position in the chunk | set bits << 8
     __shared__ uint8_t s_evt[64];                       // by codon index: bit 0 forward start, 1 reverse start, 2 forward stop, 3 reverse stop
+    __shared__ uint32_t s_tab[MASKS ? 256 : 1];         // four bases -> byte m: the two codons' membership in set m (fs, rs, ft, rt)
     if (threadIdx.x < 64) {
         const uint64_t bit = 1ull << threadIdx.x;
         s_evt[threadIdx.x] = (uint8_t)(((a.fwd_start & bit) ? 1 : 0) | ((a.rev_start & bit) ? 2 : 0) | ((a.fwd_stop & bit) ? 4 : 0) | ((a.rev_stop & bit) ? 8 : 0));
     }
+    if (MASKS)
+        for (uint32_t key = threadIdx.x; key < 256; key += MG_EV_LANES) {
+            const uint32_t c0 = (key & 3u) << 4 | (key & 12u) | ((key >> 4) & 3u), k1 = key >> 2;
+            const uint32_t c1 = (k1 & 3u) << 4 | (k1 & 12u) | ((k1 >> 4) & 3u);
+            const uint64_t sets[4] = {a.fwd_start, a.rev_start, a.fwd_stop, a.rev_stop};
+            uint32_t e = 0;
+#pragma unroll
+            for (int m = 0; m < 4; m++) e |= (uint32_t)(((sets[m] >> c0) & 1ull) | ((sets[m] >> c1) & 1ull) << 1) << (8 * m);
+            s_tab[key] = e;
+        }
     __syncthreads();
     const uint32_t lane = threadIdx.x;
     const int mgl = a.min_gene_len;
@@ -621,6 +637,66 @@ __global__ __launch_bounds__(MG_EV_LANES) void k_mg_find_orfs_ev(MgArgs a)
         BaseStream<1> bs;
         bs.init(a.packed, off);
         uint32_t idx6 = 0;
+        // the reference's steps at one codon that is in a start or stop set (position I_ of the read, B_: which sets).  A macro: as a lambda
+        // that captures the three classes' states the compiler kept them in scratch memory (160 bytes per lane: the pass took 7 ms)
+#define MG_EV_EVENT(I_, B_)                                                                                                        \
+        {                                                                                                                        \
+            const int i = (I_);                                                                                                  \
+            const uint32_t bits = (B_);                                                                                          \
+                const int c = (int)((uint32_t)i % 3u);                                                                           \
+                MgClass S = c == 0 ? cs[0] : c == 1 ? cs[1] : cs[2];                                                             \
+                int li = c == 0 ? last_i[0] : c == 1 ? last_i[1] : last_i[2];                                                    \
+                if (counting) {                                                                                                  \
+                    advance(S, li, i, (bits & 5u) == 1u ? 1ull : 0ull);                                                          \
+                    if ((bits & 10u) == 2u && i >= S.rev_from) S.rev_cnt++;                                                      \
+                }                                                                                                                \
+                if ((bits & 1u) && S.first_fwd_start == INT_MAX) S.first_fwd_start = i - 1;                                      \
+                if (bits & 2u) S.last_rev_start = i - 1;                                                                         \
+                if (bits & 4u) { fwd_stop(i, S, c); S.fwd_last = i; }                                                            \
+                if (bits & 8u) rev_stop(i, S, c);                                                                                \
+                if (c == 0) { cs[0] = S; last_i[0] = li; } else if (c == 1) { cs[1] = S; last_i[1] = li; } else { cs[2] = S; last_i[2] = li; } \
+        }
+        if (MASKS) {
+            // ---- 32 word-aligned bases at a time: the four tests of their codons as masks (bit b: the codon whose LAST base is base 32 w + b)
+            const uint64_t wb = off & ~31ull;
+            const int lead = (int)(off - wb);           // bases of the first word in front of the read
+            for (uint64_t g0 = wb; g0 < off + (uint64_t)n; g0 += 32) {
+                const uint32_t *pw = a.packed + (g0 >> 4);
+                const uint32_t q0 = pw[-1], q1 = pw[0], q2 = pw[1];        // (guard words in front of the first read)
+                const uint32_t s0 = q0 >> 28 | q1 << 4, s1 = q1 >> 28 | q2 << 4, s2 = q2 >> 28;
+                uint32_t X[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    uint32_t t[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int j = 4 * g + u;
+                        uint32_t key;
+                        if (j < 7) key = (s0 >> (4 * j)) & 255u;
+                        else if (j == 7) key = (s0 >> 28 | s1 << 4) & 255u;
+                        else if (j < 15) key = (s1 >> (4 * (j - 8))) & 255u;
+                        else key = (s1 >> 28 | s2 << 4) & 255u;
+                        t[u] = s_tab[key];
+                    }
+                    X[g] = t[0] | t[1] << 2 | t[2] << 4 | t[3] << 6;       // byte m: eight codons' membership in set m
+                }
+                uint32_t msk[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+                    msk[m] = ((X[0] >> (8 * m)) & 255u) | ((X[1] >> (8 * m)) & 255u) << 8 | ((X[2] >> (8 * m)) & 255u) << 16 | ((X[3] >> (8 * m)) & 255u) << 24;
+                // positions of the read with a whole codon behind them: i = 32 w + b - lead in [2, n)
+                const int i0 = (int)(g0 - wb) - lead;   // position of bit 0
+                uint32_t valid = ~0u;
+                if (i0 < 2) valid = 2 - i0 >= 32 ? 0u : ~0u << (2 - i0);
+                if (n - i0 < 32) valid &= (1u << (n - i0)) - 1u;
+                uint32_t any = (msk[0] | msk[1] | msk[2] | msk[3]) & valid;
+                while (any) {
+                    const uint32_t b = (uint32_t)__ffs((int)any) - 1u;
+                    any &= any - 1u;
+                    MG_EV_EVENT(i0 + (int)b, ((msk[0] >> b) & 1u) | ((msk[1] >> b) & 1u) << 1 | ((msk[2] >> b) & 1u) << 2 | ((msk[3] >> b) & 1u) << 3)
+                }
+            }
+        } else
         for (int chunk0 = 0; chunk0 < n; chunk0 += MG_EV_CH) {
             // ---- phase A: look
             const int kn = n - chunk0 < MG_EV_CH ? n - chunk0 : MG_EV_CH;
@@ -634,22 +710,10 @@ __global__ __launch_bounds__(MG_EV_LANES) void k_mg_find_orfs_ev(MgArgs a)
             // ---- phase B: the reference's steps at the queued codons
             for (uint32_t e = 0; e < nq; e++) {
                 const uint32_t ev = s_q[e][lane];
-                const int i = chunk0 + (int)(ev & 255u);
-                const uint32_t bits = ev >> 8;
-                const int c = (int)((uint32_t)i % 3u);
-                MgClass S = c == 0 ? cs[0] : c == 1 ? cs[1] : cs[2];
-                int li = c == 0 ? last_i[0] : c == 1 ? last_i[1] : last_i[2];
-                if (counting) {                         // (the stop codon that ends a region is no start, even when the start set holds it)
-                    advance(S, li, i, (bits & 5u) == 1u ? 1ull : 0ull);
-                    if ((bits & 10u) == 2u && i >= S.rev_from) S.rev_cnt++;
-                }
-                if ((bits & 1u) && S.first_fwd_start == INT_MAX) S.first_fwd_start = i - 1;
-                if (bits & 2u) S.last_rev_start = i - 1;
-                if (bits & 4u) { fwd_stop(i, S, c); S.fwd_last = i; }
-                if (bits & 8u) rev_stop(i, S, c);
-                if (c == 0) { cs[0] = S; last_i[0] = li; } else if (c == 1) { cs[1] = S; last_i[1] = li; } else { cs[2] = S; last_i[2] = li; }
+                MG_EV_EVENT(chunk0 + (int)(ev & 255u), ev >> 8)
             }
         }
+#undef MG_EV_EVENT
         // Finish_Orfs (glimmer_base.cc:783-817) + Handle_Last_Reverse_Stop, linear (:1053-1066)
 #pragma unroll
         for (int fr = 0; fr < 3; fr++) {
@@ -3704,7 +3768,8 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         hipLaunchKernelGGL(k_mg_find_orfs_bits<true>, dim3(ob_grid), dim3(64 * OB_WAVES), 0, s2, a, ob_windows, ob_win_bases, ob_rpw);
     } else if (nr && gmg_opt(GMG_OPT_MG_ORFS_EVENTS)) {
         const uint64_t blocks = (nr + MG_EV_LANES - 1) / MG_EV_LANES;
-        hipLaunchKernelGGL(k_mg_find_orfs_ev, dim3((unsigned)(blocks < 256 * 128 ? blocks : 256 * 128)), dim3(MG_EV_LANES), 0, s2, a);
+        if (gmg_opt(GMG_OPT_MG_ORFS_EVENTS) == 1) hipLaunchKernelGGL(k_mg_find_orfs_ev<false>, dim3((unsigned)(blocks < 256 * 128 ? blocks : 256 * 128)), dim3(MG_EV_LANES), 0, s2, a);
+        else hipLaunchKernelGGL(k_mg_find_orfs_ev<true>, dim3((unsigned)(blocks < 256 * 128 ? blocks : 256 * 128)), dim3(MG_EV_LANES), 0, s2, a);
     } else if (nr) hipLaunchKernelGGL(k_mg_find_orfs<true>, dim3(grid_for(nr)), dim3(256), 0, s2, a);
     MG_TRY(hipGetLastError());
     tm.lap("find orfs");

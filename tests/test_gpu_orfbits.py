@@ -112,3 +112,23 @@ def test_a_million_bases_of_short_and_long_reads(gpu):
             with gpu.option("mg_orfs_bits", 0):
                 orfs0, off0 = gpu.find_orfs(reads, **kw)
             assert np.array_equal(off, off0) and np.array_equal(fields(orfs), fields(orfs0)) and len(orfs) > 1000
+
+
+@pytest.mark.parametrize("opt", sorted(OPTIONS))
+@pytest.mark.parametrize("batch", ["ragged", "ragged_with_tiny_reads", "word_edges", "uniform_500", "at_rich"])
+def test_write_pass_forms_of_the_orf_scan_agree(gpu, batch, opt):
+    """k_mg_find_orfs_ev with its events from register masks (mg_orfs_events = 2, the default), from the LDS queue (1), and
+    k_mg_find_orfs<write> at every position (0): the same records, and through gmg_mg_score_reads the same start counts and lists"""
+    rng = np.random.default_rng(sum(map(ord, batch + opt)) + 1)
+    seqs = BATCHES[batch](rng) + ["a" * 40 + "atg" + "gct" * 40 + "taa", "tta" + "cat" * 30 + "c" * 33]
+    kw = OPTIONS[opt]
+    reads = gpu.Reads.from_strings(seqs)
+    nc = gpu.Icm.open(os.path.join(DATA, "NC_000915.icm"))
+    stops = kw.get("stop_codons", ("taa", "tag", "tga"))
+    got = {}
+    for form in (2, 1, 0):
+        with gpu.option("mg_orfs_events", form):
+            orfs, off = gpu.find_orfs(reads, **kw)
+            full = gpu.mg_score_reads(nc, gpu.Icm.indep(0.45, stops), reads, **kw)
+        got[form] = (fields(orfs).tobytes(), off.tobytes(), tuple(x.tobytes() for x in full))
+    assert got[2] == got[1] == got[0]

@@ -118,7 +118,7 @@ def test_frame6_uniform_batches_vs_oracle(gpu, nc, oracle, o_nc, n, L):
 
 def test_options_api(gpu):
     assert gpu.get_option("strings_fused") == 1
-    assert (gpu.get_option("mg_fused"), gpu.get_option("mg_err_skip"), gpu.get_option("mg_orfs_events")) == (1, 1, 1)
+    assert (gpu.get_option("mg_fused"), gpu.get_option("mg_err_skip"), gpu.get_option("mg_orfs_events")) == (1, 1, 2)
     with gpu.option("mg_tile", 512):
         assert gpu.get_option("mg_tile") == 512
     assert gpu.get_option("mg_tile") == 0
