@@ -1406,7 +1406,10 @@ struct MtTile { uint64_t w0; uint32_t first, nfit, span, o0, o1, rn0; };    // r
 // NC: the per-read null tables held (PRN): MT_NC, or 2 when the batch's reads let a tile take two at most (uniform 500-bp reads in two-wave tiles:
 // 4 KB less LDS = eight work-groups per CU there too)
 template <int NW, bool G32, int EL, bool PRN, int NC = MT_NC>
-__global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? MT_MIN_WAVES : EL == 9 ? 3 : 1) void k_mg_tile_starts(MgArgs a)
+#ifndef MT_PRN_WAVES
+#define MT_PRN_WAVES MT_MIN_WAVES    // ... with a null model per read (the form spills 8 registers at four waves: 3 was measured, profiles/r05_prn_ab.txt)
+#endif
+__global__ __launch_bounds__(64 * NW, G32 && EL == 8 ? (PRN ? MT_PRN_WAVES : MT_MIN_WAVES) : EL == 9 ? 3 : 1) void k_mg_tile_starts(MgArgs a)
 {
     constexpr int BLOCK = 64 * NW, WV = 3 * MT_CL * EL, CAP = WV * NW;
     constexpr bool DIST = !(G32 && PRN);                                // a base's distance to its read's ends from s_oinfo instead of followed read offsets
@@ -2913,16 +2916,28 @@ __global__ __launch_bounds__(256) void k_mg_order_starts(const gmg_mg_orf *orfs,
         if (n == 0) continue;
         if (n <= 64) {                                  // the keys sit in the lanes
             const uint64_t key = lane < n ? keys[b + lane] : ~0ull;
-            gmg_start st;
-            gmg_start_errors er;
-            if (lane < n) { st = s_in[b + lane]; er = e_in[b + lane]; }
+            // (a start = three 64-bit words, its Error_t list three 32-bit ones: as words they stay in registers -- the structs went through scratch)
+            uint64_t sw[3] = {0, 0, 0};
+            uint32_t ew[3] = {0, 0, 0};
+            static_assert(sizeof(gmg_start) == 24 && sizeof(gmg_start_errors) == 12, "k_mg_order_starts moves them as words");
+            if (lane < n) {
+                const uint64_t *sp = (const uint64_t *)(const void *)(s_in + b + lane);
+                const uint32_t *ep = (const uint32_t *)(const void *)(e_in + b + lane);
+#pragma unroll
+                for (int w = 0; w < 3; w++) { sw[w] = sp[w]; ew[w] = ep[w]; }
+            }
             uint32_t rank = 0;
             for (uint32_t j = 0; j < n; j++) {
                 const uint64_t kj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, (int)j) |
                                     (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), (int)j) << 32;
                 rank += (kj < key || (kj == key && j < lane)) ? 1u : 0u;
             }
-            if (lane < n) { s_out[b + rank] = st; e_out[b + rank] = er; }
+            if (lane < n) {
+                uint64_t *sp = (uint64_t *)(void *)(s_out + b + rank);
+                uint32_t *ep = (uint32_t *)(void *)(e_out + b + rank);
+#pragma unroll
+                for (int w = 0; w < 3; w++) { sp[w] = sw[w]; ep[w] = ew[w]; }
+            }
             continue;
         }
         // E starts per lane and round (start m0 + lane + 64 e), every key read once per round from LDS by all lanes
