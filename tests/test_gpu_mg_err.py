@@ -247,3 +247,32 @@ def test_accepted_only_is_the_full_result_filtered(gpu, nc, name, kw):
     idx = np.concatenate([np.arange(b, b + c) for b, c in zip(fo["start_begin"].astype(np.int64), fo["n_starts"].astype(np.int64))])
     assert full[1][idx].tobytes() == kept[1].tobytes() and full[3][idx].tobytes() == kept[3].tobytes()
     assert np.array_equal(kept[2], np.concatenate([[0], np.cumsum(keep)])[full[2].astype(np.int64)])
+
+
+def test_long_start_lists_keep_the_reference_order(gpu, oracle, nc):
+    """k_mg_order_starts puts an ORF's starts into push order by counting: up to 64 starts with the keys in the lanes, beyond that through
+    LDS 512 at a time, eight starts per lane and round.  Reads rich in G + C (ORFs that span them) with a quality file that lets every
+    third base branch give lists of several thousand starts: every tier, against the oracle entry by entry."""
+    rng = np.random.default_rng(3)
+
+    def rr(n, at):
+        return "".join("acgt"[c] for c in rng.choice(4, size=n, p=[at, .5 - at, .5 - at, at]))
+    seqs = [rr(900, 0.12) for _ in range(5)] + [rr(600, 0.2) for _ in range(5)] + [rr(300, 0.25) for _ in range(5)]
+    reads = gpu.Reads.from_strings(seqs)
+    quals = [rng.integers(0, 41, size=len(s)).astype(np.int32) for s in seqs]
+    ekw = dict(allow_indels=True, indel_quality_threshold=30, indel_suffix_score_threshold=-12.0)
+    orfs, starts, off, errs = gpu.mg_score_reads(nc, gpu.Icm.indep(0.5), reads, quality=np.concatenate(quals).astype(np.uint8), **ekw)
+    ns = orfs["n_starts"]
+    assert int((ns <= 64).sum()) > 0 and int(((ns > 64) & (ns <= 512)).sum()) > 0 and int((ns > 1024).sum()) > 0, int(ns.max())
+    prm, ep = oracle.mg_params(), oracle.mg_err_params(**ekw)
+    o_nc, o_indep = oracle.read(os.path.join(DATA, "NC_000915.icm")), oracle.indep(0.5, ("taa", "tag", "tga"))
+    checked = 0
+    for r, s in enumerate(seqs):
+        want_orfs, _, scored = oracle.mg_read_errors(o_nc, o_indep, s.encode(), prm, ep, quals[r])
+        mine = orfs[int(off[r]):int(off[r + 1])]
+        assert len(mine) == len(scored)
+        for o, (out, want) in zip(mine, scored):
+            sl = slice(o["start_begin"], o["start_begin"] + o["n_starts"])
+            assert dev_err_rows(starts[sl], errs[sl]) == err_rows(want), (r, int(o["n_starts"]))
+            checked += len(want)
+    assert checked == int(ns.sum())
