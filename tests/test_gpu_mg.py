@@ -487,3 +487,21 @@ def test_find_orfs_ignore_regions_and_circular_on_the_device(gpu, oracle, name):
     # the front half itself does not take such calls
     with pytest.raises(gpu.GmgError):
         gpu.find_orfs(reads, ignore_regions=[(50, 40)], **kw)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 1023, 1024, 4095, 4096, 4097, 8191, 8193, 65537, 300001])
+def test_prefix_sums_at_tile_and_chunk_edges(gpu, n):
+    """gmg_scan.h (tiles of 4,096 items, 16-byte chunks of four; 32-bit and 64-bit items): the offsets of a selection of n reads
+    (64-bit lengths -> offsets) and the ORF offsets of gmg_find_orfs (32-bit counts -> 64-bit offsets) against numpy's cumsum"""
+    rng = np.random.default_rng(n)
+    base_lens = rng.integers(0, 120, size=257)
+    seqs = random_reads(rng, base_lens)
+    reads = gpu.Reads.from_strings(seqs)
+    idx = rng.integers(0, len(seqs), size=n)
+    sub = reads.select(idx)
+    _, off = sub.download()
+    assert np.array_equal(off, np.concatenate([[0], np.cumsum(base_lens[idx])]).astype(np.uint64))
+    orfs, orf_off = gpu.find_orfs(sub, min_gene_len=33, allow_truncated=True)
+    counts = np.bincount(orfs["read"].astype(np.int64), minlength=n) if len(orfs) else np.zeros(n, np.int64)
+    assert np.array_equal(orf_off, np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)) and int(orf_off[-1]) == len(orfs)
+    assert np.all(np.diff(orfs["read"].astype(np.int64)) >= 0)
