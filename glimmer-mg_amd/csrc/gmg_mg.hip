@@ -3941,7 +3941,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
             } else st = st0;
             const uint32_t lo = bounds[cls], hi = bounds[cls + 1] < ew_cap ? bounds[cls + 1] : ew_cap;
             if (hi <= lo || reads->max_len <= lo || reads->min_len > hi) continue;
-            const uint32_t bytes = wcount ? ewc_layout(bounds[cls + 1], write).bytes : ew_layout(hi, ew_qcap, write).bytes;
+            const uint32_t bytes = wcount ? ewc_layout(bounds[cls + 1], write, a.err_mode == 1).bytes : ew_layout(hi, ew_qcap, write).bytes;
             uint32_t per_cu = (uint32_t)((160u * 1024u) / (bytes + 1024u));
             if (per_cu > 16) per_cu = 16;
             if (per_cu < 1) per_cu = 1;
@@ -3949,7 +3949,8 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
             if (grid > n_blocks) grid = n_blocks;
             if (grid == 0) continue;
 #define MG_EW_LAUNCH(W_, G_, K_) hipLaunchKernelGGL((k_mg_err_wave<W_, G_, K_>), dim3((unsigned)grid), dim3(EW_BLOCK), bytes, st, a, err_acc_only, lo, hi, ew_qcap, d_item_flag, st_ptr)
-#define MG_EWC_LAUNCH(W_, G_, K_) hipLaunchKernelGGL((k_mg_err_wcount<W_, G_, K_>), dim3((unsigned)grid), dim3(EW_BLOCK), 0, st, a, err_acc_only, lo, hi, d_item_flag, st_ptr)
+#define MG_EWC_LAUNCH_I(W_, G_, K_, I_) hipLaunchKernelGGL((k_mg_err_wcount<W_, G_, K_, I_>), dim3((unsigned)grid), dim3(EW_BLOCK), 0, st, a, err_acc_only, lo, hi, d_item_flag, st_ptr)
+#define MG_EWC_LAUNCH(W_, G_, K_) do { if (a.err_mode == 1) MG_EWC_LAUNCH_I(W_, G_, K_, true); else MG_EWC_LAUNCH_I(W_, G_, K_, false); } while (0)
 #define MG_EW_LAUNCH_K(W_, G_) do { if (cls == 0) MG_EW_LAUNCH(W_, G_, 8); else MG_EW_LAUNCH(W_, G_, 15); } while (0)
 #define MG_EWC_LAUNCH_K(W_, G_) do { if (cls == 0) MG_EWC_LAUNCH(W_, G_, 6); else if (cls == 1) MG_EWC_LAUNCH(W_, G_, 7); else if (cls == 2) MG_EWC_LAUNCH(W_, G_, 8); else MG_EWC_LAUNCH(W_, G_, 15); } while (0)
             if (wcount && write) { if (a.gene32) MG_EWC_LAUNCH_K(true, true); else MG_EWC_LAUNCH_K(true, false); }
@@ -3959,6 +3960,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
 #undef MG_EWC_LAUNCH_K
 #undef MG_EW_LAUNCH_K
 #undef MG_EWC_LAUNCH
+#undef MG_EWC_LAUNCH_I
 #undef MG_EW_LAUNCH
             e = hipGetLastError();
             if (e != hipSuccess) return e;

@@ -687,36 +687,39 @@ struct EwcLayout {
     uint32_t l1_key, l2_key, l1_e, l2_e, a_best, a_exa, a_exb;   // WRITE only
     uint32_t srow, nw;           // doubles per class row; words per mask row (one guard word in front, zero words behind)
 };
-__host__ __device__ constexpr EwcLayout ewc_layout(uint32_t cap, bool write = false)
+// indels = false (the substitution branch alone: one child per ORF, no (call, low-quality base) pairs, no level 2): the level-1
+// list holds EW_MAXO entries and the pair tables, the level-2 list, the low-quality list and the ORF-at-step table are not laid out
+__host__ __device__ constexpr EwcLayout ewc_layout(uint32_t cap, bool write = false, bool indels = true)
 {
     EwcLayout L = {};
     L.srow = cap + 4;
     L.nw = cap / 64 + 3;
+    const uint32_t cap1 = indels ? EWC_CAP1 : EW_MAXO, cap2 = indels ? EWC_CAP2 : 0u, pcap = indels ? EWC_PCAP : 0u, pmax = indels ? EWC_PMAX : 0u;
     uint32_t o = 0;
     L.S = o; o += 3 * L.srow * 8;
     L.msk = o; o += 3 * L.nw * 8;
-    L.l1_ss = o; o += EWC_CAP1 * 8;
-    L.l2_ss = o; o += EWC_CAP2 * 8;
+    L.l1_ss = o; o += cap1 * 8;
+    L.l2_ss = o; o += cap2 * 8;
     L.acc = o; o += 8;
-    L.l1_key = o; o += write ? EWC_CAP1 * 8 : 0;
-    L.l2_key = o; o += write ? EWC_CAP2 * 8 : 0;
+    L.l1_key = o; o += write ? cap1 * 8 : 0;
+    L.l2_key = o; o += write ? cap2 * 8 : 0;
     L.a_best = o; o += write ? EW_MAXO * 8 : 0;
     L.a_exa = o; o += write ? EW_MAXO * 8 : 0;
     L.a_exb = o; o += write ? EW_MAXO * 8 : 0;
-    L.l1_e = o; o += write ? EWC_CAP1 * 4 : 0;
-    L.l2_e = o; o += write ? EWC_CAP2 * 4 : 0;
-    L.l1_w = o; o += EWC_CAP1 * 4;
-    L.l2_w = o; o += EWC_CAP2 * 4;
+    L.l1_e = o; o += write ? cap1 * 4 : 0;
+    L.l2_e = o; o += write ? cap2 * 4 : 0;
+    L.l1_w = o; o += cap1 * 4;
+    L.l2_w = o; o += cap2 * 4;
     L.a_cnt = o; o += EW_MAXO * 4;
     L.a_m0 = o; o += EW_MAXO * 4;
     L.gi = o; o += EW_MAXO * 4;
-    L.l1_x = o; o += EWC_CAP1 * 2;
+    L.l1_x = o; o += indels ? cap1 * 2 : 0u;
     L.xs = o; o += EW_MAXO * 2;
-    L.pcall = o; o += EWC_PCAP * 2;
-    L.plist = o; o += EWC_PMAX * 2;
-    L.cum = o; o += ((L.nw + 1) * 2 + 3) & ~3u;
-    L.pq = o; o += EWC_PMAX;
-    L.orf_at = o; o += (cap + 8 + 7) & ~7u;
+    L.pcall = o; o += pcap * 2;
+    L.plist = o; o += pmax * 2;
+    L.cum = o; o += indels ? ((L.nw + 1) * 2 + 3) & ~3u : 0u;
+    L.pq = o; o += pmax;
+    L.orf_at = o; o += indels ? (cap + 8 + 7) & ~7u : 0u;
     L.bytes = (o + 15) & ~15u;
     return L;
 }
@@ -889,18 +892,19 @@ extern "C" int gmg_debug_ew_stamps(unsigned long long *out, int reset)
 #define EW_STAMP(i) do { } while (0)
 #endif
 
-template <bool WRITE, bool G32, int KMAX>
+template <bool WRITE, bool G32, int KMAX, bool INDELS>
 __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int accepted_only, const uint32_t cap_lo, const uint32_t cap,
                                                             uint8_t *item_flag, uint32_t *stats)
 {
-    // (the LDS share is sized by the length class, 64 KMAX bases: every offset a constant; reads of cap_lo < n <= cap are taken)
-    constexpr EwcLayout L = ewc_layout(64u * (uint32_t)KMAX, WRITE);
+    // (the LDS share is sized by the length class, 64 KMAX bases: every offset a constant; reads of cap_lo < n <= cap are taken;
+    // INDELS = (a.err_mode == 1): without it the arrays of the branching levels are not laid out and their code is not compiled)
+    constexpr EwcLayout L = ewc_layout(64u * (uint32_t)KMAX, WRITE, INDELS);
     __shared__ __attribute__((aligned(16))) unsigned char ew_lds[L.bytes];
-    __shared__ double s_pen[64];
+    __shared__ double s_pen[INDELS ? 64 : 1];
     __shared__ float s_nt[G32 ? MG_NULL_FLOATS + 4 : 4];
     __shared__ int8_t s_which[64];
     const uint32_t lane = threadIdx.x;
-    s_pen[lane] = a.err_mode == 1 ? a.pen[lane] : 0.0;
+    if (INDELS) s_pen[lane] = a.pen[lane];
     s_which[lane] = a.which[lane];
     if (G32 && !a.read_null)
         for (uint32_t k = lane; k < MG_NULL_FLOATS; k += 64) s_nt[k] = a.null_tab[k];
@@ -924,7 +928,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
     const bool pen_lds = a.indel_q_thr < 64;
     const int mgl = a.min_gene_len;
     const int lowest_j = mgl - 3 < 3 ? mgl - 3 : 3;
-    const bool indels = a.err_mode == 1;
+    constexpr bool indels = INDELS;
     const uint32_t nw = L.nw, srow = L.srow;
     const uint64_t n_items = 2 * a.n_reads;
     const bool trunc_ok = a.allow_truncated != 0;
@@ -1024,7 +1028,8 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 if (lane < nw) cum[lane] = (uint16_t)(iw - pw);
             }
         }
-        for (uint32_t t = lane; 4u * t < n + 8u; t += 64) ((uint32_t *)orf_at)[t] = 0xffffffffu;
+        if (indels)
+            for (uint32_t t = lane; 4u * t < n + 8u; t += 64) ((uint32_t *)orf_at)[t] = 0xffffffffu;
         if (lane == 0) *acc_mask = 0;
         wcs_sync();
         EW_STAMP(2);                                    // sums, masks, lists (waits for the pair's loads)

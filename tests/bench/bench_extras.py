@@ -274,7 +274,7 @@ if want("score_orfs"):
             ok = ok and [(int(s["j"]), int(s["pos"]), float(s["score"])) for s in st] == [(x.j, x.pos, x.score) for x in wst] and float(res["best_score"][i]) == w.best_score
             n_ck += 1
     lib.gmg_orf_batch_free(batch)
-    leg("score_orfs", ms, all_ms, hbm(ms, 64.5 * total + 40 * len(o) + 24 * n_st, "64.5 B per read base (gene rows written and read, running sums written, packed reads) + 40 B/ORF + 24 B/start"),
+    leg("score_orfs", ms, all_ms, hbm(ms, 52.6 * total + 40 * len(o) + 24 * n_st, "52.6 B per read base (gene rows written and read 48, packed reads 0.5, running sums in compact form 3.4 + 0.75; rounds 3 - 4 wrote all of them: 64.5) + 40 B/ORF + 24 B/start"),
         "%d ORFs of %d reads vs the oracle: %s" % (n_ck, len(sample), "bit-exact" if ok else "MISMATCH"),
         orfs=len(o), starts=int(n_st), ms_per_million_orfs=round(ms / (len(o) / 1e6), 3))
 
