@@ -677,9 +677,9 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
 // The tree is processed breadth first, every trip with full lanes: ~10 trips per (read, strand) instead of the ~15 dependent
 // event trips of the stack walker at 28 % of the lanes (mg_timing prints both kernels' counts).  -s: level 0 + one child per ORF.
 // ---------------------------------------------------------------------------------------------------
-#define EWC_CAP1 256             // level-1 calls of one (read, strand)
-#define EWC_CAP2 192             // level-2 calls waiting (drained whenever fewer than 128 slots are free)
-#define EWC_PCAP 512             // (level-1 call, low-quality base) pairs of one batch of 64 calls
+#define EWC_CAP1 128             // level-1 calls waiting (worked off whenever the next 64 pairs' children would not fit: two each at most)
+#define EWC_CAP2 128             // level-2 calls waiting (the same)
+#define EWC_PCAP 256             // (level-1 call, low-quality base) pairs of one batch of 64 calls, taken that many at a time
 #define EWC_PMAX 160             // low-quality bases of one read
 
 struct EwcLayout {
@@ -713,12 +713,12 @@ __host__ __device__ constexpr EwcLayout ewc_layout(uint32_t cap, bool write = fa
     L.a_cnt = o; o += EW_MAXO * 4;
     L.a_m0 = o; o += EW_MAXO * 4;
     L.gi = o; o += EW_MAXO * 4;
-    L.l1_x = o; o += indels ? cap1 * 2 : 0u;
     L.xs = o; o += EW_MAXO * 2;
     L.pcall = o; o += pcap * 2;
     L.plist = o; o += pmax * 2;
     L.cum = o; o += indels ? ((L.nw + 1) * 2 + 3) & ~3u : 0u;
     L.pq = o; o += pmax;
+    L.l1_x = o; o += indels ? cap1 : 0u;            // (a rank in the list of low-quality bases: < EWC_PMAX)
     L.orf_at = o; o += indels ? (cap + 8 + 7) & ~7u : 0u;
     L.bytes = (o + 15) & ~15u;
     return L;
@@ -900,11 +900,11 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
     // INDELS = (a.err_mode == 1): without it the arrays of the branching levels are not laid out and their code is not compiled)
     constexpr EwcLayout L = ewc_layout(64u * (uint32_t)KMAX, WRITE, INDELS);
     __shared__ __attribute__((aligned(16))) unsigned char ew_lds[L.bytes];
-    __shared__ double s_pen[INDELS ? 64 : 1];
+    __shared__ double s_pen[INDELS ? 32 : 1];          // (penalties of the qualities a low-quality base can have)
     __shared__ float s_nt[G32 ? MG_NULL_FLOATS + 4 : 4];
     __shared__ int8_t s_which[64];
     const uint32_t lane = threadIdx.x;
-    if (INDELS) s_pen[lane] = a.pen[lane];
+    if (INDELS && lane < 32) s_pen[lane] = a.pen[lane];
     s_which[lane] = a.which[lane];
     if (G32 && !a.read_null)
         for (uint32_t k = lane; k < MG_NULL_FLOATS; k += 64) s_nt[k] = a.null_tab[k];
@@ -913,7 +913,8 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
     uint64_t *Mstart = msk + 1, *Mstop = msk + L.nw + 1, *Mlow = msk + 2 * L.nw + 1;       // (row[-1]: the guard word)
     double *l1_ss = (double *)(ew_lds + L.l1_ss), *l2_ss = (double *)(ew_lds + L.l2_ss);
     uint32_t *l1_w = (uint32_t *)(ew_lds + L.l1_w), *l2_w = (uint32_t *)(ew_lds + L.l2_w);
-    uint16_t *l1_x = (uint16_t *)(ew_lds + L.l1_x), *pcall = (uint16_t *)(ew_lds + L.pcall), *plist = (uint16_t *)(ew_lds + L.plist),
+    uint8_t *l1_x = ew_lds + L.l1_x;
+    uint16_t *pcall = (uint16_t *)(ew_lds + L.pcall), *plist = (uint16_t *)(ew_lds + L.plist),
              *cum = (uint16_t *)(ew_lds + L.cum), *s_xs = (uint16_t *)(ew_lds + L.xs);
     uint8_t *pq = ew_lds + L.pq, *orf_at = ew_lds + L.orf_at;
     uint32_t *a_cnt = (uint32_t *)(ew_lds + L.a_cnt), *a_m0 = (uint32_t *)(ew_lds + L.a_m0), *s_gi = (uint32_t *)(ew_lds + L.gi);
@@ -925,10 +926,11 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
     unsigned long long *a_best = (unsigned long long *)(ew_lds + L.a_best), *a_exa = (unsigned long long *)(ew_lds + L.a_exa),
                        *a_exb = (unsigned long long *)(ew_lds + L.a_exb);
     __syncthreads();
-    const bool pen_lds = a.indel_q_thr < 64;
+    const bool pen_lds = a.indel_q_thr < 32;
     const int mgl = a.min_gene_len;
     const int lowest_j = mgl - 3 < 3 ? mgl - 3 : 3;
     constexpr bool indels = INDELS;
+    constexpr uint32_t CAP1 = INDELS ? EWC_CAP1 : EW_MAXO, CAP2 = EWC_CAP2;
     const uint32_t nw = L.nw, srow = L.srow;
     const uint64_t n_items = 2 * a.n_reads;
     const bool trunc_ok = a.allow_truncated != 0;
@@ -1121,92 +1123,22 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
             const uint64_t cm = __ballot(child);
             if (child) {
                 const uint32_t e = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-                if (e < EWC_CAP1) {
+                if (e < CAP1) {
                     l1_ss[e] = es_sub; l1_w[e] = child_w;
                     if (WRITE) { l1_key[e] = 0ull; l1_e[e] = child_e; }      // (key field 0: before every position of the call)
                 }
             }
             n1 += (uint32_t)__popcll(cm);
         }
-        if (n1 > EWC_CAP1) overflow = true;
+        if (n1 > CAP1) overflow = true;
         wcs_sync();
 
         EW_STAMP(3);                                    // level 0
-        // ---- level 0 -> 1: every (low-quality base, phase) pair
-        if (indels && a.indel_max >= 1 && !overflow) {
-            for (uint32_t i0 = 0; i0 < 3u * npos; i0 += 64) {
-                const uint32_t id = i0 + lane;
-                bool pi = false, pd = false;
-                double es_i = 0.0, es_d = 0.0;
-                uint32_t t = 0, xs = 0, lidx = 0, jj = 0;
-                if (id < 3u * npos) {
-                    const uint32_t k = id / 3u, phi = id - 3u * k, p = plist[k];
-                    const uint32_t pj = (p + 3u - phi) % 3u;
-                    if (pj <= p && p - pj + 2u < n) {
-                        t = p - pj;
-                        if (!((Mstop[t >> 6] >> (t & 63u)) & 1ull)) {
-                            // the nearest stop codon of the phase in front of t: the region's call begins behind it
-                            int u = (int)t - 3;
-                            xs = phi;
-                            while (u >= 0) {
-                                const uint64_t m = ewc_window(Mstop, u - 63) & EW_THIN;
-                                if (m) { xs = (uint32_t)(u - __builtin_clzll(m)) + 3u; break; }
-                                u -= 66;
-                            }
-                            lidx = orf_at[xs];
-                            const uint32_t j0 = t - xs, j = j0 + pj;
-                            jj = j;
-                            if (lidx != 255u && (int)j >= lowest_j) {
-                                const uint32_t cls = (off_m3 + (fwd ? n - 1u - xs : xs)) % 3u;
-                                const double *Sc = S + cls * srow;
-                                const double p0 = Sc[xs], before = Sc[p] - p0, at = Sc[p + 1] - p0;
-                                const int q = pq[k];
-                                const double pen = pen_lds ? s_pen[q & 63] : a.pen[q];
-                                es_i = ((0.0 + before) - 0.0) + pen;
-                                es_d = ((0.0 + at) - 0.0) + pen;
-                                const int c_sj = (int)j0 + 2;
-                                pi = c_sj + ((int)n - (int)(t + 4u)) + 12 >= mgl && es_i > a.indel_suffix_thr;
-                                pd = c_sj + ((int)n - (int)(t + 2u)) + 12 >= mgl && es_d > a.indel_suffix_thr;
-                            }
-                        }
-                    }
-                }
-#ifdef EWC_DEBUG
-                if (id < 3u * npos && t < 40) printf("PAIR it %llu id %u p %u t %u xs %u lidx %u pi %d pd %d es %g %g\n", (unsigned long long)it, id, (unsigned)plist[id / 3u], t, xs, lidx, (int)pi, (int)pd, es_i, es_d);
-#endif
-                const uint64_t mi = __ballot(pi), md = __ballot(pd);
-                if (pi) {
-                    const uint32_t e = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
-                    if (e < EWC_CAP1) {
-                        l1_ss[e] = es_i; l1_w[e] = (t + 4u) | (xs + 2u) << 10 | lidx << 21;
-                        if (WRITE) {                    // Error_t of an insertion: k + 2 / k - 2 at the start's pos k of position j (Score_Indels)
-                            const int kj = fwd ? (int)n - (int)xs - 2 - (int)jj : (int)xs + 3 + (int)jj;
-                            l1_key[e] = (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 1u) << 26;
-                            l1_e[e] = (uint32_t)((fwd ? kj + 2 : kj - 2) + 8) << 2 | 0u;
-                        }
-                    }
-                }
-                n1 += (uint32_t)__popcll(mi);
-                if (pd) {
-                    const uint32_t e = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(md >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md, 0u));
-                    if (e < EWC_CAP1) {
-                        l1_ss[e] = es_d; l1_w[e] = (t + 2u) | xs << 10 | lidx << 21;
-                        if (WRITE) {                    // ... of a deletion: k + 3 / k - 1
-                            const int kj = fwd ? (int)n - (int)xs - 2 - (int)jj : (int)xs + 3 + (int)jj;
-                            l1_key[e] = (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 0u) << 26;
-                            l1_e[e] = (uint32_t)((fwd ? kj + 3 : kj - 1) + 8) << 2 | 1u;
-                        }
-                    }
-                }
-                n1 += (uint32_t)__popcll(md);
-                if (n1 > EWC_CAP1) { overflow = true; break; }
-            }
-        }
-        wcs_sync();
-
-        EW_STAMP(4);                                    // level 0 -> 1
-        // ---- level 1 (own starts), level 1 -> 2 (pairs), level 2 (own starts), batch by batch
-        uint32_t n2 = 0;
+        // ---- levels 1 and 2.  The level-1 list holds CAP1 calls and the level-2 list CAP2: whenever the children of the next 64
+        //      pairs would not fit, the calls listed so far are worked off first (level 1: their own starts, their (call, low-quality
+        //      base) pairs, the children of those at level 2) and the same 64 pairs are evaluated again; the order in which calls are
+        //      taken is free (COUNT adds up, WRITE carries order keys).  Short lists are what lets ten waves share a CU's LDS.
+        uint32_t n2 = 0, n1_max = 0;
         auto drain2 = [&]() __attribute__((always_inline)) {
             wcs_sync();
             for (uint32_t b0 = 0; b0 < n2; b0 += 64) {
@@ -1228,101 +1160,176 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
             wcs_sync();
         };
         const bool expand1 = indels && a.indel_max >= 2;
-        for (uint32_t b0 = 0; b0 < n1 && !overflow; b0 += 64) {
-            const uint32_t i = b0 + lane;
-            uint32_t nq = 0;
-            if (i < n1) {
-                const uint32_t w = l1_w[i], x1 = w & 1023u;
-                const int D1 = (int)((w >> 10) & 2047u);
-                uint32_t o_t_last = 0;
-                bool o_has = false;
-                if (WRITE)
-                    ew_own_write(a, S, srow, Mstart, Mstop, n, fwd, off, off_m3, x1, l1_ss[i], D1, mgl, isl, trunc_ok, w >> 21, 1u, l1_key[i], l1_e[i], a_cnt, a_m0,
-                                 a_best, a_exa, a_exb, s_which, o_t_last, o_has);
-                else {
-                    const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, x1, l1_ss[i], D1, mgl, isl, thr, trunc_ok);
-                    if (o.cnt) atomicAdd(&a_cnt[w >> 21], o.cnt);
-                    if (o.acc) atomicOr(acc_mask, 1ull << (w >> 21));
-                    o_t_last = o.t_last; o_has = o.has;
-                }
-                if (expand1 && o_has) {
-                    // the low-quality bases from the call's first step to the last base of its region, by rank
-                    const uint32_t e = o_t_last + 3u;
-                    const uint32_t r0 = cum[x1 >> 6] + (uint32_t)__popcll(Mlow[x1 >> 6] & ((1ull << (x1 & 63u)) - 1ull));
-                    const uint32_t r1 = cum[e >> 6] + (uint32_t)__popcll(Mlow[e >> 6] & ((1ull << (e & 63u)) - 1ull));
-                    nq = r1 - r0;
-                    l1_x[i] = (uint16_t)r0;
-                }
-            }
-            if (!expand1) continue;
-            const uint32_t incl = ewc_scan_u32(nq), T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            for (uint32_t pb = 0; pb < T; pb += EWC_PCAP) {             // (the pair table holds EWC_PCAP pairs at a time)
-            const uint32_t Tn = T - pb < EWC_PCAP ? T - pb : EWC_PCAP;
-            for (uint32_t u = 0; __ballot(u < nq); u++) {
-                const uint32_t gq = incl - nq + u;
-                if (u < nq && gq >= pb && gq < pb + EWC_PCAP) pcall[gq - pb] = (uint16_t)(lane | u << 6);
-            }
+        auto level1 = [&]() __attribute__((always_inline)) {
             wcs_sync();
-            for (uint32_t q0 = 0; q0 < Tn; q0 += 64) {
-                const uint32_t qi = q0 + lane;
-                bool pi = false, pd = false;
-                double es_i = 0.0, es_d = 0.0;
-                uint32_t t = 0, lidx = 0, jj = 0, x1k = 0, e1 = 0;
-                uint64_t key1 = 0;
-                int D1 = 0;
-                if (qi < Tn) {
-                    const uint32_t pc = pcall[qi], ci = b0 + (pc & 63u), u = pc >> 6;
-                    if (WRITE) { key1 = l1_key[ci]; e1 = l1_e[ci]; }
-                    const uint32_t w = l1_w[ci], x1 = w & 1023u;
-                    D1 = (int)((w >> 10) & 2047u); lidx = w >> 21;
-                    const double ss1 = l1_ss[ci];
-                    const uint32_t k = (uint32_t)l1_x[ci] + u, p = plist[k];
-                    const uint32_t pj = (p - x1) % 3u;
+            if (n1 > n1_max) n1_max = n1;
+            for (uint32_t b0 = 0; b0 < n1 && !overflow; b0 += 64) {
+                const uint32_t i = b0 + lane;
+                uint32_t nq = 0;
+                if (i < n1) {
+                    const uint32_t w = l1_w[i], x1 = w & 1023u;
+                    const int D1 = (int)((w >> 10) & 2047u);
+                    uint32_t o_t_last = 0;
+                    bool o_has = false;
+                    if (WRITE)
+                        ew_own_write(a, S, srow, Mstart, Mstop, n, fwd, off, off_m3, x1, l1_ss[i], D1, mgl, isl, trunc_ok, w >> 21, 1u, l1_key[i], l1_e[i], a_cnt, a_m0,
+                                     a_best, a_exa, a_exb, s_which, o_t_last, o_has);
+                    else {
+                        const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, x1, l1_ss[i], D1, mgl, isl, thr, trunc_ok);
+                        if (o.cnt) atomicAdd(&a_cnt[w >> 21], o.cnt);
+                        if (o.acc) atomicOr(acc_mask, 1ull << (w >> 21));
+                        o_t_last = o.t_last; o_has = o.has;
+                    }
+                    if (expand1 && o_has) {
+                        // the low-quality bases from the call's first step to the last base of its region, by rank
+                        const uint32_t e = o_t_last + 3u;
+                        const uint32_t r0 = cum[x1 >> 6] + (uint32_t)__popcll(Mlow[x1 >> 6] & ((1ull << (x1 & 63u)) - 1ull));
+                        const uint32_t r1 = cum[e >> 6] + (uint32_t)__popcll(Mlow[e >> 6] & ((1ull << (e & 63u)) - 1ull));
+                        nq = r1 - r0;
+                        l1_x[i] = (uint8_t)r0;
+                    }
+                }
+                if (!expand1) continue;
+                const uint32_t incl = ewc_scan_u32(nq), T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                for (uint32_t pb = 0; pb < T; pb += EWC_PCAP) {             // (the pair table holds EWC_PCAP pairs at a time)
+                const uint32_t Tn = T - pb < EWC_PCAP ? T - pb : EWC_PCAP;
+                for (uint32_t u = 0; __ballot(u < nq); u++) {
+                    const uint32_t gq = incl - nq + u;
+                    if (u < nq && gq >= pb && gq < pb + EWC_PCAP) pcall[gq - pb] = (uint16_t)(lane | u << 6);
+                }
+                wcs_sync();
+                for (uint32_t q0 = 0; q0 < Tn;) {
+                    const uint32_t qi = q0 + lane;
+                    bool pi = false, pd = false;
+                    double es_i = 0.0, es_d = 0.0;
+                    uint32_t t = 0, lidx = 0, jj = 0, x1k = 0, e1 = 0;
+                    uint64_t key1 = 0;
+                    int D1 = 0;
+                    if (qi < Tn) {
+                        const uint32_t pc = pcall[qi], ci = b0 + (pc & 63u), u = pc >> 6;
+                        if (WRITE) { key1 = l1_key[ci]; e1 = l1_e[ci]; }
+                        const uint32_t w = l1_w[ci], x1 = w & 1023u;
+                        D1 = (int)((w >> 10) & 2047u); lidx = w >> 21;
+                        const double ss1 = l1_ss[ci];
+                        const uint32_t k = (uint32_t)l1_x[ci] + u, p = plist[k];
+                        const uint32_t pj = (p - x1) % 3u;
+                        t = p - pj;
+                        const uint32_t j0 = t - x1, j = j0 + pj;
+                        jj = j; x1k = x1;
+                        if ((int)j >= lowest_j) {
+                            const uint32_t cls = (off_m3 + (fwd ? n - 1u - x1 : x1)) % 3u;
+                            const double *Sc = S + cls * srow;
+                            const double p0 = Sc[x1], before = Sc[p] - p0, at = Sc[p + 1] - p0;
+                            const int q = pq[k];
+                            const double pen = pen_lds ? s_pen[q & 31] : a.pen[q];
+                            es_i = ((ss1 + before) - 0.0) + pen;
+                            es_d = ((ss1 + at) - 0.0) + pen;
+                            const int c_sj = ((int)x1 - D1) + (int)j0 + 2;
+                            pi = c_sj + ((int)n - (int)(t + 4u)) + 12 >= mgl && es_i > a.indel_suffix_thr;
+                            pd = c_sj + ((int)n - (int)(t + 2u)) + 12 >= mgl && es_d > a.indel_suffix_thr;
+                        }
+                    }
+                    const uint64_t mi = __ballot(pi), md = __ballot(pd);
+                    if (n2 + (uint32_t)__popcll(mi) + (uint32_t)__popcll(md) > CAP2) { drain2(); continue; }    // (the list is empty then: these lanes' children fit)
+                    if (pi) {
+                        const uint32_t e = n2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
+                        l2_ss[e] = es_i; l2_w[e] = (t + 4u) | (uint32_t)(D1 + 2) << 10 | lidx << 21;
+                        if (WRITE) {
+                            const int kj = fwd ? (int)n - (int)x1k - 2 - (int)jj : (int)x1k + 3 + (int)jj;
+                            l2_key[e] = key1 | (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 1u) << 13;
+                            l2_e[e] = (e1 & 0x3fffu) | ((uint32_t)((fwd ? kj + 2 : kj - 2) + 8) << 2 | 0u) << 14;
+                        }
+                    }
+                    n2 += (uint32_t)__popcll(mi);
+                    if (pd) {
+                        const uint32_t e = n2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(md >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md, 0u));
+                        l2_ss[e] = es_d; l2_w[e] = (t + 2u) | (uint32_t)D1 << 10 | lidx << 21;
+                        if (WRITE) {
+                            const int kj = fwd ? (int)n - (int)x1k - 2 - (int)jj : (int)x1k + 3 + (int)jj;
+                            l2_key[e] = key1 | (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 0u) << 13;
+                            l2_e[e] = (e1 & 0x3fffu) | ((uint32_t)((fwd ? kj + 3 : kj - 1) + 8) << 2 | 1u) << 14;
+                        }
+                    }
+                    n2 += (uint32_t)__popcll(md);
+                    q0 += 64;
+                }
+                wcs_sync();
+                }
+            }
+            if (n2 && !overflow) drain2();
+            n1 = 0;
+            wcs_sync();
+        };
+        // level 0 -> 1: every (low-quality base, phase) pair
+        const uint32_t n_ids = indels && a.indel_max >= 1 && !overflow ? 3u * npos : 0u;
+        for (uint32_t i0 = 0;;) {
+            const bool more = i0 < n_ids;
+            const uint32_t id = i0 + lane;
+            bool pi = false, pd = false;
+            double es_i = 0.0, es_d = 0.0;
+            uint32_t t = 0, xs = 0, lidx = 0, jj = 0;
+            if (more && id < n_ids) {
+                const uint32_t k = id / 3u, phi = id - 3u * k, p = plist[k];
+                const uint32_t pj = (p + 3u - phi) % 3u;
+                if (pj <= p && p - pj + 2u < n) {
                     t = p - pj;
-                    const uint32_t j0 = t - x1, j = j0 + pj;
-                    jj = j; x1k = x1;
-                    if ((int)j >= lowest_j) {
-                        const uint32_t cls = (off_m3 + (fwd ? n - 1u - x1 : x1)) % 3u;
-                        const double *Sc = S + cls * srow;
-                        const double p0 = Sc[x1], before = Sc[p] - p0, at = Sc[p + 1] - p0;
-                        const int q = pq[k];
-                        const double pen = pen_lds ? s_pen[q & 63] : a.pen[q];
-                        es_i = ((ss1 + before) - 0.0) + pen;
-                        es_d = ((ss1 + at) - 0.0) + pen;
-                        const int c_sj = ((int)x1 - D1) + (int)j0 + 2;
-                        pi = c_sj + ((int)n - (int)(t + 4u)) + 12 >= mgl && es_i > a.indel_suffix_thr;
-                        pd = c_sj + ((int)n - (int)(t + 2u)) + 12 >= mgl && es_d > a.indel_suffix_thr;
+                    if (!((Mstop[t >> 6] >> (t & 63u)) & 1ull)) {
+                        // the nearest stop codon of the phase in front of t: the region's call begins behind it
+                        int u = (int)t - 3;
+                        xs = phi;
+                        while (u >= 0) {
+                            const uint64_t m = ewc_window(Mstop, u - 63) & EW_THIN;
+                            if (m) { xs = (uint32_t)(u - __builtin_clzll(m)) + 3u; break; }
+                            u -= 66;
+                        }
+                        lidx = orf_at[xs];
+                        const uint32_t j0 = t - xs, j = j0 + pj;
+                        jj = j;
+                        if (lidx != 255u && (int)j >= lowest_j) {
+                            const uint32_t cls = (off_m3 + (fwd ? n - 1u - xs : xs)) % 3u;
+                            const double *Sc = S + cls * srow;
+                            const double p0 = Sc[xs], before = Sc[p] - p0, at = Sc[p + 1] - p0;
+                            const int q = pq[k];
+                            const double pen = pen_lds ? s_pen[q & 31] : a.pen[q];
+                            es_i = ((0.0 + before) - 0.0) + pen;
+                            es_d = ((0.0 + at) - 0.0) + pen;
+                            const int c_sj = (int)j0 + 2;
+                            pi = c_sj + ((int)n - (int)(t + 4u)) + 12 >= mgl && es_i > a.indel_suffix_thr;
+                            pd = c_sj + ((int)n - (int)(t + 2u)) + 12 >= mgl && es_d > a.indel_suffix_thr;
+                        }
                     }
                 }
-                const uint64_t mi = __ballot(pi), md = __ballot(pd);
-                if (pi) {
-                    const uint32_t e = n2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
-                    l2_ss[e] = es_i; l2_w[e] = (t + 4u) | (uint32_t)(D1 + 2) << 10 | lidx << 21;
-                    if (WRITE) {
-                        const int kj = fwd ? (int)n - (int)x1k - 2 - (int)jj : (int)x1k + 3 + (int)jj;
-                        l2_key[e] = key1 | (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 1u) << 13;
-                        l2_e[e] = (e1 & 0x3fffu) | ((uint32_t)((fwd ? kj + 2 : kj - 2) + 8) << 2 | 0u) << 14;
-                    }
-                }
-                n2 += (uint32_t)__popcll(mi);
-                if (pd) {
-                    const uint32_t e = n2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(md >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md, 0u));
-                    l2_ss[e] = es_d; l2_w[e] = (t + 2u) | (uint32_t)D1 << 10 | lidx << 21;
-                    if (WRITE) {
-                        const int kj = fwd ? (int)n - (int)x1k - 2 - (int)jj : (int)x1k + 3 + (int)jj;
-                        l2_key[e] = key1 | (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 0u) << 13;
-                        l2_e[e] = (e1 & 0x3fffu) | ((uint32_t)((fwd ? kj + 3 : kj - 1) + 8) << 2 | 1u) << 14;
-                    }
-                }
-                n2 += (uint32_t)__popcll(md);
-                if (n2 > EWC_CAP2 - 128u) drain2();
             }
-            wcs_sync();
+            const uint64_t mi = __ballot(pi), md = __ballot(pd);
+            if (!more || n1 + (uint32_t)__popcll(mi) + (uint32_t)__popcll(md) > CAP1) {
+                level1();                               // (... and the list is empty)
+                if (!more) break;
+                continue;
             }
+            if (pi) {
+                const uint32_t e = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
+                l1_ss[e] = es_i; l1_w[e] = (t + 4u) | (xs + 2u) << 10 | lidx << 21;
+                if (WRITE) {                            // Error_t of an insertion: k + 2 / k - 2 at the start's pos k of position j (Score_Indels)
+                    const int kj = fwd ? (int)n - (int)xs - 2 - (int)jj : (int)xs + 3 + (int)jj;
+                    l1_key[e] = (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 1u) << 26;
+                    l1_e[e] = (uint32_t)((fwd ? kj + 2 : kj - 2) + 8) << 2 | 0u;
+                }
+            }
+            n1 += (uint32_t)__popcll(mi);
+            if (pd) {
+                const uint32_t e = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(md >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md, 0u));
+                l1_ss[e] = es_d; l1_w[e] = (t + 2u) | xs << 10 | lidx << 21;
+                if (WRITE) {                            // ... of a deletion: k + 3 / k - 1
+                    const int kj = fwd ? (int)n - (int)xs - 2 - (int)jj : (int)xs + 3 + (int)jj;
+                    l1_key[e] = (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 0u) << 26;
+                    l1_e[e] = (uint32_t)((fwd ? kj + 3 : kj - 1) + 8) << 2 | 1u;
+                }
+            }
+            n1 += (uint32_t)__popcll(md);
+            i0 += 64;
         }
-        if (n2 && !overflow) drain2();
-        EW_STAMP(5);                                    // levels 1 and 2
-        if (stats && lane == 0) { atomicMax(&stats[0], n1); atomicMax(&stats[1], nloc); atomicMax(&stats[2], npos); atomicAdd(&stats[4], 1u); }
+        EW_STAMP(5);                                    // levels 0 -> 1, 1 and 2
+        if (stats && lane == 0) { atomicMax(&stats[0], n1_max); atomicMax(&stats[1], nloc); atomicMax(&stats[2], npos); atomicAdd(&stats[4], 1u); }
         if (overflow) { if (lane == 0) atomicOr(a.err_flag, 1u); continue; }
         if (WRITE) {
             // first_j and best_score of the ORFs whose starts were written; an ORF that shares its first step with the one that wrote the
