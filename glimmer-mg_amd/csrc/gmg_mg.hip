@@ -3903,7 +3903,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     const uint32_t ew_qcap = gmg_opt(GMG_OPT_MG_ERR_WAVE_Q) > 0 ? (uint32_t)gmg_opt(GMG_OPT_MG_ERR_WAVE_Q) : (uint32_t)EW_QCAP;
     auto launch_err_wave = [&](hipStream_t st, bool write) -> hipError_t {
         // Length classes, a launch each (a wave's LDS share is sized by its class: more waves per CU for the short reads): up to
-        // 384 / 448 / 512 / EW_MAX_CAP bases.  Both passes on k_mg_err_wcount (breadth first, no walks); mg_err_wave = 2: the stack
+        // 384 / 448 / 512 / 704 / EW_MAX_CAP bases.  Both passes on k_mg_err_wcount (breadth first, no walks); mg_err_wave = 2: the stack
         // walker (k_mg_err_wave) for both, 3: the stack walker as the write pass only (cross-checks), up to 512 / ew_cap bases.
         int n_cu = 0;
         hipError_t e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
@@ -3912,18 +3912,18 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         const long long mode = gmg_opt(GMG_OPT_MG_ERR_WAVE);
         const bool wcount = mode == 1 || (mode == 3 && !write);
         uint32_t *st_ptr = tm.on && !write ? d_err_flag + 24 : (uint32_t *)nullptr;
-        static const uint32_t bounds_c[5] = {0, 384, 448, 512, EW_MAX_CAP}, bounds_w[3] = {0, 512, EW_MAX_CAP};
+        static const uint32_t bounds_c[6] = {0, 384, 448, 512, 704, EW_MAX_CAP}, bounds_w[3] = {0, 512, EW_MAX_CAP};
         const uint32_t *bounds = wcount ? bounds_c : bounds_w;
-        const int n_cls = wcount ? 4 : 2;
+        const int n_cls = wcount ? 5 : 2;
         // the classes' launches go to streams of their own (forked from st, joined into it): a class's last work-groups run beside the
         // next class's first instead of holding the device for the launch's tail
-        static thread_local hipStream_t cls_stream[16][3] = {};
-        static thread_local hipEvent_t cls_fork[16] = {}, cls_done[16][3] = {};
+        static thread_local hipStream_t cls_stream[16][4] = {};
+        static thread_local hipEvent_t cls_fork[16] = {}, cls_done[16][4] = {};
         const bool forked = !tm.on && dev_id >= 0 && dev_id < 16 && !gmg_opt(GMG_OPT_MG_ONE_STREAM);
         if (forked) {
             if (!cls_fork[dev_id]) {
                 e = hipEventCreateWithFlags(&cls_fork[dev_id], hipEventDisableTiming);
-                for (int k = 0; k < 3 && e == hipSuccess; k++) {
+                for (int k = 0; k < 4 && e == hipSuccess; k++) {
                     e = hipStreamCreateWithFlags(&cls_stream[dev_id][k], hipStreamNonBlocking);
                     if (e == hipSuccess) e = hipEventCreateWithFlags(&cls_done[dev_id][k], hipEventDisableTiming);
                 }
@@ -3932,7 +3932,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
             e = hipEventRecord(cls_fork[dev_id], st);
             if (e != hipSuccess) return e;
         }
-        bool used[3] = {false, false, false};
+        bool used[4] = {false, false, false, false};
         hipStream_t st0 = st;
         for (int cls = 0; cls < n_cls; cls++) {
             if (forked && cls > 0) {
@@ -3952,7 +3952,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
 #define MG_EWC_LAUNCH_I(W_, G_, K_, I_) hipLaunchKernelGGL((k_mg_err_wcount<W_, G_, K_, I_>), dim3((unsigned)grid), dim3(EW_BLOCK), 0, st, a, err_acc_only, lo, hi, d_item_flag, st_ptr)
 #define MG_EWC_LAUNCH(W_, G_, K_) do { if (a.err_mode == 1) MG_EWC_LAUNCH_I(W_, G_, K_, true); else MG_EWC_LAUNCH_I(W_, G_, K_, false); } while (0)
 #define MG_EW_LAUNCH_K(W_, G_) do { if (cls == 0) MG_EW_LAUNCH(W_, G_, 8); else MG_EW_LAUNCH(W_, G_, 15); } while (0)
-#define MG_EWC_LAUNCH_K(W_, G_) do { if (cls == 0) MG_EWC_LAUNCH(W_, G_, 6); else if (cls == 1) MG_EWC_LAUNCH(W_, G_, 7); else if (cls == 2) MG_EWC_LAUNCH(W_, G_, 8); else MG_EWC_LAUNCH(W_, G_, 15); } while (0)
+#define MG_EWC_LAUNCH_K(W_, G_) do { if (cls == 0) MG_EWC_LAUNCH(W_, G_, 6); else if (cls == 1) MG_EWC_LAUNCH(W_, G_, 7); else if (cls == 2) MG_EWC_LAUNCH(W_, G_, 8); else if (cls == 3) MG_EWC_LAUNCH(W_, G_, 11); else MG_EWC_LAUNCH(W_, G_, 15); } while (0)
             if (wcount && write) { if (a.gene32) MG_EWC_LAUNCH_K(true, true); else MG_EWC_LAUNCH_K(true, false); }
             else if (wcount) { if (a.gene32) MG_EWC_LAUNCH_K(false, true); else MG_EWC_LAUNCH_K(false, false); }
             else if (write) { if (a.gene32) MG_EW_LAUNCH_K(true, true); else MG_EW_LAUNCH_K(true, false); }
@@ -3965,7 +3965,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }
-        for (int k = 0; k < 3; k++)
+        for (int k = 0; k < 4; k++)
             if (used[k]) {
                 e = hipEventRecord(cls_done[dev_id][k], cls_stream[dev_id][k]);
                 if (e == hipSuccess) e = hipStreamWaitEvent(st0, cls_done[dev_id][k], 0);

@@ -701,8 +701,8 @@ __host__ __device__ constexpr EwcLayout ewc_layout(uint32_t cap, bool write = fa
     L.l1_ss = o; o += cap1 * 8;
     L.l2_ss = o; o += cap2 * 8;
     L.acc = o; o += 8;
-    L.l1_key = o; o += write ? cap1 * 8 : 0;
-    L.l2_key = o; o += write ? cap2 * 8 : 0;
+    L.l1_key = o; o += write ? cap1 * 2 : 0;        // (a call's order key in 13-bit fields: one for level 1, two for level 2)
+    L.l2_key = o; o += write ? cap2 * 4 : 0;
     L.a_best = o; o += write ? EW_MAXO * 8 : 0;
     L.a_exa = o; o += write ? EW_MAXO * 8 : 0;
     L.a_exb = o; o += write ? EW_MAXO * 8 : 0;
@@ -921,7 +921,8 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
     unsigned long long *acc_mask = (unsigned long long *)(ew_lds + L.acc);
     // WRITE: the lists carry the order key and the Error_t entries of every call; a_cnt = slots handed out inside the ORF's slice,
     // a_m0 = where the slice begins; the ORFs' best score / entry at the extreme pos for first_j and best_score
-    uint64_t *l1_key = (uint64_t *)(ew_lds + L.l1_key), *l2_key = (uint64_t *)(ew_lds + L.l2_key);
+    uint16_t *l1_key = (uint16_t *)(ew_lds + L.l1_key);
+    uint32_t *l2_key = (uint32_t *)(ew_lds + L.l2_key);
     uint32_t *l1_e = (uint32_t *)(ew_lds + L.l1_e), *l2_e = (uint32_t *)(ew_lds + L.l2_e);
     unsigned long long *a_best = (unsigned long long *)(ew_lds + L.a_best), *a_exa = (unsigned long long *)(ew_lds + L.a_exa),
                        *a_exb = (unsigned long long *)(ew_lds + L.a_exb);
@@ -1125,7 +1126,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 const uint32_t e = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
                 if (e < CAP1) {
                     l1_ss[e] = es_sub; l1_w[e] = child_w;
-                    if (WRITE) { l1_key[e] = 0ull; l1_e[e] = child_e; }      // (key field 0: before every position of the call)
+                    if (WRITE) { l1_key[e] = 0; l1_e[e] = child_e; }      // (key field 0: before every position of the call)
                 }
             }
             n1 += (uint32_t)__popcll(cm);
@@ -1148,7 +1149,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                     if (WRITE) {
                         uint32_t tl; bool hs;
                         ew_own_write(a, S, srow, Mstart, Mstop, n, fwd, off, off_m3, w & 1023u, l2_ss[i], (int)((w >> 10) & 2047u), mgl, isl, trunc_ok, w >> 21, 2u,
-                                     l2_key[i], l2_e[i], a_cnt, a_m0, a_best, a_exa, a_exb, s_which, tl, hs);
+                                     (uint64_t)l2_key[i] << 13, l2_e[i], a_cnt, a_m0, a_best, a_exa, a_exb, s_which, tl, hs);
                     } else {
                         const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, w & 1023u, l2_ss[i], (int)((w >> 10) & 2047u), mgl, isl, thr, trunc_ok);
                         if (o.cnt) atomicAdd(&a_cnt[w >> 21], o.cnt);
@@ -1172,7 +1173,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                     uint32_t o_t_last = 0;
                     bool o_has = false;
                     if (WRITE)
-                        ew_own_write(a, S, srow, Mstart, Mstop, n, fwd, off, off_m3, x1, l1_ss[i], D1, mgl, isl, trunc_ok, w >> 21, 1u, l1_key[i], l1_e[i], a_cnt, a_m0,
+                        ew_own_write(a, S, srow, Mstart, Mstop, n, fwd, off, off_m3, x1, l1_ss[i], D1, mgl, isl, trunc_ok, w >> 21, 1u, (uint64_t)l1_key[i] << 26, l1_e[i], a_cnt, a_m0,
                                      a_best, a_exa, a_exb, s_which, o_t_last, o_has);
                     else {
                         const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, x1, l1_ss[i], D1, mgl, isl, thr, trunc_ok);
@@ -1203,7 +1204,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                     bool pi = false, pd = false;
                     double es_i = 0.0, es_d = 0.0;
                     uint32_t t = 0, lidx = 0, jj = 0, x1k = 0, e1 = 0;
-                    uint64_t key1 = 0;
+                    uint32_t key1 = 0;
                     int D1 = 0;
                     if (qi < Tn) {
                         const uint32_t pc = pcall[qi], ci = b0 + (pc & 63u), u = pc >> 6;
@@ -1236,7 +1237,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                         l2_ss[e] = es_i; l2_w[e] = (t + 4u) | (uint32_t)(D1 + 2) << 10 | lidx << 21;
                         if (WRITE) {
                             const int kj = fwd ? (int)n - (int)x1k - 2 - (int)jj : (int)x1k + 3 + (int)jj;
-                            l2_key[e] = key1 | (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 1u) << 13;
+                            l2_key[e] = key1 << 13 | ((uint32_t)(2047 - (int)jj) << 2 | 1u);
                             l2_e[e] = (e1 & 0x3fffu) | ((uint32_t)((fwd ? kj + 2 : kj - 2) + 8) << 2 | 0u) << 14;
                         }
                     }
@@ -1246,7 +1247,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                         l2_ss[e] = es_d; l2_w[e] = (t + 2u) | (uint32_t)D1 << 10 | lidx << 21;
                         if (WRITE) {
                             const int kj = fwd ? (int)n - (int)x1k - 2 - (int)jj : (int)x1k + 3 + (int)jj;
-                            l2_key[e] = key1 | (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 0u) << 13;
+                            l2_key[e] = key1 << 13 | ((uint32_t)(2047 - (int)jj) << 2 | 0u);
                             l2_e[e] = (e1 & 0x3fffu) | ((uint32_t)((fwd ? kj + 3 : kj - 1) + 8) << 2 | 1u) << 14;
                         }
                     }
@@ -1311,7 +1312,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 l1_ss[e] = es_i; l1_w[e] = (t + 4u) | (xs + 2u) << 10 | lidx << 21;
                 if (WRITE) {                            // Error_t of an insertion: k + 2 / k - 2 at the start's pos k of position j (Score_Indels)
                     const int kj = fwd ? (int)n - (int)xs - 2 - (int)jj : (int)xs + 3 + (int)jj;
-                    l1_key[e] = (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 1u) << 26;
+                    l1_key[e] = (uint16_t)((uint32_t)(2047 - (int)jj) << 2 | 1u);
                     l1_e[e] = (uint32_t)((fwd ? kj + 2 : kj - 2) + 8) << 2 | 0u;
                 }
             }
@@ -1321,7 +1322,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 l1_ss[e] = es_d; l1_w[e] = (t + 2u) | xs << 10 | lidx << 21;
                 if (WRITE) {                            // ... of a deletion: k + 3 / k - 1
                     const int kj = fwd ? (int)n - (int)xs - 2 - (int)jj : (int)xs + 3 + (int)jj;
-                    l1_key[e] = (uint64_t)((uint32_t)(2047 - (int)jj) << 2 | 0u) << 26;
+                    l1_key[e] = (uint16_t)((uint32_t)(2047 - (int)jj) << 2 | 0u);
                     l1_e[e] = (uint32_t)((fwd ? kj + 3 : kj - 1) + 8) << 2 | 1u;
                 }
             }
