@@ -79,6 +79,15 @@ __device__ __forceinline__ uint64_t ew_reverse_fields64(uint64_t y, uint32_t nfi
     return ((z & 0x5555555555555555ull) << 1) | ((z >> 1) & 0x5555555555555555ull);
 }
 
+// the value of the lane in front (lane 0: 0.0) -- DPP wave_shr:1
+__device__ __forceinline__ double ew_wave_shr1(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x138, 0xf, 0xf, false),
+                   hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
+}
+
 // What a lane holds of its K consecutive walk steps between the loads and the sums
 template <bool G32, int KMAX>
 struct EwRegs {
@@ -190,40 +199,54 @@ __device__ __forceinline__ void ew_build(const MgArgs &a, const uint64_t r, cons
     }
 #pragma unroll
     for (int e = 0; e < KMAX; e++) {
-        const uint32_t t = tb + (uint32_t)e;
-        const bool in = (uint32_t)e < K && t < n;
-        double v[3];
-        if (G32) {
-            // the (3,2,3) null model's value at walk step t (mg_null_value in walk codes: the window is steps t - 2, t - 1, t)
-            const uint32_t full = (uint32_t)(W >> (2 * e)) & 63u, b0 = full >> 4, b1 = (full >> 2) & 3u;
-            const uint32_t i0 = t >= 2u ? full : t == 1u ? 192u + 4u + (b1 | b0 << 2) : 192u + b0;
-            const uint32_t stride = t >= 2u ? 64u : 20u;
+        if ((uint32_t)e < K) {                          // (uniform: the lanes' steps K .. KMAX - 1 do not exist)
+            const uint32_t t = tb + (uint32_t)e;
+            const bool in = t < n;
+            // (Steps beyond the read -- in the lane that holds the read's last step and in the lanes behind it -- are not masked here:
+            // what they add to the sums reaches only entries behind S[.][n], which nobody stores or reads; their mask bits go below.)
+            double v[3];
+            if (G32) {
+                // the (3,2,3) null model's value at walk step t (mg_null_value in walk codes: the window is steps t - 2, t - 1, t)
+                const uint32_t full = (uint32_t)(W >> (2 * e)) & 63u;
+                uint32_t i0 = full, stride = 64u;
+                if (e < 2 && t < 2u) {                      // (the read's first two steps: lane 0 alone)
+                    const uint32_t b0 = full >> 4, b1 = (full >> 2) & 3u;
+                    i0 = t == 1u ? 192u + 4u + (b1 | b0 << 2) : 192u + b0;
+                    stride = 20u;
+                }
 #pragma unroll
-            for (int f = 0; f < 3; f++) v[f] = in ? (double)R.gv[e][f] - (double)nt[i0 + (uint32_t)f * stride] : 0.0;
-        } else {
+                for (int f = 0; f < 3; f++) v[f] = (double)R.gv[e][f] - (double)nt[i0 + (uint32_t)f * stride];
+            } else {
 #pragma unroll
-            for (int f = 0; f < 3; f++) v[f] = in ? R.fv[e][f] : 0.0;
+                for (int f = 0; f < 3; f++) v[f] = R.fv[e][f];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) { acc3[c] += v[(c + e) % 3]; P[e][c] = acc3[c]; }
+            const uint32_t idx = (uint32_t)(W >> (2 * e + 4)) & 63u;          // code (t) | code (t + 1) << 2 | code (t + 2) << 4
+            f_start |= ((uint32_t)(a.fwd_start >> idx) & 1u) << e;
+            f_stop |= ((uint32_t)(a.fwd_stop >> idx) & 1u) << e;
+            uint32_t q = R.qv[e];
+            if (q454) {
+                const uint32_t kq = fwd ? 6u + K - 1u - (uint32_t)e : 6u + (uint32_t)e;       // the base's index in winq
+                const uint32_t si = fwd ? n - 1u - t : t;                           // ... and its position in the read
+                // equal pairs at k, k - 1, ..: the even bits from bit 2 k downwards, brought to the top of the word
+                const uint64_t z = (eq << (62u - 2u * kq)) | 0xAAAAAAAAAAAAAAAAull;
+                uint32_t run = 1u + (((uint32_t)__builtin_clzll(~z | 1ull) - 1u) >> 1);
+                if (run > si + 1u) run = si + 1u;                                   // (not beyond the read's first base)
+                const bool inside = si + 1u < n && ((eq >> (2u * kq + 2u)) & 1ull);   // the next base continues the run
+                q = inside ? 31u : run < 6u ? 31u - 5u * run : 6u;
+            }
+            if (indels && q <= (uint32_t)a.indel_q_thr) f_low |= 1u << e;
+            if (s_q && indels && in) s_q[t] = (uint8_t)q;
+            if (q454) Rq[e] = q;
         }
-#pragma unroll
-        for (int c = 0; c < 3; c++) { acc3[c] += v[(c + e) % 3]; P[e][c] = acc3[c]; }
-        const uint32_t idx = (uint32_t)(W >> (2 * e + 4)) & 63u;          // code (t) | code (t + 1) << 2 | code (t + 2) << 4
-        const bool codon = in && t + 2 < n;
-        if (codon && ((a.fwd_start >> idx) & 1ull)) f_start |= 1u << e;
-        if (codon && ((a.fwd_stop >> idx) & 1ull)) f_stop |= 1u << e;
-        uint32_t q = R.qv[e];
-        if (q454) {
-            const uint32_t kq = fwd ? 6u + K - 1u - (uint32_t)e : 6u + (uint32_t)e;       // the base's index in winq
-            const uint32_t si = fwd ? n - 1u - t : t;                           // ... and its position in the read
-            // equal pairs at k, k - 1, ..: the even bits from bit 2 k downwards, brought to the top of the word
-            const uint64_t z = (eq << (62u - 2u * kq)) | 0xAAAAAAAAAAAAAAAAull;
-            uint32_t run = 1u + (((uint32_t)__builtin_clzll(~z | 1ull) - 1u) >> 1);
-            if (run > si + 1u) run = si + 1u;                                   // (not beyond the read's first base)
-            const bool inside = si + 1u < n && ((eq >> (2u * kq + 2u)) & 1ull);   // the next base continues the run
-            q = inside ? 31u : run < 6u ? 31u - 5u * run : 6u;
-        }
-        if (in && indels && q <= (uint32_t)a.indel_q_thr) f_low |= 1u << e;
-        if (s_q && indels && in) s_q[t] = (uint8_t)q;
-        if (q454) Rq[e] = q;
+    }
+    {
+        // the lane's steps inside the read, and those of them where a whole codon begins
+        const uint32_t left = tb < n ? n - tb : 0u, n_in = left < K ? left : K, n_cod = left < 2u ? 0u : left - 2u < K ? left - 2u : K;
+        f_start &= (1u << n_cod) - 1u;
+        f_stop &= (1u << n_cod) - 1u;
+        f_low &= (1u << n_in) - 1u;
     }
     f_low_out = f_low;
     if (q_out) {
@@ -238,7 +261,7 @@ __device__ __forceinline__ void ew_build(const MgArgs &a, const uint64_t r, cons
         tot[c] = cp == 0u ? acc3[0] : cp == 1u ? acc3[1] : acc3[2];
     }
 #pragma unroll
-    for (int c = 0; c < 3; c++) basec[c] = mg_wave_scan(tot[c]) - tot[c];      // what the lanes in front add up to
+    for (int c = 0; c < 3; c++) basec[c] = ew_wave_shr1(mg_wave_scan(tot[c]));  // what the lanes in front add up to (not "- tot": see above)
     wcs_sync();                                     // (the zeroed masks before the ORs)
 #pragma unroll
     for (int cp = 0; cp < 3; cp++) {
