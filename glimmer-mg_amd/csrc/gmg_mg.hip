@@ -3870,8 +3870,8 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
     };
     if (res->n_orfs && err_mode && err_path == 0) {
         MG_TRY(gmg_pool_alloc((void **)&d_read_fit, nr ? nr : 1));
-        MG_TRY(gmg_pool_alloc((void **)&d_err_flag, 128));          // the flag + the two call counters + six tile counters; tile path: + the number of tiles, the item and staging counters
-        MG_TRY(hipMemsetAsync(d_err_flag, 0, 128, s3));             // (not behind the ORF write pass on the first side stream; both join the caller's below)
+        MG_TRY(gmg_pool_alloc((void **)&d_err_flag, 256));          // the flag + the two call counters + six tile counters; tile path: + the number of tiles, the item and staging counters; [32 ..]: the block queues of k_mg_err_wcount (count, write x length class)
+        MG_TRY(hipMemsetAsync(d_err_flag, 0, 256, s3));             // (not behind the ORF write pass on the first side stream; both join the caller's below)
         a.read_fit = d_read_fit;
         a.err_flag = d_err_flag;
         a.n_calls = (unsigned long long *)(d_err_flag + 2);
@@ -3908,9 +3908,9 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
         int n_cu = 0;
         hipError_t e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
         if (e != hipSuccess) return e;
-        const uint64_t n_blocks = (2 * nr + 63) / 64;
         const long long mode = gmg_opt(GMG_OPT_MG_ERR_WAVE);
         const bool wcount = mode == 1 || (mode == 3 && !write);
+        const uint64_t n_blocks = wcount ? (2 * nr + EWC_ITEMS - 1) / EWC_ITEMS : (2 * nr + 63) / 64;
         uint32_t *st_ptr = tm.on && !write ? d_err_flag + 24 : (uint32_t *)nullptr;
         static const uint32_t bounds_c[6] = {0, 384, 448, 512, 704, EW_MAX_CAP}, bounds_w[3] = {0, 512, EW_MAX_CAP};
         const uint32_t *bounds = wcount ? bounds_c : bounds_w;
@@ -3949,7 +3949,8 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
             if (grid > n_blocks) grid = n_blocks;
             if (grid == 0) continue;
 #define MG_EW_LAUNCH(W_, G_, K_) hipLaunchKernelGGL((k_mg_err_wave<W_, G_, K_>), dim3((unsigned)grid), dim3(EW_BLOCK), bytes, st, a, err_acc_only, lo, hi, ew_qcap, d_item_flag, st_ptr)
-#define MG_EWC_LAUNCH_I(W_, G_, K_, I_) hipLaunchKernelGGL((k_mg_err_wcount<W_, G_, K_, I_>), dim3((unsigned)grid), dim3(EW_BLOCK), 0, st, a, err_acc_only, lo, hi, d_item_flag, st_ptr)
+#define MG_EWC_LAUNCH_I(W_, G_, K_, I_) hipLaunchKernelGGL((k_mg_err_wcount<W_, G_, K_, I_>), dim3((unsigned)grid), dim3(EW_BLOCK), 0, st, a, err_acc_only, lo, hi, d_item_flag, st_ptr, \
+                                                                d_err_flag + 32 + (write ? 8 : 0) + cls)
 #define MG_EWC_LAUNCH(W_, G_, K_) do { if (a.err_mode == 1) MG_EWC_LAUNCH_I(W_, G_, K_, true); else MG_EWC_LAUNCH_I(W_, G_, K_, false); } while (0)
 #define MG_EW_LAUNCH_K(W_, G_) do { if (cls == 0) MG_EW_LAUNCH(W_, G_, 8); else MG_EW_LAUNCH(W_, G_, 15); } while (0)
 #define MG_EWC_LAUNCH_K(W_, G_) do { if (cls == 0) MG_EWC_LAUNCH(W_, G_, 6); else if (cls == 1) MG_EWC_LAUNCH(W_, G_, 7); else if (cls == 2) MG_EWC_LAUNCH(W_, G_, 8); else if (cls == 3) MG_EWC_LAUNCH(W_, G_, 11); else MG_EWC_LAUNCH(W_, G_, 15); } while (0)
@@ -4068,7 +4069,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
             unsigned long long asked = 0;
             memcpy(&asked, st + 22, 8);
             MG_TRY(alloc_staging(asked + 1024));
-            MG_TRY(hipMemsetAsync(d_err_flag, 0, 128, s2));
+            MG_TRY(hipMemsetAsync(d_err_flag, 0, 256, s2));
             MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
             continue;
         }
@@ -4079,7 +4080,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
             if (a.pfx) MG_TRY(build_run_tables(s2));
             MG_TRY(build_walk_rows(s2));
             MG_TRY(alloc_level_scratch());
-            MG_TRY(hipMemsetAsync(d_err_flag, 0, 128, s2));
+            MG_TRY(hipMemsetAsync(d_err_flag, 0, 256, s2));
             MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
             continue;
         }
@@ -4113,7 +4114,7 @@ static int mg_run_once(const gmg_model *gene, const gmg_model *nul, const gmg_re
                     a.gene32 = nullptr;
                 }
             }
-            MG_TRY(hipMemsetAsync(d_err_flag, 0, 128, s2));
+            MG_TRY(hipMemsetAsync(d_err_flag, 0, 256, s2));
             MG_TRY(hipMemsetAsync(d_orf_cnt, 0, (no + 1) * 4, s2));
             continue;
         }

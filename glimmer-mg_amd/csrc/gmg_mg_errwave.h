@@ -704,6 +704,9 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
 #define EWC_CAP2 128             // level-2 calls waiting (the same)
 #define EWC_PCAP 256             // (level-1 call, low-quality base) pairs of one batch of 64 calls, taken that many at a time
 #define EWC_PMAX 160             // low-quality bases of one read
+#ifndef EWC_ITEMS
+#define EWC_ITEMS 64              // (read, strand) pairs per block (measured with the queue below: 32 and 16 cost 1 and 4 ms with -i)
+#endif
 
 struct EwcLayout {
     uint32_t S, msk, l1_ss, l2_ss, l1_w, l2_w, l1_x, pcall, plist, pq, cum, orf_at, a_cnt, a_m0, gi, xs, acc, bytes;
@@ -917,7 +920,7 @@ extern "C" int gmg_debug_ew_stamps(unsigned long long *out, int reset)
 
 template <bool WRITE, bool G32, int KMAX, bool INDELS>
 __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int accepted_only, const uint32_t cap_lo, const uint32_t cap,
-                                                            uint8_t *item_flag, uint32_t *stats)
+                                                            uint8_t *item_flag, uint32_t *stats, uint32_t *queue)
 {
     // (the LDS share is sized by the length class, 64 KMAX bases: every offset a constant; reads of cap_lo < n <= cap are taken;
     // INDELS = (a.err_mode == 1): without it the arrays of the branching levels are not laid out and their code is not compiled)
@@ -963,13 +966,26 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
 #if GMG_EW_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
 #endif
-    for (uint64_t blk = blockIdx.x; blk * 64 < n_items; blk += gridDim.x) {
+    // With -i the blocks of EWC_ITEMS (read, strand) pairs are handed out by a counter (*queue, zero at the launch; the next block's
+    // number is asked for while this one is worked on): the length classes' launches share the device, work-groups that become
+    // resident late -- when another class has finished -- then simply take fewer blocks (with a fixed stride they had a full share
+    // left: the classes' launches ended up to 6 ms apart; -0.5 ms over seven interleaved process pairs, -0.3 .. +1.1 each; the queue's last
+    // eighth in blocks of a quarter did not add to that).  With -s the launches end within a millisecond of each other as
+    // they are, and the queue costs 0.8 ms (the first launch takes the whole device, the classes run one after the other): fixed stride.
+    uint32_t blk_next = blockIdx.x;
+    if (INDELS) { blk_next = 0; if (lane == 0) blk_next = atomicAdd(queue, 1u); }
+    for (;;) {
+    const uint64_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk_next);
+    const uint64_t blk_base = blk * EWC_ITEMS;
+    if (blk_base >= n_items) break;
+    if (INDELS) { if (lane == 0) blk_next = atomicAdd(queue, 1u); }
+    else blk_next = (uint32_t)blk + gridDim.x;
     uint64_t l_off = 0, l_ob = 0;
     uint32_t l_n = 0, l_no = 0;
     bool elig = false;
     {
-        const uint64_t my = blk * 64 + lane;
-        if (my < n_items) {
+        const uint64_t my = blk_base + lane;
+        if (lane < EWC_ITEMS && my < n_items) {
             const uint64_t r_ = my >> 1;
             l_off = a.read_off[r_];
             l_n = (uint32_t)(a.read_off[r_ + 1] - l_off);
@@ -991,7 +1007,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
     auto fetch_next = [&]() __attribute__((always_inline)) {
         src_n = (uint32_t)__builtin_ctzll(todo);
         todo &= todo - 1ull;
-        const uint64_t it_ = blk * 64 + src_n;
+        const uint64_t it_ = blk_base + src_n;
         const uint64_t off_ = ew_readlane64(l_off, src_n), ob_ = ew_readlane64(l_ob, src_n);
         const uint32_t n_ = (uint32_t)__builtin_amdgcn_readlane((int)l_n, (int)src_n);
         const uint64_t oe_ = ob_ + (uint32_t)__builtin_amdgcn_readlane((int)l_no, (int)src_n);
@@ -1020,7 +1036,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         have_n = todo != 0;
         if (have_n) fetch_next();
         EW_STAMP(1);                                    // the next pair's loads issued
-        const uint64_t it = blk * 64 + src;
+        const uint64_t it = blk_base + src;
         const uint64_t r = it >> 1;
         const bool fwd = (it & 1) == 0;
         const uint64_t off = ew_readlane64(l_off, src), ob = ew_readlane64(l_ob, src);
