@@ -276,3 +276,41 @@ def test_long_start_lists_keep_the_reference_order(gpu, oracle, nc):
             assert dev_err_rows(starts[sl], errs[sl]) == err_rows(want), (r, int(o["n_starts"]))
             checked += len(want)
     assert checked == int(ns.sum())
+
+
+def test_level_lists_drained_on_demand(gpu, oracle, nc):
+    """k_mg_err_wcount holds 128 calls per level and works a list off whenever the children of the next 64 pairs would not fit (then it
+    evaluates those 64 pairs again).  Reads of every length class with 100 - 155 low-quality bases each (up to the 160 a wave takes) and
+    a suffix threshold that lets most candidates through: hundreds of level-1 and thousands of level-2 calls per strand, i.e. many drains
+    in both passes.  Every ORF against the oracle on the short reads, and the level kernels on all of them, byte for byte."""
+    rng = np.random.default_rng(41)
+    lengths = [200, 260, 330, 384, 385, 420, 448, 449, 500, 512, 513, 600, 704, 705, 800, 960]
+    seqs = ["".join("acgt"[c] for c in rng.choice(4, size=n, p=[.2, .3, .3, .2])) for n in lengths for _ in range(3)]
+    quals = []
+    for s in seqs:
+        q = np.full(len(s), 35, np.int32)
+        q[rng.choice(len(s), size=int(rng.integers(100, 156)), replace=False)] = rng.integers(0, 19, size=1)[0]
+        quals.append(q)
+    reads = gpu.Reads.from_strings(seqs)
+    ekw = dict(allow_indels=True, indel_suffix_score_threshold=-40.0)
+    qual = np.concatenate(quals).astype(np.uint8)
+    with gpu.option("mg_err_wave", 1), gpu.option("mg_err_tile", 0):
+        wave = gpu.mg_score_reads(nc, gpu.Icm.indep(0.5), reads, quality=qual, **ekw)
+    with gpu.option("mg_err_wave", 0), gpu.option("mg_err_tile", 0):
+        level = gpu.mg_score_reads(nc, gpu.Icm.indep(0.5), reads, quality=qual, **ekw)
+    for x, y in zip(wave, level):
+        assert x.dtype == y.dtype and x.shape == y.shape and x.tobytes() == y.tobytes()
+    orfs, starts, off, errs = wave
+    assert int(orfs["n_starts"].max()) > 2000 and int((errs["n"] == 2).sum()) > 100000
+    prm, ep = oracle.mg_params(), oracle.mg_err_params(**ekw)
+    o_nc, o_indep = oracle.read(os.path.join(DATA, "NC_000915.icm")), oracle.indep(0.5, ("taa", "tag", "tga"))
+    checked = 0
+    for r in (0, 4, 9, 13):                              # 200, 260, 384 and 420 bases
+        want_orfs, _, scored = oracle.mg_read_errors(o_nc, o_indep, seqs[r].encode(), prm, ep, quals[r])
+        mine = orfs[int(off[r]):int(off[r + 1])]
+        assert len(mine) == len(scored)
+        for o, (out, want) in zip(mine, scored):
+            sl = slice(o["start_begin"], o["start_begin"] + o["n_starts"])
+            assert dev_err_rows(starts[sl], errs[sl]) == err_rows(want), (r, int(o["n_starts"]))
+            checked += len(want)
+    assert checked > 5000
