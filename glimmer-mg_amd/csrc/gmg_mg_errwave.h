@@ -170,7 +170,7 @@ template <bool G32, int KMAX, bool NTL = false>
 __device__ __forceinline__ void ew_build(const MgArgs &a, const uint64_t r, const uint64_t off, const uint32_t n, const bool fwd, const bool indels,
                                          const uint32_t lane, const EwRegs<G32, KMAX> &R, double *S, const uint32_t srow, uint64_t *Mstart,
                                          uint64_t *Mstop, uint64_t *Mlow, const uint32_t nw, uint64_t *zero, const uint32_t n_zero, uint8_t *s_q,
-                                         uint32_t &f_low_out, const float *nt_lds = nullptr, uint32_t *q_out = nullptr)
+                                         uint32_t &f_low_out, const float *nt_lds = nullptr, uint32_t *q_out = nullptr, const uint32_t ncw = 0)
 {
     const uint32_t K = R.K, tb = R.tb;
     uint32_t Rq[KMAX];                                  // (the qualities computed here, for the caller's list of low-quality bases)
@@ -275,8 +275,23 @@ __device__ __forceinline__ void ew_build(const MgArgs &a, const uint64_t r, cons
     if (tb < n) {                                   // the lane's K bits of every mask, at bit tb
         const uint32_t wi = tb >> 6, sh = tb & 63u;
         const bool two = sh + K > 64u;
+        if (ncw) {
+            // compact form (k_mg_err_wcount): a row per phase, bit k of row p = the codon that starts at step 3 k + p (Mstart / Mstop
+            // = row 0 of each kind, ncw words per row).  The lane's steps of phase p are every third from e0 on: consecutive codons.
+            const uint32_t r3 = tb % 3u, q3 = tb / 3u;
+#pragma unroll
+            for (uint32_t p = 0; p < 3; p++) {
+                const uint32_t e0 = (p + 3u - r3) % 3u, c0 = q3 + (r3 + e0) / 3u, cw = c0 >> 6, cs = c0 & 63u;
+                const uint32_t bs = (f_start >> e0) & 0x1249u, bp = (f_stop >> e0) & 0x1249u;
+                const uint32_t gs = (bs & 1u) | ((bs >> 2) & 2u) | ((bs >> 4) & 4u) | ((bs >> 6) & 8u) | ((bs >> 8) & 16u),
+                               gp = (bp & 1u) | ((bp >> 2) & 2u) | ((bp >> 4) & 4u) | ((bp >> 6) & 8u) | ((bp >> 8) & 16u);
+                if (gs) { atomicOr((unsigned long long *)&Mstart[p * ncw + cw], (unsigned long long)gs << cs); if (cs > 59u) atomicOr((unsigned long long *)&Mstart[p * ncw + cw + 1], (unsigned long long)gs >> (64u - cs)); }
+                if (gp) { atomicOr((unsigned long long *)&Mstop[p * ncw + cw], (unsigned long long)gp << cs); if (cs > 59u) atomicOr((unsigned long long *)&Mstop[p * ncw + cw + 1], (unsigned long long)gp >> (64u - cs)); }
+            }
+        } else {
         if (f_start) { atomicOr((unsigned long long *)&Mstart[wi], (unsigned long long)f_start << sh); if (two) atomicOr((unsigned long long *)&Mstart[wi + 1], (unsigned long long)f_start >> (64u - sh)); }
         if (f_stop) { atomicOr((unsigned long long *)&Mstop[wi], (unsigned long long)f_stop << sh); if (two) atomicOr((unsigned long long *)&Mstop[wi + 1], (unsigned long long)f_stop >> (64u - sh)); }
+        }
         if (f_low) { atomicOr((unsigned long long *)&Mlow[wi], (unsigned long long)f_low << sh); if (two) atomicOr((unsigned long long *)&Mlow[wi + 1], (unsigned long long)f_low >> (64u - sh)); }
     }
     wcs_sync();
@@ -711,7 +726,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wave(MgArgs a, const int ac
 struct EwcLayout {
     uint32_t S, msk, l1_ss, l2_ss, l1_w, l2_w, l1_x, pcall, plist, pq, cum, orf_at, a_cnt, a_m0, gi, xs, acc, bytes;
     uint32_t l1_key, l2_key, l1_e, l2_e, a_best, a_exa, a_exb;   // WRITE only
-    uint32_t srow, nw;           // doubles per class row; words per mask row (one guard word in front, zero words behind)
+    uint32_t srow, nw, ncw;      // doubles per class row; words per mask row over the steps / over a phase's codons (one guard word in front, zero words behind)
 };
 // indels = false (the substitution branch alone: one child per ORF, no (call, low-quality base) pairs, no level 2): the level-1
 // list holds EW_MAXO entries and the pair tables, the level-2 list, the low-quality list and the ORF-at-step table are not laid out
@@ -720,10 +735,11 @@ __host__ __device__ constexpr EwcLayout ewc_layout(uint32_t cap, bool write = fa
     EwcLayout L = {};
     L.srow = cap + 4;
     L.nw = cap / 64 + 3;
+    L.ncw = (cap / 3 + 63) / 64 + 2;
     const uint32_t cap1 = indels ? EWC_CAP1 : EW_MAXO, cap2 = indels ? EWC_CAP2 : 0u, pcap = indels ? EWC_PCAP : 0u, pmax = indels ? EWC_PMAX : 0u;
     uint32_t o = 0;
     L.S = o; o += 3 * L.srow * 8;
-    L.msk = o; o += 3 * L.nw * 8;
+    L.msk = o; o += (L.nw + 6 * L.ncw) * 8;         // low-quality bases by step; start and stop codons by phase and codon
     L.l1_ss = o; o += cap1 * 8;
     L.l2_ss = o; o += cap2 * 8;
     L.acc = o; o += 8;
@@ -773,20 +789,23 @@ struct EwOwn { uint32_t cnt, t_last, m_end; bool acc, has, trunc; };
 // a start codon at j0 = t - x counts when j0 >= lowest_j (j0 >= 3: j0 is a multiple of 3 and lowest_j >= 1) and
 // j0 + 3 + suffix_j >= Min_Gene_Len, i.e. t + 3 - D >= Min_Gene_Len; the truncated start sits on the last codon of a region that
 // runs into the read's end.
-__device__ __forceinline__ EwOwn ew_own(const double *S, const uint32_t srow, const uint64_t *Mstart, const uint64_t *Mstop, const uint32_t n,
-                                        const bool fwd, const uint32_t off_m3, const uint32_t x, const double ss, const int D, const int mgl,
-                                        const int isl, const double thr, const bool allow_trunc)
+// Cstart / Cstop: the masks by phase and codon (ew_build's compact form: row p at + p ncw, bit k = the codon that starts at step
+// 3 k + p): a 64-bit window is 64 codons of the call's phase -- 192 steps
+__device__ __forceinline__ EwOwn ew_own(const double *S, const uint32_t srow, const uint64_t *Cstart, const uint64_t *Cstop, const uint32_t ncw,
+                                        const uint32_t n, const bool fwd, const uint32_t off_m3, const uint32_t x, const double ss, const int D,
+                                        const int mgl, const int isl, const double thr, const bool allow_trunc)
 {
     EwOwn o;
     o.cnt = 0; o.t_last = 0; o.m_end = 0; o.acc = false; o.has = false; o.trunc = false;
     if (x >= n) return o;
     if (n - x < 3) { o.trunc = allow_trunc; return o; }
-    uint32_t t = x, s = 0;
+    const uint32_t ph = x % 3u, k0 = x / 3u, kc = (n - ph) / 3u;      // kc: the codons of this phase that lie inside the read
+    const uint64_t *cstop = Cstop + ph * ncw, *cstart = Cstart + ph * ncw;
+    uint32_t s = 0;
     bool found = false;
-    while (t + 2 < n) {                                 // the first stop codon of the call's phase at or behind x
-        const uint64_t win = ewc_window(Mstop, (int)t) & EW_THIN;
-        if (win) { s = t + (uint32_t)__builtin_ctzll(win); found = true; break; }
-        t += 66u;
+    for (uint32_t k = k0; k < kc; k += 64u) {           // the first stop codon of the call's phase at or behind x
+        const uint64_t win = ewc_window(cstop, (int)k);
+        if (win) { s = 3u * (k + (uint32_t)__builtin_ctzll(win)) + ph; found = true; break; }
     }
     if (found && s == x) return o;
     const uint32_t t_last = found ? s - 3u : x + (n - 3u - x) / 3u * 3u;
@@ -799,13 +818,14 @@ __device__ __forceinline__ EwOwn ew_own(const double *S, const uint32_t srow, co
     const uint32_t cls = (off_m3 + (fwd ? n - 1u - x : x)) % 3u;
     const double *Sc = S + cls * srow;
     const double p0 = Sc[x];
-    for (t = tq; t <= t_last; t += 66u) {
-        uint64_t win = ewc_window(Mstart, (int)t) & EW_THIN;
-        const uint32_t span = t_last - t;
+    const uint32_t kl = t_last / 3u;
+    for (uint32_t k = tq / 3u; k <= kl; k += 64u) {
+        uint64_t win = ewc_window(cstart, (int)k);
+        const uint32_t span = kl - k;
         if (span < 63u) win &= (2ull << span) - 1ull;
         o.cnt += (uint32_t)__popcll(win);
         while (win) {
-            const uint32_t tt = t + (uint32_t)__builtin_ctzll(win);
+            const uint32_t tt = 3u * (k + (uint32_t)__builtin_ctzll(win)) + ph;
             win &= win - 1ull;
             const double raw = ((Sc[tt] - p0) - 0.0) + ss;
             const int j_full = (int)tt + 2 - D;
@@ -827,20 +847,21 @@ __device__ __forceinline__ EwOwn ew_own(const double *S, const uint32_t srow, co
 // order key restores the reference's push order afterwards, as for k_mg_err_level), with the Error_t entries of its path; the
 // call's best score and its entry at the extreme pos are merged into the ORF's aggregates (first_j / best_score of the record).
 // Returns the region's last codon through t_last / has (what the branching needs).
-__device__ __forceinline__ void ew_own_write(const MgArgs &a, const double *S, const uint32_t srow, const uint64_t *Mstart, const uint64_t *Mstop,
-                                             const uint32_t n, const bool fwd, const uint64_t off, const uint32_t off_m3, const uint32_t x, const double ss,
+__device__ __forceinline__ void ew_own_write(const MgArgs &a, const double *S, const uint32_t srow, const uint64_t *Cstart, const uint64_t *Cstop,
+                                             const uint32_t ncw, const uint32_t n, const bool fwd, const uint64_t off, const uint32_t off_m3, const uint32_t x, const double ss,
                                              const int D, const int mgl, const int isl, const bool allow_trunc, const uint32_t lidx, const uint32_t level,
                                              const uint64_t key, const uint32_t ee, uint32_t *fill, const uint32_t *sbeg, unsigned long long *a_best,
                                              unsigned long long *a_exa, unsigned long long *a_exb, const int8_t *s_which, uint32_t &t_last_out, bool &has_out)
 {
     has_out = false; t_last_out = 0;
     if (x >= n || n - x < 3) return;
-    uint32_t t = x, s = 0;
+    const uint32_t ph = x % 3u, k0 = x / 3u, kc = (n - ph) / 3u;
+    const uint64_t *cstop = Cstop + ph * ncw, *cstart = Cstart + ph * ncw;
+    uint32_t s = 0;
     bool found = false;
-    while (t + 2 < n) {
-        const uint64_t win = ewc_window(Mstop, (int)t) & EW_THIN;
-        if (win) { s = t + (uint32_t)__builtin_ctzll(win); found = true; break; }
-        t += 66u;
+    for (uint32_t k = k0; k < kc; k += 64u) {
+        const uint64_t win = ewc_window(cstop, (int)k);
+        if (win) { s = 3u * (k + (uint32_t)__builtin_ctzll(win)) + ph; found = true; break; }
     }
     if (found && s == x) return;
     const uint32_t t_last = found ? s - 3u : x + (n - 3u - x) / 3u * 3u;
@@ -878,12 +899,13 @@ __device__ __forceinline__ void ew_own_write(const MgArgs &a, const double *S, c
         cnt++;
         return slot;
     };
-    for (t = tq; t <= t_last; t += 66u) {
-        uint64_t win = ewc_window(Mstart, (int)t) & EW_THIN;
-        const uint32_t span = t_last - t;
+    const uint32_t kl = t_last / 3u;
+    for (uint32_t k = tq / 3u; k <= kl; k += 64u) {
+        uint64_t win = ewc_window(cstart, (int)k);
+        const uint32_t span = kl - k;
         if (span < 63u) win &= (2ull << span) - 1ull;
         while (win) {
-            const uint32_t tt = t + (uint32_t)__builtin_ctzll(win);
+            const uint32_t tt = 3u * (k + (uint32_t)__builtin_ctzll(win)) + ph;
             win &= win - 1ull;
             // which start codon: the codon's index as the walks form it
             const uint64_t g = fwd ? off + n - 1 - tt : off + tt;
@@ -928,15 +950,16 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
     __shared__ __attribute__((aligned(16))) unsigned char ew_lds[L.bytes];
     __shared__ double s_pen[INDELS ? 32 : 1];          // (penalties of the qualities a low-quality base can have)
     __shared__ float s_nt[G32 ? MG_NULL_FLOATS + 4 : 4];
-    __shared__ int8_t s_which[64];
+    __shared__ int8_t s_which[WRITE ? 64 : 1];              // (which start codon: the write pass's records)
     const uint32_t lane = threadIdx.x;
     if (INDELS && lane < 32) s_pen[lane] = a.pen[lane];
-    s_which[lane] = a.which[lane];
+    if (WRITE) s_which[lane] = a.which[lane];
     if (G32 && !a.read_null)
         for (uint32_t k = lane; k < MG_NULL_FLOATS; k += 64) s_nt[k] = a.null_tab[k];
     double *S = (double *)(ew_lds + L.S);
     uint64_t *msk = (uint64_t *)(ew_lds + L.msk);
-    uint64_t *Mstart = msk + 1, *Mstop = msk + L.nw + 1, *Mlow = msk + 2 * L.nw + 1;       // (row[-1]: the guard word)
+    uint64_t *Mlow = msk + 1, *Cstart = msk + L.nw + 1, *Cstop = Cstart + 3 * L.ncw;          // (row[-1]: the guard word)
+    constexpr uint32_t ncw = L.ncw;
     double *l1_ss = (double *)(ew_lds + L.l1_ss), *l2_ss = (double *)(ew_lds + L.l2_ss);
     uint32_t *l1_w = (uint32_t *)(ew_lds + L.l1_w), *l2_w = (uint32_t *)(ew_lds + L.l2_w);
     uint8_t *l1_x = ew_lds + L.l1_x;
@@ -1053,7 +1076,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
             wcs_sync();
         }
         uint32_t qv_lane[KMAX];
-        ew_build<G32, KMAX, true>(a, r, off, n, fwd, indels, lane, R, S, srow, Mstart, Mstop, Mlow, nw - 1, msk, 3 * nw, (uint8_t *)nullptr, f_low, s_nt, qv_lane);
+        ew_build<G32, KMAX, true>(a, r, off, n, fwd, indels, lane, R, S, srow, Cstart, Cstop, Mlow, nw - 1, msk, nw + 6 * ncw, (uint8_t *)nullptr, f_low, s_nt, qv_lane, ncw);
         uint32_t npos = 0;
         bool overflow = false;
         if (indels) {
@@ -1126,13 +1149,13 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                     if (!(indels && a.indel_max >= 1) || orf_at[xs] == lane) {
                         uint32_t t_last = 0;
                         bool has = false;
-                        ew_own_write(a, S, srow, Mstart, Mstop, n, fwd, off, off_m3, xs, 0.0, (int)xs, mgl, isl, trunc_ok, lane, 0u, 0ull, 0u, a_cnt, a_m0,
+                        ew_own_write(a, S, srow, Cstart, Cstop, ncw, n, fwd, off, off_m3, xs, 0.0, (int)xs, mgl, isl, trunc_ok, lane, 0u, 0ull, 0u, a_cnt, a_m0,
                                      a_best, a_exa, a_exb, s_which, t_last, has);
                         m_end = has ? t_last + 3u - xs : 0u;
                         reach = true;
                     }
                 } else {
-                    const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, xs, 0.0, (int)xs, mgl, isl, thr, trunc_ok);
+                    const EwOwn o = ew_own(S, srow, Cstart, Cstop, ncw, n, fwd, off_m3, xs, 0.0, (int)xs, mgl, isl, thr, trunc_ok);
                     a_cnt[lane] = o.cnt;
                     a_m0[lane] = o.m_end << 1 | (o.trunc ? 1u : 0u);
                     if (o.acc) atomicOr(acc_mask, 1ull << lane);
@@ -1187,10 +1210,10 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                     const uint32_t w = l2_w[i];
                     if (WRITE) {
                         uint32_t tl; bool hs;
-                        ew_own_write(a, S, srow, Mstart, Mstop, n, fwd, off, off_m3, w & 1023u, l2_ss[i], (int)((w >> 10) & 2047u), mgl, isl, trunc_ok, w >> 21, 2u,
+                        ew_own_write(a, S, srow, Cstart, Cstop, ncw, n, fwd, off, off_m3, w & 1023u, l2_ss[i], (int)((w >> 10) & 2047u), mgl, isl, trunc_ok, w >> 21, 2u,
                                      (uint64_t)l2_key[i] << 13, l2_e[i], a_cnt, a_m0, a_best, a_exa, a_exb, s_which, tl, hs);
                     } else {
-                        const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, w & 1023u, l2_ss[i], (int)((w >> 10) & 2047u), mgl, isl, thr, trunc_ok);
+                        const EwOwn o = ew_own(S, srow, Cstart, Cstop, ncw, n, fwd, off_m3, w & 1023u, l2_ss[i], (int)((w >> 10) & 2047u), mgl, isl, thr, trunc_ok);
                         if (o.cnt) atomicAdd(&a_cnt[w >> 21], o.cnt);
                         if (o.acc) atomicOr(acc_mask, 1ull << (w >> 21));
                     }
@@ -1212,10 +1235,10 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                     uint32_t o_t_last = 0;
                     bool o_has = false;
                     if (WRITE)
-                        ew_own_write(a, S, srow, Mstart, Mstop, n, fwd, off, off_m3, x1, l1_ss[i], D1, mgl, isl, trunc_ok, w >> 21, 1u, (uint64_t)l1_key[i] << 26, l1_e[i], a_cnt, a_m0,
+                        ew_own_write(a, S, srow, Cstart, Cstop, ncw, n, fwd, off, off_m3, x1, l1_ss[i], D1, mgl, isl, trunc_ok, w >> 21, 1u, (uint64_t)l1_key[i] << 26, l1_e[i], a_cnt, a_m0,
                                      a_best, a_exa, a_exb, s_which, o_t_last, o_has);
                     else {
-                        const EwOwn o = ew_own(S, srow, Mstart, Mstop, n, fwd, off_m3, x1, l1_ss[i], D1, mgl, isl, thr, trunc_ok);
+                        const EwOwn o = ew_own(S, srow, Cstart, Cstop, ncw, n, fwd, off_m3, x1, l1_ss[i], D1, mgl, isl, thr, trunc_ok);
                         if (o.cnt) atomicAdd(&a_cnt[w >> 21], o.cnt);
                         if (o.acc) atomicOr(acc_mask, 1ull << (w >> 21));
                         o_t_last = o.t_last; o_has = o.has;
@@ -1313,14 +1336,16 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 const uint32_t pj = (p + 3u - phi) % 3u;
                 if (pj <= p && p - pj + 2u < n) {
                     t = p - pj;
-                    if (!((Mstop[t >> 6] >> (t & 63u)) & 1ull)) {
+                    const uint64_t *cstop = Cstop + phi * ncw;
+                    const uint32_t kt = t / 3u;             // (t is a step of phase phi)
+                    if (!((cstop[kt >> 6] >> (kt & 63u)) & 1ull)) {
                         // the nearest stop codon of the phase in front of t: the region's call begins behind it
-                        int u = (int)t - 3;
+                        int u = (int)kt - 1;
                         xs = phi;
                         while (u >= 0) {
-                            const uint64_t m = ewc_window(Mstop, u - 63) & EW_THIN;
-                            if (m) { xs = (uint32_t)(u - __builtin_clzll(m)) + 3u; break; }
-                            u -= 66;
+                            const uint64_t m = ewc_window(cstop, u - 63);
+                            if (m) { xs = 3u * (uint32_t)(u - __builtin_clzll(m)) + phi + 3u; break; }
+                            u -= 64;
                         }
                         lidx = orf_at[xs];
                         const uint32_t j0 = t - xs, j = j0 + pj;
