@@ -1056,6 +1056,10 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         const EwRegs<G32, KMAX> R = Rn;
         const int o_frame = on_frame, o_stop = on_stop;
         const uint32_t o_acc = on_acc, o_sbeg = on_sbeg;
+#if GMG_EW_STAMPS
+        __builtin_amdgcn_s_waitcnt(0);                  // (diagnostic build: what the wave waits here for its own loads, apart from issuing the next ones)
+        EW_STAMP(7);
+#endif
         have_n = todo != 0;
         if (have_n) fetch_next();
         EW_STAMP(1);                                    // the next pair's loads issued
