@@ -728,15 +728,15 @@ struct EwcLayout {
     uint32_t l1_key, l2_key, l1_e, l2_e, a_best, a_exa, a_exb;   // WRITE only
     uint32_t srow, nw, ncw;      // doubles per class row; words per mask row over the steps / over a phase's codons (one guard word in front, zero words behind)
 };
-// indels = false (the substitution branch alone: one child per ORF, no (call, low-quality base) pairs, no level 2): the level-1
-// list holds EW_MAXO entries and the pair tables, the level-2 list, the low-quality list and the ORF-at-step table are not laid out
+// indels = false (the substitution branch alone: one child per ORF, taken by the ORF's lane at once; no (call, low-quality base)
+// pairs, no level 2): the level lists, the pair tables, the low-quality list and the ORF-at-step table are not laid out
 __host__ __device__ constexpr EwcLayout ewc_layout(uint32_t cap, bool write = false, bool indels = true)
 {
     EwcLayout L = {};
     L.srow = cap + 4;
     L.nw = cap / 64 + 3;
     L.ncw = (cap / 3 + 63) / 64 + 2;
-    const uint32_t cap1 = indels ? EWC_CAP1 : EW_MAXO, cap2 = indels ? EWC_CAP2 : 0u, pcap = indels ? EWC_PCAP : 0u, pmax = indels ? EWC_PMAX : 0u;
+    const uint32_t cap1 = indels ? EWC_CAP1 : 0u, cap2 = indels ? EWC_CAP2 : 0u, pcap = indels ? EWC_PCAP : 0u, pmax = indels ? EWC_PMAX : 0u;
     uint32_t o = 0;
     L.S = o; o += 3 * L.srow * 8;
     L.msk = o; o += (L.nw + 6 * L.ncw) * 8;         // low-quality bases by step; start and stop codons by phase and codon
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
     const int mgl = a.min_gene_len;
     const int lowest_j = mgl - 3 < 3 ? mgl - 3 : 3;
     constexpr bool indels = INDELS;
-    constexpr uint32_t CAP1 = INDELS ? EWC_CAP1 : EW_MAXO, CAP2 = EWC_CAP2;
+    constexpr uint32_t CAP1 = INDELS ? EWC_CAP1 : 0u, CAP2 = EWC_CAP2;
     const uint32_t nw = L.nw, srow = L.srow;
     const uint64_t n_items = 2 * a.n_reads;
     const bool trunc_ok = a.allow_truncated != 0;
@@ -1187,6 +1187,23 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                     }
                 }
             }
+            if (!INDELS) {
+                // -s: the ORF's one child (level 1, never branches) by the ORF's own lane, at once: no list (there is as many a child
+                // as there are ORF lanes: nothing to pack) -- the lists' 768 bytes buy a 14th wave per CU in the first length class
+                if (child) {
+                    const uint32_t x1 = child_w & 1023u;
+                    const int D1 = (int)((child_w >> 10) & 2047u);
+                    if (WRITE) {
+                        uint32_t tl; bool hs;
+                        ew_own_write(a, S, srow, Cstart, Cstop, ncw, n, fwd, off, off_m3, x1, es_sub, D1, mgl, isl, trunc_ok, lane, 1u, 0ull, child_e, a_cnt, a_m0,
+                                     a_best, a_exa, a_exb, s_which, tl, hs);      // (key field 0: before every position of the call)
+                    } else {
+                        const EwOwn oc = ew_own(S, srow, Cstart, Cstop, ncw, n, fwd, off_m3, x1, es_sub, D1, mgl, isl, thr, trunc_ok);
+                        if (oc.cnt) a_cnt[lane] += oc.cnt;
+                        if (oc.acc) atomicOr(acc_mask, 1ull << lane);
+                    }
+                }
+            } else {
             const uint64_t cm = __ballot(child);
             if (child) {
                 const uint32_t e = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
@@ -1196,6 +1213,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
                 }
             }
             n1 += (uint32_t)__popcll(cm);
+            }
         }
         if (n1 > CAP1) overflow = true;
         wcs_sync();
