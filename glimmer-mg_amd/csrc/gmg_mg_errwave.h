@@ -117,7 +117,7 @@ __device__ __forceinline__ void ew_load(const MgArgs &a, const uint64_t off, con
     } else R.win = dev_window_bits(a.packed, g_lo);
     const int64_t g0 = fwd ? (int64_t)(off + n - 1) - (int64_t)tb : (int64_t)(off + tb);
     R.g0 = g0;
-    if (G32 && a.ew_slack) {
+    if (G32) {                                          // (a.ew_slack: the fp32 gene rows always come with their spare entries)
         // the call's own gene rows and quality bytes have 64 spare entries on both sides: no lane needs a predicate, every load is
         // the lane's pointer + a constant (what lies outside the read is masked where it is used)
         const float *p0 = a.gene32 + (uint64_t)(fwd ? 0 : 3) * a.fs_stride + g0, *p1 = p0 + a.fs_stride, *p2 = p1 + a.fs_stride;
