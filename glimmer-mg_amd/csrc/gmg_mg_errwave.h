@@ -1226,6 +1226,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
         uint32_t n2 = 0, n1_max = 0;
         auto drain2 = [&]() __attribute__((always_inline)) {
             wcs_sync();
+            EW_STAMP(5);                                // (what came before: level 1 and the pairs)
             for (uint32_t b0 = 0; b0 < n2; b0 += 64) {
                 const uint32_t i = b0 + lane;
                 if (i < n2) {
@@ -1243,6 +1244,7 @@ __global__ __launch_bounds__(EW_BLOCK) void k_mg_err_wcount(MgArgs a, const int 
             }
             n2 = 0;
             wcs_sync();
+            EW_STAMP(4);                                // level 2: the calls' own starts
         };
         const bool expand1 = indels && a.indel_max >= 2;
         auto level1 = [&]() __attribute__((always_inline)) {

@@ -34,7 +34,7 @@ buf = np.zeros(8, np.uint64)
 assert lib.gmg_debug_ew_stamps(buf.ctypes.data, 0) == 0
 st = buf.astype(np.float64)
 names = ["block header (reads, ORF ranges, first loads)", "next pair's loads issued", "sums, masks, lists (waits for the loads)", "level 0 (ORFs)",
-         "(level 0 -> 1: counted below since the lists are drained on demand)", "levels 0 -> 1, 1 and 2", "verdicts", "waiting for the pair's own loads (asked for one pair earlier)"]
+         "level 2 (the calls' own starts)", "level 0 -> 1, level 1 and its pairs", "verdicts", "waiting for the pair's own loads (asked for one pair earlier)"]
 tot = st.sum()
 print("%s: cycles over all waves: %.3e (whole call incl. fetch %.1f ms)" % (mode, tot, dt * 1e3))
 for nm, v in zip(names, st):
